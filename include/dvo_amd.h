@@ -1,0 +1,189 @@
+/*
+ * dvo_amd.h -- C ABI of the MI355X-native dense RGB-D edge-alignment engine.
+ *
+ * Drop-in boundary for ONE hot path of mpkuse/rgbd_odometry: the per-level pose
+ * iteration loop SolveDVO::runIterations and its coarse-to-fine schedule.  The
+ * reference has no plugin / FFI layer; the seam is the private method
+ *   SolveDVO::runIterations          include/SolveDVO.h:228-230, src/SolveDVO.cpp:619-1017
+ * and its helpers
+ *   computeJacobianOfNowFrame        include/SolveDVO.h:312,     src/SolveDVO.cpp:306-414
+ *   getReprojectedEpsilons           include/SolveDVO.h:313,     src/SolveDVO.cpp:425-462
+ * called from SolveDVO::loop (src/SolveDVO.cpp:2097-2104, :2220-2227) and
+ * casualTestFunction (:2426).  INTEGRATION.md shows the patch that makes the
+ * reference's SolveDVO call these entry points.
+ *
+ * Conventions (identical to the reference's Eigen members):
+ *   - images are COLUMN-major rows x cols float32, element (yy,xx) at yy + xx*rows
+ *     (Eigen::MatrixXf; now_distance_transform / now_DT_gradientX/Y, SolveDVO.h:279-282)
+ *   - reference edge points are 3 x N column-major float32 in metres
+ *     (SpaceCordList, SolveDVO.h:137,304), in the column-major scan order of
+ *     enlistRefEdgePts (SolveDVO.cpp:237-239)
+ *   - pose is (R 3x3 column-major double, t 3 double), "now in ref":
+ *     P_now = R^T (P_ref - t)  (SolveDVO.cpp:330); in/out like cR,cT
+ *   - intrinsics are the LEVEL-0 K; level l uses diag(s,s,1)*K, s = 2^-l (:334-337)
+ *
+ * Ownership: the caller owns every host buffer (borrowed for the duration of the
+ * call); the context owns all device memory.  One context per host thread and
+ * HIP stream; calls on one context are not re-entrant.
+ * Errors: int status (0 = DVO_OK); dvo_last_error() gives the message.  The
+ * reference's behaviour on the same conditions is assert->abort (SolveDVO.h:124).
+ * There is NO CPU fallback: without a HIP device every compute entry point
+ * returns DVO_ERR_NO_DEVICE.
+ */
+#ifndef DVO_AMD_H_
+#define DVO_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVO_MAX_LEVELS 8
+#define DVO_NUM_ACC 29      /* 21 H (upper triangle, row-major) + 6 g + sum eps^2 + n_visible */
+
+enum {
+    DVO_OK = 0,
+    DVO_ERR_INVALID = 1,     /* bad argument */
+    DVO_ERR_NO_DEVICE = 2,   /* no HIP device / runtime */
+    DVO_ERR_HIP = 3,         /* HIP runtime error, see dvo_last_error */
+    DVO_ERR_STATE = 4,       /* data for the requested pair/level not set */
+    DVO_ERR_NOMEM = 5
+};
+
+/* flags for the align entry points */
+enum {
+    DVO_FLAG_FINAL_OUTPUTS = 1    /* also produce finalEpsilons / finalReprojections (SolveDVO.cpp:1002-1003) */
+};
+
+/* Every literal of SolveDVO::runIterations as a runtime parameter; defaults are
+ * the reference's values (file:line in the comments). */
+typedef struct dvo_params {
+    double beta;               /* heavy-ball BETA = 0.5                       SolveDVO.cpp:653 */
+    double precond_rot;        /* PFactor = .5, P = diag(1,1,1,.5,.5,.5)      :724-730 */
+    double reg_lambda;         /* regularizationLambda = 0.05                 :742 */
+    double step_a;             /* 9.0     stepLength = 9.0*1.0E-2/(...)       :773 */
+    double step_b;             /* 1.0E-2                                      :773 */
+    int    step_decay_after;   /* 5  : (itr>5) ? (itr-4) : 1                  :773 */
+    int    step_decay_offset;  /* 4                                           :773 */
+    float  trust_radius;       /* trustRegionHyperSphereRadius = 0.003 (float member) :25 */
+    float  psi_norm_stop;      /* psiNormTerminationThreshold  = 1.0E-7 (float member) :24 */
+    int    enable_rotationize; /* __ENABLE_ROTATIONIZE__       SolveDVO.h:107 */
+    int    enable_l2_reg;      /* __ENABLE_L2_REGULARIZATION   SolveDVO.h:112 */
+    int    interpolate_dt;     /* __INTERPOLATE_DISTANCE_TRANSFORM (off) SolveDVO.h:97; only 0 supported */
+    int    block_threads;      /* engine tuning: threads per workgroup of the fused kernel (256/512/1024; 0 = default) */
+    int    reserved[7];
+} dvo_params;
+
+typedef struct dvo_ctx dvo_ctx;
+
+/* ---- lifecycle ------------------------------------------------------------ */
+int  dvo_params_default(dvo_params *p);
+/* One frame pair, current HIP device.  Mirrors constructing a SolveDVO (SolveDVO.cpp:5-70). */
+int  dvo_create(const dvo_params *p, dvo_ctx **out);
+/* n_pairs independent frame pairs resident at once (batch / throughput mode). */
+int  dvo_create_batch(const dvo_params *p, int n_pairs, dvo_ctx **out);
+int  dvo_destroy(dvo_ctx *ctx);
+const char *dvo_last_error(const dvo_ctx *ctx);      /* ctx may be NULL: last creation error */
+int  dvo_num_pairs(const dvo_ctx *ctx);
+/* Use an existing HIP stream (hipStream_t as void*); NULL = the context's own stream. */
+int  dvo_set_stream(dvo_ctx *ctx, void *hip_stream);
+int  dvo_synchronize(dvo_ctx *ctx);
+
+/* ---- inputs ----------------------------------------------------------------
+ * setCameraMatrix (SolveDVO.cpp:88-126): level-0 fx, fy, cx, cy as floats. */
+int  dvo_set_intrinsics(dvo_ctx *ctx, float fx, float fy, float cx, float cy);
+
+/* _ref_edge_3d[level] (SolveDVO.h:304) of pair `pair`: 3 x N floats. */
+int  dvo_set_ref_level(dvo_ctx *ctx, int level, const float *xyz_3xN, int N);
+int  dvo_set_ref_level_pair(dvo_ctx *ctx, int pair, int level, const float *xyz_3xN, int N);
+
+/* now_distance_transform / now_DT_gradientX / now_DT_gradientY [level]
+ * (SolveDVO.h:279-282), column-major rows x cols.  All pairs of one context
+ * must use the same rows x cols per level. */
+int  dvo_set_now_level(dvo_ctx *ctx, int level, const float *dt, const float *gx, const float *gy,
+                       int rows, int cols);
+int  dvo_set_now_level_pair(dvo_ctx *ctx, int pair, int level, const float *dt, const float *gx,
+                            const float *gy, int rows, int cols);
+/* Same, from DEVICE pointers (e.g. torch tensors); asynchronous on the context stream. */
+int  dvo_set_ref_level_device(dvo_ctx *ctx, int pair, int level, const float *d_xyz_3xN, int N);
+int  dvo_set_now_level_device(dvo_ctx *ctx, int pair, int level, const float *d_dt, const float *d_gx,
+                              const float *d_gy, int rows, int cols);
+
+/* selectedPts + enlistRefEdgePts (SolveDVO.cpp:1230-1264, :224-264) on the GPU:
+ * edge (int32, >0 = edge) and depth_mm (f32), column-major rows x cols, host
+ * pointers.  Builds the 3xN list in the reference's column-major scan order and
+ * installs it as the ref level of `pair`.  xyz_out / uv_out (host, capacity
+ * points) may be NULL.  *N_out receives N. */
+int  dvo_set_ref_level_from_images(dvo_ctx *ctx, int pair, int level, const int32_t *edge,
+                                   const float *depth_mm, int rows, int cols,
+                                   float *xyz_out, float *uv_out, int capacity, int *N_out);
+
+/* ---- the hot path -----------------------------------------------------------
+ * SolveDVO::runIterations (SolveDVO.cpp:619-1017) for pair 0.
+ *   R[9], t[3]        in/out   cR, cT
+ *   energy[max_iters] out      energyAtEachIteration (zero after an early exit, :634)
+ *   final_eps[N]      out/NULL finalEpsilons
+ *   final_reproj[3N]  out/NULL finalReprojections (3 x N column-major, row 2 = z*(1/z))
+ *   best_idx          out      bestEnergyIndex (-1 if no iterate was accepted)
+ *   visible_ratio     out      finalVisibleRatio */
+int  dvo_run_iterations(dvo_ctx *ctx, int level, int max_iters, double *R, double *t,
+                        float *energy, float *final_eps, float *final_reproj,
+                        int *best_idx, float *visible_ratio);
+int  dvo_run_iterations_pair(dvo_ctx *ctx, int pair, int level, int max_iters, double *R, double *t,
+                             float *energy, float *final_eps, float *final_reproj,
+                             int *best_idx, float *visible_ratio);
+
+/* The level schedule of SolveDVO::loop (SolveDVO.cpp:2097-2104) fused into one
+ * launch: for f = n_levels-1 .. 0: if iters[f] > 0: runIterations(f, iters[f], R, t).
+ * Synchronous; R (9*n_pairs) and t (3*n_pairs) are in/out for pairs
+ * [first_pair, first_pair+n_pairs). */
+int  dvo_align_pyramid(dvo_ctx *ctx, int n_levels, const int *iters, int flags, double *R, double *t);
+int  dvo_align_batch(dvo_ctx *ctx, int first_pair, int n_pairs, int n_levels, const int *iters,
+                     int flags, double *R, double *t);
+
+/* Asynchronous form: poses stay device-resident between calls (the reference
+ * carries cR_64/cT_64 from frame to frame, SolveDVO.cpp:2102). */
+int  dvo_set_poses(dvo_ctx *ctx, int first_pair, int n_pairs, const double *R, const double *t);
+int  dvo_align_batch_enqueue(dvo_ctx *ctx, int first_pair, int n_pairs, int n_levels,
+                             const int *iters, int flags);
+int  dvo_get_poses(dvo_ctx *ctx, int first_pair, int n_pairs, double *R, double *t);   /* synchronises */
+
+/* Per-level outputs of the last align call for `pair` (synchronises).
+ * energy: iters[level] floats; any pointer may be NULL. */
+int  dvo_get_level_report(dvo_ctx *ctx, int pair, int level, float *energy, int n_energy,
+                          int *best_idx, float *visible_ratio);
+/* finalEpsilons / finalReprojections of the last level run (needs DVO_FLAG_FINAL_OUTPUTS). */
+int  dvo_get_final_outputs(dvo_ctx *ctx, int pair, float *final_eps, float *final_reproj, int capacity,
+                           int *N_out);
+
+/* ---- inspection (used by the parity tests) ---------------------------------
+ * One evaluation of computeJacobianOfNowFrame + getReprojectedEpsilons at the
+ * given pose (cast to float exactly as SolveDVO.cpp:673-674).  Host outputs, any
+ * may be NULL: reproj 3xN, J Nx6 row-major, eps[N], w[N], visible[N]. */
+int  dvo_eval_points(dvo_ctx *ctx, int pair, int level, const double *R, const double *t,
+                     float *reproj, float *J, float *eps, float *w, int *visible);
+/* The 29 accumulators of one iteration at the given pose:
+ * acc[0..20] = upper triangle of sum_i w_i J_i J_i^T, acc[21..26] = g = J^T W eps
+ * (SolveDVO.cpp:777), acc[27] = sum eps_i^2, acc[28] = number of visible points. */
+int  dvo_accumulate(dvo_ctx *ctx, int pair, int level, const double *R, const double *t,
+                    double *acc29);
+/* Device SE(3) helpers exposed for property tests (same code the kernels use). */
+int  dvo_device_se3_exp(dvo_ctx *ctx, const double *psi6, double *R, double *t);
+int  dvo_device_se3_log(dvo_ctx *ctx, const double *R, const double *t, double *psi6);
+int  dvo_device_rotationize(dvo_ctx *ctx, double *R);
+
+/* ---- measurement support ------------------------------------------------------
+ * Algorithmic (compulsory) bytes of one alignment of `pair` under the given
+ * schedule: sum_l [12*rows*cols + 12*N_l] over levels with iters>0, + 16*N_last
+ * when DVO_FLAG_FINAL_OUTPUTS. */
+int  dvo_algorithmic_bytes(dvo_ctx *ctx, int pair, int n_levels, const int *iters, int flags,
+                           uint64_t *bytes);
+/* Sum over levels of iters[l]*N_l (point-iterations) for `pair`. */
+int  dvo_point_iterations(dvo_ctx *ctx, int pair, int n_levels, const int *iters, uint64_t *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVO_AMD_H_ */

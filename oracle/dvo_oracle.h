@@ -1,0 +1,134 @@
+/*
+ * dvo_oracle.h -- CPU ORACLE for the SolveDVO edge-alignment hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke()
+ * entry point and bench.py's cpu_baseline leg may load it.  The shipped engine
+ * (rgbd_odometry_amd/csrc) never includes, links or calls anything in here.
+ *
+ * PARITY UNPINNED: the reference (mpkuse/rgbd_odometry) ships no tests, golden
+ * vectors or fixtures for this path and cannot be compiled in this image (it
+ * needs ROS, OpenCV 2.4, Eigen3, Sophus and libigl, none of which are present),
+ * so this restatement is pinned only by (a) the algebraic properties the cited
+ * lines imply and (b) its own committed golden vectors (tests/golden).
+ *
+ * What it restates (all paths relative to /root/reference):
+ *   src/SolveDVO.cpp:224-264    enlistRefEdgePts      -> dvo_oracle_enlist_ref_points
+ *   src/SolveDVO.cpp:1230-1264  selectedPts           -> (same function, mask rule)
+ *   src/SolveDVO.cpp:306-414    computeJacobianOfNowFrame
+ *   src/SolveDVO.cpp:425-462    getReprojectedEpsilons -> dvo_oracle_eval_points
+ *   src/SolveDVO.cpp:1047-1053  getWeightOf           -> dvo_oracle_weight
+ *   src/SolveDVO.cpp:1285-1308  interpolate           -> (flag interpolate_dt)
+ *   src/SolveDVO.cpp:1310-1312  aggregateEpsilons
+ *   src/SolveDVO.cpp:619-1017   runIterations         -> dvo_oracle_run_iterations
+ *   src/SolveDVO.cpp:1269-1282  rotationize           -> dvo_oracle_rotationize
+ *   src/SolveDVO.cpp:2097-2104  level schedule        -> dvo_oracle_align_pyramid
+ * Third-party arithmetic on the path that is NOT in /root/reference and is
+ * restated from its published algorithm (versions unpinned by the reference's
+ * package.xml / CMakeLists.txt):
+ *   Sophus (templated SE3Group/SO3Group, 2012-2015): SE3d::exp, SE3d::log,
+ *     setRotationMatrix, rotationMatrix  (call sites SolveDVO.cpp:736-739,905-907)
+ *   Eigen 3: JacobiSVD<Matrix3d,NoQRPreconditioner> (two-sided Jacobi),
+ *     Quaternion(Matrix3) and Quaternion::toRotationMatrix
+ *   libigl: igl::repmat (trivial)
+ *
+ * Layout conventions (Eigen defaults): images are COLUMN-major H x W floats,
+ * element (yy,xx) at data[yy + xx*rows]; point lists are 3xN column-major
+ * (xyz interleaved); R is 3x3 column-major double, R(i,j) = R[i+3*j].
+ */
+#ifndef DVO_ORACLE_H_
+#define DVO_ORACLE_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Every literal of runIterations, with the reference value as default. */
+typedef struct dvo_oracle_params {
+    double beta;                /* heavy-ball BETA = 0.5                    SolveDVO.cpp:653 */
+    double precond_rot;         /* PFactor = .5 -> P=diag(1,1,1,.5,.5,.5)   :724-730 */
+    double reg_lambda;          /* regularizationLambda = 0.05              :742 */
+    double step_a;              /* 9.0      (stepLength = 9.0*1.0E-2/...)   :773 */
+    double step_b;              /* 1.0E-2                                   :773 */
+    int    step_decay_after;    /* 5  : (itr>5)?(itr-4):1                   :773 */
+    int    step_decay_offset;   /* 4                                        :773 */
+    float  trust_radius;        /* trustRegionHyperSphereRadius = 0.003     :25  (float member) */
+    float  psi_norm_stop;       /* psiNormTerminationThreshold = 1.0E-7     :24  (float member) */
+    int    enable_rotationize;  /* __ENABLE_ROTATIONIZE__      SolveDVO.h:107 */
+    int    enable_l2_reg;       /* __ENABLE_L2_REGULARIZATION  SolveDVO.h:112 */
+    int    interpolate_dt;      /* __INTERPOLATE_DISTANCE_TRANSFORM, off  SolveDVO.h:97 */
+} dvo_oracle_params;
+
+void dvo_oracle_params_default(dvo_oracle_params *p);
+
+/* Per-iteration trace record (for golden vectors and step-by-step parity). */
+typedef struct dvo_oracle_iter_trace {
+    double g[6];        /* J^T W eps before the regulariser (:777) */
+    double H[21];       /* upper triangle of sum_i w_i J_i J_i^T (not used by the reference policy) */
+    double sum_eps2;    /* sum eps_i^2 in double */
+    double psi[6];      /* step actually applied (after clamp); zeros if the loop broke */
+    double R[9];        /* pose AFTER the update (col-major) */
+    double t[3];
+    float  energy;
+    int    n_visible;
+    int    broke;       /* 1 if early termination happened in this iteration */
+} dvo_oracle_iter_trace;
+
+/* SolveDVO.cpp:1230-1264 + :224-264.  edge (int32) and depth_mm (f32) are
+ * column-major rows x cols.  Returns N (number of selected points) or -1 if
+ * capacity is too small.  xyz: 3xN, uv: 2xN (may be NULL). */
+int dvo_oracle_enlist_ref_points(int level, const int *edge, const float *depth_mm,
+                                 int rows, int cols,
+                                 float fx, float fy, float cx, float cy,
+                                 float *xyz, float *uv, int capacity);
+
+/* One evaluation of :306-414 + :425-462 at a float pose.
+ * Rf: 3x3 col-major float, tf: 3 float.  Outputs (any may be NULL):
+ * reproj 3xN col-major; J Nx6 ROW-major (J[6*i+k]); eps[N]; w[N]; visible[N] (0/1). */
+void dvo_oracle_eval_points(const dvo_oracle_params *prm, int level,
+                            const float *xyz, int N,
+                            const float *dt, const float *gx, const float *gy,
+                            int rows, int cols,
+                            float fx, float fy, float cx, float cy,
+                            const float *Rf, const float *tf,
+                            float *reproj, float *J, float *eps, float *w, int *visible);
+
+/* :619-1017.  R,t in/out.  energy[max_iters] zero-filled first.
+ * final_eps[N], final_reproj[3N] may be NULL.  trace[max_iters] may be NULL.
+ * Returns the number of iterations whose energy was evaluated. */
+int dvo_oracle_run_iterations(const dvo_oracle_params *prm, int level, int max_iters,
+                              const float *xyz, int N,
+                              const float *dt, const float *gx, const float *gy,
+                              int rows, int cols,
+                              float fx, float fy, float cx, float cy,
+                              double *R, double *t,
+                              float *energy, float *final_eps, float *final_reproj,
+                              int *best_idx, float *visible_ratio,
+                              dvo_oracle_iter_trace *trace);
+
+/* :2097-2104: for f = n_levels-1 .. 0: if iters[f] > 0: runIterations(f, ...).
+ * Per-level inputs are arrays of pointers / sizes indexed by level.
+ * energy_out: concatenated per level in LEVEL order (level 0 first), each block
+ * iters[l] floats.  best_idx_out[n_levels], ratio_out[n_levels] (entries of
+ * skipped levels are -1 / 0).  final_* refer to the last level run (level of
+ * the smallest index with iters>0). */
+int dvo_oracle_align_pyramid(const dvo_oracle_params *prm, int n_levels, const int *iters,
+                             const float *const *xyz, const int *N,
+                             const float *const *dt, const float *const *gx, const float *const *gy,
+                             const int *rows, const int *cols,
+                             float fx, float fy, float cx, float cy,
+                             double *R, double *t,
+                             float *energy_out, int *best_idx_out, float *ratio_out,
+                             float *final_eps, float *final_reproj);
+
+/* Helpers exported for property tests. */
+float dvo_oracle_weight(float r);                                   /* :1047-1053 */
+float dvo_oracle_interpolate(const float *F, int rows, int cols, float ry, float rx); /* :1285-1308 */
+void  dvo_oracle_se3_exp(const double *psi, double *R, double *t);  /* Sophus SE3d::exp */
+void  dvo_oracle_se3_log(const double *R, const double *t, double *psi); /* Sophus SE3d::log */
+void  dvo_oracle_rotationize(double *R);                            /* :1269-1282 */
+void  dvo_oracle_svd3(const double *A, double *U, double *S, double *V); /* JacobiSVD */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,321 @@
+"""ctypes binding of include/dvo_amd.h (one Python method per C entry point).
+
+Fails loudly when the HIP library has not been built or when no HIP device is present:
+there is no CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+DVO_MAX_LEVELS = 8
+DVO_NUM_ACC = 29
+DVO_OK, DVO_ERR_INVALID, DVO_ERR_NO_DEVICE, DVO_ERR_HIP, DVO_ERR_STATE, DVO_ERR_NOMEM = range(6)
+DVO_FLAG_FINAL_OUTPUTS = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+#: every symbol include/dvo_amd.h declares (checked by tests/test_capi_symbols.py)
+C_ABI_SYMBOLS = [
+    "dvo_params_default", "dvo_create", "dvo_create_batch", "dvo_destroy", "dvo_last_error",
+    "dvo_num_pairs", "dvo_set_stream", "dvo_synchronize", "dvo_set_intrinsics",
+    "dvo_set_ref_level", "dvo_set_ref_level_pair", "dvo_set_now_level", "dvo_set_now_level_pair",
+    "dvo_set_ref_level_device", "dvo_set_now_level_device", "dvo_set_ref_level_from_images",
+    "dvo_run_iterations", "dvo_run_iterations_pair", "dvo_align_pyramid", "dvo_align_batch",
+    "dvo_set_poses", "dvo_align_batch_enqueue", "dvo_get_poses", "dvo_get_level_report",
+    "dvo_get_final_outputs", "dvo_eval_points", "dvo_accumulate", "dvo_device_se3_exp",
+    "dvo_device_se3_log", "dvo_device_rotationize", "dvo_algorithmic_bytes", "dvo_point_iterations",
+]
+
+
+class DvoParams(C.Structure):
+    """Mirror of ``struct dvo_params`` (defaults = the literals of SolveDVO.cpp:21-33,653-773)."""
+    _fields_ = [
+        ("beta", C.c_double), ("precond_rot", C.c_double), ("reg_lambda", C.c_double),
+        ("step_a", C.c_double), ("step_b", C.c_double),
+        ("step_decay_after", C.c_int), ("step_decay_offset", C.c_int),
+        ("trust_radius", C.c_float), ("psi_norm_stop", C.c_float),
+        ("enable_rotationize", C.c_int), ("enable_l2_reg", C.c_int), ("interpolate_dt", C.c_int),
+        ("block_threads", C.c_int), ("reserved", C.c_int * 7),
+    ]
+
+
+class DvoError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"dvo error {code}: {msg}")
+        self.code = code
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "lib", "libdvo_amd.so")
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load lib/libdvo_amd.so; raise if it is missing (build with __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C rgbd_odometry_amd/csrc)")
+    lib = C.CDLL(path)
+    vp, ip, fp, dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)
+    i, f = C.c_int, C.c_float
+    sig = {
+        "dvo_params_default": [C.POINTER(DvoParams)],
+        "dvo_create": [C.POINTER(DvoParams), C.POINTER(vp)],
+        "dvo_create_batch": [C.POINTER(DvoParams), i, C.POINTER(vp)],
+        "dvo_destroy": [vp],
+        "dvo_num_pairs": [vp],
+        "dvo_set_stream": [vp, vp],
+        "dvo_synchronize": [vp],
+        "dvo_set_intrinsics": [vp, f, f, f, f],
+        "dvo_set_ref_level": [vp, i, vp, i],
+        "dvo_set_ref_level_pair": [vp, i, i, vp, i],
+        "dvo_set_now_level": [vp, i, vp, vp, vp, i, i],
+        "dvo_set_now_level_pair": [vp, i, i, vp, vp, vp, i, i],
+        "dvo_set_ref_level_device": [vp, i, i, vp, i],
+        "dvo_set_now_level_device": [vp, i, i, vp, vp, vp, i, i],
+        "dvo_set_ref_level_from_images": [vp, i, i, vp, vp, i, i, vp, vp, i, ip],
+        "dvo_run_iterations": [vp, i, i, vp, vp, vp, vp, vp, ip, fp],
+        "dvo_run_iterations_pair": [vp, i, i, i, vp, vp, vp, vp, vp, ip, fp],
+        "dvo_align_pyramid": [vp, i, ip, i, vp, vp],
+        "dvo_align_batch": [vp, i, i, i, ip, i, vp, vp],
+        "dvo_set_poses": [vp, i, i, vp, vp],
+        "dvo_align_batch_enqueue": [vp, i, i, i, ip, i],
+        "dvo_get_poses": [vp, i, i, vp, vp],
+        "dvo_get_level_report": [vp, i, i, vp, i, ip, fp],
+        "dvo_get_final_outputs": [vp, i, vp, vp, i, ip],
+        "dvo_eval_points": [vp, i, i, vp, vp, vp, vp, vp, vp, vp],
+        "dvo_accumulate": [vp, i, i, vp, vp, vp],
+        "dvo_device_se3_exp": [vp, vp, vp, vp],
+        "dvo_device_se3_log": [vp, vp, vp, vp],
+        "dvo_device_rotationize": [vp, vp],
+        "dvo_algorithmic_bytes": [vp, i, i, ip, i, C.POINTER(C.c_uint64)],
+        "dvo_point_iterations": [vp, i, i, ip, C.POINTER(C.c_uint64)],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.dvo_last_error.argtypes = [vp]
+    lib.dvo_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _iters(iters: Sequence[int]):
+    arr = (C.c_int * len(iters))(*[int(x) for x in iters])
+    return arr
+
+
+class DvoContext:
+    """One engine context = ``dvo_ctx`` (n_pairs frame pairs resident in HBM)."""
+
+    def __init__(self, n_pairs: int = 1, params: Optional[DvoParams] = None, **overrides):
+        self.lib = load_library()
+        p = DvoParams()
+        self.lib.dvo_params_default(C.byref(p))
+        if params is not None:
+            p = params
+        for k, v in overrides.items():
+            setattr(p, k, v)
+        self.params = p
+        self._h = C.c_void_p()
+        rc = self.lib.dvo_create_batch(C.byref(p), int(n_pairs), C.byref(self._h))
+        if rc != DVO_OK:
+            raise DvoError(rc, (self.lib.dvo_last_error(None) or b"").decode())
+        self.n_pairs = int(n_pairs)
+        self._N = {}      # (pair, level) -> N
+        self._dims = {}   # level -> (rows, cols)
+
+    # -- plumbing -----------------------------------------------------------
+    def _chk(self, rc: int):
+        if rc != DVO_OK:
+            raise DvoError(rc, (self.lib.dvo_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.dvo_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, hip_stream: int):
+        self._chk(self.lib.dvo_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def synchronize(self):
+        self._chk(self.lib.dvo_synchronize(self._h))
+
+    # -- inputs -------------------------------------------------------------
+    def set_intrinsics(self, fx, fy, cx, cy):
+        self._chk(self.lib.dvo_set_intrinsics(self._h, fx, fy, cx, cy))
+
+    def set_ref_level(self, level: int, xyz, pair: int = 0):
+        xyz = _f32(xyz).reshape(-1)
+        n = xyz.size // 3
+        self._chk(self.lib.dvo_set_ref_level_pair(self._h, pair, level, _ptr(xyz), n))
+        self._N[(pair, level)] = n
+
+    def set_now_level(self, level: int, dt, gx, gy, rows: int, cols: int, pair: int = 0):
+        dt, gx, gy = _f32(dt).reshape(-1), _f32(gx).reshape(-1), _f32(gy).reshape(-1)
+        assert dt.size == gx.size == gy.size == rows * cols
+        self._chk(self.lib.dvo_set_now_level_pair(self._h, pair, level, _ptr(dt), _ptr(gx), _ptr(gy), rows, cols))
+        self._dims[level] = (rows, cols)
+
+    def set_ref_level_device(self, level: int, d_xyz_ptr: int, n: int, pair: int = 0):
+        self._chk(self.lib.dvo_set_ref_level_device(self._h, pair, level, C.c_void_p(d_xyz_ptr), n))
+        self._N[(pair, level)] = n
+
+    def set_now_level_device(self, level: int, d_dt: int, d_gx: int, d_gy: int, rows: int, cols: int, pair: int = 0):
+        self._chk(self.lib.dvo_set_now_level_device(self._h, pair, level, C.c_void_p(d_dt), C.c_void_p(d_gx),
+                                                    C.c_void_p(d_gy), rows, cols))
+        self._dims[level] = (rows, cols)
+
+    def set_ref_level_from_images(self, level: int, edge, depth_mm, rows: int, cols: int, pair: int = 0):
+        """selectedPts + enlistRefEdgePts on the GPU; returns (xyz[N,3], uv[N,2])."""
+        edge = np.ascontiguousarray(edge, dtype=np.int32).reshape(-1)
+        depth = _f32(depth_mm).reshape(-1)
+        cap = rows * cols
+        xyz = np.zeros(3 * cap, np.float32)
+        uv = np.zeros(2 * cap, np.float32)
+        n = C.c_int(0)
+        self._chk(self.lib.dvo_set_ref_level_from_images(self._h, pair, level, _ptr(edge), _ptr(depth), rows, cols,
+                                                         _ptr(xyz), _ptr(uv), cap, C.byref(n)))
+        self._N[(pair, level)] = n.value
+        return xyz[:3 * n.value].reshape(-1, 3).copy(), uv[:2 * n.value].reshape(-1, 2).copy()
+
+    # -- hot path -----------------------------------------------------------
+    def run_iterations(self, level: int, max_iters: int, R, t, pair: int = 0, want_final: bool = True):
+        """SolveDVO::runIterations.  Returns dict(R, t, energy, final_eps, final_reproj, best_idx, visible_ratio)."""
+        R = np.array(R, dtype=np.float64, order="F").copy(order="F")
+        t = np.array(t, dtype=np.float64).copy()
+        n = self._N[(pair, level)]
+        energy = np.zeros(max_iters, np.float32)
+        feps = np.zeros(n, np.float32) if want_final else None
+        frep = np.zeros(3 * n, np.float32) if want_final else None
+        best = C.c_int(-2)
+        ratio = C.c_float(0)
+        self._chk(self.lib.dvo_run_iterations_pair(self._h, pair, level, max_iters, _ptr(R), _ptr(t), _ptr(energy),
+                                                   _ptr(feps), _ptr(frep), C.byref(best), C.byref(ratio)))
+        return dict(R=R, t=t, energy=energy, final_eps=feps,
+                    final_reproj=None if frep is None else frep.reshape(-1, 3),
+                    best_idx=best.value, visible_ratio=ratio.value)
+
+    def align_batch(self, iters: Sequence[int], R, t, first_pair: int = 0, n_pairs: Optional[int] = None,
+                    flags: int = 0):
+        """Level schedule of SolveDVO::loop for a range of pairs.  R: [n,3,3] (math layout), t: [n,3]."""
+        n_pairs = self.n_pairs - first_pair if n_pairs is None else n_pairs
+        Rm = np.asarray(R, dtype=np.float64).reshape(n_pairs, 3, 3)
+        Rc = np.ascontiguousarray(np.transpose(Rm, (0, 2, 1)))   # column-major per pair
+        tc = np.ascontiguousarray(np.asarray(t, dtype=np.float64).reshape(n_pairs, 3))
+        self._chk(self.lib.dvo_align_batch(self._h, first_pair, n_pairs, len(iters), _iters(iters), flags,
+                                           _ptr(Rc), _ptr(tc)))
+        return np.transpose(Rc, (0, 2, 1)).copy(), tc
+
+    def set_poses(self, R, t, first_pair: int = 0):
+        Rm = np.asarray(R, dtype=np.float64).reshape(-1, 3, 3)
+        n = Rm.shape[0]
+        Rc = np.ascontiguousarray(np.transpose(Rm, (0, 2, 1)))
+        tc = np.ascontiguousarray(np.asarray(t, dtype=np.float64).reshape(n, 3))
+        self._chk(self.lib.dvo_set_poses(self._h, first_pair, n, _ptr(Rc), _ptr(tc)))
+
+    def enqueue(self, iters: Sequence[int], first_pair: int = 0, n_pairs: Optional[int] = None, flags: int = 0):
+        n_pairs = self.n_pairs - first_pair if n_pairs is None else n_pairs
+        self._chk(self.lib.dvo_align_batch_enqueue(self._h, first_pair, n_pairs, len(iters), _iters(iters), flags))
+
+    def get_poses(self, first_pair: int = 0, n_pairs: Optional[int] = None):
+        n_pairs = self.n_pairs - first_pair if n_pairs is None else n_pairs
+        Rc = np.zeros((n_pairs, 3, 3))
+        tc = np.zeros((n_pairs, 3))
+        self._chk(self.lib.dvo_get_poses(self._h, first_pair, n_pairs, _ptr(Rc), _ptr(tc)))
+        return np.transpose(Rc, (0, 2, 1)).copy(), tc
+
+    def level_report(self, pair: int, level: int, n_energy: int):
+        energy = np.zeros(n_energy, np.float32)
+        best = C.c_int(-2)
+        ratio = C.c_float(0)
+        self._chk(self.lib.dvo_get_level_report(self._h, pair, level, _ptr(energy), n_energy, C.byref(best),
+                                                C.byref(ratio)))
+        return energy, best.value, ratio.value
+
+    def final_outputs(self, pair: int, capacity: int):
+        feps = np.zeros(capacity, np.float32)
+        frep = np.zeros(3 * capacity, np.float32)
+        n = C.c_int(0)
+        self._chk(self.lib.dvo_get_final_outputs(self._h, pair, _ptr(feps), _ptr(frep), capacity, C.byref(n)))
+        return feps[:n.value].copy(), frep[:3 * n.value].reshape(-1, 3).copy()
+
+    # -- inspection -----------------------------------------------------------
+    def eval_points(self, level: int, R, t, pair: int = 0):
+        n = self._N[(pair, level)]
+        R = np.array(R, dtype=np.float64, order="F")
+        t = np.array(t, dtype=np.float64)
+        rep, J = np.zeros(3 * n, np.float32), np.zeros(6 * n, np.float32)
+        eps, w, vis = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+        self._chk(self.lib.dvo_eval_points(self._h, pair, level, _ptr(R), _ptr(t), _ptr(rep), _ptr(J), _ptr(eps),
+                                           _ptr(w), _ptr(vis)))
+        return dict(reproj=rep.reshape(-1, 3), J=J.reshape(-1, 6), eps=eps, w=w, visible=vis)
+
+    def accumulate(self, level: int, R, t, pair: int = 0) -> np.ndarray:
+        R = np.array(R, dtype=np.float64, order="F")
+        t = np.array(t, dtype=np.float64)
+        acc = np.zeros(DVO_NUM_ACC)
+        self._chk(self.lib.dvo_accumulate(self._h, pair, level, _ptr(R), _ptr(t), _ptr(acc)))
+        return acc
+
+    def se3_exp(self, psi):
+        psi = np.array(psi, dtype=np.float64)
+        R = np.zeros((3, 3), order="F")
+        t = np.zeros(3)
+        self._chk(self.lib.dvo_device_se3_exp(self._h, _ptr(psi), _ptr(R), _ptr(t)))
+        return R, t
+
+    def se3_log(self, R, t):
+        R = np.array(R, dtype=np.float64, order="F")
+        t = np.array(t, dtype=np.float64)
+        psi = np.zeros(6)
+        self._chk(self.lib.dvo_device_se3_log(self._h, _ptr(R), _ptr(t), _ptr(psi)))
+        return psi
+
+    def rotationize(self, R):
+        R = np.array(R, dtype=np.float64, order="F").copy(order="F")
+        self._chk(self.lib.dvo_device_rotationize(self._h, _ptr(R)))
+        return R
+
+    # -- measurement ----------------------------------------------------------
+    def algorithmic_bytes(self, iters: Sequence[int], pair: int = 0, flags: int = 0) -> int:
+        b = C.c_uint64(0)
+        self._chk(self.lib.dvo_algorithmic_bytes(self._h, pair, len(iters), _iters(iters), flags, C.byref(b)))
+        return b.value
+
+    def point_iterations(self, iters: Sequence[int], pair: int = 0) -> int:
+        b = C.c_uint64(0)
+        self._chk(self.lib.dvo_point_iterations(self._h, pair, len(iters), _iters(iters), C.byref(b)))
+        return b.value

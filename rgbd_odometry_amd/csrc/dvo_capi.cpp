@@ -1,0 +1,675 @@
+/*
+ * dvo_capi.cpp -- implementation of the C ABI declared in include/dvo_amd.h.
+ *
+ * Host side only: context + HBM slab management, uploads, kernel launches.
+ * There is deliberately no CPU compute path in this file: every compute entry
+ * point needs a HIP device and fails with DVO_ERR_NO_DEVICE / DVO_ERR_HIP
+ * otherwise.
+ *
+ * HBM layout ("slabs", sized for batch mode): per pyramid level ONE allocation
+ * for the texels of all pairs and ONE for the points of all pairs (see
+ * dvo_launch.h::LevelSlab), so a 256-pair 640x480x4 batch is 8 large
+ * allocations (~1.7 GB of texels) instead of 2048 small ones.
+ */
+#include "../../include/dvo_amd.h"
+#include "dvo_launch.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace dvo;
+
+namespace {
+thread_local std::string g_create_error;
+
+struct Level {
+    int rows = 0, cols = 0;
+    float4 *tex = nullptr;
+    size_t tex_stride = 0;
+    float *pts = nullptr;
+    int pt_cap = 0;
+    int *dN = nullptr;
+    std::vector<int> hN;            /* 0 = not set */
+    std::vector<char> have_now;
+};
+}  // namespace
+
+struct dvo_ctx {
+    dvo_params prm;
+    DevParams dprm;
+    int n_pairs = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    Intrinsics K{0, 0, 0, 0};
+    bool have_K = false;
+    Level lv[DVO_LEVELS];
+    float *staging = nullptr;       /* 3 planes (or one point list) of the largest upload so far */
+    size_t staging_bytes = 0;
+    double *d_poses = nullptr;
+    float *d_energy = nullptr;
+    size_t energy_floats = 0;
+    int *d_best = nullptr;
+    float *d_ratio = nullptr;
+    float *d_final_eps = nullptr, *d_final_reproj = nullptr;
+    int *d_final_N = nullptr;
+    int final_cap = 0;
+    double *d_scratch = nullptr;    /* partials (1024 x 32) + acc (32) + misc doubles */
+    int *d_colcounts = nullptr;
+    size_t colcounts_cap = 0;
+    Schedule sched{};
+    bool have_sched = false;
+    std::string err;
+};
+
+namespace {
+
+int fail(dvo_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+#define HIPCHK(c, expr)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail((c), DVO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int ensure_staging(dvo_ctx *c, size_t bytes) {
+    if (bytes <= c->staging_bytes) return DVO_OK;
+    if (c->staging) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->staging)); c->staging = nullptr; }
+    HIPCHK(c, hipMalloc((void **)&c->staging, bytes));
+    c->staging_bytes = bytes;
+    return DVO_OK;
+}
+
+bool pair_ok(const dvo_ctx *c, int pair) { return pair >= 0 && pair < c->n_pairs; }
+bool level_ok(int level) { return level >= 0 && level < DVO_LEVELS; }
+
+/* make room for N points per pair at `level` (keeps existing contents) */
+int ensure_points(dvo_ctx *c, int level, int N) {
+    Level &L = c->lv[level];
+    if (L.hN.empty()) { L.hN.assign(c->n_pairs, 0); }
+    if (!L.dN) {
+        HIPCHK(c, hipMalloc((void **)&L.dN, sizeof(int) * c->n_pairs));
+        HIPCHK(c, hipMemsetAsync(L.dN, 0, sizeof(int) * c->n_pairs, c->stream));
+    }
+    if (N <= L.pt_cap) return DVO_OK;
+    int new_cap = std::max(N, L.pt_cap + L.pt_cap / 4);
+    new_cap = (new_cap + 255) / 256 * 256;
+    float *np = nullptr;
+    HIPCHK(c, hipMalloc((void **)&np, sizeof(float) * 3 * (size_t)new_cap * c->n_pairs));
+    if (L.pts) {
+        HIPCHK(c, hipMemcpy2DAsync(np, sizeof(float) * 3 * (size_t)new_cap, L.pts,
+                                   sizeof(float) * 3 * (size_t)L.pt_cap,
+                                   sizeof(float) * 3 * (size_t)L.pt_cap, c->n_pairs,
+                                   hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(L.pts));
+    }
+    L.pts = np;
+    L.pt_cap = new_cap;
+    return DVO_OK;
+}
+
+int ensure_texels(dvo_ctx *c, int level, int rows, int cols) {
+    Level &L = c->lv[level];
+    if (L.have_now.empty()) L.have_now.assign(c->n_pairs, 0);
+    if (L.tex && L.rows == rows && L.cols == cols) return DVO_OK;
+    if (L.tex) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(L.tex));
+        L.tex = nullptr;
+        std::fill(L.have_now.begin(), L.have_now.end(), 0);
+    }
+    L.rows = rows; L.cols = cols;
+    L.tex_stride = (size_t)rows * cols;
+    HIPCHK(c, hipMalloc((void **)&L.tex, sizeof(float4) * L.tex_stride * c->n_pairs));
+    return DVO_OK;
+}
+
+LevelSlab slab_of(const dvo_ctx *c, int level) {
+    const Level &L = c->lv[level];
+    LevelSlab s;
+    s.tex = L.tex; s.pts = L.pts; s.N = L.dN;
+    s.tex_stride = L.tex_stride; s.pt_cap = L.pt_cap; s.rows = L.rows; s.cols = L.cols;
+    return s;
+}
+
+int check_ready(dvo_ctx *c, int pair, int level) {
+    if (!c->have_K) return fail(c, DVO_ERR_STATE, "intrinsics not set (dvo_set_intrinsics)");
+    const Level &L = c->lv[level];
+    if (L.hN.empty() || L.hN[pair] <= 0)
+        return fail(c, DVO_ERR_STATE, "reference points of pair " + std::to_string(pair) + " level " +
+                                          std::to_string(level) + " not set");
+    if (L.have_now.empty() || !L.have_now[pair])
+        return fail(c, DVO_ERR_STATE, "now level " + std::to_string(level) + " of pair " +
+                                          std::to_string(pair) + " not set");
+    return DVO_OK;
+}
+
+int build_schedule(dvo_ctx *c, int n_levels, const int *iters, int flags, Schedule &sc) {
+    if (n_levels < 1 || n_levels > DVO_LEVELS || !iters) return fail(c, DVO_ERR_INVALID, "bad level schedule");
+    std::memset(&sc, 0, sizeof(sc));
+    sc.n_levels = n_levels;
+    sc.flags = flags;
+    sc.last_level = -1;
+    int off = 0;
+    for (int l = 0; l < n_levels; l++) {
+        sc.iters[l] = iters[l] > 0 ? iters[l] : 0;
+        sc.e_off[l] = off;
+        off += sc.iters[l];
+    }
+    for (int l = n_levels - 1; l >= 0; l--) if (sc.iters[l] > 0) sc.last_level = l;
+    if (sc.last_level < 0) return fail(c, DVO_ERR_INVALID, "schedule has no iterations");
+    sc.e_stride = off;
+    return DVO_OK;
+}
+
+int ensure_outputs(dvo_ctx *c, const Schedule &sc) {
+    const size_t need = (size_t)sc.e_stride * c->n_pairs;
+    if (need > c->energy_floats) {
+        if (c->d_energy) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->d_energy)); }
+        HIPCHK(c, hipMalloc((void **)&c->d_energy, sizeof(float) * need));
+        c->energy_floats = need;
+    }
+    if (sc.flags & DVO_FLAG_FINAL_OUTPUTS) {
+        const int cap = c->lv[sc.last_level].pt_cap;
+        if (cap > c->final_cap) {
+            if (c->d_final_eps) {
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                HIPCHK(c, hipFree(c->d_final_eps));
+                HIPCHK(c, hipFree(c->d_final_reproj));
+            }
+            HIPCHK(c, hipMalloc((void **)&c->d_final_eps, sizeof(float) * (size_t)cap * c->n_pairs));
+            HIPCHK(c, hipMalloc((void **)&c->d_final_reproj, sizeof(float) * 3 * (size_t)cap * c->n_pairs));
+            c->final_cap = cap;
+        }
+    }
+    return DVO_OK;
+}
+
+Outputs outputs_of(const dvo_ctx *c) {
+    Outputs o;
+    o.poses = c->d_poses; o.energy = c->d_energy; o.best_idx = c->d_best; o.ratio = c->d_ratio;
+    o.final_eps = c->d_final_eps; o.final_reproj = c->d_final_reproj; o.final_N = c->d_final_N;
+    o.final_cap = c->final_cap;
+    return o;
+}
+
+void cast_pose(const double *R, const double *t, float *Rf, float *tf) {
+    for (int k = 0; k < 9; k++) Rf[k] = (float)R[k];       /* cR.cast<float>()  SolveDVO.cpp:673 */
+    for (int k = 0; k < 3; k++) tf[k] = (float)t[k];       /* :674 */
+}
+
+int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *iters, int flags) {
+    if (!pair_ok(c, first_pair) || n_pairs < 1 || first_pair + n_pairs > c->n_pairs)
+        return fail(c, DVO_ERR_INVALID, "pair range out of bounds");
+    Schedule sc;
+    int rc = build_schedule(c, n_levels, iters, flags, sc);
+    if (rc) return rc;
+    for (int l = 0; l < n_levels; l++) {
+        if (sc.iters[l] <= 0) continue;
+        for (int p = first_pair; p < first_pair + n_pairs; p++)
+            if ((rc = check_ready(c, p, l))) return rc;
+    }
+    if ((rc = ensure_outputs(c, sc))) return rc;
+    LevelSet ls;
+    for (int l = 0; l < DVO_LEVELS; l++) ls.l[l] = slab_of(c, l);
+    int block = c->prm.block_threads;
+    if (block != 256 && block != 512 && block != 1024) block = 512;
+    HIPCHK(c, launch_align_fused(block, ls, sc, c->K, c->dprm, outputs_of(c), first_pair, n_pairs, c->stream));
+    c->sched = sc;
+    c->have_sched = true;
+    return DVO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvo_params_default(dvo_params *p) {
+    if (!p) return DVO_ERR_INVALID;
+    std::memset(p, 0, sizeof(*p));
+    p->beta = 0.5;
+    p->precond_rot = .5;
+    p->reg_lambda = 0.05;
+    p->step_a = 9.0;
+    p->step_b = 1.0E-2;
+    p->step_decay_after = 5;
+    p->step_decay_offset = 4;
+    p->trust_radius = 0.003;
+    p->psi_norm_stop = 1.0E-7;
+    p->enable_rotationize = 1;
+    p->enable_l2_reg = 1;
+    p->interpolate_dt = 0;
+    p->block_threads = 0;
+    return DVO_OK;
+}
+
+int dvo_create_batch(const dvo_params *p, int n_pairs, dvo_ctx **out) {
+    if (!out) return fail(nullptr, DVO_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n_pairs < 1) return fail(nullptr, DVO_ERR_INVALID, "n_pairs must be >= 1");
+    dvo_params prm;
+    if (p) prm = *p; else dvo_params_default(&prm);
+    if (prm.interpolate_dt)
+        return fail(nullptr, DVO_ERR_INVALID, "interpolate_dt=1 (__INTERPOLATE_DISTANCE_TRANSFORM) is not supported by the HIP path");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(nullptr, DVO_ERR_NO_DEVICE, std::string("no HIP device available: ") +
+                                                    (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") +
+                                                    " (this engine has no CPU fallback)");
+    dvo_ctx *c = new dvo_ctx();
+    c->prm = prm;
+    c->n_pairs = n_pairs;
+    c->dprm.beta = prm.beta; c->dprm.precond_rot = prm.precond_rot; c->dprm.reg_lambda = prm.reg_lambda;
+    c->dprm.step_a = prm.step_a; c->dprm.step_b = prm.step_b;
+    c->dprm.trust_radius = (double)prm.trust_radius;        /* widened at use, SolveDVO.cpp:835 */
+    c->dprm.psi_norm_stop = (double)prm.psi_norm_stop;      /* :872 */
+    c->dprm.step_decay_after = prm.step_decay_after; c->dprm.step_decay_offset = prm.step_decay_offset;
+    c->dprm.enable_rotationize = prm.enable_rotationize; c->dprm.enable_l2_reg = prm.enable_l2_reg;
+#define CRCHK(expr)                                                                                     \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            fail(nullptr, DVO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));              \
+            dvo_destroy(c);                                                                             \
+            return DVO_ERR_HIP;                                                                         \
+        }                                                                                               \
+    } while (0)
+    CRCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    CRCHK(hipMalloc((void **)&c->d_poses, sizeof(double) * 12 * n_pairs));
+    CRCHK(hipMalloc((void **)&c->d_best, sizeof(int) * DVO_LEVELS * n_pairs));
+    CRCHK(hipMalloc((void **)&c->d_ratio, sizeof(float) * DVO_LEVELS * n_pairs));
+    CRCHK(hipMalloc((void **)&c->d_final_N, sizeof(int) * n_pairs));
+    CRCHK(hipMalloc((void **)&c->d_scratch, sizeof(double) * (1024 * DVO_NACC_PAD + 64)));
+    CRCHK(hipMemset(c->d_best, 0xff, sizeof(int) * DVO_LEVELS * n_pairs));
+    CRCHK(hipMemset(c->d_ratio, 0, sizeof(float) * DVO_LEVELS * n_pairs));
+    CRCHK(hipMemset(c->d_final_N, 0, sizeof(int) * n_pairs));
+    {   /* identity poses */
+        std::vector<double> id((size_t)12 * n_pairs, 0.0);
+        for (int p_ = 0; p_ < n_pairs; p_++) { id[12 * p_] = id[12 * p_ + 4] = id[12 * p_ + 8] = 1.0; }
+        CRCHK(hipMemcpy(c->d_poses, id.data(), sizeof(double) * id.size(), hipMemcpyHostToDevice));
+    }
+#undef CRCHK
+    *out = c;
+    return DVO_OK;
+}
+
+int dvo_create(const dvo_params *p, dvo_ctx **out) { return dvo_create_batch(p, 1, out); }
+
+int dvo_destroy(dvo_ctx *c) {
+    if (!c) return DVO_OK;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int l = 0; l < DVO_LEVELS; l++) {
+        if (c->lv[l].tex) (void)hipFree(c->lv[l].tex);
+        if (c->lv[l].pts) (void)hipFree(c->lv[l].pts);
+        if (c->lv[l].dN) (void)hipFree(c->lv[l].dN);
+    }
+    void *ptrs[] = {c->staging, c->d_poses, c->d_energy, c->d_best, c->d_ratio, c->d_final_eps,
+                    c->d_final_reproj, c->d_final_N, c->d_scratch, c->d_colcounts};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return DVO_OK;
+}
+
+const char *dvo_last_error(const dvo_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+int dvo_num_pairs(const dvo_ctx *c) { return c ? c->n_pairs : 0; }
+
+int dvo_set_stream(dvo_ctx *c, void *hip_stream) {
+    if (!c) return DVO_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return DVO_OK;
+}
+int dvo_synchronize(dvo_ctx *c) {
+    if (!c) return DVO_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DVO_OK;
+}
+
+int dvo_set_intrinsics(dvo_ctx *c, float fx, float fy, float cx, float cy) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!(fx > 0.0f) || !(fy > 0.0f)) return fail(c, DVO_ERR_INVALID, "fx, fy must be positive");
+    c->K = Intrinsics{fx, fy, cx, cy};
+    c->have_K = true;
+    return DVO_OK;
+}
+
+/* ---- reference side -------------------------------------------------------- */
+static int set_ref_common(dvo_ctx *c, int pair, int level, const float *xyz, int N, bool device_src) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair) || !level_ok(level)) return fail(c, DVO_ERR_INVALID, "pair/level out of range");
+    if (!xyz || N < 1) return fail(c, DVO_ERR_INVALID, "need N >= 1 reference points (reference asserts nSelectedPts > 0, SolveDVO.cpp:282)");
+    int rc = ensure_points(c, level, N);
+    if (rc) return rc;
+    Level &L = c->lv[level];
+    float *dst = L.pts + (size_t)pair * L.pt_cap * 3;
+    HIPCHK(c, hipMemcpyAsync(dst, xyz, sizeof(float) * 3 * (size_t)N,
+                             device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    L.hN[pair] = N;
+    HIPCHK(c, hipMemcpyAsync(L.dN + pair, &L.hN[pair], sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (!device_src) HIPCHK(c, hipStreamSynchronize(c->stream));   /* host buffer is only borrowed */
+    return DVO_OK;
+}
+int dvo_set_ref_level_pair(dvo_ctx *c, int pair, int level, const float *xyz, int N) {
+    return set_ref_common(c, pair, level, xyz, N, false);
+}
+int dvo_set_ref_level(dvo_ctx *c, int level, const float *xyz, int N) {
+    return set_ref_common(c, 0, level, xyz, N, false);
+}
+int dvo_set_ref_level_device(dvo_ctx *c, int pair, int level, const float *d_xyz, int N) {
+    return set_ref_common(c, pair, level, d_xyz, N, true);
+}
+
+int dvo_set_ref_level_from_images(dvo_ctx *c, int pair, int level, const int32_t *edge,
+                                  const float *depth_mm, int rows, int cols,
+                                  float *xyz_out, float *uv_out, int capacity, int *N_out) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair) || !level_ok(level)) return fail(c, DVO_ERR_INVALID, "pair/level out of range");
+    if (!edge || !depth_mm || rows < 1 || cols < 1) return fail(c, DVO_ERR_INVALID, "bad image arguments");
+    if (!c->have_K) return fail(c, DVO_ERR_STATE, "intrinsics not set (dvo_set_intrinsics)");
+    const size_t npx = (size_t)rows * cols;
+    /* staging: edge (int32) | depth (f32) | uv (2 floats per pixel worst case) */
+    int rc = ensure_staging(c, npx * (4 + 4 + 8));
+    if (rc) return rc;
+    int32_t *d_edge = (int32_t *)c->staging;
+    float *d_depth = c->staging + npx;
+    float *d_uv = c->staging + 2 * npx;
+    if ((size_t)cols + 2 > c->colcounts_cap) {
+        if (c->d_colcounts) HIPCHK(c, hipFree(c->d_colcounts));
+        HIPCHK(c, hipMalloc((void **)&c->d_colcounts, sizeof(int) * ((size_t)cols + 2)));
+        c->colcounts_cap = (size_t)cols + 2;
+    }
+    HIPCHK(c, hipMemcpyAsync(d_edge, edge, npx * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_depth, depth_mm, npx * 4, hipMemcpyHostToDevice, c->stream));
+    /* pass 1: count, so the slab can be grown before the write pass */
+    int *d_N = c->d_colcounts + cols + 1;
+    /* run count+scan+write with capacity 0 first?  Cheaper: count on the device, read N, grow, write. */
+    HIPCHK(c, launch_enlist_ref_points(d_edge, d_depth, rows, cols, level, c->K, c->d_colcounts,
+                                       nullptr, nullptr, 0, d_N, c->stream));
+    int N = 0;
+    HIPCHK(c, hipMemcpyAsync(&N, d_N, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (N_out) *N_out = N;
+    if (N < 1) return fail(c, DVO_ERR_INVALID, "no reference point selected (reference asserts nSelectedPts > 0, SolveDVO.cpp:282)");
+    if ((rc = ensure_points(c, level, N))) return rc;
+    Level &L = c->lv[level];
+    float *dst = L.pts + (size_t)pair * L.pt_cap * 3;
+    HIPCHK(c, launch_enlist_ref_points(d_edge, d_depth, rows, cols, level, c->K, c->d_colcounts,
+                                       dst, d_uv, N, d_N, c->stream));
+    L.hN[pair] = N;
+    HIPCHK(c, hipMemcpyAsync(L.dN + pair, &L.hN[pair], sizeof(int), hipMemcpyHostToDevice, c->stream));
+    const int ncopy = std::min(N, capacity);
+    if (xyz_out && ncopy > 0)
+        HIPCHK(c, hipMemcpyAsync(xyz_out, dst, sizeof(float) * 3 * (size_t)ncopy, hipMemcpyDeviceToHost, c->stream));
+    if (uv_out && ncopy > 0)
+        HIPCHK(c, hipMemcpyAsync(uv_out, d_uv, sizeof(float) * 2 * (size_t)ncopy, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DVO_OK;
+}
+
+/* ---- now side --------------------------------------------------------------- */
+static int set_now_common(dvo_ctx *c, int pair, int level, const float *dt, const float *gx,
+                          const float *gy, int rows, int cols, bool device_src) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair) || !level_ok(level)) return fail(c, DVO_ERR_INVALID, "pair/level out of range");
+    if (!dt || !gx || !gy || rows < 1 || cols < 1) return fail(c, DVO_ERR_INVALID, "bad image arguments");
+    int rc = ensure_texels(c, level, rows, cols);
+    if (rc) return rc;
+    Level &L = c->lv[level];
+    const size_t npx = (size_t)rows * cols;
+    const float *s_dt = dt, *s_gx = gx, *s_gy = gy;
+    if (!device_src) {
+        if ((rc = ensure_staging(c, npx * 3 * sizeof(float)))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->staging, dt, npx * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->staging + npx, gx, npx * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->staging + 2 * npx, gy, npx * 4, hipMemcpyHostToDevice, c->stream));
+        s_dt = c->staging; s_gx = c->staging + npx; s_gy = c->staging + 2 * npx;
+    }
+    HIPCHK(c, launch_pack_texels(s_dt, s_gx, s_gy, L.tex + (size_t)pair * L.tex_stride, npx, c->stream));
+    L.have_now[pair] = 1;
+    if (!device_src) HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DVO_OK;
+}
+int dvo_set_now_level_pair(dvo_ctx *c, int pair, int level, const float *dt, const float *gx,
+                           const float *gy, int rows, int cols) {
+    return set_now_common(c, pair, level, dt, gx, gy, rows, cols, false);
+}
+int dvo_set_now_level(dvo_ctx *c, int level, const float *dt, const float *gx, const float *gy,
+                      int rows, int cols) {
+    return set_now_common(c, 0, level, dt, gx, gy, rows, cols, false);
+}
+int dvo_set_now_level_device(dvo_ctx *c, int pair, int level, const float *d_dt, const float *d_gx,
+                             const float *d_gy, int rows, int cols) {
+    return set_now_common(c, pair, level, d_dt, d_gx, d_gy, rows, cols, true);
+}
+
+/* ---- hot path ---------------------------------------------------------------- */
+int dvo_set_poses(dvo_ctx *c, int first_pair, int n_pairs, const double *R, const double *t) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, first_pair) || n_pairs < 1 || first_pair + n_pairs > c->n_pairs || !R || !t)
+        return fail(c, DVO_ERR_INVALID, "bad pose arguments");
+    std::vector<double> h((size_t)12 * n_pairs);
+    for (int p = 0; p < n_pairs; p++) {
+        std::memcpy(&h[12 * p], R + 9 * p, sizeof(double) * 9);
+        std::memcpy(&h[12 * p + 9], t + 3 * p, sizeof(double) * 3);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_poses + (size_t)12 * first_pair, h.data(), sizeof(double) * h.size(),
+                             hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DVO_OK;
+}
+
+int dvo_get_poses(dvo_ctx *c, int first_pair, int n_pairs, double *R, double *t) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, first_pair) || n_pairs < 1 || first_pair + n_pairs > c->n_pairs || !R || !t)
+        return fail(c, DVO_ERR_INVALID, "bad pose arguments");
+    std::vector<double> h((size_t)12 * n_pairs);
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->d_poses + (size_t)12 * first_pair, sizeof(double) * h.size(),
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int p = 0; p < n_pairs; p++) {
+        std::memcpy(R + 9 * p, &h[12 * p], sizeof(double) * 9);
+        std::memcpy(t + 3 * p, &h[12 * p + 9], sizeof(double) * 3);
+    }
+    return DVO_OK;
+}
+
+int dvo_align_batch_enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *iters, int flags) {
+    if (!c) return DVO_ERR_INVALID;
+    return enqueue(c, first_pair, n_pairs, n_levels, iters, flags);
+}
+
+int dvo_align_batch(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *iters,
+                    int flags, double *R, double *t) {
+    if (!c) return DVO_ERR_INVALID;
+    int rc = dvo_set_poses(c, first_pair, n_pairs, R, t);
+    if (rc) return rc;
+    if ((rc = enqueue(c, first_pair, n_pairs, n_levels, iters, flags))) return rc;
+    return dvo_get_poses(c, first_pair, n_pairs, R, t);
+}
+
+int dvo_align_pyramid(dvo_ctx *c, int n_levels, const int *iters, int flags, double *R, double *t) {
+    return dvo_align_batch(c, 0, 1, n_levels, iters, flags, R, t);
+}
+
+int dvo_get_level_report(dvo_ctx *c, int pair, int level, float *energy, int n_energy,
+                         int *best_idx, float *visible_ratio) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair) || !level_ok(level)) return fail(c, DVO_ERR_INVALID, "pair/level out of range");
+    if (!c->have_sched || level >= c->sched.n_levels) return fail(c, DVO_ERR_STATE, "no alignment has been run for this level");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (energy) {
+        const int n = std::min(n_energy, c->sched.iters[level]);
+        if (n > 0)
+            HIPCHK(c, hipMemcpy(energy, c->d_energy + (size_t)pair * c->sched.e_stride + c->sched.e_off[level],
+                                sizeof(float) * n, hipMemcpyDeviceToHost));
+    }
+    if (best_idx) HIPCHK(c, hipMemcpy(best_idx, c->d_best + pair * DVO_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
+    if (visible_ratio) HIPCHK(c, hipMemcpy(visible_ratio, c->d_ratio + pair * DVO_LEVELS + level, sizeof(float), hipMemcpyDeviceToHost));
+    return DVO_OK;
+}
+
+int dvo_get_final_outputs(dvo_ctx *c, int pair, float *final_eps, float *final_reproj, int capacity, int *N_out) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair)) return fail(c, DVO_ERR_INVALID, "pair out of range");
+    if (!c->have_sched || !(c->sched.flags & DVO_FLAG_FINAL_OUTPUTS) || !c->d_final_eps)
+        return fail(c, DVO_ERR_STATE, "last alignment did not request DVO_FLAG_FINAL_OUTPUTS");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int N = 0;
+    HIPCHK(c, hipMemcpy(&N, c->d_final_N + pair, sizeof(int), hipMemcpyDeviceToHost));
+    if (N_out) *N_out = N;
+    const int n = std::min(N, capacity);
+    if (n > 0 && final_eps)
+        HIPCHK(c, hipMemcpy(final_eps, c->d_final_eps + (size_t)pair * c->final_cap, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (n > 0 && final_reproj)
+        HIPCHK(c, hipMemcpy(final_reproj, c->d_final_reproj + (size_t)pair * c->final_cap * 3, sizeof(float) * 3 * n, hipMemcpyDeviceToHost));
+    return DVO_OK;
+}
+
+int dvo_run_iterations_pair(dvo_ctx *c, int pair, int level, int max_iters, double *R, double *t,
+                            float *energy, float *final_eps, float *final_reproj,
+                            int *best_idx, float *visible_ratio) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair) || !level_ok(level)) return fail(c, DVO_ERR_INVALID, "pair/level out of range (reference: assert level>=0, SolveDVO.cpp:625)");
+    if (max_iters < 1) return fail(c, DVO_ERR_INVALID, "maxIterations must be > 0 (SolveDVO.cpp:626)");
+    if (!R || !t) return fail(c, DVO_ERR_INVALID, "R/t are NULL");
+    int iters[DVO_LEVELS] = {0};
+    iters[level] = max_iters;
+    const int flags = (final_eps || final_reproj) ? DVO_FLAG_FINAL_OUTPUTS : 0;
+    int rc = dvo_align_batch(c, pair, 1, level + 1, iters, flags, R, t);
+    if (rc) return rc;
+    if ((rc = dvo_get_level_report(c, pair, level, energy, max_iters, best_idx, visible_ratio))) return rc;
+    if (flags) {
+        const int N = c->lv[level].hN[pair];
+        if ((rc = dvo_get_final_outputs(c, pair, final_eps, final_reproj, N, nullptr))) return rc;
+    }
+    return DVO_OK;
+}
+
+int dvo_run_iterations(dvo_ctx *c, int level, int max_iters, double *R, double *t,
+                       float *energy, float *final_eps, float *final_reproj,
+                       int *best_idx, float *visible_ratio) {
+    return dvo_run_iterations_pair(c, 0, level, max_iters, R, t, energy, final_eps, final_reproj,
+                                   best_idx, visible_ratio);
+}
+
+/* ---- inspection ------------------------------------------------------------- */
+int dvo_eval_points(dvo_ctx *c, int pair, int level, const double *R, const double *t,
+                    float *reproj, float *J, float *eps, float *w, int *visible) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair) || !level_ok(level) || !R || !t) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    int rc = check_ready(c, pair, level);
+    if (rc) return rc;
+    const int N = c->lv[level].hN[pair];
+    /* staging: reproj 3N | J 6N | eps N | w N | vis N  (floats/ints, 4 bytes each) */
+    if ((rc = ensure_staging(c, sizeof(float) * 12 * (size_t)N))) return rc;
+    float *d_re = c->staging, *d_J = d_re + 3 * (size_t)N, *d_e = d_J + 6 * (size_t)N, *d_w = d_e + N;
+    int *d_v = (int *)(d_w + N);
+    float Rf[9], tf[3];
+    cast_pose(R, t, Rf, tf);
+    HIPCHK(c, launch_eval_points(slab_of(c, level), pair, level, c->K, Rf, tf, d_re, d_J, d_e, d_w, d_v, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (reproj) HIPCHK(c, hipMemcpy(reproj, d_re, sizeof(float) * 3 * (size_t)N, hipMemcpyDeviceToHost));
+    if (J) HIPCHK(c, hipMemcpy(J, d_J, sizeof(float) * 6 * (size_t)N, hipMemcpyDeviceToHost));
+    if (eps) HIPCHK(c, hipMemcpy(eps, d_e, sizeof(float) * (size_t)N, hipMemcpyDeviceToHost));
+    if (w) HIPCHK(c, hipMemcpy(w, d_w, sizeof(float) * (size_t)N, hipMemcpyDeviceToHost));
+    if (visible) HIPCHK(c, hipMemcpy(visible, d_v, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost));
+    return DVO_OK;
+}
+
+int dvo_accumulate(dvo_ctx *c, int pair, int level, const double *R, const double *t, double *acc29) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair) || !level_ok(level) || !R || !t || !acc29) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    int rc = check_ready(c, pair, level);
+    if (rc) return rc;
+    const int N = c->lv[level].hN[pair];
+    float Rf[9], tf[3];
+    cast_pose(R, t, Rf, tf);
+    const int nb = accumulate_blocks_for(N);
+    double *partials = c->d_scratch, *acc = c->d_scratch + 1024 * DVO_NACC_PAD;
+    HIPCHK(c, launch_accumulate(slab_of(c, level), pair, level, c->K, Rf, tf, 0, N, partials, nb, acc, c->stream));
+    double h[DVO_NACC_PAD];
+    HIPCHK(c, hipMemcpyAsync(h, acc, sizeof(double) * DVO_NACC_PAD, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(acc29, h, sizeof(double) * DVO_NUM_ACC);
+    return DVO_OK;
+}
+
+int dvo_device_se3_exp(dvo_ctx *c, const double *psi6, double *R, double *t) {
+    if (!c || !psi6 || !R || !t) return DVO_ERR_INVALID;
+    double *d = c->d_scratch;
+    HIPCHK(c, hipMemcpyAsync(d, psi6, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_se3_exp(d, d + 8, c->stream));
+    double h[12];
+    HIPCHK(c, hipMemcpyAsync(h, d + 8, sizeof(double) * 12, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(R, h, sizeof(double) * 9);
+    std::memcpy(t, h + 9, sizeof(double) * 3);
+    return DVO_OK;
+}
+int dvo_device_se3_log(dvo_ctx *c, const double *R, const double *t, double *psi6) {
+    if (!c || !psi6 || !R || !t) return DVO_ERR_INVALID;
+    double *d = c->d_scratch;
+    double h[12];
+    std::memcpy(h, R, sizeof(double) * 9);
+    std::memcpy(h + 9, t, sizeof(double) * 3);
+    HIPCHK(c, hipMemcpyAsync(d, h, sizeof(double) * 12, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_se3_log(d, d + 16, c->stream));
+    HIPCHK(c, hipMemcpyAsync(psi6, d + 16, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DVO_OK;
+}
+int dvo_device_rotationize(dvo_ctx *c, double *R) {
+    if (!c || !R) return DVO_ERR_INVALID;
+    double *d = c->d_scratch;
+    HIPCHK(c, hipMemcpyAsync(d, R, sizeof(double) * 9, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_rotationize(d, c->stream));
+    HIPCHK(c, hipMemcpyAsync(R, d, sizeof(double) * 9, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DVO_OK;
+}
+
+/* ---- measurement support ------------------------------------------------------ */
+int dvo_algorithmic_bytes(dvo_ctx *c, int pair, int n_levels, const int *iters, int flags, uint64_t *bytes) {
+    if (!c || !bytes) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair)) return fail(c, DVO_ERR_INVALID, "pair out of range");
+    Schedule sc;
+    int rc = build_schedule(c, n_levels, iters, flags, sc);
+    if (rc) return rc;
+    uint64_t b = 0;
+    for (int l = 0; l < n_levels; l++) {
+        if (sc.iters[l] <= 0) continue;
+        if ((rc = check_ready(c, pair, l))) return rc;
+        b += 12ull * (uint64_t)c->lv[l].rows * (uint64_t)c->lv[l].cols;   /* DT, gx, gy f32 */
+        b += 12ull * (uint64_t)c->lv[l].hN[pair];                         /* xyz f32 */
+    }
+    if (flags & DVO_FLAG_FINAL_OUTPUTS) b += 16ull * (uint64_t)c->lv[sc.last_level].hN[pair];
+    *bytes = b;
+    return DVO_OK;
+}
+
+int dvo_point_iterations(dvo_ctx *c, int pair, int n_levels, const int *iters, uint64_t *count) {
+    if (!c || !count) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair)) return fail(c, DVO_ERR_INVALID, "pair out of range");
+    Schedule sc;
+    int rc = build_schedule(c, n_levels, iters, 0, sc);
+    if (rc) return rc;
+    uint64_t n = 0;
+    for (int l = 0; l < n_levels; l++) {
+        if (sc.iters[l] <= 0) continue;
+        if ((rc = check_ready(c, pair, l))) return rc;
+        n += (uint64_t)sc.iters[l] * (uint64_t)c->lv[l].hN[pair];
+    }
+    *count = n;
+    return DVO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+/*
+ * dvo_launch.h -- internal interface between the C-ABI host code (dvo_capi.cpp)
+ * and the HIP kernels (dvo_kernels.hip).  Not installed; plain structs only.
+ */
+#ifndef DVO_LAUNCH_H_
+#define DVO_LAUNCH_H_
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "dvo_device_math.h"
+
+#define DVO_LEVELS 8          /* == DVO_MAX_LEVELS of include/dvo_amd.h */
+#define DVO_NACC 29           /* == DVO_NUM_ACC */
+#define DVO_NACC_PAD 32
+
+namespace dvo {
+
+/* One pyramid level of every pair of a context ("slab" layout in HBM):
+ *   tex : n_pairs x (rows*cols) texels {DT, gx, gy, 0}, pixel (yy,xx) of pair p at
+ *         tex[p*tex_stride + yy + xx*rows]                    (16 B / pixel)
+ *   pts : n_pairs x pt_cap x 3 floats, point i of pair p at pts[(p*pt_cap + i)*3]
+ *         (the reference's 3xN column-major SpaceCordList, 12 B / point)
+ *   N   : n_pairs ints                                                          */
+struct LevelSlab {
+    const float4 *tex;
+    const float *pts;
+    const int *N;
+    size_t tex_stride;      /* texels per pair */
+    int pt_cap;             /* points per pair (capacity) */
+    int rows, cols;
+};
+struct LevelSet { LevelSlab l[DVO_LEVELS]; };
+
+struct Schedule {
+    int n_levels;
+    int iters[DVO_LEVELS];
+    int e_off[DVO_LEVELS];   /* offset of level l inside a pair's energy block */
+    int e_stride;            /* floats per pair = sum iters */
+    int last_level;          /* smallest l with iters[l] > 0 (its outputs survive, SolveDVO.cpp:2102) */
+    int flags;
+};
+
+struct Intrinsics { float fx, fy, cx, cy; };
+
+struct Outputs {
+    double *poses;           /* n_pairs x 12 : R[9] col-major, t[3] */
+    float *energy;           /* n_pairs x e_stride */
+    int *best_idx;           /* n_pairs x DVO_LEVELS */
+    float *ratio;            /* n_pairs x DVO_LEVELS */
+    float *final_eps;        /* n_pairs x final_cap */
+    float *final_reproj;     /* n_pairs x 3*final_cap */
+    int *final_N;            /* n_pairs */
+    int final_cap;
+};
+
+hipError_t launch_pack_texels(const float *dt, const float *gx, const float *gy, float4 *out,
+                              size_t n, hipStream_t s);
+hipError_t launch_align_fused(int block_threads, const LevelSet &lv, const Schedule &sc,
+                              const Intrinsics &K, const DevParams &prm, const Outputs &out,
+                              int first_pair, int n_pairs, hipStream_t s);
+/* per-point dump at a float pose (inspection) */
+hipError_t launch_eval_points(const LevelSlab &L, int pair, int level, const Intrinsics &K,
+                              const float *Rf, const float *tf,
+                              float *reproj, float *J, float *eps, float *w, int *vis, hipStream_t s);
+/* 29 accumulators at a float pose: partials [nblocks x 32] then acc[32] */
+hipError_t launch_accumulate(const LevelSlab &L, int pair, int level, const Intrinsics &K,
+                             const float *Rf, const float *tf, int first_point, int n_points,
+                             double *partials, int nblocks, double *acc, hipStream_t s);
+int accumulate_blocks_for(int n_points);
+/* SE(3) helpers on one lane (property tests) */
+hipError_t launch_se3_exp(const double *psi, double *Rt12, hipStream_t s);
+hipError_t launch_se3_log(const double *Rt12, double *psi, hipStream_t s);
+hipError_t launch_rotationize(double *R9, hipStream_t s);
+/* selectedPts + enlistRefEdgePts on the device (SolveDVO.cpp:1230-1264, :224-264) */
+hipError_t launch_enlist_ref_points(const int32_t *edge, const float *depth_mm, int rows, int cols,
+                                    int level, const Intrinsics &K, int *col_counts /*cols+1*/,
+                                    float *xyz, float *uv, int capacity, int *N_out, hipStream_t s);
+
+}  // namespace dvo
+#endif

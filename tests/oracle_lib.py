@@ -1,0 +1,192 @@
+"""ctypes wrapper of the CPU oracle (oracle/build/libdvo_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "build", "libdvo_oracle.so")
+
+
+class OracleParams(C.Structure):
+    _fields_ = [
+        ("beta", C.c_double), ("precond_rot", C.c_double), ("reg_lambda", C.c_double),
+        ("step_a", C.c_double), ("step_b", C.c_double),
+        ("step_decay_after", C.c_int), ("step_decay_offset", C.c_int),
+        ("trust_radius", C.c_float), ("psi_norm_stop", C.c_float),
+        ("enable_rotationize", C.c_int), ("enable_l2_reg", C.c_int), ("interpolate_dt", C.c_int),
+    ]
+
+
+class IterTrace(C.Structure):
+    _fields_ = [
+        ("g", C.c_double * 6), ("H", C.c_double * 21), ("sum_eps2", C.c_double),
+        ("psi", C.c_double * 6), ("R", C.c_double * 9), ("t", C.c_double * 3),
+        ("energy", C.c_float), ("n_visible", C.c_int), ("broke", C.c_int),
+    ]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+_lib = None
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+
+    def default_params(self) -> OracleParams:
+        p = OracleParams()
+        self.lib.dvo_oracle_params_default(C.byref(p))
+        return p
+
+    def weight(self, r: float) -> float:
+        return self.lib.dvo_oracle_weight(C.c_float(r))
+
+    def enlist_ref_points(self, level, edge, depth_mm, rows, cols, K):
+        edge = np.ascontiguousarray(edge, dtype=np.int32)
+        depth = _f32(depth_mm)
+        cap = rows * cols
+        xyz = np.zeros(3 * cap, np.float32)
+        uv = np.zeros(2 * cap, np.float32)
+        n = self.lib.dvo_oracle_enlist_ref_points(level, _p(edge), _p(depth), rows, cols,
+                                                  *[C.c_float(k) for k in K], _p(xyz), _p(uv), cap)
+        assert n >= 0
+        return xyz[:3 * n].reshape(-1, 3).copy(), uv[:2 * n].reshape(-1, 2).copy()
+
+    def eval_points(self, level, xyz, dt, gx, gy, rows, cols, K, R, t, params=None):
+        """R (3x3 math layout, double) and t are cast to float exactly like SolveDVO.cpp:673-674."""
+        xyz = _f32(xyz).reshape(-1)
+        n = xyz.size // 3
+        Rf = np.asfortranarray(np.asarray(R, dtype=np.float64)).astype(np.float32, order="F")
+        tf = np.asarray(t, dtype=np.float64).astype(np.float32)
+        rep, J = np.zeros(3 * n, np.float32), np.zeros(6 * n, np.float32)
+        eps, w, vis = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+        self.lib.dvo_oracle_eval_points(C.byref(params) if params is not None else None, level, _p(xyz), n,
+                                        _p(_f32(dt)), _p(_f32(gx)), _p(_f32(gy)), rows, cols,
+                                        *[C.c_float(k) for k in K], _p(Rf), _p(tf),
+                                        _p(rep), _p(J), _p(eps), _p(w), _p(vis))
+        return dict(reproj=rep.reshape(-1, 3), J=J.reshape(-1, 6), eps=eps, w=w, visible=vis)
+
+    def run_iterations(self, level, max_iters, xyz, dt, gx, gy, rows, cols, K, R, t, params=None, trace=False):
+        xyz = _f32(xyz).reshape(-1)
+        n = xyz.size // 3
+        R = np.array(R, dtype=np.float64, order="F").copy(order="F")
+        t = np.array(t, dtype=np.float64).copy()
+        energy = np.zeros(max_iters, np.float32)
+        feps, frep = np.zeros(n, np.float32), np.zeros(3 * n, np.float32)
+        best, ratio = C.c_int(-2), C.c_float(0)
+        tr = (IterTrace * max_iters)() if trace else None
+        nit = self.lib.dvo_oracle_run_iterations(
+            C.byref(params) if params is not None else None, level, max_iters, _p(xyz), n,
+            _p(_f32(dt)), _p(_f32(gx)), _p(_f32(gy)), rows, cols, *[C.c_float(k) for k in K],
+            _p(R), _p(t), _p(energy), _p(feps), _p(frep), C.byref(best), C.byref(ratio), tr)
+        out = dict(R=R, t=t, energy=energy, final_eps=feps, final_reproj=frep.reshape(-1, 3),
+                   best_idx=best.value, visible_ratio=ratio.value, iters_run=nit)
+        if trace:
+            out["trace"] = [dict(g=np.array(x.g), H=np.array(x.H), sum_eps2=x.sum_eps2, psi=np.array(x.psi),
+                                 R=np.array(x.R).reshape(3, 3, order="F"), t=np.array(x.t), energy=x.energy,
+                                 n_visible=x.n_visible, broke=x.broke) for x in tr[:nit]]
+        return out
+
+    def align_pyramid(self, iters, levels, K, R, t, params=None):
+        """levels: list of dict(xyz, dt, gx, gy, rows, cols).  Coarse-to-fine schedule of SolveDVO::loop."""
+        R = np.array(R, dtype=np.float64, order="F").copy(order="F")
+        t = np.array(t, dtype=np.float64).copy()
+        reports = {}
+        last = None
+        for l in range(len(iters) - 1, -1, -1):
+            if iters[l] <= 0:
+                continue
+            L = levels[l]
+            r = self.run_iterations(l, iters[l], L["xyz"], L["dt"], L["gx"], L["gy"], L["rows"], L["cols"], K, R, t,
+                                    params=params)
+            R, t = r["R"], r["t"]
+            reports[l] = r
+            last = l
+        return dict(R=R, t=t, levels=reports, last_level=last)
+
+    def se3_exp(self, psi):
+        psi = np.array(psi, dtype=np.float64)
+        R, t = np.zeros((3, 3), order="F"), np.zeros(3)
+        self.lib.dvo_oracle_se3_exp(_p(psi), _p(R), _p(t))
+        return R, t
+
+    def se3_log(self, R, t):
+        R = np.array(R, dtype=np.float64, order="F")
+        t = np.array(t, dtype=np.float64)
+        psi = np.zeros(6)
+        self.lib.dvo_oracle_se3_log(_p(R), _p(t), _p(psi))
+        return psi
+
+    def rotationize(self, R):
+        R = np.array(R, dtype=np.float64, order="F").copy(order="F")
+        self.lib.dvo_oracle_rotationize(_p(R))
+        return R
+
+    def svd3(self, A):
+        A = np.array(A, dtype=np.float64, order="F")
+        U, V, S = np.zeros((3, 3), order="F"), np.zeros((3, 3), order="F"), np.zeros(3)
+        self.lib.dvo_oracle_svd3(_p(A), _p(U), _p(S), _p(V))
+        return U, S, V
+
+    def interpolate(self, F, rows, cols, ry, rx):
+        return self.lib.dvo_oracle_interpolate(_p(_f32(F)), rows, cols, C.c_float(ry), C.c_float(rx))
+
+
+def load() -> Oracle:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(
+                os.path.join(ORACLE_DIR, "dvo_oracle.cpp")):
+            build()
+        lib = C.CDLL(ORACLE_SO)
+        lib.dvo_oracle_weight.restype = C.c_float
+        lib.dvo_oracle_weight.argtypes = [C.c_float]
+        lib.dvo_oracle_interpolate.restype = C.c_float
+        lib.dvo_oracle_interpolate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
+        lib.dvo_oracle_enlist_ref_points.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + \
+            [C.c_float] * 4 + [C.c_void_p, C.c_void_p, C.c_int]
+        lib.dvo_oracle_eval_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_void_p] * 7
+        lib.dvo_oracle_eval_points.restype = None
+        lib.dvo_oracle_run_iterations.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 4 + \
+            [C.c_void_p] * 5 + [C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_void_p]
+        for n in ("se3_exp", "se3_log"):
+            getattr(lib, "dvo_oracle_" + n).argtypes = [C.c_void_p] * 3
+        lib.dvo_oracle_rotationize.argtypes = [C.c_void_p]
+        lib.dvo_oracle_svd3.argtypes = [C.c_void_p] * 4
+        _lib = Oracle(lib)
+    return _lib
+
+
+def scene_levels(scene, oracle: Oracle):
+    """Per-level hot-path inputs of a SynthScene: ref points via the oracle's enlistRefEdgePts."""
+    out = []
+    for l, L in enumerate(scene.levels):
+        xyz, uv = oracle.enlist_ref_points(l, L.ref_edge, L.ref_depth, L.rows, L.cols, scene.intrinsics)
+        out.append(dict(xyz=xyz, uv=uv, dt=L.now_dt, gx=L.now_gx, gy=L.now_gy, rows=L.rows, cols=L.cols))
+    return out
+
+
+def rot_angle(Ra, Rb) -> float:
+    M = np.asarray(Ra).T @ np.asarray(Rb)
+    return float(np.arccos(np.clip((np.trace(M) - 1.0) / 2.0, -1.0, 1.0)))

@@ -1,0 +1,301 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Bars (BASELINE.json north_star): float32 per-point quantities bit-equal; energies and best
+index bit-equal; final pose within 1e-5 rad / 1e-4 m of the oracle (in practice ~1e-15: the only
+non-bit-identical ingredients are double-precision libm vs ocml sin/cos/atan and the order of
+the double-precision sums, both ~1e-16 relative, far below the float cast at SolveDVO.cpp:673-674).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib
+from oracle_lib import rot_angle
+
+pytestmark = pytest.mark.gpu
+
+ROT_TOL = 1e-5      # rad  (north_star)
+TRANS_TOL = 1e-4    # m    (north_star)
+
+
+def _ctx_for(scene, levels, n_pairs=1, **kw):
+    from rgbd_odometry_amd import DvoContext
+    ctx = DvoContext(n_pairs, **kw)
+    ctx.set_intrinsics(*scene.intrinsics)
+    for p in range(n_pairs):
+        for l, L in enumerate(levels):
+            ctx.set_ref_level(l, L["xyz"], pair=p)
+            ctx.set_now_level(l, L["dt"], L["gx"], L["gy"], L["rows"], L["cols"], pair=p)
+    return ctx
+
+
+def _same(a, b):
+    """value equality for float arrays, NaN == NaN, -0 == +0"""
+    a, b = np.asarray(a), np.asarray(b)
+    return np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.fixture(scope="module")
+def scene320(oracle):
+    from rgbd_odometry_amd import SynthScene
+    sc = SynthScene(320, 240, 4, 0)
+    return sc, oracle_lib.scene_levels(sc, oracle)
+
+
+@pytest.fixture(scope="module")
+def ctx320(scene320):
+    sc, lv = scene320
+    ctx = _ctx_for(sc, lv)
+    yield ctx
+    ctx.close()
+
+
+def _poses(scene, oracle):
+    """identity, the true pose, and a few perturbed poses (incl. points leaving the image)"""
+    rng = np.random.default_rng(42)
+    out = [(np.eye(3), np.zeros(3)), (scene.R_true, scene.t_true)]
+    for scale in (0.01, 0.05, 0.3):
+        psi = rng.standard_normal(6) * scale
+        out.append(oracle.se3_exp(psi))
+    return out
+
+
+def test_per_point_bit_equal(scene320, ctx320, oracle):
+    sc, lv = scene320
+    for R, t in _poses(sc, oracle):
+        for l, L in enumerate(lv):
+            ref = oracle.eval_points(l, L["xyz"], L["dt"], L["gx"], L["gy"], L["rows"], L["cols"], sc.intrinsics, R, t)
+            got = ctx320.eval_points(l, R, t)
+            assert np.array_equal(ref["visible"], got["visible"]), (l, "visible")
+            # reprojections of ALL points (visible or not) -- SolveDVO.cpp:345
+            assert _same(ref["reproj"], got["reproj"]), (l, "reproj")
+            for key in ("eps", "w", "J"):
+                assert _same(ref[key], got[key]), (l, key, np.abs(ref[key] - got[key]).max())
+            assert ref["visible"].sum() > 0
+
+
+def test_accumulators(scene320, ctx320, oracle):
+    sc, lv = scene320
+    for R, t in _poses(sc, oracle)[:4]:
+        for l, L in enumerate(lv):
+            r = oracle.run_iterations(l, 1, L["xyz"], L["dt"], L["gx"], L["gy"], L["rows"], L["cols"], sc.intrinsics,
+                                      R, t, trace=True)
+            tr = r["trace"][0]
+            acc = ctx320.accumulate(l, R, t)
+            assert int(acc[28]) == tr["n_visible"]
+            np.testing.assert_allclose(acc[27], tr["sum_eps2"], rtol=1e-13)
+            np.testing.assert_allclose(acc[21:27], tr["g"], rtol=1e-11, atol=1e-9 * np.abs(tr["g"]).max())
+            # H: per-lane float partial sums, double tree -> float-level agreement
+            np.testing.assert_allclose(acc[:21], tr["H"], rtol=2e-4, atol=2e-5 * np.abs(tr["H"]).max())
+
+
+def test_device_se3_matches_oracle(ctx320, oracle):
+    rng = np.random.default_rng(1)
+    for k in range(60):
+        scale = [1e-12, 3e-3, 0.3, 1.2][k % 4]
+        psi = rng.standard_normal(6) * scale
+        n = np.linalg.norm(psi[3:])
+        if n > 3.0:
+            psi[3:] *= 3.0 / n
+        Ro, to = oracle.se3_exp(psi)
+        Rg, tg = ctx320.se3_exp(psi)
+        np.testing.assert_allclose(Rg, Ro, atol=1e-14)
+        np.testing.assert_allclose(tg, to, atol=1e-14 * max(1.0, scale))
+        back = ctx320.se3_log(Rg, tg)
+        np.testing.assert_allclose(back, oracle.se3_log(Ro, to), atol=1e-11)
+        np.testing.assert_allclose(back, psi, atol=1e-10)
+        A = Ro + 1e-3 * rng.standard_normal((3, 3))
+        np.testing.assert_allclose(ctx320.rotationize(A), oracle.rotationize(A), atol=1e-13)
+
+
+@pytest.mark.parametrize("level,iters", [(3, 50), (2, 50), (0, 20)])
+def test_run_iterations_single_level(scene320, ctx320, oracle, level, iters):
+    sc, lv = scene320
+    L = lv[level]
+    ref = oracle.run_iterations(level, iters, L["xyz"], L["dt"], L["gx"], L["gy"], L["rows"], L["cols"],
+                                sc.intrinsics, np.eye(3), np.zeros(3))
+    got = ctx320.run_iterations(level, iters, np.eye(3), np.zeros(3))
+    assert np.array_equal(ref["energy"], got["energy"]), (ref["energy"], got["energy"])
+    assert ref["best_idx"] == got["best_idx"]
+    assert ref["visible_ratio"] == got["visible_ratio"]
+    assert rot_angle(ref["R"], got["R"]) <= ROT_TOL
+    assert np.linalg.norm(ref["t"] - got["t"]) <= TRANS_TOL
+    assert _same(ref["final_eps"], got["final_eps"])
+    assert _same(ref["final_reproj"], got["final_reproj"])
+    # tighter, informational: double-side agreement
+    assert np.abs(ref["R"] - got["R"]).max() < 1e-9
+    assert np.abs(ref["t"] - got["t"]).max() < 1e-9
+
+
+def _check_pyramid(sc, lv, ctx, oracle, iters, pair=0, R0=None, t0=None):
+    from rgbd_odometry_amd.capi import DVO_FLAG_FINAL_OUTPUTS
+    R0 = np.eye(3) if R0 is None else R0
+    t0 = np.zeros(3) if t0 is None else t0
+    ref = oracle.align_pyramid(iters, lv, sc.intrinsics, R0, t0)
+    R, t = ctx.align_batch(iters, R0[None], t0[None], first_pair=pair, n_pairs=1, flags=DVO_FLAG_FINAL_OUTPUTS)
+    for l, rep in ref["levels"].items():
+        e, b, ratio = ctx.level_report(pair, l, iters[l])
+        assert np.array_equal(e, rep["energy"]), (l, e, rep["energy"])
+        assert b == rep["best_idx"], l
+        assert ratio == rep["visible_ratio"], l
+    assert rot_angle(ref["R"], R[0]) <= ROT_TOL
+    assert np.linalg.norm(ref["t"] - t[0]) <= TRANS_TOL
+    last = ref["levels"][ref["last_level"]]
+    feps, frep = ctx.final_outputs(pair, len(last["final_eps"]))
+    assert _same(feps, last["final_eps"])
+    assert _same(frep, last["final_reproj"])
+    return ref, R[0], t[0]
+
+
+def test_align_pyramid_reference_default(scene320, ctx320, oracle):
+    """the reference's shipped configuration: 320x240, 4 levels, 50 iterations each (SolveDVO.cpp:30-33)"""
+    sc, lv = scene320
+    ref, R, t = _check_pyramid(sc, lv, ctx320, oracle, [50, 50, 50, 50])
+    # and it actually converges toward the true motion
+    assert rot_angle(sc.R_true, R) < rot_angle(sc.R_true, np.eye(3))
+
+
+def test_align_pyramid_skipped_levels(scene320, ctx320, oracle):
+    sc, lv = scene320
+    _check_pyramid(sc, lv, ctx320, oracle, [0, 7, 0, 13])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_align_pyramid_c2_640x480(oracle, seed):
+    """BASELINE config 2: 640x480, 4 levels, 10 iterations per level"""
+    from rgbd_odometry_amd import SynthScene
+    sc = SynthScene(640, 480, 4, seed)
+    lv = oracle_lib.scene_levels(sc, oracle)
+    ctx = _ctx_for(sc, lv)
+    try:
+        _check_pyramid(sc, lv, ctx, oracle, [10, 10, 10, 10])
+    finally:
+        ctx.close()
+
+
+def test_warm_start_from_previous_pose(scene320, ctx320, oracle):
+    """pose is carried from frame to frame (SolveDVO.cpp:2102): start from a non-identity pose"""
+    sc, lv = scene320
+    R0, t0 = oracle.se3_exp(np.array([0.01, -0.005, 0.008, 0.004, -0.01, 0.006]))
+    _check_pyramid(sc, lv, ctx320, oracle, [5, 5, 5, 5], R0=np.array(R0), t0=t0)
+
+
+@pytest.mark.parametrize("block", [256, 1024])
+def test_block_size_variants(scene320, oracle, block):
+    sc, lv = scene320
+    ctx = _ctx_for(sc, lv, block_threads=block)
+    try:
+        _check_pyramid(sc, lv, ctx, oracle, [10, 10, 10, 10])
+    finally:
+        ctx.close()
+
+
+def test_batch_of_independent_pairs(oracle):
+    """BASELINE config 4 in miniature: distinct pairs in one launch, each equal to its own oracle run"""
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    n = 6
+    scenes = [SynthScene(320, 240, 4, 1000 + i) for i in range(n)]
+    lvs = [oracle_lib.scene_levels(s, oracle) for s in scenes]
+    ctx = DvoContext(n)
+    try:
+        ctx.set_intrinsics(*scenes[0].intrinsics)
+        for p in range(n):
+            for l, L in enumerate(lvs[p]):
+                ctx.set_ref_level(l, L["xyz"], pair=p)
+                ctx.set_now_level(l, L["dt"], L["gx"], L["gy"], L["rows"], L["cols"], pair=p)
+        iters = [10, 10, 10, 10]
+        R, t = ctx.align_batch(iters, np.tile(np.eye(3), (n, 1, 1)), np.zeros((n, 3)))
+        for p in range(n):
+            ref = oracle.align_pyramid(iters, lvs[p], scenes[p].intrinsics, np.eye(3), np.zeros(3))
+            assert rot_angle(ref["R"], R[p]) <= ROT_TOL
+            assert np.linalg.norm(ref["t"] - t[p]) <= TRANS_TOL
+            for l, rep in ref["levels"].items():
+                e, b, ratio = ctx.level_report(p, l, iters[l])
+                assert np.array_equal(e, rep["energy"]) and b == rep["best_idx"] and ratio == rep["visible_ratio"]
+        # run-to-run determinism: same launch again gives the same bits
+        R2, t2 = ctx.align_batch(iters, np.tile(np.eye(3), (n, 1, 1)), np.zeros((n, 3)))
+        assert np.array_equal(R, R2) and np.array_equal(t, t2)
+    finally:
+        ctx.close()
+
+
+def test_enlist_ref_points_on_gpu(scene320, oracle):
+    """selectedPts + enlistRefEdgePts (SolveDVO.cpp:1230-1264, :224-264): same points, same order"""
+    from rgbd_odometry_amd import DvoContext
+    sc, lv = scene320
+    ctx = DvoContext(1)
+    try:
+        ctx.set_intrinsics(*sc.intrinsics)
+        for l, L in enumerate(sc.levels):
+            depth = L.ref_depth.copy()
+            depth[::7] = 50.0          # some pixels fail the depth > 100 test
+            xyz_o, uv_o = oracle.enlist_ref_points(l, L.ref_edge, depth, L.rows, L.cols, sc.intrinsics)
+            xyz_g, uv_g = ctx.set_ref_level_from_images(l, L.ref_edge, depth, L.rows, L.cols)
+            assert xyz_g.shape == xyz_o.shape
+            assert np.array_equal(xyz_g, xyz_o) and np.array_equal(uv_g, uv_o)
+    finally:
+        ctx.close()
+
+
+def test_edge_cases(oracle):
+    """single point, all points invisible, point behind the camera, early termination"""
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    sc = SynthScene(320, 240, 4, 3)
+    lv = oracle_lib.scene_levels(sc, oracle)
+    L = lv[2]
+    K = sc.intrinsics
+    cases = {
+        "single": L["xyz"][:1],
+        "ragged_65": L["xyz"][:65],
+        "behind_camera": np.concatenate([L["xyz"][:40], L["xyz"][:40] * np.array([1, 1, -1], np.float32)]),
+        "all_invisible": (L["xyz"][:50] + np.array([100.0, 0, 0], np.float32)),
+        "z_zero": np.concatenate([L["xyz"][:10], np.array([[0.1, 0.1, 0.0]], np.float32)]),
+    }
+    ctx = DvoContext(1)
+    try:
+        ctx.set_intrinsics(*K)
+        ctx.set_now_level(2, L["dt"], L["gx"], L["gy"], L["rows"], L["cols"])
+        for name, xyz in cases.items():
+            ctx.set_ref_level(2, xyz)
+            ref = oracle.run_iterations(2, 12, xyz, L["dt"], L["gx"], L["gy"], L["rows"], L["cols"], K,
+                                        np.eye(3), np.zeros(3))
+            got = ctx.run_iterations(2, 12, np.eye(3), np.zeros(3))
+            assert np.array_equal(ref["energy"], got["energy"]), name
+            assert ref["best_idx"] == got["best_idx"], name
+            assert _same(ref["final_eps"], got["final_eps"]), name
+            assert _same(ref["final_reproj"], got["final_reproj"]), name
+            assert rot_angle(ref["R"], got["R"]) <= ROT_TOL and np.linalg.norm(ref["t"] - got["t"]) <= TRANS_TOL, name
+        # early termination: zero gradient + zero regulariser -> |psi| < 1e-7 at itr 0 (SolveDVO.cpp:872)
+        ctx2 = DvoContext(1, enable_l2_reg=0)
+        try:
+            ctx2.set_intrinsics(*K)
+            flat = np.zeros_like(L["dt"])
+            ctx2.set_now_level(2, flat, flat, flat, L["rows"], L["cols"])
+            ctx2.set_ref_level(2, L["xyz"])
+            p = oracle.default_params()
+            p.enable_l2_reg = 0
+            ref = oracle.run_iterations(2, 9, L["xyz"], flat, flat, flat, L["rows"], L["cols"], K, np.eye(3),
+                                        np.zeros(3), params=p)
+            got = ctx2.run_iterations(2, 9, np.eye(3), np.zeros(3))
+            assert ref["iters_run"] == 1
+            assert np.array_equal(ref["energy"], got["energy"]) and got["best_idx"] == ref["best_idx"] == 0
+        finally:
+            ctx2.close()
+    finally:
+        ctx.close()
+
+
+def test_errors_are_loud():
+    from rgbd_odometry_amd import DvoContext, DvoError
+    ctx = DvoContext(2)
+    try:
+        with pytest.raises(DvoError):
+            ctx.align_batch([5], np.eye(3)[None], np.zeros((1, 3)), first_pair=0, n_pairs=1)   # nothing set
+        ctx.set_intrinsics(500, 500, 160, 120)
+        with pytest.raises(DvoError):
+            ctx.set_ref_level(0, np.zeros((0, 3), np.float32))
+        with pytest.raises(DvoError):
+            ctx.set_ref_level(9, np.zeros((4, 3), np.float32))
+        with pytest.raises(DvoError):
+            ctx.set_ref_level(0, np.zeros((4, 3), np.float32), pair=2)
+    finally:
+        ctx.close()
