@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Benchmark of the edge-alignment hot path (SolveDVO::runIterations + level schedule) on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic frame pairs: ONE launch of the
+fused alignment kernel over `--batch` pairs per GPU (inputs already resident in HBM), followed by
+the delivery of the poses to the host.  Default workload = BASELINE.json configs[1]:
+640x480, 4-level pyramid, 10 iterations per level.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: independent frame pairs are sharded across ranks (no data-path collective; weak
+scaling: the per-GPU batch is fixed).  torch.distributed (RCCL) is used only for the barrier and the
+MAX over ranks of the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch  # imported before the HIP library on purpose: one HIP runtime per process (capi.py)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak ~6290
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="frame pairs per GPU per step")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--iters", type=int, default=10, help="iterations per level")
+    ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic scenes (cycled over the batch)")
+    ap.add_argument("--block", type=int, default=0, help="workgroup size of the fused kernel (0 = default)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-oracle baseline budget (0 = skip)")
+    ap.add_argument("--no-final-outputs", action="store_true")
+    return ap.parse_args()
+
+
+def build_batch(ctx, args, rank):
+    """Generate `distinct` scenes, extract their reference points on the GPU (enlistRefEdgePts) and
+    make every pair slot of the context resident in HBM."""
+    from rgbd_odometry_amd import SynthScene
+    D = max(1, min(args.distinct, args.batch))
+    scenes = [SynthScene(args.width, args.height, args.levels, 1000 + rank * D + i) for i in range(D)]
+    ctx.set_intrinsics(*scenes[0].intrinsics)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    planes = []     # per distinct scene, per level: device tensors dt, gx, gy, xyz
+    for i, sc in enumerate(scenes):
+        per_level = []
+        for l, L in enumerate(sc.levels):
+            xyz, _ = ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols, pair=i)
+            per_level.append(dict(
+                dt=torch.from_numpy(L.now_dt).to(dev), gx=torch.from_numpy(L.now_gx).to(dev),
+                gy=torch.from_numpy(L.now_gy).to(dev), xyz=torch.from_numpy(xyz.reshape(-1)).to(dev),
+                n=xyz.shape[0], rows=L.rows, cols=L.cols))
+        planes.append(per_level)
+    torch.cuda.synchronize()
+    for p in range(args.batch):
+        for l, T in enumerate(planes[p % D]):
+            ctx.set_ref_level_device(l, T["xyz"].data_ptr(), T["n"], pair=p)
+            ctx.set_now_level_device(l, T["dt"].data_ptr(), T["gx"].data_ptr(), T["gy"].data_ptr(),
+                                     T["rows"], T["cols"], pair=p)
+    ctx.synchronize()
+    return scenes
+
+
+def cpu_baseline(args, scenes, iters, budget_s):
+    """The CPU oracle (the reference path restated, single thread like the reference:
+    EIGEN_DONT_PARALLELIZE, SolveDVO.h:14) timed on this host over the same span the reference
+    times (SolveDVO.cpp:2092-2109): all levels of one alignment, preprocessing excluded."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    oracle = oracle_lib.load()
+    lvs = [oracle_lib.scene_levels(sc, oracle) for sc in scenes[:8]]
+    n, t0 = 0, time.perf_counter()
+    while True:
+        lv = lvs[n % len(lvs)]
+        oracle.align_pyramid(iters, lv, scenes[n % len(lvs)].intrinsics, np.eye(3), np.zeros(3))
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 2000:
+            break
+    return dict(value=n / el, unit="aligns/s", cores=1, kind="port",
+                sample=f"{n} alignments of the same workload ({len(lvs)} distinct scenes) in {el:.1f} s, "
+                       f"1 thread of {os.cpu_count()} host cores, oracle/ built -O2 -ffp-contract=off"), oracle, lvs
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from rgbd_odometry_amd import DvoContext
+    from rgbd_odometry_amd.capi import DVO_FLAG_FINAL_OUTPUTS, DVO_FLAG_IDENTITY_START
+
+    iters = [args.iters] * args.levels
+    flags = DVO_FLAG_IDENTITY_START | (0 if args.no_final_outputs else DVO_FLAG_FINAL_OUTPUTS)
+    ctx = DvoContext(args.batch, block_threads=args.block)
+    scenes = build_batch(ctx, args, rank)
+    stream = torch.cuda.Stream()
+    ctx.set_stream(stream.cuda_stream)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record(stream)
+        ctx.enqueue(iters, flags=flags)                 # one launch: the whole batch, all levels
+        if ev is not None:
+            ev[1].record(stream)
+        return ctx.get_poses()                          # deliver poses to the host (synchronises)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        R, t = step(events[k])
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    bytes_per_launch = sum(ctx.algorithmic_bytes(iters, pair=p, flags=flags & DVO_FLAG_FINAL_OUTPUTS)
+                           for p in range(args.batch))
+    point_iters = sum(ctx.point_iterations(iters, pair=p) for p in range(args.batch))
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+
+    total_aligns = args.batch * args.steps * world
+    value = total_aligns / elapsed
+
+    if rank == 0:
+        out = {
+            "metric": "frame-pair aligns/sec (%dx%d, %d-lvl pyr)" % (args.width, args.height, args.levels),
+            "value": value, "unit": "aligns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "%dx%d edge-alignment, %d-level pyramid, %d iters/level, batch of %d independent "
+                            "frame pairs per GPU (%d distinct synthetic scenes), identity start, "
+                            "sub-gradient policy of SolveDVO::runIterations" %
+                            (args.width, args.height, args.levels, args.iters, args.batch, len(scenes)),
+                "pairs_per_gpu": args.batch, "iters_per_level": iters,
+                "final_outputs": not args.no_final_outputs,
+                "block_threads": args.block or 512,
+                "point_iterations_per_launch": point_iters,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "kernel": "align_fused_kernel", "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "algorithmic_bytes_per_alignment": bytes_per_launch / args.batch,
+            },
+        }
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                key = "%dx%dx%dx%d_b%d" % (args.width, args.height, args.levels, args.iters, args.batch)
+                if key in rec:
+                    out["roofline"]["traffic"] = rec[key]["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = rec[key].get("source")
+            except Exception:
+                pass
+        if world == 1 and args.cpu_seconds > 0:
+            base, oracle, lvs = cpu_baseline(args, scenes, iters, args.cpu_seconds)
+            out["cpu_baseline"] = base
+            # parity spot check in the same run: pair 0 against the oracle on the same inputs
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib
+            ref = oracle.align_pyramid(iters, lvs[0], scenes[0].intrinsics, np.eye(3), np.zeros(3))
+            out["parity_check"] = {
+                "rot_err_rad": oracle_lib.rot_angle(ref["R"], R[0]),
+                "trans_err_m": float(np.linalg.norm(ref["t"] - t[0])),
+                "tolerance": "1e-5 rad / 1e-4 m",
+            }
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,7 +54,9 @@ enum {
 
 /* flags for the align entry points */
 enum {
-    DVO_FLAG_FINAL_OUTPUTS = 1    /* also produce finalEpsilons / finalReprojections (SolveDVO.cpp:1002-1003) */
+    DVO_FLAG_FINAL_OUTPUTS = 1,   /* also produce finalEpsilons / finalReprojections (SolveDVO.cpp:1002-1003) */
+    DVO_FLAG_IDENTITY_START = 2   /* start from cR=I, cT=0 instead of the stored pose: what the reference does
+                                     on a keyframe switch (SolveDVO.cpp:2210-2211); enqueue form only */
 };
 
 /* Every literal of SolveDVO::runIterations as a runtime parameter; defaults are
@@ -87,8 +89,11 @@ int  dvo_create_batch(const dvo_params *p, int n_pairs, dvo_ctx **out);
 int  dvo_destroy(dvo_ctx *ctx);
 const char *dvo_last_error(const dvo_ctx *ctx);      /* ctx may be NULL: last creation error */
 int  dvo_num_pairs(const dvo_ctx *ctx);
-/* Use an existing HIP stream (hipStream_t as void*); NULL = the context's own stream. */
+/* Launch on an existing HIP stream (hipStream_t as void*; NULL = the HIP null stream, which is
+ * what torch.cuda.current_stream().cuda_stream reports for torch's default stream).
+ * dvo_use_own_stream() switches back to the context's private non-blocking stream. */
 int  dvo_set_stream(dvo_ctx *ctx, void *hip_stream);
+int  dvo_use_own_stream(dvo_ctx *ctx);
 int  dvo_synchronize(dvo_ctx *ctx);
 
 /* ---- inputs ----------------------------------------------------------------

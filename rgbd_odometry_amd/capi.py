@@ -15,13 +15,14 @@ DVO_MAX_LEVELS = 8
 DVO_NUM_ACC = 29
 DVO_OK, DVO_ERR_INVALID, DVO_ERR_NO_DEVICE, DVO_ERR_HIP, DVO_ERR_STATE, DVO_ERR_NOMEM = range(6)
 DVO_FLAG_FINAL_OUTPUTS = 1
+DVO_FLAG_IDENTITY_START = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 #: every symbol include/dvo_amd.h declares (checked by tests/test_capi_symbols.py)
 C_ABI_SYMBOLS = [
     "dvo_params_default", "dvo_create", "dvo_create_batch", "dvo_destroy", "dvo_last_error",
-    "dvo_num_pairs", "dvo_set_stream", "dvo_synchronize", "dvo_set_intrinsics",
+    "dvo_num_pairs", "dvo_set_stream", "dvo_use_own_stream", "dvo_synchronize", "dvo_set_intrinsics",
     "dvo_set_ref_level", "dvo_set_ref_level_pair", "dvo_set_now_level", "dvo_set_now_level_pair",
     "dvo_set_ref_level_device", "dvo_set_now_level_device", "dvo_set_ref_level_from_images",
     "dvo_run_iterations", "dvo_run_iterations_pair", "dvo_align_pyramid", "dvo_align_batch",
@@ -61,6 +62,12 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch's wheel bundles its own libamdhip64 (SONAME
+    # libamdhip64.so.7, same as /opt/rocm's).  Importing torch FIRST makes the dynamic loader bind
+    # libdvo_amd.so to that already-loaded copy, so torch streams / device pointers / RCCL and this
+    # library share one runtime.  Loading in the other order would put two runtimes in the process.
+    if os.environ.get("DVO_NO_TORCH", "0") != "1":
+        import torch  # noqa: F401
     path = library_path()
     if not os.path.exists(path):
         raise FileNotFoundError(
@@ -76,6 +83,7 @@ def load_library() -> C.CDLL:
         "dvo_destroy": [vp],
         "dvo_num_pairs": [vp],
         "dvo_set_stream": [vp, vp],
+        "dvo_use_own_stream": [vp],
         "dvo_synchronize": [vp],
         "dvo_set_intrinsics": [vp, f, f, f, f],
         "dvo_set_ref_level": [vp, i, vp, i],
@@ -169,6 +177,9 @@ class DvoContext:
 
     def set_stream(self, hip_stream: int):
         self._chk(self.lib.dvo_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def use_own_stream(self):
+        self._chk(self.lib.dvo_use_own_stream(self._h))
 
     def synchronize(self):
         self._chk(self.lib.dvo_synchronize(self._h))

@@ -325,7 +325,13 @@ int dvo_num_pairs(const dvo_ctx *c) { return c ? c->n_pairs : 0; }
 int dvo_set_stream(dvo_ctx *c, void *hip_stream) {
     if (!c) return DVO_ERR_INVALID;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->stream = (hipStream_t)hip_stream;
+    return DVO_OK;
+}
+int dvo_use_own_stream(dvo_ctx *c) {
+    if (!c) return DVO_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = c->own_stream;
     return DVO_OK;
 }
 int dvo_synchronize(dvo_ctx *c) {
@@ -492,7 +498,7 @@ int dvo_align_batch(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const
     if (!c) return DVO_ERR_INVALID;
     int rc = dvo_set_poses(c, first_pair, n_pairs, R, t);
     if (rc) return rc;
-    if ((rc = enqueue(c, first_pair, n_pairs, n_levels, iters, flags))) return rc;
+    if ((rc = enqueue(c, first_pair, n_pairs, n_levels, iters, flags & ~DVO_FLAG_IDENTITY_START))) return rc;
     return dvo_get_poses(c, first_pair, n_pairs, R, t);
 }
 

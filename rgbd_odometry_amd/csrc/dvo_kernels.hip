@@ -150,10 +150,11 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
 
     if (tid == 0) {
         const double *p = out.poses + (size_t)pair * 12;
+        const bool ident = (sc.flags & 2) != 0;                  /* DVO_FLAG_IDENTITY_START (:2210-2211) */
 #pragma unroll
-        for (int k = 0; k < 9; k++) st.R[k] = p[k];
+        for (int k = 0; k < 9; k++) st.R[k] = ident ? ((k % 4 == 0) ? 1.0 : 0.0) : p[k];
 #pragma unroll
-        for (int k = 0; k < 3; k++) st.t[k] = p[9 + k];
+        for (int k = 0; k < 3; k++) st.t[k] = ident ? 0.0 : p[9 + k];
     }
     __syncthreads();
 
