@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--block", type=int, default=0, help="workgroup size of the fused kernel (0 = default)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-oracle baseline budget (0 = skip)")
     ap.add_argument("--no-final-outputs", action="store_true")
+    ap.add_argument("--inflight", type=int, default=0, help="points in flight per lane (1/2/4; 0 = default)")
+    ap.add_argument("--lds-point-bytes", type=int, default=0, help="LDS bytes per workgroup for resident points (0 auto, <0 none)")
+    ap.add_argument("--debug-alias", type=int, default=0, help="diagnostics: pair p reads data of pair p %% N")
     return ap.parse_args()
 
 
@@ -113,7 +116,8 @@ def main():
 
     iters = [args.iters] * args.levels
     flags = DVO_FLAG_IDENTITY_START | (0 if args.no_final_outputs else DVO_FLAG_FINAL_OUTPUTS)
-    ctx = DvoContext(args.batch, block_threads=args.block)
+    ctx = DvoContext(args.batch, block_threads=args.block, debug_alias_mod=args.debug_alias,
+                     points_in_flight=args.inflight, lds_point_bytes=args.lds_point_bytes)
     scenes = build_batch(ctx, args, rank)
     stream = torch.cuda.Stream()
     ctx.set_stream(stream.cuda_stream)
@@ -168,7 +172,8 @@ def main():
                             (args.width, args.height, args.levels, args.iters, args.batch, len(scenes)),
                 "pairs_per_gpu": args.batch, "iters_per_level": iters,
                 "final_outputs": not args.no_final_outputs,
-                "block_threads": args.block or 512,
+                "block_threads": args.block or 512, "points_in_flight": args.inflight or 1,
+                **({"debug_alias_mod": args.debug_alias} if args.debug_alias else {}),
                 "point_iterations_per_launch": point_iters,
             },
             "roofline": {

@@ -74,8 +74,14 @@ typedef struct dvo_params {
     int    enable_rotationize; /* __ENABLE_ROTATIONIZE__       SolveDVO.h:107 */
     int    enable_l2_reg;      /* __ENABLE_L2_REGULARIZATION   SolveDVO.h:112 */
     int    interpolate_dt;     /* __INTERPOLATE_DISTANCE_TRANSFORM (off) SolveDVO.h:97; only 0 supported */
-    int    block_threads;      /* engine tuning: threads per workgroup of the fused kernel (256/512/1024; 0 = default) */
-    int    reserved[7];
+    int    block_threads;      /* engine tuning: threads per workgroup of the fused kernel (256/512/1024; 0 = default 512) */
+    int    points_in_flight;   /* engine tuning: reference points per lane and pipeline stage (1/2/4; 0 = default 1) */
+    int    reserved0;
+    int    lds_point_bytes;    /* engine tuning: LDS bytes per workgroup for the level's resident point list
+                                  (0 = auto from block_threads, < 0 = none) */
+    int    debug_alias_mod;    /* diagnostics only: if > 0, pair p reads the inputs of pair p % debug_alias_mod
+                                  (shrinks the HBM working set without changing the arithmetic); 0 = off */
+    int    reserved[3];
 } dvo_params;
 
 typedef struct dvo_ctx dvo_ctx;
@@ -178,6 +184,11 @@ int  dvo_accumulate(dvo_ctx *ctx, int pair, int level, const double *R, const do
 int  dvo_device_se3_exp(dvo_ctx *ctx, const double *psi6, double *R, double *t);
 int  dvo_device_se3_log(dvo_ctx *ctx, const double *R, const double *t, double *psi6);
 int  dvo_device_rotationize(dvo_ctx *ctx, double *R);
+
+/* Diagnostic builds only (make STAMPS=1): per-level phase cycle counters of `pair`,
+ * out64[level*8 + {0: per-point loop, 1: reduction, 2: pose update, 3: barrier, 4: iterations}];
+ * all zeros in the product library. */
+int  dvo_debug_stamps(dvo_ctx *ctx, int pair, unsigned long long *out64);
 
 /* ---- measurement support ------------------------------------------------------
  * Algorithmic (compulsory) bytes of one alignment of `pair` under the given

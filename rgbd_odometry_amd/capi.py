@@ -29,6 +29,7 @@ C_ABI_SYMBOLS = [
     "dvo_set_poses", "dvo_align_batch_enqueue", "dvo_get_poses", "dvo_get_level_report",
     "dvo_get_final_outputs", "dvo_eval_points", "dvo_accumulate", "dvo_device_se3_exp",
     "dvo_device_se3_log", "dvo_device_rotationize", "dvo_algorithmic_bytes", "dvo_point_iterations",
+    "dvo_debug_stamps",
 ]
 
 
@@ -40,7 +41,8 @@ class DvoParams(C.Structure):
         ("step_decay_after", C.c_int), ("step_decay_offset", C.c_int),
         ("trust_radius", C.c_float), ("psi_norm_stop", C.c_float),
         ("enable_rotationize", C.c_int), ("enable_l2_reg", C.c_int), ("interpolate_dt", C.c_int),
-        ("block_threads", C.c_int), ("reserved", C.c_int * 7),
+        ("block_threads", C.c_int), ("points_in_flight", C.c_int), ("reserved0", C.c_int),
+        ("lds_point_bytes", C.c_int), ("debug_alias_mod", C.c_int), ("reserved", C.c_int * 3),
     ]
 
 
@@ -51,7 +53,8 @@ class DvoError(RuntimeError):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "lib", "libdvo_amd.so")
+    # DVO_LIB_VARIANT (e.g. "_w4") selects an experiment build made by `make -C csrc variants`
+    return os.path.join(_HERE, "lib", "libdvo_amd%s.so" % os.environ.get("DVO_LIB_VARIANT", ""))
 
 
 _lib = None
@@ -107,6 +110,7 @@ def load_library() -> C.CDLL:
         "dvo_device_se3_exp": [vp, vp, vp, vp],
         "dvo_device_se3_log": [vp, vp, vp, vp],
         "dvo_device_rotationize": [vp, vp],
+        "dvo_debug_stamps": [vp, i, vp],
         "dvo_algorithmic_bytes": [vp, i, i, ip, i, C.POINTER(C.c_uint64)],
         "dvo_point_iterations": [vp, i, i, ip, C.POINTER(C.c_uint64)],
     }
@@ -319,6 +323,11 @@ class DvoContext:
         R = np.array(R, dtype=np.float64, order="F").copy(order="F")
         self._chk(self.lib.dvo_device_rotationize(self._h, _ptr(R)))
         return R
+
+    def debug_stamps(self, pair: int = 0) -> np.ndarray:
+        out = np.zeros(64, np.uint64)
+        self._chk(self.lib.dvo_debug_stamps(self._h, pair, _ptr(out)))
+        return out.reshape(8, 8)
 
     # -- measurement ----------------------------------------------------------
     def algorithmic_bytes(self, iters: Sequence[int], pair: int = 0, flags: int = 0) -> int:

@@ -57,6 +57,7 @@ struct dvo_ctx {
     int *d_final_N = nullptr;
     int final_cap = 0;
     double *d_scratch = nullptr;    /* partials (1024 x 32) + acc (32) + misc doubles */
+    unsigned long long *d_dbg = nullptr;
     int *d_colcounts = nullptr;
     size_t colcounts_cap = 0;
     Schedule sched{};
@@ -125,8 +126,10 @@ int ensure_texels(dvo_ctx *c, int level, int rows, int cols) {
         std::fill(L.have_now.begin(), L.have_now.end(), 0);
     }
     L.rows = rows; L.cols = cols;
-    L.tex_stride = (size_t)rows * cols;
+    L.tex_stride = texel_count(rows, cols);
     HIPCHK(c, hipMalloc((void **)&L.tex, sizeof(float4) * L.tex_stride * c->n_pairs));
+    if (L.tex_stride != (size_t)rows * cols)      /* tile padding is never read, but keep it defined */
+        HIPCHK(c, hipMemsetAsync(L.tex, 0, sizeof(float4) * L.tex_stride * c->n_pairs, c->stream));
     return DVO_OK;
 }
 
@@ -196,6 +199,7 @@ Outputs outputs_of(const dvo_ctx *c) {
     o.poses = c->d_poses; o.energy = c->d_energy; o.best_idx = c->d_best; o.ratio = c->d_ratio;
     o.final_eps = c->d_final_eps; o.final_reproj = c->d_final_reproj; o.final_N = c->d_final_N;
     o.final_cap = c->final_cap;
+    o.dbg = c->d_dbg;
     return o;
 }
 
@@ -216,11 +220,24 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
             if ((rc = check_ready(c, p, l))) return rc;
     }
     if ((rc = ensure_outputs(c, sc))) return rc;
+    sc.alias_mod = c->prm.debug_alias_mod > 0 ? c->prm.debug_alias_mod : 0;
     LevelSet ls;
     for (int l = 0; l < DVO_LEVELS; l++) ls.l[l] = slab_of(c, l);
     int block = c->prm.block_threads;
     if (block != 256 && block != 512 && block != 1024) block = 512;
-    HIPCHK(c, launch_align_fused(block, ls, sc, c->K, c->dprm, outputs_of(c), first_pair, n_pairs, c->stream));
+    /* LDS budget of the level's resident point list */
+    {
+        int bytes = c->prm.lds_point_bytes;
+        /* auto: one workgroup per CU for >= 512 threads (it owns the CU's LDS), two for 256 */
+        if (bytes == 0) bytes = (block >= 512) ? 155000 : 77000;
+        if (bytes > 156 * 1024) bytes = 156 * 1024;
+        sc.lds_points = bytes / 12;
+        if (c->prm.lds_point_bytes < 0) sc.lds_points = 0;
+    }
+    int u = c->prm.points_in_flight;
+    if (u != 1 && u != 2 && u != 4) u = 1;
+    HIPCHK(c, launch_align_fused(block, u, ls, sc, c->K, c->dprm, outputs_of(c),
+                                 first_pair, n_pairs, c->stream));
     c->sched = sc;
     c->have_sched = true;
     return DVO_OK;
@@ -288,6 +305,10 @@ int dvo_create_batch(const dvo_params *p, int n_pairs, dvo_ctx **out) {
     CRCHK(hipMalloc((void **)&c->d_ratio, sizeof(float) * DVO_LEVELS * n_pairs));
     CRCHK(hipMalloc((void **)&c->d_final_N, sizeof(int) * n_pairs));
     CRCHK(hipMalloc((void **)&c->d_scratch, sizeof(double) * (1024 * DVO_NACC_PAD + 64)));
+#ifdef DVO_STAMPS
+    CRCHK(hipMalloc((void **)&c->d_dbg, sizeof(unsigned long long) * 64 * n_pairs));
+    CRCHK(hipMemset(c->d_dbg, 0, sizeof(unsigned long long) * 64 * n_pairs));
+#endif
     CRCHK(hipMemset(c->d_best, 0xff, sizeof(int) * DVO_LEVELS * n_pairs));
     CRCHK(hipMemset(c->d_ratio, 0, sizeof(float) * DVO_LEVELS * n_pairs));
     CRCHK(hipMemset(c->d_final_N, 0, sizeof(int) * n_pairs));
@@ -312,7 +333,7 @@ int dvo_destroy(dvo_ctx *c) {
         if (c->lv[l].dN) (void)hipFree(c->lv[l].dN);
     }
     void *ptrs[] = {c->staging, c->d_poses, c->d_energy, c->d_best, c->d_ratio, c->d_final_eps,
-                    c->d_final_reproj, c->d_final_N, c->d_scratch, c->d_colcounts};
+                    c->d_final_reproj, c->d_final_N, c->d_scratch, c->d_colcounts, c->d_dbg};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -439,7 +460,7 @@ static int set_now_common(dvo_ctx *c, int pair, int level, const float *dt, cons
         HIPCHK(c, hipMemcpyAsync(c->staging + 2 * npx, gy, npx * 4, hipMemcpyHostToDevice, c->stream));
         s_dt = c->staging; s_gx = c->staging + npx; s_gy = c->staging + 2 * npx;
     }
-    HIPCHK(c, launch_pack_texels(s_dt, s_gx, s_gy, L.tex + (size_t)pair * L.tex_stride, npx, c->stream));
+    HIPCHK(c, launch_pack_texels(s_dt, s_gx, s_gy, L.tex + (size_t)pair * L.tex_stride, rows, cols, c->stream));
     L.have_now[pair] = 1;
     if (!device_src) HIPCHK(c, hipStreamSynchronize(c->stream));
     return DVO_OK;
@@ -640,6 +661,17 @@ int dvo_device_rotationize(dvo_ctx *c, double *R) {
     HIPCHK(c, launch_rotationize(d, c->stream));
     HIPCHK(c, hipMemcpyAsync(R, d, sizeof(double) * 9, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DVO_OK;
+}
+
+/* diagnostics: phase cycle counters of a DVO_STAMPS build (zeros otherwise); resets them */
+int dvo_debug_stamps(dvo_ctx *c, int pair, unsigned long long *out64) {
+    if (!c || !out64 || !pair_ok(c, pair)) return DVO_ERR_INVALID;
+    std::memset(out64, 0, sizeof(unsigned long long) * 64);
+    if (!c->d_dbg) return DVO_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out64, c->d_dbg + (size_t)pair * 64, sizeof(unsigned long long) * 64, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemset(c->d_dbg + (size_t)pair * 64, 0, sizeof(unsigned long long) * 64));
     return DVO_OK;
 }
 

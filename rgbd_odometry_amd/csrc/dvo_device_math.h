@@ -20,9 +20,6 @@
 #include <hip/hip_runtime.h>
 
 #define DVO_DEV __device__ __forceinline__
-/* the double-precision update runs on one lane per workgroup; keeping it out of
- * line keeps its register appetite away from the per-point loop */
-#define DVO_DEV_NOINLINE __device__ __noinline__
 
 namespace dvo {
 
@@ -43,6 +40,7 @@ struct IterConst {
     float m00, m02, m11, m12;   /* s*fx, s*cx, s*fy, s*cy  (float products) */
     float ncols_f, nrows_f;
     int rows;
+    int tiles_per_col;          /* texel tiles along yy (see texel_index) */
 };
 
 struct PointEval {
@@ -99,8 +97,31 @@ DVO_DEV void jacobian_row(const IterConst &c, float xn, float yn, float zn,
     J[5] = ga0 * w1 - ga1 * w0;
 }
 
-/* texel = {DT, dDT/dx, dDT/dy, 0} of the now level; index of pixel (yy,xx) */
-DVO_DEV int texel_index(int yy, int xx, int rows) { return yy + xx * rows; }
+/* texel = {DT, dDT/dx, dDT/dy, getWeightOf(DT)} of the now level (16 B): the weight (:1047-1053) is a
+ * pure function of the pixel's DT value, so it is evaluated once per pixel when the level is
+ * packed (same double-precision formula, weight_of above) instead of once per point per iteration.  Texels are stored in
+ * tiles of DVO_TILE_Y x DVO_TILE_X pixels (yy fastest inside a tile, tiles in
+ * column-major order), so that one 64/128-byte memory request covers a 2-D
+ * patch: reprojected contour points that are neighbours in either direction
+ * then share requests.  1x1 = the reference's plain column-major layout. */
+#ifndef DVO_TILE_Y_LOG2
+#define DVO_TILE_Y_LOG2 2
+#endif
+#ifndef DVO_TILE_X_LOG2
+#define DVO_TILE_X_LOG2 1
+#endif
+#define DVO_TILE_Y (1 << DVO_TILE_Y_LOG2)
+#define DVO_TILE_X (1 << DVO_TILE_X_LOG2)
+__host__ __device__ inline int texel_tiles_per_col(int rows) { return (rows + DVO_TILE_Y - 1) >> DVO_TILE_Y_LOG2; }
+__host__ __device__ inline size_t texel_count(int rows, int cols) {
+    return (size_t)texel_tiles_per_col(rows) * (size_t)((cols + DVO_TILE_X - 1) >> DVO_TILE_X_LOG2) *
+           (size_t)(DVO_TILE_Y * DVO_TILE_X);
+}
+__host__ __device__ inline int texel_index(int yy, int xx, int tiles_per_col) {
+    const int tile = (xx >> DVO_TILE_X_LOG2) * tiles_per_col + (yy >> DVO_TILE_Y_LOG2);
+    return (tile << (DVO_TILE_Y_LOG2 + DVO_TILE_X_LOG2)) + ((xx & (DVO_TILE_X - 1)) << DVO_TILE_Y_LOG2) +
+           (yy & (DVO_TILE_Y - 1));
+}
 
 DVO_DEV PointEval eval_point(const IterConst &c, const float4 *__restrict__ tex,
                              float X, float Y, float Z) {
@@ -112,43 +133,158 @@ DVO_DEV PointEval eval_point(const IterConst &c, const float4 *__restrict__ tex,
     for (int k = 0; k < 6; k++) o.J[k] = 0.0f;
     if (o.vis) {
         const int xx = (int)o.u, yy = (int)o.v;         /* :376-377 == floor for u,v >= 0 (:446) */
-        const float4 tx = tex[texel_index(yy, xx, c.rows)];
+        const float4 tx = tex[texel_index(yy, xx, c.tiles_per_col)];
         jacobian_row(c, xn, yn, o.zn, tx.y, tx.z, o.J);
         o.eps = tx.x;
-        o.w = weight_of(tx.x);
+        o.w = tx.w;             /* getWeightOf(eps), evaluated once per pixel when the texel is packed */
     }
     return o;
 }
 
 /* ------------------------------------------------------------------------- */
-/*  double-precision 3x3 / SE(3) helpers (single lane)                        */
+/*  double-precision helpers of the 6-DoF update (one lane per workgroup)      */
+/*                                                                             */
+/*  This lane is the serial section of every iteration, so its instruction     */
+/*  count is the latency floor of the whole alignment.  Everything here is     */
+/*  inlined, keeps its operands in registers and avoids the generic IEEE       */
+/*  division / ocml transcendental sequences: reciprocal and square root are   */
+/*  hardware seeds + Newton/Goldschmidt steps (<= ~1 ulp), sin/cos/atan are    */
+/*  short series after an exact-enough argument reduction (~1e-16 relative).   */
+/*  Parity with the CPU oracle does not need bit-equality here: the pose is    */
+/*  narrowed to float before it touches the per-point math (:673-674), and     */
+/*  1e-16-level differences change that cast with probability ~1e-9.           */
 /* ------------------------------------------------------------------------- */
+DVO_DEV double d_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+DVO_DEV double d_div(double a, double b) {
+    const double r = d_rcp(b);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+DVO_DEV double d_sqrt(double x) {            /* x >= 0, normal range */
+    if (x == 0.0) return 0.0;
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    return fma(fma(-g, g, x), h, g);
+}
+/* sin and cos of |x| <= ~2*pi : quadrant reduction with a two-part pi/2, then
+ * Taylor series on [-pi/4, pi/4] (terms below 1e-19). */
+DVO_DEV void d_sincos(double x, double &s, double &c) {
+    const double k = rint(x * 0.63661977236758134308);          /* 2/pi */
+    double r = fma(-k, 1.57079632679489655800e+00, x);          /* pi/2 hi */
+    r = fma(-k, 6.12323399573676603587e-17, r);                 /* pi/2 lo */
+    const double z = r * r;
+    double ps = 1.0 / 355687428096000.0;                        /* 1/17! */
+    ps = fma(ps, z, -1.0 / 1307674368000.0);                    /* 1/15! */
+    ps = fma(ps, z, 1.0 / 6227020800.0);                        /* 1/13! */
+    ps = fma(ps, z, -1.0 / 39916800.0);                         /* 1/11! */
+    ps = fma(ps, z, 1.0 / 362880.0);                            /* 1/9!  */
+    ps = fma(ps, z, -1.0 / 5040.0);                             /* 1/7!  */
+    ps = fma(ps, z, 1.0 / 120.0);                               /* 1/5!  */
+    ps = fma(ps, z, -1.0 / 6.0);                                /* 1/3!  */
+    const double sr = fma(ps * z, r, r);
+    double pc = -1.0 / 6402373705728000.0;                      /* 1/18! */
+    pc = fma(pc, z, 1.0 / 20922789888000.0);                    /* 1/16! */
+    pc = fma(pc, z, -1.0 / 87178291200.0);                      /* 1/14! */
+    pc = fma(pc, z, 1.0 / 479001600.0);                         /* 1/12! */
+    pc = fma(pc, z, -1.0 / 3628800.0);                          /* 1/10! */
+    pc = fma(pc, z, 1.0 / 40320.0);                             /* 1/8!  */
+    pc = fma(pc, z, -1.0 / 720.0);                              /* 1/6!  */
+    pc = fma(pc, z, 1.0 / 24.0);                                /* 1/4!  */
+    pc = fma(pc, z, -0.5);
+    const double cr = fma(pc, z, 1.0);
+    const int q = ((int)k) & 3;
+    const double s0 = (q & 1) ? cr : sr;
+    const double c0 = (q & 1) ? sr : cr;
+    s = (q & 2) ? -s0 : s0;
+    c = ((q == 1) || (q == 2)) ? -c0 : c0;
+}
+/* atan(x) for any finite x: |x|>1 -> pi/2 - atan(1/|x|); two half-angle steps
+ * atan(y) = 2 atan(y / (1 + sqrt(1+y^2))) bring |y| <= tan(pi/16); 12-term series. */
+DVO_DEV double d_atan_series(double y, int nterms_from) {
+    (void)nterms_from;
+    const double z = y * y;
+    double p = 1.0 / 29.0;
+    p = fma(p, z, -1.0 / 27.0);
+    p = fma(p, z, 1.0 / 25.0);
+    p = fma(p, z, -1.0 / 23.0);
+    p = fma(p, z, 1.0 / 21.0);
+    p = fma(p, z, -1.0 / 19.0);
+    p = fma(p, z, 1.0 / 17.0);
+    p = fma(p, z, -1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, -1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, -1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, -1.0 / 3.0);
+    return fma(p * z, y, y);
+}
+DVO_DEV double d_atan(double x) {
+    if (fabs(x) <= 0.25) return d_atan_series(x, 0);     /* |x|^31/31 < 1e-20: plain series (the usual case) */
+    const double ax = fabs(x);
+    const bool inv = ax > 1.0;
+    double y = inv ? d_rcp(ax) : ax;
+    y = d_div(y, 1.0 + d_sqrt(fma(y, y, 1.0)));
+    y = d_div(y, 1.0 + d_sqrt(fma(y, y, 1.0)));
+    const double z = y * y;
+    double p = -1.0 / 23.0;
+    p = fma(p, z, 1.0 / 21.0);
+    p = fma(p, z, -1.0 / 19.0);
+    p = fma(p, z, 1.0 / 17.0);
+    p = fma(p, z, -1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, -1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, -1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, -1.0 / 3.0);
+    double a = 4.0 * fma(p * z, y, y);
+    if (inv) a = 1.57079632679489655800e+00 - a + 6.12323399573676603587e-17;
+    return (x < 0.0) ? -a : a;
+}
+
 DVO_DEV void m3_mul(const double *A, const double *B, double *C) {
     double tmp[9];
 #pragma unroll
     for (int j = 0; j < 3; j++)
 #pragma unroll
         for (int i = 0; i < 3; i++)
-            tmp[i + 3 * j] = (A[i] * B[3 * j] + A[i + 3] * B[1 + 3 * j]) + A[i + 6] * B[2 + 3 * j];
+            tmp[i + 3 * j] = fma(A[i + 6], B[2 + 3 * j], fma(A[i + 3], B[1 + 3 * j], A[i] * B[3 * j]));
 #pragma unroll
     for (int k = 0; k < 9; k++) C[k] = tmp[k];
 }
 DVO_DEV void m3_vec(const double *A, const double *x, double *y) {
-    const double y0 = (A[0] * x[0] + A[3] * x[1]) + A[6] * x[2];
-    const double y1 = (A[1] * x[0] + A[4] * x[1]) + A[7] * x[2];
-    const double y2 = (A[2] * x[0] + A[5] * x[1]) + A[8] * x[2];
+    const double y0 = fma(A[6], x[2], fma(A[3], x[1], A[0] * x[0]));
+    const double y1 = fma(A[7], x[2], fma(A[4], x[1], A[1] * x[0]));
+    const double y2 = fma(A[8], x[2], fma(A[5], x[1], A[2] * x[0]));
     y[0] = y0; y[1] = y1; y[2] = y2;
 }
-DVO_DEV void hat3(const double *w, double *W) {          /* to_se_3 / SO3::hat */
-    W[0] = 0.0;   W[3] = -w[2]; W[6] = w[1];
-    W[1] = w[2];  W[4] = 0.0;   W[7] = -w[0];
-    W[2] = -w[1]; W[5] = w[0];  W[8] = 0.0;
+/* y = (I + a*hat(w) + b*hat(w)^2) x   without forming the matrices:
+ * hat(w) x = w cross x ;  hat(w)^2 x = w (w.x) - (w.w) x */
+DVO_DEV void apply_I_aW_bW2(const double *w, double a, double b, const double *x, double *y) {
+    const double c0 = w[1] * x[2] - w[2] * x[1];
+    const double c1 = w[2] * x[0] - w[0] * x[2];
+    const double c2 = w[0] * x[1] - w[1] * x[0];
+    const double wx = fma(w[2], x[2], fma(w[1], x[1], w[0] * x[0]));
+    const double ww = fma(w[2], w[2], fma(w[1], w[1], w[0] * w[0]));
+    y[0] = fma(b, fma(w[0], wx, -ww * x[0]), fma(a, c0, x[0]));
+    y[1] = fma(b, fma(w[1], wx, -ww * x[1]), fma(a, c1, x[1]));
+    y[2] = fma(b, fma(w[2], wx, -ww * x[2]), fma(a, c2, x[2]));
 }
 DVO_DEV double norm6(const double *v) {
-    double s = 0.0;
+    double s = v[0] * v[0];
 #pragma unroll
-    for (int k = 0; k < 6; k++) s += v[k] * v[k];
-    return sqrt(s);
+    for (int k = 1; k < 6; k++) s = fma(v[k], v[k], s);
+    return d_sqrt(s);
 }
 
 #define DVO_SOPHUS_EPS 1e-10
@@ -158,82 +294,44 @@ DVO_DEV double norm6(const double *v) {
 DVO_DEV void quat_of_matrix(const double *m, double *q) {
     double t = m[0] + m[4] + m[8];
     if (t > 0.0) {
-        t = sqrt(t + 1.0);
+        t = d_sqrt(t + 1.0);
         q[0] = 0.5 * t;
-        t = 0.5 / t;
+        t = 0.5 * d_rcp(t);
         q[1] = (m[5] - m[7]) * t;      /* m(2,1)-m(1,2) */
         q[2] = (m[6] - m[2]) * t;      /* m(0,2)-m(2,0) */
         q[3] = (m[1] - m[3]) * t;      /* m(1,0)-m(0,1) */
     } else {
-        int i = 0;
-        if (m[4] > m[0]) i = 1;
-        if (m[8] > m[i * 4]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(m[i * 4] - m[j * 4] - m[k * 4] + 1.0);
-        double qi = 0.5 * t;
-        t = 0.5 / t;
-        const double qw = (m[k + 3 * j] - m[j + 3 * k]) * t;
-        const double qj = (m[j + 3 * i] + m[i + 3 * j]) * t;
-        const double qk = (m[k + 3 * i] + m[i + 3 * k]) * t;
-        q[0] = qw;
-        q[1] = (i == 0) ? qi : ((j == 0) ? qj : qk);
-        q[2] = (i == 1) ? qi : ((j == 1) ? qj : qk);
-        q[3] = (i == 2) ? qi : ((j == 2) ? qj : qk);
+        /* largest diagonal element first (Eigen's branch for trace <= 0) */
+        const bool i1 = m[4] > m[0];
+        const bool i2 = m[8] > (i1 ? m[4] : m[0]);
+        if (i2) {            /* i=2, j=0, k=1 */
+            t = d_sqrt(m[8] - m[0] - m[4] + 1.0);
+            q[3] = 0.5 * t; t = 0.5 * d_rcp(t);
+            q[0] = (m[1] - m[3]) * t;              /* m(k,j)-m(j,k) = m(1,0)-m(0,1) */
+            q[1] = (m[2] + m[6]) * t;              /* m(j,i)+m(i,j) = m(0,2)+m(2,0) */
+            q[2] = (m[5] + m[7]) * t;              /* m(k,i)+m(i,k) = m(1,2)+m(2,1) */
+        } else if (i1) {     /* i=1, j=2, k=0 */
+            t = d_sqrt(m[4] - m[8] - m[0] + 1.0);
+            q[2] = 0.5 * t; t = 0.5 * d_rcp(t);
+            q[0] = (m[6] - m[2]) * t;              /* m(0,2)-m(2,0) */
+            q[3] = (m[5] + m[7]) * t;              /* m(2,1)+m(1,2) */
+            q[1] = (m[1] + m[3]) * t;              /* m(0,1)+m(1,0) */
+        } else {             /* i=0, j=1, k=2 */
+            t = d_sqrt(m[0] - m[4] - m[8] + 1.0);
+            q[1] = 0.5 * t; t = 0.5 * d_rcp(t);
+            q[0] = (m[5] - m[7]) * t;              /* m(2,1)-m(1,2) */
+            q[2] = (m[1] + m[3]) * t;              /* m(1,0)+m(0,1) */
+            q[3] = (m[2] + m[6]) * t;              /* m(2,0)+m(0,2) */
+        }
     }
-    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+    const double n2 = fma(q[3], q[3], fma(q[2], q[2], fma(q[1], q[1], q[0] * q[0])));
+    const double rn = d_rcp(d_sqrt(n2));
+    q[0] *= rn; q[1] *= rn; q[2] *= rn; q[3] *= rn;
 }
 
-/* SE(3) logarithm, tangent order [upsilon(3), omega(3)] like Sophus::SE3d::log. */
-DVO_DEV_NOINLINE void se3_log(const double *R, const double *t, double *psi) {
-    double q[4];
-    quat_of_matrix(R, q);
-    const double squared_n = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
-    const double n = sqrt(squared_n);
-    const double w = q[0];
-    double k2;                               /* 2*atan(n/w)/n */
-    if (n < DVO_SOPHUS_EPS) {
-        k2 = 2.0 / w - 2.0 * squared_n / (w * (w * w));
-    } else if (fabs(w) < DVO_SOPHUS_EPS) {
-        k2 = (w > 0.0) ? (M_PI / n) : (-M_PI / n);
-    } else {
-        k2 = 2.0 * atan(n / w) / n;
-    }
-    const double theta = k2 * n;
-    double om[3] = {k2 * q[1], k2 * q[2], k2 * q[3]};
-    double W[9], W2[9];
-    hat3(om, W);
-    m3_mul(W, W, W2);
-    double c;
-    if (fabs(theta) < DVO_SOPHUS_EPS) c = 1. / 12.;
-    else c = (1.0 - theta / (2.0 * tan(theta / 2.0))) / (theta * theta);
-    double Vi[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) Vi[k] = (((k % 4 == 0) ? 1.0 : 0.0) - 0.5 * W[k]) + c * W2[k];
-    m3_vec(Vi, t, psi);
-    psi[3] = om[0]; psi[4] = om[1]; psi[5] = om[2];
-}
-
-/* SE(3) exponential, Sophus::SE3d::exp: quaternion from the half angle, then
- * V = I + (1-cos)/th^2 W + (th-sin)/th^3 W^2. */
-DVO_DEV_NOINLINE void se3_exp(const double *psi, double *R, double *t) {
-    const double *om = psi + 3;
-    const double theta_sq = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
-    const double theta = sqrt(theta_sq);
-    const double half_theta = 0.5 * theta;
-    double imag, real;
-    if (theta < DVO_SOPHUS_EPS) {
-        const double theta_po4 = theta_sq * theta_sq;
-        imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
-        real = 1.0 - 0.5 * theta_sq + (1.0 / 384.0) * theta_po4;
-    } else {
-        imag = sin(half_theta) / theta;
-        real = cos(half_theta);
-    }
-    double qw = real, qx = imag * om[0], qy = imag * om[1], qz = imag * om[2];
-    const double qn = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
-    qw /= qn; qx /= qn; qy /= qn; qz /= qn;
-    /* Eigen::Quaternion::toRotationMatrix */
+/* Eigen::Quaternion::toRotationMatrix (what Sophus' rotationMatrix() returns, :906) */
+DVO_DEV void quat_to_matrix(const double *q, double *R) {
+    const double qw = q[0], qx = q[1], qy = q[2], qz = q[3];
     const double tx = 2.0 * qx, ty = 2.0 * qy, tz = 2.0 * qz;
     const double twx = tx * qw, twy = ty * qw, twz = tz * qw;
     const double txx = tx * qx, txy = ty * qx, txz = tz * qx;
@@ -241,30 +339,99 @@ DVO_DEV_NOINLINE void se3_exp(const double *psi, double *R, double *t) {
     R[0] = 1.0 - (tyy + tzz); R[3] = txy - twz;         R[6] = txz + twy;
     R[1] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[7] = tyz - twx;
     R[2] = txz - twy;         R[5] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
-    double W[9], W2[9], V[9];
-    hat3(om, W);
-    m3_mul(W, W, W2);
-    if (theta < DVO_SOPHUS_EPS) {
-#pragma unroll
-        for (int k = 0; k < 9; k++) V[k] = R[k];
+}
+
+/* out = normalise(a (x) b): the rotation cR*xRot of :917 followed by the
+ * re-orthogonalisation of :919 -- for unit quaternions the orthogonal polar
+ * factor of the product matrix is the matrix of the normalised product. */
+DVO_DEV void quat_mul_normalize(const double *a, const double *b, double *o) {
+    const double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    const double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    const double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    const double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+    const double rn = d_rcp(d_sqrt(fma(z, z, fma(y, y, fma(x, x, w * w)))));
+    o[0] = w * rn; o[1] = x * rn; o[2] = y * rn; o[3] = z * rn;
+}
+
+/* SE(3) logarithm of (unit quaternion q, translation t); tangent order
+ * [upsilon(3), omega(3)] like Sophus::SE3d::log (atan form of SO3::logAndTheta).
+ * tan(theta/2) = |q.vec| / q.w for a unit quaternion, so no sin/cos is needed. */
+DVO_DEV void se3_log_q(const double *q, const double *t, double *psi) {
+    const double squared_n = fma(q[3], q[3], fma(q[2], q[2], q[1] * q[1]));
+    const double n = d_sqrt(squared_n);
+    const double w = q[0];
+    double k2;                               /* 2*atan(n/w)/n */
+    if (n < DVO_SOPHUS_EPS) {
+        const double rw = d_rcp(w);
+        k2 = 2.0 * rw - 2.0 * squared_n * (rw * rw * rw);
+    } else if (fabs(w) < DVO_SOPHUS_EPS) {
+        k2 = (w > 0.0) ? d_div(M_PI, n) : -d_div(M_PI, n);
     } else {
-        const double a = (1.0 - cos(theta)) / theta_sq;
-        const double b = (theta - sin(theta)) / (theta_sq * theta);
-#pragma unroll
-        for (int k = 0; k < 9; k++) V[k] = (((k % 4 == 0) ? 1.0 : 0.0) + a * W[k]) + b * W2[k];
+        k2 = 2.0 * d_atan(n * d_rcp(w)) * d_rcp(n);
     }
-    m3_vec(V, psi, t);
+    const double theta = k2 * n;
+    const double om[3] = {k2 * q[1], k2 * q[2], k2 * q[3]};
+    double c;                                /* (1 - theta/(2 tan(theta/2))) / theta^2 */
+    if (fabs(theta) < DVO_SOPHUS_EPS) c = 1. / 12.;
+    else c = (1.0 - 0.5 * theta * w * d_rcp(n)) * d_rcp(theta * theta);
+    apply_I_aW_bW2(om, -0.5, c, t, psi);     /* V^-1 t = (I - W/2 + c W^2) t */
+    psi[3] = om[0]; psi[4] = om[1]; psi[5] = om[2];
+}
+
+/* SE(3) exponential, Sophus::SE3d::exp: unit quaternion from the half angle and
+ * t = V upsilon with V = I + (1-cos)/th^2 W + (th-sin)/th^3 W^2. */
+DVO_DEV void se3_exp_q(const double *psi, double *q, double *t) {
+    const double *om = psi + 3;
+    const double theta_sq = fma(om[2], om[2], fma(om[1], om[1], om[0] * om[0]));
+    const double theta = d_sqrt(theta_sq);
+    double imag, real, a, b;
+    const bool small_angle = theta < DVO_SOPHUS_EPS;
+    if (small_angle) {
+        const double theta_po4 = theta_sq * theta_sq;
+        imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
+        real = 1.0 - 0.5 * theta_sq + (1.0 / 384.0) * theta_po4;
+        a = 0.0; b = 0.0;
+    } else {
+        double sh, ch;
+        d_sincos(0.5 * theta, sh, ch);
+        const double rth = d_rcp(theta);
+        imag = sh * rth;
+        real = ch;
+        const double rth2 = rth * rth;
+        a = (2.0 * sh * sh) * rth2;                       /* (1-cos th)/th^2 */
+        b = (theta - 2.0 * sh * ch) * (rth2 * rth);       /* (th-sin th)/th^3 */
+    }
+    double qw = real, qx = imag * om[0], qy = imag * om[1], qz = imag * om[2];
+    const double rn = d_rcp(d_sqrt(fma(qz, qz, fma(qy, qy, fma(qx, qx, qw * qw)))));
+    q[0] = qw * rn; q[1] = qx * rn; q[2] = qy * rn; q[3] = qz * rn;
+    if (small_angle) {                                    /* Sophus: V = so3.matrix() */
+        double R[9];
+        quat_to_matrix(q, R);
+        m3_vec(R, psi, t);
+    } else {
+        apply_I_aW_bW2(om, a, b, psi, t);
+    }
+}
+
+/* matrix forms (C ABI helpers and tests) */
+DVO_DEV void se3_log(const double *R, const double *t, double *psi) {
+    double q[4];
+    quat_of_matrix(R, q);
+    se3_log_q(q, t, psi);
+}
+DVO_DEV void se3_exp(const double *psi, double *R, double *t) {
+    double q[4];
+    se3_exp_q(psi, q, t);
+    quat_to_matrix(q, R);
 }
 
 /* rotationize (:1269-1282): R <- U V^T of R = U S V^T, i.e. the orthogonal polar
  * factor.  The reference gets it from a Jacobi SVD; the polar factor is unique
- * for a non-singular matrix, so a scaled Newton iteration X <- (g X + X^-T / g)/2
- * converges to the same matrix (quadratically; 1-2 steps for the nearly
- * orthogonal products that reach this function). */
-DVO_DEV_NOINLINE void rotationize(double *R) {
-    double X[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) X[k] = R[k];
+ * for a non-singular matrix, so the Newton iteration X <- (g X + X^-T / g)/2
+ * converges to the same matrix.  Only used for caller-supplied matrices: inside
+ * the iteration loop the rotation is carried as a unit quaternion, whose
+ * normalisation is the same projection (see quat_mul_normalize). */
+DVO_DEV void rotationize(double *X) {
     for (int it = 0; it < 32; it++) {
         /* cofactor matrix, C(i,j) at C[i+3j]  (= det * X^-T) */
         double C[9];
@@ -277,45 +444,63 @@ DVO_DEV_NOINLINE void rotationize(double *R) {
         C[6] = X[1] * X[5] - X[4] * X[2];
         C[7] = X[3] * X[2] - X[0] * X[5];
         C[8] = X[0] * X[4] - X[3] * X[1];
-        const double det = X[0] * C[0] + X[1] * C[1] + X[2] * C[2];
+        const double det = fma(X[2], C[2], fma(X[1], C[1], X[0] * C[0]));
         if (det == 0.0 || !(det == det)) break;          /* singular / NaN: leave as is */
-        const double idet = 1.0 / det;
-        /* Frobenius-norm scaling (Higham) */
-        double nx = 0.0, ny = 0.0;
+        const double idet = d_rcp(det);
+        double nx = 0.0, nc = 0.0;
 #pragma unroll
-        for (int k = 0; k < 9; k++) { nx += X[k] * X[k]; const double y = C[k] * idet; ny += y * y; }
-        const double gam = sqrt(sqrt(ny / nx));
+        for (int k = 0; k < 9; k++) { nx = fma(X[k], X[k], nx); nc = fma(C[k], C[k], nc); }
+        const double ny = nc * idet * idet;              /* ||X^-T||_F^2 */
+        double gx = 0.5, gy = 0.5 * idet;
+        if (fabs(ny - nx) > 1e-3 * nx) {                 /* far from orthogonal: scaled step */
+            const double gam = d_sqrt(d_sqrt(d_div(ny, nx)));
+            gx = 0.5 * gam; gy = 0.5 * idet * d_rcp(gam);
+        }
         double diff = 0.0;
 #pragma unroll
         for (int k = 0; k < 9; k++) {
-            const double xn_ = 0.5 * (gam * X[k] + (C[k] * idet) / gam);
+            const double xn_ = fma(gx, X[k], gy * C[k]);
             const double d = xn_ - X[k];
-            diff += d * d;
+            diff = fma(d, d, diff);
             X[k] = xn_;
         }
         if (diff <= 1e-30 * nx) break;
     }
-#pragma unroll
-    for (int k = 0; k < 9; k++) R[k] = X[k];
 }
 
-/* Optimiser state of one runIterations call (lives in LDS, touched by one lane). */
+/* Optimiser state of one runIterations call (lives in LDS, touched by one lane).
+ * The rotation cR is carried as a unit quaternion q; R is its matrix (what the
+ * reference holds in cR after rotationize, :919). */
 struct PoseState {
-    double R[9], t[3];           /* cR, cT */
+    double q[4], t[3];           /* cR (as quaternion), cT */
+    double R[9];                 /* matrix of q */
     double d[6];                 /* descentDirection (:654) */
-    double bestR[9], bestT[3];   /* :646-647 */
+    double bq[4], bt[3];         /* best iterate (:646-647) */
     float bestE, bestRatio;      /* :644-645 */
     int bestItr;                 /* :648 */
     int stop;
     float Rf[9], tf[3];          /* cR_32, cT_32 (:673-674) for the next evaluation */
+    float bRf[9], btf[3];        /* cR_32, cT_32 of the best iterate (for finalEpsilons/Reprojections) */
 };
 
+/* state from a caller-supplied pose (kernel entry) */
+DVO_DEV void pose_state_load(PoseState &s, const double *R, const double *t) {
+    double Rl[9], q[4];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { Rl[k] = R[k]; s.R[k] = R[k]; }
+    quat_of_matrix(Rl, q);
+#pragma unroll
+    for (int k = 0; k < 4; k++) s.q[k] = q[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) s.t[k] = t[k];
+}
+
+/* start of one runIterations call (:642-657) */
 DVO_DEV void pose_state_begin(PoseState &s) {
 #pragma unroll
     for (int k = 0; k < 6; k++) s.d[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 9; k++) s.bestR[k] = (k % 4 == 0) ? 1.0 : 0.0;
-    s.bestT[0] = s.bestT[1] = s.bestT[2] = 0.0;
+    s.bq[0] = 1.0; s.bq[1] = s.bq[2] = s.bq[3] = 0.0;     /* bestcR = I  :646 */
+    s.bt[0] = s.bt[1] = s.bt[2] = 0.0;                     /* bestcT = 0  :647 */
     s.bestE = 1.0E10f;
     s.bestRatio = 1.0f;
     s.bestItr = -1;
@@ -326,64 +511,115 @@ DVO_DEV void pose_state_begin(PoseState &s) {
     for (int k = 0; k < 3; k++) s.tf[k] = (float)s.t[k];
 }
 
+/* end of one runIterations call (:997-1001): pose <- best iterate */
+DVO_DEV void pose_state_finish(PoseState &s) {
+    double q[4], R[9];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { q[k] = s.bq[k]; s.q[k] = q[k]; }
+    quat_to_matrix(q, R);
+#pragma unroll
+    for (int k = 0; k < 9; k++) s.R[k] = R[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) s.t[k] = s.bt[k];
+}
+
+/* Phase fence for the single-lane update: the update is written as short phases
+ * that hand their results over through LDS (PoseState) or a few registers, and
+ * this fence stops the compiler from hoisting the next phase's loads / keeping
+ * the previous phase's values alive across it. */
+#define DVO_PHASE_FENCE()                       \
+    do {                                        \
+        asm volatile("" ::: "memory");          \
+        __builtin_amdgcn_sched_barrier(0);      \
+    } while (0)
+
 /* Everything runIterations does after the per-point phase of iteration `itr`
  * (:689-920).  g = J^T W eps (:777), sum_eps2 = sum eps^2, n_vis visible points.
  * Returns the energy; sets s.stop on early termination. */
-DVO_DEV_NOINLINE float pose_update(PoseState &s, const DevParams &prm, int itr, int N,
+DVO_DEV float pose_update(PoseState &s, const DevParams &prm, int itr, int N,
                           const double *g_in, double sum_eps2, int n_vis) {
-    const float energy = (float)sqrt(sum_eps2);                          /* :689, :1312 */
+    /* ---- phase 1: energy and best-iterate bookkeeping (:689-705) ------------
+     * energy narrows to float, so it needs the correctly rounded double sqrt to
+     * match the oracle's (float)sqrt(double) bit for bit. */
+    const float energy = (float)sqrt(sum_eps2);                           /* :689, :1312 */
     if (energy <= s.bestE) {                                              /* :696 */
         s.bestE = energy;
         s.bestRatio = (float)n_vis / (float)N;                            /* :457 */
 #pragma unroll
-        for (int k = 0; k < 9; k++) s.bestR[k] = s.R[k];
+        for (int k = 0; k < 4; k++) s.bq[k] = s.q[k];
 #pragma unroll
-        for (int k = 0; k < 3; k++) s.bestT[k] = s.t[k];
+        for (int k = 0; k < 3; k++) { s.bt[k] = s.t[k]; s.btf[k] = s.tf[k]; }
+#pragma unroll
+        for (int k = 0; k < 9; k++) s.bRf[k] = s.Rf[k];
         s.bestItr = itr;
     }
-    double g[6];
+    DVO_PHASE_FENCE();
+    /* ---- phase 2: regulariser, heavy ball, step, trust region (:724-878) ---- */
+    double psi[6];
+    {
+        double g[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) g[k] = g_in[k];
-    if (prm.enable_l2_reg) {                                              /* :734-743, :796 */
-        double cpsi[6];
-        se3_log(s.R, s.t, cpsi);
-        const double n = norm6(cpsi);
-        if (n > 0.0) {
+        for (int k = 0; k < 6; k++) g[k] = g_in[k];
+        if (prm.enable_l2_reg) {                                          /* :734-743, :796 */
+            double q[4], t[3], cpsi[6];
 #pragma unroll
-            for (int k = 0; k < 6; k++) cpsi[k] = cpsi[k] / n;
+            for (int k = 0; k < 4; k++) q[k] = s.q[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) t[k] = s.t[k];
+            se3_log_q(q, t, cpsi);
+            const double n = norm6(cpsi);
+            if (n > 0.0) {
+                const double lam_n = prm.reg_lambda * d_rcp(n);
+#pragma unroll
+                for (int k = 0; k < 6; k++) g[k] = fma(lam_n, cpsi[k], g[k]);
+            }
+        }
+        const double step = prm.step_a * prm.step_b *
+                            ((itr > prm.step_decay_after) ? d_rcp((double)(itr - prm.step_decay_offset)) : 1.0);  /* :773 */
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const double dk = (1.0 - prm.beta) * g[k] + prm.beta * s.d[k];    /* :799 */
+            s.d[k] = dk;
+            const double pk = (k < 3) ? 1.0 : prm.precond_rot;                /* :729 */
+            psi[k] = ((-step) * pk) * dk;                                     /* :821 */
+        }
+        double nrm = norm6(psi);                                              /* :832 */
+        if (nrm > prm.trust_radius) {                                         /* :835 */
+            const double sc = prm.trust_radius * d_rcp(nrm);                  /* :837 */
+#pragma unroll
+            for (int k = 0; k < 6; k++) psi[k] *= sc;
+            nrm = prm.trust_radius;  /* |psi| after the projection; only compared with 1e-7 below */
+        }
+        if (nrm < prm.psi_norm_stop) {                                        /* :872 */
+            s.stop = 1;
+            return energy;
+        }
+    }
+    DVO_PHASE_FENCE();
+    /* ---- phase 3: exponential map (:905-907) --------------------------------- */
+    double qx[4], xT[3];
+    se3_exp_q(psi, qx, xT);
+    DVO_PHASE_FENCE();
+    /* ---- phase 4: compose, publish (:916-919, :673-674) ------------------------ */
+    {
+        double R[9], dT[3], q[4];
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = s.R[k];
+        m3_vec(R, xT, dT);                                                    /* cR*xTrans */
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double tk = s.t[k] + dT[k];                                 /* :916 */
+            s.t[k] = tk; s.tf[k] = (float)tk;
         }
 #pragma unroll
-        for (int k = 0; k < 6; k++) g[k] += prm.reg_lambda * cpsi[k];
-    }
-    const double step = prm.step_a * prm.step_b /
-                        ((itr > prm.step_decay_after) ? (double)(itr - prm.step_decay_offset) : 1.0);  /* :773 */
-    double psi[6];
+        for (int k = 0; k < 4; k++) q[k] = s.q[k];
+        quat_mul_normalize(q, qx, q);                                         /* :917 + :919 */
+        quat_to_matrix(q, R);
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-        s.d[k] = (1.0 - prm.beta) * g[k] + prm.beta * s.d[k];             /* :799 */
-        const double pk = (k < 3) ? 1.0 : prm.precond_rot;                /* :729 */
-        psi[k] = ((-step) * pk) * s.d[k];                                 /* :821 */
-    }
-    const double nrm = norm6(psi);                                        /* :832 */
-    if (nrm > prm.trust_radius) {                                         /* :835 */
+        for (int k = 0; k < 4; k++) s.q[k] = q[k];
 #pragma unroll
-        for (int k = 0; k < 6; k++) psi[k] = psi[k] / nrm * prm.trust_radius;   /* :837 */
+        for (int k = 0; k < 9; k++) { s.R[k] = R[k]; s.Rf[k] = (float)R[k]; }
     }
-    if (norm6(psi) < prm.psi_norm_stop) {                                 /* :872 */
-        s.stop = 1;
-        return energy;
-    }
-    double xR[9], xT[3], dT[3];
-    se3_exp(psi, xR, xT);                                                 /* :905-907 */
-    m3_vec(s.R, xT, dT);
-    s.t[0] += dT[0]; s.t[1] += dT[1]; s.t[2] += dT[2];                    /* :916 */
-    double nR[9];
-    m3_mul(s.R, xR, nR);                                                  /* :917 */
-    if (prm.enable_rotationize) rotationize(nR);                          /* :919 */
-#pragma unroll
-    for (int k = 0; k < 9; k++) { s.R[k] = nR[k]; s.Rf[k] = (float)nR[k]; }
-#pragma unroll
-    for (int k = 0; k < 3; k++) s.tf[k] = (float)s.t[k];
     return energy;
 }
 

@@ -41,14 +41,16 @@ DVO_DEV void level_consts(IterConst &c, const Intrinsics &K, int level, int rows
     c.m11 = s * K.fy; c.m12 = s * K.cy;
     c.ncols_f = (float)cols; c.nrows_f = (float)rows;
     c.rows = rows;
+    c.tiles_per_col = texel_tiles_per_col(rows);
 }
 
 /* per-lane partial sums of one iteration */
 struct Acc {
     double g[6];        /* J^T W eps          (:777)   exact products, double fma */
     double e2;          /* sum eps^2          (:1312) */
-    float H[21];        /* sum w J J^T upper triangle; per-lane float, tree in double */
-    int nvis;
+    float H[21];        /* sum w J J^T upper triangle (accumulate_kernel only; the fused kernel runs the
+                           reference's sub-gradient policy, which never forms H -- SolveDVO.cpp:777) */
+    int nvis;           /* visible points, counted per WAVE with ballots (uniform) */
 };
 DVO_DEV void acc_zero(Acc &a) {
 #pragma unroll
@@ -61,6 +63,7 @@ DVO_DEV void acc_zero(Acc &a) {
 /* visible point -> accumulators.  jw = (float)(J_k*w) (:716) widened, times eps
  * widened (:719-720): both factors are floats, so the double product is exact and
  * fma(a,b,c) == c + a*b bit for bit. */
+template <bool WITH_H>
 DVO_DEV void acc_add(Acc &a, const float *J, float eps, float w) {
     const double e = (double)eps;
     float jw[6];
@@ -70,42 +73,168 @@ DVO_DEV void acc_add(Acc &a, const float *J, float eps, float w) {
         a.g[k] = fma((double)jw[k], e, a.g[k]);
     }
     a.e2 = fma(e, e, a.e2);
-    int h = 0;
+    if (WITH_H) {
+        int h = 0;
 #pragma unroll
-    for (int i = 0; i < 6; i++)
+        for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int j = i; j < 6; j++) { a.H[h] = fmaf(jw[i], J[j], a.H[h]); h++; }
-    a.nvis += 1;
+            for (int j = i; j < 6; j++) { a.H[h] = fmaf(jw[i], J[j], a.H[h]); h++; }
+    }
 }
 
-DVO_DEV double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
+/* The per-point phase of one iteration over points [first, end) with a lane
+ * stride of `stride` (:369-407 + :433-451).  U points per lane are in flight at
+ * once: their coordinates are loaded, projected, and the U texel gathers are
+ * issued back to back (unconditionally, index 0 when not visible) before any
+ * Jacobian arithmetic, so a lane waits for one memory round trip per U points
+ * instead of one per point.  The trip count is wave-uniform, so the visible
+ * count can be taken from ballots. */
+/* Where a lane finds reference point i: the first `n_lds` points of the level
+ * live in LDS as three planes (x | y | z, each `cap` floats; conflict-free
+ * ds_read_b32), the rest are read from HBM (3 x N column-major, 12 B / point). */
+struct PointSrc {
+    const float *__restrict__ g;    /* global list */
+    const float *l;                 /* LDS planes  */
+    int n_lds, cap;
+};
+/* branch-free on purpose: a (divergent) LDS-or-HBM choice per point makes the compiler drain all
+ * outstanding gathers before it; whole rounds are served from one source instead */
+template <bool USE_LDS>
+DVO_DEV void load_point(const PointSrc &p, int i, float &X, float &Y, float &Z) {
+    if (USE_LDS) {
+        X = p.l[i]; Y = p.l[p.cap + i]; Z = p.l[2 * p.cap + i];
+    } else {
+        X = p.g[3 * i]; Y = p.g[3 * i + 1]; Z = p.g[3 * i + 2];
+    }
 }
 
-/* Fixed-shape reduction of the 29 accumulators over a workgroup: shuffle tree
- * inside each wave, one LDS row per wave, lanes 0..28 of the workgroup add the
- * rows in wave order.  Deterministic: same inputs -> same bits.
+/* One "round" = U points per lane.  The per-point phase is software-pipelined
+ * over rounds: while the Jacobian rows of round r are computed, the U texel
+ * gathers of round r+1 are already in flight (loads return in order on CDNA, so
+ * waiting for round r's texels leaves the younger requests outstanding).  Two
+ * named buffer sets (ping-pong, loop unrolled by two rounds) avoid register
+ * copies, and the compute stage is branch-free (a lane whose point is not
+ * visible works on a harmless dummy and contributes exact zeros), so the steady
+ * state is straight-line code. */
+template <int U> struct RoundBuf {
+    float xn[U], yn[U], zn[U];
+    float4 t[U];
+    bool vis[U];
+};
+
+/* stage B: load U points, project, issue the gathers (texel 0 when not visible) */
+template <int U, bool USE_LDS>
+DVO_DEV void round_issue(const IterConst &c, const float4 *__restrict__ tex, const PointSrc &pts,
+                         int base, int end, int lane_off, int stride, RoundBuf<U> &b) {
+    int idx[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int i = base + lane_off + u * stride;
+        const bool valid = i < end;
+        const int ii = valid ? i : (end - 1);
+        float X, Y, Z, uu, vv;
+        load_point<USE_LDS>(pts, ii, X, Y, Z);
+        const bool vis = project_point(c, X, Y, Z, b.xn[u], b.yn[u], b.zn[u], uu, vv) && valid;
+        b.vis[u] = vis;
+        idx[u] = vis ? texel_index((int)vv, (int)uu, c.tiles_per_col) : 0;
+        if (!vis) { b.xn[u] = 0.0f; b.yn[u] = 0.0f; b.zn[u] = 1.0f; }    /* finite dummy */
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) b.t[u] = tex[idx[u]];
+}
+/* stage C: Jacobian rows + accumulation; invisible lanes add exact zeros */
+template <int U, bool WITH_H>
+DVO_DEV void round_compute(const IterConst &c, const RoundBuf<U> &b, Acc &a) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        a.nvis += __popcll(__ballot(b.vis[u]));
+        float J[6];
+        jacobian_row(c, b.xn[u], b.yn[u], b.zn[u], b.t[u].y, b.t[u].z, J);
+        const float eps = b.vis[u] ? b.t[u].x : 0.0f;
+        const float w = b.vis[u] ? b.t[u].w : 0.0f;
+        acc_add<WITH_H>(a, J, eps, w);
+    }
+}
+
+/* The per-point phase of one iteration over points [first, end) with a lane
+ * stride of `stride` (:369-407 + :433-451).  The trip count is wave-uniform, so
+ * the visible count can be taken from ballots. */
+template <int U, bool WITH_H, bool USE_LDS>
+DVO_DEV void accumulate_points(const IterConst &c, const float4 *__restrict__ tex,
+                               const PointSrc &pts, int first, int end, int lane_off,
+                               int stride, Acc &a) {
+    if (first >= end) return;
+    const int step = stride * U;
+    const int n_rounds = (end - first + step - 1) / step;
+    RoundBuf<U> A, B;
+    round_issue<U, USE_LDS>(c, tex, pts, first, end, lane_off, stride, A);
+    int r = 0;
+    for (; r + 2 < n_rounds; r += 2) {                       /* steady state: A = round r */
+        round_issue<U, USE_LDS>(c, tex, pts, first + (r + 1) * step, end, lane_off, stride, B);
+        round_compute<U, WITH_H>(c, A, a);
+        round_issue<U, USE_LDS>(c, tex, pts, first + (r + 2) * step, end, lane_off, stride, A);
+        round_compute<U, WITH_H>(c, B, a);
+    }
+    if (r + 1 < n_rounds) {                                  /* two rounds left */
+        round_issue<U, USE_LDS>(c, tex, pts, first + (r + 1) * step, end, lane_off, stride, B);
+        round_compute<U, WITH_H>(c, A, a);
+        round_compute<U, WITH_H>(c, B, a);
+    } else {
+        round_compute<U, WITH_H>(c, A, a);
+    }
+}
+
+/* Butterfly reduce-scatter inside a wave: NV values per lane; at step s lanes
+ * that differ in bit (5-s) exchange half of their values and add the other half,
+ * so the work halves every step (NV-1 exchanges instead of 6*NV).  The remaining
+ * lane bits are folded with plain xor steps.  On return every lane L holds, in
+ * v[0], the wave total of value index L >> (6 - log2 NV).  Fixed shape:
+ * deterministic. */
+template <typename T, int NV>
+DVO_DEV void wave_reduce_scatter(T (&v)[NV]) {
+    const int lane = threadIdx.x & 63;
+    int bit = 32;
+#pragma unroll
+    for (int half = NV / 2; half >= 1; half >>= 1) {
+        const bool up = (lane & bit) != 0;
+#pragma unroll
+        for (int j = 0; j < half; j++) {
+            const T keep = up ? v[j + half] : v[j];
+            const T send = up ? v[j] : v[j + half];
+            v[j] = keep + __shfl_xor(send, bit, 64);
+        }
+        bit >>= 1;
+    }
+#pragma unroll
+    for (; bit >= 1; bit >>= 1) v[0] += __shfl_xor(v[0], bit, 64);
+}
+
+/* Fixed-shape reduction of the 29 accumulators over a workgroup.
  * Result in tot[0..28] (valid after the trailing barrier). */
-template <int BLOCK>
+template <int BLOCK, bool WITH_H>
 DVO_DEV void block_reduce(const Acc &a, double (*red)[DVO_NACC_PAD], double *tot) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double v;
+    if (WITH_H) {
+        float h[32];
 #pragma unroll
-    for (int k = 0; k < 21; k++) {
-        v = wave_sum((double)a.H[k]);
-        if (lane == 0) red[wave][k] = v;
+        for (int k = 0; k < 32; k++) h[k] = (k < 21) ? a.H[k] : 0.0f;
+        wave_reduce_scatter<float, 32>(h);
+        const int idx = lane >> 1;
+        if ((lane & 1) == 0 && idx < 21) red[wave][idx] = (double)h[0];
+    } else if (lane < 21) {
+        red[wave][lane] = 0.0;
     }
+    {
+        double d[8];
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-        v = wave_sum(a.g[k]);
-        if (lane == 0) red[wave][21 + k] = v;
+        for (int k = 0; k < 6; k++) d[k] = a.g[k];
+        d[6] = a.e2;
+        d[7] = 0.0;
+        wave_reduce_scatter<double, 8>(d);
+        const int idx = lane >> 3;
+        if ((lane & 7) == 0 && idx < 7) red[wave][21 + idx] = d[0];
     }
-    v = wave_sum(a.e2);
-    if (lane == 0) red[wave][27] = v;
-    v = wave_sum((double)a.nvis);
-    if (lane == 0) red[wave][28] = v;
+    if (lane == 0) red[wave][28] = (double)a.nvis;
     __syncthreads();
     if (threadIdx.x < DVO_NACC) {
         double s = 0.0;
@@ -121,40 +250,69 @@ DVO_DEV void block_reduce(const Acc &a, double (*red)[DVO_NACC_PAD], double *tot
 /* ------------------------------------------------------------------------- */
 __global__ void __launch_bounds__(256)
 pack_texels_kernel(const float *__restrict__ dt, const float *__restrict__ gx,
-                   const float *__restrict__ gy, float4 *__restrict__ out, size_t n) {
+                   const float *__restrict__ gy, float4 *__restrict__ out, int rows, int cols) {
+    const size_t n = (size_t)rows * cols;
+    const int tpc = texel_tiles_per_col(rows);
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) out[i] = make_float4(dt[i], gx[i], gy[i], 0.0f);
+    for (; i < n; i += stride) {
+        const int xx = (int)(i / rows), yy = (int)(i - (size_t)xx * rows);
+        out[texel_index(yy, xx, tpc)] = make_float4(dt[i], gx[i], gy[i], weight_of(dt[i]));
+    }
 }
 
 hipError_t launch_pack_texels(const float *dt, const float *gx, const float *gy, float4 *out,
-                              size_t n, hipStream_t s) {
+                              int rows, int cols, hipStream_t s) {
+    const size_t n = (size_t)rows * cols;
     if (n == 0) return hipSuccess;
     size_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(pack_texels_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dt, gx, gy, out, n);
+    hipLaunchKernelGGL(pack_texels_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dt, gx, gy, out, rows, cols);
     return hipGetLastError();
 }
 
 /* ------------------------------------------------------------------------- */
 /* fused coarse-to-fine alignment: one workgroup per frame pair                */
 /* ------------------------------------------------------------------------- */
-template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK)
+/* DVO_STAMPS: diagnostic build only (make STAMPS=1 -> libdvo_amd_stamps.so).  Lane 0 of wave 0
+ * accumulates s_memtime differences of the four phases of every iteration into out.dbg
+ * (a buffer nothing else reads).  Never enabled in the product library. */
+#ifdef DVO_STAMPS
+DVO_DEV unsigned long long stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define DVO_STAMP(var) const unsigned long long var = stamp_now()
+#define DVO_STAMP_ADD(slot, a, b) do { if (tid == 0 && out.dbg) out.dbg[(size_t)pair * 64 + l * 8 + (slot)] += (b) - (a); } while (0)
+#else
+#define DVO_STAMP(var) do {} while (0)
+#define DVO_STAMP_ADD(slot, a, b) do {} while (0)
+#endif
+#ifndef DVO_WAVES_PER_EU
+#define DVO_WAVES_PER_EU 1       /* register budget of the fused kernel: 512 / waves VGPRs */
+#endif
+template <int BLOCK, int U>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(DVO_WAVES_PER_EU, 8)))
 align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outputs out, int first_pair) {
     const int pair = first_pair + blockIdx.x;
     const int tid = threadIdx.x;
     __shared__ PoseState st;
     __shared__ double red[BLOCK / 64][DVO_NACC_PAD];
     __shared__ double tot[DVO_NACC_PAD];
+    extern __shared__ float lds_points[];     /* 3 planes of sc.lds_points floats: this level's points */
 
     if (tid == 0) {
         const double *p = out.poses + (size_t)pair * 12;
         const bool ident = (sc.flags & 2) != 0;                  /* DVO_FLAG_IDENTITY_START (:2210-2211) */
+        double R0[9], t0[3];
 #pragma unroll
-        for (int k = 0; k < 9; k++) st.R[k] = ident ? ((k % 4 == 0) ? 1.0 : 0.0) : p[k];
+        for (int k = 0; k < 9; k++) R0[k] = ident ? ((k % 4 == 0) ? 1.0 : 0.0) : p[k];
 #pragma unroll
-        for (int k = 0; k < 3; k++) st.t[k] = ident ? 0.0 : p[9 + k];
+        for (int k = 0; k < 3; k++) t0[k] = ident ? 0.0 : p[9 + k];
+        pose_state_load(st, R0, t0);
     }
     __syncthreads();
 
@@ -162,9 +320,10 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
         const int iters = sc.iters[l];
         if (iters <= 0) continue;                                 /* :2099 */
         const LevelSlab &L = lv.l[l];
-        const int N = L.N[pair];
-        const float4 *__restrict__ tex = L.tex + (size_t)pair * L.tex_stride;
-        const float *__restrict__ pts = L.pts + (size_t)pair * L.pt_cap * 3;
+        const int dpair = (sc.alias_mod > 0) ? (pair % sc.alias_mod) : pair;
+        const int N = L.N[dpair];
+        const float4 *__restrict__ tex = L.tex + (size_t)dpair * L.tex_stride;
+        const float *__restrict__ pts = L.pts + (size_t)dpair * L.pt_cap * 3;
         float *energy = out.energy + (size_t)pair * sc.e_stride + sc.e_off[l];
 
         IterConst c;
@@ -172,6 +331,17 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
 
         for (int i = tid; i < iters; i += BLOCK) energy[i] = 0.0f;          /* :634 */
         if (tid == 0) pose_state_begin(st);                                  /* :642-657 */
+        /* The reference re-reads (in fact deep-copies, :670) the 3xN point list every
+         * iteration; here the level's points are staged into LDS once and stay there
+         * for all its iterations, so HBM sees them once per level. */
+        PointSrc psrc;
+        psrc.g = pts; psrc.l = lds_points; psrc.cap = sc.lds_points;
+        psrc.n_lds = (N < sc.lds_points) ? N : (sc.lds_points / (BLOCK * U)) * (BLOCK * U);   /* whole rounds only */
+        for (int i = tid; i < psrc.n_lds; i += BLOCK) {
+            lds_points[i] = pts[3 * i];
+            lds_points[psrc.cap + i] = pts[3 * i + 1];
+            lds_points[2 * psrc.cap + i] = pts[3 * i + 2];
+        }
         __syncthreads();
 
         for (int itr = 0; itr < iters; ++itr) {                              /* :658 */
@@ -180,24 +350,23 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
 #pragma unroll
             for (int k = 0; k < 3; k++) c.t[k] = uniform_f(st.tf[k]);        /* :674 */
 
+            DVO_STAMP(t0);
             Acc a;
             acc_zero(a);
-            for (int i = tid; i < N; i += BLOCK) {                           /* :369, :433 */
-                const float X = pts[3 * i], Y = pts[3 * i + 1], Z = pts[3 * i + 2];
-                float xn, yn, zn, u, v;
-                if (project_point(c, X, Y, Z, xn, yn, zn, u, v)) {
-                    const float4 tx = tex[texel_index((int)v, (int)u, c.rows)];
-                    float J[6];
-                    jacobian_row(c, xn, yn, zn, tx.y, tx.z, J);
-                    acc_add(a, J, tx.x, weight_of(tx.x));
-                }
-            }
-            block_reduce<BLOCK>(a, red, tot);
+            accumulate_points<U, false, true>(c, tex, psrc, 0, psrc.n_lds, tid, BLOCK, a);    /* :369, :433 */
+            accumulate_points<U, false, false>(c, tex, psrc, psrc.n_lds, N, tid, BLOCK, a);  /* beyond the LDS budget */
+            DVO_STAMP(t1);
+            block_reduce<BLOCK, false>(a, red, tot);
+            DVO_STAMP(t2);
             if (tid == 0) {
                 const float e = pose_update(st, prm, itr, N, &tot[21], tot[27], (int)tot[28]);
                 energy[itr] = e;                                             /* :690 */
             }
+            DVO_STAMP(t3);
             __syncthreads();
+            DVO_STAMP(t4);
+            DVO_STAMP_ADD(0, t0, t1); DVO_STAMP_ADD(1, t1, t2); DVO_STAMP_ADD(2, t2, t3); DVO_STAMP_ADD(3, t3, t4);
+            DVO_STAMP_ADD(4, t0, t0 + 1);
             if (st.stop) break;                                              /* :877 */
         }
 
@@ -206,17 +375,18 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
         if ((sc.flags & 1) && l == sc.last_level) {
             if (st.bestItr >= 0) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) c.r[k] = uniform_f((float)st.bestR[k]);
+                for (int k = 0; k < 9; k++) c.r[k] = uniform_f(st.bRf[k]);
 #pragma unroll
-                for (int k = 0; k < 3; k++) c.t[k] = uniform_f((float)st.bestT[k]);
+                for (int k = 0; k < 3; k++) c.t[k] = uniform_f(st.btf[k]);
                 float *fe = out.final_eps + (size_t)pair * out.final_cap;
                 float *fr = out.final_reproj + (size_t)pair * out.final_cap * 3;
                 for (int i = tid; i < N; i += BLOCK) {
-                    const float X = pts[3 * i], Y = pts[3 * i + 1], Z = pts[3 * i + 2];
-                    float xn, yn, zn, u, v;
+                    float X, Y, Z, xn, yn, zn, u, v;
+                    if (i < psrc.n_lds) load_point<true>(psrc, i, X, Y, Z);
+                    else load_point<false>(psrc, i, X, Y, Z);
                     const bool vis = project_point(c, X, Y, Z, xn, yn, zn, u, v);
                     float e = 0.0f;
-                    if (vis) e = tex[texel_index((int)v, (int)u, c.rows)].x;
+                    if (vis) e = tex[texel_index((int)v, (int)u, c.tiles_per_col)].x;
                     fe[i] = e;
                     fr[3 * i] = u; fr[3 * i + 1] = v; fr[3 * i + 2] = zn;
                 }
@@ -225,11 +395,7 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
         }
         __syncthreads();
         if (tid == 0) {                                                      /* :997-1005 */
-#pragma unroll
-            for (int k = 0; k < 9; k++) st.R[k] = st.bestR[k];
-            if (prm.enable_rotationize) rotationize(st.R);
-#pragma unroll
-            for (int k = 0; k < 3; k++) st.t[k] = st.bestT[k];
+            pose_state_finish(st);
             out.best_idx[pair * DVO_LEVELS + l] = st.bestItr;
             out.ratio[pair * DVO_LEVELS + l] = st.bestRatio;
         }
@@ -245,20 +411,30 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
     }
 }
 
-hipError_t launch_align_fused(int block_threads, const LevelSet &lv, const Schedule &sc,
-                              const Intrinsics &K, const DevParams &prm, const Outputs &out,
-                              int first_pair, int n_pairs, hipStream_t s) {
+template <int BLOCK, int U>
+static void launch_fused_bu(const LevelSet &lv, const Schedule &sc, const Intrinsics &K,
+                            const DevParams &prm, const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {
+    const size_t dyn = (size_t)sc.lds_points * 3 * sizeof(float);
+    auto kern = align_fused_kernel<BLOCK, U>;
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    hipLaunchKernelGGL(kern, dim3(n_pairs), dim3(BLOCK), dyn, s, lv, sc, K, prm, out, first_pair);
+}
+template <int BLOCK>
+static void launch_fused_b(int u, const LevelSet &lv, const Schedule &sc, const Intrinsics &K,
+                           const DevParams &prm, const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {
+    if (u >= 4) launch_fused_bu<BLOCK, 4>(lv, sc, K, prm, out, first_pair, n_pairs, s);
+    else if (u == 2) launch_fused_bu<BLOCK, 2>(lv, sc, K, prm, out, first_pair, n_pairs, s);
+    else launch_fused_bu<BLOCK, 1>(lv, sc, K, prm, out, first_pair, n_pairs, s);
+}
+
+hipError_t launch_align_fused(int block_threads, int points_in_flight, const LevelSet &lv,
+                              const Schedule &sc, const Intrinsics &K, const DevParams &prm,
+                              const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {
     if (n_pairs <= 0) return hipSuccess;
     switch (block_threads) {
-    case 256:
-        hipLaunchKernelGGL(align_fused_kernel<256>, dim3(n_pairs), dim3(256), 0, s, lv, sc, K, prm, out, first_pair);
-        break;
-    case 1024:
-        hipLaunchKernelGGL(align_fused_kernel<1024>, dim3(n_pairs), dim3(1024), 0, s, lv, sc, K, prm, out, first_pair);
-        break;
-    default:
-        hipLaunchKernelGGL(align_fused_kernel<512>, dim3(n_pairs), dim3(512), 0, s, lv, sc, K, prm, out, first_pair);
-        break;
+    case 256: launch_fused_b<256>(points_in_flight, lv, sc, K, prm, out, first_pair, n_pairs, s); break;
+    case 1024: launch_fused_b<1024>(points_in_flight, lv, sc, K, prm, out, first_pair, n_pairs, s); break;
+    default: launch_fused_b<512>(points_in_flight, lv, sc, K, prm, out, first_pair, n_pairs, s); break;
     }
     return hipGetLastError();
 }
@@ -320,18 +496,15 @@ accumulate_kernel(LevelSlab L, int pair, int level, Intrinsics K, FloatPose P,
     for (int k = 0; k < 3; k++) c.t[k] = P.t[k];
     Acc a;
     acc_zero(a);
-    const int end = first + n;
-    for (int i = first + blockIdx.x * 256 + threadIdx.x; i < end; i += gridDim.x * 256) {
-        const float X = pts[3 * i], Y = pts[3 * i + 1], Z = pts[3 * i + 2];
-        float xn, yn, zn, u, v;
-        if (project_point(c, X, Y, Z, xn, yn, zn, u, v)) {
-            const float4 tx = tex[texel_index((int)v, (int)u, c.rows)];
-            float J[6];
-            jacobian_row(c, xn, yn, zn, tx.y, tx.z, J);
-            acc_add(a, J, tx.x, weight_of(tx.x));
-        }
-    }
-    block_reduce<256>(a, red, tot);
+    /* contiguous chunk per block (each block = a contiguous index range of the point list) */
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int b0 = first + blockIdx.x * per;
+    int b1 = b0 + per;
+    if (b1 > first + n) b1 = first + n;
+    PointSrc psrc;
+    psrc.g = pts; psrc.l = nullptr; psrc.n_lds = 0; psrc.cap = 0;
+    if (b0 < b1) accumulate_points<4, true, false>(c, tex, psrc, b0, b1, threadIdx.x, 256, a);
+    block_reduce<256, true>(a, red, tot);
     if (threadIdx.x < DVO_NACC_PAD)
         partials[(size_t)blockIdx.x * DVO_NACC_PAD + threadIdx.x] = (threadIdx.x < DVO_NACC) ? tot[threadIdx.x] : 0.0;
 }

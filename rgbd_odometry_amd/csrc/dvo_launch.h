@@ -18,8 +18,8 @@
 namespace dvo {
 
 /* One pyramid level of every pair of a context ("slab" layout in HBM):
- *   tex : n_pairs x (rows*cols) texels {DT, gx, gy, 0}, pixel (yy,xx) of pair p at
- *         tex[p*tex_stride + yy + xx*rows]                    (16 B / pixel)
+ *   tex : n_pairs x tex_stride texels {DT, gx, gy, 0} (16 B / pixel), pixel (yy,xx) of pair p at
+ *         tex[p*tex_stride + texel_index(yy, xx, tiles_per_col)]   (tiled, see dvo_device_math.h)
  *   pts : n_pairs x pt_cap x 3 floats, point i of pair p at pts[(p*pt_cap + i)*3]
  *         (the reference's 3xN column-major SpaceCordList, 12 B / point)
  *   N   : n_pairs ints                                                          */
@@ -40,6 +40,8 @@ struct Schedule {
     int e_stride;            /* floats per pair = sum iters */
     int last_level;          /* smallest l with iters[l] > 0 (its outputs survive, SolveDVO.cpp:2102) */
     int flags;
+    int alias_mod;           /* diagnostics: data of pair p % alias_mod (0 = off) */
+    int lds_points;          /* reference points kept resident in LDS per workgroup (3 floats each) */
 };
 
 struct Intrinsics { float fx, fy, cx, cy; };
@@ -53,13 +55,14 @@ struct Outputs {
     float *final_reproj;     /* n_pairs x 3*final_cap */
     int *final_N;            /* n_pairs */
     int final_cap;
+    unsigned long long *dbg; /* diagnostics (DVO_STAMPS builds): n_pairs x 64 counters, else NULL */
 };
 
 hipError_t launch_pack_texels(const float *dt, const float *gx, const float *gy, float4 *out,
-                              size_t n, hipStream_t s);
-hipError_t launch_align_fused(int block_threads, const LevelSet &lv, const Schedule &sc,
-                              const Intrinsics &K, const DevParams &prm, const Outputs &out,
-                              int first_pair, int n_pairs, hipStream_t s);
+                              int rows, int cols, hipStream_t s);
+hipError_t launch_align_fused(int block_threads, int points_in_flight, const LevelSet &lv,
+                              const Schedule &sc, const Intrinsics &K, const DevParams &prm,
+                              const Outputs &out, int first_pair, int n_pairs, hipStream_t s);
 /* per-point dump at a float pose (inspection) */
 hipError_t launch_eval_points(const LevelSlab &L, int pair, int level, const Intrinsics &K,
                               const float *Rf, const float *tf,

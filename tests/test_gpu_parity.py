@@ -179,10 +179,17 @@ def test_warm_start_from_previous_pose(scene320, ctx320, oracle):
     _check_pyramid(sc, lv, ctx320, oracle, [5, 5, 5, 5], R0=np.array(R0), t0=t0)
 
 
-@pytest.mark.parametrize("block", [256, 1024])
-def test_block_size_variants(scene320, oracle, block):
+@pytest.mark.parametrize("kw", [
+    dict(block_threads=256), dict(block_threads=1024),
+    dict(points_in_flight=2), dict(points_in_flight=4), dict(block_threads=256, points_in_flight=4),
+    dict(lds_point_bytes=-1),                 # every point read from HBM
+    dict(lds_point_bytes=12 * 1024),          # 1024 points in LDS, the rest from HBM (both passes run)
+    dict(block_threads=256, lds_point_bytes=12 * 700),   # budget smaller than one round -> 0 resident
+])
+def test_engine_tuning_variants(scene320, oracle, kw):
+    """every tuning knob must leave the results bit-identical to the oracle"""
     sc, lv = scene320
-    ctx = _ctx_for(sc, lv, block_threads=block)
+    ctx = _ctx_for(sc, lv, **kw)
     try:
         _check_pyramid(sc, lv, ctx, oracle, [10, 10, 10, 10])
     finally:
