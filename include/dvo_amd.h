@@ -169,6 +169,25 @@ int  dvo_get_level_report(dvo_ctx *ctx, int pair, int level, float *energy, int 
 int  dvo_get_final_outputs(dvo_ctx *ctx, int pair, float *final_eps, float *final_reproj, int capacity,
                            int *N_out);
 
+/* ---- host-driven iteration: one very large frame, or one frame tiled over several GPUs --------
+ * runIterations (SolveDVO.cpp:619-1017) opened up at the only point where its per-point work
+ * couples: the sum.  Per iteration the caller runs
+ *     dvo_iter_accumulate(points [first, first+n) of this GPU's shard) -> 32 doubles on the device
+ *     [all-reduce of those doubles over the GPUs that share the frame: RCCL, ncclSum]
+ *     dvo_iter_update(the reduced sums)        -- the reference's 6-DoF update, on the device
+ * The grid of the accumulate kernel spans all CUs, so this is also the path for frames whose
+ * point lists are too long for one workgroup (1920x1080, 4096x3072).  All calls except
+ * dvo_iter_begin/_end are asynchronous on the context stream.
+ *   d_acc32: DEVICE pointer to 32 doubles: [0..20] H upper triangle, [21..26] g, [27] sum eps^2,
+ *            [28] visible points, [29..31] zero.
+ *   n_total: number of reference points of the level over ALL shards (visible ratio, :457).
+ * After an early termination (:877) later dvo_iter_update calls are no-ops, like the reference's break. */
+int  dvo_iter_begin(dvo_ctx *ctx, int pair, int level, int max_iters, const double *R, const double *t);
+int  dvo_iter_accumulate(dvo_ctx *ctx, int pair, int level, int first_point, int n_points, double *d_acc32);
+int  dvo_iter_update(dvo_ctx *ctx, int pair, int level, int itr, int n_total, const double *d_acc32);
+int  dvo_iter_end(dvo_ctx *ctx, int pair, int level, double *R, double *t, float *energy /*[max_iters] or NULL*/,
+                  int *best_idx, float *visible_ratio);
+
 /* ---- inspection (used by the parity tests) ---------------------------------
  * One evaluation of computeJacobianOfNowFrame + getReprojectedEpsilons at the
  * given pose (cast to float exactly as SolveDVO.cpp:673-674).  Host outputs, any

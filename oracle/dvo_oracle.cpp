@@ -541,6 +541,124 @@ void dvo_oracle_rotationize(double *R) {
     mat3_mul(US, Vt, R);
 }
 
+static void accumulate_from(const float *J, const float *eps, const float *w, const int *vis, int n,
+                            double *acc29);
+
+/* The 29 sums of one evaluation over points [first, first+n) at a float pose:
+ * acc[0..20] upper triangle of sum w J J^T, acc[21..26] g = (J^T W) eps (:714-720, :777),
+ * acc[27] sum eps^2 (:1312), acc[28] number of visible points.  Sequential order. */
+void dvo_oracle_accumulate(const dvo_oracle_params *prm, int level, const float *xyz, int first, int n,
+                           const float *dt, const float *gx, const float *gy, int rows, int cols,
+                           float fx, float fy, float cx, float cy,
+                           const float *cR_32, const float *cT_32, double *acc29) {
+    std::vector<float> J(6 * (size_t)n), eps(n), w(n);
+    std::vector<int> vis(n);
+    dvo_oracle_eval_points(prm, level, xyz + 3 * (size_t)first, n, dt, gx, gy, rows, cols, fx, fy, cx, cy,
+                           cR_32, cT_32, nullptr, J.data(), eps.data(), w.data(), vis.data());
+    accumulate_from(J.data(), eps.data(), w.data(), vis.data(), n, acc29);
+}
+
+static void accumulate_from(const float *J, const float *eps, const float *w, const int *vis, int n,
+                            double *acc29) {
+    for (int k = 0; k < 29; k++) acc29[k] = 0.0;
+    for (int i = 0; i < n; i++) {
+        float jw[6];
+        for (int k = 0; k < 6; k++) jw[k] = J[6 * i + k] * w[i];                    /* :716 */
+        for (int k = 0; k < 6; k++) acc29[21 + k] += (double)jw[k] * (double)eps[i];   /* :719-720, :777 */
+        int h = 0;
+        for (int a_ = 0; a_ < 6; a_++)
+            for (int b_ = a_; b_ < 6; b_++) acc29[h++] += (double)jw[a_] * (double)J[6 * i + b_];
+        acc29[27] += (double)eps[i] * (double)eps[i];
+        if (vis[i]) acc29[28] += 1.0;
+    }
+}
+
+/* ---- runIterations as an explicit state machine (same arithmetic as :642-1005) ---- */
+void dvo_oracle_state_begin(dvo_oracle_state *s, const double *R, const double *t) {
+    std::memcpy(s->R, R, sizeof(double) * 9);
+    std::memcpy(s->t, t, sizeof(double) * 3);
+    for (int k = 0; k < 6; k++) s->d[k] = 0.0;                      /* :654 */
+    mat3_identity(s->bestR);                                        /* :646 */
+    s->bestT[0] = s->bestT[1] = s->bestT[2] = 0.0;                  /* :647 */
+    s->bestE = 1.0E10;                                              /* :644 */
+    s->bestRatio = 1.0f;                                            /* :645 */
+    s->bestItr = -1;                                                /* :648 */
+    s->stop = 0;
+}
+
+/* everything after the per-point phase of iteration itr (:689-920); returns 1 on early termination */
+int dvo_oracle_state_update(const dvo_oracle_params *prm, dvo_oracle_state *s, int itr, int N,
+                            const double *g_in, double sum_eps2, int n_vis, float *energy_out,
+                            double *psi_out) {
+    double *cR = s->R, *cT = s->t;
+    /* aggregateEpsilons (:1310-1312) = epsilon.norm().  Oracle definition:
+     * (float)sqrt(sum of (double)eps^2), order-insensitive before narrowing. */
+    const float currentTotalEpsilon = (float)std::sqrt(sum_eps2);
+    *energy_out = currentTotalEpsilon;                              /* :690 */
+    const float ratio_of_visible_pts = (float)n_vis / (float)N;     /* :457 */
+    if (currentTotalEpsilon <= s->bestE) {                          /* :696 */
+        s->bestE = currentTotalEpsilon;
+        s->bestRatio = ratio_of_visible_pts;
+        std::memcpy(s->bestR, cR, sizeof(double) * 9);
+        std::memcpy(s->bestT, cT, sizeof(double) * 3);
+        s->bestItr = itr;
+    }
+    double g[6];
+    for (int k = 0; k < 6; k++) g[k] = g_in[k];
+    if (psi_out) for (int k = 0; k < 6; k++) psi_out[k] = 0.0;
+
+    /* :724-730 pre-conditioner */
+    double PVec[6] = {1.0, 1.0, 1.0, prm->precond_rot, prm->precond_rot, prm->precond_rot};
+
+    /* :734-743 L2 regulariser direction */
+    double cPsi[6] = {0, 0, 0, 0, 0, 0};
+    if (prm->enable_l2_reg) {
+        dvo_oracle_se3_log(cR, cT, cPsi);
+        const double n = norm_n(cPsi, 6);
+        if (n > 0) for (int k = 0; k < 6; k++) cPsi[k] = cPsi[k] / n;
+    }
+
+    /* :773 */
+    const double stepLength = prm->step_a * prm->step_b /
+                              ((itr > prm->step_decay_after) ? (double)(itr - prm->step_decay_offset) : 1.0);
+
+    if (prm->enable_l2_reg)
+        for (int k = 0; k < 6; k++) g[k] += prm->reg_lambda * cPsi[k];            /* :796 */
+
+    for (int k = 0; k < 6; k++)                                     /* :799, 1.0f-BETA promotes to double */
+        s->d[k] = (1.0f - prm->beta) * g[k] + prm->beta * s->d[k];
+
+    double psi[6];
+    for (int k = 0; k < 6; k++) psi[k] = -stepLength * PVec[k] * s->d[k];          /* :821 */
+
+    const double norm = norm_n(psi, 6);                             /* :832 */
+    if (norm > (double)prm->trust_radius) {                         /* :835 */
+        for (int k = 0; k < 6; k++) psi[k] = psi[k] / norm * (double)prm->trust_radius;   /* :837 */
+    }
+    /* :840 dangling else binds to :872; behaviourally "clamp, then test" (quirk Q5) */
+    if (norm_n(psi, 6) < (double)prm->psi_norm_stop) {              /* :872 */
+        s->stop = 1;
+        return 1;                                                   /* :877 */
+    }
+
+    double xRot[9], xTrans[3];
+    dvo_oracle_se3_exp(psi, xRot, xTrans);                          /* :905-907 */
+    double dT[3];
+    mat3_vec(cR, xTrans, dT);
+    for (int k = 0; k < 3; k++) cT[k] += dT[k];                     /* :916 */
+    mat3_mul(cR, xRot, cR);                                         /* :917 */
+    if (prm->enable_rotationize) dvo_oracle_rotationize(cR);        /* :919 */
+    if (psi_out) std::memcpy(psi_out, psi, sizeof(psi));
+    return 0;
+}
+
+/* :997-1001 */
+void dvo_oracle_state_finish(const dvo_oracle_params *prm, dvo_oracle_state *s, double *R, double *t) {
+    std::memcpy(R, s->bestR, sizeof(double) * 9);                   /* :997 */
+    if (prm->enable_rotationize) dvo_oracle_rotationize(R);         /* :999 */
+    std::memcpy(t, s->bestT, sizeof(double) * 3);                   /* :1001 */
+}
+
 /* SolveDVO::runIterations (:619-1017) */
 int dvo_oracle_run_iterations(const dvo_oracle_params *prm_in, int level, int maxIterations,
                               const float *xyz, int N,
@@ -557,140 +675,53 @@ int dvo_oracle_run_iterations(const dvo_oracle_params *prm_in, int level, int ma
 
     for (int k = 0; k < maxIterations; k++) energyAtEachIteration[k] = 0.0f;     /* :634 */
 
-    float bestTotalEpsilon = 1.0E10;                               /* :644 */
-    float bestRatioVisiblePts = 1.0f;                              /* :645 */
-    double bestcR[9]; mat3_identity(bestcR);                       /* :646 */
-    double bestcT[3] = {0, 0, 0};                                  /* :647 */
-    int bestItrNumber = -1;                                        /* :648 */
-    std::vector<float> bestEpsilon, bestReprojections;             /* :649-650 */
-
-    double stepLength = 1E-1;                                      /* :652 */
-    const double BETA = prm->beta;                                 /* :653 */
-    double descentDirection[6] = {0, 0, 0, 0, 0, 0};               /* :654 */
-    double g_prev[6] = {0, 0, 0, 0, 0, 0};                         /* :657 */
-
-    std::vector<float> reprojections(3 * (size_t)N), Jcbian(6 * (size_t)N), epsilon(N), weights(N);
+    dvo_oracle_state st;
+    dvo_oracle_state_begin(&st, cR, cT);                            /* :642-657 */
+    std::vector<float> bestEpsilon, bestReprojections;              /* :649-650 */
+    std::vector<float> reprojections(3 * (size_t)N), epsilon(N), Jcbian(6 * (size_t)N), weights(N);
     std::vector<int> visible(N);
     int evaluated = 0;
 
     for (int itr = 0; itr < maxIterations; itr++) {                /* :658 */
         float cR_32[9], cT_32[3];
-        for (int k = 0; k < 9; k++) cR_32[k] = (float)cR[k];       /* :673 */
-        for (int k = 0; k < 3; k++) cT_32[k] = (float)cT[k];       /* :674 */
+        for (int k = 0; k < 9; k++) cR_32[k] = (float)st.R[k];     /* :673 */
+        for (int k = 0; k < 3; k++) cT_32[k] = (float)st.t[k];     /* :674 */
         dvo_oracle_eval_points(prm, level, xyz, N, dt, gx, gy, rows, cols, fx, fy, cx, cy,
                                cR_32, cT_32, reprojections.data(), Jcbian.data(),
                                epsilon.data(), weights.data(), visible.data());   /* :675, :687 */
-        int notJ = 0;
-        for (int i = 0; i < N; i++) if (!visible[i]) notJ++;
-        const float ratio_of_visible_pts = (float)(N - notJ) / (float)N;          /* :457 */
-
-        /* aggregateEpsilons (:1310-1312) = epsilon.norm().  Oracle definition:
-         * (float)sqrt(sum of (double)eps^2), order-insensitive before narrowing. */
-        double sum_eps2 = 0.0;
-        for (int i = 0; i < N; i++) sum_eps2 += (double)epsilon[i] * (double)epsilon[i];
-        const float currentTotalEpsilon = (float)std::sqrt(sum_eps2);
-        energyAtEachIteration[itr] = currentTotalEpsilon;          /* :690 */
+        double acc[29];
+        accumulate_from(Jcbian.data(), epsilon.data(), weights.data(), visible.data(), N, acc);   /* :714-720, :777 */
+        const int prevBest = st.bestItr;
+        float energy;
+        double psi[6];
+        const int broke = dvo_oracle_state_update(prm, &st, itr, N, acc + 21, acc[27], (int)acc[28], &energy, psi);
+        energyAtEachIteration[itr] = energy;                        /* :690 */
         evaluated = itr + 1;
-
-        if (currentTotalEpsilon <= bestTotalEpsilon) {             /* :696 */
-            bestTotalEpsilon = currentTotalEpsilon;
-            bestRatioVisiblePts = ratio_of_visible_pts;
-            std::memcpy(bestcR, cR, sizeof(bestcR));
-            std::memcpy(bestcT, cT, sizeof(bestcT));
-            bestItrNumber = itr;
+        if (st.bestItr != prevBest) {                               /* :703-704 */
             bestEpsilon = epsilon;
             bestReprojections = reprojections;
         }
-
-        /* :714-720, :777  g = (J^T W)_64 * eps_64 with (J_ik*w_i) rounded to float first */
-        double g[6] = {0, 0, 0, 0, 0, 0};
-        double H[21];
-        for (int k = 0; k < 21; k++) H[k] = 0.0;
-        for (int i = 0; i < N; i++) {
-            float jw[6];
-            for (int k = 0; k < 6; k++) jw[k] = Jcbian[6 * i + k] * weights[i];   /* :716 */
-            for (int k = 0; k < 6; k++) g[k] += (double)jw[k] * (double)epsilon[i];
-            /* H = sum w J J^T (upper triangle, row-major order 00,01,..,05,11,..,55);
-             * not used by the reference policy -- SURVEY F1. */
-            int h = 0;
-            for (int a = 0; a < 6; a++)
-                for (int b = a; b < 6; b++) H[h++] += (double)jw[a] * (double)Jcbian[6 * i + b];
-        }
         if (trace) {
-            std::memcpy(trace[itr].g, g, sizeof(g));
-            std::memcpy(trace[itr].H, H, sizeof(H));
-            trace[itr].sum_eps2 = sum_eps2;
-            trace[itr].energy = currentTotalEpsilon;
-            trace[itr].n_visible = N - notJ;
-            trace[itr].broke = 0;
-            for (int k = 0; k < 6; k++) trace[itr].psi[k] = 0.0;
-        }
-
-        /* :724-730 pre-conditioner */
-        double PVec[6] = {1.0, 1.0, 1.0, prm->precond_rot, prm->precond_rot, prm->precond_rot};
-
-        /* :734-743 L2 regulariser direction */
-        double cPsi[6] = {0, 0, 0, 0, 0, 0};
-        if (prm->enable_l2_reg) {
-            dvo_oracle_se3_log(cR, cT, cPsi);
-            const double n = norm_n(cPsi, 6);
-            if (n > 0) for (int k = 0; k < 6; k++) cPsi[k] = cPsi[k] / n;
-        }
-
-        /* :773 */
-        stepLength = prm->step_a * prm->step_b /
-                     ((itr > prm->step_decay_after) ? (double)(itr - prm->step_decay_offset) : 1.0);
-
-        if (prm->enable_l2_reg)
-            for (int k = 0; k < 6; k++) g[k] += prm->reg_lambda * cPsi[k];        /* :796 */
-
-        for (int k = 0; k < 6; k++)                                 /* :799, 1.0f-BETA promotes to double */
-            descentDirection[k] = (1.0f - BETA) * g[k] + BETA * descentDirection[k];
-        for (int k = 0; k < 6; k++) g_prev[k] = g[k];               /* :805 (unused) */
-        (void)g_prev;
-
-        double psi[6];
-        for (int k = 0; k < 6; k++) psi[k] = -stepLength * PVec[k] * descentDirection[k];   /* :821 */
-
-        const double norm = norm_n(psi, 6);                         /* :832 */
-        if (norm > (double)prm->trust_radius) {                     /* :835 */
-            for (int k = 0; k < 6; k++) psi[k] = psi[k] / norm * (double)prm->trust_radius;   /* :837 */
-        }
-        /* :840 dangling else binds to :872; behaviourally "clamp, then test" (quirk Q5) */
-        if (norm_n(psi, 6) < (double)prm->psi_norm_stop) {          /* :872 */
-            if (trace) {
-                trace[itr].broke = 1;
-                std::memcpy(trace[itr].R, cR, sizeof(double) * 9);
-                std::memcpy(trace[itr].t, cT, sizeof(double) * 3);
-            }
-            break;                                                  /* :877 */
-        }
-
-        double xRot[9], xTrans[3];
-        dvo_oracle_se3_exp(psi, xRot, xTrans);                      /* :905-907 */
-        double dT[3];
-        mat3_vec(cR, xTrans, dT);
-        for (int k = 0; k < 3; k++) cT[k] += dT[k];                 /* :916 */
-        mat3_mul(cR, xRot, cR);                                     /* :917 */
-        if (prm->enable_rotationize) dvo_oracle_rotationize(cR);    /* :919 */
-
-        if (trace) {
+            std::memcpy(trace[itr].g, acc + 21, sizeof(double) * 6);
+            std::memcpy(trace[itr].H, acc, sizeof(double) * 21);
+            trace[itr].sum_eps2 = acc[27];
+            trace[itr].energy = energy;
+            trace[itr].n_visible = (int)acc[28];
+            trace[itr].broke = broke;
             std::memcpy(trace[itr].psi, psi, sizeof(psi));
-            std::memcpy(trace[itr].R, cR, sizeof(double) * 9);
-            std::memcpy(trace[itr].t, cT, sizeof(double) * 3);
+            std::memcpy(trace[itr].R, st.R, sizeof(double) * 9);
+            std::memcpy(trace[itr].t, st.t, sizeof(double) * 3);
         }
+        if (broke) break;                                           /* :877 */
     }
 
-    std::memcpy(cR, bestcR, sizeof(bestcR));                        /* :997 */
-    if (prm->enable_rotationize) dvo_oracle_rotationize(cR);        /* :999 */
-    std::memcpy(cT, bestcT, sizeof(bestcT));                        /* :1001 */
+    dvo_oracle_state_finish(prm, &st, cR, cT);                      /* :997-1001 */
     if (finalEpsilons && !bestEpsilon.empty())
         std::memcpy(finalEpsilons, bestEpsilon.data(), sizeof(float) * (size_t)N);         /* :1002 */
     if (finalReprojections && !bestReprojections.empty())
         std::memcpy(finalReprojections, bestReprojections.data(), sizeof(float) * 3 * (size_t)N);   /* :1003 */
-    *bestEnergyIndex = bestItrNumber;                               /* :1004 */
-    *finalVisibleRatio = bestRatioVisiblePts;                       /* :1005 */
-    (void)stepLength;
+    *bestEnergyIndex = st.bestItr;                                  /* :1004 */
+    *finalVisibleRatio = st.bestRatio;                              /* :1005 */
     return evaluated;
 }
 

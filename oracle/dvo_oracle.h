@@ -105,6 +105,27 @@ int dvo_oracle_run_iterations(const dvo_oracle_params *prm, int level, int max_i
                               int *best_idx, float *visible_ratio,
                               dvo_oracle_iter_trace *trace);
 
+/* The 29 sums of one evaluation over points [first, first+n): acc[0..20] = upper triangle of
+ * sum w J J^T, acc[21..26] = g, acc[27] = sum eps^2, acc[28] = n_visible. */
+void dvo_oracle_accumulate(const dvo_oracle_params *prm, int level, const float *xyz, int first, int n,
+                           const float *dt, const float *gx, const float *gy, int rows, int cols,
+                           float fx, float fy, float cx, float cy,
+                           const float *Rf, const float *tf, double *acc29);
+
+/* runIterations as an explicit state machine (what run_iterations itself uses), so that a
+ * host-driven loop -- e.g. the multi-GPU tiled mode with an all-reduce between the per-point
+ * phase and the update -- can be checked step by step. */
+typedef struct dvo_oracle_state {
+    double R[9], t[3], d[6], bestR[9], bestT[3];
+    float bestE, bestRatio;
+    int bestItr, stop;
+} dvo_oracle_state;
+void dvo_oracle_state_begin(dvo_oracle_state *s, const double *R, const double *t);
+int  dvo_oracle_state_update(const dvo_oracle_params *prm, dvo_oracle_state *s, int itr, int N,
+                             const double *g6, double sum_eps2, int n_vis, float *energy_out,
+                             double *psi_out /* may be NULL */);
+void dvo_oracle_state_finish(const dvo_oracle_params *prm, dvo_oracle_state *s, double *R, double *t);
+
 /* :2097-2104: for f = n_levels-1 .. 0: if iters[f] > 0: runIterations(f, ...).
  * Per-level inputs are arrays of pointers / sizes indexed by level.
  * energy_out: concatenated per level in LEVEL order (level 0 first), each block

@@ -29,7 +29,7 @@ C_ABI_SYMBOLS = [
     "dvo_set_poses", "dvo_align_batch_enqueue", "dvo_get_poses", "dvo_get_level_report",
     "dvo_get_final_outputs", "dvo_eval_points", "dvo_accumulate", "dvo_device_se3_exp",
     "dvo_device_se3_log", "dvo_device_rotationize", "dvo_algorithmic_bytes", "dvo_point_iterations",
-    "dvo_debug_stamps",
+    "dvo_debug_stamps", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
 ]
 
 
@@ -111,6 +111,10 @@ def load_library() -> C.CDLL:
         "dvo_device_se3_log": [vp, vp, vp, vp],
         "dvo_device_rotationize": [vp, vp],
         "dvo_debug_stamps": [vp, i, vp],
+        "dvo_iter_begin": [vp, i, i, i, vp, vp],
+        "dvo_iter_accumulate": [vp, i, i, i, i, vp],
+        "dvo_iter_update": [vp, i, i, i, i, vp],
+        "dvo_iter_end": [vp, i, i, vp, vp, vp, ip, fp],
         "dvo_algorithmic_bytes": [vp, i, i, ip, i, C.POINTER(C.c_uint64)],
         "dvo_point_iterations": [vp, i, i, ip, C.POINTER(C.c_uint64)],
     }
@@ -286,6 +290,30 @@ class DvoContext:
         n = C.c_int(0)
         self._chk(self.lib.dvo_get_final_outputs(self._h, pair, _ptr(feps), _ptr(frep), capacity, C.byref(n)))
         return feps[:n.value].copy(), frep[:3 * n.value].reshape(-1, 3).copy()
+
+    # -- host-driven iteration (large frames / multi-GPU tiled mode) ---------
+    def n_points(self, level: int, pair: int = 0) -> int:
+        return self._N[(pair, level)]
+
+    def iter_begin(self, level: int, max_iters: int, R, t, pair: int = 0):
+        R = np.array(R, dtype=np.float64, order="F")
+        t = np.array(t, dtype=np.float64)
+        self._chk(self.lib.dvo_iter_begin(self._h, pair, level, max_iters, _ptr(R), _ptr(t)))
+        self._iter_max = max_iters
+
+    def iter_accumulate(self, level: int, first: int, count: int, d_acc32_ptr: int, pair: int = 0):
+        self._chk(self.lib.dvo_iter_accumulate(self._h, pair, level, first, count, C.c_void_p(d_acc32_ptr)))
+
+    def iter_update(self, level: int, itr: int, n_total: int, d_acc32_ptr: int, pair: int = 0):
+        self._chk(self.lib.dvo_iter_update(self._h, pair, level, itr, n_total, C.c_void_p(d_acc32_ptr)))
+
+    def iter_end(self, level: int, pair: int = 0):
+        R, t = np.zeros((3, 3), order="F"), np.zeros(3)
+        energy = np.zeros(self._iter_max, np.float32)
+        best, ratio = C.c_int(-2), C.c_float(0)
+        self._chk(self.lib.dvo_iter_end(self._h, pair, level, _ptr(R), _ptr(t), _ptr(energy), C.byref(best),
+                                        C.byref(ratio)))
+        return dict(R=R, t=t, energy=energy, best_idx=best.value, visible_ratio=ratio.value)
 
     # -- inspection -----------------------------------------------------------
     def eval_points(self, level: int, R, t, pair: int = 0):

@@ -58,6 +58,10 @@ struct dvo_ctx {
     int final_cap = 0;
     double *d_scratch = nullptr;    /* partials (1024 x 32) + acc (32) + misc doubles */
     unsigned long long *d_dbg = nullptr;
+    char *d_states = nullptr;       /* n_pairs x pose_state_bytes(): host-driven iteration state */
+    float *d_iter_energy = nullptr; /* n_pairs x iter_energy_cap */
+    int iter_energy_cap = 0;
+    std::vector<int> iter_max;      /* per pair: max_iters of the running dvo_iter_begin (0 = none) */
     int *d_colcounts = nullptr;
     size_t colcounts_cap = 0;
     Schedule sched{};
@@ -333,7 +337,8 @@ int dvo_destroy(dvo_ctx *c) {
         if (c->lv[l].dN) (void)hipFree(c->lv[l].dN);
     }
     void *ptrs[] = {c->staging, c->d_poses, c->d_energy, c->d_best, c->d_ratio, c->d_final_eps,
-                    c->d_final_reproj, c->d_final_N, c->d_scratch, c->d_colcounts, c->d_dbg};
+                    c->d_final_reproj, c->d_final_N, c->d_scratch, c->d_colcounts, c->d_dbg,
+                    c->d_states, c->d_iter_energy};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -586,6 +591,78 @@ int dvo_run_iterations(dvo_ctx *c, int level, int max_iters, double *R, double *
                        int *best_idx, float *visible_ratio) {
     return dvo_run_iterations_pair(c, 0, level, max_iters, R, t, energy, final_eps, final_reproj,
                                    best_idx, visible_ratio);
+}
+
+/* ---- host-driven iteration ------------------------------------------------------ */
+int dvo_iter_begin(dvo_ctx *c, int pair, int level, int max_iters, const double *R, const double *t) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair) || !level_ok(level) || max_iters < 1 || !R || !t) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    int rc = check_ready(c, pair, level);
+    if (rc) return rc;
+    if (!c->d_states) {
+        HIPCHK(c, hipMalloc((void **)&c->d_states, pose_state_bytes() * c->n_pairs));
+        c->iter_max.assign(c->n_pairs, 0);
+    }
+    if (max_iters > c->iter_energy_cap) {
+        if (c->d_iter_energy) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->d_iter_energy)); }
+        const int cap = std::max(max_iters, 64);
+        HIPCHK(c, hipMalloc((void **)&c->d_iter_energy, sizeof(float) * (size_t)cap * c->n_pairs));
+        c->iter_energy_cap = cap;
+    }
+    double h[12];
+    std::memcpy(h, R, sizeof(double) * 9);
+    std::memcpy(h + 9, t, sizeof(double) * 3);
+    double *d_pose = c->d_poses + (size_t)12 * pair;
+    HIPCHK(c, hipMemcpyAsync(d_pose, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_iter_begin(c->d_states + pose_state_bytes() * pair, d_pose,
+                                c->d_iter_energy + (size_t)c->iter_energy_cap * pair, max_iters, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));     /* h is a stack buffer */
+    c->iter_max[pair] = max_iters;
+    return DVO_OK;
+}
+
+int dvo_iter_accumulate(dvo_ctx *c, int pair, int level, int first_point, int n_points, double *d_acc32) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair) || !level_ok(level) || !d_acc32) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    if (!c->d_states || c->iter_max[pair] == 0) return fail(c, DVO_ERR_STATE, "dvo_iter_begin has not been called for this pair");
+    const int N = c->lv[level].hN.empty() ? 0 : c->lv[level].hN[pair];
+    if (first_point < 0 || n_points < 0 || first_point + n_points > N) return fail(c, DVO_ERR_INVALID, "point range out of bounds");
+    const int nb = accumulate_blocks_for(n_points);
+    HIPCHK(c, launch_iter_accumulate(slab_of(c, level), pair, level, c->K, c->d_states + pose_state_bytes() * pair,
+                                     first_point, n_points, c->d_scratch, nb, d_acc32, c->stream));
+    return DVO_OK;
+}
+
+int dvo_iter_update(dvo_ctx *c, int pair, int level, int itr, int n_total, const double *d_acc32) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair) || !level_ok(level) || !d_acc32 || n_total < 1) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    if (!c->d_states || c->iter_max[pair] == 0) return fail(c, DVO_ERR_STATE, "dvo_iter_begin has not been called for this pair");
+    if (itr < 0 || itr >= c->iter_max[pair]) return fail(c, DVO_ERR_INVALID, "iteration index out of range");
+    HIPCHK(c, launch_iter_update(c->d_states + pose_state_bytes() * pair, c->dprm, itr, n_total, d_acc32,
+                                 c->d_iter_energy + (size_t)c->iter_energy_cap * pair, c->stream));
+    return DVO_OK;
+}
+
+int dvo_iter_end(dvo_ctx *c, int pair, int level, double *R, double *t, float *energy, int *best_idx,
+                 float *visible_ratio) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair) || !level_ok(level) || !R || !t) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    if (!c->d_states || c->iter_max[pair] == 0) return fail(c, DVO_ERR_STATE, "dvo_iter_begin has not been called for this pair");
+    double *d_pose = c->d_poses + (size_t)12 * pair;
+    HIPCHK(c, launch_iter_end(c->d_states + pose_state_bytes() * pair, d_pose, c->d_best + pair * DVO_LEVELS + level,
+                              c->d_ratio + pair * DVO_LEVELS + level, c->stream));
+    double h[12];
+    HIPCHK(c, hipMemcpyAsync(h, d_pose, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    if (energy)
+        HIPCHK(c, hipMemcpyAsync(energy, c->d_iter_energy + (size_t)c->iter_energy_cap * pair,
+                                 sizeof(float) * c->iter_max[pair], hipMemcpyDeviceToHost, c->stream));
+    if (best_idx) HIPCHK(c, hipMemcpyAsync(best_idx, c->d_best + pair * DVO_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (visible_ratio) HIPCHK(c, hipMemcpyAsync(visible_ratio, c->d_ratio + pair * DVO_LEVELS + level, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(R, h, sizeof(double) * 9);
+    std::memcpy(t, h + 9, sizeof(double) * 3);
+    c->iter_max[pair] = 0;
+    return DVO_OK;
 }
 
 /* ---- inspection ------------------------------------------------------------- */

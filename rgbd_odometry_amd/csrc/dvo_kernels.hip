@@ -74,11 +74,13 @@ DVO_DEV void acc_add(Acc &a, const float *J, float eps, float w) {
     }
     a.e2 = fma(e, e, a.e2);
     if (WITH_H) {
-        int h = 0;
+        /* upper triangle, row-major: index(i,j) = i*6 - i*(i-1)/2 + (j-i); written with
+         * compile-time indices so H stays in registers */
 #pragma unroll
         for (int i = 0; i < 6; i++)
 #pragma unroll
-            for (int j = i; j < 6; j++) { a.H[h] = fmaf(jw[i], J[j], a.H[h]); h++; }
+            for (int j = 0; j < 6; j++)
+                if (j >= i) a.H[i * 6 - (i * (i - 1)) / 2 + (j - i)] = fmaf(jw[i], J[j], a.H[i * 6 - (i * (i - 1)) / 2 + (j - i)]);
     }
 }
 
@@ -190,23 +192,29 @@ DVO_DEV void accumulate_points(const IterConst &c, const float4 *__restrict__ te
  * lane bits are folded with plain xor steps.  On return every lane L holds, in
  * v[0], the wave total of value index L >> (6 - log2 NV).  Fixed shape:
  * deterministic. */
+template <typename T, int NV, int HALF, int BIT>
+struct ReduceScatterStep {
+    static DVO_DEV void run(T (&v)[NV], int lane) {
+        const bool up = (lane & BIT) != 0;
+#pragma unroll
+        for (int j = 0; j < HALF; j++) {
+            const T keep = up ? v[j + HALF] : v[j];
+            const T send = up ? v[j] : v[j + HALF];
+            v[j] = keep + __shfl_xor(send, BIT, 64);
+        }
+        ReduceScatterStep<T, NV, HALF / 2, BIT / 2>::run(v, lane);
+    }
+};
+template <typename T, int NV, int BIT>
+struct ReduceScatterStep<T, NV, 0, BIT> {          /* one value per lane left: fold the remaining lane bits */
+    static DVO_DEV void run(T (&v)[NV], int) {
+#pragma unroll
+        for (int b = BIT; b >= 1; b >>= 1) v[0] += __shfl_xor(v[0], b, 64);
+    }
+};
 template <typename T, int NV>
 DVO_DEV void wave_reduce_scatter(T (&v)[NV]) {
-    const int lane = threadIdx.x & 63;
-    int bit = 32;
-#pragma unroll
-    for (int half = NV / 2; half >= 1; half >>= 1) {
-        const bool up = (lane & bit) != 0;
-#pragma unroll
-        for (int j = 0; j < half; j++) {
-            const T keep = up ? v[j + half] : v[j];
-            const T send = up ? v[j] : v[j + half];
-            v[j] = keep + __shfl_xor(send, bit, 64);
-        }
-        bit >>= 1;
-    }
-#pragma unroll
-    for (; bit >= 1; bit >>= 1) v[0] += __shfl_xor(v[0], bit, 64);
+    ReduceScatterStep<T, NV, NV / 2, 32>::run(v, threadIdx.x & 63);   /* all indices are compile-time */
 }
 
 /* Fixed-shape reduction of the 29 accumulators over a workgroup.
@@ -538,6 +546,94 @@ hipError_t launch_accumulate(const LevelSlab &L, int pair, int level, const Intr
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, s, partials, nblocks, acc);
     return hipGetLastError();
 }
+
+/* ------------------------------------------------------------------------- */
+/* host-driven iteration (large single frames, multi-GPU tiled mode):          */
+/* the optimiser state lives in HBM, one PoseState per pair                    */
+/* ------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(64)
+iter_begin_kernel(PoseState *st, const double *Rt12, float *energy, int max_iters) {
+    if (threadIdx.x == 0) {
+        double R[9], t[3];
+        for (int k = 0; k < 9; k++) R[k] = Rt12[k];
+        for (int k = 0; k < 3; k++) t[k] = Rt12[9 + k];
+        pose_state_load(*st, R, t);
+        pose_state_begin(*st);
+    }
+    for (int i = threadIdx.x; i < max_iters; i += 64) energy[i] = 0.0f;      /* :634 */
+}
+
+/* same as accumulate_kernel, but the float pose is read from the device-resident state */
+__global__ void __launch_bounds__(256)
+accumulate_state_kernel(LevelSlab L, int pair, int level, Intrinsics K, const PoseState *st,
+                        int first, int n, double *__restrict__ partials) {
+    __shared__ double red[256 / 64][DVO_NACC_PAD];
+    __shared__ double tot[DVO_NACC_PAD];
+    const float4 *__restrict__ tex = L.tex + (size_t)pair * L.tex_stride;
+    const float *__restrict__ pts = L.pts + (size_t)pair * L.pt_cap * 3;
+    IterConst c;
+    level_consts(c, K, level, L.rows, L.cols);
+#pragma unroll
+    for (int k = 0; k < 9; k++) c.r[k] = uniform_f(st->Rf[k]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) c.t[k] = uniform_f(st->tf[k]);
+    Acc a;
+    acc_zero(a);
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int b0 = first + blockIdx.x * per;
+    int b1 = b0 + per;
+    if (b1 > first + n) b1 = first + n;
+    PointSrc psrc;
+    psrc.g = pts; psrc.l = nullptr; psrc.n_lds = 0; psrc.cap = 0;
+    if (b0 < b1) accumulate_points<2, true, false>(c, tex, psrc, b0, b1, threadIdx.x, 256, a);
+    block_reduce<256, true>(a, red, tot);
+    if (threadIdx.x < DVO_NACC_PAD)
+        partials[(size_t)blockIdx.x * DVO_NACC_PAD + threadIdx.x] = (threadIdx.x < DVO_NACC) ? tot[threadIdx.x] : 0.0;
+}
+
+__global__ void __launch_bounds__(64)
+iter_update_kernel(PoseState *st, DevParams prm, int itr, int n_total, const double *__restrict__ acc,
+                   float *energy) {
+    if (threadIdx.x == 0 && !st->stop) {                                    /* after :877 nothing runs */
+        double g[6];
+        for (int k = 0; k < 6; k++) g[k] = acc[21 + k];
+        energy[itr] = pose_update(*st, prm, itr, n_total, g, acc[27], (int)acc[28]);
+    }
+}
+
+__global__ void __launch_bounds__(64)
+iter_end_kernel(PoseState *st, double *Rt12, int *best_idx, float *ratio) {
+    if (threadIdx.x == 0) {
+        pose_state_finish(*st);                                             /* :997-1001 */
+        for (int k = 0; k < 9; k++) Rt12[k] = st->R[k];
+        for (int k = 0; k < 3; k++) Rt12[9 + k] = st->t[k];
+        *best_idx = st->bestItr;
+        *ratio = st->bestRatio;
+    }
+}
+
+hipError_t launch_iter_begin(void *state, const double *Rt12, float *energy, int max_iters, hipStream_t s) {
+    hipLaunchKernelGGL(iter_begin_kernel, dim3(1), dim3(64), 0, s, (PoseState *)state, Rt12, energy, max_iters);
+    return hipGetLastError();
+}
+hipError_t launch_iter_accumulate(const LevelSlab &L, int pair, int level, const Intrinsics &K, const void *state,
+                                  int first_point, int n_points, double *partials, int nblocks, double *acc,
+                                  hipStream_t s) {
+    hipLaunchKernelGGL(accumulate_state_kernel, dim3(nblocks), dim3(256), 0, s, L, pair, level, K,
+                       (const PoseState *)state, first_point, n_points, partials);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, s, partials, nblocks, acc);
+    return hipGetLastError();
+}
+hipError_t launch_iter_update(void *state, const DevParams &prm, int itr, int n_total, const double *acc,
+                              float *energy, hipStream_t s) {
+    hipLaunchKernelGGL(iter_update_kernel, dim3(1), dim3(64), 0, s, (PoseState *)state, prm, itr, n_total, acc, energy);
+    return hipGetLastError();
+}
+hipError_t launch_iter_end(void *state, double *Rt12, int *best_idx, float *ratio, hipStream_t s) {
+    hipLaunchKernelGGL(iter_end_kernel, dim3(1), dim3(64), 0, s, (PoseState *)state, Rt12, best_idx, ratio);
+    return hipGetLastError();
+}
+size_t pose_state_bytes() { return sizeof(PoseState); }
 
 /* ------------------------------------------------------------------------- */
 /* SE(3) helpers on one lane (property tests of the device math)               */

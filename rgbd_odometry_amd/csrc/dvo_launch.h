@@ -72,6 +72,15 @@ hipError_t launch_accumulate(const LevelSlab &L, int pair, int level, const Intr
                              const float *Rf, const float *tf, int first_point, int n_points,
                              double *partials, int nblocks, double *acc, hipStream_t s);
 int accumulate_blocks_for(int n_points);
+/* host-driven iteration: optimiser state (opaque, pose_state_bytes() each) in HBM */
+size_t pose_state_bytes();
+hipError_t launch_iter_begin(void *state, const double *Rt12, float *energy, int max_iters, hipStream_t s);
+hipError_t launch_iter_accumulate(const LevelSlab &L, int pair, int level, const Intrinsics &K, const void *state,
+                                  int first_point, int n_points, double *partials, int nblocks, double *acc,
+                                  hipStream_t s);
+hipError_t launch_iter_update(void *state, const DevParams &prm, int itr, int n_total, const double *acc,
+                              float *energy, hipStream_t s);
+hipError_t launch_iter_end(void *state, double *Rt12, int *best_idx, float *ratio, hipStream_t s);
 /* SE(3) helpers on one lane (property tests) */
 hipError_t launch_se3_exp(const double *psi, double *Rt12, hipStream_t s);
 hipError_t launch_se3_log(const double *Rt12, double *psi, hipStream_t s);

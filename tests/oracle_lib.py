@@ -33,6 +33,14 @@ class IterTrace(C.Structure):
     ]
 
 
+class OracleState(C.Structure):
+    _fields_ = [
+        ("R", C.c_double * 9), ("t", C.c_double * 3), ("d", C.c_double * 6),
+        ("bestR", C.c_double * 9), ("bestT", C.c_double * 3),
+        ("bestE", C.c_float), ("bestRatio", C.c_float), ("bestItr", C.c_int), ("stop", C.c_int),
+    ]
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
 
@@ -106,6 +114,43 @@ class Oracle:
                                  n_visible=x.n_visible, broke=x.broke) for x in tr[:nit]]
         return out
 
+    def accumulate(self, level, xyz, first, n, dt, gx, gy, rows, cols, K, R, t, params=None):
+        """29 accumulators over points [first, first+n) at the float cast of (R, t)."""
+        xyz = _f32(xyz).reshape(-1)
+        Rf = np.asfortranarray(np.asarray(R, dtype=np.float64)).astype(np.float32, order="F")
+        tf = np.asarray(t, dtype=np.float64).astype(np.float32)
+        acc = np.zeros(29)
+        self.lib.dvo_oracle_accumulate(C.byref(params) if params is not None else C.byref(self.default_params()),
+                                       level, _p(xyz), first, n, _p(_f32(dt)), _p(_f32(gx)), _p(_f32(gy)), rows, cols,
+                                       *[C.c_float(k) for k in K], _p(Rf), _p(tf), _p(acc))
+        return acc
+
+    def state_begin(self, R, t) -> OracleState:
+        st = OracleState()
+        R = np.array(R, dtype=np.float64, order="F")
+        t = np.array(t, dtype=np.float64)
+        self.lib.dvo_oracle_state_begin(C.byref(st), _p(R), _p(t))
+        return st
+
+    def state_update(self, st: OracleState, itr, N, g6, sum_eps2, n_vis, params=None):
+        g6 = np.array(g6, dtype=np.float64)
+        e = C.c_float(0)
+        psi = np.zeros(6)
+        p = params if params is not None else self.default_params()
+        broke = self.lib.dvo_oracle_state_update(C.byref(p), C.byref(st), itr, N, _p(g6), C.c_double(sum_eps2),
+                                                 int(n_vis), C.byref(e), _p(psi))
+        return e.value, bool(broke), psi
+
+    def state_finish(self, st: OracleState, params=None):
+        R, t = np.zeros((3, 3), order="F"), np.zeros(3)
+        p = params if params is not None else self.default_params()
+        self.lib.dvo_oracle_state_finish(C.byref(p), C.byref(st), _p(R), _p(t))
+        return R, t
+
+    @staticmethod
+    def state_pose(st: OracleState):
+        return np.array(st.R).reshape(3, 3, order="F"), np.array(st.t)
+
     def align_pyramid(self, iters, levels, K, R, t, params=None):
         """levels: list of dict(xyz, dt, gx, gy, rows, cols).  Coarse-to-fine schedule of SolveDVO::loop."""
         R = np.array(R, dtype=np.float64, order="F").copy(order="F")
@@ -170,6 +215,16 @@ def load() -> Oracle:
         lib.dvo_oracle_run_iterations.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                                   C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 4 + \
             [C.c_void_p] * 5 + [C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_void_p]
+        lib.dvo_oracle_accumulate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_void_p] * 3
+        lib.dvo_oracle_accumulate.restype = None
+        lib.dvo_oracle_state_begin.argtypes = [C.c_void_p] * 3
+        lib.dvo_oracle_state_begin.restype = None
+        lib.dvo_oracle_state_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double,
+                                                C.c_int, C.POINTER(C.c_float), C.c_void_p]
+        lib.dvo_oracle_state_update.restype = C.c_int
+        lib.dvo_oracle_state_finish.argtypes = [C.c_void_p] * 4
+        lib.dvo_oracle_state_finish.restype = None
         for n in ("se3_exp", "se3_log"):
             getattr(lib, "dvo_oracle_" + n).argtypes = [C.c_void_p] * 3
         lib.dvo_oracle_rotationize.argtypes = [C.c_void_p]
