@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Tiled / large-frame mode (BASELINE configs[4] and [2]): ONE frame pair, host-driven iterations
+(dvo_iter_*), point list sharded over the ranks, per-iteration all-reduce of 32 doubles (RCCL) when
+WORLD_SIZE > 1.   python tools/bench_tiled.py --width 4096 --height 3072 --levels 5 --iters 10
+Under torchrun every rank builds the same scene (same seed) and holds the full now-pyramid."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--width", type=int, default=4096); ap.add_argument("--height", type=int, default=3072)
+ap.add_argument("--levels", type=int, default=5); ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=1)
+ap.add_argument("--seed", type=int, default=7); ap.add_argument("--fused", action="store_true", help="also time the one-workgroup fused kernel")
+args = ap.parse_args()
+rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
+torch.cuda.set_device(local)
+import torch.distributed as dist
+if world > 1:
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+from rgbd_odometry_amd import DvoContext, SynthScene
+from rgbd_odometry_amd.distributed import HipTiledEngine, TiledAligner
+t0 = time.time(); sc = SynthScene(args.width, args.height, args.levels, args.seed); tgen = time.time() - t0
+ctx = DvoContext(1)
+ctx.set_intrinsics(*sc.intrinsics)
+N = []
+for l, L in enumerate(sc.levels):
+    xyz, _ = ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols)
+    ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols)
+    N.append(len(xyz))
+iters = [args.iters] * args.levels
+al = TiledAligner(HipTiledEngine(ctx))
+def run():
+    return al.align(iters, np.eye(3), np.zeros(3))
+for _ in range(args.warmup): res = run()
+torch.cuda.synchronize()
+if world > 1: dist.barrier()
+t0 = time.perf_counter()
+for _ in range(args.steps): res = run()
+torch.cuda.synchronize()
+if world > 1: dist.barrier()
+dt = (time.perf_counter() - t0) / args.steps
+out = dict(mode="tiled", n_gpus=world, width=args.width, height=args.height, levels=args.levels, iters=args.iters,
+           points_per_level=N, ms_per_alignment=1e3 * dt, aligns_per_s=1.0 / dt,
+           us_per_iteration=1e6 * dt / sum(iters), scene_gen_s=tgen,
+           algorithmic_bytes=ctx.algorithmic_bytes(iters), rot_err_vs_truth=float(np.arccos(np.clip((np.trace(sc.R_true.T @ res["R"]) - 1) / 2, -1, 1))))
+out["algorithmic_GBps"] = out["algorithmic_bytes"] / dt / 1e9
+if args.fused and world == 1:
+    ctx.use_own_stream()
+    R, t = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
+    t0 = time.perf_counter()
+    for _ in range(args.steps): R, t = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
+    out["fused_one_workgroup_ms"] = 1e3 * (time.perf_counter() - t0) / args.steps
+    out["fused_vs_tiled_pose_maxdiff"] = float(max(np.abs(R[0] - res["R"]).max(), np.abs(t[0] - res["t"]).max()))
+if rank == 0: print(json.dumps(out))
+if world > 1: dist.destroy_process_group()
