@@ -56,23 +56,11 @@ def build_batch(ctx, args, rank):
     D = max(1, min(args.distinct, args.batch))
     scenes = [SynthScene(args.width, args.height, args.levels, 1000 + rank * D + i) for i in range(D)]
     ctx.set_intrinsics(*scenes[0].intrinsics)
-    dev = torch.device("cuda", torch.cuda.current_device())
-    planes = []     # per distinct scene, per level: device tensors dt, gx, gy, xyz
     for i, sc in enumerate(scenes):
-        per_level = []
         for l, L in enumerate(sc.levels):
-            xyz, _ = ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols, pair=i)
-            per_level.append(dict(
-                dt=torch.from_numpy(L.now_dt).to(dev), gx=torch.from_numpy(L.now_gx).to(dev),
-                gy=torch.from_numpy(L.now_gy).to(dev), xyz=torch.from_numpy(xyz.reshape(-1)).to(dev),
-                n=xyz.shape[0], rows=L.rows, cols=L.cols))
-        planes.append(per_level)
-    torch.cuda.synchronize()
-    for p in range(args.batch):
-        for l, T in enumerate(planes[p % D]):
-            ctx.set_ref_level_device(l, T["xyz"].data_ptr(), T["n"], pair=p)
-            ctx.set_now_level_device(l, T["dt"].data_ptr(), T["gx"].data_ptr(), T["gy"].data_ptr(),
-                                     T["rows"], T["cols"], pair=p)
+            ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols, pair=i)   # GPU enlistRefEdgePts
+            ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols, pair=i)
+    ctx.replicate_pairs(D)          # slots D.. <- device copies of the D distinct pairs (own HBM each)
     ctx.synchronize()
     return scenes
 
@@ -190,7 +178,8 @@ def main():
             try:
                 rec = json.load(open(pmc))
                 key = "%dx%dx%dx%d_b%d" % (args.width, args.height, args.levels, args.iters, args.batch)
-                if key in rec:
+                default_knobs = not (args.block or args.inflight or args.lds_point_bytes or args.debug_alias or args.no_final_outputs)
+                if key in rec and default_knobs:
                     out["roofline"]["traffic"] = rec[key]["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = rec[key].get("source")
             except Exception:

@@ -122,6 +122,11 @@ int  dvo_set_ref_level_device(dvo_ctx *ctx, int pair, int level, const float *d_
 int  dvo_set_now_level_device(dvo_ctx *ctx, int pair, int level, const float *d_dt, const float *d_gx,
                               const float *d_gy, int rows, int cols);
 
+/* Batch set-up helper: pair slot p in [dst_first, dst_first+dst_count) becomes a device-side copy of
+ * pair (p - dst_first) % n_src (all levels that are set), one launch per level.  dst_first = 0 leaves the
+ * sources in place and fills the rest of the range cyclically. */
+int  dvo_replicate_pairs(dvo_ctx *ctx, int n_src, int dst_first, int dst_count);
+
 /* selectedPts + enlistRefEdgePts (SolveDVO.cpp:1230-1264, :224-264) on the GPU:
  * edge (int32, >0 = edge) and depth_mm (f32), column-major rows x cols, host
  * pointers.  Builds the 3xN list in the reference's column-major scan order and

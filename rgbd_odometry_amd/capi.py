@@ -29,7 +29,7 @@ C_ABI_SYMBOLS = [
     "dvo_set_poses", "dvo_align_batch_enqueue", "dvo_get_poses", "dvo_get_level_report",
     "dvo_get_final_outputs", "dvo_eval_points", "dvo_accumulate", "dvo_device_se3_exp",
     "dvo_device_se3_log", "dvo_device_rotationize", "dvo_algorithmic_bytes", "dvo_point_iterations",
-    "dvo_debug_stamps", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
+    "dvo_debug_stamps", "dvo_replicate_pairs", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
 ]
 
 
@@ -111,6 +111,7 @@ def load_library() -> C.CDLL:
         "dvo_device_se3_log": [vp, vp, vp, vp],
         "dvo_device_rotationize": [vp, vp],
         "dvo_debug_stamps": [vp, i, vp],
+        "dvo_replicate_pairs": [vp, i, i, i],
         "dvo_iter_begin": [vp, i, i, i, vp, vp],
         "dvo_iter_accumulate": [vp, i, i, i, i, vp],
         "dvo_iter_update": [vp, i, i, i, i, vp],
@@ -216,6 +217,16 @@ class DvoContext:
         self._chk(self.lib.dvo_set_now_level_device(self._h, pair, level, C.c_void_p(d_dt), C.c_void_p(d_gx),
                                                     C.c_void_p(d_gy), rows, cols))
         self._dims[level] = (rows, cols)
+
+    def replicate_pairs(self, n_src: int, dst_first: int = 0, dst_count: Optional[int] = None):
+        """slot p <- device copy of pair (p - dst_first) % n_src, for every level that is set"""
+        dst_count = self.n_pairs - dst_first if dst_count is None else dst_count
+        self._chk(self.lib.dvo_replicate_pairs(self._h, n_src, dst_first, dst_count))
+        for (p, l), n in list(self._N.items()):
+            if p < n_src:
+                for q in range(dst_first, dst_first + dst_count):
+                    if (q - dst_first) % n_src == p:
+                        self._N[(q, l)] = n
 
     def set_ref_level_from_images(self, level: int, edge, depth_mm, rows: int, cols: int, pair: int = 0):
         """selectedPts + enlistRefEdgePts on the GPU; returns (xyz[N,3], uv[N,2])."""

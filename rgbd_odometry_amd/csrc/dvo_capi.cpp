@@ -483,6 +483,29 @@ int dvo_set_now_level_device(dvo_ctx *c, int pair, int level, const float *d_dt,
     return set_now_common(c, pair, level, d_dt, d_gx, d_gy, rows, cols, true);
 }
 
+/* replicate the first n_src pairs over [dst_first, dst_first+dst_count): slot p <- pair (p-dst_first) % n_src */
+int dvo_replicate_pairs(dvo_ctx *c, int n_src, int dst_first, int dst_count) {
+    if (!c) return DVO_ERR_INVALID;
+    if (n_src < 1 || dst_first < 0 || dst_count < 0 || dst_first + dst_count > c->n_pairs || n_src > c->n_pairs)
+        return fail(c, DVO_ERR_INVALID, "bad replicate arguments");
+    if (dst_first != 0 && dst_first < n_src) return fail(c, DVO_ERR_INVALID, "destination range overlaps the sources");
+    for (int l = 0; l < DVO_LEVELS; l++) {
+        Level &L = c->lv[l];
+        if (!L.tex && !L.pts) continue;
+        for (int p = 0; p < n_src; p++) {
+            int rc = check_ready(c, p, l);
+            if (rc) return rc;
+        }
+        HIPCHK(c, launch_replicate_level(L.tex, L.tex_stride, L.pts, L.pt_cap, L.dN, n_src, dst_first, dst_count, c->stream));
+        for (int p = dst_first; p < dst_first + dst_count; p++) {
+            L.hN[p] = L.hN[(p - dst_first) % n_src];
+            L.have_now[p] = 1;
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DVO_OK;
+}
+
 /* ---- hot path ---------------------------------------------------------------- */
 int dvo_set_poses(dvo_ctx *c, int first_pair, int n_pairs, const double *R, const double *t) {
     if (!c) return DVO_ERR_INVALID;

@@ -38,6 +38,7 @@ struct IterConst {
     float r[9];      /* cR, column-major */
     float t[3];      /* cT */
     float m00, m02, m11, m12;   /* s*fx, s*cx, s*fy, s*cy  (float products) */
+    float m00_z1, m11_z1;       /* m00/(1-2^-24), m11/(1-2^-24): A1(0,0), A1(1,1) when Z = 1-2^-24 */
     float ncols_f, nrows_f;
     int rows;
     int tiles_per_col;          /* texel tiles along yy (see texel_index) */
@@ -55,6 +56,45 @@ DVO_DEV float weight_of(float r) {
     return (float)(6.0 / (6.0 + (double)(r * r) / .25));
 }
 
+/* ---- exact float divisions without the IEEE division sequence --------------------------------
+ * The five float divisions per point of the reference (:339, :388-393) dominate the instruction
+ * count of the per-point loop.  All of them can be produced bit-exactly with a few cheap
+ * instructions; every identity below is verified over ALL 2^32 bit patterns on the GPU by
+ * tools/exhaustive/div_tricks.hip (run by tests/test_gpu_exact_division.py):
+ *   (1) 1.0f/x  ==  rcp(x) refined by one fma Newton step, for 2^-126 <= |x| <= 2^126
+ *   (2) for such x,  zn = x * (1.0f/x)  is exactly 1 or 1-2^-24            (quirk Q1's "Z")
+ *   (3) n / (1-2^-24)  ==  the next float away from zero (n normal); n itself for 0/subnormal/inf/nan
+ *   (4) n / (1-2^-23)  ==  n advanced by 1 ulp if its 24-bit significand <= 12582910, else by 2
+ *                          (subnormals: by 1 if the mantissa >= 2^22; overflow saturates to inf)
+ *   and (1-2^-24)^2 rounds to 1-2^-23, so zn*zn is 1 or 1-2^-23.
+ * Outside the proven range (|x| subnormal, huge, 0, inf, nan) the callers fall back to real divisions. */
+DVO_DEV bool rcp_in_proven_range(float x) {
+    const float ax = fabsf(x);
+    return (ax >= 1.17549435e-38f) && (ax <= 8.50705917e37f);       /* 2^-126 .. 2^126 */
+}
+DVO_DEV float exact_rcp(float x) {                                    /* identity (1) */
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+DVO_DEV float exact_div_z1(float n) {                                 /* identity (3): n / (1-2^-24) */
+    const unsigned b = __float_as_uint(n);
+    const unsigned ex = b & 0x7f800000u;
+    return ((ex != 0u) && (ex != 0x7f800000u)) ? __uint_as_float(b + 1u) : n;
+}
+DVO_DEV float exact_div_zz1(float n) {                                /* identity (4): n / (1-2^-23) */
+    const unsigned b = __float_as_uint(n);
+    const unsigned ex = b & 0x7f800000u;
+    const unsigned man = b & 0x007fffffu;
+    /* normal: significand (man | 2^23) <= 12582910  <=>  man <= 4194302 */
+    unsigned inc = (man <= 4194302u) ? 1u : 2u;
+    inc = (ex == 0u) ? ((man >= 0x00400000u) ? 1u : 0u) : inc;        /* zero / subnormal */
+    inc = (ex == 0x7f800000u) ? 0u : inc;                             /* inf / nan unchanged */
+    unsigned r = b + inc;
+    r = ((r & 0x7fffffffu) > 0x7f800000u && ex != 0x7f800000u) ? ((b & 0x80000000u) | 0x7f800000u) : r;   /* +-FLT_MAX -> +-inf */
+    return __uint_as_float(r);
+}
+#define DVO_Z1 0x3f7fffffu          /* bits of 1-2^-24 */
+
 /* One reference edge point through :328-345 (warp + project).  Returns visibility
  * (half-open bounds, false for NaN -- SURVEY Q3). */
 DVO_DEV bool project_point(const IterConst &c, float X, float Y, float Z,
@@ -64,7 +104,11 @@ DVO_DEV bool project_point(const IterConst &c, float X, float Y, float Z,
     const float p0 = (c.r[0] * d0 + c.r[1] * d1) + c.r[2] * d2;
     const float p1 = (c.r[3] * d0 + c.r[4] * d1) + c.r[5] * d2;
     const float p2 = (c.r[6] * d0 + c.r[7] * d1) + c.r[8] * d2;
-    const float inv = 1.0f / p2;                                           /* :339 */
+    float inv = exact_rcp(p2);                                             /* :339, == 1.0f/p2 (identity 1) */
+    const bool odd = !rcp_in_proven_range(p2);                             /* 0, subnormal, huge, nan: never in practice */
+    if (__builtin_amdgcn_ballot_w64(odd) != 0ull) {                        /* wave-uniform branch: not if-converted */
+        if (odd) inv = 1.0f / p2;
+    }
     xn = p0 * inv; yn = p1 * inv; zn = p2 * inv;                            /* :340-341 */
     u = c.m00 * xn + c.m02 * zn;                                            /* :344 */
     v = c.m11 * yn + c.m12 * zn;
@@ -75,11 +119,24 @@ DVO_DEV bool project_point(const IterConst &c, float X, float Y, float Z,
  * DEHOMOGENISED coordinates (quirk Q1), cR^T is applied a second time (Q2). */
 DVO_DEV void jacobian_row(const IterConst &c, float xn, float yn, float zn,
                           float gxv, float gyv, float *J) {
-    const float zz = zn * zn;
-    const float a00 = c.m00 / zn;                      /* scaleFac*fx/Z            :388 */
-    const float a02 = ((-c.m00) * xn) / zz;            /* -scaleFac*fx*X/(Z*Z)     :390 */
-    const float a11 = c.m11 / zn;                      /* :392 */
-    const float a12 = ((-c.m11) * yn) / zz;            /* :393 */
+    /* Z is z*(1/z): exactly 1 or 1-2^-24 for every point whose 1/z took the fast path; the four
+     * divisions by Z and Z*Z then have closed forms (identities 3 and 4).  Anything else (a point
+     * with a degenerate z) takes the literal divisions. */
+    const float n02 = (-c.m00) * xn, n12 = (-c.m11) * yn;
+    const unsigned zb = __float_as_uint(zn);
+    const bool z_is_1 = (zb == 0x3f800000u);           /* Z == 1 */
+    const bool z_is_z1 = (zb == DVO_Z1);               /* Z == 1-2^-24, Z*Z == 1-2^-23 */
+    float a00 = z_is_1 ? c.m00 : c.m00_z1;             /* scaleFac*fx/Z            :388 */
+    float a11 = z_is_1 ? c.m11 : c.m11_z1;             /* :392 */
+    float a02 = z_is_1 ? n02 : exact_div_zz1(n02);     /* -scaleFac*fx*X/(Z*Z)     :390 */
+    float a12 = z_is_1 ? n12 : exact_div_zz1(n12);     /* :393 */
+    const bool odd = !(z_is_1 || z_is_z1);
+    if (__builtin_amdgcn_ballot_w64(odd) != 0ull) {    /* wave-uniform; literal divisions for degenerate z */
+        if (odd) {
+            const float zz = zn * zn;
+            a00 = c.m00 / zn; a02 = n02 / zz; a11 = c.m11 / zn; a12 = n12 / zz;
+        }
+    }
     const float ga0 = gxv * a00;                       /* G*A1, structural zeros dropped */
     const float ga1 = gyv * a11;
     const float ga2 = gxv * a02 + gyv * a12;
@@ -536,7 +593,14 @@ DVO_DEV void pose_state_finish(PoseState &s) {
 /* Everything runIterations does after the per-point phase of iteration `itr`
  * (:689-920).  g = J^T W eps (:777), sum_eps2 = sum eps^2, n_vis visible points.
  * Returns the energy; sets s.stop on early termination. */
-DVO_DEV float pose_update(PoseState &s, const DevParams &prm, int itr, int N,
+#ifndef DVO_NOINLINE_UPDATE
+DVO_DEV
+#else
+/* experiment (make NOINLINE_UPDATE=1): out of line the fused kernel fits 128 VGPRs (4 waves per SIMD)
+ * but the update itself takes 1.6-2x longer; measured slower at 512 threads, faster only at 1024. */
+__device__ __noinline__
+#endif
+float pose_update(PoseState &s, const DevParams &prm, int itr, int N,
                           const double *g_in, double sum_eps2, int n_vis) {
     /* ---- phase 1: energy and best-iterate bookkeeping (:689-705) ------------
      * energy narrows to float, so it needs the correctly rounded double sqrt to

@@ -39,6 +39,7 @@ DVO_DEV void level_consts(IterConst &c, const Intrinsics &K, int level, int rows
     const float s = pow2_neg(level);
     c.m00 = s * K.fx; c.m02 = s * K.cx;       /* (scaleMatrix*K), :344 */
     c.m11 = s * K.fy; c.m12 = s * K.cy;
+    c.m00_z1 = exact_div_z1(c.m00); c.m11_z1 = exact_div_z1(c.m11);
     c.ncols_f = (float)cols; c.nrows_f = (float)rows;
     c.rows = rows;
     c.tiles_per_col = texel_tiles_per_col(rows);
@@ -279,6 +280,32 @@ hipError_t launch_pack_texels(const float *dt, const float *gx, const float *gy,
     return hipGetLastError();
 }
 
+/* slot p in [dst_first, dst_first+dst_count) <- copy of slot (p - dst_first) % n_src : one launch per level
+ * instead of a pack + copies per pair (bench / throughput set-up, warm replicas) */
+__global__ void __launch_bounds__(256)
+replicate_level_kernel(float4 *tex, size_t tex_stride, float *pts, int pt_cap, int *N,
+                       int n_src, int dst_first, int dst_count) {
+    const int p = dst_first + blockIdx.y;
+    const int src = blockIdx.y % n_src;
+    if (p == src) return;
+    const float4 *st = tex + (size_t)src * tex_stride;
+    float4 *dt = tex + (size_t)p * tex_stride;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tex_stride; i += stride) dt[i] = st[i];
+    const int n = N[src];
+    const float *sp = pts + (size_t)src * pt_cap * 3;
+    float *dp = pts + (size_t)p * pt_cap * 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)3 * n; i += stride) dp[i] = sp[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) N[p] = n;
+}
+hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, int pt_cap, int *N,
+                                  int n_src, int dst_first, int dst_count, hipStream_t s) {
+    if (dst_count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(replicate_level_kernel, dim3(64, dst_count), dim3(256), 0, s, tex, tex_stride, pts, pt_cap, N,
+                       n_src, dst_first, dst_count);
+    return hipGetLastError();
+}
+
 /* ------------------------------------------------------------------------- */
 /* fused coarse-to-fine alignment: one workgroup per frame pair                */
 /* ------------------------------------------------------------------------- */
@@ -359,10 +386,18 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
             for (int k = 0; k < 3; k++) c.t[k] = uniform_f(st.tf[k]);        /* :674 */
 
             DVO_STAMP(t0);
+#ifdef DVO_YOUNG_WAVE_PRIO
+            /* the second-dispatched half of the workgroup loses VALU arbitration to the older half
+             * (MI355X_MICROARCH.md, two waves per SIMD) and would finish the loop late */
+            if (__builtin_amdgcn_readfirstlane(tid >> 6) >= BLOCK / 128) __builtin_amdgcn_s_setprio(DVO_YOUNG_WAVE_PRIO);
+#endif
             Acc a;
             acc_zero(a);
             accumulate_points<U, false, true>(c, tex, psrc, 0, psrc.n_lds, tid, BLOCK, a);    /* :369, :433 */
             accumulate_points<U, false, false>(c, tex, psrc, psrc.n_lds, N, tid, BLOCK, a);  /* beyond the LDS budget */
+#ifdef DVO_YOUNG_WAVE_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             DVO_STAMP(t1);
             block_reduce<BLOCK, false>(a, red, tot);
             DVO_STAMP(t2);

@@ -60,6 +60,8 @@ struct Outputs {
 
 hipError_t launch_pack_texels(const float *dt, const float *gx, const float *gy, float4 *out,
                               int rows, int cols, hipStream_t s);
+hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, int pt_cap, int *N,
+                                  int n_src, int dst_first, int dst_count, hipStream_t s);
 hipError_t launch_align_fused(int block_threads, int points_in_flight, const LevelSet &lv,
                               const Schedule &sc, const Intrinsics &K, const DevParams &prm,
                               const Outputs &out, int first_pair, int n_pairs, hipStream_t s);

@@ -357,3 +357,27 @@ def test_point_shards_sum_to_the_full_frame(scene320, oracle):
         assert rot_angle(ref["R"], got["R"]) <= ROT_TOL and np.linalg.norm(ref["t"] - got["t"]) <= TRANS_TOL
     finally:
         ctx.close()
+
+
+def test_replicate_pairs(oracle):
+    """dvo_replicate_pairs: slot p is a faithful device copy of pair p % n_src"""
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    n, n_src = 7, 3
+    scenes = [SynthScene(160, 120, 3, 50 + i) for i in range(n_src)]
+    lvs = [oracle_lib.scene_levels(s, oracle) for s in scenes]
+    ctx = DvoContext(n)
+    try:
+        ctx.set_intrinsics(*scenes[0].intrinsics)
+        for p in range(n_src):
+            for l, L in enumerate(lvs[p]):
+                ctx.set_ref_level(l, L["xyz"], pair=p)
+                ctx.set_now_level(l, L["dt"], L["gx"], L["gy"], L["rows"], L["cols"], pair=p)
+        ctx.replicate_pairs(n_src)
+        iters = [6, 6, 6]
+        R, t = ctx.align_batch(iters, np.tile(np.eye(3), (n, 1, 1)), np.zeros((n, 3)))
+        for p in range(n):
+            assert np.array_equal(R[p], R[p % n_src]) and np.array_equal(t[p], t[p % n_src])
+            ref = oracle.align_pyramid(iters, lvs[p % n_src], scenes[0].intrinsics, np.eye(3), np.zeros(3))
+            assert rot_angle(ref["R"], R[p]) <= ROT_TOL and np.linalg.norm(ref["t"] - t[p]) <= TRANS_TOL
+    finally:
+        ctx.close()
