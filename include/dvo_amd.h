@@ -193,6 +193,11 @@ int  dvo_iter_update(dvo_ctx *ctx, int pair, int level, int itr, int n_total, co
 int  dvo_iter_end(dvo_ctx *ctx, int pair, int level, double *R, double *t, float *energy /*[max_iters] or NULL*/,
                   int *best_idx, float *visible_ratio);
 
+/* The same loop for ONE GPU, enqueued from C: the level schedule of SolveDVO::loop with every iteration
+ * spread over all CUs (frames whose point lists are too long for one workgroup).  Synchronous; per-level
+ * energies / best index / ratio afterwards through dvo_get_level_report. */
+int  dvo_align_pyramid_wide(dvo_ctx *ctx, int pair, int n_levels, const int *iters, double *R, double *t);
+
 /* ---- inspection (used by the parity tests) ---------------------------------
  * One evaluation of computeJacobianOfNowFrame + getReprojectedEpsilons at the
  * given pose (cast to float exactly as SolveDVO.cpp:673-674).  Host outputs, any

@@ -30,6 +30,7 @@ C_ABI_SYMBOLS = [
     "dvo_get_final_outputs", "dvo_eval_points", "dvo_accumulate", "dvo_device_se3_exp",
     "dvo_device_se3_log", "dvo_device_rotationize", "dvo_algorithmic_bytes", "dvo_point_iterations",
     "dvo_debug_stamps", "dvo_replicate_pairs", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
+    "dvo_align_pyramid_wide",
 ]
 
 
@@ -116,6 +117,7 @@ def load_library() -> C.CDLL:
         "dvo_iter_accumulate": [vp, i, i, i, i, vp],
         "dvo_iter_update": [vp, i, i, i, i, vp],
         "dvo_iter_end": [vp, i, i, vp, vp, vp, ip, fp],
+        "dvo_align_pyramid_wide": [vp, i, i, ip, vp, vp],
         "dvo_algorithmic_bytes": [vp, i, i, ip, i, C.POINTER(C.c_uint64)],
         "dvo_point_iterations": [vp, i, i, ip, C.POINTER(C.c_uint64)],
     }
@@ -325,6 +327,13 @@ class DvoContext:
         self._chk(self.lib.dvo_iter_end(self._h, pair, level, _ptr(R), _ptr(t), _ptr(energy), C.byref(best),
                                         C.byref(ratio)))
         return dict(R=R, t=t, energy=energy, best_idx=best.value, visible_ratio=ratio.value)
+
+    def align_pyramid_wide(self, iters: Sequence[int], R, t, pair: int = 0):
+        """level schedule with every iteration spread over all CUs (large single frames), driven from C"""
+        R = np.array(R, dtype=np.float64, order="F").copy(order="F")
+        t = np.array(t, dtype=np.float64).copy()
+        self._chk(self.lib.dvo_align_pyramid_wide(self._h, pair, len(iters), _iters(iters), _ptr(R), _ptr(t)))
+        return R, t
 
     # -- inspection -----------------------------------------------------------
     def eval_points(self, level: int, R, t, pair: int = 0):

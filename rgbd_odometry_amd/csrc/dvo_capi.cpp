@@ -688,6 +688,48 @@ int dvo_iter_end(dvo_ctx *c, int pair, int level, double *R, double *t, float *e
     return DVO_OK;
 }
 
+/* The level schedule (SolveDVO.cpp:2097-2104) with every iteration spread over all CUs: the single-GPU
+ * form of the host-driven loop, enqueued back to back from C (no collective, one synchronisation). */
+int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters, double *R, double *t) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair) || !R || !t) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    Schedule sc;
+    int rc = build_schedule(c, n_levels, iters, 0, sc);
+    if (rc) return rc;
+    for (int l = 0; l < n_levels; l++)
+        if (sc.iters[l] > 0 && (rc = check_ready(c, pair, l))) return rc;
+    if ((rc = ensure_outputs(c, sc))) return rc;
+    if (!c->d_states) {
+        HIPCHK(c, hipMalloc((void **)&c->d_states, pose_state_bytes() * c->n_pairs));
+        c->iter_max.assign(c->n_pairs, 0);
+    }
+    double h[12];
+    std::memcpy(h, R, sizeof(double) * 9);
+    std::memcpy(h + 9, t, sizeof(double) * 3);
+    double *d_pose = c->d_poses + (size_t)12 * pair;
+    void *state = c->d_states + pose_state_bytes() * pair;
+    double *partials = c->d_scratch;
+    HIPCHK(c, hipMemcpyAsync(d_pose, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+    for (int l = n_levels - 1; l >= 0; --l) {                       /* :2097 */
+        if (sc.iters[l] <= 0) continue;                             /* :2099 */
+        const int N = c->lv[l].hN[pair];
+        float *energy = c->d_energy + (size_t)pair * sc.e_stride + sc.e_off[l];
+        HIPCHK(c, launch_iter_begin(state, d_pose, energy, sc.iters[l], c->stream));
+        const int nb = accumulate_blocks_for(N);
+        for (int itr = 0; itr < sc.iters[l]; itr++) {
+            HIPCHK(c, launch_iter_step_fused(slab_of(c, l), pair, l, c->K, state, c->dprm, itr, N, partials, nb, energy, c->stream));
+        }
+        HIPCHK(c, launch_iter_end(state, d_pose, c->d_best + pair * DVO_LEVELS + l, c->d_ratio + pair * DVO_LEVELS + l, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(h, d_pose, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(R, h, sizeof(double) * 9);
+    std::memcpy(t, h + 9, sizeof(double) * 3);
+    c->sched = sc;
+    c->have_sched = true;
+    return DVO_OK;
+}
+
 /* ---- inspection ------------------------------------------------------------- */
 int dvo_eval_points(dvo_ctx *c, int pair, int level, const double *R, const double *t,
                     float *reproj, float *J, float *eps, float *w, int *visible) {

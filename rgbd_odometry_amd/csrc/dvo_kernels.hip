@@ -552,21 +552,28 @@ accumulate_kernel(LevelSlab L, int pair, int level, Intrinsics K, FloatPose P,
         partials[(size_t)blockIdx.x * DVO_NACC_PAD + threadIdx.x] = (threadIdx.x < DVO_NACC) ? tot[threadIdx.x] : 0.0;
 }
 
-/* acc[k] = sum over blocks in block order (fixed order => reproducible) */
-__global__ void __launch_bounds__(64)
+/* acc[k] = sum over blocks of partials[b][k], in a fixed two-level order (32 interleaved chains per value,
+ * then the chains in order) => reproducible, and 32x shorter than one serial chain */
+__global__ void __launch_bounds__(1024)
 reduce_partials_kernel(const double *__restrict__ partials, int nblocks, double *__restrict__ acc) {
-    const int k = threadIdx.x;
-    if (k < DVO_NACC_PAD) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; b++) s += partials[(size_t)b * DVO_NACC_PAD + k];
-        acc[k] = s;
+    __shared__ double part[32][DVO_NACC_PAD + 1];
+    const int k = threadIdx.x & 31, c = threadIdx.x >> 5;
+    double s = 0.0;
+    for (int b = c; b < nblocks; b += 32) s += partials[(size_t)b * DVO_NACC_PAD + k];
+    part[c][k] = s;
+    __syncthreads();
+    if (threadIdx.x < DVO_NACC_PAD) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < 32; j++) t += part[j][threadIdx.x];
+        acc[threadIdx.x] = t;
     }
 }
 
 int accumulate_blocks_for(int n_points) {
     int b = (n_points + 255) / 256;
     if (b < 1) b = 1;
-    if (b > 1024) b = 1024;
+    if (b > 512) b = 512;             /* two 256-thread workgroups per CU */
     return b;
 }
 
@@ -578,7 +585,7 @@ hipError_t launch_accumulate(const LevelSlab &L, int pair, int level, const Intr
     for (int k = 0; k < 3; k++) P.t[k] = tf[k];
     hipLaunchKernelGGL(accumulate_kernel, dim3(nblocks), dim3(256), 0, s, L, pair, level, K, P,
                        first_point, n_points, partials);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, s, partials, nblocks, acc);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, partials, nblocks, acc);
     return hipGetLastError();
 }
 
@@ -636,6 +643,31 @@ iter_update_kernel(PoseState *st, DevParams prm, int itr, int n_total, const dou
     }
 }
 
+/* single-GPU form: partial sums -> totals -> update in one launch (no collective in between) */
+__global__ void __launch_bounds__(1024)
+iter_reduce_update_kernel(PoseState *st, DevParams prm, int itr, int n_total,
+                          const double *__restrict__ partials, int nblocks, float *energy) {
+    __shared__ double part[32][DVO_NACC_PAD + 1];
+    __shared__ double acc[DVO_NACC_PAD];
+    const int k = threadIdx.x & 31, c = threadIdx.x >> 5;
+    double s = 0.0;
+    for (int b = c; b < nblocks; b += 32) s += partials[(size_t)b * DVO_NACC_PAD + k];
+    part[c][k] = s;
+    __syncthreads();
+    if (threadIdx.x < DVO_NACC_PAD) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < 32; j++) t += part[j][threadIdx.x];
+        acc[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && !st->stop) {
+        double g[6];
+        for (int q = 0; q < 6; q++) g[q] = acc[21 + q];
+        energy[itr] = pose_update(*st, prm, itr, n_total, g, acc[27], (int)acc[28]);
+    }
+}
+
 __global__ void __launch_bounds__(64)
 iter_end_kernel(PoseState *st, double *Rt12, int *best_idx, float *ratio) {
     if (threadIdx.x == 0) {
@@ -656,12 +688,21 @@ hipError_t launch_iter_accumulate(const LevelSlab &L, int pair, int level, const
                                   hipStream_t s) {
     hipLaunchKernelGGL(accumulate_state_kernel, dim3(nblocks), dim3(256), 0, s, L, pair, level, K,
                        (const PoseState *)state, first_point, n_points, partials);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, s, partials, nblocks, acc);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, partials, nblocks, acc);
     return hipGetLastError();
 }
 hipError_t launch_iter_update(void *state, const DevParams &prm, int itr, int n_total, const double *acc,
                               float *energy, hipStream_t s) {
     hipLaunchKernelGGL(iter_update_kernel, dim3(1), dim3(64), 0, s, (PoseState *)state, prm, itr, n_total, acc, energy);
+    return hipGetLastError();
+}
+hipError_t launch_iter_step_fused(const LevelSlab &L, int pair, int level, const Intrinsics &K, void *state,
+                                  const DevParams &prm, int itr, int n_points, double *partials, int nblocks,
+                                  float *energy, hipStream_t s) {
+    hipLaunchKernelGGL(accumulate_state_kernel, dim3(nblocks), dim3(256), 0, s, L, pair, level, K,
+                       (const PoseState *)state, 0, n_points, partials);
+    hipLaunchKernelGGL(iter_reduce_update_kernel, dim3(1), dim3(1024), 0, s, (PoseState *)state, prm, itr, n_points,
+                       partials, nblocks, energy);
     return hipGetLastError();
 }
 hipError_t launch_iter_end(void *state, double *Rt12, int *best_idx, float *ratio, hipStream_t s) {

@@ -82,6 +82,9 @@ hipError_t launch_iter_accumulate(const LevelSlab &L, int pair, int level, const
                                   hipStream_t s);
 hipError_t launch_iter_update(void *state, const DevParams &prm, int itr, int n_total, const double *acc,
                               float *energy, hipStream_t s);
+hipError_t launch_iter_step_fused(const LevelSlab &L, int pair, int level, const Intrinsics &K, void *state,
+                                  const DevParams &prm, int itr, int n_points, double *partials, int nblocks,
+                                  float *energy, hipStream_t s);
 hipError_t launch_iter_end(void *state, double *Rt12, int *best_idx, float *ratio, hipStream_t s);
 /* SE(3) helpers on one lane (property tests) */
 hipError_t launch_se3_exp(const double *psi, double *Rt12, hipStream_t s);

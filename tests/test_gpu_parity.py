@@ -381,3 +381,19 @@ def test_replicate_pairs(oracle):
             assert rot_angle(ref["R"], R[p]) <= ROT_TOL and np.linalg.norm(ref["t"] - t[p]) <= TRANS_TOL
     finally:
         ctx.close()
+
+
+def test_align_pyramid_wide_matches_oracle(scene320, oracle):
+    """dvo_align_pyramid_wide: the host-driven schedule enqueued from C"""
+    sc, lv = scene320
+    ctx = _ctx_for(sc, lv)
+    try:
+        iters = [9, 0, 9, 9]
+        R, t = ctx.align_pyramid_wide(iters, np.eye(3), np.zeros(3))
+        ref = oracle.align_pyramid(iters, lv, sc.intrinsics, np.eye(3), np.zeros(3))
+        for l, rep in ref["levels"].items():
+            e, b, ratio = ctx.level_report(0, l, iters[l])
+            assert np.array_equal(e, rep["energy"]) and b == rep["best_idx"] and ratio == rep["visible_ratio"]
+        assert rot_angle(ref["R"], R) <= ROT_TOL and np.linalg.norm(ref["t"] - t) <= TRANS_TOL
+    finally:
+        ctx.close()

@@ -47,6 +47,16 @@ out = dict(mode="tiled", n_gpus=world, width=args.width, height=args.height, lev
            us_per_iteration=1e6 * dt / sum(iters), scene_gen_s=tgen,
            algorithmic_bytes=ctx.algorithmic_bytes(iters), rot_err_vs_truth=float(np.arccos(np.clip((np.trace(sc.R_true.T @ res["R"]) - 1) / 2, -1, 1))))
 out["algorithmic_GBps"] = out["algorithmic_bytes"] / dt / 1e9
+if world == 1:
+    ctx.use_own_stream()
+    Rw, tw = ctx.align_pyramid_wide(iters, np.eye(3), np.zeros(3))
+    t0 = time.perf_counter()
+    for _ in range(args.steps): Rw, tw = ctx.align_pyramid_wide(iters, np.eye(3), np.zeros(3))
+    dtw = (time.perf_counter() - t0) / args.steps
+    out["wide_from_c_ms"] = 1e3 * dtw
+    out["wide_us_per_iteration"] = 1e6 * dtw / sum(iters)
+    out["wide_algorithmic_GBps"] = out["algorithmic_bytes"] / dtw / 1e9
+    out["wide_vs_tiled_pose_maxdiff"] = float(max(np.abs(Rw - res["R"]).max(), np.abs(tw - res["t"]).max()))
 if args.fused and world == 1:
     ctx.use_own_stream()
     R, t = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
