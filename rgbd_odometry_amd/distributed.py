@@ -52,9 +52,10 @@ class TiledAligner:
         new_acc() -> tensor of ACC_LEN float64 on the engine's device; acc_ptr(t) -> what iter_* take
     """
 
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, force_collective: bool = False):
         self.engine = engine
         self.group = group
+        self.force_collective = force_collective      # run the all-reduce even at world size 1 (testing)
         import torch.distributed as dist
         self.dist = dist
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -68,7 +69,7 @@ class TiledAligner:
         eng.iter_begin(level, iters, R, t)
         for itr in range(iters):
             eng.iter_accumulate(level, first, count, eng.acc_ptr(acc))
-            if self.world > 1:
+            if self.world > 1 or self.force_collective:
                 self.dist.all_reduce(acc, op=self.dist.ReduceOp.SUM, group=self.group)
             eng.iter_update(level, itr, n_total, eng.acc_ptr(acc))
         return eng.iter_end(level)

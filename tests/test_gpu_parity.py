@@ -397,3 +397,43 @@ def test_align_pyramid_wide_matches_oracle(scene320, oracle):
         assert rot_angle(ref["R"], R) <= ROT_TOL and np.linalg.norm(ref["t"] - t) <= TRANS_TOL
     finally:
         ctx.close()
+
+
+def test_config3_1920x1080_five_levels(oracle):
+    """BASELINE configs[2]: 1920x1080, 5-level pyramid (level sizes by cvRound, 67.5 -> 68), fused kernel and wide path"""
+    from rgbd_odometry_amd import SynthScene
+    sc = SynthScene(1920, 1080, 5, 0)
+    assert [(L.rows, L.cols) for L in sc.levels] == [(1080, 1920), (540, 960), (270, 480), (135, 240), (68, 120)]
+    lv = oracle_lib.scene_levels(sc, oracle)
+    ctx = _ctx_for(sc, lv)
+    try:
+        iters = [4, 4, 4, 4, 4]
+        ref, R, t = _check_pyramid(sc, lv, ctx, oracle, iters)
+        Rw, tw = ctx.align_pyramid_wide(iters, np.eye(3), np.zeros(3))
+        for l, rep in ref["levels"].items():
+            e, b, ratio = ctx.level_report(0, l, iters[l])
+            assert np.array_equal(e, rep["energy"]) and b == rep["best_idx"] and ratio == rep["visible_ratio"]
+        assert rot_angle(ref["R"], Rw) <= ROT_TOL and np.linalg.norm(ref["t"] - tw) <= TRANS_TOL
+    finally:
+        ctx.close()
+
+
+def test_large_frame_wide_path(oracle):
+    """a 2048x1536 frame (N0 ~ 170 k points, beyond one workgroup's LDS budget many times over)"""
+    from rgbd_odometry_amd import SynthScene
+    sc = SynthScene(2048, 1536, 3, 7)
+    lv = oracle_lib.scene_levels(sc, oracle)
+    ctx = _ctx_for(sc, lv)
+    try:
+        iters = [3, 3, 3]
+        ref = oracle.align_pyramid(iters, lv, sc.intrinsics, np.eye(3), np.zeros(3))
+        Rw, tw = ctx.align_pyramid_wide(iters, np.eye(3), np.zeros(3))
+        for l, rep in ref["levels"].items():
+            e, b, ratio = ctx.level_report(0, l, iters[l])
+            assert np.array_equal(e, rep["energy"]) and b == rep["best_idx"] and ratio == rep["visible_ratio"]
+        assert rot_angle(ref["R"], Rw) <= ROT_TOL and np.linalg.norm(ref["t"] - tw) <= TRANS_TOL
+        # the fused one-workgroup kernel must agree too (points mostly streamed from HBM)
+        Rf, tf = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
+        assert rot_angle(ref["R"], Rf[0]) <= ROT_TOL and np.linalg.norm(ref["t"] - tf[0]) <= TRANS_TOL
+    finally:
+        ctx.close()

@@ -13,13 +13,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--width", type=int, default=4096); ap.add_argument("--height", type=int, default=3072)
 ap.add_argument("--levels", type=int, default=5); ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=1)
-ap.add_argument("--seed", type=int, default=7); ap.add_argument("--fused", action="store_true", help="also time the one-workgroup fused kernel")
+ap.add_argument("--seed", type=int, default=7); ap.add_argument("--force-collective", action="store_true"); ap.add_argument("--fused", action="store_true", help="also time the one-workgroup fused kernel")
 args = ap.parse_args()
 rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
 torch.cuda.set_device(local)
 import torch.distributed as dist
-if world > 1:
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+if world > 1 or args.force_collective:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 from rgbd_odometry_amd import DvoContext, SynthScene
 from rgbd_odometry_amd.distributed import HipTiledEngine, TiledAligner
 t0 = time.time(); sc = SynthScene(args.width, args.height, args.levels, args.seed); tgen = time.time() - t0
@@ -31,7 +32,7 @@ for l, L in enumerate(sc.levels):
     ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols)
     N.append(len(xyz))
 iters = [args.iters] * args.levels
-al = TiledAligner(HipTiledEngine(ctx))
+al = TiledAligner(HipTiledEngine(ctx), force_collective=args.force_collective)
 def run():
     return al.align(iters, np.eye(3), np.zeros(3))
 for _ in range(args.warmup): res = run()
@@ -65,4 +66,4 @@ if args.fused and world == 1:
     out["fused_one_workgroup_ms"] = 1e3 * (time.perf_counter() - t0) / args.steps
     out["fused_vs_tiled_pose_maxdiff"] = float(max(np.abs(R[0] - res["R"]).max(), np.abs(t[0] - res["t"]).max()))
 if rank == 0: print(json.dumps(out))
-if world > 1: dist.destroy_process_group()
+if world > 1 or args.force_collective: dist.destroy_process_group()
