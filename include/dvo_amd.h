@@ -122,6 +122,16 @@ int  dvo_set_ref_level_device(dvo_ctx *ctx, int pair, int level, const float *d_
 int  dvo_set_now_level_device(dvo_ctx *ctx, int pair, int level, const float *d_dt, const float *d_gx,
                               const float *d_gy, int rows, int cols);
 
+/* computeDistTransfrmOfNow after the Canny step (SolveDVO.cpp:1768-1795) + imageGradient (:1063-1098) on
+ * the GPU: edge (uint8, >0 = edge pixel, column-major rows x cols, host pointer) -> exact Euclidean
+ * distance transform -> cv::normalize(0,255,NORM_MINMAX) (:1774) -> [-.5 0 .5] gradients with a
+ * reflect-101 border (:1077-1090) -> resident now level.  1 byte per pixel crosses PCIe instead of 12.
+ * (the Canny detector itself stays with the caller.) */
+int  dvo_set_now_level_from_edges(dvo_ctx *ctx, int pair, int level, const unsigned char *edge, int rows, int cols);
+/* The planar DT / gradient images of a resident now level (host outputs, rows*cols floats each, any may
+ * be NULL). */
+int  dvo_get_now_level(dvo_ctx *ctx, int pair, int level, float *dt, float *gx, float *gy);
+
 /* Batch set-up helper: pair slot p in [dst_first, dst_first+dst_count) becomes a device-side copy of
  * pair (p - dst_first) % n_src (all levels that are set), one launch per level.  dst_first = 0 leaves the
  * sources in place and fills the rest of the range cyclically. */

@@ -725,6 +725,70 @@ int dvo_oracle_run_iterations(const dvo_oracle_params *prm_in, int level, int ma
     return evaluated;
 }
 
+/* ---- now-frame preprocessing after Canny (computeDistTransfrmOfNow, :1768-1795; imageGradient :1063-1098) ----
+ * edge > 0 marks an edge pixel (the reference inverts the Canny output so that edges are the zero set of
+ * cv::distanceTransform(CV_DIST_L2, CV_DIST_MASK_PRECISE), :1768-1771).  OpenCV 2.4 is not available here
+ * (PARITY UNPINNED for this step as well); the definition restated is: exact Euclidean distance
+ * (Felzenszwalb-Huttenlocher lower envelopes, as DIST_MASK_PRECISE does), narrowed to float;
+ * cv::normalize(0,255,NORM_MINMAX) as dst = (src-min)*(255/(max-min)) evaluated in double (:1774);
+ * filter2D with [-.5 0 .5] kernels and the default BORDER_REFLECT_101 (:1077-1090). */
+static void fh_1d(const double *f, int n, double *d, int *v, double *z) {
+    const double INF = 1e20;
+    int k = 0;
+    v[0] = 0; z[0] = -INF; z[1] = INF;
+    for (int q = 1; q < n; q++) {
+        double s;
+        for (;;) {
+            s = ((f[q] + (double)q * q) - (f[v[k]] + (double)v[k] * v[k])) / (2.0 * q - 2.0 * v[k]);
+            if (s <= z[k] && k > 0) k--; else break;
+        }
+        if (s <= z[k]) { v[k] = q; z[k] = -INF; z[k + 1] = INF; }      /* k == 0 and q dominates */
+        else { k++; v[k] = q; z[k] = s; z[k + 1] = INF; }
+    }
+    k = 0;
+    for (int q = 0; q < n; q++) {
+        while (z[k + 1] < (double)q) k++;
+        d[q] = ((double)q - v[k]) * ((double)q - v[k]) + f[v[k]];
+    }
+}
+
+void dvo_oracle_now_level_from_edges(const unsigned char *edge, int rows, int cols,
+                                     float *dt, float *gx, float *gy) {
+    const double INF = 1e20;
+    const size_t n = (size_t)rows * cols;
+    std::vector<double> d2(n);
+    const int m = rows > cols ? rows : cols;
+    std::vector<double> f(m), d(m), z(m + 1);
+    std::vector<int> v(m);
+    for (size_t i = 0; i < n; i++) d2[i] = edge[i] ? 0.0 : INF;
+    for (int x = 0; x < cols; x++) {                                 /* along yy (contiguous) */
+        for (int y = 0; y < rows; y++) f[y] = d2[(size_t)x * rows + y];
+        fh_1d(f.data(), rows, d.data(), v.data(), z.data());
+        for (int y = 0; y < rows; y++) d2[(size_t)x * rows + y] = d[y];
+    }
+    for (int y = 0; y < rows; y++) {                                 /* along xx */
+        for (int x = 0; x < cols; x++) f[x] = d2[(size_t)x * rows + y];
+        fh_1d(f.data(), cols, d.data(), v.data(), z.data());
+        for (int x = 0; x < cols; x++) d2[(size_t)x * rows + y] = d[x];
+    }
+    float mn = 0.f, mx = 0.f;
+    for (size_t i = 0; i < n; i++) {
+        dt[i] = (float)std::sqrt(d2[i]);
+        if (i == 0 || dt[i] < mn) mn = dt[i];
+        if (i == 0 || dt[i] > mx) mx = dt[i];
+    }
+    const double scale = (mx > mn) ? 255.0 / ((double)mx - (double)mn) : 0.0;
+    for (size_t i = 0; i < n; i++) dt[i] = (float)(((double)dt[i] - (double)mn) * scale);       /* :1774 */
+    auto r101 = [](int i, int len) { if (len == 1) return 0; if (i < 0) return -i; if (i >= len) return 2 * len - 2 - i; return i; };
+    for (int x = 0; x < cols; x++)
+        for (int y = 0; y < rows; y++) {
+            const float l_ = dt[(size_t)r101(x - 1, cols) * rows + y], r_ = dt[(size_t)r101(x + 1, cols) * rows + y];
+            const float u_ = dt[(size_t)x * rows + r101(y - 1, rows)], b_ = dt[(size_t)x * rows + r101(y + 1, rows)];
+            gx[(size_t)x * rows + y] = 0.5f * r_ - 0.5f * l_;        /* kernX :1077-1079 */
+            gy[(size_t)x * rows + y] = 0.5f * b_ - 0.5f * u_;        /* kernY :1080-1082 */
+        }
+}
+
 /* level schedule of SolveDVO::loop (:2097-2104) */
 int dvo_oracle_align_pyramid(const dvo_oracle_params *prm, int n_levels, const int *iters,
                              const float *const *xyz, const int *N,

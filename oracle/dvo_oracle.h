@@ -22,6 +22,8 @@
  *   src/SolveDVO.cpp:619-1017   runIterations         -> dvo_oracle_run_iterations
  *   src/SolveDVO.cpp:1269-1282  rotationize           -> dvo_oracle_rotationize
  *   src/SolveDVO.cpp:2097-2104  level schedule        -> dvo_oracle_align_pyramid
+ *   src/SolveDVO.cpp:1768-1795, :1063-1098  DT / normalise / gradients of the now frame (after Canny)
+ *                                                     -> dvo_oracle_now_level_from_edges
  * Third-party arithmetic on the path that is NOT in /root/reference and is
  * restated from its published algorithm (versions unpinned by the reference's
  * package.xml / CMakeLists.txt):
@@ -140,6 +142,12 @@ int dvo_oracle_align_pyramid(const dvo_oracle_params *prm, int n_levels, const i
                              double *R, double *t,
                              float *energy_out, int *best_idx_out, float *ratio_out,
                              float *final_eps, float *final_reproj);
+
+/* Now-frame preprocessing after Canny (computeDistTransfrmOfNow :1768-1795, imageGradient :1063-1098):
+ * edge mask (uint8, >0 = edge, column-major) -> exact EDT -> min-max normalise to [0,255] -> central
+ * differences with reflect-101 border.  OpenCV 2.4 semantics restated, unpinned (see the .cpp). */
+void dvo_oracle_now_level_from_edges(const unsigned char *edge, int rows, int cols,
+                                     float *dt, float *gx, float *gy);
 
 /* Helpers exported for property tests. */
 float dvo_oracle_weight(float r);                                   /* :1047-1053 */

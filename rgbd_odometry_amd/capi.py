@@ -29,7 +29,7 @@ C_ABI_SYMBOLS = [
     "dvo_set_poses", "dvo_align_batch_enqueue", "dvo_get_poses", "dvo_get_level_report",
     "dvo_get_final_outputs", "dvo_eval_points", "dvo_accumulate", "dvo_device_se3_exp",
     "dvo_device_se3_log", "dvo_device_rotationize", "dvo_algorithmic_bytes", "dvo_point_iterations",
-    "dvo_debug_stamps", "dvo_replicate_pairs", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
+    "dvo_debug_stamps", "dvo_replicate_pairs", "dvo_set_now_level_from_edges", "dvo_get_now_level", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
     "dvo_align_pyramid_wide",
 ]
 
@@ -113,6 +113,8 @@ def load_library() -> C.CDLL:
         "dvo_device_rotationize": [vp, vp],
         "dvo_debug_stamps": [vp, i, vp],
         "dvo_replicate_pairs": [vp, i, i, i],
+        "dvo_set_now_level_from_edges": [vp, i, i, vp, i, i],
+        "dvo_get_now_level": [vp, i, i, vp, vp, vp],
         "dvo_iter_begin": [vp, i, i, i, vp, vp],
         "dvo_iter_accumulate": [vp, i, i, i, i, vp],
         "dvo_iter_update": [vp, i, i, i, i, vp],
@@ -219,6 +221,19 @@ class DvoContext:
         self._chk(self.lib.dvo_set_now_level_device(self._h, pair, level, C.c_void_p(d_dt), C.c_void_p(d_gx),
                                                     C.c_void_p(d_gy), rows, cols))
         self._dims[level] = (rows, cols)
+
+    def set_now_level_from_edges(self, level: int, edge, rows: int, cols: int, pair: int = 0):
+        """computeDistTransfrmOfNow after Canny, on the GPU: uint8 edge mask -> resident now level"""
+        edge = np.ascontiguousarray(edge, dtype=np.uint8).reshape(-1)
+        assert edge.size == rows * cols
+        self._chk(self.lib.dvo_set_now_level_from_edges(self._h, pair, level, _ptr(edge), rows, cols))
+        self._dims[level] = (rows, cols)
+
+    def get_now_level(self, level: int, pair: int = 0):
+        rows, cols = self._dims[level]
+        dt, gx, gy = (np.zeros(rows * cols, np.float32) for _ in range(3))
+        self._chk(self.lib.dvo_get_now_level(self._h, pair, level, _ptr(dt), _ptr(gx), _ptr(gy)))
+        return dt, gx, gy
 
     def replicate_pairs(self, n_src: int, dst_first: int = 0, dst_count: Optional[int] = None):
         """slot p <- device copy of pair (p - dst_first) % n_src, for every level that is set"""

@@ -483,6 +483,48 @@ int dvo_set_now_level_device(dvo_ctx *c, int pair, int level, const float *d_dt,
     return set_now_common(c, pair, level, d_dt, d_gx, d_gy, rows, cols, true);
 }
 
+/* computeDistTransfrmOfNow after Canny (SolveDVO.cpp:1768-1795) on the device */
+int dvo_set_now_level_from_edges(dvo_ctx *c, int pair, int level, const unsigned char *edge, int rows, int cols) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair) || !level_ok(level)) return fail(c, DVO_ERR_INVALID, "pair/level out of range");
+    if (!edge || rows < 1 || cols < 1) return fail(c, DVO_ERR_INVALID, "bad image arguments");
+    int rc = ensure_texels(c, level, rows, cols);
+    if (rc) return rc;
+    const size_t npx = (size_t)rows * cols;
+    bool any = false;
+    for (size_t i = 0; i < npx && !any; i++) any = edge[i] != 0;
+    if (!any) return fail(c, DVO_ERR_INVALID, "edge mask has no edge pixel: the distance transform is undefined");
+    /* staging: edge bytes (rounded up to ints) | work ints */
+    const size_t edge_ints = (npx + 3) / 4;
+    if ((rc = ensure_staging(c, sizeof(int) * (edge_ints + 4 * npx + 2)))) return rc;
+    unsigned char *d_edge = (unsigned char *)c->staging;
+    int *work = (int *)c->staging + edge_ints;
+    HIPCHK(c, hipMemcpyAsync(d_edge, edge, npx, hipMemcpyHostToDevice, c->stream));
+    Level &L = c->lv[level];
+    HIPCHK(c, launch_now_level_from_edges(d_edge, rows, cols, work, L.tex + (size_t)pair * L.tex_stride, c->stream));
+    L.have_now[pair] = 1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DVO_OK;
+}
+
+/* the three planar images of a resident now level (inspection) */
+int dvo_get_now_level(dvo_ctx *c, int pair, int level, float *dt, float *gx, float *gy) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair) || !level_ok(level)) return fail(c, DVO_ERR_INVALID, "pair/level out of range");
+    Level &L = c->lv[level];
+    if (L.have_now.empty() || !L.have_now[pair]) return fail(c, DVO_ERR_STATE, "now level not set");
+    const size_t npx = (size_t)L.rows * L.cols;
+    int rc = ensure_staging(c, sizeof(float) * 3 * npx);
+    if (rc) return rc;
+    float *d = c->staging;
+    HIPCHK(c, launch_unpack_texels(L.tex + (size_t)pair * L.tex_stride, L.rows, L.cols, d, d + npx, d + 2 * npx, c->stream));
+    if (dt) HIPCHK(c, hipMemcpyAsync(dt, d, sizeof(float) * npx, hipMemcpyDeviceToHost, c->stream));
+    if (gx) HIPCHK(c, hipMemcpyAsync(gx, d + npx, sizeof(float) * npx, hipMemcpyDeviceToHost, c->stream));
+    if (gy) HIPCHK(c, hipMemcpyAsync(gy, d + 2 * npx, sizeof(float) * npx, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DVO_OK;
+}
+
 /* replicate the first n_src pairs over [dst_first, dst_first+dst_count): slot p <- pair (p-dst_first) % n_src */
 int dvo_replicate_pairs(dvo_ctx *c, int n_src, int dst_first, int dst_count) {
     if (!c) return DVO_ERR_INVALID;

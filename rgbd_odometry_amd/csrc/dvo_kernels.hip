@@ -712,6 +712,159 @@ hipError_t launch_iter_end(void *state, double *Rt12, int *best_idx, float *rati
 size_t pose_state_bytes() { return sizeof(PoseState); }
 
 /* ------------------------------------------------------------------------- */
+/* now-frame preprocessing after Canny: computeDistTransfrmOfNow (SolveDVO.cpp:1768-1795) +
+ * imageGradient (:1063-1098).  edge mask -> exact squared EDT in integers (Meijster, Roerdink,
+ * Hesselink) -> sqrt -> min-max normalise to [0,255] (:1774) -> central differences with a
+ * reflect-101 border (:1077-1090) -> tiled texels {DT,gx,gy,w}.                              */
+/* ------------------------------------------------------------------------- */
+#define DVO_EDT_INF(rows, cols) ((rows) + (cols) + 1)
+
+/* phase 1: per column, distance to the nearest edge pixel of that column; one wave per column,
+ * 64 rows per step, nearest set bit of the ballot above / below each lane */
+__global__ void __launch_bounds__(64)
+edt_columns_kernel(const unsigned char *__restrict__ edge, int rows, int cols, int *__restrict__ g) {
+    const int xx = blockIdx.x, lane = threadIdx.x;
+    const size_t base = (size_t)xx * rows;
+    const int INF = DVO_EDT_INF(rows, cols);
+    const int nchunk = (rows + 63) / 64;
+    int carry = INF;                                    /* distance from the row above this chunk to the nearest edge above it */
+    for (int c = 0; c < nchunk; c++) {
+        const int yy = c * 64 + lane;
+        const bool e = (yy < rows) && (edge[base + yy] != 0);
+        const unsigned long long m = __ballot(e);
+        const unsigned long long low = m & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));   /* bits 0..lane */
+        int da;
+        if (low) da = lane - (63 - __clzll((long long)low));
+        else da = (carry >= INF) ? INF : carry + lane + 1;
+        if (yy < rows) g[base + yy] = da;
+        if (m) carry = 63 - (63 - __clzll((long long)m));                 /* from lane 63 up to the highest edge */
+        else carry = (carry >= INF) ? INF : carry + 64;
+    }
+    carry = INF;                                        /* distance from the row below this chunk to the nearest edge below it */
+    for (int c = nchunk - 1; c >= 0; c--) {
+        const int yy = c * 64 + lane;
+        const bool e = (yy < rows) && (edge[base + yy] != 0);
+        const unsigned long long m = __ballot(e);
+        const unsigned long long high = m & (~0ull << lane);                                     /* bits lane..63 */
+        int db;
+        if (high) db = (__ffsll((long long)high) - 1) - lane;
+        else db = (carry >= INF) ? INF : carry + (63 - lane) + 1;
+        if (yy < rows) { const int da = g[base + yy]; int v = da < db ? da : db; if (v > INF) v = INF; g[base + yy] = v; }
+        if (m) carry = __ffsll((long long)m) - 1;                          /* from lane 0 down to the lowest edge */
+        else carry = (carry >= INF) ? INF : carry + 64;
+    }
+}
+
+/* phase 2: per row, lower envelope of the parabolas (x-i)^2 + g(i)^2 (integer arithmetic, exact);
+ * one thread per row, its two stacks interleaved over rows so that neighbouring threads coalesce */
+__global__ void __launch_bounds__(128)
+edt_rows_kernel(const int *__restrict__ g, int rows, int cols, int *__restrict__ st_s, int *__restrict__ st_t,
+                int *__restrict__ d2, int *__restrict__ max_d2) {
+    const int yy = blockIdx.x * blockDim.x + threadIdx.x;
+    int mx = 0;
+    if (yy < rows) {
+#define G_(x) ((long long)g[(size_t)(x) * rows + yy])
+#define S_(q) st_s[(size_t)(q) * rows + yy]
+#define T_(q) st_t[(size_t)(q) * rows + yy]
+        auto F = [&](long long x, long long i, long long gi) { return (x - i) * (x - i) + gi * gi; };
+        int q = 0;
+        S_(0) = 0; T_(0) = 0;
+        for (int u = 1; u < cols; u++) {
+            const long long gu = G_(u);
+            while (q >= 0) {
+                const int sq = S_(q), tq = T_(q);
+                if (F(tq, sq, G_(sq)) > F(tq, u, gu)) q--; else break;
+            }
+            if (q < 0) { q = 0; S_(0) = u; }
+            else {
+                const long long i = S_(q), gi = G_(i);
+                const long long num = (long long)u * u - i * i + gu * gu - gi * gi, den = 2 * ((long long)u - i);
+                long long w = num / den;
+                if ((num % den != 0) && (num < 0)) w--;                   /* floor division */
+                w += 1;
+                if (w < cols) { q++; S_(q) = u; T_(q) = (int)w; }
+            }
+        }
+        for (int u = cols - 1; u >= 0; u--) {
+            const int sq = S_(q);
+            const long long v = F(u, sq, G_(sq));
+            const int vi = v > 0x3fffffffLL ? 0x3fffffff : (int)v;
+            d2[(size_t)u * rows + yy] = vi;
+            mx = vi > mx ? vi : mx;
+            if (u == T_(q)) q--;
+        }
+#undef G_
+#undef S_
+#undef T_
+    }
+    /* max over the level (min is 0: the edge pixels) */
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_down(mx, off, 64); mx = o > mx ? o : mx; }
+    if ((threadIdx.x & 63) == 0) atomicMax(max_d2, mx);
+}
+
+/* raw distance -> normalised [0,255] float, in place (the int buffer is reused as float) */
+__global__ void __launch_bounds__(256)
+dt_normalize_kernel(int *__restrict__ d2_inout, size_t n, const int *__restrict__ max_d2) {
+    const float mxf = (float)sqrt((double)*max_d2), mnf = 0.0f;
+    const double scale = (mxf > mnf) ? 255.0 / ((double)mxf - (double)mnf) : 0.0;     /* cv::normalize NORM_MINMAX, :1774 */
+    float *out = reinterpret_cast<float *>(d2_inout);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float raw = (float)sqrt((double)d2_inout[i]);
+        out[i] = (float)(((double)raw - (double)mnf) * scale);
+    }
+}
+
+DVO_DEV int reflect101(int i, int n) { return (n == 1) ? 0 : (i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i)); }
+
+__global__ void __launch_bounds__(256)
+dt_gradient_pack_kernel(const float *__restrict__ dt, int rows, int cols, float4 *__restrict__ out) {
+    const size_t n = (size_t)rows * cols;
+    const int tpc = texel_tiles_per_col(rows);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i / rows), yy = (int)(i - (size_t)xx * rows);
+        const float l_ = dt[(size_t)reflect101(xx - 1, cols) * rows + yy], r_ = dt[(size_t)reflect101(xx + 1, cols) * rows + yy];
+        const float u_ = dt[(size_t)xx * rows + reflect101(yy - 1, rows)], b_ = dt[(size_t)xx * rows + reflect101(yy + 1, rows)];
+        const float v = dt[i];
+        out[texel_index(yy, xx, tpc)] = make_float4(v, 0.5f * r_ - 0.5f * l_, 0.5f * b_ - 0.5f * u_, weight_of(v));
+    }
+}
+
+/* texels -> the three planar images (inspection / tests) */
+__global__ void __launch_bounds__(256)
+unpack_texels_kernel(const float4 *__restrict__ tex, int rows, int cols, float *__restrict__ dt,
+                     float *__restrict__ gx, float *__restrict__ gy) {
+    const size_t n = (size_t)rows * cols;
+    const int tpc = texel_tiles_per_col(rows);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i / rows), yy = (int)(i - (size_t)xx * rows);
+        const float4 t = tex[texel_index(yy, xx, tpc)];
+        dt[i] = t.x; gx[i] = t.y; gy[i] = t.z;
+    }
+}
+
+hipError_t launch_now_level_from_edges(const unsigned char *edge, int rows, int cols, int *work /* 3*rows*cols + 1 ints */,
+                                       float4 *tex_out, hipStream_t s) {
+    const size_t n = (size_t)rows * cols;
+    int *g = work, *st_s = work + n, *st_t = work + 2 * n, *max_d2 = work + 3 * n;
+    hipError_t e = hipMemsetAsync(max_d2, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(edt_columns_kernel, dim3(cols), dim3(64), 0, s, edge, rows, cols, g);
+    /* d2 overwrites st_s?  no: d2 goes to its own region = reuse g is not possible (read while written) -> st_s is free after the scan of a row only; use a 4th region */
+    hipLaunchKernelGGL(edt_rows_kernel, dim3((rows + 127) / 128), dim3(128), 0, s, g, rows, cols, st_s, st_t, work + 3 * n + 1, max_d2);
+    size_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(dt_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, s, work + 3 * n + 1, n, max_d2);
+    hipLaunchKernelGGL(dt_gradient_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                       reinterpret_cast<const float *>(work + 3 * n + 1), rows, cols, tex_out);
+    return hipGetLastError();
+}
+hipError_t launch_unpack_texels(const float4 *tex, int rows, int cols, float *dt, float *gx, float *gy, hipStream_t s) {
+    const size_t n = (size_t)rows * cols;
+    size_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(unpack_texels_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tex, rows, cols, dt, gx, gy);
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------- */
 /* SE(3) helpers on one lane (property tests of the device math)               */
 /* ------------------------------------------------------------------------- */
 __global__ void se3_exp_kernel(const double *psi, double *Rt) {

@@ -168,6 +168,12 @@ class Oracle:
             last = l
         return dict(R=R, t=t, levels=reports, last_level=last)
 
+    def now_level_from_edges(self, edge, rows, cols):
+        edge = np.ascontiguousarray(edge, dtype=np.uint8)
+        dt, gx, gy = (np.zeros(rows * cols, np.float32) for _ in range(3))
+        self.lib.dvo_oracle_now_level_from_edges(_p(edge), rows, cols, _p(dt), _p(gx), _p(gy))
+        return dt, gx, gy
+
     def se3_exp(self, psi):
         psi = np.array(psi, dtype=np.float64)
         R, t = np.zeros((3, 3), order="F"), np.zeros(3)
@@ -225,6 +231,8 @@ def load() -> Oracle:
         lib.dvo_oracle_state_update.restype = C.c_int
         lib.dvo_oracle_state_finish.argtypes = [C.c_void_p] * 4
         lib.dvo_oracle_state_finish.restype = None
+        lib.dvo_oracle_now_level_from_edges.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.dvo_oracle_now_level_from_edges.restype = None
         for n in ("se3_exp", "se3_log"):
             getattr(lib, "dvo_oracle_" + n).argtypes = [C.c_void_p] * 3
         lib.dvo_oracle_rotationize.argtypes = [C.c_void_p]

@@ -437,3 +437,43 @@ def test_large_frame_wide_path(oracle):
         assert rot_angle(ref["R"], Rf[0]) <= ROT_TOL and np.linalg.norm(ref["t"] - tf[0]) <= TRANS_TOL
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("W,H,nl,seed", [(320, 240, 4, 0), (640, 480, 4, 1), (1000, 700, 2, 2)])
+def test_now_level_from_edges_on_gpu(oracle, W, H, nl, seed):
+    """f1: exact EDT -> normalise -> gradients -> texels on the device == the oracle's restatement, bit for bit"""
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    sc = SynthScene(W, H, nl, seed)
+    ctx = DvoContext(2)
+    try:
+        for l, L in enumerate(sc.levels):
+            edge = (L.now_edge > 0).astype(np.uint8)
+            dt, gx, gy = oracle.now_level_from_edges(edge, L.rows, L.cols)
+            ctx.set_now_level_from_edges(l, edge, L.rows, L.cols, pair=1)
+            gdt, ggx, ggy = ctx.get_now_level(l, pair=1)
+            assert np.array_equal(gdt, dt), (l, np.abs(gdt - dt).max())
+            assert np.array_equal(ggx, gx) and np.array_equal(ggy, gy), l
+            # the planar upload path round-trips too
+            ctx.set_now_level(l, dt, gx, gy, L.rows, L.cols, pair=0)
+            a, b, c = ctx.get_now_level(l, pair=0)
+            assert np.array_equal(a, dt) and np.array_equal(b, gx) and np.array_equal(c, gy)
+    finally:
+        ctx.close()
+
+
+def test_now_level_from_edges_edge_cases(oracle):
+    from rgbd_odometry_amd import DvoContext, DvoError
+    ctx = DvoContext(1)
+    try:
+        rng = np.random.default_rng(3)
+        for rows, cols in [(1, 70), (65, 1), (64, 64), (130, 3), (37, 129)]:
+            edge = (rng.random(rows * cols) < 0.02).astype(np.uint8)
+            edge[rng.integers(rows * cols)] = 1
+            dt, gx, gy = oracle.now_level_from_edges(edge, rows, cols)
+            ctx.set_now_level_from_edges(0, edge, rows, cols)
+            gdt, ggx, ggy = ctx.get_now_level(0)
+            assert np.array_equal(gdt, dt) and np.array_equal(ggx, gx) and np.array_equal(ggy, gy), (rows, cols)
+        with pytest.raises(DvoError):
+            ctx.set_now_level_from_edges(0, np.zeros(64, np.uint8), 8, 8)      # no edge pixel at all
+    finally:
+        ctx.close()

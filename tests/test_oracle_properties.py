@@ -192,3 +192,31 @@ def test_oracle_converges_towards_true_motion(scene, oracle):
     r = oracle.align_pyramid([50, 50, 50, 50], lv, sc.intrinsics, np.eye(3), np.zeros(3))
     assert rot_angle(sc.R_true, r["R"]) < 0.25 * rot_angle(sc.R_true, np.eye(3))
     assert np.linalg.norm(r["t"] - sc.t_true) < 0.35 * np.linalg.norm(sc.t_true)
+
+
+def test_now_level_from_edges_brute_force(oracle):
+    """exact EDT of the oracle (Felzenszwalb envelopes) against an O(n^2) brute force, and against the
+    scene generator's independent implementation (Meijster, integers)"""
+    rng = np.random.default_rng(5)
+    rows, cols = 23, 31
+    edge = (rng.random(rows * cols) < 0.05).astype(np.uint8)
+    edge[7] = 1
+    dt, gx, gy = oracle.now_level_from_edges(edge, rows, cols)
+    E = edge.reshape(rows, cols, order="F")
+    ys, xs = np.nonzero(E)
+    Y, X = np.mgrid[0:rows, 0:cols]
+    d2 = ((Y[..., None] - ys) ** 2 + (X[..., None] - xs) ** 2).min(axis=-1)
+    raw = np.sqrt(d2.astype(np.float64)).astype(np.float32)
+    want = ((raw.astype(np.float64) - 0.0) * (255.0 / float(raw.max()))).astype(np.float32)
+    got = dt.reshape(rows, cols, order="F")
+    assert np.array_equal(got, want)
+    assert got.min() == 0.0 and got.max() == 255.0                       # cv::normalize(0,255,NORM_MINMAX), :1774
+    # central differences with reflect-101 (:1077-1090): zero at the first/last column/row
+    GX = gx.reshape(rows, cols, order="F")
+    assert np.all(GX[:, 0] == 0) and np.all(GX[:, -1] == 0)
+    assert np.array_equal(GX[:, 1:-1], np.float32(0.5) * got[:, 2:] - np.float32(0.5) * got[:, :-2])
+    from rgbd_odometry_amd import SynthScene
+    sc = SynthScene(320, 240, 3, 9)
+    for L in sc.levels:
+        a, b, c = oracle.now_level_from_edges((L.now_edge > 0).astype(np.uint8), L.rows, L.cols)
+        assert np.array_equal(a, L.now_dt) and np.array_equal(b, L.now_gx) and np.array_equal(c, L.now_gy)
