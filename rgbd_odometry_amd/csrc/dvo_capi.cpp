@@ -43,7 +43,7 @@ struct dvo_ctx {
     int n_pairs = 0;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
-    Intrinsics K{0, 0, 0, 0};
+    Intrinsics K{0, 0, 0, 0, 0};
     bool have_K = false;
     Level lv[DVO_LEVELS];
     float *staging = nullptr;       /* 3 planes (or one point list) of the largest upload so far */
@@ -276,8 +276,6 @@ int dvo_create_batch(const dvo_params *p, int n_pairs, dvo_ctx **out) {
     if (n_pairs < 1) return fail(nullptr, DVO_ERR_INVALID, "n_pairs must be >= 1");
     dvo_params prm;
     if (p) prm = *p; else dvo_params_default(&prm);
-    if (prm.interpolate_dt)
-        return fail(nullptr, DVO_ERR_INVALID, "interpolate_dt=1 (__INTERPOLATE_DISTANCE_TRANSFORM) is not supported by the HIP path");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev < 1)
@@ -293,6 +291,7 @@ int dvo_create_batch(const dvo_params *p, int n_pairs, dvo_ctx **out) {
     c->dprm.psi_norm_stop = (double)prm.psi_norm_stop;      /* :872 */
     c->dprm.step_decay_after = prm.step_decay_after; c->dprm.step_decay_offset = prm.step_decay_offset;
     c->dprm.enable_rotationize = prm.enable_rotationize; c->dprm.enable_l2_reg = prm.enable_l2_reg;
+    c->dprm.interpolate_dt = prm.interpolate_dt ? 1 : 0;
 #define CRCHK(expr)                                                                                     \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \
@@ -369,7 +368,7 @@ int dvo_synchronize(dvo_ctx *c) {
 int dvo_set_intrinsics(dvo_ctx *c, float fx, float fy, float cx, float cy) {
     if (!c) return DVO_ERR_INVALID;
     if (!(fx > 0.0f) || !(fy > 0.0f)) return fail(c, DVO_ERR_INVALID, "fx, fy must be positive");
-    c->K = Intrinsics{fx, fy, cx, cy};
+    c->K = Intrinsics{fx, fy, cx, cy, c->prm.interpolate_dt ? 1 : 0};
     c->have_K = true;
     return DVO_OK;
 }

@@ -30,6 +30,7 @@ struct DevParams {
     double trust_radius, psi_norm_stop;
     int step_decay_after, step_decay_offset;
     int enable_rotationize, enable_l2_reg;
+    int interpolate_dt;
 };
 
 /* Per-iteration, per-level constants: float pose (cast at :673-674) and the
@@ -40,8 +41,9 @@ struct IterConst {
     float m00, m02, m11, m12;   /* s*fx, s*cx, s*fy, s*cy  (float products) */
     float m00_z1, m11_z1;       /* m00/(1-2^-24), m11/(1-2^-24): A1(0,0), A1(1,1) when Z = 1-2^-24 */
     float ncols_f, nrows_f;
-    int rows;
+    int rows, cols;
     int tiles_per_col;          /* texel tiles along yy (see texel_index) */
+    int interp;                 /* __INTERPOLATE_DISTANCE_TRANSFORM (SolveDVO.h:97): eps from interpolate() */
 };
 
 struct PointEval {
@@ -180,6 +182,26 @@ __host__ __device__ inline int texel_index(int yy, int xx, int tiles_per_col) {
            (yy & (DVO_TILE_Y - 1));
 }
 
+/* SolveDVO::interpolate (:1285-1308), the reference's optional residual lookup (call site :443-444,
+ * compiled out by default): a "bilinear" interpolation of SQUARES, sqrt((1-a) F0^2 + a F1^2), along x for
+ * the floor and ceil rows, then along y.  Only eps uses it; the gradient lookup stays nearest (:376-385).
+ * The reference would index one past the end when ceil() reaches rows/cols; clamped like the oracle. */
+DVO_DEV float interpolate_dt(const IterConst &c, const float4 *__restrict__ tex, float ry, float rx) {
+    const int ry_d = (int)floor((double)ry), rx_d = (int)floor((double)rx);
+    int ry_u = (int)ceil((double)ry), rx_u = (int)ceil((double)rx);
+    const float inc_x = rx - (float)rx_d, inc_y = ry - (float)ry_d;
+    if (ry_u > c.rows - 1) ry_u = c.rows - 1;
+    if (rx_u > c.cols - 1) rx_u = c.cols - 1;
+    const float f00 = tex[texel_index(ry_d, rx_d, c.tiles_per_col)].x, f01 = tex[texel_index(ry_d, rx_u, c.tiles_per_col)].x;
+    const float f10 = tex[texel_index(ry_u, rx_d, c.tiles_per_col)].x, f11 = tex[texel_index(ry_u, rx_u, c.tiles_per_col)].x;
+    const float a = (1.0f - inc_x) * f00 * f00 + (inc_x) * f01 * f01;
+    const float f_d = (float)sqrt((double)a);
+    const float b = (1.0f - inc_x) * f10 * f10 + (inc_x) * f11 * f11;
+    const float f_u = (float)sqrt((double)b);
+    const float cc = (1.0f - inc_y) * f_d * f_d + inc_y * f_u * f_u;
+    return (float)sqrt((double)cc);
+}
+
 DVO_DEV PointEval eval_point(const IterConst &c, const float4 *__restrict__ tex,
                              float X, float Y, float Z) {
     PointEval o;
@@ -194,6 +216,10 @@ DVO_DEV PointEval eval_point(const IterConst &c, const float4 *__restrict__ tex,
         jacobian_row(c, xn, yn, o.zn, tx.y, tx.z, o.J);
         o.eps = tx.x;
         o.w = tx.w;             /* getWeightOf(eps), evaluated once per pixel when the texel is packed */
+        if (c.interp) {         /* :443-444 */
+            o.eps = interpolate_dt(c, tex, o.v, o.u);
+            o.w = weight_of(o.eps);
+        }
     }
     return o;
 }

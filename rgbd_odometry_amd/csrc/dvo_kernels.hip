@@ -36,6 +36,8 @@ DVO_DEV float pow2_neg(int level) {          /* (float)pow(2,-level), exact (:23
     return __int_as_float((127 - level) << 23);
 }
 DVO_DEV void level_consts(IterConst &c, const Intrinsics &K, int level, int rows, int cols) {
+    c.interp = K.interp;
+    c.cols = cols;
     const float s = pow2_neg(level);
     c.m00 = s * K.fx; c.m02 = s * K.cx;       /* (scaleMatrix*K), :344 */
     c.m11 = s * K.fy; c.m12 = s * K.cy;
@@ -121,6 +123,7 @@ DVO_DEV void load_point(const PointSrc &p, int i, float &X, float &Y, float &Z) 
  * state is straight-line code. */
 template <int U> struct RoundBuf {
     float xn[U], yn[U], zn[U];
+    float u[U], v[U];          /* reprojection, only consumed by the optional interpolate() lookup */
     float4 t[U];
     bool vis[U];
 };
@@ -139,6 +142,7 @@ DVO_DEV void round_issue(const IterConst &c, const float4 *__restrict__ tex, con
         load_point<USE_LDS>(pts, ii, X, Y, Z);
         const bool vis = project_point(c, X, Y, Z, b.xn[u], b.yn[u], b.zn[u], uu, vv) && valid;
         b.vis[u] = vis;
+        b.u[u] = uu; b.v[u] = vv;
         idx[u] = vis ? texel_index((int)vv, (int)uu, c.tiles_per_col) : 0;
         if (!vis) { b.xn[u] = 0.0f; b.yn[u] = 0.0f; b.zn[u] = 1.0f; }    /* finite dummy */
     }
@@ -147,14 +151,17 @@ DVO_DEV void round_issue(const IterConst &c, const float4 *__restrict__ tex, con
 }
 /* stage C: Jacobian rows + accumulation; invisible lanes add exact zeros */
 template <int U, bool WITH_H>
-DVO_DEV void round_compute(const IterConst &c, const RoundBuf<U> &b, Acc &a) {
+DVO_DEV void round_compute(const IterConst &c, const float4 *__restrict__ tex, const RoundBuf<U> &b, Acc &a) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
         a.nvis += __popcll(__ballot(b.vis[u]));
         float J[6];
         jacobian_row(c, b.xn[u], b.yn[u], b.zn[u], b.t[u].y, b.t[u].z, J);
-        const float eps = b.vis[u] ? b.t[u].x : 0.0f;
-        const float w = b.vis[u] ? b.t[u].w : 0.0f;
+        float eps = b.vis[u] ? b.t[u].x : 0.0f;
+        float w = b.vis[u] ? b.t[u].w : 0.0f;
+        if (c.interp) {                                    /* wave-uniform; off in the reference's build (SolveDVO.h:97) */
+            if (b.vis[u]) { eps = interpolate_dt(c, tex, b.v[u], b.u[u]); w = weight_of(eps); }
+        }
         acc_add<WITH_H>(a, J, eps, w);
     }
 }
@@ -174,16 +181,16 @@ DVO_DEV void accumulate_points(const IterConst &c, const float4 *__restrict__ te
     int r = 0;
     for (; r + 2 < n_rounds; r += 2) {                       /* steady state: A = round r */
         round_issue<U, USE_LDS>(c, tex, pts, first + (r + 1) * step, end, lane_off, stride, B);
-        round_compute<U, WITH_H>(c, A, a);
+        round_compute<U, WITH_H>(c, tex, A, a);
         round_issue<U, USE_LDS>(c, tex, pts, first + (r + 2) * step, end, lane_off, stride, A);
-        round_compute<U, WITH_H>(c, B, a);
+        round_compute<U, WITH_H>(c, tex, B, a);
     }
     if (r + 1 < n_rounds) {                                  /* two rounds left */
         round_issue<U, USE_LDS>(c, tex, pts, first + (r + 1) * step, end, lane_off, stride, B);
-        round_compute<U, WITH_H>(c, A, a);
-        round_compute<U, WITH_H>(c, B, a);
+        round_compute<U, WITH_H>(c, tex, A, a);
+        round_compute<U, WITH_H>(c, tex, B, a);
     } else {
-        round_compute<U, WITH_H>(c, A, a);
+        round_compute<U, WITH_H>(c, tex, A, a);
     }
 }
 
@@ -429,7 +436,7 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
                     else load_point<false>(psrc, i, X, Y, Z);
                     const bool vis = project_point(c, X, Y, Z, xn, yn, zn, u, v);
                     float e = 0.0f;
-                    if (vis) e = tex[texel_index((int)v, (int)u, c.tiles_per_col)].x;
+                    if (vis) e = c.interp ? interpolate_dt(c, tex, v, u) : tex[texel_index((int)v, (int)u, c.tiles_per_col)].x;
                     fe[i] = e;
                     fr[3 * i] = u; fr[3 * i + 1] = v; fr[3 * i + 2] = zn;
                 }

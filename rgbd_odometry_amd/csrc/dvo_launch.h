@@ -44,7 +44,7 @@ struct Schedule {
     int lds_points;          /* reference points kept resident in LDS per workgroup (3 floats each) */
 };
 
-struct Intrinsics { float fx, fy, cx, cy; };
+struct Intrinsics { float fx, fy, cx, cy; int interp; /* dvo_params.interpolate_dt, travels with the camera model to every kernel */ };
 
 struct Outputs {
     double *poses;           /* n_pairs x 12 : R[9] col-major, t[3] */

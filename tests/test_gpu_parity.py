@@ -477,3 +477,35 @@ def test_now_level_from_edges_edge_cases(oracle):
             ctx.set_now_level_from_edges(0, np.zeros(64, np.uint8), 8, 8)      # no edge pixel at all
     finally:
         ctx.close()
+
+
+def test_interpolate_distance_transform_flag(scene320, oracle):
+    """row A10: __INTERPOLATE_DISTANCE_TRANSFORM (SolveDVO.h:97, :443-444): eps from SolveDVO::interpolate"""
+    sc, lv = scene320
+    p = oracle.default_params()
+    p.interpolate_dt = 1
+    ctx = _ctx_for(sc, lv, interpolate_dt=1)
+    try:
+        R0, t0 = oracle.se3_exp(np.array([0.004, -0.003, 0.002, 0.003, -0.004, 0.002]))
+        for l, L in enumerate(lv):
+            ref = oracle.eval_points(l, L["xyz"], L["dt"], L["gx"], L["gy"], L["rows"], L["cols"], sc.intrinsics, R0, t0,
+                                     params=p)
+            got = ctx.eval_points(l, R0, t0)
+            for key in ("eps", "w", "J", "reproj"):
+                assert _same(ref[key], got[key]), (l, key)
+        iters = [6, 6, 6, 6]
+        ref = oracle.align_pyramid(iters, lv, sc.intrinsics, np.eye(3), np.zeros(3), params=p)
+        plain = oracle.align_pyramid(iters, lv, sc.intrinsics, np.eye(3), np.zeros(3))
+        assert not np.array_equal(ref["levels"][0]["energy"], plain["levels"][0]["energy"])   # the flag matters
+        from rgbd_odometry_amd.capi import DVO_FLAG_FINAL_OUTPUTS
+        R, t = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)), flags=DVO_FLAG_FINAL_OUTPUTS)
+        for l, rep in ref["levels"].items():
+            e, b, ratio = ctx.level_report(0, l, iters[l])
+            assert np.array_equal(e, rep["energy"]) and b == rep["best_idx"], l
+        assert rot_angle(ref["R"], R[0]) <= ROT_TOL and np.linalg.norm(ref["t"] - t[0]) <= TRANS_TOL
+        feps, _ = ctx.final_outputs(0, len(lv[0]["xyz"]))
+        assert _same(feps, ref["levels"][0]["final_eps"])
+        Rw, tw = ctx.align_pyramid_wide(iters, np.eye(3), np.zeros(3))
+        assert rot_angle(ref["R"], Rw) <= ROT_TOL and np.linalg.norm(ref["t"] - tw) <= TRANS_TOL
+    finally:
+        ctx.close()
