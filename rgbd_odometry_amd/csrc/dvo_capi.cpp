@@ -228,12 +228,24 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
     LevelSet ls;
     for (int l = 0; l < DVO_LEVELS; l++) ls.l[l] = slab_of(c, l);
     int block = c->prm.block_threads;
-    if (block != 256 && block != 512 && block != 1024) block = 512;
+    int auto_lds = 0;
+    if (block != 256 && block != 512 && block != 1024) {
+        /* auto: when the longest point list of the launch fits half a CU's LDS, two 256-thread workgroups
+         * per CU overlap each other's serial phases (measured: 320x240x4x50 213 k -> 288 k aligns/s); otherwise
+         * one 512-thread workgroup owns the CU and its LDS (640x480: 386 k vs 374 k) */
+        int max_n = 0;
+        for (int l = 0; l < n_levels; l++) {
+            if (sc.iters[l] <= 0) continue;
+            for (int p = first_pair; p < first_pair + n_pairs; p++) max_n = std::max(max_n, c->lv[l].hN[p]);
+        }
+        if ((size_t)max_n * 12 <= 77000 && !c->prm.interpolate_dt) { block = 256; auto_lds = 77000; }
+        else { block = 512; auto_lds = 155000; }
+    }
     /* LDS budget of the level's resident point list */
     {
         int bytes = c->prm.lds_point_bytes;
         /* auto: one workgroup per CU for >= 512 threads (it owns the CU's LDS), two for 256 */
-        if (bytes == 0) bytes = (block >= 512) ? 155000 : 77000;
+        if (bytes == 0) bytes = auto_lds ? auto_lds : ((block >= 512) ? 155000 : 77000);
         if (bytes > 156 * 1024) bytes = 156 * 1024;
         sc.lds_points = bytes / 12;
         if (c->prm.lds_point_bytes < 0) sc.lds_points = 0;

@@ -123,7 +123,6 @@ DVO_DEV void load_point(const PointSrc &p, int i, float &X, float &Y, float &Z) 
  * state is straight-line code. */
 template <int U> struct RoundBuf {
     float xn[U], yn[U], zn[U];
-    float u[U], v[U];          /* reprojection, only consumed by the optional interpolate() lookup */
     float4 t[U];
     bool vis[U];
 };
@@ -142,7 +141,6 @@ DVO_DEV void round_issue(const IterConst &c, const float4 *__restrict__ tex, con
         load_point<USE_LDS>(pts, ii, X, Y, Z);
         const bool vis = project_point(c, X, Y, Z, b.xn[u], b.yn[u], b.zn[u], uu, vv) && valid;
         b.vis[u] = vis;
-        b.u[u] = uu; b.v[u] = vv;
         idx[u] = vis ? texel_index((int)vv, (int)uu, c.tiles_per_col) : 0;
         if (!vis) { b.xn[u] = 0.0f; b.yn[u] = 0.0f; b.zn[u] = 1.0f; }    /* finite dummy */
     }
@@ -150,7 +148,9 @@ DVO_DEV void round_issue(const IterConst &c, const float4 *__restrict__ tex, con
     for (int u = 0; u < U; u++) b.t[u] = tex[idx[u]];
 }
 /* stage C: Jacobian rows + accumulation; invisible lanes add exact zeros */
-template <int U, bool WITH_H>
+/* INTERP: 0 = nearest lookup only (the reference's build), 1 = interpolate() always, 2 = decide at run time
+ * from c.interp (the non-critical single-evaluation kernels) */
+template <int U, bool WITH_H, int INTERP>
 DVO_DEV void round_compute(const IterConst &c, const float4 *__restrict__ tex, const RoundBuf<U> &b, Acc &a) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -159,8 +159,12 @@ DVO_DEV void round_compute(const IterConst &c, const float4 *__restrict__ tex, c
         jacobian_row(c, b.xn[u], b.yn[u], b.zn[u], b.t[u].y, b.t[u].z, J);
         float eps = b.vis[u] ? b.t[u].x : 0.0f;
         float w = b.vis[u] ? b.t[u].w : 0.0f;
-        if (c.interp) {                                    /* wave-uniform; off in the reference's build (SolveDVO.h:97) */
-            if (b.vis[u]) { eps = interpolate_dt(c, tex, b.v[u], b.u[u]); w = weight_of(eps); }
+        if (INTERP == 1 || (INTERP == 2 && c.interp)) {     /* off in the reference's build (SolveDVO.h:97) */
+            if (b.vis[u]) {     /* u, v recomputed exactly as project_point does (:344) */
+                const float uu = c.m00 * b.xn[u] + c.m02 * b.zn[u], vv = c.m11 * b.yn[u] + c.m12 * b.zn[u];
+                eps = interpolate_dt(c, tex, vv, uu);
+                w = weight_of(eps);
+            }
         }
         acc_add<WITH_H>(a, J, eps, w);
     }
@@ -169,7 +173,7 @@ DVO_DEV void round_compute(const IterConst &c, const float4 *__restrict__ tex, c
 /* The per-point phase of one iteration over points [first, end) with a lane
  * stride of `stride` (:369-407 + :433-451).  The trip count is wave-uniform, so
  * the visible count can be taken from ballots. */
-template <int U, bool WITH_H, bool USE_LDS>
+template <int U, bool WITH_H, bool USE_LDS, int INTERP>
 DVO_DEV void accumulate_points(const IterConst &c, const float4 *__restrict__ tex,
                                const PointSrc &pts, int first, int end, int lane_off,
                                int stride, Acc &a) {
@@ -181,16 +185,16 @@ DVO_DEV void accumulate_points(const IterConst &c, const float4 *__restrict__ te
     int r = 0;
     for (; r + 2 < n_rounds; r += 2) {                       /* steady state: A = round r */
         round_issue<U, USE_LDS>(c, tex, pts, first + (r + 1) * step, end, lane_off, stride, B);
-        round_compute<U, WITH_H>(c, tex, A, a);
+        round_compute<U, WITH_H, INTERP>(c, tex, A, a);
         round_issue<U, USE_LDS>(c, tex, pts, first + (r + 2) * step, end, lane_off, stride, A);
-        round_compute<U, WITH_H>(c, tex, B, a);
+        round_compute<U, WITH_H, INTERP>(c, tex, B, a);
     }
     if (r + 1 < n_rounds) {                                  /* two rounds left */
         round_issue<U, USE_LDS>(c, tex, pts, first + (r + 1) * step, end, lane_off, stride, B);
-        round_compute<U, WITH_H>(c, tex, A, a);
-        round_compute<U, WITH_H>(c, tex, B, a);
+        round_compute<U, WITH_H, INTERP>(c, tex, A, a);
+        round_compute<U, WITH_H, INTERP>(c, tex, B, a);
     } else {
-        round_compute<U, WITH_H>(c, tex, A, a);
+        round_compute<U, WITH_H, INTERP>(c, tex, A, a);
     }
 }
 
@@ -336,7 +340,7 @@ DVO_DEV unsigned long long stamp_now() {
 #ifndef DVO_WAVES_PER_EU
 #define DVO_WAVES_PER_EU 1       /* register budget of the fused kernel: 512 / waves VGPRs */
 #endif
-template <int BLOCK, int U>
+template <int BLOCK, int U, int INTERP>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(DVO_WAVES_PER_EU, 8)))
 align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outputs out, int first_pair) {
     const int pair = first_pair + blockIdx.x;
@@ -400,8 +404,8 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
 #endif
             Acc a;
             acc_zero(a);
-            accumulate_points<U, false, true>(c, tex, psrc, 0, psrc.n_lds, tid, BLOCK, a);    /* :369, :433 */
-            accumulate_points<U, false, false>(c, tex, psrc, psrc.n_lds, N, tid, BLOCK, a);  /* beyond the LDS budget */
+            accumulate_points<U, false, true, INTERP>(c, tex, psrc, 0, psrc.n_lds, tid, BLOCK, a);    /* :369, :433 */
+            accumulate_points<U, false, false, INTERP>(c, tex, psrc, psrc.n_lds, N, tid, BLOCK, a);  /* beyond the LDS budget */
 #ifdef DVO_YOUNG_WAVE_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
@@ -436,7 +440,7 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
                     else load_point<false>(psrc, i, X, Y, Z);
                     const bool vis = project_point(c, X, Y, Z, xn, yn, zn, u, v);
                     float e = 0.0f;
-                    if (vis) e = c.interp ? interpolate_dt(c, tex, v, u) : tex[texel_index((int)v, (int)u, c.tiles_per_col)].x;
+                    if (vis) e = (INTERP == 1) ? interpolate_dt(c, tex, v, u) : tex[texel_index((int)v, (int)u, c.tiles_per_col)].x;
                     fe[i] = e;
                     fr[3 * i] = u; fr[3 * i + 1] = v; fr[3 * i + 2] = zn;
                 }
@@ -465,7 +469,7 @@ template <int BLOCK, int U>
 static void launch_fused_bu(const LevelSet &lv, const Schedule &sc, const Intrinsics &K,
                             const DevParams &prm, const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {
     const size_t dyn = (size_t)sc.lds_points * 3 * sizeof(float);
-    auto kern = align_fused_kernel<BLOCK, U>;
+    auto kern = align_fused_kernel<BLOCK, U, 0>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     hipLaunchKernelGGL(kern, dim3(n_pairs), dim3(BLOCK), dyn, s, lv, sc, K, prm, out, first_pair);
 }
@@ -481,6 +485,13 @@ hipError_t launch_align_fused(int block_threads, int points_in_flight, const Lev
                               const Schedule &sc, const Intrinsics &K, const DevParams &prm,
                               const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {
     if (n_pairs <= 0) return hipSuccess;
+    if (K.interp) {     /* optional interpolate() lookup: one configuration only, it is not the tuned path */
+        const size_t dyn = (size_t)sc.lds_points * 3 * sizeof(float);
+        auto kern = align_fused_kernel<512, 1, 1>;
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        hipLaunchKernelGGL(kern, dim3(n_pairs), dim3(512), dyn, s, lv, sc, K, prm, out, first_pair);
+        return hipGetLastError();
+    }
     switch (block_threads) {
     case 256: launch_fused_b<256>(points_in_flight, lv, sc, K, prm, out, first_pair, n_pairs, s); break;
     case 1024: launch_fused_b<1024>(points_in_flight, lv, sc, K, prm, out, first_pair, n_pairs, s); break;
@@ -553,7 +564,7 @@ accumulate_kernel(LevelSlab L, int pair, int level, Intrinsics K, FloatPose P,
     if (b1 > first + n) b1 = first + n;
     PointSrc psrc;
     psrc.g = pts; psrc.l = nullptr; psrc.n_lds = 0; psrc.cap = 0;
-    if (b0 < b1) accumulate_points<4, true, false>(c, tex, psrc, b0, b1, threadIdx.x, 256, a);
+    if (b0 < b1) accumulate_points<4, true, false, 2>(c, tex, psrc, b0, b1, threadIdx.x, 256, a);
     block_reduce<256, true>(a, red, tot);
     if (threadIdx.x < DVO_NACC_PAD)
         partials[(size_t)blockIdx.x * DVO_NACC_PAD + threadIdx.x] = (threadIdx.x < DVO_NACC) ? tot[threadIdx.x] : 0.0;
@@ -634,7 +645,7 @@ accumulate_state_kernel(LevelSlab L, int pair, int level, Intrinsics K, const Po
     if (b1 > first + n) b1 = first + n;
     PointSrc psrc;
     psrc.g = pts; psrc.l = nullptr; psrc.n_lds = 0; psrc.cap = 0;
-    if (b0 < b1) accumulate_points<2, true, false>(c, tex, psrc, b0, b1, threadIdx.x, 256, a);
+    if (b0 < b1) accumulate_points<2, true, false, 2>(c, tex, psrc, b0, b1, threadIdx.x, 256, a);
     block_reduce<256, true>(a, red, tot);
     if (threadIdx.x < DVO_NACC_PAD)
         partials[(size_t)blockIdx.x * DVO_NACC_PAD + threadIdx.x] = (threadIdx.x < DVO_NACC) ? tot[threadIdx.x] : 0.0;
