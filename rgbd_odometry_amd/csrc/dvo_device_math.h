@@ -292,8 +292,7 @@ DVO_DEV void d_sincos(double x, double &s, double &c) {
 }
 /* atan(x) for any finite x: |x|>1 -> pi/2 - atan(1/|x|); two half-angle steps
  * atan(y) = 2 atan(y / (1 + sqrt(1+y^2))) bring |y| <= tan(pi/16); 12-term series. */
-DVO_DEV double d_atan_series(double y, int nterms_from) {
-    (void)nterms_from;
+DVO_DEV double d_atan_series(double y) {        /* |y| <= 0.25: |y|^31/31 < 1e-20 */
     const double z = y * y;
     double p = 1.0 / 29.0;
     p = fma(p, z, -1.0 / 27.0);
@@ -312,7 +311,7 @@ DVO_DEV double d_atan_series(double y, int nterms_from) {
     return fma(p * z, y, y);
 }
 DVO_DEV double d_atan(double x) {
-    if (fabs(x) <= 0.25) return d_atan_series(x, 0);     /* |x|^31/31 < 1e-20: plain series (the usual case) */
+    if (fabs(x) <= 0.25) return d_atan_series(x);        /* plain series (the usual case) */
     const double ax = fabs(x);
     const bool inv = ax > 1.0;
     double y = inv ? d_rcp(ax) : ax;

@@ -3,24 +3,26 @@
  * SolveDVO edge-alignment hot path (reference src/SolveDVO.cpp:306-462, :619-1017).
  *
  * Kernels
- *   align_fused_kernel   the whole coarse-to-fine schedule of one frame pair in
- *                        ONE workgroup: per iteration every lane warps its share
- *                        of the reference edge points, gathers one 16-byte texel
- *                        {DT,gx,gy} of the now level, forms the 1x6 Jacobian row
- *                        and accumulates 29 sums in registers; a wave-shuffle +
- *                        LDS tree reduces them in a fixed order; lane 0 then
- *                        performs the reference's double-precision sub-gradient /
- *                        heavy-ball / trust-region update and publishes the next
- *                        float pose through LDS.  grid = number of frame pairs.
- *   pack_texels_kernel   planar DT/gx/gy (reference layout) -> float4 texels.
- *   eval_points_kernel, accumulate_kernel (+reduce_partials_kernel)
- *                        single-evaluation forms used for inspection, large
- *                        frames and the multi-GPU tiled mode.
+ *   align_fused_kernel   the whole coarse-to-fine schedule of one frame pair in ONE workgroup
+ *                        (throughput path, grid = number of frame pairs).  Per level the reference
+ *                        points are staged once into LDS; per iteration every lane warps its share of
+ *                        them, gathers one 16-byte texel {DT,gx,gy,w} of the now level (software
+ *                        pipelined, ping-pong registers), forms the 1x6 Jacobian row and accumulates
+ *                        g = J^T W eps and sum eps^2 in double; a wave butterfly + LDS tree reduces them
+ *                        in a fixed order; lane 0 performs the reference's double-precision sub-gradient /
+ *                        heavy-ball / trust-region update and publishes the next float pose through LDS.
+ *   accumulate_state_kernel + reduce_partials_kernel / iter_reduce_update_kernel + iter_*_kernel
+ *                        one iteration spread over all CUs with the optimiser state in HBM: large single
+ *                        frames (dvo_align_pyramid_wide) and the multi-GPU tiled mode (dvo_iter_*), where
+ *                        the 32 sums (21 H + 6 g + sum eps^2 + visible count) are all-reduced in between.
+ *   eval_points_kernel, accumulate_kernel      single evaluations for inspection / parity tests.
+ *   pack_texels_kernel, replicate_level_kernel, unpack_texels_kernel     resident-data management.
  *   enlist_* kernels     selectedPts + enlistRefEdgePts (:1230-1264, :224-264).
+ *   edt_* / dt_* kernels computeDistTransfrmOfNow after Canny + imageGradient (:1768-1795, :1063-1098).
  *
- * No MFMA: the path is per-point arithmetic plus a tree reduction, not a dense
- * contraction.  Compile with -ffp-contract=off (see Makefile): bit-parity of the
- * float32 per-point math with the CPU oracle depends on it.
+ * No MFMA: the path is per-point arithmetic plus a tree reduction, not a dense contraction.
+ * Compile with -ffp-contract=off (see Makefile): bit-parity of the float32 per-point math with the
+ * CPU oracle depends on it.
  */
 #include "dvo_launch.h"
 
