@@ -132,11 +132,9 @@ def main():
         R, t = step(events[k])
     torch.cuda.synchronize()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
+    elapsed_local = time.perf_counter() - t0
+    from rgbd_odometry_amd.distributed import whole_job_throughput
+    value, elapsed = whole_job_throughput(args.batch, args.steps, elapsed_local, device="cuda")   # MAX over ranks
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
     bytes_per_launch = sum(ctx.algorithmic_bytes(iters, pair=p, flags=flags & DVO_FLAG_FINAL_OUTPUTS)
@@ -144,8 +142,6 @@ def main():
     point_iters = sum(ctx.point_iterations(iters, pair=p) for p in range(args.batch))
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
 
-    total_aligns = args.batch * args.steps * world
-    value = total_aligns / elapsed
 
     if rank == 0:
         out = {

@@ -39,6 +39,21 @@ def shard_sizes(n_items: int, world: int) -> List[int]:
     return [shard_range(n_items, r, world)[1] for r in range(world)]
 
 
+def whole_job_throughput(units_per_rank: int, steps: int, elapsed_local_s: float, device=None) -> float:
+    """Batch mode accounting of bench.py: every rank processed units_per_rank * steps units in its own
+    timed region; the job's rate is the total over all ranks divided by the SLOWEST rank's time
+    (MAX all-reduce; RCCL when the group backend is nccl, gloo in the CPU tests)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    elapsed = elapsed_local_s
+    if world > 1:
+        t = torch.tensor([elapsed_local_s], dtype=torch.float64, device=device or "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return units_per_rank * steps * world / elapsed, elapsed
+
+
 class TiledAligner:
     """Coarse-to-fine alignment of one frame pair whose point lists are sharded over the ranks of a
     process group (level schedule of SolveDVO::loop, SolveDVO.cpp:2097-2104).

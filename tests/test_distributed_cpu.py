@@ -121,6 +121,36 @@ def test_tiled_mode_two_ranks_gloo(world):
     assert dR < 1e-9 and dt < 1e-9          # sums are associated differently (2 partials): ~1e-16 noise
 
 
+def _rate_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rgbd_odometry_amd.distributed import whole_job_throughput
+        dist.barrier()
+        value, elapsed = whole_job_throughput(1024, 20, 0.050 * (rank + 1))      # rank 1 is the slow one
+        q.put((rank, value, elapsed))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_batch_mode_whole_job_throughput_two_ranks():
+    """bench.py's N>1 accounting: total units of all ranks / MAX over ranks of the timed region"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_rate_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    for rank, value, elapsed in got:
+        assert abs(elapsed - 0.100) < 1e-12                       # the slower rank's time, on both ranks
+        assert abs(value - 2 * 1024 * 20 / 0.100) < 1e-6
+
+
 def test_batch_mode_sharding_covers_all_pairs():
     """BASELINE config 4: 256 pairs over 8 GPUs -> 32 contiguous pairs each, no overlap"""
     owners = np.full(256, -1)
