@@ -42,6 +42,8 @@ def parse_args():
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic scenes (cycled over the batch)")
     ap.add_argument("--block", type=int, default=0, help="workgroup size of the fused kernel (0 = default)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-oracle baseline budget (0 = skip)")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time the CPU oracle with one alignment per host core (extra ~cpu-seconds)")
     ap.add_argument("--no-final-outputs", action="store_true")
     ap.add_argument("--inflight", type=int, default=0, help="points in flight per lane (1/2/4; 0 = default)")
     ap.add_argument("--lds-point-bytes", type=int, default=0, help="LDS bytes per workgroup for resident points (0 auto, <0 none)")
@@ -84,6 +86,32 @@ def cpu_baseline(args, scenes, iters, budget_s):
     return dict(value=n / el, unit="aligns/s", cores=1, kind="port",
                 sample=f"{n} alignments of the same workload ({len(lvs)} distinct scenes) in {el:.1f} s, "
                        f"1 thread of {os.cpu_count()} host cores, oracle/ built -O2 -ffp-contract=off"), oracle, lvs
+
+
+def _cpu_worker(job):
+    """one process = one host core: aligns its share of pairs with the oracle for `budget_s` seconds"""
+    W, H, levels, iters, seed, budget_s = job
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from rgbd_odometry_amd import SynthScene
+    oracle = oracle_lib.load()
+    sc = SynthScene(W, H, levels, seed)
+    lv = oracle_lib.scene_levels(sc, oracle)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        oracle.align_pyramid(iters, lv, sc.intrinsics, np.eye(3), np.zeros(3))
+        n += 1
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(args, iters, budget_s):
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    with mp.get_context("spawn").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(args.width, args.height, args.levels, iters, 1000 + i % 8, budget_s) for i in range(cores)])
+    rate = sum(n / t for n, t in res)
+    return dict(value=rate, unit="aligns/s", cores=cores, kind="port",
+                sample=f"{sum(n for n, _ in res)} alignments, one oracle process per host core for {budget_s:.0f} s each")
 
 
 def main():
@@ -184,6 +212,8 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             base, oracle, lvs = cpu_baseline(args, scenes, iters, args.cpu_seconds)
             out["cpu_baseline"] = base
+            if args.cpu_all_cores:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args, iters, args.cpu_seconds)
             # parity spot check in the same run: pair 0 against the oracle on the same inputs
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib

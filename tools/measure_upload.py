@@ -25,3 +25,16 @@ t0 = time.perf_counter(); ctx.enqueue(iters, flags=DVO_FLAG_IDENTITY_START); ctx
 bytes_pair = sum(12 * L.rows * L.cols for L in sc.levels) + sum(12 * len(x) for x in xyzs)
 print(json.dumps(dict(pairs=B, host_bytes_per_pair=bytes_pair, upload_pack_s=t_up, upload_GBps=B * bytes_pair / t_up / 1e9,
                       pairs_per_s_upload_only=B / t_up, align_s=t_al, pairs_per_s_including_upload=B / (t_up + t_al))))
+
+# second variant: raw-frame hand-over (row f1): 1-byte now edge masks + reference edge/depth images, everything else on the GPU
+edges = [(L.now_edge > 0).astype(np.uint8) for L in sc.levels]
+def upload_raw():
+    for p in range(B):
+        for l, L in enumerate(sc.levels):
+            ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols, pair=p)
+            ctx.set_now_level_from_edges(l, edges[l], L.rows, L.cols, pair=p)
+upload_raw(); ctx.synchronize()
+t0 = time.perf_counter(); upload_raw(); ctx.synchronize(); t_raw = time.perf_counter() - t0
+raw_bytes = sum(L.rows * L.cols * (1 + 4 + 4) for L in sc.levels)
+print(json.dumps(dict(variant="raw frames (edge masks + depth), preprocessing on the GPU", pairs=B, host_bytes_per_pair=raw_bytes,
+                      upload_preprocess_s=t_raw, pairs_per_s=B / t_raw, ms_per_pair=1e3 * t_raw / B)))
