@@ -507,7 +507,7 @@ int dvo_set_now_level_from_edges(dvo_ctx *c, int pair, int level, const unsigned
     if (!any) return fail(c, DVO_ERR_INVALID, "edge mask has no edge pixel: the distance transform is undefined");
     /* staging: edge bytes (rounded up to ints) | work ints */
     const size_t edge_ints = (npx + 3) / 4;
-    if ((rc = ensure_staging(c, sizeof(int) * (edge_ints + 4 * npx + 2)))) return rc;
+    if ((rc = ensure_staging(c, sizeof(int) * (edge_ints + 2 * npx + 2)))) return rc;
     unsigned char *d_edge = (unsigned char *)c->staging;
     int *work = (int *)c->staging + edge_ints;
     HIPCHK(c, hipMemcpyAsync(d_edge, edge, npx, hipMemcpyHostToDevice, c->stream));

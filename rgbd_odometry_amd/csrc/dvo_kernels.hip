@@ -733,8 +733,8 @@ size_t pose_state_bytes() { return sizeof(PoseState); }
 
 /* ------------------------------------------------------------------------- */
 /* now-frame preprocessing after Canny: computeDistTransfrmOfNow (SolveDVO.cpp:1768-1795) +
- * imageGradient (:1063-1098).  edge mask -> exact squared EDT in integers (Meijster, Roerdink,
- * Hesselink) -> sqrt -> min-max normalise to [0,255] (:1774) -> central differences with a
+ * imageGradient (:1063-1098).  edge mask -> exact squared EDT in integers (two separable passes)
+ * -> sqrt -> min-max normalise to [0,255] (:1774) -> central differences with a
  * reflect-101 border (:1077-1090) -> tiled texels {DT,gx,gy,w}.                              */
 /* ------------------------------------------------------------------------- */
 #define DVO_EDT_INF(rows, cols) ((rows) + (cols) + 1)
@@ -775,49 +775,26 @@ edt_columns_kernel(const unsigned char *__restrict__ edge, int rows, int cols, i
     }
 }
 
-/* phase 2: per row, lower envelope of the parabolas (x-i)^2 + g(i)^2 (integer arithmetic, exact);
- * one thread per row, its two stacks interleaved over rows so that neighbouring threads coalesce */
-__global__ void __launch_bounds__(128)
-edt_rows_kernel(const int *__restrict__ g, int rows, int cols, int *__restrict__ st_s, int *__restrict__ st_t,
-                int *__restrict__ d2, int *__restrict__ max_d2) {
-    const int yy = blockIdx.x * blockDim.x + threadIdx.x;
+/* phase 2: d2(x,y) = min_i (x-i)^2 + g(i,y)^2 along the row, exactly, in integers.  One thread per pixel
+ * scans outwards while i^2 < best: with edges every few pixels that is a few dozen coalesced loads, far
+ * cheaper on a GPU than the sequential lower-envelope scan (Meijster) a CPU would use -- same minimum. */
+__global__ void __launch_bounds__(256)
+edt_rows_kernel(const int *__restrict__ g, int rows, int cols, int *__restrict__ d2, int *__restrict__ max_d2) {
+    const size_t n = (size_t)rows * cols;
     int mx = 0;
-    if (yy < rows) {
-#define G_(x) ((long long)g[(size_t)(x) * rows + yy])
-#define S_(q) st_s[(size_t)(q) * rows + yy]
-#define T_(q) st_t[(size_t)(q) * rows + yy]
-        auto F = [&](long long x, long long i, long long gi) { return (x - i) * (x - i) + gi * gi; };
-        int q = 0;
-        S_(0) = 0; T_(0) = 0;
-        for (int u = 1; u < cols; u++) {
-            const long long gu = G_(u);
-            while (q >= 0) {
-                const int sq = S_(q), tq = T_(q);
-                if (F(tq, sq, G_(sq)) > F(tq, u, gu)) q--; else break;
-            }
-            if (q < 0) { q = 0; S_(0) = u; }
-            else {
-                const long long i = S_(q), gi = G_(i);
-                const long long num = (long long)u * u - i * i + gu * gu - gi * gi, den = 2 * ((long long)u - i);
-                long long w = num / den;
-                if ((num % den != 0) && (num < 0)) w--;                   /* floor division */
-                w += 1;
-                if (w < cols) { q++; S_(q) = u; T_(q) = (int)w; }
-            }
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(idx / rows);
+        const int g0 = g[idx];
+        int best = g0 * g0;                                   /* (rows+cols+1)^2 < 2^31 for every supported size */
+        for (int i = 1; i * i < best; i++) {
+            const bool l = xx - i >= 0, r = xx + i < cols;
+            if (!l && !r) break;
+            if (l) { const int gl = g[idx - (size_t)i * rows]; const int c = i * i + gl * gl; best = c < best ? c : best; }
+            if (r) { const int gr = g[idx + (size_t)i * rows]; const int c = i * i + gr * gr; best = c < best ? c : best; }
         }
-        for (int u = cols - 1; u >= 0; u--) {
-            const int sq = S_(q);
-            const long long v = F(u, sq, G_(sq));
-            const int vi = v > 0x3fffffffLL ? 0x3fffffff : (int)v;
-            d2[(size_t)u * rows + yy] = vi;
-            mx = vi > mx ? vi : mx;
-            if (u == T_(q)) q--;
-        }
-#undef G_
-#undef S_
-#undef T_
+        d2[idx] = best;
+        mx = best > mx ? best : mx;
     }
-    /* max over the level (min is 0: the edge pixels) */
     for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_down(mx, off, 64); mx = o > mx ? o : mx; }
     if ((threadIdx.x & 63) == 0) atomicMax(max_d2, mx);
 }
@@ -862,19 +839,18 @@ unpack_texels_kernel(const float4 *__restrict__ tex, int rows, int cols, float *
     }
 }
 
-hipError_t launch_now_level_from_edges(const unsigned char *edge, int rows, int cols, int *work /* 3*rows*cols + 1 ints */,
+hipError_t launch_now_level_from_edges(const unsigned char *edge, int rows, int cols, int *work /* 2*rows*cols + 1 ints */,
                                        float4 *tex_out, hipStream_t s) {
     const size_t n = (size_t)rows * cols;
-    int *g = work, *st_s = work + n, *st_t = work + 2 * n, *max_d2 = work + 3 * n;
+    int *g = work, *d2 = work + n, *max_d2 = work + 2 * n;
     hipError_t e = hipMemsetAsync(max_d2, 0, sizeof(int), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(edt_columns_kernel, dim3(cols), dim3(64), 0, s, edge, rows, cols, g);
-    /* d2 overwrites st_s?  no: d2 goes to its own region = reuse g is not possible (read while written) -> st_s is free after the scan of a row only; use a 4th region */
-    hipLaunchKernelGGL(edt_rows_kernel, dim3((rows + 127) / 128), dim3(128), 0, s, g, rows, cols, st_s, st_t, work + 3 * n + 1, max_d2);
     size_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(dt_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, s, work + 3 * n + 1, n, max_d2);
+    hipLaunchKernelGGL(edt_columns_kernel, dim3(cols), dim3(64), 0, s, edge, rows, cols, g);
+    hipLaunchKernelGGL(edt_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, rows, cols, d2, max_d2);
+    hipLaunchKernelGGL(dt_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d2, n, max_d2);
     hipLaunchKernelGGL(dt_gradient_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
-                       reinterpret_cast<const float *>(work + 3 * n + 1), rows, cols, tex_out);
+                       reinterpret_cast<const float *>(d2), rows, cols, tex_out);
     return hipGetLastError();
 }
 hipError_t launch_unpack_texels(const float4 *tex, int rows, int cols, float *dt, float *gx, float *gy, hipStream_t s) {

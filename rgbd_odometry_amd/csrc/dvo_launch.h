@@ -87,7 +87,7 @@ hipError_t launch_iter_step_fused(const LevelSlab &L, int pair, int level, const
                                   float *energy, hipStream_t s);
 hipError_t launch_iter_end(void *state, double *Rt12, int *best_idx, float *ratio, hipStream_t s);
 /* now-frame preprocessing after Canny (SolveDVO.cpp:1768-1795): edge mask -> texels.
- * work: device scratch of (4*rows*cols + 1) ints */
+ * work: device scratch of (2*rows*cols + 1) ints */
 hipError_t launch_now_level_from_edges(const unsigned char *edge, int rows, int cols, int *work,
                                        float4 *tex_out, hipStream_t s);
 hipError_t launch_unpack_texels(const float4 *tex, int rows, int cols, float *dt, float *gx, float *gy, hipStream_t s);
