@@ -61,6 +61,12 @@ def library_path() -> str:
 _lib = None
 
 
+def _build_native():
+    """make -C rgbd_odometry_amd/csrc: builds lib/libdvo_amd.so (gfx950), lib/libdvo_synth.so and the helper binaries"""
+    import subprocess
+    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
 def load_library() -> C.CDLL:
     """Load lib/libdvo_amd.so; raise if it is missing (build with __graft_entry__.build())."""
     global _lib
@@ -73,6 +79,8 @@ def load_library() -> C.CDLL:
     if os.environ.get("DVO_NO_TORCH", "0") != "1":
         import torch  # noqa: F401
     path = library_path()
+    if not os.path.exists(path) and not os.environ.get("DVO_LIB_VARIANT"):
+        _build_native()           # a fresh checkout: compile in-tree (hipcc), never fall back to anything else
     if not os.path.exists(path):
         raise FileNotFoundError(
             f"{path} not found: build the HIP extension first "

@@ -16,6 +16,10 @@ def _load():
         return _lib
     path = os.path.join(_HERE, "lib", "libdvo_synth.so")
     if not os.path.exists(path):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), os.path.join("..", "lib", "libdvo_synth.so")], check=False,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    if not os.path.exists(path):
         raise FileNotFoundError(f"{path} not found: run __graft_entry__.build() or make -C rgbd_odometry_amd/csrc")
     lib = C.CDLL(path)
     lib.dvo_synth_create.restype = C.c_void_p
