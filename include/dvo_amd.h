@@ -82,7 +82,9 @@ typedef struct dvo_params {
                                   (0 = auto from block_threads, < 0 = none) */
     int    debug_alias_mod;    /* diagnostics only: if > 0, pair p reads the inputs of pair p % debug_alias_mod
                                   (shrinks the HBM working set without changing the arithmetic); 0 = off */
-    int    reserved[3];
+    int    canny_threshold1;   /* cv::Canny(img, edge, 150, 100, 3, true): the two thresholds (order-free, the detector */
+    int    canny_threshold2;   /* swaps them), SolveDVO.cpp:1704,1764; used by the dvo_frame* entry points; 0,0 = 150,100 */
+    int    reserved[1];
 } dvo_params;
 
 typedef struct dvo_ctx dvo_ctx;
@@ -132,6 +134,9 @@ int  dvo_set_now_level_from_edges(dvo_ctx *ctx, int pair, int level, const unsig
 /* The planar DT / gradient images of a resident now level (host outputs, rows*cols floats each, any may
  * be NULL). */
 int  dvo_get_now_level(dvo_ctx *ctx, int pair, int level, float *dt, float *gx, float *gy);
+
+/* The resident reference point list of a level (3 x N floats, host output of `capacity` points; *N_out = N). */
+int  dvo_get_ref_level(dvo_ctx *ctx, int pair, int level, float *xyz_out, int capacity, int *N_out);
 
 /* Batch set-up helper: pair slot p in [dst_first, dst_first+dst_count) becomes a device-side copy of
  * pair (p - dst_first) % n_src (all levels that are set), one launch per level.  dst_first = 0 leaves the
@@ -238,6 +243,54 @@ int  dvo_algorithmic_bytes(dvo_ctx *ctx, int pair, int n_levels, const int *iter
                            uint64_t *bytes);
 /* Sum over levels of iters[l]*N_l (point-iterations) for `pair`. */
 int  dvo_point_iterations(dvo_ctx *ctx, int pair, int n_levels, const int *iters, uint64_t *count);
+
+/* ---- frames in (SURVEY.md section 8f rows f1 + f2) ----------------------------------------------------
+ * Everything between the camera / the RGBDFramePyd message and the hot path, on the GPU:
+ *   row f2  camTopic2PublisherPyD.cpp:73-77,322-347   depth m -> mm u16 (0 -> 1), INTER_NEAREST pyramid, BGR2GRAY
+ *   row f1  SolveDVO.cpp:1679-1799                     Canny(150,100,3,L2) -> distance transform -> normalise ->
+ *                                                      gradients (now side); :1700-1712 + :1230-1264 + :224-264
+ *                                                      Canny -> selectedPts -> enlistRefEdgePts (ref side)
+ * A context holds a FRAME STORE of `n_slots` frames (grey, depth in mm, Canny edge map per level, all in
+ * HBM).  A stored frame can be installed as the now frame and/or as the reference frame of any pair without
+ * another upload -- what setRcvdFrameAsNowFrame / setRcvdFrameAsRefFrame / setPrevFrameAsRefFrame
+ * (SolveDVO.cpp:535-618) do with host copies.  All slots share one pyramid geometry.
+ * Frame-store calls are batched: `count` consecutive slots per call, one kernel launch per stage and level. */
+enum { DVO_PIX_U8 = 0, DVO_PIX_U16 = 1, DVO_PIX_F32 = 2 };
+enum { DVO_LAYOUT_COL_MAJOR = 0,    /* Eigen (im_n[level].data()): (yy,xx) at yy + xx*rows */
+       DVO_LAYOUT_ROW_MAJOR = 1 };  /* cv::Mat / sensor_msgs::Image: (yy,xx) at yy*cols + xx */
+enum { DVO_UPLOAD_ASYNC = 1 };      /* do not wait for the copies: host buffers stay borrowed until dvo_synchronize() */
+
+typedef struct dvo_image {          /* one single-channel host image */
+    const void *data;
+    int rows, cols;
+    int dtype;                      /* DVO_PIX_* : grey U8 or F32 (values 0..255), depth U16 (mm) or F32 (mm) */
+    int layout;                     /* DVO_LAYOUT_* */
+} dvo_image;
+
+/* (re)size the frame store; default on first use: min(2*n_pairs + 2, 64) slots */
+int  dvo_frames_reserve(dvo_ctx *ctx, int n_slots);
+/* the pyramids of `count` frames as the dvo node receives them (RGBDFramePyd: framemono[] mono8 + dframe[] mono16,
+ * imageArrivedCallBack SolveDVO.cpp:490-534) or as the class holds them (im_n/dim_n: F32 column-major).
+ * grey[f*n_levels + l], depth[f*n_levels + l]; depth may be NULL (frames that will only ever be "now" frames).
+ * U16 depth gets the node's 0 -> 1 treatment (:514); F32 depth is taken as is.  Runs Canny per level. */
+int  dvo_frames_upload_pyramids(dvo_ctx *ctx, int first_slot, int count, int n_levels,
+                                const dvo_image *grey, const dvo_image *depth, int flags);
+/* camera frames: full-resolution BGR8 (rows x cols x 3, row-major) + depth in metres (F32 row-major, may be NULL);
+ * level l is decimated by 2^(first_shift + l) (the reference publishes first_shift = 1: 320x240 .. 40x30).
+ * Builds the pyramid on the device, then as above. */
+int  dvo_frames_upload_cameras(dvo_ctx *ctx, int first_slot, int count, const unsigned char *const *bgr8,
+                               const float *const *depth_m, int rows, int cols, int n_levels, int first_shift, int flags);
+/* computeDistTransfrmOfNow (SolveDVO.cpp:1740-1799): slot first_slot+i becomes the now frame of pair first_pair+i.
+ * Asynchronous on the context stream. */
+int  dvo_frames_as_now(dvo_ctx *ctx, int first_slot, int first_pair, int count);
+/* computeDistTransfrmOfRef's edge map + preProcessRefFrame (:269-303): slot first_slot+i becomes the reference
+ * frame of pair first_pair+i.  N_out[i*n_levels + l] (may be NULL) receives the point counts.  Needs intrinsics
+ * and depth.  One host synchronisation (the point counts size the slabs). */
+int  dvo_frames_as_ref(dvo_ctx *ctx, int first_slot, int first_pair, int count, int *N_out);
+/* inspection: geometry and resident images of one stored level (host outputs, column-major, any may be NULL) */
+int  dvo_frame_get_level(dvo_ctx *ctx, int slot, int level, int *rows, int *cols, unsigned char *grey,
+                         float *depth_mm, unsigned char *edge, int *n_edges);
+int  dvo_frames_num_levels(const dvo_ctx *ctx);
 
 #ifdef __cplusplus
 }

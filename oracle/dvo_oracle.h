@@ -40,6 +40,8 @@
 #ifndef DVO_ORACLE_H_
 #define DVO_ORACLE_H_
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -148,6 +150,24 @@ int dvo_oracle_align_pyramid(const dvo_oracle_params *prm, int n_levels, const i
  * differences with reflect-101 border.  OpenCV 2.4 semantics restated, unpinned (see the .cpp). */
 void dvo_oracle_now_level_from_edges(const unsigned char *edge, int rows, int cols,
                                      float *dt, float *gx, float *gy);
+
+/* ---- rows f1/f2: per-frame preprocessing outside the iteration loop (dvo_oracle_frames.cpp; OpenCV 2.4
+ * semantics restated, PARITY UNPINNED).  Images here are ROW-major (OpenCV layout). ---- */
+/* cv::Sobel(src, CV_16S, 1,0 / 0,1, 3, BORDER_REPLICATE) as cv::Canny calls it */
+void dvo_oracle_sobel3(const unsigned char *src, int rows, int cols, short *dx, short *dy);
+/* cv::Canny(src, dst, threshold1, threshold2, 3, true)  (SolveDVO.cpp:1704, :1764 with 150, 100); dst 0/255 */
+void dvo_oracle_canny(const unsigned char *src, int rows, int cols, double threshold1, double threshold2,
+                      unsigned char *dst);
+/* same with the intermediate stages: squared magnitude, candidate map (0 / 1 weak / 2 strong); any may be NULL */
+void dvo_oracle_canny_stages(const unsigned char *src, int rows, int cols, double threshold1, double threshold2,
+                             int *mag_out, unsigned char *cand_out, unsigned char *dst);
+/* cv::cvtColor(CV_BGR2GRAY), 8-bit  (camTopic2PublisherPyD.cpp:347) */
+void dvo_oracle_bgr2gray(const unsigned char *bgr, size_t npx, unsigned char *grey);
+/* cv::resize(src, dst, Size(), scale, scale, INTER_NEAREST)  (camTopic2PublisherPyD.cpp:344-345) */
+void dvo_oracle_resize_nn_size(int rows, int cols, double scale, int *drows, int *dcols);
+void dvo_oracle_resize_nn(const void *src, int rows, int cols, int elem_bytes, double scale, void *dst);
+/* depthRcvd (camTopic2PublisherPyD.cpp:73-77): 1000.0*depth -> CV_16U -> 0 becomes 1 */
+void dvo_oracle_depth_m_to_mm16(const float *depth_m, size_t npx, unsigned short *out);
 
 /* Helpers exported for property tests. */
 float dvo_oracle_weight(float r);                                   /* :1047-1053 */

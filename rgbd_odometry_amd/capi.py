@@ -31,7 +31,18 @@ C_ABI_SYMBOLS = [
     "dvo_device_se3_log", "dvo_device_rotationize", "dvo_algorithmic_bytes", "dvo_point_iterations",
     "dvo_debug_stamps", "dvo_replicate_pairs", "dvo_set_now_level_from_edges", "dvo_get_now_level", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
     "dvo_align_pyramid_wide",
+    "dvo_get_ref_level", "dvo_frames_reserve", "dvo_frames_upload_pyramids", "dvo_frames_upload_cameras", "dvo_frames_as_now",
+    "dvo_frames_as_ref", "dvo_frame_get_level", "dvo_frames_num_levels",
 ]
+
+DVO_PIX_U8, DVO_PIX_U16, DVO_PIX_F32 = 0, 1, 2
+DVO_LAYOUT_COL_MAJOR, DVO_LAYOUT_ROW_MAJOR = 0, 1
+DVO_UPLOAD_ASYNC = 1
+
+
+class DvoImage(C.Structure):
+    """Mirror of ``struct dvo_image``."""
+    _fields_ = [("data", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("dtype", C.c_int), ("layout", C.c_int)]
 
 
 class DvoParams(C.Structure):
@@ -43,7 +54,8 @@ class DvoParams(C.Structure):
         ("trust_radius", C.c_float), ("psi_norm_stop", C.c_float),
         ("enable_rotationize", C.c_int), ("enable_l2_reg", C.c_int), ("interpolate_dt", C.c_int),
         ("block_threads", C.c_int), ("points_in_flight", C.c_int), ("reserved0", C.c_int),
-        ("lds_point_bytes", C.c_int), ("debug_alias_mod", C.c_int), ("reserved", C.c_int * 3),
+        ("lds_point_bytes", C.c_int), ("debug_alias_mod", C.c_int),
+        ("canny_threshold1", C.c_int), ("canny_threshold2", C.c_int), ("reserved", C.c_int * 1),
     ]
 
 
@@ -128,6 +140,14 @@ def load_library() -> C.CDLL:
         "dvo_iter_update": [vp, i, i, i, i, vp],
         "dvo_iter_end": [vp, i, i, vp, vp, vp, ip, fp],
         "dvo_align_pyramid_wide": [vp, i, i, ip, vp, vp],
+        "dvo_get_ref_level": [vp, i, i, vp, i, ip],
+        "dvo_frames_reserve": [vp, i],
+        "dvo_frames_upload_pyramids": [vp, i, i, i, C.POINTER(DvoImage), C.POINTER(DvoImage), i],
+        "dvo_frames_upload_cameras": [vp, i, i, C.POINTER(vp), C.POINTER(vp), i, i, i, i, i],
+        "dvo_frames_as_now": [vp, i, i, i],
+        "dvo_frames_as_ref": [vp, i, i, i, ip],
+        "dvo_frame_get_level": [vp, i, i, ip, ip, vp, vp, vp, ip],
+        "dvo_frames_num_levels": [vp],
         "dvo_algorithmic_bytes": [vp, i, i, ip, i, C.POINTER(C.c_uint64)],
         "dvo_point_iterations": [vp, i, i, ip, C.POINTER(C.c_uint64)],
     }
@@ -243,6 +263,13 @@ class DvoContext:
         self._chk(self.lib.dvo_get_now_level(self._h, pair, level, _ptr(dt), _ptr(gx), _ptr(gy)))
         return dt, gx, gy
 
+    def get_ref_level(self, level: int, pair: int = 0):
+        n = C.c_int()
+        self._chk(self.lib.dvo_get_ref_level(self._h, pair, level, None, 0, C.byref(n)))
+        xyz = np.zeros(3 * n.value, np.float32)
+        self._chk(self.lib.dvo_get_ref_level(self._h, pair, level, _ptr(xyz), n.value, C.byref(n)))
+        return xyz.reshape(-1, 3)
+
     def replicate_pairs(self, n_src: int, dst_first: int = 0, dst_count: Optional[int] = None):
         """slot p <- device copy of pair (p - dst_first) % n_src, for every level that is set"""
         dst_count = self.n_pairs - dst_first if dst_count is None else dst_count
@@ -326,6 +353,84 @@ class DvoContext:
         n = C.c_int(0)
         self._chk(self.lib.dvo_get_final_outputs(self._h, pair, _ptr(feps), _ptr(frep), capacity, C.byref(n)))
         return feps[:n.value].copy(), frep[:3 * n.value].reshape(-1, 3).copy()
+
+    # -- frames in: rows f1 + f2 (Canny, distance transform, point extraction, pyramid on the GPU) -----
+    def frames_reserve(self, n_slots: int):
+        self._chk(self.lib.dvo_frames_reserve(self._h, n_slots))
+
+    @staticmethod
+    def _image(a, kind: str, layout: int):
+        """kind 'grey': uint8 or float32; 'depth': uint16 (mm) or float32 (mm).  `a` is a 2-D (rows, cols) array
+        for ROW_MAJOR, or the same 2-D array given in Fortran order / a transposed buffer for COL_MAJOR."""
+        a = np.asarray(a)
+        rows, cols = a.shape
+        if a.dtype == np.uint8 and kind == "grey":
+            dt = DVO_PIX_U8
+        elif a.dtype == np.uint16 and kind == "depth":
+            dt = DVO_PIX_U16
+        else:
+            a = a.astype(np.float32, copy=False)
+            dt = DVO_PIX_F32
+        buf = np.ascontiguousarray(a) if layout == DVO_LAYOUT_ROW_MAJOR else np.ascontiguousarray(a.T)
+        return DvoImage(buf.ctypes.data, rows, cols, dt, layout), buf
+
+    def frames_upload_pyramids(self, frames, first_slot: int = 0, layout: int = DVO_LAYOUT_ROW_MAJOR, flags: int = 0):
+        """frames: list of frames; a frame = list over levels of (grey, depth) or (grey, None); 2-D (rows, cols) arrays."""
+        count, nl = len(frames), len(frames[0])
+        keep, G, D = [], (DvoImage * (count * nl))(), (DvoImage * (count * nl))()
+        have_depth = frames[0][0][1] is not None
+        for f, fr in enumerate(frames):
+            for l, (g, d) in enumerate(fr):
+                G[f * nl + l], b = self._image(g, "grey", layout); keep.append(b)
+                if have_depth:
+                    D[f * nl + l], b = self._image(d, "depth", layout); keep.append(b)
+        self._chk(self.lib.dvo_frames_upload_pyramids(self._h, first_slot, count, nl, G, D if have_depth else None, flags))
+        self._frame_keep = keep if flags & DVO_UPLOAD_ASYNC else None
+        for l, (g, _) in enumerate(frames[0]):
+            self._dims[l] = tuple(np.asarray(g).shape)
+
+    def frames_upload_cameras(self, bgr_list, depth_list=None, n_levels: int = 4, first_shift: int = 1,
+                              first_slot: int = 0, flags: int = 0):
+        """bgr_list: list of (rows, cols, 3) uint8 BGR images; depth_list: list of (rows, cols) float32 metres or None"""
+        count = len(bgr_list)
+        bl = [np.ascontiguousarray(b, dtype=np.uint8) for b in bgr_list]
+        rows, cols = bl[0].shape[:2]
+        B = (C.c_void_p * count)(*[b.ctypes.data for b in bl])
+        Dp, dl = None, None
+        if depth_list is not None:
+            dl = [np.ascontiguousarray(d, dtype=np.float32) for d in depth_list]
+            Dp = (C.c_void_p * count)(*[d.ctypes.data for d in dl])
+        self._chk(self.lib.dvo_frames_upload_cameras(self._h, first_slot, count, B, Dp, rows, cols, n_levels, first_shift, flags))
+        self._frame_keep = (bl, dl) if flags & DVO_UPLOAD_ASYNC else None
+
+    def frames_as_now(self, first_slot: int = 0, first_pair: int = 0, count: int = 1):
+        self._chk(self.lib.dvo_frames_as_now(self._h, first_slot, first_pair, count))
+        for l in range(self.lib.dvo_frames_num_levels(self._h)):
+            r, c_ = C.c_int(), C.c_int()
+            self._chk(self.lib.dvo_frame_get_level(self._h, first_slot, l, C.byref(r), C.byref(c_), None, None, None, None))
+            self._dims[l] = (r.value, c_.value)
+
+    def frames_as_ref(self, first_slot: int = 0, first_pair: int = 0, count: int = 1):
+        nl = self.lib.dvo_frames_num_levels(self._h)
+        N = (C.c_int * (count * max(nl, 1)))()
+        self._chk(self.lib.dvo_frames_as_ref(self._h, first_slot, first_pair, count, N))
+        N = np.array(N[:], dtype=np.int64).reshape(count, max(nl, 1))
+        for i in range(count):
+            for l in range(nl):
+                self._N[(first_pair + i, l)] = int(N[i, l])
+        return N
+
+    def frame_level(self, slot: int, level: int, want_depth: bool = True):
+        """resident (grey u8, depth mm f32 or None, edge u8 0/255, n_edges) of a stored level, as 2-D (rows, cols) arrays"""
+        r, c_ = C.c_int(), C.c_int()
+        self._chk(self.lib.dvo_frame_get_level(self._h, slot, level, C.byref(r), C.byref(c_), None, None, None, None))
+        rows, cols = r.value, c_.value
+        grey, edge = np.zeros(rows * cols, np.uint8), np.zeros(rows * cols, np.uint8)
+        depth = np.zeros(rows * cols, np.float32) if want_depth else None
+        ne = C.c_int()
+        self._chk(self.lib.dvo_frame_get_level(self._h, slot, level, None, None, _ptr(grey), _ptr(depth), _ptr(edge), C.byref(ne)))
+        cm = lambda a: None if a is None else a.reshape(cols, rows).T.copy()      # column-major buffer -> (rows, cols)
+        return cm(grey), cm(depth), cm(edge), ne.value
 
     # -- host-driven iteration (large frames / multi-GPU tiled mode) ---------
     def n_points(self, level: int, pair: int = 0) -> int:

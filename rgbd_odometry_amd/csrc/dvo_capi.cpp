@@ -15,6 +15,7 @@
 #include "dvo_launch.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -34,6 +35,20 @@ struct Level {
     int *dN = nullptr;
     std::vector<int> hN;            /* 0 = not set */
     std::vector<char> have_now;
+};
+
+/* frame store (rows f1/f2): per level one slab per plane for all slots, slot s at base + s*npx */
+struct FrameLevel {
+    int rows = 0, cols = 0;
+    size_t npx = 0;
+    unsigned char *grey = nullptr, *edge = nullptr;
+    float *depth = nullptr;
+    int *n_edges = nullptr;         /* n_slots ints */
+};
+struct FrameStore {
+    int n_slots = 0, n_levels = 0;
+    FrameLevel lv[DVO_LEVELS];
+    std::vector<char> valid, has_depth;
 };
 }  // namespace
 
@@ -64,6 +79,9 @@ struct dvo_ctx {
     std::vector<int> iter_max;      /* per pair: max_iters of the running dvo_iter_begin (0 = none) */
     int *d_colcounts = nullptr;
     size_t colcounts_cap = 0;
+    FrameStore fs;
+    int *work = nullptr;            /* preprocessing scratch (Canny / distance transform / point counts) */
+    size_t work_bytes = 0;
     Schedule sched{};
     bool have_sched = false;
     std::string err;
@@ -87,6 +105,14 @@ int ensure_staging(dvo_ctx *c, size_t bytes) {
     if (c->staging) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->staging)); c->staging = nullptr; }
     HIPCHK(c, hipMalloc((void **)&c->staging, bytes));
     c->staging_bytes = bytes;
+    return DVO_OK;
+}
+
+int ensure_work(dvo_ctx *c, size_t bytes) {
+    if (bytes <= c->work_bytes) return DVO_OK;
+    if (c->work) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->work)); c->work = nullptr; c->work_bytes = 0; }
+    HIPCHK(c, hipMalloc((void **)&c->work, bytes));
+    c->work_bytes = bytes;
     return DVO_OK;
 }
 
@@ -347,6 +373,12 @@ int dvo_destroy(dvo_ctx *c) {
         if (c->lv[l].pts) (void)hipFree(c->lv[l].pts);
         if (c->lv[l].dN) (void)hipFree(c->lv[l].dN);
     }
+    for (int l = 0; l < DVO_LEVELS; l++) {
+        FrameLevel &F = c->fs.lv[l];
+        void *fp[] = {F.grey, F.edge, F.depth, F.n_edges};
+        for (void *p : fp) if (p) (void)hipFree(p);
+    }
+    if (c->work) (void)hipFree(c->work);
     void *ptrs[] = {c->staging, c->d_poses, c->d_energy, c->d_best, c->d_ratio, c->d_final_eps,
                     c->d_final_reproj, c->d_final_N, c->d_scratch, c->d_colcounts, c->d_dbg,
                     c->d_states, c->d_iter_energy};
@@ -432,11 +464,10 @@ int dvo_set_ref_level_from_images(dvo_ctx *c, int pair, int level, const int32_t
     }
     HIPCHK(c, hipMemcpyAsync(d_edge, edge, npx * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_depth, depth_mm, npx * 4, hipMemcpyHostToDevice, c->stream));
-    /* pass 1: count, so the slab can be grown before the write pass */
+    /* pass 1: count on the device, read N, grow the slab; pass 2: write */
+    const ImgBatch gb{rows, cols, 1};
     int *d_N = c->d_colcounts + cols + 1;
-    /* run count+scan+write with capacity 0 first?  Cheaper: count on the device, read N, grow, write. */
-    HIPCHK(c, launch_enlist_ref_points(d_edge, d_depth, rows, cols, level, c->K, c->d_colcounts,
-                                       nullptr, nullptr, 0, d_N, c->stream));
+    HIPCHK(c, launch_enlist_count(d_edge, 0, 0, d_depth, 0, gb, c->d_colcounts, c->stream));
     int N = 0;
     HIPCHK(c, hipMemcpyAsync(&N, d_N, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -445,8 +476,8 @@ int dvo_set_ref_level_from_images(dvo_ctx *c, int pair, int level, const int32_t
     if ((rc = ensure_points(c, level, N))) return rc;
     Level &L = c->lv[level];
     float *dst = L.pts + (size_t)pair * L.pt_cap * 3;
-    HIPCHK(c, launch_enlist_ref_points(d_edge, d_depth, rows, cols, level, c->K, c->d_colcounts,
-                                       dst, d_uv, N, d_N, c->stream));
+    HIPCHK(c, launch_enlist_write(d_edge, 0, 0, d_depth, 0, gb, level, c->K, c->d_colcounts, dst, 0, d_uv, N,
+                                  nullptr, c->stream));
     L.hN[pair] = N;
     HIPCHK(c, hipMemcpyAsync(L.dN + pair, &L.hN[pair], sizeof(int), hipMemcpyHostToDevice, c->stream));
     const int ncopy = std::min(N, capacity);
@@ -507,7 +538,7 @@ int dvo_set_now_level_from_edges(dvo_ctx *c, int pair, int level, const unsigned
     if (!any) return fail(c, DVO_ERR_INVALID, "edge mask has no edge pixel: the distance transform is undefined");
     /* staging: edge bytes (rounded up to ints) | work ints */
     const size_t edge_ints = (npx + 3) / 4;
-    if ((rc = ensure_staging(c, sizeof(int) * (edge_ints + 2 * npx + 2)))) return rc;
+    if ((rc = ensure_staging(c, sizeof(int) * (edge_ints + edt_work_ints(rows, cols, 1) + 1)))) return rc;
     unsigned char *d_edge = (unsigned char *)c->staging;
     int *work = (int *)c->staging + edge_ints;
     HIPCHK(c, hipMemcpyAsync(d_edge, edge, npx, hipMemcpyHostToDevice, c->stream));
@@ -533,6 +564,22 @@ int dvo_get_now_level(dvo_ctx *c, int pair, int level, float *dt, float *gx, flo
     if (gx) HIPCHK(c, hipMemcpyAsync(gx, d + npx, sizeof(float) * npx, hipMemcpyDeviceToHost, c->stream));
     if (gy) HIPCHK(c, hipMemcpyAsync(gy, d + 2 * npx, sizeof(float) * npx, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DVO_OK;
+}
+
+int dvo_get_ref_level(dvo_ctx *c, int pair, int level, float *xyz_out, int capacity, int *N_out) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair) || !level_ok(level)) return fail(c, DVO_ERR_INVALID, "pair/level out of range");
+    Level &L = c->lv[level];
+    if (L.hN.empty() || L.hN[pair] <= 0) return fail(c, DVO_ERR_STATE, "reference level not set");
+    const int N = L.hN[pair];
+    if (N_out) *N_out = N;
+    const int ncopy = std::min(N, capacity);
+    if (xyz_out && ncopy > 0) {
+        HIPCHK(c, hipMemcpyAsync(xyz_out, L.pts + (size_t)pair * L.pt_cap * 3, sizeof(float) * 3 * (size_t)ncopy,
+                                 hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return DVO_OK;
 }
 
@@ -902,6 +949,301 @@ int dvo_point_iterations(dvo_ctx *c, int pair, int n_levels, const int *iters, u
         n += (uint64_t)sc.iters[l] * (uint64_t)c->lv[l].hN[pair];
     }
     *count = n;
+    return DVO_OK;
+}
+
+/* ---- frame store: rows f1 + f2 ------------------------------------------------------------------------ */
+namespace {
+
+constexpr size_t kWorkBudget = (size_t)1 << 30;     /* scratch per chunk of a batched preprocessing call */
+
+int round_half_even_pos(double v) {                 /* cvRound for the non-negative sizes used here */
+    const double f = std::floor(v);
+    const double d = v - f;
+    int i = (int)f;
+    if (d > 0.5 || (d == 0.5 && (i & 1))) i++;
+    return i;
+}
+
+void canny_thresholds(const dvo_ctx *c, int *low, int *high) {
+    double t1 = c->prm.canny_threshold1, t2 = c->prm.canny_threshold2;
+    if (t1 == 0 && t2 == 0) { t1 = 150; t2 = 100; }               /* SolveDVO.cpp:1704, :1764 */
+    double lo = std::min(t1, t2), hi = std::max(t1, t2);          /* the detector swaps them */
+    lo = std::min(32767.0, lo); hi = std::min(32767.0, hi);
+    if (lo > 0) lo *= lo;                                         /* L2gradient: squared magnitudes */
+    if (hi > 0) hi *= hi;
+    *low = (int)std::floor(lo); *high = (int)std::floor(hi);
+}
+
+int frames_default_slots(const dvo_ctx *c) { return std::min(2 * c->n_pairs + 2, 64); }
+
+void frames_free(dvo_ctx *c) {
+    for (int l = 0; l < DVO_LEVELS; l++) {
+        FrameLevel &F = c->fs.lv[l];
+        void *fp[] = {F.grey, F.edge, F.depth, F.n_edges};
+        for (void *p : fp) if (p) (void)hipFree(p);
+        F = FrameLevel();
+    }
+    c->fs.n_levels = 0;
+    std::fill(c->fs.valid.begin(), c->fs.valid.end(), 0);
+}
+
+/* make the store hold `n_levels` levels of the given geometry (drops the stored frames if it changes) */
+int frames_geometry(dvo_ctx *c, int n_levels, const int *rows, const int *cols) {
+    FrameStore &S = c->fs;
+    if (S.n_slots == 0) {
+        S.n_slots = frames_default_slots(c);
+        S.valid.assign(S.n_slots, 0); S.has_depth.assign(S.n_slots, 0);
+    }
+    bool same = S.n_levels == n_levels;
+    for (int l = 0; same && l < n_levels; l++) same = S.lv[l].rows == rows[l] && S.lv[l].cols == cols[l];
+    if (same) return DVO_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    frames_free(c);
+    for (int l = 0; l < n_levels; l++) {
+        FrameLevel &F = S.lv[l];
+        F.rows = rows[l]; F.cols = cols[l]; F.npx = (size_t)rows[l] * cols[l];
+        HIPCHK(c, hipMalloc((void **)&F.grey, F.npx * S.n_slots));
+        HIPCHK(c, hipMalloc((void **)&F.edge, F.npx * S.n_slots));
+        HIPCHK(c, hipMalloc((void **)&F.depth, sizeof(float) * F.npx * S.n_slots));
+        HIPCHK(c, hipMalloc((void **)&F.n_edges, sizeof(int) * S.n_slots));
+        HIPCHK(c, hipMemsetAsync(F.n_edges, 0, sizeof(int) * S.n_slots, c->stream));
+    }
+    S.n_levels = n_levels;
+    return DVO_OK;
+}
+
+bool slots_ok(const dvo_ctx *c, int first, int count) {
+    return first >= 0 && count >= 1 && first + count <= c->fs.n_slots;
+}
+
+int chunk_for(size_t bytes_per_image, int count) {
+    size_t k = kWorkBudget / std::max<size_t>(bytes_per_image, 1);
+    if (k < 1) k = 1;
+    return (int)std::min<size_t>(k, (size_t)count);
+}
+
+int run_canny(dvo_ctx *c, int level, int first_slot, int count) {
+    FrameLevel &F = c->fs.lv[level];
+    int low, high;
+    canny_thresholds(c, &low, &high);
+    const int chunk = chunk_for(sizeof(int) * canny_work_ints(F.rows, F.cols, 1), count);
+    int rc = ensure_work(c, sizeof(int) * canny_work_ints(F.rows, F.cols, chunk));
+    if (rc) return rc;
+    for (int b = 0; b < count; b += chunk) {
+        const int nc = std::min(chunk, count - b);
+        const size_t off = (size_t)(first_slot + b) * F.npx;
+        HIPCHK(c, launch_canny(F.grey + off, F.npx, ImgBatch{F.rows, F.cols, nc}, low, high, c->work,
+                               F.edge + off, F.npx, F.n_edges + first_slot + b, c->stream));
+    }
+    return DVO_OK;
+}
+
+size_t pix_bytes(int dtype) { return dtype == DVO_PIX_U8 ? 1 : (dtype == DVO_PIX_U16 ? 2 : 4); }
+
+}  // namespace
+
+int dvo_frames_reserve(dvo_ctx *c, int n_slots) {
+    if (!c) return DVO_ERR_INVALID;
+    if (n_slots < 1) return fail(c, DVO_ERR_INVALID, "n_slots must be >= 1");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    frames_free(c);
+    c->fs.n_slots = n_slots;
+    c->fs.valid.assign(n_slots, 0);
+    c->fs.has_depth.assign(n_slots, 0);
+    return DVO_OK;
+}
+
+int dvo_frames_num_levels(const dvo_ctx *c) { return c ? c->fs.n_levels : 0; }
+
+int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_levels,
+                               const dvo_image *grey, const dvo_image *depth, int flags) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!grey || count < 1 || n_levels < 1 || n_levels > DVO_LEVELS) return fail(c, DVO_ERR_INVALID, "bad frame arguments");
+    int rows[DVO_LEVELS], cols[DVO_LEVELS];
+    for (int l = 0; l < n_levels; l++) { rows[l] = grey[l].rows; cols[l] = grey[l].cols; }
+    for (int f = 0; f < count; f++)
+        for (int l = 0; l < n_levels; l++) {
+            const dvo_image &g = grey[(size_t)f * n_levels + l];
+            if (!g.data || g.rows < 1 || g.cols < 1 || g.rows != rows[l] || g.cols != cols[l] ||
+                (g.dtype != DVO_PIX_U8 && g.dtype != DVO_PIX_F32) || g.dtype != grey[l].dtype || g.layout != grey[l].layout)
+                return fail(c, DVO_ERR_INVALID, "grey images of one level must share size, dtype (U8/F32) and layout");
+            if (depth) {
+                const dvo_image &d = depth[(size_t)f * n_levels + l];
+                if (!d.data || d.rows != rows[l] || d.cols != cols[l] || (d.dtype != DVO_PIX_U16 && d.dtype != DVO_PIX_F32) ||
+                    d.dtype != depth[l].dtype || d.layout != depth[l].layout)
+                    return fail(c, DVO_ERR_INVALID, "depth images must match the grey size and share dtype (U16/F32) and layout");
+            }
+        }
+    int rc = frames_geometry(c, n_levels, rows, cols);
+    if (rc) return rc;
+    if (!slots_ok(c, first_slot, count)) return fail(c, DVO_ERR_INVALID, "frame slot range out of bounds (dvo_frames_reserve)");
+    for (int l = 0; l < n_levels; l++) {
+        FrameLevel &F = c->fs.lv[l];
+        const size_t gb = pix_bytes(grey[l].dtype), db = depth ? pix_bytes(depth[l].dtype) : 0;
+        const size_t g_img = (F.npx * gb + 15) / 16 * 16, d_img = (F.npx * db + 15) / 16 * 16;   /* 16-byte aligned images */
+        const int chunk = chunk_for(g_img + d_img, count);
+        if ((rc = ensure_staging(c, (g_img + d_img) * chunk))) return rc;
+        unsigned char *sg = (unsigned char *)c->staging, *sd = sg + g_img * chunk;
+        for (int b = 0; b < count; b += chunk) {
+            const int nc = std::min(chunk, count - b);
+            for (int i = 0; i < nc; i++) {
+                HIPCHK(c, hipMemcpyAsync(sg + g_img * i, grey[(size_t)(b + i) * n_levels + l].data, F.npx * gb,
+                                         hipMemcpyHostToDevice, c->stream));
+                if (depth)
+                    HIPCHK(c, hipMemcpyAsync(sd + d_img * i, depth[(size_t)(b + i) * n_levels + l].data, F.npx * db,
+                                             hipMemcpyHostToDevice, c->stream));
+            }
+            const size_t off = (size_t)(first_slot + b) * F.npx;
+            const ImgBatch ib{F.rows, F.cols, nc};
+            HIPCHK(c, launch_import_grey(sg, grey[l].dtype, grey[l].layout == DVO_LAYOUT_ROW_MAJOR, g_img / gb,
+                                         F.grey + off, F.npx, ib, c->stream));
+            if (depth)
+                HIPCHK(c, launch_import_depth(sd, depth[l].dtype, depth[l].layout == DVO_LAYOUT_ROW_MAJOR, d_img / db,
+                                              F.depth + off, F.npx, ib, c->stream));
+        }
+        if ((rc = run_canny(c, l, first_slot, count))) return rc;
+    }
+    for (int f = 0; f < count; f++) { c->fs.valid[first_slot + f] = 1; c->fs.has_depth[first_slot + f] = depth ? 1 : 0; }
+    if (!(flags & DVO_UPLOAD_ASYNC)) HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DVO_OK;
+}
+
+int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsigned char *const *bgr8,
+                              const float *const *depth_m, int rows, int cols, int n_levels, int first_shift, int flags) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!bgr8 || count < 1 || rows < 1 || cols < 1 || n_levels < 1 || n_levels > DVO_LEVELS || first_shift < 0 ||
+        first_shift + n_levels > 16)
+        return fail(c, DVO_ERR_INVALID, "bad camera frame arguments");
+    for (int f = 0; f < count; f++)
+        if (!bgr8[f] || (depth_m && !depth_m[f])) return fail(c, DVO_ERR_INVALID, "NULL camera image");
+    int lr[DVO_LEVELS], lc[DVO_LEVELS];
+    for (int l = 0; l < n_levels; l++) {          /* cv::resize(Size(), s, s): dsize = cvRound(size * s) */
+        const double sc = std::ldexp(1.0, -(first_shift + l));
+        lr[l] = round_half_even_pos(rows * sc); lc[l] = round_half_even_pos(cols * sc);
+        if (lr[l] < 1 || lc[l] < 1) return fail(c, DVO_ERR_INVALID, "pyramid level would be empty");
+    }
+    int rc = frames_geometry(c, n_levels, lr, lc);
+    if (rc) return rc;
+    if (!slots_ok(c, first_slot, count)) return fail(c, DVO_ERR_INVALID, "frame slot range out of bounds (dvo_frames_reserve)");
+    const size_t npx = (size_t)rows * cols;
+    const size_t b_img = (npx * 3 + 15) / 16 * 16, d_img = depth_m ? npx * 4 : 0;
+    const int chunk = chunk_for(b_img + d_img, count);
+    if ((rc = ensure_staging(c, (b_img + d_img) * chunk))) return rc;
+    unsigned char *sb = (unsigned char *)c->staging;
+    float *sd = (float *)(sb + b_img * chunk);
+    for (int b = 0; b < count; b += chunk) {
+        const int nc = std::min(chunk, count - b);
+        for (int i = 0; i < nc; i++) {
+            HIPCHK(c, hipMemcpyAsync(sb + b_img * i, bgr8[b + i], npx * 3, hipMemcpyHostToDevice, c->stream));
+            if (depth_m) HIPCHK(c, hipMemcpyAsync(sd + npx * i, depth_m[b + i], npx * 4, hipMemcpyHostToDevice, c->stream));
+        }
+        for (int l = 0; l < n_levels; l++) {
+            FrameLevel &F = c->fs.lv[l];
+            const size_t off = (size_t)(first_slot + b) * F.npx;
+            HIPCHK(c, launch_camera_level(sb, b_img, depth_m ? sd : nullptr, npx, rows, cols, first_shift + l,
+                                          F.grey + off, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, nc}, c->stream));
+        }
+    }
+    for (int l = 0; l < n_levels; l++) if ((rc = run_canny(c, l, first_slot, count))) return rc;
+    for (int f = 0; f < count; f++) { c->fs.valid[first_slot + f] = 1; c->fs.has_depth[first_slot + f] = depth_m ? 1 : 0; }
+    if (!(flags & DVO_UPLOAD_ASYNC)) HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DVO_OK;
+}
+
+static int frames_check_use(dvo_ctx *c, int first_slot, int first_pair, int count, bool need_depth) {
+    if (c->fs.n_levels < 1) return fail(c, DVO_ERR_STATE, "frame store is empty (dvo_frames_upload_*)");
+    if (!slots_ok(c, first_slot, count)) return fail(c, DVO_ERR_INVALID, "frame slot range out of bounds");
+    if (!pair_ok(c, first_pair) || first_pair + count > c->n_pairs) return fail(c, DVO_ERR_INVALID, "pair range out of bounds");
+    for (int f = first_slot; f < first_slot + count; f++) {
+        if (!c->fs.valid[f]) return fail(c, DVO_ERR_STATE, "frame slot " + std::to_string(f) + " holds no frame");
+        if (need_depth && !c->fs.has_depth[f]) return fail(c, DVO_ERR_STATE, "frame slot " + std::to_string(f) + " has no depth");
+    }
+    return DVO_OK;
+}
+
+int dvo_frames_as_now(dvo_ctx *c, int first_slot, int first_pair, int count) {
+    if (!c) return DVO_ERR_INVALID;
+    int rc = frames_check_use(c, first_slot, first_pair, count, false);
+    if (rc) return rc;
+    for (int l = 0; l < c->fs.n_levels; l++) {
+        FrameLevel &F = c->fs.lv[l];
+        if ((rc = ensure_texels(c, l, F.rows, F.cols))) return rc;
+        Level &L = c->lv[l];
+        const int chunk = chunk_for(sizeof(int) * edt_work_ints(F.rows, F.cols, 1), count);
+        if ((rc = ensure_work(c, sizeof(int) * edt_work_ints(F.rows, F.cols, chunk)))) return rc;
+        for (int b = 0; b < count; b += chunk) {
+            const int nc = std::min(chunk, count - b);
+            HIPCHK(c, launch_edges_to_texels(F.edge + (size_t)(first_slot + b) * F.npx, F.npx, ImgBatch{F.rows, F.cols, nc},
+                                             c->work, L.tex + (size_t)(first_pair + b) * L.tex_stride, L.tex_stride, c->stream));
+        }
+        for (int i = 0; i < count; i++) L.have_now[first_pair + i] = 1;
+    }
+    return DVO_OK;
+}
+
+int dvo_frames_as_ref(dvo_ctx *c, int first_slot, int first_pair, int count, int *N_out) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!c->have_K) return fail(c, DVO_ERR_STATE, "intrinsics not set (dvo_set_intrinsics)");
+    int rc = frames_check_use(c, first_slot, first_pair, count, true);
+    if (rc) return rc;
+    const int nl = c->fs.n_levels;
+    size_t cc_off[DVO_LEVELS + 1];                      /* per level: count x (cols+2) column counters */
+    cc_off[0] = 0;
+    for (int l = 0; l < nl; l++) cc_off[l + 1] = cc_off[l] + (size_t)count * (c->fs.lv[l].cols + 2);
+    if ((rc = ensure_work(c, sizeof(int) * cc_off[nl]))) return rc;
+    std::vector<int> hN((size_t)count * nl);
+    for (int l = 0; l < nl; l++) {
+        FrameLevel &F = c->fs.lv[l];
+        const size_t off = (size_t)first_slot * F.npx;
+        int *cc = c->work + cc_off[l];
+        HIPCHK(c, launch_enlist_count(F.edge + off, 1, F.npx, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, count}, cc, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(hN.data() + (size_t)l * count, sizeof(int), cc + F.cols, sizeof(int) * (F.cols + 2),
+                                   sizeof(int), count, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int bad_level = -1, bad_frame = -1;
+    for (int l = 0; l < nl; l++) {
+        FrameLevel &F = c->fs.lv[l];
+        int maxN = 0;
+        for (int i = 0; i < count; i++) {
+            const int N = hN[(size_t)l * count + i];
+            maxN = std::max(maxN, N);
+            if (N < 1 && bad_level < 0) { bad_level = l; bad_frame = i; }
+            if (N_out) N_out[(size_t)i * nl + l] = N;
+        }
+        if ((rc = ensure_points(c, l, std::max(maxN, 1)))) return rc;
+        Level &L = c->lv[l];
+        const size_t off = (size_t)first_slot * F.npx;
+        HIPCHK(c, launch_enlist_write(F.edge + off, 1, F.npx, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, count}, l, c->K,
+                                      c->work + cc_off[l], L.pts + (size_t)first_pair * L.pt_cap * 3, (size_t)L.pt_cap * 3,
+                                      nullptr, L.pt_cap, L.dN + first_pair, c->stream));
+        for (int i = 0; i < count; i++) L.hN[first_pair + i] = hN[(size_t)l * count + i];
+    }
+    if (bad_level >= 0)
+        return fail(c, DVO_ERR_INVALID, "no reference point selected in frame " + std::to_string(first_slot + bad_frame) +
+                                            " level " + std::to_string(bad_level) +
+                                            " (reference asserts nSelectedPts > 0, SolveDVO.cpp:282)");
+    return DVO_OK;
+}
+
+int dvo_frame_get_level(dvo_ctx *c, int slot, int level, int *rows, int *cols, unsigned char *grey,
+                        float *depth_mm, unsigned char *edge, int *n_edges) {
+    if (!c) return DVO_ERR_INVALID;
+    if (level < 0 || level >= c->fs.n_levels) return fail(c, DVO_ERR_INVALID, "frame level out of range");
+    if (!slots_ok(c, slot, 1) || !c->fs.valid[slot]) return fail(c, DVO_ERR_STATE, "frame slot holds no frame");
+    FrameLevel &F = c->fs.lv[level];
+    if (rows) *rows = F.rows;
+    if (cols) *cols = F.cols;
+    const size_t off = (size_t)slot * F.npx;
+    if (grey) HIPCHK(c, hipMemcpyAsync(grey, F.grey + off, F.npx, hipMemcpyDeviceToHost, c->stream));
+    if (edge) HIPCHK(c, hipMemcpyAsync(edge, F.edge + off, F.npx, hipMemcpyDeviceToHost, c->stream));
+    if (depth_mm) {
+        if (!c->fs.has_depth[slot]) return fail(c, DVO_ERR_STATE, "frame slot has no depth");
+        HIPCHK(c, hipMemcpyAsync(depth_mm, F.depth + off, sizeof(float) * F.npx, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (n_edges) HIPCHK(c, hipMemcpyAsync(n_edges, F.n_edges + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return DVO_OK;
 }
 

@@ -1,0 +1,540 @@
+/*
+ * dvo_frames.hip -- per-frame preprocessing on gfx950, the rows either side of the hot path
+ * (SURVEY.md section 8f, rows f1 and f2).  Integer / byte work bound by HBM and launch latency;
+ * every kernel is batched: blockIdx.y = image of a batch of `count` same-geometry images, image b
+ * of a buffer lives at base + b*stride.  Internal layout is the reference's Eigen layout:
+ * COLUMN-major, pixel (yy,xx) at yy + xx*rows.
+ *
+ *   import_*              wire / Eigen images -> resident grey (u8) and depth (f32 mm)
+ *                         (imageArrivedCallBack, src/SolveDVO.cpp:508-519)
+ *   camera_level_kernel   full-resolution BGR8 + depth(m) -> one pyramid level
+ *                         (camTopic2PublisherPyD.cpp:73-77, :344-347: *1000 -> u16 -> 0->1,
+ *                         INTER_NEAREST decimation, BGR2GRAY)
+ *   canny_*               cv::Canny(img, 150, 100, 3, true) (src/SolveDVO.cpp:1704, :1764): 3x3 Sobel,
+ *                         squared-L2 magnitude, sector non-maximum suppression, hysteresis as a
+ *                         union-find over the candidate pixels (order-independent, so identical to
+ *                         the sequential stack walk of the CPU implementation)
+ *   edt_* / dt_*          distanceTransform(L2, PRECISE) -> normalize(0,255,MINMAX) -> [-.5 0 .5]
+ *                         gradients -> texels (src/SolveDVO.cpp:1768-1795, :1063-1098)
+ *   enlist_*              selectedPts + enlistRefEdgePts (src/SolveDVO.cpp:1230-1264, :224-264)
+ */
+#include "dvo_launch.h"
+
+namespace dvo {
+
+namespace {
+
+DVO_DEV float pow2_neg_f(int level) { return __int_as_float((127 - level) << 23); }
+inline unsigned grid_x(size_t n, unsigned cap = 2048) {
+    size_t b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+/* ------------------------------------------------------------------------- */
+/* import: host-format images -> resident column-major grey / depth              */
+/* ------------------------------------------------------------------------- */
+template <typename T>
+__global__ void __launch_bounds__(256)
+import_grey_kernel(const T *__restrict__ src, size_t src_stride, int row_major,
+                   unsigned char *__restrict__ grey, size_t stride, int rows, int cols) {
+    const size_t n = (size_t)rows * cols;
+    src += (size_t)blockIdx.y * src_stride;
+    grey += (size_t)blockIdx.y * stride;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(p / rows), yy = (int)(p - (size_t)xx * rows);
+        const T v = src[row_major ? (size_t)yy * cols + xx : p];
+        unsigned char o;
+        if constexpr (sizeof(T) == 1) o = (unsigned char)v;
+        else {                                              /* Mat::convertTo(CV_8U): saturate_cast<uchar>(cvRound(v)) */
+            const float f = (float)v;
+            const float r = rintf(f);                       /* round half to even */
+            o = (!(f > -2147483648.5f && f < 2147483648.0f)) ? 0 : (unsigned char)(r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r));
+        }
+        grey[p] = o;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+import_depth_kernel(const T *__restrict__ src, size_t src_stride, int row_major,
+                    float *__restrict__ depth, size_t stride, int rows, int cols) {
+    const size_t n = (size_t)rows * cols;
+    src += (size_t)blockIdx.y * src_stride;
+    depth += (size_t)blockIdx.y * stride;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(p / rows), yy = (int)(p - (size_t)xx * rows);
+        const T v = src[row_major ? (size_t)yy * cols + xx : p];
+        float o;
+        if constexpr (sizeof(T) == 2) o = (float)(v == 0 ? (T)1 : v);   /* dframe.setTo(1, dframe==0)  :514 */
+        else o = (float)v;
+        depth[p] = o;
+    }
+}
+
+hipError_t launch_import_grey(const void *src, int dtype, int row_major, size_t src_stride,
+                              unsigned char *grey, size_t stride, ImgBatch g, hipStream_t s) {
+    const size_t n = (size_t)g.rows * g.cols;
+    const dim3 grid(grid_x(n), g.count);
+    if (dtype == 0)
+        hipLaunchKernelGGL(import_grey_kernel<unsigned char>, grid, dim3(256), 0, s, (const unsigned char *)src, src_stride,
+                           row_major, grey, stride, g.rows, g.cols);
+    else
+        hipLaunchKernelGGL(import_grey_kernel<float>, grid, dim3(256), 0, s, (const float *)src, src_stride,
+                           row_major, grey, stride, g.rows, g.cols);
+    return hipGetLastError();
+}
+hipError_t launch_import_depth(const void *src, int dtype, int row_major, size_t src_stride,
+                               float *depth, size_t stride, ImgBatch g, hipStream_t s) {
+    const size_t n = (size_t)g.rows * g.cols;
+    const dim3 grid(grid_x(n), g.count);
+    if (dtype == 1)
+        hipLaunchKernelGGL(import_depth_kernel<unsigned short>, grid, dim3(256), 0, s, (const unsigned short *)src,
+                           src_stride, row_major, depth, stride, g.rows, g.cols);
+    else
+        hipLaunchKernelGGL(import_depth_kernel<float>, grid, dim3(256), 0, s, (const float *)src, src_stride,
+                           row_major, depth, stride, g.rows, g.cols);
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------- */
+/* row f2: camera frame -> one pyramid level                                    */
+/* ------------------------------------------------------------------------- */
+DVO_DEV float depth_m_to_mm(float d_m) {
+    const float mm = d_m * 1000.0f;                                  /* depth = 1000.0 * depth (32F)   :75 */
+    if (!(mm > -2147483648.5f && mm < 2147483648.0f)) return 1.0f;   /* cvRound -> INT_MIN -> saturates to 0 -> 1 */
+    float r = rintf(mm);                                             /* convertTo(CV_16U)              :76 */
+    r = r < 0.0f ? 0.0f : (r > 65535.0f ? 65535.0f : r);
+    return r == 0.0f ? 1.0f : r;                                     /* setTo(1, depth16==0)           :77 */
+}
+
+__global__ void __launch_bounds__(256)
+camera_level_kernel(const unsigned char *__restrict__ bgr, size_t bgr_stride,
+                    const float *__restrict__ depth_m, size_t depth_stride,
+                    int src_rows, int src_cols, int shift,
+                    unsigned char *__restrict__ grey, float *__restrict__ depth, size_t stride, int rows, int cols) {
+    const size_t n = (size_t)rows * cols;
+    bgr += (size_t)blockIdx.y * bgr_stride;
+    grey += (size_t)blockIdx.y * stride;
+    if (depth_m) { depth_m += (size_t)blockIdx.y * depth_stride; depth += (size_t)blockIdx.y * stride; }
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(p / rows), yy = (int)(p - (size_t)xx * rows);
+        int sy = yy << shift, sx = xx << shift;                      /* resizeNN: min(floor(x/scale), size-1) */
+        sy = sy > src_rows - 1 ? src_rows - 1 : sy;
+        sx = sx > src_cols - 1 ? src_cols - 1 : sx;
+        const size_t sp = (size_t)sy * src_cols + sx;
+        const int b = bgr[3 * sp], gg = bgr[3 * sp + 1], r = bgr[3 * sp + 2];
+        grey[p] = (unsigned char)((1868 * b + 9617 * gg + 4899 * r + (1 << 13)) >> 14);   /* BGR2GRAY 8u */
+        if (depth_m) depth[p] = depth_m_to_mm(depth_m[sp]);
+    }
+}
+
+hipError_t launch_camera_level(const unsigned char *bgr, size_t bgr_stride, const float *depth_m, size_t depth_stride,
+                               int src_rows, int src_cols, int shift, unsigned char *grey, float *depth_mm,
+                               size_t stride, ImgBatch g, hipStream_t s) {
+    const size_t n = (size_t)g.rows * g.cols;
+    hipLaunchKernelGGL(camera_level_kernel, dim3(grid_x(n), g.count), dim3(256), 0, s, bgr, bgr_stride, depth_m,
+                       depth_stride, src_rows, src_cols, shift, grey, depth_mm, stride, g.rows, g.cols);
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------- */
+/* row f1: Canny                                                                */
+/* ------------------------------------------------------------------------- */
+/* work layout per batch (ints): mag[count*n] | dxdy[count*n] (short2) | label[count*n] | cand[count*n bytes] | flag[count*n bytes] */
+size_t canny_work_ints(int rows, int cols, int count) {
+    const size_t n = (size_t)rows * cols * count;
+    return 3 * n + 2 * ((n + 3) / 4);
+}
+
+__global__ void __launch_bounds__(256)
+canny_sobel_kernel(const unsigned char *__restrict__ grey, size_t stride, int rows, int cols,
+                   int *__restrict__ mag, short2 *__restrict__ dxdy) {
+    const size_t n = (size_t)rows * cols;
+    grey += (size_t)blockIdx.y * stride;
+    mag += (size_t)blockIdx.y * n;
+    dxdy += (size_t)blockIdx.y * n;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(p / rows), yy = (int)(p - (size_t)xx * rows);
+        const int ym = yy > 0 ? yy - 1 : 0, yp = yy < rows - 1 ? yy + 1 : rows - 1;     /* BORDER_REPLICATE */
+        const size_t cm = (size_t)(xx > 0 ? xx - 1 : 0) * rows, c0 = (size_t)xx * rows,
+                     cp = (size_t)(xx < cols - 1 ? xx + 1 : cols - 1) * rows;
+        const int a = grey[cm + ym], b = grey[c0 + ym], c = grey[cp + ym];
+        const int d = grey[cm + yy], f = grey[cp + yy];
+        const int g = grey[cm + yp], h = grey[c0 + yp], i = grey[cp + yp];
+        const int dx = (c - a) + 2 * (f - d) + (i - g);
+        const int dy = (g - a) + 2 * (h - b) + (i - c);
+        dxdy[p] = make_short2((short)dx, (short)dy);
+        mag[p] = dx * dx + dy * dy;
+    }
+}
+
+/* cand: 0 suppressed, 1 candidate (> low, local maximum along its sector), 2 candidate above high */
+__global__ void __launch_bounds__(256)
+canny_nms_kernel(const int *__restrict__ mag, const short2 *__restrict__ dxdy, int rows, int cols, int low, int high,
+                 unsigned char *__restrict__ cand, unsigned char *__restrict__ flag, int *__restrict__ label) {
+    const size_t n = (size_t)rows * cols;
+    mag += (size_t)blockIdx.y * n; dxdy += (size_t)blockIdx.y * n;
+    cand += (size_t)blockIdx.y * n; flag += (size_t)blockIdx.y * n; label += (size_t)blockIdx.y * n;
+    constexpr int SHIFT = 15;
+    constexpr int TG22 = 13573;                                   /* round(tan(22.5 deg) * 2^15) */
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(p / rows), yy = (int)(p - (size_t)xx * rows);
+        const int m = mag[p];
+        bool keep = false;
+        if (m > low) {
+            const short2 d = dxdy[p];
+            const int xs = d.x, ys = d.y;
+            const int ax = xs < 0 ? -xs : xs, ay = (ys < 0 ? -ys : ys) << SHIFT;
+            const int tg22x = ax * TG22;
+            int ay1, ax1, ay2, ax2;                               /* the two neighbours of the sector */
+            bool ge2;                                             /* second comparison is >= (x and y sectors) */
+            if (ay < tg22x) { ay1 = 0; ax1 = -1; ay2 = 0; ax2 = 1; ge2 = true; }
+            else if (ay > tg22x + (ax << (SHIFT + 1))) { ay1 = -1; ax1 = 0; ay2 = 1; ax2 = 0; ge2 = true; }
+            else { const int sgn = ((xs ^ ys) < 0) ? -1 : 1; ay1 = -1; ax1 = -sgn; ay2 = 1; ax2 = sgn; ge2 = false; }
+            const int y1 = yy + ay1, x1 = xx + ax1, y2 = yy + ay2, x2 = xx + ax2;
+            const int m1 = (y1 < 0 || y1 >= rows || x1 < 0 || x1 >= cols) ? 0 : mag[(size_t)x1 * rows + y1];
+            const int m2 = (y2 < 0 || y2 >= rows || x2 < 0 || x2 >= cols) ? 0 : mag[(size_t)x2 * rows + y2];
+            keep = (m > m1) && (ge2 ? (m >= m2) : (m > m2));
+        }
+        cand[p] = keep ? (m > high ? 2 : 1) : 0;
+        flag[p] = 0;
+        label[p] = keep ? (int)p : -1;
+    }
+}
+
+DVO_DEV int uf_load(const int *L, int a) { return __hip_atomic_load(L + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DVO_DEV int uf_find(const int *L, int a) {
+    int p;
+    while ((p = uf_load(L, a)) != a) a = p;
+    return a;
+}
+DVO_DEV void uf_union(int *L, int a, int b) {
+    for (;;) {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }            /* a is the larger root: hang it below b */
+        const int old = atomicMin(L + a, b);
+        if (old == a) return;
+        a = old;                                                  /* a had been re-parented meanwhile: go on from there */
+    }
+}
+
+/* hysteresis connectivity: union of every candidate with its candidate neighbours of smaller index */
+__global__ void __launch_bounds__(256)
+canny_merge_kernel(const unsigned char *__restrict__ cand, int rows, int cols, int *__restrict__ label) {
+    const size_t n = (size_t)rows * cols;
+    cand += (size_t)blockIdx.y * n; label += (size_t)blockIdx.y * n;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        if (!cand[p]) continue;
+        const int xx = (int)(p / rows), yy = (int)(p - (size_t)xx * rows);
+        if (yy > 0 && cand[p - 1]) uf_union(label, (int)p, (int)p - 1);
+        if (xx > 0) {
+            const size_t q = p - rows;
+            if (cand[q]) uf_union(label, (int)p, (int)q);
+            if (yy > 0 && cand[q - 1]) uf_union(label, (int)p, (int)q - 1);
+            if (yy < rows - 1 && cand[q + 1]) uf_union(label, (int)p, (int)q + 1);
+        }
+    }
+}
+
+/* label <- root; roots of components holding a strong candidate are flagged */
+__global__ void __launch_bounds__(256)
+canny_flag_kernel(const unsigned char *__restrict__ cand, size_t n, int *__restrict__ label, unsigned char *__restrict__ flag) {
+    cand += (size_t)blockIdx.y * n; label += (size_t)blockIdx.y * n; flag += (size_t)blockIdx.y * n;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        const unsigned char c = cand[p];
+        if (!c) continue;
+        const int r = uf_find(label, (int)p);
+        label[p] = r;                       /* racing writers only ever store ancestors: find() stays correct */
+        if (c == 2) flag[r] = 1;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+canny_final_kernel(const unsigned char *__restrict__ cand, const int *__restrict__ label, const unsigned char *__restrict__ flag,
+                   size_t n, unsigned char *__restrict__ edge, size_t edge_stride, int *__restrict__ n_edges) {
+    cand += (size_t)blockIdx.y * n; label += (size_t)blockIdx.y * n; flag += (size_t)blockIdx.y * n;
+    edge += (size_t)blockIdx.y * edge_stride;
+    int cnt = 0;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        bool e = false;
+        if (cand[p]) e = flag[uf_find(label, (int)p)] != 0;
+        edge[p] = e ? 255 : 0;
+        cnt += e ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(n_edges + blockIdx.y, cnt);
+}
+
+hipError_t launch_canny(const unsigned char *grey, size_t stride, ImgBatch g, int low, int high, int *work,
+                        unsigned char *edge, size_t edge_stride, int *n_edges, hipStream_t s) {
+    const size_t n = (size_t)g.rows * g.cols, nb = n * g.count;
+    int *mag = work;
+    short2 *dxdy = reinterpret_cast<short2 *>(work + nb);
+    int *label = work + 2 * nb;
+    unsigned char *cand = reinterpret_cast<unsigned char *>(work + 3 * nb);
+    unsigned char *flag = cand + ((nb + 3) / 4) * 4;
+    hipError_t e = hipMemsetAsync(n_edges, 0, sizeof(int) * g.count, s);
+    if (e != hipSuccess) return e;
+    const dim3 grid(grid_x(n), g.count), blk(256);
+    hipLaunchKernelGGL(canny_sobel_kernel, grid, blk, 0, s, grey, stride, g.rows, g.cols, mag, dxdy);
+    hipLaunchKernelGGL(canny_nms_kernel, grid, blk, 0, s, mag, dxdy, g.rows, g.cols, low, high, cand, flag, label);
+    hipLaunchKernelGGL(canny_merge_kernel, grid, blk, 0, s, cand, g.rows, g.cols, label);
+    hipLaunchKernelGGL(canny_flag_kernel, grid, blk, 0, s, cand, n, label, flag);
+    hipLaunchKernelGGL(canny_final_kernel, grid, blk, 0, s, cand, label, flag, n, edge, edge_stride, n_edges);
+    return hipGetLastError();
+}
+
+/* stage dump for tests: squared magnitude and candidate map of the LAST launch_canny on this work buffer */
+void canny_work_views(int *work, int rows, int cols, int count, const int **mag, const unsigned char **cand) {
+    const size_t nb = (size_t)rows * cols * count;
+    *mag = work;
+    *cand = reinterpret_cast<const unsigned char *>(work + 3 * nb);
+}
+
+/* ------------------------------------------------------------------------- */
+/* now-frame preprocessing after Canny: computeDistTransfrmOfNow (SolveDVO.cpp:1768-1795) +
+ * imageGradient (:1063-1098).  edge mask -> exact squared EDT in integers (two separable passes)
+ * -> sqrt -> min-max normalise to [0,255] (:1774) -> central differences with a
+ * reflect-101 border (:1077-1090) -> tiled texels {DT,gx,gy,w}.                              */
+/* ------------------------------------------------------------------------- */
+#define DVO_EDT_INF(rows, cols) ((rows) + (cols) + 1)
+
+/* phase 1: per column, distance to the nearest edge pixel of that column; one wave per column,
+ * 64 rows per step, nearest set bit of the ballot above / below each lane */
+__global__ void __launch_bounds__(64)
+edt_columns_kernel(const unsigned char *__restrict__ edge, size_t edge_stride, int rows, int cols, int *__restrict__ g) {
+    const int xx = blockIdx.x, lane = threadIdx.x;
+    edge += (size_t)blockIdx.y * edge_stride;
+    g += (size_t)blockIdx.y * rows * cols;
+    const size_t base = (size_t)xx * rows;
+    const int INF = DVO_EDT_INF(rows, cols);
+    const int nchunk = (rows + 63) / 64;
+    int carry = INF;                                    /* distance from the row above this chunk to the nearest edge above it */
+    for (int c = 0; c < nchunk; c++) {
+        const int yy = c * 64 + lane;
+        const bool e = (yy < rows) && (edge[base + yy] != 0);
+        const unsigned long long m = __ballot(e);
+        const unsigned long long low = m & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));   /* bits 0..lane */
+        int da;
+        if (low) da = lane - (63 - __clzll((long long)low));
+        else da = (carry >= INF) ? INF : carry + lane + 1;
+        if (yy < rows) g[base + yy] = da;
+        if (m) carry = 63 - (63 - __clzll((long long)m));                 /* from lane 63 up to the highest edge */
+        else carry = (carry >= INF) ? INF : carry + 64;
+    }
+    carry = INF;                                        /* distance from the row below this chunk to the nearest edge below it */
+    for (int c = nchunk - 1; c >= 0; c--) {
+        const int yy = c * 64 + lane;
+        const bool e = (yy < rows) && (edge[base + yy] != 0);
+        const unsigned long long m = __ballot(e);
+        const unsigned long long high = m & (~0ull << lane);                                     /* bits lane..63 */
+        int db;
+        if (high) db = (__ffsll((long long)high) - 1) - lane;
+        else db = (carry >= INF) ? INF : carry + (63 - lane) + 1;
+        if (yy < rows) { const int da = g[base + yy]; int v = da < db ? da : db; if (v > INF) v = INF; g[base + yy] = v; }
+        if (m) carry = __ffsll((long long)m) - 1;                          /* from lane 0 down to the lowest edge */
+        else carry = (carry >= INF) ? INF : carry + 64;
+    }
+}
+
+/* phase 2: d2(x,y) = min_i (x-i)^2 + g(i,y)^2 along the row, exactly, in integers.  One thread per pixel
+ * scans outwards while i^2 < best: with edges every few pixels that is a few dozen coalesced loads, far
+ * cheaper on a GPU than the sequential lower-envelope scan (Meijster) a CPU would use -- same minimum. */
+__global__ void __launch_bounds__(256)
+edt_rows_kernel(const int *__restrict__ g, int rows, int cols, int *__restrict__ d2, int *__restrict__ max_d2) {
+    const size_t n = (size_t)rows * cols;
+    g += (size_t)blockIdx.y * n; d2 += (size_t)blockIdx.y * n;
+    int mx = 0;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(idx / rows);
+        const int g0 = g[idx];
+        int best = g0 * g0;                                   /* (rows+cols+1)^2 < 2^31 for every supported size */
+        for (int i = 1; i * i < best; i++) {
+            const bool l = xx - i >= 0, r = xx + i < cols;
+            if (!l && !r) break;
+            if (l) { const int gl = g[idx - (size_t)i * rows]; const int c = i * i + gl * gl; best = c < best ? c : best; }
+            if (r) { const int gr = g[idx + (size_t)i * rows]; const int c = i * i + gr * gr; best = c < best ? c : best; }
+        }
+        d2[idx] = best;
+        mx = best > mx ? best : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_down(mx, off, 64); mx = o > mx ? o : mx; }
+    if ((threadIdx.x & 63) == 0) atomicMax(max_d2 + blockIdx.y, mx);
+}
+
+/* raw distance -> normalised [0,255] float, in place (the int buffer is reused as float).  An image without any
+ * edge pixel (every distance "infinite") normalises to all zeros, as cv::normalize does for a constant image. */
+__global__ void __launch_bounds__(256)
+dt_normalize_kernel(int *__restrict__ d2_inout, int rows, int cols, const int *__restrict__ max_d2) {
+    const size_t n = (size_t)rows * cols;
+    d2_inout += (size_t)blockIdx.y * n;
+    const int INF = DVO_EDT_INF(rows, cols);
+    const int m2 = max_d2[blockIdx.y];
+    const float mxf = (float)sqrt((double)m2), mnf = 0.0f;
+    const double scale = (mxf > mnf && m2 < INF * INF) ? 255.0 / ((double)mxf - (double)mnf) : 0.0;   /* cv::normalize NORM_MINMAX, :1774 */
+    float *out = reinterpret_cast<float *>(d2_inout);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float raw = (float)sqrt((double)d2_inout[i]);
+        out[i] = (float)(((double)raw - (double)mnf) * scale);
+    }
+}
+
+DVO_DEV int reflect101(int i, int n) { return (n == 1) ? 0 : (i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i)); }
+
+__global__ void __launch_bounds__(256)
+dt_gradient_pack_kernel(const float *__restrict__ dt, int rows, int cols, float4 *__restrict__ out, size_t tex_stride) {
+    const size_t n = (size_t)rows * cols;
+    dt += (size_t)blockIdx.y * n;
+    out += (size_t)blockIdx.y * tex_stride;
+    const int tpc = texel_tiles_per_col(rows);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i / rows), yy = (int)(i - (size_t)xx * rows);
+        const float l_ = dt[(size_t)reflect101(xx - 1, cols) * rows + yy], r_ = dt[(size_t)reflect101(xx + 1, cols) * rows + yy];
+        const float u_ = dt[(size_t)xx * rows + reflect101(yy - 1, rows)], b_ = dt[(size_t)xx * rows + reflect101(yy + 1, rows)];
+        const float v = dt[i];
+        out[texel_index(yy, xx, tpc)] = make_float4(v, 0.5f * r_ - 0.5f * l_, 0.5f * b_ - 0.5f * u_, weight_of(v));
+    }
+}
+
+size_t edt_work_ints(int rows, int cols, int count) { return (2 * (size_t)rows * cols + 1) * count; }
+
+hipError_t launch_edges_to_texels(const unsigned char *edge, size_t edge_stride, ImgBatch gb, int *work,
+                                  float4 *tex_out, size_t tex_stride, hipStream_t s) {
+    const size_t n = (size_t)gb.rows * gb.cols, nb = n * gb.count;
+    int *g = work, *d2 = work + nb, *max_d2 = work + 2 * nb;
+    hipError_t e = hipMemsetAsync(max_d2, 0, sizeof(int) * gb.count, s);
+    if (e != hipSuccess) return e;
+    const dim3 grid(grid_x(n), gb.count);
+    hipLaunchKernelGGL(edt_columns_kernel, dim3(gb.cols, gb.count), dim3(64), 0, s, edge, edge_stride, gb.rows, gb.cols, g);
+    hipLaunchKernelGGL(edt_rows_kernel, grid, dim3(256), 0, s, g, gb.rows, gb.cols, d2, max_d2);
+    hipLaunchKernelGGL(dt_normalize_kernel, grid, dim3(256), 0, s, d2, gb.rows, gb.cols, max_d2);
+    hipLaunchKernelGGL(dt_gradient_pack_kernel, grid, dim3(256), 0, s,
+                       reinterpret_cast<const float *>(d2), gb.rows, gb.cols, tex_out, tex_stride);
+    return hipGetLastError();
+}
+hipError_t launch_now_level_from_edges(const unsigned char *edge, int rows, int cols, int *work, float4 *tex_out, hipStream_t s) {
+    return launch_edges_to_texels(edge, 0, ImgBatch{rows, cols, 1}, work, tex_out, 0, s);
+}
+
+/* ------------------------------------------------------------------------- */
+/* selectedPts + enlistRefEdgePts  (SolveDVO.cpp:1230-1264, :224-264)          */
+/* Column-major scan order (xx outer, yy inner): one wave per image column.     */
+/* ------------------------------------------------------------------------- */
+DVO_DEV bool ref_selected(int e, float d) { return (e > 0) && (d > 100.0f); }   /* :1251 */
+
+template <typename E>
+__global__ void __launch_bounds__(64)
+enlist_count_kernel(const E *__restrict__ edge, size_t edge_stride, const float *__restrict__ depth, size_t depth_stride,
+                    int rows, int cols, int *__restrict__ col_counts) {
+    const int xx = blockIdx.x, lane = threadIdx.x;
+    edge += (size_t)blockIdx.y * edge_stride; depth += (size_t)blockIdx.y * depth_stride;
+    col_counts += (size_t)blockIdx.y * (cols + 2);
+    const size_t base = (size_t)xx * rows;
+    int cnt = 0;
+    for (int y0 = 0; y0 < rows; y0 += 64) {
+        const int yy = y0 + lane;
+        const bool sel = (yy < rows) && ref_selected((int)edge[base + yy], depth[base + yy]);
+        cnt += __popcll(__ballot(sel));
+    }
+    if (lane == 0) col_counts[xx] = cnt;
+}
+
+/* exclusive scan of col_counts[0..cols) in place; col_counts[cols] = col_counts[cols+1] = total */
+__global__ void __launch_bounds__(1024)
+enlist_scan_kernel(int *__restrict__ col_counts, int cols) {
+    __shared__ int part[1024];
+    col_counts += (size_t)blockIdx.y * (cols + 2);
+    const int tid = threadIdx.x;
+    const int per = (cols + 1023) / 1024;
+    const int b = tid * per;
+    int s = 0;
+    for (int k = 0; k < per; k++) if (b + k < cols) s += col_counts[b + k];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          /* Hillis-Steele inclusive scan */
+        int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = (tid == 0) ? 0 : part[tid - 1];
+    for (int k = 0; k < per; k++) {
+        if (b + k < cols) { const int cval = col_counts[b + k]; col_counts[b + k] = run; run += cval; }
+    }
+    if (tid == 1023) { col_counts[cols] = part[1023]; col_counts[cols + 1] = part[1023]; }
+}
+
+template <typename E>
+__global__ void __launch_bounds__(64)
+enlist_write_kernel(const E *__restrict__ edge, size_t edge_stride, const float *__restrict__ depth, size_t depth_stride,
+                    int rows, int cols, int level, Intrinsics K, const int *__restrict__ col_offsets,
+                    float *__restrict__ xyz, size_t xyz_stride, float *__restrict__ uv, int capacity, int *__restrict__ N_dst) {
+    const int xx = blockIdx.x, lane = threadIdx.x;
+    edge += (size_t)blockIdx.y * edge_stride; depth += (size_t)blockIdx.y * depth_stride;
+    col_offsets += (size_t)blockIdx.y * (cols + 2);
+    xyz += (size_t)blockIdx.y * xyz_stride;
+    if (N_dst && xx == 0 && lane == 0) { const int N = col_offsets[cols]; N_dst[blockIdx.y] = N < capacity ? N : capacity; }
+    const size_t base = (size_t)xx * rows;
+    const float scaleFac = pow2_neg_f(level);                           /* :231 */
+    const float tmpfx = (float)(1. / (double)(scaleFac * K.fx));        /* :232 double division */
+    const float tmpfy = (float)(1. / (double)(scaleFac * K.fy));        /* :233 */
+    const float tmpcx = scaleFac * K.cx;                                /* :234 */
+    const float tmpcy = scaleFac * K.cy;                                /* :235 */
+    int run = col_offsets[xx];
+    for (int y0 = 0; y0 < rows; y0 += 64) {
+        const int yy = y0 + lane;
+        float d = 0.0f;
+        bool sel = false;
+        if (yy < rows) { d = depth[base + yy]; sel = ref_selected((int)edge[base + yy], d); }
+        const unsigned long long m = __ballot(sel);
+        if (sel) {
+            const int nC = run + __popcll(m & ((1ull << lane) - 1ull));
+            if (nC < capacity) {
+                const float Z = d / 1000.0f;                            /* :248 */
+                const float X = Z * ((float)xx - tmpcx) * tmpfx;        /* :249 */
+                const float Y = Z * ((float)yy - tmpcy) * tmpfy;        /* :250 */
+                xyz[3 * nC] = X; xyz[3 * nC + 1] = Y; xyz[3 * nC + 2] = Z;   /* :254-256 */
+                if (uv) { uv[2 * nC] = (float)xx; uv[2 * nC + 1] = (float)yy; }   /* :244-245 */
+            }
+        }
+        run += __popcll(m);
+    }
+}
+
+template <typename E>
+static hipError_t enlist_count_t(const E *edge, size_t edge_stride, const float *depth, size_t depth_stride, ImgBatch g,
+                                 int *col_counts, hipStream_t s) {
+    hipLaunchKernelGGL(enlist_count_kernel<E>, dim3(g.cols, g.count), dim3(64), 0, s, edge, edge_stride, depth, depth_stride,
+                       g.rows, g.cols, col_counts);
+    hipLaunchKernelGGL(enlist_scan_kernel, dim3(1, g.count), dim3(1024), 0, s, col_counts, g.cols);
+    return hipGetLastError();
+}
+template <typename E>
+static hipError_t enlist_write_t(const E *edge, size_t edge_stride, const float *depth, size_t depth_stride, ImgBatch g,
+                                 int level, const Intrinsics &K, const int *col_counts, float *xyz, size_t xyz_stride,
+                                 float *uv, int capacity, int *N_dst, hipStream_t s) {
+    hipLaunchKernelGGL(enlist_write_kernel<E>, dim3(g.cols, g.count), dim3(64), 0, s, edge, edge_stride, depth, depth_stride,
+                       g.rows, g.cols, level, K, col_counts, xyz, xyz_stride, uv, capacity, N_dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_enlist_count(const void *edge, int edge_is_u8, size_t edge_stride, const float *depth, size_t depth_stride,
+                               ImgBatch g, int *col_counts, hipStream_t s) {
+    return edge_is_u8 ? enlist_count_t((const unsigned char *)edge, edge_stride, depth, depth_stride, g, col_counts, s)
+                      : enlist_count_t((const int32_t *)edge, edge_stride, depth, depth_stride, g, col_counts, s);
+}
+hipError_t launch_enlist_write(const void *edge, int edge_is_u8, size_t edge_stride, const float *depth, size_t depth_stride,
+                               ImgBatch g, int level, const Intrinsics &K, const int *col_counts, float *xyz,
+                               size_t xyz_stride, float *uv, int capacity, int *N_dst, hipStream_t s) {
+    return edge_is_u8 ? enlist_write_t((const unsigned char *)edge, edge_stride, depth, depth_stride, g, level, K, col_counts,
+                                       xyz, xyz_stride, uv, capacity, N_dst, s)
+                      : enlist_write_t((const int32_t *)edge, edge_stride, depth, depth_stride, g, level, K, col_counts,
+                                       xyz, xyz_stride, uv, capacity, N_dst, s);
+}
+
+}  // namespace dvo

@@ -17,8 +17,7 @@
  *                        the 32 sums (21 H + 6 g + sum eps^2 + visible count) are all-reduced in between.
  *   eval_points_kernel, accumulate_kernel      single evaluations for inspection / parity tests.
  *   pack_texels_kernel, replicate_level_kernel, unpack_texels_kernel     resident-data management.
- *   enlist_* kernels     selectedPts + enlistRefEdgePts (:1230-1264, :224-264).
- *   edt_* / dt_* kernels computeDistTransfrmOfNow after Canny + imageGradient (:1768-1795, :1063-1098).
+ *   (per-frame preprocessing -- Canny, distance transform, point extraction -- lives in dvo_frames.hip)
  *
  * No MFMA: the path is per-point arithmetic plus a tree reduction, not a dense contraction.
  * Compile with -ffp-contract=off (see Makefile): bit-parity of the float32 per-point math with the
@@ -731,101 +730,6 @@ hipError_t launch_iter_end(void *state, double *Rt12, int *best_idx, float *rati
 }
 size_t pose_state_bytes() { return sizeof(PoseState); }
 
-/* ------------------------------------------------------------------------- */
-/* now-frame preprocessing after Canny: computeDistTransfrmOfNow (SolveDVO.cpp:1768-1795) +
- * imageGradient (:1063-1098).  edge mask -> exact squared EDT in integers (two separable passes)
- * -> sqrt -> min-max normalise to [0,255] (:1774) -> central differences with a
- * reflect-101 border (:1077-1090) -> tiled texels {DT,gx,gy,w}.                              */
-/* ------------------------------------------------------------------------- */
-#define DVO_EDT_INF(rows, cols) ((rows) + (cols) + 1)
-
-/* phase 1: per column, distance to the nearest edge pixel of that column; one wave per column,
- * 64 rows per step, nearest set bit of the ballot above / below each lane */
-__global__ void __launch_bounds__(64)
-edt_columns_kernel(const unsigned char *__restrict__ edge, int rows, int cols, int *__restrict__ g) {
-    const int xx = blockIdx.x, lane = threadIdx.x;
-    const size_t base = (size_t)xx * rows;
-    const int INF = DVO_EDT_INF(rows, cols);
-    const int nchunk = (rows + 63) / 64;
-    int carry = INF;                                    /* distance from the row above this chunk to the nearest edge above it */
-    for (int c = 0; c < nchunk; c++) {
-        const int yy = c * 64 + lane;
-        const bool e = (yy < rows) && (edge[base + yy] != 0);
-        const unsigned long long m = __ballot(e);
-        const unsigned long long low = m & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));   /* bits 0..lane */
-        int da;
-        if (low) da = lane - (63 - __clzll((long long)low));
-        else da = (carry >= INF) ? INF : carry + lane + 1;
-        if (yy < rows) g[base + yy] = da;
-        if (m) carry = 63 - (63 - __clzll((long long)m));                 /* from lane 63 up to the highest edge */
-        else carry = (carry >= INF) ? INF : carry + 64;
-    }
-    carry = INF;                                        /* distance from the row below this chunk to the nearest edge below it */
-    for (int c = nchunk - 1; c >= 0; c--) {
-        const int yy = c * 64 + lane;
-        const bool e = (yy < rows) && (edge[base + yy] != 0);
-        const unsigned long long m = __ballot(e);
-        const unsigned long long high = m & (~0ull << lane);                                     /* bits lane..63 */
-        int db;
-        if (high) db = (__ffsll((long long)high) - 1) - lane;
-        else db = (carry >= INF) ? INF : carry + (63 - lane) + 1;
-        if (yy < rows) { const int da = g[base + yy]; int v = da < db ? da : db; if (v > INF) v = INF; g[base + yy] = v; }
-        if (m) carry = __ffsll((long long)m) - 1;                          /* from lane 0 down to the lowest edge */
-        else carry = (carry >= INF) ? INF : carry + 64;
-    }
-}
-
-/* phase 2: d2(x,y) = min_i (x-i)^2 + g(i,y)^2 along the row, exactly, in integers.  One thread per pixel
- * scans outwards while i^2 < best: with edges every few pixels that is a few dozen coalesced loads, far
- * cheaper on a GPU than the sequential lower-envelope scan (Meijster) a CPU would use -- same minimum. */
-__global__ void __launch_bounds__(256)
-edt_rows_kernel(const int *__restrict__ g, int rows, int cols, int *__restrict__ d2, int *__restrict__ max_d2) {
-    const size_t n = (size_t)rows * cols;
-    int mx = 0;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
-        const int xx = (int)(idx / rows);
-        const int g0 = g[idx];
-        int best = g0 * g0;                                   /* (rows+cols+1)^2 < 2^31 for every supported size */
-        for (int i = 1; i * i < best; i++) {
-            const bool l = xx - i >= 0, r = xx + i < cols;
-            if (!l && !r) break;
-            if (l) { const int gl = g[idx - (size_t)i * rows]; const int c = i * i + gl * gl; best = c < best ? c : best; }
-            if (r) { const int gr = g[idx + (size_t)i * rows]; const int c = i * i + gr * gr; best = c < best ? c : best; }
-        }
-        d2[idx] = best;
-        mx = best > mx ? best : mx;
-    }
-    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_down(mx, off, 64); mx = o > mx ? o : mx; }
-    if ((threadIdx.x & 63) == 0) atomicMax(max_d2, mx);
-}
-
-/* raw distance -> normalised [0,255] float, in place (the int buffer is reused as float) */
-__global__ void __launch_bounds__(256)
-dt_normalize_kernel(int *__restrict__ d2_inout, size_t n, const int *__restrict__ max_d2) {
-    const float mxf = (float)sqrt((double)*max_d2), mnf = 0.0f;
-    const double scale = (mxf > mnf) ? 255.0 / ((double)mxf - (double)mnf) : 0.0;     /* cv::normalize NORM_MINMAX, :1774 */
-    float *out = reinterpret_cast<float *>(d2_inout);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float raw = (float)sqrt((double)d2_inout[i]);
-        out[i] = (float)(((double)raw - (double)mnf) * scale);
-    }
-}
-
-DVO_DEV int reflect101(int i, int n) { return (n == 1) ? 0 : (i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i)); }
-
-__global__ void __launch_bounds__(256)
-dt_gradient_pack_kernel(const float *__restrict__ dt, int rows, int cols, float4 *__restrict__ out) {
-    const size_t n = (size_t)rows * cols;
-    const int tpc = texel_tiles_per_col(rows);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int xx = (int)(i / rows), yy = (int)(i - (size_t)xx * rows);
-        const float l_ = dt[(size_t)reflect101(xx - 1, cols) * rows + yy], r_ = dt[(size_t)reflect101(xx + 1, cols) * rows + yy];
-        const float u_ = dt[(size_t)xx * rows + reflect101(yy - 1, rows)], b_ = dt[(size_t)xx * rows + reflect101(yy + 1, rows)];
-        const float v = dt[i];
-        out[texel_index(yy, xx, tpc)] = make_float4(v, 0.5f * r_ - 0.5f * l_, 0.5f * b_ - 0.5f * u_, weight_of(v));
-    }
-}
-
 /* texels -> the three planar images (inspection / tests) */
 __global__ void __launch_bounds__(256)
 unpack_texels_kernel(const float4 *__restrict__ tex, int rows, int cols, float *__restrict__ dt,
@@ -839,20 +743,6 @@ unpack_texels_kernel(const float4 *__restrict__ tex, int rows, int cols, float *
     }
 }
 
-hipError_t launch_now_level_from_edges(const unsigned char *edge, int rows, int cols, int *work /* 2*rows*cols + 1 ints */,
-                                       float4 *tex_out, hipStream_t s) {
-    const size_t n = (size_t)rows * cols;
-    int *g = work, *d2 = work + n, *max_d2 = work + 2 * n;
-    hipError_t e = hipMemsetAsync(max_d2, 0, sizeof(int), s);
-    if (e != hipSuccess) return e;
-    size_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(edt_columns_kernel, dim3(cols), dim3(64), 0, s, edge, rows, cols, g);
-    hipLaunchKernelGGL(edt_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, rows, cols, d2, max_d2);
-    hipLaunchKernelGGL(dt_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d2, n, max_d2);
-    hipLaunchKernelGGL(dt_gradient_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
-                       reinterpret_cast<const float *>(d2), rows, cols, tex_out);
-    return hipGetLastError();
-}
 hipError_t launch_unpack_texels(const float4 *tex, int rows, int cols, float *dt, float *gx, float *gy, hipStream_t s) {
     const size_t n = (size_t)rows * cols;
     size_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
@@ -899,92 +789,6 @@ hipError_t launch_se3_log(const double *Rt12, double *psi, hipStream_t s) {
 }
 hipError_t launch_rotationize(double *R9, hipStream_t s) {
     hipLaunchKernelGGL(rotationize_kernel, dim3(1), dim3(64), 0, s, R9);
-    return hipGetLastError();
-}
-
-/* ------------------------------------------------------------------------- */
-/* selectedPts + enlistRefEdgePts  (SolveDVO.cpp:1230-1264, :224-264)          */
-/* Column-major scan order (xx outer, yy inner): one wave per image column.     */
-/* ------------------------------------------------------------------------- */
-DVO_DEV bool ref_selected(int e, float d) { return (e > 0) && (d > 100.0f); }   /* :1251 */
-
-__global__ void __launch_bounds__(64)
-enlist_count_kernel(const int32_t *__restrict__ edge, const float *__restrict__ depth,
-                    int rows, int *__restrict__ col_counts) {
-    const int xx = blockIdx.x, lane = threadIdx.x;
-    const size_t base = (size_t)xx * rows;
-    int cnt = 0;
-    for (int y0 = 0; y0 < rows; y0 += 64) {
-        const int yy = y0 + lane;
-        const bool sel = (yy < rows) && ref_selected(edge[base + yy], depth[base + yy]);
-        cnt += __popcll(__ballot(sel));
-    }
-    if (lane == 0) col_counts[xx] = cnt;
-}
-
-/* exclusive scan of col_counts[0..cols) in place; col_counts[cols] = total */
-__global__ void __launch_bounds__(1024)
-enlist_scan_kernel(int *__restrict__ col_counts, int cols, int *__restrict__ N_out) {
-    __shared__ int part[1024];
-    const int tid = threadIdx.x;
-    const int per = (cols + 1023) / 1024;
-    const int b = tid * per;
-    int s = 0;
-    for (int k = 0; k < per; k++) if (b + k < cols) s += col_counts[b + k];
-    part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {          /* Hillis-Steele inclusive scan */
-        int v = (tid >= off) ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int run = (tid == 0) ? 0 : part[tid - 1];
-    for (int k = 0; k < per; k++) {
-        if (b + k < cols) { const int cval = col_counts[b + k]; col_counts[b + k] = run; run += cval; }
-    }
-    if (tid == 1023) { col_counts[cols] = part[1023]; *N_out = part[1023]; }
-}
-
-__global__ void __launch_bounds__(64)
-enlist_write_kernel(const int32_t *__restrict__ edge, const float *__restrict__ depth,
-                    int rows, int level, Intrinsics K, const int *__restrict__ col_offsets,
-                    float *__restrict__ xyz, float *__restrict__ uv, int capacity) {
-    const int xx = blockIdx.x, lane = threadIdx.x;
-    const size_t base = (size_t)xx * rows;
-    const float scaleFac = pow2_neg(level);                             /* :231 */
-    const float tmpfx = (float)(1. / (double)(scaleFac * K.fx));        /* :232 double division */
-    const float tmpfy = (float)(1. / (double)(scaleFac * K.fy));        /* :233 */
-    const float tmpcx = scaleFac * K.cx;                                /* :234 */
-    const float tmpcy = scaleFac * K.cy;                                /* :235 */
-    int run = col_offsets[xx];
-    for (int y0 = 0; y0 < rows; y0 += 64) {
-        const int yy = y0 + lane;
-        float d = 0.0f;
-        bool sel = false;
-        if (yy < rows) { d = depth[base + yy]; sel = ref_selected(edge[base + yy], d); }
-        const unsigned long long m = __ballot(sel);
-        if (sel) {
-            const int nC = run + __popcll(m & ((1ull << lane) - 1ull));
-            if (nC < capacity) {
-                const float Z = d / 1000.0f;                            /* :248 */
-                const float X = Z * ((float)xx - tmpcx) * tmpfx;        /* :249 */
-                const float Y = Z * ((float)yy - tmpcy) * tmpfy;        /* :250 */
-                xyz[3 * nC] = X; xyz[3 * nC + 1] = Y; xyz[3 * nC + 2] = Z;   /* :254-256 */
-                if (uv) { uv[2 * nC] = (float)xx; uv[2 * nC + 1] = (float)yy; }   /* :244-245 */
-            }
-        }
-        run += __popcll(m);
-    }
-}
-
-hipError_t launch_enlist_ref_points(const int32_t *edge, const float *depth_mm, int rows, int cols,
-                                    int level, const Intrinsics &K, int *col_counts,
-                                    float *xyz, float *uv, int capacity, int *N_out, hipStream_t s) {
-    hipLaunchKernelGGL(enlist_count_kernel, dim3(cols), dim3(64), 0, s, edge, depth_mm, rows, col_counts);
-    hipLaunchKernelGGL(enlist_scan_kernel, dim3(1), dim3(1024), 0, s, col_counts, cols, N_out);
-    hipLaunchKernelGGL(enlist_write_kernel, dim3(cols), dim3(64), 0, s, edge, depth_mm, rows, level, K,
-                       col_counts, xyz, uv, capacity);
     return hipGetLastError();
 }
 

@@ -86,19 +86,45 @@ hipError_t launch_iter_step_fused(const LevelSlab &L, int pair, int level, const
                                   const DevParams &prm, int itr, int n_points, double *partials, int nblocks,
                                   float *energy, hipStream_t s);
 hipError_t launch_iter_end(void *state, double *Rt12, int *best_idx, float *ratio, hipStream_t s);
-/* now-frame preprocessing after Canny (SolveDVO.cpp:1768-1795): edge mask -> texels.
- * work: device scratch of (2*rows*cols + 1) ints */
-hipError_t launch_now_level_from_edges(const unsigned char *edge, int rows, int cols, int *work,
-                                       float4 *tex_out, hipStream_t s);
 hipError_t launch_unpack_texels(const float4 *tex, int rows, int cols, float *dt, float *gx, float *gy, hipStream_t s);
 /* SE(3) helpers on one lane (property tests) */
 hipError_t launch_se3_exp(const double *psi, double *Rt12, hipStream_t s);
 hipError_t launch_se3_log(const double *Rt12, double *psi, hipStream_t s);
 hipError_t launch_rotationize(double *R9, hipStream_t s);
-/* selectedPts + enlistRefEdgePts on the device (SolveDVO.cpp:1230-1264, :224-264) */
-hipError_t launch_enlist_ref_points(const int32_t *edge, const float *depth_mm, int rows, int cols,
-                                    int level, const Intrinsics &K, int *col_counts /*cols+1*/,
-                                    float *xyz, float *uv, int capacity, int *N_out, hipStream_t s);
+
+/* ---- per-frame preprocessing (dvo_frames.hip).  Every launcher is batched over g.count same-geometry
+ * images; image b of a buffer is at base + b*stride (in elements of that buffer). ---- */
+struct ImgBatch { int rows, cols, count; };
+
+/* host-format image -> resident column-major grey (u8) / depth (f32 mm).  dtype: 0 u8, 1 u16, 2 f32 */
+hipError_t launch_import_grey(const void *src, int dtype, int row_major, size_t src_stride,
+                              unsigned char *grey, size_t stride, ImgBatch g, hipStream_t s);
+hipError_t launch_import_depth(const void *src, int dtype, int row_major, size_t src_stride,
+                               float *depth_mm, size_t stride, ImgBatch g, hipStream_t s);
+/* row f2: full-resolution BGR8 (+ depth in metres, may be NULL) row-major -> pyramid level decimated by 2^shift */
+hipError_t launch_camera_level(const unsigned char *bgr, size_t bgr_stride, const float *depth_m, size_t depth_stride,
+                               int src_rows, int src_cols, int shift, unsigned char *grey, float *depth_mm,
+                               size_t stride, ImgBatch g, hipStream_t s);
+/* row f1: cv::Canny(grey, low/high as squared integer thresholds, 3, L2).  work: canny_work_ints() ints;
+ * edge out: 0/255 u8; n_edges[count] */
+size_t canny_work_ints(int rows, int cols, int count);
+hipError_t launch_canny(const unsigned char *grey, size_t stride, ImgBatch g, int low, int high, int *work,
+                        unsigned char *edge, size_t edge_stride, int *n_edges, hipStream_t s);
+void canny_work_views(int *work, int rows, int cols, int count, const int **mag, const unsigned char **cand);
+/* edge mask -> distance transform -> normalise -> gradients -> texels (SolveDVO.cpp:1768-1795, :1063-1098).
+ * work: edt_work_ints() ints */
+size_t edt_work_ints(int rows, int cols, int count);
+hipError_t launch_edges_to_texels(const unsigned char *edge, size_t edge_stride, ImgBatch g, int *work,
+                                  float4 *tex_out, size_t tex_stride, hipStream_t s);
+hipError_t launch_now_level_from_edges(const unsigned char *edge, int rows, int cols, int *work,
+                                       float4 *tex_out, hipStream_t s);
+/* selectedPts + enlistRefEdgePts (SolveDVO.cpp:1230-1264, :224-264).  col_counts: (cols+2) ints per image;
+ * after the count pass col_counts[cols] and [cols+1] hold N.  edge: int32 or u8 (>0 = edge). */
+hipError_t launch_enlist_count(const void *edge, int edge_is_u8, size_t edge_stride, const float *depth_mm,
+                               size_t depth_stride, ImgBatch g, int *col_counts, hipStream_t s);
+hipError_t launch_enlist_write(const void *edge, int edge_is_u8, size_t edge_stride, const float *depth_mm,
+                               size_t depth_stride, ImgBatch g, int level, const Intrinsics &K, const int *col_counts,
+                               float *xyz, size_t xyz_stride, float *uv, int capacity, int *N_dst, hipStream_t s);
 
 }  // namespace dvo
 #endif

@@ -174,6 +174,79 @@ class Oracle:
         self.lib.dvo_oracle_now_level_from_edges(_p(edge), rows, cols, _p(dt), _p(gx), _p(gy))
         return dt, gx, gy
 
+    # ---- rows f1/f2 (dvo_oracle_frames.cpp); images ROW-major numpy arrays (rows, cols) ----
+    def canny(self, grey, t1=150.0, t2=100.0, stages=False):
+        grey = np.ascontiguousarray(grey, dtype=np.uint8)
+        rows, cols = grey.shape
+        dst = np.zeros((rows, cols), np.uint8)
+        if not stages:
+            self.lib.dvo_oracle_canny(_p(grey), rows, cols, t1, t2, _p(dst))
+            return dst
+        mag = np.zeros((rows, cols), np.int32)
+        cand = np.zeros((rows, cols), np.uint8)
+        self.lib.dvo_oracle_canny_stages(_p(grey), rows, cols, t1, t2, _p(mag), _p(cand), _p(dst))
+        return dst, mag, cand
+
+    def sobel3(self, grey):
+        grey = np.ascontiguousarray(grey, dtype=np.uint8)
+        rows, cols = grey.shape
+        dx, dy = np.zeros((rows, cols), np.int16), np.zeros((rows, cols), np.int16)
+        self.lib.dvo_oracle_sobel3(_p(grey), rows, cols, _p(dx), _p(dy))
+        return dx, dy
+
+    def bgr2gray(self, bgr):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        rows, cols, _ = bgr.shape
+        out = np.zeros((rows, cols), np.uint8)
+        self.lib.dvo_oracle_bgr2gray(_p(bgr), rows * cols, _p(out))
+        return out
+
+    def resize_nn(self, img, scale):
+        img = np.ascontiguousarray(img)
+        rows, cols = img.shape[:2]
+        es = img.dtype.itemsize * (img.shape[2] if img.ndim == 3 else 1)
+        dr, dc = C.c_int(), C.c_int()
+        self.lib.dvo_oracle_resize_nn_size(rows, cols, scale, C.byref(dr), C.byref(dc))
+        out = np.zeros((dr.value, dc.value) + img.shape[2:], img.dtype)
+        self.lib.dvo_oracle_resize_nn(_p(img), rows, cols, es, scale, _p(out))
+        return out
+
+    def depth_m_to_mm16(self, depth_m):
+        d = _f32(depth_m)
+        out = np.zeros(d.shape, np.uint16)
+        self.lib.dvo_oracle_depth_m_to_mm16(_p(d), d.size, _p(out))
+        return out
+
+    def build_pyramid(self, bgr, depth_m, n_levels=4, first_shift=1):
+        """camTopic2PublisherPyD.cpp:73-77,322-347 (no camera-info topic => undistort is a copy): per level
+        (mono8 row-major, mono16 row-major); level i is decimated by 2^(first_shift+i) from full resolution."""
+        d16 = self.depth_m_to_mm16(depth_m)
+        out = []
+        for i in range(n_levels):
+            s = 0.5 ** (first_shift + i)
+            out.append((self.bgr2gray(self.resize_nn(bgr, s)), self.resize_nn(d16, s)))
+        return out
+
+    def now_level_from_grey(self, grey_rm, t1=150.0, t2=100.0):
+        """computeDistTransfrmOfNow (SolveDVO.cpp:1740-1799) of one level from the mono8 image (row-major):
+        column-major dt, gx, gy and the column-major edge map (0/255)."""
+        rows, cols = grey_rm.shape
+        edge_rm = self.canny(grey_rm, t1, t2)
+        edge_cm = np.ascontiguousarray(edge_rm.T).ravel()            # cv2eigen: (yy,xx) at yy + xx*rows
+        dt, gx, gy = self.now_level_from_edges(edge_cm, rows, cols)
+        return dt, gx, gy, edge_cm
+
+    def ref_level_from_grey(self, level, grey_rm, depth16_rm, K, t1=150.0, t2=100.0):
+        """computeDistTransfrmOfRef's edge map (:1700-1712) + selectedPts + enlistRefEdgePts of one level;
+        depth is the mono16 image after the node's 0 -> 1 step (:514), widened to float (cv2eigen)."""
+        rows, cols = grey_rm.shape
+        edge_cm = np.ascontiguousarray(self.canny(grey_rm, t1, t2).T).ravel().astype(np.int32)
+        d = np.ascontiguousarray(depth16_rm).astype(np.uint16).copy()
+        d[d == 0] = 1
+        depth_cm = np.ascontiguousarray(d.T).ravel().astype(np.float32)
+        xyz, uv = self.enlist_ref_points(level, edge_cm, depth_cm, rows, cols, K)
+        return xyz, uv, edge_cm
+
     def se3_exp(self, psi):
         psi = np.array(psi, dtype=np.float64)
         R, t = np.zeros((3, 3), order="F"), np.zeros(3)
@@ -205,8 +278,8 @@ class Oracle:
 def load() -> Oracle:
     global _lib
     if _lib is None:
-        if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(
-                os.path.join(ORACLE_DIR, "dvo_oracle.cpp")):
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("dvo_oracle.cpp", "dvo_oracle_frames.cpp", "dvo_oracle.h")]
+        if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(f) for f in srcs):
             build()
         lib = C.CDLL(ORACLE_SO)
         lib.dvo_oracle_weight.restype = C.c_float
@@ -233,6 +306,20 @@ def load() -> Oracle:
         lib.dvo_oracle_state_finish.restype = None
         lib.dvo_oracle_now_level_from_edges.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.dvo_oracle_now_level_from_edges.restype = None
+        lib.dvo_oracle_sobel3.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.dvo_oracle_sobel3.restype = None
+        lib.dvo_oracle_canny.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]
+        lib.dvo_oracle_canny.restype = None
+        lib.dvo_oracle_canny_stages.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 3
+        lib.dvo_oracle_canny_stages.restype = None
+        lib.dvo_oracle_bgr2gray.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.dvo_oracle_bgr2gray.restype = None
+        lib.dvo_oracle_resize_nn_size.argtypes = [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.dvo_oracle_resize_nn_size.restype = None
+        lib.dvo_oracle_resize_nn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+        lib.dvo_oracle_resize_nn.restype = None
+        lib.dvo_oracle_depth_m_to_mm16.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.dvo_oracle_depth_m_to_mm16.restype = None
         for n in ("se3_exp", "se3_log"):
             getattr(lib, "dvo_oracle_" + n).argtypes = [C.c_void_p] * 3
         lib.dvo_oracle_rotationize.argtypes = [C.c_void_p]

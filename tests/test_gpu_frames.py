@@ -1,0 +1,205 @@
+"""Rows f1 + f2 on the GPU (frames in: pyramid, Canny, distance transform, point extraction) vs the oracle,
+bit for bit, through the C ABI (dvo_frames_*)."""
+import numpy as np
+import pytest
+
+import frame_gen
+import oracle_lib
+from oracle_lib import rot_angle
+
+pytestmark = pytest.mark.gpu
+
+K640 = (525.0, 525.0, 319.5, 239.5)
+
+
+def _ctx(n_pairs=1, **kw):
+    from rgbd_odometry_amd import DvoContext
+    return DvoContext(n_pairs, **kw)
+
+
+def _cm(a_rm):
+    """row-major 2-D array -> flat column-major buffer (cv2eigen)"""
+    return np.ascontiguousarray(np.asarray(a_rm).T).ravel()
+
+
+@pytest.mark.parametrize("shape,first_shift,levels", [((480, 640), 0, 4), ((480, 640), 1, 4), ((241, 323), 1, 3), ((97, 131), 0, 2)])
+def test_camera_pyramid_matches_oracle(oracle, shape, first_shift, levels):
+    bgr, depth = frame_gen.camera_frame(3, *shape)
+    ref = oracle.build_pyramid(bgr, depth, levels, first_shift)
+    with _ctx() as ctx:
+        ctx.frames_upload_cameras([bgr], [depth], n_levels=levels, first_shift=first_shift)
+        for l, (g, d16) in enumerate(ref):
+            grey, dep, edge, ne = ctx.frame_level(0, l)
+            assert grey.shape == g.shape
+            assert np.array_equal(grey, g), f"grey level {l}"
+            assert np.array_equal(dep, d16.astype(np.float32)), f"depth level {l}"          # includes NaN/0 -> 1
+            assert np.array_equal(edge, oracle.canny(g)), f"canny level {l}"
+            assert ne == int((edge > 0).sum())
+
+
+def _canny_images():
+    rng = np.random.default_rng(7)
+    yield "noise", rng.integers(0, 256, (75, 101)).astype(np.uint8)
+    yield "noise_small_amplitude", (120 + rng.integers(0, 40, (64, 64))).astype(np.uint8)
+    g = np.zeros((48, 64), np.uint8); g[:, 32:] = 200
+    yield "step_x", g
+    yield "step_y", np.ascontiguousarray(g.T)
+    yy, xx = np.mgrid[0:90, 0:70]
+    yield "diag", ((xx + yy) % 23 < 11).astype(np.uint8) * 180 + 20
+    yield "disc_ties", (((xx - 35) ** 2 + (yy - 45) ** 2) < 900).astype(np.uint8) * 255       # plateaus -> equal magnitudes
+    yield "checker", (((xx // 4) + (yy // 4)) % 2).astype(np.uint8) * 255
+    yield "flat", np.full((33, 47), 99, np.uint8)
+    yield "tiny3", rng.integers(0, 256, (3, 3)).astype(np.uint8)
+    yield "row1", rng.integers(0, 256, (1, 19)).astype(np.uint8)
+    yield "col1", rng.integers(0, 256, (23, 1)).astype(np.uint8)
+    yield "long_chain", np.kron(rng.integers(0, 2, (30, 40)).astype(np.uint8) * 200, np.ones((6, 6), np.uint8))
+    yield "frame", oracle_lib.load().bgr2gray(frame_gen.camera_frame(11, 240, 320)[0])
+
+
+@pytest.mark.parametrize("name,img", list(_canny_images()))
+def test_canny_matches_oracle(oracle, name, img):
+    with _ctx() as ctx:
+        ctx.frames_upload_pyramids([[(img, None)]])
+        _, _, edge, ne = ctx.frame_level(0, 0, want_depth=False)
+        ref = oracle.canny(img)
+        assert np.array_equal(edge, ref), f"{name}: {int((edge != ref).sum())} pixels differ"
+        assert ne == int((ref > 0).sum())
+
+
+def test_canny_thresholds_from_params(oracle):
+    img = oracle.bgr2gray(frame_gen.camera_frame(5, 120, 160)[0])
+    with _ctx(canny_threshold1=40, canny_threshold2=90) as ctx:
+        ctx.frames_upload_pyramids([[(img, None)]])
+        edge = ctx.frame_level(0, 0, want_depth=False)[2]
+        assert np.array_equal(edge, oracle.canny(img, 40.0, 90.0))
+        assert not np.array_equal(edge, oracle.canny(img))
+
+
+def test_layout_and_dtype_variants_agree(oracle):
+    """mono8/mono16 row-major (the message) == float column-major (im_n/dim_n, after the node's 0 -> 1)"""
+    from rgbd_odometry_amd.capi import DVO_LAYOUT_COL_MAJOR, DVO_LAYOUT_ROW_MAJOR
+    bgr, depth = frame_gen.camera_frame(9, 120, 160)
+    pyr = oracle.build_pyramid(bgr, depth, 2, 0)
+    with _ctx() as a, _ctx() as b:
+        a.frames_upload_pyramids([pyr], layout=DVO_LAYOUT_ROW_MAJOR)
+        eig = [(g.astype(np.float32), np.where(d == 0, 1, d).astype(np.float32)) for g, d in pyr]
+        b.frames_upload_pyramids([eig], layout=DVO_LAYOUT_COL_MAJOR)
+        for l in range(2):
+            for x, y in zip(a.frame_level(0, l)[:3], b.frame_level(0, l)[:3]):
+                assert np.array_equal(x, y)
+
+
+def test_now_frame_matches_oracle(oracle):
+    bgr, depth = frame_gen.camera_frame(21, 240, 320)
+    pyr = oracle.build_pyramid(bgr, depth, 3, 0)
+    with _ctx() as ctx:
+        ctx.frames_upload_pyramids([pyr])
+        ctx.frames_as_now(0, 0, 1)
+        for l, (g, _) in enumerate(pyr):
+            dt, gx, gy, _ = oracle.now_level_from_grey(g)
+            ddt, dgx, dgy = ctx.get_now_level(l)
+            assert np.array_equal(ddt, dt) and np.array_equal(dgx, gx) and np.array_equal(dgy, gy), f"level {l}"
+
+
+def test_ref_frame_matches_oracle(oracle):
+    bgr, depth = frame_gen.camera_frame(22, 240, 320)
+    pyr = oracle.build_pyramid(bgr, depth, 3, 0)
+    K = tuple(np.float32(k * 0.5) for k in K640)
+    with _ctx() as ctx:
+        ctx.set_intrinsics(*[float(k) for k in K])
+        ctx.frames_upload_pyramids([pyr])
+        N = ctx.frames_as_ref(0, 0, 1)
+        ctx.frames_as_now(0, 0, 1)
+        for l, (g, d) in enumerate(pyr):
+            xyz, uv, _ = oracle.ref_level_from_grey(l, g, d, K)
+            assert N[0, l] == len(xyz)
+            assert np.array_equal(ctx.get_ref_level(l), xyz), f"level {l}"
+
+
+def test_frames_end_to_end_alignment(oracle):
+    """frames in -> poses out, against the oracle's preprocessing + align_pyramid on the same frames"""
+    iters = [10, 10, 10, 10]
+    K = tuple(np.float32(k) for k in K640)
+    ref_bgr, ref_d = frame_gen.camera_frame(31, 480, 640, holes=True)
+    now_bgr, now_d = frame_gen.camera_frame(31, 480, 640, shift=(2, -3), holes=True)
+    rp, nw = oracle.build_pyramid(ref_bgr, ref_d, 4, 0), oracle.build_pyramid(now_bgr, now_d, 4, 0)
+    levels = []
+    for l in range(4):
+        xyz, uv, _ = oracle.ref_level_from_grey(l, rp[l][0], rp[l][1], K)
+        dt, gx, gy, _ = oracle.now_level_from_grey(nw[l][0])
+        levels.append(dict(xyz=xyz, uv=uv, dt=dt, gx=gx, gy=gy, rows=rp[l][0].shape[0], cols=rp[l][0].shape[1]))
+    want = oracle.align_pyramid(iters, levels, K, np.eye(3), np.zeros(3))
+    with _ctx() as ctx:
+        ctx.set_intrinsics(*[float(k) for k in K])
+        ctx.frames_upload_cameras([ref_bgr, now_bgr], [ref_d, now_d], n_levels=4, first_shift=0)
+        ctx.frames_as_ref(0, 0, 1)
+        ctx.frames_as_now(1, 0, 1)
+        R, t = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
+        assert rot_angle(want["R"], R[0]) <= 1e-5 and np.linalg.norm(want["t"] - t[0]) <= 1e-4       # north_star tolerance
+        for l in range(4):
+            e, best, ratio = ctx.level_report(0, l, iters[l])
+            assert np.array_equal(e, want["levels"][l]["energy"]) and best == want["levels"][l]["best_idx"]
+        assert np.linalg.norm(t[0]) > 1e-4          # the shifted frame really moved the pose
+
+
+def test_batched_calls_equal_single_calls(oracle):
+    frames = [frame_gen.camera_frame(40 + i, 120, 160) for i in range(5)]
+    K = tuple(float(k) * 0.25 for k in K640)
+    with _ctx(5) as a, _ctx(1) as b:
+        a.set_intrinsics(*K); b.set_intrinsics(*K)
+        a.frames_reserve(8)
+        a.frames_upload_cameras([f[0] for f in frames], [f[1] for f in frames], n_levels=3, first_shift=0, first_slot=2)
+        Na = a.frames_as_ref(2, 0, 5)
+        a.frames_as_now(2, 0, 5)
+        for i, (bgr, d) in enumerate(frames):
+            b.frames_upload_cameras([bgr], [d], n_levels=3, first_shift=0)
+            Nb = b.frames_as_ref(0, 0, 1)
+            b.frames_as_now(0, 0, 1)
+            assert np.array_equal(Na[i], Nb[0])
+            for l in range(3):
+                for x, y in zip(a.frame_level(2 + i, l)[:3], b.frame_level(0, l)[:3]):
+                    assert np.array_equal(x, y)
+                for x, y in zip(a.get_now_level(l, pair=i), b.get_now_level(l)):
+                    assert np.array_equal(x, y)
+                ea, eb = a.eval_points(l, np.eye(3), np.zeros(3), pair=i), b.eval_points(l, np.eye(3), np.zeros(3))
+                assert np.array_equal(ea["reproj"], eb["reproj"]) and np.array_equal(ea["eps"], eb["eps"])
+
+
+def test_prev_now_frame_becomes_reference_without_upload(oracle):
+    """setPrevFrameAsRefFrame (SolveDVO.cpp:559-583): a stored frame serves as now frame, then as reference"""
+    K = tuple(float(k) * 0.5 for k in K640)
+    f0, f1 = frame_gen.camera_frame(50, 240, 320), frame_gen.camera_frame(50, 240, 320, shift=(1, 2))
+    with _ctx() as ctx:
+        ctx.set_intrinsics(*K)
+        ctx.frames_upload_cameras([f0[0], f1[0]], [f0[1], f1[1]], n_levels=3, first_shift=0)
+        ctx.frames_as_ref(0, 0, 1); ctx.frames_as_now(1, 0, 1)
+        R1, t1 = ctx.align_batch([8, 8, 8], np.eye(3)[None], np.zeros((1, 3)))
+        ctx.frames_as_ref(1, 0, 1); ctx.frames_as_now(0, 0, 1)           # roles swapped, nothing uploaded
+        R2, t2 = ctx.align_batch([8, 8, 8], np.eye(3)[None], np.zeros((1, 3)))
+        assert np.all(np.isfinite(t1)) and np.all(np.isfinite(t2))
+        assert np.dot(t1[0], t2[0]) < 0                                  # opposite motions
+
+
+def test_frame_api_errors():
+    from rgbd_odometry_amd.capi import DvoError
+    bgr, depth = frame_gen.camera_frame(1, 60, 80)
+    with _ctx() as ctx:
+        with pytest.raises(DvoError):
+            ctx.frames_as_now(0, 0, 1)                                   # empty store
+        ctx.frames_upload_cameras([bgr], None, n_levels=2, first_shift=0)
+        with pytest.raises(DvoError):
+            ctx.frames_as_ref(0, 0, 1)                                   # no intrinsics
+        ctx.set_intrinsics(60.0, 60.0, 40.0, 30.0)
+        with pytest.raises(DvoError):
+            ctx.frames_as_ref(0, 0, 1)                                   # no depth in that slot
+        with pytest.raises(DvoError):
+            ctx.frames_as_now(1, 0, 1)                                   # slot never filled
+        with pytest.raises(DvoError):
+            ctx.frames_upload_cameras([bgr], None, n_levels=2, first_shift=0, first_slot=10 ** 6)
+        flat = np.full((60, 80, 3), 77, np.uint8)
+        ctx.frames_upload_cameras([flat], [np.full((60, 80), 2.0, np.float32)], n_levels=2, first_shift=0)
+        with pytest.raises(DvoError):
+            ctx.frames_as_ref(0, 0, 1)                                   # no edge => no reference point (:282)
+        ctx.frames_as_now(0, 0, 1)                                       # an edge-free now frame is all zeros
+        dt, gx, gy = ctx.get_now_level(0)
+        assert not dt.any() and not gx.any() and not gy.any()
