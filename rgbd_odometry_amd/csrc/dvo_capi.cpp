@@ -43,7 +43,6 @@ struct FrameLevel {
     size_t npx = 0;
     unsigned char *grey = nullptr, *edge = nullptr;
     float *depth = nullptr;
-    int *n_edges = nullptr;         /* n_slots ints */
 };
 struct FrameStore {
     int n_slots = 0, n_levels = 0;
@@ -375,7 +374,7 @@ int dvo_destroy(dvo_ctx *c) {
     }
     for (int l = 0; l < DVO_LEVELS; l++) {
         FrameLevel &F = c->fs.lv[l];
-        void *fp[] = {F.grey, F.edge, F.depth, F.n_edges};
+        void *fp[] = {F.grey, F.edge, F.depth};
         for (void *p : fp) if (p) (void)hipFree(p);
     }
     if (c->work) (void)hipFree(c->work);
@@ -980,7 +979,7 @@ int frames_default_slots(const dvo_ctx *c) { return std::min(2 * c->n_pairs + 2,
 void frames_free(dvo_ctx *c) {
     for (int l = 0; l < DVO_LEVELS; l++) {
         FrameLevel &F = c->fs.lv[l];
-        void *fp[] = {F.grey, F.edge, F.depth, F.n_edges};
+        void *fp[] = {F.grey, F.edge, F.depth};
         for (void *p : fp) if (p) (void)hipFree(p);
         F = FrameLevel();
     }
@@ -1006,8 +1005,6 @@ int frames_geometry(dvo_ctx *c, int n_levels, const int *rows, const int *cols) 
         HIPCHK(c, hipMalloc((void **)&F.grey, F.npx * S.n_slots));
         HIPCHK(c, hipMalloc((void **)&F.edge, F.npx * S.n_slots));
         HIPCHK(c, hipMalloc((void **)&F.depth, sizeof(float) * F.npx * S.n_slots));
-        HIPCHK(c, hipMalloc((void **)&F.n_edges, sizeof(int) * S.n_slots));
-        HIPCHK(c, hipMemsetAsync(F.n_edges, 0, sizeof(int) * S.n_slots, c->stream));
     }
     S.n_levels = n_levels;
     return DVO_OK;
@@ -1034,7 +1031,7 @@ int run_canny(dvo_ctx *c, int level, int first_slot, int count) {
         const int nc = std::min(chunk, count - b);
         const size_t off = (size_t)(first_slot + b) * F.npx;
         HIPCHK(c, launch_canny(F.grey + off, F.npx, ImgBatch{F.rows, F.cols, nc}, low, high, c->work,
-                               F.edge + off, F.npx, F.n_edges + first_slot + b, c->stream));
+                               F.edge + off, F.npx, c->stream));
     }
     return DVO_OK;
 }
@@ -1242,7 +1239,12 @@ int dvo_frame_get_level(dvo_ctx *c, int slot, int level, int *rows, int *cols, u
         if (!c->fs.has_depth[slot]) return fail(c, DVO_ERR_STATE, "frame slot has no depth");
         HIPCHK(c, hipMemcpyAsync(depth_mm, F.depth + off, sizeof(float) * F.npx, hipMemcpyDeviceToHost, c->stream));
     }
-    if (n_edges) HIPCHK(c, hipMemcpyAsync(n_edges, F.n_edges + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (n_edges) {
+        int rc = ensure_work(c, sizeof(int));
+        if (rc) return rc;
+        HIPCHK(c, launch_count_edges(F.edge + off, F.npx, c->work, c->stream));
+        HIPCHK(c, hipMemcpyAsync(n_edges, c->work, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return DVO_OK;
 }

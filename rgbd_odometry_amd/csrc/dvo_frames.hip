@@ -25,6 +25,18 @@ namespace dvo {
 namespace {
 
 DVO_DEV float pow2_neg_f(int level) { return __int_as_float((127 - level) << 23); }
+/* one value per 256-thread block: wave shuffle, then the four wave results through LDS; valid in thread 0 */
+template <bool MAX>
+DVO_DEV int block_reduce_256(int v) {
+    __shared__ int part[4];
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_down(v, off, 64); v = MAX ? (o > v ? o : v) : v + o; }
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) v = MAX ? (part[k] > v ? part[k] : v) : v + part[k];
+    }
+    return v;
+}
 inline unsigned grid_x(size_t n, unsigned cap = 2048) {
     size_t b = (n + 255) / 256;
     if (b < 1) b = 1;
@@ -256,36 +268,44 @@ canny_flag_kernel(const unsigned char *__restrict__ cand, size_t n, int *__restr
 
 __global__ void __launch_bounds__(256)
 canny_final_kernel(const unsigned char *__restrict__ cand, const int *__restrict__ label, const unsigned char *__restrict__ flag,
-                   size_t n, unsigned char *__restrict__ edge, size_t edge_stride, int *__restrict__ n_edges) {
+                   size_t n, unsigned char *__restrict__ edge, size_t edge_stride) {
     cand += (size_t)blockIdx.y * n; label += (size_t)blockIdx.y * n; flag += (size_t)blockIdx.y * n;
     edge += (size_t)blockIdx.y * edge_stride;
-    int cnt = 0;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
         bool e = false;
         if (cand[p]) e = flag[uf_find(label, (int)p)] != 0;
         edge[p] = e ? 255 : 0;
-        cnt += e ? 1 : 0;
     }
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(n_edges + blockIdx.y, cnt);
+}
+
+/* number of edge pixels of one image (inspection only: kept out of the per-frame pipeline, thousands of
+ * blocks adding into a handful of adjacent counters serialise in one L2 channel) */
+__global__ void __launch_bounds__(256)
+count_edges_kernel(const unsigned char *__restrict__ edge, size_t n, int *__restrict__ out) {
+    int cnt = 0;
+    for (size_t p = threadIdx.x; p < n; p += blockDim.x) cnt += edge[p] ? 1 : 0;
+    cnt = block_reduce_256<false>(cnt);
+    if (threadIdx.x == 0) *out = cnt;
+}
+hipError_t launch_count_edges(const unsigned char *edge, size_t n, int *out, hipStream_t s) {
+    hipLaunchKernelGGL(count_edges_kernel, dim3(1), dim3(256), 0, s, edge, n, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_canny(const unsigned char *grey, size_t stride, ImgBatch g, int low, int high, int *work,
-                        unsigned char *edge, size_t edge_stride, int *n_edges, hipStream_t s) {
+                        unsigned char *edge, size_t edge_stride, hipStream_t s) {
     const size_t n = (size_t)g.rows * g.cols, nb = n * g.count;
     int *mag = work;
     short2 *dxdy = reinterpret_cast<short2 *>(work + nb);
     int *label = work + 2 * nb;
     unsigned char *cand = reinterpret_cast<unsigned char *>(work + 3 * nb);
     unsigned char *flag = cand + ((nb + 3) / 4) * 4;
-    hipError_t e = hipMemsetAsync(n_edges, 0, sizeof(int) * g.count, s);
-    if (e != hipSuccess) return e;
     const dim3 grid(grid_x(n), g.count), blk(256);
     hipLaunchKernelGGL(canny_sobel_kernel, grid, blk, 0, s, grey, stride, g.rows, g.cols, mag, dxdy);
     hipLaunchKernelGGL(canny_nms_kernel, grid, blk, 0, s, mag, dxdy, g.rows, g.cols, low, high, cand, flag, label);
     hipLaunchKernelGGL(canny_merge_kernel, grid, blk, 0, s, cand, g.rows, g.cols, label);
     hipLaunchKernelGGL(canny_flag_kernel, grid, blk, 0, s, cand, n, label, flag);
-    hipLaunchKernelGGL(canny_final_kernel, grid, blk, 0, s, cand, label, flag, n, edge, edge_stride, n_edges);
+    hipLaunchKernelGGL(canny_final_kernel, grid, blk, 0, s, cand, label, flag, n, edge, edge_stride);
     return hipGetLastError();
 }
 
@@ -342,18 +362,52 @@ edt_columns_kernel(const unsigned char *__restrict__ edge, size_t edge_stride, i
     }
 }
 
-/* phase 2: d2(x,y) = min_i (x-i)^2 + g(i,y)^2 along the row, exactly, in integers.  One thread per pixel
- * scans outwards while i^2 < best: with edges every few pixels that is a few dozen coalesced loads, far
- * cheaper on a GPU than the sequential lower-envelope scan (Meijster) a CPU would use -- same minimum. */
+/* phase 2: d2(x,y) = min_i (x-i)^2 + g(i,y)^2 along the row, exactly, in integers.  Each pixel scans outwards
+ * while i^2 < best: with edges every few pixels that is a few dozen steps, far cheaper on a GPU than the sequential
+ * lower-envelope scan (Meijster) a CPU would use -- same minimum.  A workgroup stages R whole rows of g in LDS
+ * (16-bit: g <= rows+cols+1) so that the scan runs out of LDS, not L2; per-block maxima go to `partial`. */
+template <int R>
 __global__ void __launch_bounds__(256)
-edt_rows_kernel(const int *__restrict__ g, int rows, int cols, int *__restrict__ d2, int *__restrict__ max_d2) {
+edt_rows_lds_kernel(const int *__restrict__ g, int rows, int cols, int *__restrict__ d2, int *__restrict__ partial) {
+    extern __shared__ unsigned short tile[];                  /* [cols][R] */
+    const size_t n = (size_t)rows * cols;
+    g += (size_t)blockIdx.y * n; d2 += (size_t)blockIdx.y * n;
+    const int y0 = blockIdx.x * R;
+    const int total = cols * R;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        const int xx = idx / R, r = idx - xx * R, yy = y0 + r;
+        tile[idx] = (unsigned short)((yy < rows) ? g[(size_t)xx * rows + yy] : 0);
+    }
+    __syncthreads();
+    int mx = 0;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        const int xx = idx / R, r = idx - xx * R, yy = y0 + r;
+        if (yy >= rows) continue;
+        const int g0 = tile[idx];
+        int best = g0 * g0;                                   /* (rows+cols+1)^2 < 2^31 for every supported size */
+        for (int i = 1; i * i < best; i++) {
+            const bool l = xx - i >= 0, rr = xx + i < cols;
+            if (!l && !rr) break;
+            if (l) { const int gl = tile[idx - i * R]; const int c = i * i + gl * gl; best = c < best ? c : best; }
+            if (rr) { const int gr = tile[idx + i * R]; const int c = i * i + gr * gr; best = c < best ? c : best; }
+        }
+        d2[(size_t)xx * rows + yy] = best;
+        mx = best > mx ? best : mx;
+    }
+    mx = block_reduce_256<true>(mx);
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = mx;
+}
+
+/* fallback for rows too long for LDS: the same scan out of global memory */
+__global__ void __launch_bounds__(256)
+edt_rows_kernel(const int *__restrict__ g, int rows, int cols, int *__restrict__ d2, int *__restrict__ partial) {
     const size_t n = (size_t)rows * cols;
     g += (size_t)blockIdx.y * n; d2 += (size_t)blockIdx.y * n;
     int mx = 0;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
         const int xx = (int)(idx / rows);
         const int g0 = g[idx];
-        int best = g0 * g0;                                   /* (rows+cols+1)^2 < 2^31 for every supported size */
+        int best = g0 * g0;
         for (int i = 1; i * i < best; i++) {
             const bool l = xx - i >= 0, r = xx + i < cols;
             if (!l && !r) break;
@@ -363,18 +417,25 @@ edt_rows_kernel(const int *__restrict__ g, int rows, int cols, int *__restrict__
         d2[idx] = best;
         mx = best > mx ? best : mx;
     }
-    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_down(mx, off, 64); mx = o > mx ? o : mx; }
-    if ((threadIdx.x & 63) == 0) atomicMax(max_d2 + blockIdx.y, mx);
+    mx = block_reduce_256<true>(mx);
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = mx;
 }
 
 /* raw distance -> normalised [0,255] float, in place (the int buffer is reused as float).  An image without any
  * edge pixel (every distance "infinite") normalises to all zeros, as cv::normalize does for a constant image. */
 __global__ void __launch_bounds__(256)
-dt_normalize_kernel(int *__restrict__ d2_inout, int rows, int cols, const int *__restrict__ max_d2) {
+dt_normalize_kernel(int *__restrict__ d2_inout, int rows, int cols, const int *__restrict__ partial, int n_partial) {
     const size_t n = (size_t)rows * cols;
     d2_inout += (size_t)blockIdx.y * n;
+    partial += (size_t)blockIdx.y * n_partial;
+    __shared__ int s_max;
+    int m = 0;
+    for (int k = threadIdx.x; k < n_partial; k += 256) { const int v = partial[k]; m = v > m ? v : m; }
+    m = block_reduce_256<true>(m);
+    if (threadIdx.x == 0) s_max = m;
+    __syncthreads();
     const int INF = DVO_EDT_INF(rows, cols);
-    const int m2 = max_d2[blockIdx.y];
+    const int m2 = s_max;
     const float mxf = (float)sqrt((double)m2), mnf = 0.0f;
     const double scale = (mxf > mnf && m2 < INF * INF) ? 255.0 / ((double)mxf - (double)mnf) : 0.0;   /* cv::normalize NORM_MINMAX, :1774 */
     float *out = reinterpret_cast<float *>(d2_inout);
@@ -401,18 +462,33 @@ dt_gradient_pack_kernel(const float *__restrict__ dt, int rows, int cols, float4
     }
 }
 
-size_t edt_work_ints(int rows, int cols, int count) { return (2 * (size_t)rows * cols + 1) * count; }
+static int edt_rows_per_block(int rows, int cols) {   /* LDS rows per workgroup; 0 = row too long, use the global-memory scan */
+    if (rows + cols + 1 > 65535) return 0;            /* g would not fit 16 bits */
+    if ((size_t)cols * 16 * 2 <= 64 * 1024) return 16;
+    if ((size_t)cols * 8 * 2 <= 64 * 1024) return 8;
+    if ((size_t)cols * 4 * 2 <= 64 * 1024) return 4;
+    return 0;
+}
+static unsigned edt_row_blocks(int rows, int cols) {
+    const int R = edt_rows_per_block(rows, cols);
+    return R ? (unsigned)((rows + R - 1) / R) : grid_x((size_t)rows * cols);
+}
+size_t edt_work_ints(int rows, int cols, int count) { return (2 * (size_t)rows * cols + edt_row_blocks(rows, cols)) * count; }
 
 hipError_t launch_edges_to_texels(const unsigned char *edge, size_t edge_stride, ImgBatch gb, int *work,
                                   float4 *tex_out, size_t tex_stride, hipStream_t s) {
     const size_t n = (size_t)gb.rows * gb.cols, nb = n * gb.count;
-    int *g = work, *d2 = work + nb, *max_d2 = work + 2 * nb;
-    hipError_t e = hipMemsetAsync(max_d2, 0, sizeof(int) * gb.count, s);
-    if (e != hipSuccess) return e;
+    int *g = work, *d2 = work + nb, *partial = work + 2 * nb;
     const dim3 grid(grid_x(n), gb.count);
+    const int R = edt_rows_per_block(gb.rows, gb.cols);
+    const unsigned nblk = edt_row_blocks(gb.rows, gb.cols);
     hipLaunchKernelGGL(edt_columns_kernel, dim3(gb.cols, gb.count), dim3(64), 0, s, edge, edge_stride, gb.rows, gb.cols, g);
-    hipLaunchKernelGGL(edt_rows_kernel, grid, dim3(256), 0, s, g, gb.rows, gb.cols, d2, max_d2);
-    hipLaunchKernelGGL(dt_normalize_kernel, grid, dim3(256), 0, s, d2, gb.rows, gb.cols, max_d2);
+    const size_t lds = (size_t)gb.cols * R * 2;
+    if (R == 16) hipLaunchKernelGGL(edt_rows_lds_kernel<16>, dim3(nblk, gb.count), dim3(256), lds, s, g, gb.rows, gb.cols, d2, partial);
+    else if (R == 8) hipLaunchKernelGGL(edt_rows_lds_kernel<8>, dim3(nblk, gb.count), dim3(256), lds, s, g, gb.rows, gb.cols, d2, partial);
+    else if (R == 4) hipLaunchKernelGGL(edt_rows_lds_kernel<4>, dim3(nblk, gb.count), dim3(256), lds, s, g, gb.rows, gb.cols, d2, partial);
+    else hipLaunchKernelGGL(edt_rows_kernel, grid, dim3(256), 0, s, g, gb.rows, gb.cols, d2, partial);
+    hipLaunchKernelGGL(dt_normalize_kernel, grid, dim3(256), 0, s, d2, gb.rows, gb.cols, partial, (int)nblk);
     hipLaunchKernelGGL(dt_gradient_pack_kernel, grid, dim3(256), 0, s,
                        reinterpret_cast<const float *>(d2), gb.rows, gb.cols, tex_out, tex_stride);
     return hipGetLastError();

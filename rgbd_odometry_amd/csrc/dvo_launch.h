@@ -106,10 +106,11 @@ hipError_t launch_camera_level(const unsigned char *bgr, size_t bgr_stride, cons
                                int src_rows, int src_cols, int shift, unsigned char *grey, float *depth_mm,
                                size_t stride, ImgBatch g, hipStream_t s);
 /* row f1: cv::Canny(grey, low/high as squared integer thresholds, 3, L2).  work: canny_work_ints() ints;
- * edge out: 0/255 u8; n_edges[count] */
+ * edge out: 0/255 u8 */
 size_t canny_work_ints(int rows, int cols, int count);
 hipError_t launch_canny(const unsigned char *grey, size_t stride, ImgBatch g, int low, int high, int *work,
-                        unsigned char *edge, size_t edge_stride, int *n_edges, hipStream_t s);
+                        unsigned char *edge, size_t edge_stride, hipStream_t s);
+hipError_t launch_count_edges(const unsigned char *edge, size_t n, int *out, hipStream_t s);
 void canny_work_views(int *work, int rows, int cols, int count, const int **mag, const unsigned char **cand);
 /* edge mask -> distance transform -> normalise -> gradients -> texels (SolveDVO.cpp:1768-1795, :1063-1098).
  * work: edt_work_ints() ints */

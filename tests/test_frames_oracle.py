@@ -1,0 +1,100 @@
+"""Rows f1/f2, CPU side: the oracle restatement of the OpenCV-2.4 steps (oracle/dvo_oracle_frames.cpp) against its
+committed golden vectors and against the properties the definitions imply.  GPU: the HIP path reproduces the vectors."""
+import os
+
+import numpy as np
+import pytest
+
+import frame_gen
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frames_golden.npz")
+
+
+def _mg():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_frames_golden", os.path.join(os.path.dirname(GOLDEN), "make_frames_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(GOLDEN)
+
+
+def test_frame_generator_and_oracle_reproduce_golden(golden, oracle):
+    fresh = _mg().build()
+    assert set(fresh) == set(golden.files)
+    for k in golden.files:
+        assert np.array_equal(golden[k], fresh[k], equal_nan=True), k
+
+
+def test_sobel_is_the_3x3_operator_with_replicated_border(oracle):
+    rng = np.random.default_rng(0)
+    g = rng.integers(0, 256, (19, 23)).astype(np.uint8)
+    dx, dy = oracle.sobel3(g)
+    p = np.pad(g.astype(np.int32), 1, mode="edge")
+    kx = np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]])
+    ex = sum(kx[i, j] * p[i:i + 19, j:j + 23] for i in range(3) for j in range(3))
+    ey = sum(kx.T[i, j] * p[i:i + 19, j:j + 23] for i in range(3) for j in range(3))
+    assert np.array_equal(dx, ex) and np.array_equal(dy, ey)
+
+
+def test_canny_structure(oracle):
+    """edges = candidates 8-connected to a strong candidate; candidates = (mag > low^2) local maxima"""
+    from scipy import ndimage
+    g = oracle.bgr2gray(frame_gen.camera_frame(2, 120, 160)[0])
+    edge, mag, cand = oracle.canny(g, stages=True)
+    assert set(np.unique(edge)) <= {0, 255}
+    assert np.all(cand[edge > 0] > 0)                                   # edges are candidates
+    assert np.all(edge[cand == 2] == 255)                               # every strong candidate is an edge
+    assert np.all(mag[cand > 0] > 100 * 100) and np.all(mag[cand == 2] > 150 * 150)
+    lab, n = ndimage.label(cand > 0, structure=np.ones((3, 3)))
+    strong = np.zeros(n + 1, bool)
+    strong[np.unique(lab[cand == 2])] = True
+    assert np.array_equal(edge > 0, strong[lab] & (cand > 0))           # hysteresis == connected components
+    assert 0.005 < (edge > 0).mean() < 0.25
+
+
+def test_canny_threshold_order_is_irrelevant_and_flat_image_has_no_edges(oracle):
+    g = oracle.bgr2gray(frame_gen.camera_frame(4, 60, 80)[0])
+    assert np.array_equal(oracle.canny(g, 150, 100), oracle.canny(g, 100, 150))
+    assert not oracle.canny(np.full((20, 30), 200, np.uint8)).any()
+    g2 = np.zeros((48, 64), np.uint8); g2[:, 32:] = 200
+    e = oracle.canny(g2)
+    assert np.array_equal(np.unique(np.nonzero(e)[1]), [31])            # ties: "> left, >= right" keeps the left pixel
+
+
+def test_bgr2gray_resize_depth_definitions(oracle):
+    rng = np.random.default_rng(1)
+    bgr = rng.integers(0, 256, (31, 45, 3)).astype(np.uint8)
+    b64 = bgr.astype(np.int64)
+    want = (1868 * b64[..., 0] + 9617 * b64[..., 1] + 4899 * b64[..., 2] + 8192) >> 14
+    assert np.array_equal(oracle.bgr2gray(bgr), want)
+    assert np.array_equal(oracle.bgr2gray(np.full((2, 2, 3), 255, np.uint8)), np.full((2, 2), 255))
+    half = oracle.resize_nn(bgr, 0.5)
+    assert half.shape == (16, 22, 3)                                    # cvRound(15.5) = 16, cvRound(22.5) = 22
+    assert np.array_equal(half, bgr[np.minimum(np.arange(16) * 2, 30)][:, np.minimum(np.arange(22) * 2, 44)])
+    d = np.array([0.0, 1.2345, np.nan, 70.0, -1.0, 0.0004, np.inf, 0.0005, 0.0015, 0.0025, 65.5354], np.float32)
+    assert np.array_equal(oracle.depth_m_to_mm16(d), [1, 1234, 1, 65535, 1, 1, 1, 1, 2, 2, 65535])
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_frames_golden(golden):
+    from rgbd_odometry_amd import DvoContext
+    mg = _mg()
+    for name, seed, rows, cols, nl, fs in mg.CASES:
+        with DvoContext(1) as ctx:
+            ctx.set_intrinsics(*mg.K)
+            ctx.frames_upload_cameras([golden[f"{name}_bgr"]], [golden[f"{name}_depth_m"]], n_levels=nl, first_shift=fs)
+            ctx.frames_as_ref(0, 0, 1)
+            ctx.frames_as_now(0, 0, 1)
+            for l in range(nl):
+                grey, depth, edge, ne = ctx.frame_level(0, l)
+                assert np.array_equal(grey, golden[f"{name}_L{l}_grey"])
+                assert np.array_equal(depth, golden[f"{name}_L{l}_depth16"].astype(np.float32))
+                assert np.array_equal(edge, golden[f"{name}_L{l}_edge"])
+                for got, key in zip(ctx.get_now_level(l), ("dt", "gx", "gy")):
+                    assert np.array_equal(got, golden[f"{name}_L{l}_{key}"]), (name, l, key)
+                assert np.array_equal(ctx.get_ref_level(l), golden[f"{name}_L{l}_xyz"])

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Rows f1+f2 measured: camera frames (BGR8 + depth in metres, host memory) -> resident now / reference levels,
+batched, and the end-to-end rate frames-in -> poses-out.  Not the headline bench (bench.py); DESIGN.md quotes it.
+
+    python tools/bench_frames.py [--batch 256] [--width 640 --height 480] [--levels 4] [--first-shift 0] [--pinned]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--first-shift", type=int, default=0)
+    ap.add_argument("--distinct", type=int, default=8)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--pinned", action="store_true", help="frames live in pinned host memory (torch pin_memory)")
+    args = ap.parse_args()
+    import frame_gen
+    from rgbd_odometry_amd import DvoContext
+    from rgbd_odometry_amd.capi import DVO_FLAG_IDENTITY_START, DVO_UPLOAD_ASYNC
+
+    B, D = args.batch, min(args.distinct, args.batch)
+    ref = [frame_gen.camera_frame(100 + i, args.height, args.width) for i in range(D)]
+    now = [frame_gen.camera_frame(100 + i, args.height, args.width, shift=(1 + i % 2, -2)) for i in range(D)]
+
+    def hold(a):
+        if not args.pinned:
+            return a
+        t = torch.empty(a.shape, dtype=torch.from_numpy(a).dtype, pin_memory=True)
+        t.numpy()[...] = a
+        return t.numpy()
+    ref = [(hold(b), hold(d)) for b, d in ref]
+    now = [(hold(b), hold(d)) for b, d in now]
+    ref_b, ref_d = [ref[i % D][0] for i in range(B)], [ref[i % D][1] for i in range(B)]
+    now_b = [now[i % D][0] for i in range(B)]
+
+    ctx = DvoContext(B)
+    s = 2.0 ** (-args.first_shift) * args.width / 640.0
+    ctx.set_intrinsics(525.0 * s, 525.0 * s, 319.5 * s, 239.5 * s * args.height / 480.0 * 640.0 / args.width)
+    ctx.frames_reserve(2 * B)
+    iters = [args.iters] * args.levels
+    res = {}
+
+    def timed(name, fn, units):
+        fn(); ctx.synchronize()                       # warm-up (allocations)
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            fn()
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / args.reps
+        res[name] = dict(ms=1e3 * dt, per_s=units / dt)
+
+    kw = dict(n_levels=args.levels, first_shift=args.first_shift, flags=DVO_UPLOAD_ASYNC)
+    timed("upload_ref_frames(bgr+depth: H2D, pyramid, Canny)", lambda: ctx.frames_upload_cameras(ref_b, ref_d, first_slot=0, **kw), B)
+    timed("upload_now_frames(bgr only: H2D, pyramid, Canny)", lambda: ctx.frames_upload_cameras(now_b, None, first_slot=B, **kw), B)
+    timed("frames_as_ref(selectedPts+enlistRefEdgePts)", lambda: ctx.frames_as_ref(0, 0, B), B)
+    timed("frames_as_now(EDT+normalise+gradients+texels)", lambda: ctx.frames_as_now(B, 0, B), B)
+    timed("align(%s)" % iters, lambda: ctx.enqueue(iters, flags=DVO_FLAG_IDENTITY_START), B)
+
+    def tracking_step():                              # every pair gets a fresh now frame against its resident reference
+        ctx.frames_upload_cameras(now_b, None, first_slot=B, **kw)
+        ctx.frames_as_now(B, 0, B)
+        ctx.enqueue(iters, flags=DVO_FLAG_IDENTITY_START)
+        return ctx.get_poses()
+    timed("now frame in -> pose out (reference resident)", tracking_step, B)
+
+    def pair_step():                                  # both frames of every pair from the host
+        ctx.frames_upload_cameras(ref_b, ref_d, first_slot=0, **kw)
+        ctx.frames_upload_cameras(now_b, None, first_slot=B, **kw)
+        ctx.frames_as_ref(0, 0, B)
+        ctx.frames_as_now(B, 0, B)
+        ctx.enqueue(iters, flags=DVO_FLAG_IDENTITY_START)
+        return ctx.get_poses()
+    timed("frame pair in -> pose out", pair_step, B)
+    R, t = tracking_step()
+    out = dict(config=dict(batch=B, width=args.width, height=args.height, levels=args.levels, first_shift=args.first_shift,
+                           pinned=args.pinned, host_bytes_per_ref_frame=args.width * args.height * 7,
+                           host_bytes_per_now_frame=args.width * args.height * 3),
+               stages=res, mean_translation_m=float(np.linalg.norm(t, axis=1).mean()))
+    print(json.dumps(out))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
