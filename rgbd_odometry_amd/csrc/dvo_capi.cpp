@@ -81,6 +81,13 @@ struct dvo_ctx {
     FrameStore fs;
     int *work = nullptr;            /* preprocessing scratch (Canny / distance transform / point counts) */
     size_t work_bytes = 0;
+    /* frame uploads: two landing buffers filled by a copy stream while the context stream preprocesses the other */
+    unsigned char *up_buf[2] = {nullptr, nullptr};
+    size_t up_bytes = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    bool up_used[2] = {false, false};
+    int up_next = 0;
     Schedule sched{};
     bool have_sched = false;
     std::string err;
@@ -378,6 +385,12 @@ int dvo_destroy(dvo_ctx *c) {
         for (void *p : fp) if (p) (void)hipFree(p);
     }
     if (c->work) (void)hipFree(c->work);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    for (int b = 0; b < 2; b++) {
+        if (c->up_buf[b]) (void)hipFree(c->up_buf[b]);
+        if (c->ev_copied[b]) (void)hipEventDestroy(c->ev_copied[b]);
+        if (c->ev_done[b]) (void)hipEventDestroy(c->ev_done[b]);
+    }
     void *ptrs[] = {c->staging, c->d_poses, c->d_energy, c->d_best, c->d_ratio, c->d_final_eps,
                     c->d_final_reproj, c->d_final_N, c->d_scratch, c->d_colcounts, c->d_dbg,
                     c->d_states, c->d_iter_energy};
@@ -1036,6 +1049,50 @@ int run_canny(dvo_ctx *c, int level, int first_slot, int count) {
     return DVO_OK;
 }
 
+constexpr size_t kUploadHalf = (size_t)64 << 20;   /* landing buffer per pipeline stage */
+
+/* landing buffers of at least `bytes` each + copy stream + events */
+int ensure_upload(dvo_ctx *c, size_t bytes) {
+    if (!c->copy_stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; b++) {
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_copied[b], hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_done[b], hipEventDisableTiming));
+        }
+    }
+    if (bytes <= c->up_bytes) return DVO_OK;
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int b = 0; b < 2; b++) {
+        if (c->up_buf[b]) HIPCHK(c, hipFree(c->up_buf[b]));
+        c->up_buf[b] = nullptr;
+        HIPCHK(c, hipMalloc((void **)&c->up_buf[b], bytes));
+        c->up_used[b] = false;
+    }
+    c->up_bytes = bytes;
+    return DVO_OK;
+}
+/* stage A of a chunk: returns the landing buffer; copies must go to c->copy_stream */
+int upload_begin(dvo_ctx *c, unsigned char **buf, int *slot) {
+    const int b = c->up_next;
+    if (c->up_used[b]) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_done[b], 0));    /* its previous consumer finished */
+    *buf = c->up_buf[b]; *slot = b;
+    return DVO_OK;
+}
+/* stage B: everything enqueued on c->stream after this sees the copies */
+int upload_copied(dvo_ctx *c, int b) {
+    HIPCHK(c, hipEventRecord(c->ev_copied[b], c->copy_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copied[b], 0));
+    return DVO_OK;
+}
+/* stage C: the kernels reading the landing buffer are enqueued */
+int upload_consumed(dvo_ctx *c, int b) {
+    HIPCHK(c, hipEventRecord(c->ev_done[b], c->stream));
+    c->up_used[b] = true;
+    c->up_next = b ^ 1;
+    return DVO_OK;
+}
+
 size_t pix_bytes(int dtype) { return dtype == DVO_PIX_U8 ? 1 : (dtype == DVO_PIX_U16 ? 2 : 4); }
 
 }  // namespace
@@ -1075,31 +1132,46 @@ int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_leve
     int rc = frames_geometry(c, n_levels, rows, cols);
     if (rc) return rc;
     if (!slots_ok(c, first_slot, count)) return fail(c, DVO_ERR_INVALID, "frame slot range out of bounds (dvo_frames_reserve)");
+    /* chunks of frames flow through copy (copy stream) -> import + Canny (context stream), double-buffered */
+    size_t g_img[DVO_LEVELS], d_img[DVO_LEVELS], g_off[DVO_LEVELS], d_off[DVO_LEVELS], frame_bytes = 0;
     for (int l = 0; l < n_levels; l++) {
-        FrameLevel &F = c->fs.lv[l];
-        const size_t gb = pix_bytes(grey[l].dtype), db = depth ? pix_bytes(depth[l].dtype) : 0;
-        const size_t g_img = (F.npx * gb + 15) / 16 * 16, d_img = (F.npx * db + 15) / 16 * 16;   /* 16-byte aligned images */
-        const int chunk = chunk_for(g_img + d_img, count);
-        if ((rc = ensure_staging(c, (g_img + d_img) * chunk))) return rc;
-        unsigned char *sg = (unsigned char *)c->staging, *sd = sg + g_img * chunk;
-        for (int b = 0; b < count; b += chunk) {
-            const int nc = std::min(chunk, count - b);
+        const size_t npx = c->fs.lv[l].npx;
+        g_img[l] = (npx * pix_bytes(grey[l].dtype) + 15) / 16 * 16;           /* 16-byte aligned images */
+        d_img[l] = depth ? (npx * pix_bytes(depth[l].dtype) + 15) / 16 * 16 : 0;
+        frame_bytes += g_img[l] + d_img[l];
+    }
+    const int chunk = (int)std::min<size_t>(std::max<size_t>(kUploadHalf / frame_bytes, 1), (size_t)count);
+    if ((rc = ensure_upload(c, frame_bytes * chunk))) return rc;
+    {   size_t o = 0;                                   /* landing layout: per level, `chunk` grey images then `chunk` depth images */
+        for (int l = 0; l < n_levels; l++) { g_off[l] = o; o += g_img[l] * chunk; d_off[l] = o; o += d_img[l] * chunk; }
+    }
+    for (int b = 0; b < count; b += chunk) {
+        const int nc = std::min(chunk, count - b);
+        unsigned char *buf; int ub;
+        if ((rc = upload_begin(c, &buf, &ub))) return rc;
+        for (int l = 0; l < n_levels; l++) {
+            const size_t npx = c->fs.lv[l].npx, gb = pix_bytes(grey[l].dtype), db = depth ? pix_bytes(depth[l].dtype) : 0;
             for (int i = 0; i < nc; i++) {
-                HIPCHK(c, hipMemcpyAsync(sg + g_img * i, grey[(size_t)(b + i) * n_levels + l].data, F.npx * gb,
-                                         hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync(buf + g_off[l] + g_img[l] * i, grey[(size_t)(b + i) * n_levels + l].data, npx * gb,
+                                         hipMemcpyHostToDevice, c->copy_stream));
                 if (depth)
-                    HIPCHK(c, hipMemcpyAsync(sd + d_img * i, depth[(size_t)(b + i) * n_levels + l].data, F.npx * db,
-                                             hipMemcpyHostToDevice, c->stream));
+                    HIPCHK(c, hipMemcpyAsync(buf + d_off[l] + d_img[l] * i, depth[(size_t)(b + i) * n_levels + l].data, npx * db,
+                                             hipMemcpyHostToDevice, c->copy_stream));
             }
+        }
+        if ((rc = upload_copied(c, ub))) return rc;
+        for (int l = 0; l < n_levels; l++) {
+            FrameLevel &F = c->fs.lv[l];
             const size_t off = (size_t)(first_slot + b) * F.npx;
             const ImgBatch ib{F.rows, F.cols, nc};
-            HIPCHK(c, launch_import_grey(sg, grey[l].dtype, grey[l].layout == DVO_LAYOUT_ROW_MAJOR, g_img / gb,
-                                         F.grey + off, F.npx, ib, c->stream));
+            HIPCHK(c, launch_import_grey(buf + g_off[l], grey[l].dtype, grey[l].layout == DVO_LAYOUT_ROW_MAJOR,
+                                         g_img[l] / pix_bytes(grey[l].dtype), F.grey + off, F.npx, ib, c->stream));
             if (depth)
-                HIPCHK(c, launch_import_depth(sd, depth[l].dtype, depth[l].layout == DVO_LAYOUT_ROW_MAJOR, d_img / db,
-                                              F.depth + off, F.npx, ib, c->stream));
+                HIPCHK(c, launch_import_depth(buf + d_off[l], depth[l].dtype, depth[l].layout == DVO_LAYOUT_ROW_MAJOR,
+                                              d_img[l] / pix_bytes(depth[l].dtype), F.depth + off, F.npx, ib, c->stream));
         }
-        if ((rc = run_canny(c, l, first_slot, count))) return rc;
+        if ((rc = upload_consumed(c, ub))) return rc;
+        for (int l = 0; l < n_levels; l++) if ((rc = run_canny(c, l, first_slot + b, nc))) return rc;
     }
     for (int f = 0; f < count; f++) { c->fs.valid[first_slot + f] = 1; c->fs.has_depth[first_slot + f] = depth ? 1 : 0; }
     if (!(flags & DVO_UPLOAD_ASYNC)) HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1125,24 +1197,27 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
     if (!slots_ok(c, first_slot, count)) return fail(c, DVO_ERR_INVALID, "frame slot range out of bounds (dvo_frames_reserve)");
     const size_t npx = (size_t)rows * cols;
     const size_t b_img = (npx * 3 + 15) / 16 * 16, d_img = depth_m ? npx * 4 : 0;
-    const int chunk = chunk_for(b_img + d_img, count);
-    if ((rc = ensure_staging(c, (b_img + d_img) * chunk))) return rc;
-    unsigned char *sb = (unsigned char *)c->staging;
-    float *sd = (float *)(sb + b_img * chunk);
-    for (int b = 0; b < count; b += chunk) {
+    const int chunk = (int)std::min<size_t>(std::max<size_t>(kUploadHalf / (b_img + d_img), 1), (size_t)count);
+    if ((rc = ensure_upload(c, (b_img + d_img) * chunk))) return rc;
+    for (int b = 0; b < count; b += chunk) {            /* copy chunk k+1 (copy stream) while chunk k is preprocessed */
         const int nc = std::min(chunk, count - b);
+        unsigned char *sb; int ub;
+        if ((rc = upload_begin(c, &sb, &ub))) return rc;
+        float *sd = (float *)(sb + b_img * chunk);
         for (int i = 0; i < nc; i++) {
-            HIPCHK(c, hipMemcpyAsync(sb + b_img * i, bgr8[b + i], npx * 3, hipMemcpyHostToDevice, c->stream));
-            if (depth_m) HIPCHK(c, hipMemcpyAsync(sd + npx * i, depth_m[b + i], npx * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(sb + b_img * i, bgr8[b + i], npx * 3, hipMemcpyHostToDevice, c->copy_stream));
+            if (depth_m) HIPCHK(c, hipMemcpyAsync(sd + npx * i, depth_m[b + i], npx * 4, hipMemcpyHostToDevice, c->copy_stream));
         }
+        if ((rc = upload_copied(c, ub))) return rc;
         for (int l = 0; l < n_levels; l++) {
             FrameLevel &F = c->fs.lv[l];
             const size_t off = (size_t)(first_slot + b) * F.npx;
             HIPCHK(c, launch_camera_level(sb, b_img, depth_m ? sd : nullptr, npx, rows, cols, first_shift + l,
                                           F.grey + off, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, nc}, c->stream));
         }
+        if ((rc = upload_consumed(c, ub))) return rc;
+        for (int l = 0; l < n_levels; l++) if ((rc = run_canny(c, l, first_slot + b, nc))) return rc;
     }
-    for (int l = 0; l < n_levels; l++) if ((rc = run_canny(c, l, first_slot, count))) return rc;
     for (int f = 0; f < count; f++) { c->fs.valid[first_slot + f] = 1; c->fs.has_depth[first_slot + f] = depth_m ? 1 : 0; }
     if (!(flags & DVO_UPLOAD_ASYNC)) HIPCHK(c, hipStreamSynchronize(c->stream));
     return DVO_OK;

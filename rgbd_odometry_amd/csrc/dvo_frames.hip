@@ -155,68 +155,13 @@ hipError_t launch_camera_level(const unsigned char *bgr, size_t bgr_stride, cons
 /* ------------------------------------------------------------------------- */
 /* row f1: Canny                                                                */
 /* ------------------------------------------------------------------------- */
-/* work layout per batch (ints): mag[count*n] | dxdy[count*n] (short2) | label[count*n] | cand[count*n bytes] | flag[count*n bytes] */
+/* work layout per batch: label[count*n] (int) | cand[count*n] (u8) | flag[count*n] (u8) */
 size_t canny_work_ints(int rows, int cols, int count) {
     const size_t n = (size_t)rows * cols * count;
-    return 3 * n + 2 * ((n + 3) / 4);
+    return n + 2 * ((n + 3) / 4);
 }
 
-__global__ void __launch_bounds__(256)
-canny_sobel_kernel(const unsigned char *__restrict__ grey, size_t stride, int rows, int cols,
-                   int *__restrict__ mag, short2 *__restrict__ dxdy) {
-    const size_t n = (size_t)rows * cols;
-    grey += (size_t)blockIdx.y * stride;
-    mag += (size_t)blockIdx.y * n;
-    dxdy += (size_t)blockIdx.y * n;
-    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
-        const int xx = (int)(p / rows), yy = (int)(p - (size_t)xx * rows);
-        const int ym = yy > 0 ? yy - 1 : 0, yp = yy < rows - 1 ? yy + 1 : rows - 1;     /* BORDER_REPLICATE */
-        const size_t cm = (size_t)(xx > 0 ? xx - 1 : 0) * rows, c0 = (size_t)xx * rows,
-                     cp = (size_t)(xx < cols - 1 ? xx + 1 : cols - 1) * rows;
-        const int a = grey[cm + ym], b = grey[c0 + ym], c = grey[cp + ym];
-        const int d = grey[cm + yy], f = grey[cp + yy];
-        const int g = grey[cm + yp], h = grey[c0 + yp], i = grey[cp + yp];
-        const int dx = (c - a) + 2 * (f - d) + (i - g);
-        const int dy = (g - a) + 2 * (h - b) + (i - c);
-        dxdy[p] = make_short2((short)dx, (short)dy);
-        mag[p] = dx * dx + dy * dy;
-    }
-}
-
-/* cand: 0 suppressed, 1 candidate (> low, local maximum along its sector), 2 candidate above high */
-__global__ void __launch_bounds__(256)
-canny_nms_kernel(const int *__restrict__ mag, const short2 *__restrict__ dxdy, int rows, int cols, int low, int high,
-                 unsigned char *__restrict__ cand, unsigned char *__restrict__ flag, int *__restrict__ label) {
-    const size_t n = (size_t)rows * cols;
-    mag += (size_t)blockIdx.y * n; dxdy += (size_t)blockIdx.y * n;
-    cand += (size_t)blockIdx.y * n; flag += (size_t)blockIdx.y * n; label += (size_t)blockIdx.y * n;
-    constexpr int SHIFT = 15;
-    constexpr int TG22 = 13573;                                   /* round(tan(22.5 deg) * 2^15) */
-    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
-        const int xx = (int)(p / rows), yy = (int)(p - (size_t)xx * rows);
-        const int m = mag[p];
-        bool keep = false;
-        if (m > low) {
-            const short2 d = dxdy[p];
-            const int xs = d.x, ys = d.y;
-            const int ax = xs < 0 ? -xs : xs, ay = (ys < 0 ? -ys : ys) << SHIFT;
-            const int tg22x = ax * TG22;
-            int ay1, ax1, ay2, ax2;                               /* the two neighbours of the sector */
-            bool ge2;                                             /* second comparison is >= (x and y sectors) */
-            if (ay < tg22x) { ay1 = 0; ax1 = -1; ay2 = 0; ax2 = 1; ge2 = true; }
-            else if (ay > tg22x + (ax << (SHIFT + 1))) { ay1 = -1; ax1 = 0; ay2 = 1; ax2 = 0; ge2 = true; }
-            else { const int sgn = ((xs ^ ys) < 0) ? -1 : 1; ay1 = -1; ax1 = -sgn; ay2 = 1; ax2 = sgn; ge2 = false; }
-            const int y1 = yy + ay1, x1 = xx + ax1, y2 = yy + ay2, x2 = xx + ax2;
-            const int m1 = (y1 < 0 || y1 >= rows || x1 < 0 || x1 >= cols) ? 0 : mag[(size_t)x1 * rows + y1];
-            const int m2 = (y2 < 0 || y2 >= rows || x2 < 0 || x2 >= cols) ? 0 : mag[(size_t)x2 * rows + y2];
-            keep = (m > m1) && (ge2 ? (m >= m2) : (m > m2));
-        }
-        cand[p] = keep ? (m > high ? 2 : 1) : 0;
-        flag[p] = 0;
-        label[p] = keep ? (int)p : -1;
-    }
-}
-
+/* union-find on int labels (global or LDS): a root points to itself, links only ever go to smaller indices */
 DVO_DEV int uf_load(const int *L, int a) { return __hip_atomic_load(L + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DVO_DEV int uf_find(const int *L, int a) {
     int p;
@@ -235,20 +180,127 @@ DVO_DEV void uf_union(int *L, int a, int b) {
     }
 }
 
-/* hysteresis connectivity: union of every candidate with its candidate neighbours of smaller index */
+/* Canny front end, one 64 x 32 pixel tile per workgroup, everything between the grey load and the candidate
+ * map in LDS: 3x3 Sobel (BORDER_REPLICATE) -> squared magnitude -> sector non-maximum suppression ->
+ * union-find of the tile's candidates.  Out: cand (0 suppressed, 1 candidate, 2 candidate above `high`), and for
+ * candidates label = global index of the tile-local root, flag = 0.  Pairs of candidates in different tiles
+ * are joined by canny_border_kernel. */
+constexpr int CT_Y = 64, CT_X = 32;
 __global__ void __launch_bounds__(256)
-canny_merge_kernel(const unsigned char *__restrict__ cand, int rows, int cols, int *__restrict__ label) {
+canny_tile_kernel(const unsigned char *__restrict__ grey, size_t stride, int rows, int cols, int tiles_y, int low, int high,
+                  unsigned char *__restrict__ cand, unsigned char *__restrict__ flag, int *__restrict__ label) {
+    constexpr int GH = CT_Y + 4, GW = CT_X + 4, MH = CT_Y + 2, MW = CT_X + 2, NT = CT_Y * CT_X;
+    __shared__ unsigned char sg[GW * GH];         /* grey, halo 2, [x][y] */
+    __shared__ int smag[MW * MH];                 /* squared magnitude, halo 1 (0 outside the image) */
+    __shared__ short2 sdxy[MW * MH];
+    __shared__ int slab[NT];
+    __shared__ unsigned char scand[NT];
+    const size_t n = (size_t)rows * cols;
+    grey += (size_t)blockIdx.y * stride;
+    cand += (size_t)blockIdx.y * n; flag += (size_t)blockIdx.y * n; label += (size_t)blockIdx.y * n;
+    const int ty = blockIdx.x % tiles_y, tx = blockIdx.x / tiles_y;
+    const int y0 = ty * CT_Y, x0 = tx * CT_X;
+    const int tid = threadIdx.x;
+
+    for (int idx = tid; idx < GW * GH; idx += 256) {
+        const int lx = idx / GH, ly = idx - lx * GH;
+        int gy = y0 + ly - 2, gx = x0 + lx - 2;
+        gy = gy < 0 ? 0 : (gy > rows - 1 ? rows - 1 : gy);                      /* BORDER_REPLICATE */
+        gx = gx < 0 ? 0 : (gx > cols - 1 ? cols - 1 : gx);
+        sg[idx] = grey[(size_t)gx * rows + gy];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < MW * MH; idx += 256) {
+        const int lx = idx / MH, ly = idx - lx * MH;
+        const int py = y0 + ly - 1, px = x0 + lx - 1;
+        int m = 0, dx = 0, dy = 0;
+        if (py >= 0 && py < rows && px >= 0 && px < cols) {
+            const unsigned char *c = sg + (lx + 1) * GH + (ly + 1);             /* the pixel itself */
+            const int a = c[-GH - 1], b = c[-1], cc = c[GH - 1];                /* row above: x-1, x, x+1 */
+            const int d = c[-GH], f = c[GH];
+            const int g = c[-GH + 1], h = c[1], i = c[GH + 1];
+            dx = (cc - a) + 2 * (f - d) + (i - g);
+            dy = (g - a) + 2 * (h - b) + (i - cc);
+            m = dx * dx + dy * dy;
+        }
+        smag[idx] = m;
+        sdxy[idx] = make_short2((short)dx, (short)dy);
+    }
+    __syncthreads();
+    constexpr int SHIFT = 15;
+    constexpr int TG22 = 13573;                                   /* round(tan(22.5 deg) * 2^15) */
+    for (int idx = tid; idx < NT; idx += 256) {
+        const int lx = idx / CT_Y, ly = idx - lx * CT_Y;
+        const int mi = (lx + 1) * MH + (ly + 1);
+        const int m = smag[mi];
+        bool keep = false;
+        if (m > low && y0 + ly < rows && x0 + lx < cols) {
+            const short2 d = sdxy[mi];
+            const int xs = d.x, ys = d.y;
+            const int ax = xs < 0 ? -xs : xs, ay = (ys < 0 ? -ys : ys) << SHIFT;
+            const int tg22x = ax * TG22;
+            int o1, o2;                                           /* the two neighbours of the sector (offsets in smag) */
+            bool ge2;                                             /* second comparison is >= (x and y sectors) */
+            if (ay < tg22x) { o1 = -MH; o2 = MH; ge2 = true; }
+            else if (ay > tg22x + (ax << (SHIFT + 1))) { o1 = -1; o2 = 1; ge2 = true; }
+            else { const int sgn = ((xs ^ ys) < 0) ? -1 : 1; o1 = -1 - sgn * MH; o2 = 1 + sgn * MH; ge2 = false; }
+            const int m1 = smag[mi + o1], m2 = smag[mi + o2];
+            keep = (m > m1) && (ge2 ? (m >= m2) : (m > m2));
+        }
+        scand[idx] = keep ? (m > high ? 2 : 1) : 0;
+        slab[idx] = keep ? idx : -1;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < NT; idx += 256) {                   /* join with the candidate neighbours of smaller index */
+        if (!scand[idx]) continue;
+        const int lx = idx / CT_Y, ly = idx - lx * CT_Y;
+        if (ly > 0 && scand[idx - 1]) uf_union(slab, idx, idx - 1);
+        if (lx > 0) {
+            const int q = idx - CT_Y;
+            if (scand[q]) uf_union(slab, idx, q);
+            if (ly > 0 && scand[q - 1]) uf_union(slab, idx, q - 1);
+            if (ly < CT_Y - 1 && scand[q + 1]) uf_union(slab, idx, q + 1);
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < NT; idx += 256) {
+        const int lx = idx / CT_Y, ly = idx - lx * CT_Y;
+        const int py = y0 + ly, px = x0 + lx;
+        if (py >= rows || px >= cols) continue;
+        const size_t p = (size_t)px * rows + py;
+        const unsigned char c = scand[idx];
+        cand[p] = c;
+        if (c) {
+            const int r = uf_find(slab, idx);
+            const int rx = r / CT_Y, ry = r - rx * CT_Y;
+            label[p] = (x0 + rx) * rows + (y0 + ry);
+            flag[p] = 0;
+        }
+    }
+}
+
+/* candidate pairs that straddle a tile boundary: rows r = 64, 128, ... looking up, columns c = 32, 64, ... looking left */
+__global__ void __launch_bounds__(256)
+canny_border_kernel(const unsigned char *__restrict__ cand, int rows, int cols, int *__restrict__ label) {
     const size_t n = (size_t)rows * cols;
     cand += (size_t)blockIdx.y * n; label += (size_t)blockIdx.y * n;
-    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
-        if (!cand[p]) continue;
-        const int xx = (int)(p / rows), yy = (int)(p - (size_t)xx * rows);
-        if (yy > 0 && cand[p - 1]) uf_union(label, (int)p, (int)p - 1);
-        if (xx > 0) {
-            const size_t q = p - rows;
+    const int nA = ((rows - 1) / CT_Y) * cols, nB = ((cols - 1) / CT_X) * rows;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nA + nB; i += gridDim.x * blockDim.x) {
+        if (i < nB) {                                             /* lanes along yy: coalesced */
+            const int xx = (i / rows + 1) * CT_X, yy = i % rows;
+            const size_t p = (size_t)xx * rows + yy, q = p - rows;
+            if (!cand[p]) continue;
             if (cand[q]) uf_union(label, (int)p, (int)q);
             if (yy > 0 && cand[q - 1]) uf_union(label, (int)p, (int)q - 1);
             if (yy < rows - 1 && cand[q + 1]) uf_union(label, (int)p, (int)q + 1);
+        } else {
+            const int j = i - nB;
+            const int yy = (j / cols + 1) * CT_Y, xx = j % cols;
+            const size_t p = (size_t)xx * rows + yy;
+            if (!cand[p]) continue;
+            if (cand[p - 1]) uf_union(label, (int)p, (int)p - 1);
+            if (xx > 0 && cand[p - 1 - rows]) uf_union(label, (int)p, (int)(p - 1 - rows));
+            if (xx < cols - 1 && cand[p - 1 + rows]) uf_union(label, (int)p, (int)(p - 1 + rows));
         }
     }
 }
@@ -295,25 +347,19 @@ hipError_t launch_count_edges(const unsigned char *edge, size_t n, int *out, hip
 hipError_t launch_canny(const unsigned char *grey, size_t stride, ImgBatch g, int low, int high, int *work,
                         unsigned char *edge, size_t edge_stride, hipStream_t s) {
     const size_t n = (size_t)g.rows * g.cols, nb = n * g.count;
-    int *mag = work;
-    short2 *dxdy = reinterpret_cast<short2 *>(work + nb);
-    int *label = work + 2 * nb;
-    unsigned char *cand = reinterpret_cast<unsigned char *>(work + 3 * nb);
+    int *label = work;
+    unsigned char *cand = reinterpret_cast<unsigned char *>(work + nb);
     unsigned char *flag = cand + ((nb + 3) / 4) * 4;
+    const int tiles_y = (g.rows + CT_Y - 1) / CT_Y, tiles_x = (g.cols + CT_X - 1) / CT_X;
     const dim3 grid(grid_x(n), g.count), blk(256);
-    hipLaunchKernelGGL(canny_sobel_kernel, grid, blk, 0, s, grey, stride, g.rows, g.cols, mag, dxdy);
-    hipLaunchKernelGGL(canny_nms_kernel, grid, blk, 0, s, mag, dxdy, g.rows, g.cols, low, high, cand, flag, label);
-    hipLaunchKernelGGL(canny_merge_kernel, grid, blk, 0, s, cand, g.rows, g.cols, label);
+    hipLaunchKernelGGL(canny_tile_kernel, dim3(tiles_y * tiles_x, g.count), blk, 0, s, grey, stride, g.rows, g.cols, tiles_y,
+                       low, high, cand, flag, label);
+    const int n_border = ((g.rows - 1) / CT_Y) * g.cols + ((g.cols - 1) / CT_X) * g.rows;
+    if (n_border > 0)
+        hipLaunchKernelGGL(canny_border_kernel, dim3(grid_x((size_t)n_border), g.count), blk, 0, s, cand, g.rows, g.cols, label);
     hipLaunchKernelGGL(canny_flag_kernel, grid, blk, 0, s, cand, n, label, flag);
     hipLaunchKernelGGL(canny_final_kernel, grid, blk, 0, s, cand, label, flag, n, edge, edge_stride);
     return hipGetLastError();
-}
-
-/* stage dump for tests: squared magnitude and candidate map of the LAST launch_canny on this work buffer */
-void canny_work_views(int *work, int rows, int cols, int count, const int **mag, const unsigned char **cand) {
-    const size_t nb = (size_t)rows * cols * count;
-    *mag = work;
-    *cand = reinterpret_cast<const unsigned char *>(work + 3 * nb);
 }
 
 /* ------------------------------------------------------------------------- */

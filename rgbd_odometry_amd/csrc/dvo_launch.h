@@ -111,7 +111,6 @@ size_t canny_work_ints(int rows, int cols, int count);
 hipError_t launch_canny(const unsigned char *grey, size_t stride, ImgBatch g, int low, int high, int *work,
                         unsigned char *edge, size_t edge_stride, hipStream_t s);
 hipError_t launch_count_edges(const unsigned char *edge, size_t n, int *out, hipStream_t s);
-void canny_work_views(int *work, int rows, int cols, int count, const int **mag, const unsigned char **cand);
 /* edge mask -> distance transform -> normalise -> gradients -> texels (SolveDVO.cpp:1768-1795, :1063-1098).
  * work: edt_work_ints() ints */
 size_t edt_work_ints(int rows, int cols, int count);
