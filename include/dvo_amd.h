@@ -272,14 +272,17 @@ int  dvo_frames_reserve(dvo_ctx *ctx, int n_slots);
 /* the pyramids of `count` frames as the dvo node receives them (RGBDFramePyd: framemono[] mono8 + dframe[] mono16,
  * imageArrivedCallBack SolveDVO.cpp:490-534) or as the class holds them (im_n/dim_n: F32 column-major).
  * grey[f*n_levels + l], depth[f*n_levels + l]; depth may be NULL (frames that will only ever be "now" frames).
- * U16 depth gets the node's 0 -> 1 treatment (:514); F32 depth is taken as is.  Runs Canny per level. */
+ * U16 depth gets the node's 0 -> 1 treatment (:514); F32 depth is taken as is.  Runs Canny per level.
+ * now_first_pair >= 0: slot first_slot+i is also installed as the now frame of pair now_first_pair+i (as
+ * dvo_frames_as_now would), chunk by chunk in the shadow of the next chunk's host-to-device copies; -1: no. */
 int  dvo_frames_upload_pyramids(dvo_ctx *ctx, int first_slot, int count, int n_levels,
-                                const dvo_image *grey, const dvo_image *depth, int flags);
+                                const dvo_image *grey, const dvo_image *depth, int now_first_pair, int flags);
 /* camera frames: full-resolution BGR8 (rows x cols x 3, row-major) + depth in metres (F32 row-major, may be NULL);
  * level l is decimated by 2^(first_shift + l) (the reference publishes first_shift = 1: 320x240 .. 40x30).
  * Builds the pyramid on the device, then as above. */
 int  dvo_frames_upload_cameras(dvo_ctx *ctx, int first_slot, int count, const unsigned char *const *bgr8,
-                               const float *const *depth_m, int rows, int cols, int n_levels, int first_shift, int flags);
+                               const float *const *depth_m, int rows, int cols, int n_levels, int first_shift,
+                               int now_first_pair, int flags);
 /* computeDistTransfrmOfNow (SolveDVO.cpp:1740-1799): slot first_slot+i becomes the now frame of pair first_pair+i.
  * Asynchronous on the context stream. */
 int  dvo_frames_as_now(dvo_ctx *ctx, int first_slot, int first_pair, int count);

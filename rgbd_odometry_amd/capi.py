@@ -142,8 +142,8 @@ def load_library() -> C.CDLL:
         "dvo_align_pyramid_wide": [vp, i, i, ip, vp, vp],
         "dvo_get_ref_level": [vp, i, i, vp, i, ip],
         "dvo_frames_reserve": [vp, i],
-        "dvo_frames_upload_pyramids": [vp, i, i, i, C.POINTER(DvoImage), C.POINTER(DvoImage), i],
-        "dvo_frames_upload_cameras": [vp, i, i, C.POINTER(vp), C.POINTER(vp), i, i, i, i, i],
+        "dvo_frames_upload_pyramids": [vp, i, i, i, C.POINTER(DvoImage), C.POINTER(DvoImage), i, i],
+        "dvo_frames_upload_cameras": [vp, i, i, C.POINTER(vp), C.POINTER(vp), i, i, i, i, i, i],
         "dvo_frames_as_now": [vp, i, i, i],
         "dvo_frames_as_ref": [vp, i, i, i, ip],
         "dvo_frame_get_level": [vp, i, i, ip, ip, vp, vp, vp, ip],
@@ -374,7 +374,8 @@ class DvoContext:
         buf = np.ascontiguousarray(a) if layout == DVO_LAYOUT_ROW_MAJOR else np.ascontiguousarray(a.T)
         return DvoImage(buf.ctypes.data, rows, cols, dt, layout), buf
 
-    def frames_upload_pyramids(self, frames, first_slot: int = 0, layout: int = DVO_LAYOUT_ROW_MAJOR, flags: int = 0):
+    def frames_upload_pyramids(self, frames, first_slot: int = 0, layout: int = DVO_LAYOUT_ROW_MAJOR, flags: int = 0,
+                               now_first_pair: int = -1):
         """frames: list of frames; a frame = list over levels of (grey, depth) or (grey, None); 2-D (rows, cols) arrays."""
         count, nl = len(frames), len(frames[0])
         keep, G, D = [], (DvoImage * (count * nl))(), (DvoImage * (count * nl))()
@@ -384,13 +385,14 @@ class DvoContext:
                 G[f * nl + l], b = self._image(g, "grey", layout); keep.append(b)
                 if have_depth:
                     D[f * nl + l], b = self._image(d, "depth", layout); keep.append(b)
-        self._chk(self.lib.dvo_frames_upload_pyramids(self._h, first_slot, count, nl, G, D if have_depth else None, flags))
+        self._chk(self.lib.dvo_frames_upload_pyramids(self._h, first_slot, count, nl, G, D if have_depth else None,
+                                                      now_first_pair, flags))
         self._frame_keep = keep if flags & DVO_UPLOAD_ASYNC else None
         for l, (g, _) in enumerate(frames[0]):
             self._dims[l] = tuple(np.asarray(g).shape)
 
     def frames_upload_cameras(self, bgr_list, depth_list=None, n_levels: int = 4, first_shift: int = 1,
-                              first_slot: int = 0, flags: int = 0):
+                              first_slot: int = 0, flags: int = 0, now_first_pair: int = -1):
         """bgr_list: list of (rows, cols, 3) uint8 BGR images; depth_list: list of (rows, cols) float32 metres or None"""
         count = len(bgr_list)
         bl = [np.ascontiguousarray(b, dtype=np.uint8) for b in bgr_list]
@@ -400,11 +402,17 @@ class DvoContext:
         if depth_list is not None:
             dl = [np.ascontiguousarray(d, dtype=np.float32) for d in depth_list]
             Dp = (C.c_void_p * count)(*[d.ctypes.data for d in dl])
-        self._chk(self.lib.dvo_frames_upload_cameras(self._h, first_slot, count, B, Dp, rows, cols, n_levels, first_shift, flags))
+        self._chk(self.lib.dvo_frames_upload_cameras(self._h, first_slot, count, B, Dp, rows, cols, n_levels, first_shift,
+                                                     now_first_pair, flags))
+        if now_first_pair >= 0:
+            self._note_dims(first_slot)
         self._frame_keep = (bl, dl) if flags & DVO_UPLOAD_ASYNC else None
 
     def frames_as_now(self, first_slot: int = 0, first_pair: int = 0, count: int = 1):
         self._chk(self.lib.dvo_frames_as_now(self._h, first_slot, first_pair, count))
+        self._note_dims(first_slot)
+
+    def _note_dims(self, first_slot: int):
         for l in range(self.lib.dvo_frames_num_levels(self._h)):
             r, c_ = C.c_int(), C.c_int()
             self._chk(self.lib.dvo_frame_get_level(self._h, first_slot, l, C.byref(r), C.byref(c_), None, None, None, None))

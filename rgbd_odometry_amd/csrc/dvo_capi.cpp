@@ -84,8 +84,8 @@ struct dvo_ctx {
     /* frame uploads: two landing buffers filled by a copy stream while the context stream preprocesses the other */
     unsigned char *up_buf[2] = {nullptr, nullptr};
     size_t up_bytes = 0;
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr, copy_stream2 = nullptr;      /* two SDMA queues: frames alternate between them */
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_copied2[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     bool up_used[2] = {false, false};
     int up_next = 0;
     Schedule sched{};
@@ -386,9 +386,11 @@ int dvo_destroy(dvo_ctx *c) {
     }
     if (c->work) (void)hipFree(c->work);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->copy_stream2) { (void)hipStreamSynchronize(c->copy_stream2); (void)hipStreamDestroy(c->copy_stream2); }
     for (int b = 0; b < 2; b++) {
         if (c->up_buf[b]) (void)hipFree(c->up_buf[b]);
         if (c->ev_copied[b]) (void)hipEventDestroy(c->ev_copied[b]);
+        if (c->ev_copied2[b]) (void)hipEventDestroy(c->ev_copied2[b]);
         if (c->ev_done[b]) (void)hipEventDestroy(c->ev_done[b]);
     }
     void *ptrs[] = {c->staging, c->d_poses, c->d_energy, c->d_best, c->d_ratio, c->d_final_eps,
@@ -1049,19 +1051,22 @@ int run_canny(dvo_ctx *c, int level, int first_slot, int count) {
     return DVO_OK;
 }
 
-constexpr size_t kUploadHalf = (size_t)64 << 20;   /* landing buffer per pipeline stage */
+constexpr size_t kUploadHalf = (size_t)32 << 20;   /* landing buffer per pipeline stage */
 
 /* landing buffers of at least `bytes` each + copy stream + events */
 int ensure_upload(dvo_ctx *c, size_t bytes) {
     if (!c->copy_stream) {
         HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking));
         for (int b = 0; b < 2; b++) {
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_copied[b], hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_copied2[b], hipEventDisableTiming));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_done[b], hipEventDisableTiming));
         }
     }
     if (bytes <= c->up_bytes) return DVO_OK;
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream2));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int b = 0; b < 2; b++) {
         if (c->up_buf[b]) HIPCHK(c, hipFree(c->up_buf[b]));
@@ -1075,14 +1080,19 @@ int ensure_upload(dvo_ctx *c, size_t bytes) {
 /* stage A of a chunk: returns the landing buffer; copies must go to c->copy_stream */
 int upload_begin(dvo_ctx *c, unsigned char **buf, int *slot) {
     const int b = c->up_next;
-    if (c->up_used[b]) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_done[b], 0));    /* its previous consumer finished */
+    if (c->up_used[b]) {                                /* its previous consumer finished */
+        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_done[b], 0));
+        HIPCHK(c, hipStreamWaitEvent(c->copy_stream2, c->ev_done[b], 0));
+    }
     *buf = c->up_buf[b]; *slot = b;
     return DVO_OK;
 }
 /* stage B: everything enqueued on c->stream after this sees the copies */
 int upload_copied(dvo_ctx *c, int b) {
     HIPCHK(c, hipEventRecord(c->ev_copied[b], c->copy_stream));
+    HIPCHK(c, hipEventRecord(c->ev_copied2[b], c->copy_stream2));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copied[b], 0));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copied2[b], 0));
     return DVO_OK;
 }
 /* stage C: the kernels reading the landing buffer are enqueued */
@@ -1096,6 +1106,8 @@ int upload_consumed(dvo_ctx *c, int b) {
 size_t pix_bytes(int dtype) { return dtype == DVO_PIX_U8 ? 1 : (dtype == DVO_PIX_U16 ? 2 : 4); }
 
 }  // namespace
+
+static int frames_as_now_range(dvo_ctx *c, int first_slot, int first_pair, int count);
 
 int dvo_frames_reserve(dvo_ctx *c, int n_slots) {
     if (!c) return DVO_ERR_INVALID;
@@ -1111,7 +1123,7 @@ int dvo_frames_reserve(dvo_ctx *c, int n_slots) {
 int dvo_frames_num_levels(const dvo_ctx *c) { return c ? c->fs.n_levels : 0; }
 
 int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_levels,
-                               const dvo_image *grey, const dvo_image *depth, int flags) {
+                               const dvo_image *grey, const dvo_image *depth, int now_first_pair, int flags) {
     if (!c) return DVO_ERR_INVALID;
     if (!grey || count < 1 || n_levels < 1 || n_levels > DVO_LEVELS) return fail(c, DVO_ERR_INVALID, "bad frame arguments");
     int rows[DVO_LEVELS], cols[DVO_LEVELS];
@@ -1132,6 +1144,8 @@ int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_leve
     int rc = frames_geometry(c, n_levels, rows, cols);
     if (rc) return rc;
     if (!slots_ok(c, first_slot, count)) return fail(c, DVO_ERR_INVALID, "frame slot range out of bounds (dvo_frames_reserve)");
+    if (now_first_pair >= 0 && (!pair_ok(c, now_first_pair) || now_first_pair + count > c->n_pairs))
+        return fail(c, DVO_ERR_INVALID, "now_first_pair range out of bounds");
     /* chunks of frames flow through copy (copy stream) -> import + Canny (context stream), double-buffered */
     size_t g_img[DVO_LEVELS], d_img[DVO_LEVELS], g_off[DVO_LEVELS], d_off[DVO_LEVELS], frame_bytes = 0;
     for (int l = 0; l < n_levels; l++) {
@@ -1152,11 +1166,12 @@ int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_leve
         for (int l = 0; l < n_levels; l++) {
             const size_t npx = c->fs.lv[l].npx, gb = pix_bytes(grey[l].dtype), db = depth ? pix_bytes(depth[l].dtype) : 0;
             for (int i = 0; i < nc; i++) {
+                hipStream_t cs = (i & 1) ? c->copy_stream2 : c->copy_stream;
                 HIPCHK(c, hipMemcpyAsync(buf + g_off[l] + g_img[l] * i, grey[(size_t)(b + i) * n_levels + l].data, npx * gb,
-                                         hipMemcpyHostToDevice, c->copy_stream));
+                                         hipMemcpyHostToDevice, cs));
                 if (depth)
                     HIPCHK(c, hipMemcpyAsync(buf + d_off[l] + d_img[l] * i, depth[(size_t)(b + i) * n_levels + l].data, npx * db,
-                                             hipMemcpyHostToDevice, c->copy_stream));
+                                             hipMemcpyHostToDevice, cs));
             }
         }
         if ((rc = upload_copied(c, ub))) return rc;
@@ -1172,6 +1187,7 @@ int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_leve
         }
         if ((rc = upload_consumed(c, ub))) return rc;
         for (int l = 0; l < n_levels; l++) if ((rc = run_canny(c, l, first_slot + b, nc))) return rc;
+        if (now_first_pair >= 0 && (rc = frames_as_now_range(c, first_slot + b, now_first_pair + b, nc))) return rc;
     }
     for (int f = 0; f < count; f++) { c->fs.valid[first_slot + f] = 1; c->fs.has_depth[first_slot + f] = depth ? 1 : 0; }
     if (!(flags & DVO_UPLOAD_ASYNC)) HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1179,7 +1195,8 @@ int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_leve
 }
 
 int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsigned char *const *bgr8,
-                              const float *const *depth_m, int rows, int cols, int n_levels, int first_shift, int flags) {
+                              const float *const *depth_m, int rows, int cols, int n_levels, int first_shift,
+                              int now_first_pair, int flags) {
     if (!c) return DVO_ERR_INVALID;
     if (!bgr8 || count < 1 || rows < 1 || cols < 1 || n_levels < 1 || n_levels > DVO_LEVELS || first_shift < 0 ||
         first_shift + n_levels > 16)
@@ -1195,6 +1212,8 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
     int rc = frames_geometry(c, n_levels, lr, lc);
     if (rc) return rc;
     if (!slots_ok(c, first_slot, count)) return fail(c, DVO_ERR_INVALID, "frame slot range out of bounds (dvo_frames_reserve)");
+    if (now_first_pair >= 0 && (!pair_ok(c, now_first_pair) || now_first_pair + count > c->n_pairs))
+        return fail(c, DVO_ERR_INVALID, "now_first_pair range out of bounds");
     const size_t npx = (size_t)rows * cols;
     const size_t b_img = (npx * 3 + 15) / 16 * 16, d_img = depth_m ? npx * 4 : 0;
     const int chunk = (int)std::min<size_t>(std::max<size_t>(kUploadHalf / (b_img + d_img), 1), (size_t)count);
@@ -1205,8 +1224,9 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
         if ((rc = upload_begin(c, &sb, &ub))) return rc;
         float *sd = (float *)(sb + b_img * chunk);
         for (int i = 0; i < nc; i++) {
-            HIPCHK(c, hipMemcpyAsync(sb + b_img * i, bgr8[b + i], npx * 3, hipMemcpyHostToDevice, c->copy_stream));
-            if (depth_m) HIPCHK(c, hipMemcpyAsync(sd + npx * i, depth_m[b + i], npx * 4, hipMemcpyHostToDevice, c->copy_stream));
+            hipStream_t cs = (i & 1) ? c->copy_stream2 : c->copy_stream;
+            HIPCHK(c, hipMemcpyAsync(sb + b_img * i, bgr8[b + i], npx * 3, hipMemcpyHostToDevice, cs));
+            if (depth_m) HIPCHK(c, hipMemcpyAsync(sd + npx * i, depth_m[b + i], npx * 4, hipMemcpyHostToDevice, cs));
         }
         if ((rc = upload_copied(c, ub))) return rc;
         for (int l = 0; l < n_levels; l++) {
@@ -1217,6 +1237,7 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
         }
         if ((rc = upload_consumed(c, ub))) return rc;
         for (int l = 0; l < n_levels; l++) if ((rc = run_canny(c, l, first_slot + b, nc))) return rc;
+        if (now_first_pair >= 0 && (rc = frames_as_now_range(c, first_slot + b, now_first_pair + b, nc))) return rc;
     }
     for (int f = 0; f < count; f++) { c->fs.valid[first_slot + f] = 1; c->fs.has_depth[first_slot + f] = depth_m ? 1 : 0; }
     if (!(flags & DVO_UPLOAD_ASYNC)) HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1234,10 +1255,8 @@ static int frames_check_use(dvo_ctx *c, int first_slot, int first_pair, int coun
     return DVO_OK;
 }
 
-int dvo_frames_as_now(dvo_ctx *c, int first_slot, int first_pair, int count) {
-    if (!c) return DVO_ERR_INVALID;
-    int rc = frames_check_use(c, first_slot, first_pair, count, false);
-    if (rc) return rc;
+static int frames_as_now_range(dvo_ctx *c, int first_slot, int first_pair, int count) {
+    int rc;
     for (int l = 0; l < c->fs.n_levels; l++) {
         FrameLevel &F = c->fs.lv[l];
         if ((rc = ensure_texels(c, l, F.rows, F.cols))) return rc;
@@ -1252,6 +1271,13 @@ int dvo_frames_as_now(dvo_ctx *c, int first_slot, int first_pair, int count) {
         for (int i = 0; i < count; i++) L.have_now[first_pair + i] = 1;
     }
     return DVO_OK;
+}
+
+int dvo_frames_as_now(dvo_ctx *c, int first_slot, int first_pair, int count) {
+    if (!c) return DVO_ERR_INVALID;
+    int rc = frames_check_use(c, first_slot, first_pair, count, false);
+    if (rc) return rc;
+    return frames_as_now_range(c, first_slot, first_pair, count);
 }
 
 int dvo_frames_as_ref(dvo_ctx *c, int first_slot, int first_pair, int count, int *N_out) {

@@ -79,6 +79,12 @@ def main():
         return ctx.get_poses()
     timed("now frame in -> pose out (reference resident)", tracking_step, B)
 
+    def tracking_step_fused():                        # as_now rides in the upload pipeline (now_first_pair)
+        ctx.frames_upload_cameras(now_b, None, first_slot=B, now_first_pair=0, **kw)
+        ctx.enqueue(iters, flags=DVO_FLAG_IDENTITY_START)
+        return ctx.get_poses()
+    timed("now frame in -> pose out, as_now inside the upload pipeline", tracking_step_fused, B)
+
     def tracking_step_chunked(ch=32):                 # same, in chunks: copies of chunk k+1 overlap the kernels of chunk k
         for b in range(0, B, ch):
             n = min(ch, B - b)
@@ -86,7 +92,7 @@ def main():
             ctx.frames_as_now(B + b, b, n)
         ctx.enqueue(iters, flags=DVO_FLAG_IDENTITY_START)
         return ctx.get_poses()
-    for ch in (16, 32, 64):
+    for ch in (64,):
         timed("now frame in -> pose out, chunks of %d" % ch, lambda ch=ch: tracking_step_chunked(ch), B)
 
     def pair_step():                                  # both frames of every pair from the host
