@@ -13,6 +13,14 @@
  *       runIterations               :619-1017, same argument order and meaning
  *       alignPyramid                the level loop of SolveDVO::loop :2097-2104 (+ :2220-2227)
  *       iterationsConfig            :30-33, SolveDVO.h:354
+ *       setRcvdFrame / loadFromFile imageArrivedCallBack :490-534 / loadFromFile :154-190 (OpenCV-XML mono_%d, depth_%d)
+ *       setRcvdFrameAsRefFrame, setPrevFrameAsRefFrame, setRcvdFrameAsNowFrame, preProcessRefFrame
+ *                                   :535-618, :269-303 -- on the engine's frame store (Canny, distance transform,
+ *                                   point extraction on the GPU; the previous now frame stays resident)
+ *       processFirstFrame / processFrame   the body of SolveDVO::loop :1970-2241: level schedule, forced key frame
+ *                                   every 5 frames with the n-1 re-reference + re-run (__NEW__REF_UPDATE), GOP push
+ *       printPose                   :1341-1354 ("qx qy qz qw tx ty tz" lines, __WRITE_EST_POSE_TO_FILE)
+ *   dvo_amd::GOP<T>                 include/GOP.h, src/GOP.cpp:138-196 (key-frame relative -> global pose chain)
  *   dvo_amd::PyramidalStorageStruct include/PyramidalStorage.h:37-78 (addLevel/getLevel/clearPyramid/printSize):
  *                                   here the per-level container of the now-frame pyramid
  *   dvo_amd::RGBDOdometry           include/RGBDOdometry.h:41-43: the legacy photometric node; only the
@@ -24,7 +32,11 @@
 #ifndef DVO_AMD_HPP_
 #define DVO_AMD_HPP_
 
+#include <cmath>
+#include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <ostream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -66,9 +78,131 @@ private:
     std::vector<ImageF> dt_, gx_, gy_;
 };
 
+/* geometry_msgs::Pose stand-in */
+struct Pose { double px = 0, py = 0, pz = 0, qx = 0, qy = 0, qz = 0, qw = 1; };
+
+/* Eigen::Quaternion<T>(Matrix3) as GOPElement::matrixToPose uses it (src/GOP.cpp:103-115); R column-major */
+template <typename T>
+inline void quaternionFromMatrix(const T *R, T &qx, T &qy, T &qz, T &qw) {
+    auto m = [&](int i, int j) { return R[i + 3 * j]; };
+    T t = m(0, 0) + m(1, 1) + m(2, 2);
+    if (t > T(0)) {
+        t = std::sqrt(t + T(1.0));
+        qw = T(0.5) * t;
+        t = T(0.5) / t;
+        qx = (m(2, 1) - m(1, 2)) * t; qy = (m(0, 2) - m(2, 0)) * t; qz = (m(1, 0) - m(0, 1)) * t;
+    } else {
+        int i = 0;
+        if (m(1, 1) > m(0, 0)) i = 1;
+        if (m(2, 2) > m(i, i)) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(m(i, i) - m(j, j) - m(k, k) + T(1.0));
+        T q[3];
+        q[i] = T(0.5) * t;
+        t = T(0.5) / t;
+        qw = (m(k, j) - m(j, k)) * t;
+        q[j] = (m(j, i) + m(i, j)) * t;
+        q[k] = (m(k, i) + m(i, k)) * t;
+        qx = q[0]; qy = q[1]; qz = q[2];
+    }
+}
+
+/* Key-frame relative poses -> global pose chain (include/GOP.h, src/GOP.cpp:138-196). */
+template <typename T>
+class GOP {
+public:
+    struct Element { int frameNum; bool keyFrame; int reason; T R[9]; T t[3]; };
+    GOP() { identity(lastKeyFr_R_); lastKeyFr_T_[0] = lastKeyFr_T_[1] = lastKeyFr_T_[2] = T(0); }
+    void pushAsOrdinaryFrame(int frameNum, const T *cR, const T *cT) {            /* GOP.cpp:138-153 */
+        Element e; compose(cR, cT, e.R, e.t);
+        e.frameNum = frameNum; e.keyFrame = false; e.reason = -1;
+        v_.push_back(e);
+    }
+    void pushAsKeyFrame(int frameNum, int reason, const T *cR, const T *cT) {      /* GOP.cpp:162-186 */
+        Element e; compose(cR, cT, e.R, e.t);
+        e.frameNum = frameNum; e.keyFrame = true; e.reason = reason;
+        v_.push_back(e);
+        for (int k = 0; k < 9; k++) lastKeyFr_R_[k] = e.R[k];
+        for (int k = 0; k < 3; k++) lastKeyFr_T_[k] = e.t[k];
+    }
+    void updateMostRecentToKeyFrame(int reason) {                                  /* GOP.cpp:189-196 */
+        Element &e = v_.at(v_.size() - 1);
+        for (int k = 0; k < 9; k++) lastKeyFr_R_[k] = e.R[k];
+        for (int k = 0; k < 3; k++) lastKeyFr_T_[k] = e.t[k];
+        e.keyFrame = true; e.reason = reason;
+    }
+    int size() const { return (int)v_.size(); }
+    const T *getGlobalRAt(int i) const { return v_.at(i).R; }
+    const T *getGlobalTAt(int i) const { return v_.at(i).t; }
+    bool isKeyFrameAt(int i) const { return v_.at(i).keyFrame; }
+    int getReasonAt(int i) const { return v_.at(i).reason; }
+    int getFrameNumAt(int i) const { return v_.at(i).frameNum; }
+    Pose getGlobalPoseAt(int i) const {
+        const Element &e = v_.at(i);
+        Pose p; T qx, qy, qz, qw;
+        quaternionFromMatrix<T>(e.R, qx, qy, qz, qw);
+        p.px = e.t[0]; p.py = e.t[1]; p.pz = e.t[2]; p.qx = qx; p.qy = qy; p.qz = qz; p.qw = qw;
+        return p;
+    }
+private:
+    static void identity(T *R) { for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? T(1) : T(0); }
+    void compose(const T *cR, const T *cT, T *gR, T *gT) const {   /* global_T = key_T + key_R*cT; global_R = key_R*cR */
+        for (int i = 0; i < 3; i++) {
+            gT[i] = lastKeyFr_T_[i] + (lastKeyFr_R_[i] * cT[0] + lastKeyFr_R_[i + 3] * cT[1] + lastKeyFr_R_[i + 6] * cT[2]);
+            for (int j = 0; j < 3; j++)
+                gR[i + 3 * j] = lastKeyFr_R_[i] * cR[3 * j] + lastKeyFr_R_[i + 3] * cR[3 * j + 1] + lastKeyFr_R_[i + 6] * cR[3 * j + 2];
+        }
+    }
+    std::vector<Element> v_;
+    T lastKeyFr_R_[9], lastKeyFr_T_[3];
+};
+
+/* One received frame: the pyramid of the RGBDFramePyd message (msg/RGBDFramePyd.msg: framemono[] mono8, dframe[]
+ * mono16), row-major like cv::Mat / sensor_msgs::Image. */
+struct RGBDFramePyd {
+    struct Level { int rows = 0, cols = 0; std::vector<uint8_t> mono; std::vector<uint16_t> depth; };
+    std::vector<Level> levels;
+};
+
+/* OpenCV FileStorage XML written by the publisher (camTopic2PublisherPyD.cpp:306-383): matrices mono_%d (dt u) and
+ * depth_%d (dt w).  Minimal reader for that layout: <name type_id="opencv-matrix"><rows><cols><dt><data>. */
+inline bool readOpenCvXmlMatrix(const std::string &xml, const std::string &name, int &rows, int &cols, std::string &dt,
+                                std::vector<double> &values) {
+    size_t a = xml.find("<" + name + " ");
+    if (a == std::string::npos) a = xml.find("<" + name + ">");
+    if (a == std::string::npos) return false;
+    const size_t end = xml.find("</" + name + ">", a);
+    auto field = [&](const char *tag, std::string &out) {
+        const std::string open = std::string("<") + tag + ">", close = std::string("</") + tag + ">";
+        const size_t b = xml.find(open, a);
+        if (b == std::string::npos || b > end) return false;
+        const size_t e = xml.find(close, b);
+        if (e == std::string::npos) return false;
+        out = xml.substr(b + open.size(), e - b - open.size());
+        return true;
+    };
+    std::string r, c, d;
+    if (!field("rows", r) || !field("cols", c) || !field("dt", dt) || !field("data", d)) return false;
+    rows = std::atoi(r.c_str()); cols = std::atoi(c.c_str());
+    while (!dt.empty() && (dt.back() == ' ' || dt.back() == '\n')) dt.pop_back();
+    while (!dt.empty() && (dt.front() == ' ' || dt.front() == '\n')) dt.erase(dt.begin());
+    values.clear();
+    values.reserve((size_t)rows * cols);
+    const char *p = d.c_str();
+    char *q = nullptr;
+    for (;;) {
+        const double v = std::strtod(p, &q);
+        if (q == p) break;
+        values.push_back(v);
+        p = q;
+    }
+    return (int)values.size() == rows * cols;
+}
+
 class SolveDVO {
 public:
     std::vector<int> iterationsConfig;      /* SolveDVO.cpp:30-33 */
+    GOP<double> gop;                        /* SolveDVO.h: GOP<double> gop */
 
     explicit SolveDVO(const dvo_params *params = nullptr) {
         iterationsConfig = {50, 50, 50, 50};
@@ -154,6 +288,113 @@ public:
         chk(dvo_get_level_report(ctx_, 0, level, energy.data(), (int)energy.size(), &bestEnergyIndex, &visibleRatio));
     }
 
+    /* ---- frames in: the engine's frame store instead of host copies + OpenCV -------------------------------- */
+    /* imageArrivedCallBack (:490-534): hand the received pyramid to the engine (upload + Canny per level) */
+    void setRcvdFrame(const RGBDFramePyd &f) {
+        std::vector<dvo_image> g(f.levels.size()), d(f.levels.size());
+        for (size_t l = 0; l < f.levels.size(); l++) {
+            const RGBDFramePyd::Level &L = f.levels[l];
+            g[l] = dvo_image{L.mono.data(), L.rows, L.cols, DVO_PIX_U8, DVO_LAYOUT_ROW_MAJOR};
+            d[l] = dvo_image{L.depth.data(), L.rows, L.cols, DVO_PIX_U16, DVO_LAYOUT_ROW_MAJOR};
+        }
+        rcvd_slot_ = freeSlot();
+        chk(dvo_frames_upload_pyramids(ctx_, rcvd_slot_, 1, (int)f.levels.size(), g.data(), d.data(), -1, 0));
+        isFrameAvailable = true;
+    }
+    /* loadFromFile (:154-190): mono_0..3 / depth_0..3 of an OpenCV-XML frame file; false if it cannot be read */
+    bool loadFromFile(const char *xmlFileName, int nLevels = 4) {
+        std::FILE *fp = std::fopen(xmlFileName, "rb");
+        if (!fp) return false;                                                     /* ROS_ERROR "Cannot Open File" :160 */
+        std::string s; char buf[1 << 16]; size_t n;
+        while ((n = std::fread(buf, 1, sizeof(buf), fp)) > 0) s.append(buf, n);
+        std::fclose(fp);
+        RGBDFramePyd f;
+        f.levels.resize(nLevels);
+        for (int i = 0; i < nLevels; i++) {
+            int r = 0, c = 0, r2 = 0, c2 = 0; std::string dt; std::vector<double> v, w;
+            if (!readOpenCvXmlMatrix(s, "mono_" + std::to_string(i), r, c, dt, v)) return false;
+            if (!readOpenCvXmlMatrix(s, "depth_" + std::to_string(i), r2, c2, dt, w) || r2 != r || c2 != c) return false;
+            RGBDFramePyd::Level &L = f.levels[i];
+            L.rows = r; L.cols = c;
+            L.mono.assign(v.begin(), v.end());
+            L.depth.assign(w.begin(), w.end());
+        }
+        setRcvdFrame(f);
+        return true;
+    }
+    void setRcvdFrameAsRefFrame() {                 /* :535-556 (+ computeDistTransfrmOfRef: the Canny edge map is already resident) */
+        need(isFrameAvailable, "setRcvdFrameAsRefFrame: no frame received");
+        ref_slot_ = rcvd_slot_;
+        isRefFrameAvailable = false; refPreprocessed_ = false;
+    }
+    void setPrevFrameAsRefFrame() {                 /* :559-583: the previous now frame is still in the store */
+        need(prev_slot_ >= 0, "setPrevFrameAsRefFrame: n-1 frame not available");
+        ref_slot_ = prev_slot_;
+        isRefFrameAvailable = false; refPreprocessed_ = false;
+    }
+    void preProcessRefFrame() {                     /* :269-303: selectedPts + enlistRefEdgePts per level */
+        need(ref_slot_ >= 0, "preProcessRefFrame: no reference frame");
+        const int nl = dvo_frames_num_levels(ctx_);
+        std::vector<int> N(nl);
+        chk(dvo_frames_as_ref(ctx_, ref_slot_, 0, 1, N.data()));
+        ref_points_.assign(nl, {});
+        for (int l = 0; l < nl; l++) {
+            ref_points_[l].resize((size_t)3 * N[l]);
+            int n = 0;
+            chk(dvo_get_ref_level(ctx_, 0, l, ref_points_[l].data(), N[l], &n));
+        }
+        isRefFrameAvailable = true; refPreprocessed_ = true;
+    }
+    void setRcvdFrameAsNowFrame() {                 /* :587-618 incl. computeDistTransfrmOfNow :1740-1799 */
+        need(isFrameAvailable, "setRcvdFrameAsNowFrame: FRAME NOT AVAILABLE");
+        if (isNowFrameAvailable && now_slot_ >= 0) prev_slot_ = now_slot_;         /* p_now_framemono / p_now_depth :594-600 */
+        now_slot_ = rcvd_slot_;
+        chk(dvo_frames_as_now(ctx_, now_slot_, 0, 1));
+        isNowFrameAvailable = true;
+    }
+
+    /* ---- the body of SolveDVO::loop (:1970-2241), one call per received frame ------------------------------------ */
+    /* first frame: reference frame + first key frame (:1972-2021) */
+    void processFirstFrame() {
+        setRcvdFrameAsRefFrame();
+        preProcessRefFrame();
+        lastRefFrame = 0;
+        identityPose();
+        gop.pushAsKeyFrame((int)nFrame, 1, cR_64, cT_64);
+        isFrameAvailable = false;
+        nFrame++;
+    }
+    /* every other frame (:2059-2241 with __NEW__REF_UPDATE): returns the latest global pose (what publishGOP hands to printPose) */
+    Pose processFrame() {
+        setRcvdFrameAsNowFrame();
+        alignPyramid(cR_64, cT_64);                                                /* :2097-2104 (warm start from the last estimate) */
+        bool signalGetNewRefImage = false;
+        int reasonForChange = 0;
+        if ((nFrame - lastRefFrame) == keyFrameEvery) { signalGetNewRefImage = true; reasonForChange = 5; }   /* :2155-2160 */
+        if (signalGetNewRefImage && lastRefFrame != nFrame - 1) {                  /* :2198 */
+            lastRefFrame = nFrame - 1;
+            setPrevFrameAsRefFrame();
+            preProcessRefFrame();
+            gop.updateMostRecentToKeyFrame(reasonForChange);                       /* :2207 */
+            identityPose();                                                        /* :2210-2211 */
+            alignPyramid(cR_64, cT_64);                                            /* re-run :2220-2227 */
+            gop.pushAsOrdinaryFrame((int)nFrame, cR_64, cT_64);                    /* :2232 */
+        } else {
+            gop.pushAsOrdinaryFrame((int)nFrame, cR_64, cT_64);                    /* :2239 */
+        }
+        isFrameAvailable = false;
+        nFrame++;
+        return gop.getGlobalPoseAt(gop.size() - 1);                                /* MentisVisualHandle::publishGOP :283-300 */
+    }
+    /* printPose (:1341-1354): the line format of poses/estPoses.txt */
+    static void printPose(const Pose &p, std::ostream &stream) {
+        stream << p.qx << " " << p.qy << " " << p.qz << " " << p.qw << " " << p.px << " " << p.py << " " << p.pz << "\n";
+        stream.flush();
+    }
+    double cR_64[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, cT_64[3] = {0, 0, 0};          /* key-frame relative estimate (column-major) */
+    long nFrame = 0, lastRefFrame = 0;
+    int keyFrameEvery = 5;                                                         /* (nFrame - lastRefFrame) == 5  :2156 */
+
     /* frame loop hooks of the reference; the ROS node keeps its own loop() */
     void loopDry() {}
     void loopFromFile() { throw std::runtime_error("loopFromFile: body is commented out in the reference too (SolveDVO.cpp:2444-2678)"); }
@@ -162,9 +403,17 @@ public:
 
 private:
     void chk(int rc) { if (rc != DVO_OK) throw std::runtime_error(dvo_last_error(ctx_)); }
+    static void need(bool ok, const char *what) { if (!ok) throw std::runtime_error(what); }
+    void identityPose() { for (int k = 0; k < 9; k++) cR_64[k] = (k % 4 == 0) ? 1.0 : 0.0; cT_64[0] = cT_64[1] = cT_64[2] = 0.0; }
+    int freeSlot() const {                          /* a store slot that holds neither the reference, the now nor the n-1 frame */
+        for (int s = 0; s < 4; s++) if (s != ref_slot_ && s != now_slot_ && s != prev_slot_) return s;
+        return 3;
+    }
     dvo_ctx *ctx_ = nullptr;
     std::vector<std::vector<float>> ref_points_;
     bool isCameraIntrinsicsAvailable = false, isRefFrameAvailable = false, isNowFrameAvailable = false;
+    bool isFrameAvailable = false, refPreprocessed_ = false;
+    int rcvd_slot_ = -1, ref_slot_ = -1, now_slot_ = -1, prev_slot_ = -1;
 };
 
 /* Legacy photometric Gauss-Newton node (rgbdSubsc).  Only the class surface is kept; see SURVEY.md 2.1. */

@@ -15,7 +15,9 @@ def test_cpp_mirror_compiles_and_declares_reference_surface():
     hdr = open(os.path.join(ROOT, "include", "dvo_amd.hpp")).read()
     for name in ("class SolveDVO", "class PyramidalStorageStruct", "class RGBDOdometry", "void runIterations(",
                  "void setCameraMatrix(", "void addLevel(", "void getLevel(", "void clearPyramid(", "void eventLoop(",
-                 "iterationsConfig"):
+                 "iterationsConfig", "class GOP", "void pushAsKeyFrame(", "void pushAsOrdinaryFrame(",
+                 "void updateMostRecentToKeyFrame(", "void setRcvdFrameAsRefFrame(", "void setPrevFrameAsRefFrame(",
+                 "void setRcvdFrameAsNowFrame(", "void preProcessRefFrame(", "bool loadFromFile(", "static void printPose("):
         assert name in hdr, name
     assert os.path.exists(DEMO), "run __graft_entry__.build()"
 
