@@ -6,6 +6,7 @@
  *
  *   track_demo <dir> <start> <end> <skip> <n_levels> <fx> <fy> <cx> <cy> <iters_per_level> <poses.txt>
  */
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -26,21 +27,35 @@ int main(int argc, char **argv) {
         dvo.iterationsConfig.assign(nl, iters);
         std::ofstream poses(argv[11]);
         char name[1024];
+        double load_ms = 0, track_ms = 0;
+        long tracked = 0;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::milli>(b - a).count(); };
         for (long n = 0;; n++) {
             const int idx = start + skip * (int)n;                       /* iDataFrameNum, :1953 / :2034 */
             if (idx > end) break;
             std::snprintf(name, sizeof(name), "%s/framemono_%04d.xml", dir, idx);
+            const auto t0 = now();
             if (!dvo.loadFromFile(name, nl)) { std::fprintf(stderr, "No More files, Quitting.. (%s)\n", name); break; }
+            const auto t1 = now();
+            load_ms += ms(t0, t1);
             if (n == 0) {
                 dvo.processFirstFrame();                                 /* no pose line for the first frame, like the reference */
                 continue;
             }
             const dvo_amd::Pose p = dvo.processFrame();
             dvo_amd::SolveDVO::printPose(p, poses);
+            const double dt = ms(t1, now());
+            if (std::getenv("TRACK_DEMO_VERBOSE")) std::printf("frame %ld: %.3f ms  t = %.4f %.4f %.4f\n", n, dt, p.px, p.py, p.pz);
+            track_ms += dt;
+            tracked++;
         }
         std::printf("frames %ld keyframes:", dvo.nFrame);
         for (int i = 0; i < dvo.gop.size(); i++) if (dvo.gop.isKeyFrameAt(i)) std::printf(" %d(reason %d)", dvo.gop.getFrameNumAt(i), dvo.gop.getReasonAt(i));
         std::printf("\n");
+        if (tracked) std::printf("per frame: load+parse+upload+Canny %.3f ms, now-frame preprocessing + alignment(s) + pose %.3f ms\n",
+                                 load_ms / (tracked + 1), track_ms / tracked);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "track_demo: %s\n", e.what());
         return 1;

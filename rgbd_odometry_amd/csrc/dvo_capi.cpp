@@ -55,6 +55,7 @@ struct dvo_ctx {
     dvo_params prm;
     DevParams dprm;
     int n_pairs = 0;
+    int n_cu = 256;                 /* compute units of the device (auto tuning of launch shapes) */
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     Intrinsics K{0, 0, 0, 0, 0};
@@ -270,7 +271,10 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
             if (sc.iters[l] <= 0) continue;
             for (int p = first_pair; p < first_pair + n_pairs; p++) max_n = std::max(max_n, c->lv[l].hN[p]);
         }
-        if ((size_t)max_n * 12 <= 77000 && !c->prm.interpolate_dt) { block = 256; auto_lds = 77000; }
+        /* ... which only pays when there are enough pairs to put two workgroups on a CU: a launch of fewer pairs than
+         * half the CUs is latency-bound and 512 threads finish an iteration sooner (single pair, 320x240x4x50:
+         * 1.20 -> 1.06 ms) */
+        if ((size_t)max_n * 12 <= 77000 && !c->prm.interpolate_dt && 2 * n_pairs > c->n_cu) { block = 256; auto_lds = 77000; }
         else { block = 512; auto_lds = 155000; }
     }
     /* LDS budget of the level's resident point list */
@@ -329,6 +333,12 @@ int dvo_create_batch(const dvo_params *p, int n_pairs, dvo_ctx **out) {
     dvo_ctx *c = new dvo_ctx();
     c->prm = prm;
     c->n_pairs = n_pairs;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            c->n_cu = prop.multiProcessorCount;
+    }
     c->dprm.beta = prm.beta; c->dprm.precond_rot = prm.precond_rot; c->dprm.reg_lambda = prm.reg_lambda;
     c->dprm.step_a = prm.step_a; c->dprm.step_b = prm.step_b;
     c->dprm.trust_radius = (double)prm.trust_radius;        /* widened at use, SolveDVO.cpp:835 */
