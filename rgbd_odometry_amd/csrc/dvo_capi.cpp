@@ -554,6 +554,7 @@ int dvo_set_now_level_from_edges(dvo_ctx *c, int pair, int level, const unsigned
     if (!c) return DVO_ERR_INVALID;
     if (!pair_ok(c, pair) || !level_ok(level)) return fail(c, DVO_ERR_INVALID, "pair/level out of range");
     if (!edge || rows < 1 || cols < 1) return fail(c, DVO_ERR_INVALID, "bad image arguments");
+    if ((long long)rows + cols + 1 > 46340) return fail(c, DVO_ERR_INVALID, "image too large for the exact distance transform (rows + cols must stay below 46339)");
     int rc = ensure_texels(c, level, rows, cols);
     if (rc) return rc;
     const size_t npx = (size_t)rows * cols;
@@ -1015,6 +1016,9 @@ void frames_free(dvo_ctx *c) {
 /* make the store hold `n_levels` levels of the given geometry (drops the stored frames if it changes) */
 int frames_geometry(dvo_ctx *c, int n_levels, const int *rows, const int *cols) {
     FrameStore &S = c->fs;
+    for (int l = 0; l < n_levels; l++)      /* squared distances are kept in 32-bit integers: (rows+cols+1)^2 < 2^31 */
+        if ((long long)rows[l] + cols[l] + 1 > 46340)
+            return fail(c, DVO_ERR_INVALID, "image too large for the exact distance transform (rows + cols must stay below 46339)");
     if (S.n_slots == 0) {
         S.n_slots = frames_default_slots(c);
         S.valid.assign(S.n_slots, 0); S.has_depth.assign(S.n_slots, 0);

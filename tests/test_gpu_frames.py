@@ -66,6 +66,25 @@ def test_canny_matches_oracle(oracle, name, img):
         assert ne == int((ref > 0).sum())
 
 
+@pytest.mark.parametrize("shape", [(37, 3000), (20, 5000), (12, 9000), (6, 40000), (3000, 41), (1100, 700)])
+def test_extreme_aspect_ratios_through_every_row_pass_variant(oracle, shape):
+    """long rows exercise the 8- and 4-row LDS tiles and the global-memory fallback of the exact distance transform
+    (and 16-bit overflow of the column distances), tall images the multi-chunk column pass"""
+    rng = np.random.default_rng(shape[1])
+    img = np.kron(rng.integers(0, 2, ((shape[0] + 7) // 8, (shape[1] + 15) // 16)).astype(np.uint8) * 210 + 20,
+                  np.ones((8, 16), np.uint8))[:shape[0], :shape[1]]
+    img = np.ascontiguousarray(img)
+    img[:, : shape[1] // 3] = 128                           # a large edge-free region: long scans
+    with _ctx() as ctx:
+        ctx.frames_upload_pyramids([[(img, None)]])
+        ctx.frames_as_now(0, 0, 1)
+        edge = ctx.frame_level(0, 0, want_depth=False)[2]
+        assert np.array_equal(edge, oracle.canny(img))
+        dt, gx, gy, _ = oracle.now_level_from_grey(img)
+        for got, want in zip(ctx.get_now_level(0), (dt, gx, gy)):
+            assert np.array_equal(got, want)
+
+
 def test_canny_thresholds_from_params(oracle):
     img = oracle.bgr2gray(frame_gen.camera_frame(5, 120, 160)[0])
     with _ctx(canny_threshold1=40, canny_threshold2=90) as ctx:
@@ -184,6 +203,8 @@ def test_frame_api_errors():
     from rgbd_odometry_amd.capi import DvoError
     bgr, depth = frame_gen.camera_frame(1, 60, 80)
     with _ctx() as ctx:
+        with pytest.raises(DvoError):
+            ctx.frames_upload_pyramids([[(np.zeros((6, 66000), np.uint8), None)]])    # (rows+cols+1)^2 would overflow int32
         with pytest.raises(DvoError):
             ctx.frames_as_now(0, 0, 1)                                   # empty store
         ctx.frames_upload_cameras([bgr], None, n_levels=2, first_shift=0)
