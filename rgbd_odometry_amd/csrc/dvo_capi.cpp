@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -72,6 +73,10 @@ struct dvo_ctx {
     int *d_final_N = nullptr;
     int final_cap = 0;
     double *d_scratch = nullptr;    /* partials (1024 x 32) + acc (32) + misc doubles */
+    /* dvo_align_pyramid_wide as a replayable hipGraph (the schedule is ~2 dependent launches per iteration) */
+    hipGraphExec_t wide_exec = nullptr;
+    unsigned long long wide_sig = 0;
+    double *h_pose = nullptr;       /* pinned: in/out pose of the graph's copy nodes */
     unsigned long long *d_dbg = nullptr;
     char *d_states = nullptr;       /* n_pairs x pose_state_bytes(): host-driven iteration state */
     float *d_iter_energy = nullptr; /* n_pairs x iter_energy_cap */
@@ -395,6 +400,8 @@ int dvo_destroy(dvo_ctx *c) {
         for (void *p : fp) if (p) (void)hipFree(p);
     }
     if (c->work) (void)hipFree(c->work);
+    if (c->wide_exec) (void)hipGraphExecDestroy(c->wide_exec);
+    if (c->h_pose) (void)hipHostFree(c->h_pose);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->copy_stream2) { (void)hipStreamSynchronize(c->copy_stream2); (void)hipStreamDestroy(c->copy_stream2); }
     for (int b = 0; b < 2; b++) {
@@ -828,25 +835,54 @@ int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters,
         HIPCHK(c, hipMalloc((void **)&c->d_states, pose_state_bytes() * c->n_pairs));
         c->iter_max.assign(c->n_pairs, 0);
     }
-    double h[12];
+    if (!c->h_pose) HIPCHK(c, hipHostMalloc((void **)&c->h_pose, sizeof(double) * 12, hipHostMallocDefault));
+    double *h = c->h_pose;
     std::memcpy(h, R, sizeof(double) * 9);
     std::memcpy(h + 9, t, sizeof(double) * 3);
     double *d_pose = c->d_poses + (size_t)12 * pair;
     void *state = c->d_states + pose_state_bytes() * pair;
     double *partials = c->d_scratch;
-    HIPCHK(c, hipMemcpyAsync(d_pose, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
-    for (int l = n_levels - 1; l >= 0; --l) {                       /* :2097 */
-        if (sc.iters[l] <= 0) continue;                             /* :2099 */
-        const int N = c->lv[l].hN[pair];
-        float *energy = c->d_energy + (size_t)pair * sc.e_stride + sc.e_off[l];
-        HIPCHK(c, launch_iter_begin(state, d_pose, energy, sc.iters[l], c->stream));
-        const int nb = accumulate_blocks_for(N);
-        for (int itr = 0; itr < sc.iters[l]; itr++) {
-            HIPCHK(c, launch_iter_step_fused(slab_of(c, l), pair, l, c->K, state, c->dprm, itr, N, partials, nb, energy, c->stream));
-        }
-        HIPCHK(c, launch_iter_end(state, d_pose, c->d_best + pair * DVO_LEVELS + l, c->d_ratio + pair * DVO_LEVELS + l, c->stream));
+    /* everything the enqueued sequence depends on; an unchanged signature replays the instantiated graph */
+    unsigned long long sig = 1469598103934665603ull;
+    auto mix = [&sig](unsigned long long v) { sig = (sig ^ v) * 1099511628211ull; };
+    mix((unsigned long long)pair); mix((unsigned long long)n_levels); mix((unsigned long long)(size_t)c->stream);
+    mix((unsigned long long)(size_t)c->d_energy); mix((unsigned long long)sc.e_stride);
+    for (int l = 0; l < n_levels; l++) {
+        const LevelSlab sl = slab_of(c, l);
+        mix((unsigned long long)sc.iters[l]); mix((unsigned long long)c->lv[l].hN[pair]);
+        mix((unsigned long long)(size_t)sl.tex); mix((unsigned long long)(size_t)sl.pts); mix((unsigned long long)sl.tex_stride);
+        mix((unsigned long long)sl.pt_cap); mix((unsigned long long)sl.rows); mix((unsigned long long)sl.cols);
     }
-    HIPCHK(c, hipMemcpyAsync(h, d_pose, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    { unsigned long long kb[3] = {0, 0, 0}; std::memcpy(kb, &c->K, sizeof(c->K) < sizeof(kb) ? sizeof(c->K) : sizeof(kb)); mix(kb[0]); mix(kb[1]); mix(kb[2]); }
+    static const bool env_no_graph = std::getenv("DVO_WIDE_NO_GRAPH") != nullptr;  /* A/B switch for measurements */
+    const bool no_graph = env_no_graph || c->stream == nullptr;                    /* the legacy null stream cannot be captured */
+    if (no_graph || !c->wide_exec || sig != c->wide_sig) {
+        if (c->wide_exec) { (void)hipGraphExecDestroy(c->wide_exec); c->wide_exec = nullptr; }
+        if (!no_graph) HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        hipError_t first_err = hipSuccess;
+        auto rec = [&first_err](hipError_t e) { if (first_err == hipSuccess && e != hipSuccess) first_err = e; };
+        rec(hipMemcpyAsync(d_pose, h, sizeof(double) * 12, hipMemcpyHostToDevice, c->stream));
+        for (int l = n_levels - 1; l >= 0; --l) {                       /* :2097 */
+            if (sc.iters[l] <= 0) continue;                             /* :2099 */
+            const int N = c->lv[l].hN[pair];
+            float *energy = c->d_energy + (size_t)pair * sc.e_stride + sc.e_off[l];
+            rec(launch_iter_begin(state, d_pose, energy, sc.iters[l], c->stream));
+            const int nb = accumulate_blocks_for(N);
+            for (int itr = 0; itr < sc.iters[l]; itr++)
+                rec(launch_iter_step_fused(slab_of(c, l), pair, l, c->K, state, c->dprm, itr, N, partials, nb, energy, c->stream));
+            rec(launch_iter_end(state, d_pose, c->d_best + pair * DVO_LEVELS + l, c->d_ratio + pair * DVO_LEVELS + l, c->stream));
+        }
+        rec(hipMemcpyAsync(h, d_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, c->stream));
+        if (!no_graph) {
+            hipGraph_t graph = nullptr;
+            rec(hipStreamEndCapture(c->stream, &graph));
+            if (first_err == hipSuccess) rec(hipGraphInstantiate(&c->wide_exec, graph, nullptr, nullptr, 0));
+            if (graph) (void)hipGraphDestroy(graph);
+            c->wide_sig = sig;
+        }
+        HIPCHK(c, first_err);
+    }
+    if (!no_graph) HIPCHK(c, hipGraphLaunch(c->wide_exec, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::memcpy(R, h, sizeof(double) * 9);
     std::memcpy(t, h + 9, sizeof(double) * 3);
