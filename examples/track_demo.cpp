@@ -47,7 +47,7 @@ int main(int argc, char **argv) {
             const dvo_amd::Pose p = dvo.processFrame();
             dvo_amd::SolveDVO::printPose(p, poses);
             const double dt = ms(t1, now());
-            if (std::getenv("TRACK_DEMO_VERBOSE")) std::printf("frame %ld: %.3f ms  t = %.4f %.4f %.4f\n", n, dt, p.px, p.py, p.pz);
+            if (std::getenv("TRACK_DEMO_VERBOSE")) std::printf("frame %ld: %.3f ms (now-frame %.3f, first alignment %.3f)  t = %.4f %.4f %.4f\n", n, dt, dvo.lastNowFrameMs, dvo.lastAlignMs, p.px, p.py, p.pz);
             track_ms += dt;
             tracked++;
         }

@@ -32,6 +32,7 @@
 #ifndef DVO_AMD_HPP_
 #define DVO_AMD_HPP_
 
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -366,8 +367,13 @@ public:
     }
     /* every other frame (:2059-2241 with __NEW__REF_UPDATE): returns the latest global pose (what publishGOP hands to printPose) */
     Pose processFrame() {
+        const auto t0 = std::chrono::steady_clock::now();
         setRcvdFrameAsNowFrame();
+        const auto t1 = std::chrono::steady_clock::now();
         alignPyramid(cR_64, cT_64);                                                /* :2097-2104 (warm start from the last estimate) */
+        const auto t2 = std::chrono::steady_clock::now();
+        lastNowFrameMs = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        lastAlignMs = std::chrono::duration<double, std::milli>(t2 - t1).count();   /* jdur of :2092-2109 */
         bool signalGetNewRefImage = false;
         int reasonForChange = 0;
         if ((nFrame - lastRefFrame) == keyFrameEvery) { signalGetNewRefImage = true; reasonForChange = 5; }   /* :2155-2160 */
@@ -391,6 +397,7 @@ public:
         stream << p.qx << " " << p.qy << " " << p.qz << " " << p.qw << " " << p.px << " " << p.py << " " << p.pz << "\n";
         stream.flush();
     }
+    double lastNowFrameMs = 0, lastAlignMs = 0;                                    /* iterationsComputeTime of :2107 and its preprocessing */
     double cR_64[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, cT_64[3] = {0, 0, 0};          /* key-frame relative estimate (column-major) */
     long nFrame = 0, lastRefFrame = 0;
     int keyFrameEvery = 5;                                                         /* (nFrame - lastRefFrame) == 5  :2156 */

@@ -94,6 +94,9 @@ struct dvo_ctx {
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_copied2[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     bool up_used[2] = {false, false};
     int up_next = 0;
+    /* small batches (a single camera stream): the pyramid levels are independent kernel chains, run side by side */
+    hipStream_t lvl_stream[DVO_LEVELS] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[DVO_LEVELS] = {};
     Schedule sched{};
     bool have_sched = false;
     std::string err;
@@ -402,6 +405,11 @@ int dvo_destroy(dvo_ctx *c) {
     if (c->work) (void)hipFree(c->work);
     if (c->wide_exec) (void)hipGraphExecDestroy(c->wide_exec);
     if (c->h_pose) (void)hipHostFree(c->h_pose);
+    for (int l = 0; l < DVO_LEVELS; l++) {
+        if (c->lvl_stream[l]) { (void)hipStreamSynchronize(c->lvl_stream[l]); (void)hipStreamDestroy(c->lvl_stream[l]); }
+        if (c->ev_join[l]) (void)hipEventDestroy(c->ev_join[l]);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->copy_stream2) { (void)hipStreamSynchronize(c->copy_stream2); (void)hipStreamDestroy(c->copy_stream2); }
     for (int b = 0; b < 2; b++) {
@@ -1085,10 +1093,69 @@ int chunk_for(size_t bytes_per_image, int count) {
     return (int)std::min<size_t>(k, (size_t)count);
 }
 
-int run_canny(dvo_ctx *c, int level, int first_slot, int count) {
+/* Per-level execution lanes.  Large batches: every level on the context stream, scratch shared and chunked.
+ * Small batches (one camera stream): each level's kernel chain on its own stream with its own scratch, forked from
+ * and joined back into the context stream -- the chains are independent, so a frame costs the longest chain instead
+ * of their sum. */
+struct LevelLanes {
+    bool parallel = false;
+    hipStream_t s[DVO_LEVELS];
+    int *work[DVO_LEVELS];          /* nullptr: use c->work with chunking */
+};
+constexpr size_t kParallelPixels = (size_t)4 << 20;
+
+int lanes_begin(dvo_ctx *c, int n_levels, int count, bool with_now, LevelLanes &ln) {
+    int rc;
+    if (with_now)
+        for (int l = 0; l < n_levels; l++)
+            if ((rc = ensure_texels(c, l, c->fs.lv[l].rows, c->fs.lv[l].cols))) return rc;
+    ln.parallel = n_levels > 1 && (size_t)count * c->fs.lv[0].npx <= kParallelPixels;
+    for (int l = 0; l < n_levels; l++) { ln.s[l] = c->stream; ln.work[l] = nullptr; }
+    if (!ln.parallel) return DVO_OK;
+    size_t off[DVO_LEVELS + 1];
+    off[0] = 0;
+    for (int l = 0; l < n_levels; l++) {
+        const FrameLevel &F = c->fs.lv[l];
+        size_t need = canny_work_ints(F.rows, F.cols, count);
+        if (with_now) need = std::max(need, edt_work_ints(F.rows, F.cols, count));
+        off[l + 1] = off[l] + (need + 31) / 32 * 32;
+    }
+    if ((rc = ensure_work(c, sizeof(int) * off[n_levels]))) return rc;
+    if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    for (int l = 0; l < n_levels; l++) {
+        if (!c->lvl_stream[l]) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->lvl_stream[l], hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[l], hipEventDisableTiming));
+        }
+        ln.s[l] = c->lvl_stream[l];
+        ln.work[l] = c->work + off[l];
+    }
+    return DVO_OK;
+}
+int lanes_fork(dvo_ctx *c, int n_levels, const LevelLanes &ln) {
+    if (!ln.parallel) return DVO_OK;
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    for (int l = 0; l < n_levels; l++) HIPCHK(c, hipStreamWaitEvent(ln.s[l], c->ev_fork, 0));
+    return DVO_OK;
+}
+int lanes_join(dvo_ctx *c, int n_levels, const LevelLanes &ln) {
+    if (!ln.parallel) return DVO_OK;
+    for (int l = 0; l < n_levels; l++) {
+        HIPCHK(c, hipEventRecord(c->ev_join[l], ln.s[l]));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[l], 0));
+    }
+    return DVO_OK;
+}
+
+int run_canny(dvo_ctx *c, int level, int first_slot, int count, hipStream_t stream, int *work) {
     FrameLevel &F = c->fs.lv[level];
     int low, high;
     canny_thresholds(c, &low, &high);
+    if (work) {
+        const size_t off = (size_t)first_slot * F.npx;
+        HIPCHK(c, launch_canny(F.grey + off, F.npx, ImgBatch{F.rows, F.cols, count}, low, high, work, F.edge + off, F.npx, stream));
+        return DVO_OK;
+    }
     const int chunk = chunk_for(sizeof(int) * canny_work_ints(F.rows, F.cols, 1), count);
     int rc = ensure_work(c, sizeof(int) * canny_work_ints(F.rows, F.cols, chunk));
     if (rc) return rc;
@@ -1096,7 +1163,7 @@ int run_canny(dvo_ctx *c, int level, int first_slot, int count) {
         const int nc = std::min(chunk, count - b);
         const size_t off = (size_t)(first_slot + b) * F.npx;
         HIPCHK(c, launch_canny(F.grey + off, F.npx, ImgBatch{F.rows, F.cols, nc}, low, high, c->work,
-                               F.edge + off, F.npx, c->stream));
+                               F.edge + off, F.npx, stream));
     }
     return DVO_OK;
 }
@@ -1157,7 +1224,7 @@ size_t pix_bytes(int dtype) { return dtype == DVO_PIX_U8 ? 1 : (dtype == DVO_PIX
 
 }  // namespace
 
-static int frames_as_now_range(dvo_ctx *c, int first_slot, int first_pair, int count);
+static int frames_as_now_level(dvo_ctx *c, int level, int first_slot, int first_pair, int count, hipStream_t stream, int *work);
 
 int dvo_frames_reserve(dvo_ctx *c, int n_slots) {
     if (!c) return DVO_ERR_INVALID;
@@ -1224,20 +1291,35 @@ int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_leve
                                              hipMemcpyHostToDevice, cs));
             }
         }
+        LevelLanes ln;
+        if ((rc = lanes_begin(c, n_levels, nc, now_first_pair >= 0, ln))) return rc;
         if ((rc = upload_copied(c, ub))) return rc;
-        for (int l = 0; l < n_levels; l++) {
-            FrameLevel &F = c->fs.lv[l];
-            const size_t off = (size_t)(first_slot + b) * F.npx;
-            const ImgBatch ib{F.rows, F.cols, nc};
-            HIPCHK(c, launch_import_grey(buf + g_off[l], grey[l].dtype, grey[l].layout == DVO_LAYOUT_ROW_MAJOR,
-                                         g_img[l] / pix_bytes(grey[l].dtype), F.grey + off, F.npx, ib, c->stream));
-            if (depth)
-                HIPCHK(c, launch_import_depth(buf + d_off[l], depth[l].dtype, depth[l].layout == DVO_LAYOUT_ROW_MAJOR,
-                                              d_img[l] / pix_bytes(depth[l].dtype), F.depth + off, F.npx, ib, c->stream));
+        if ((rc = lanes_fork(c, n_levels, ln))) return rc;
+        for (int pass = 0; pass < 2; pass++) {              /* sequential lanes: all imports, then release the landing buffer, then the rest */
+            for (int l = 0; l < n_levels; l++) {
+                FrameLevel &F = c->fs.lv[l];
+                const size_t off = (size_t)(first_slot + b) * F.npx;
+                const ImgBatch ib{F.rows, F.cols, nc};
+                if (pass == 0 || ln.parallel) {
+                    HIPCHK(c, launch_import_grey(buf + g_off[l], grey[l].dtype, grey[l].layout == DVO_LAYOUT_ROW_MAJOR,
+                                                 g_img[l] / pix_bytes(grey[l].dtype), F.grey + off, F.npx, ib, ln.s[l]));
+                    if (depth)
+                        HIPCHK(c, launch_import_depth(buf + d_off[l], depth[l].dtype, depth[l].layout == DVO_LAYOUT_ROW_MAJOR,
+                                                      d_img[l] / pix_bytes(depth[l].dtype), F.depth + off, F.npx, ib, ln.s[l]));
+                }
+                if (pass == 1 || ln.parallel) {
+                    if ((rc = run_canny(c, l, first_slot + b, nc, ln.s[l], ln.work[l]))) return rc;
+                    if (now_first_pair >= 0 &&
+                        (rc = frames_as_now_level(c, l, first_slot + b, now_first_pair + b, nc, ln.s[l], ln.work[l]))) return rc;
+                }
+            }
+            if (ln.parallel) break;
+            if (pass == 0 && (rc = upload_consumed(c, ub))) return rc;
         }
-        if ((rc = upload_consumed(c, ub))) return rc;
-        for (int l = 0; l < n_levels; l++) if ((rc = run_canny(c, l, first_slot + b, nc))) return rc;
-        if (now_first_pair >= 0 && (rc = frames_as_now_range(c, first_slot + b, now_first_pair + b, nc))) return rc;
+        if (ln.parallel) {
+            if ((rc = lanes_join(c, n_levels, ln))) return rc;
+            if ((rc = upload_consumed(c, ub))) return rc;
+        }
     }
     for (int f = 0; f < count; f++) { c->fs.valid[first_slot + f] = 1; c->fs.has_depth[first_slot + f] = depth ? 1 : 0; }
     if (!(flags & DVO_UPLOAD_ASYNC)) HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1278,16 +1360,30 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
             HIPCHK(c, hipMemcpyAsync(sb + b_img * i, bgr8[b + i], npx * 3, hipMemcpyHostToDevice, cs));
             if (depth_m) HIPCHK(c, hipMemcpyAsync(sd + npx * i, depth_m[b + i], npx * 4, hipMemcpyHostToDevice, cs));
         }
+        LevelLanes ln;
+        if ((rc = lanes_begin(c, n_levels, nc, now_first_pair >= 0, ln))) return rc;
         if ((rc = upload_copied(c, ub))) return rc;
-        for (int l = 0; l < n_levels; l++) {
-            FrameLevel &F = c->fs.lv[l];
-            const size_t off = (size_t)(first_slot + b) * F.npx;
-            HIPCHK(c, launch_camera_level(sb, b_img, depth_m ? sd : nullptr, npx, rows, cols, first_shift + l,
-                                          F.grey + off, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, nc}, c->stream));
+        if ((rc = lanes_fork(c, n_levels, ln))) return rc;
+        for (int pass = 0; pass < 2; pass++) {
+            for (int l = 0; l < n_levels; l++) {
+                FrameLevel &F = c->fs.lv[l];
+                const size_t off = (size_t)(first_slot + b) * F.npx;
+                if (pass == 0 || ln.parallel)
+                    HIPCHK(c, launch_camera_level(sb, b_img, depth_m ? sd : nullptr, npx, rows, cols, first_shift + l,
+                                                  F.grey + off, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, nc}, ln.s[l]));
+                if (pass == 1 || ln.parallel) {
+                    if ((rc = run_canny(c, l, first_slot + b, nc, ln.s[l], ln.work[l]))) return rc;
+                    if (now_first_pair >= 0 &&
+                        (rc = frames_as_now_level(c, l, first_slot + b, now_first_pair + b, nc, ln.s[l], ln.work[l]))) return rc;
+                }
+            }
+            if (ln.parallel) break;
+            if (pass == 0 && (rc = upload_consumed(c, ub))) return rc;
         }
-        if ((rc = upload_consumed(c, ub))) return rc;
-        for (int l = 0; l < n_levels; l++) if ((rc = run_canny(c, l, first_slot + b, nc))) return rc;
-        if (now_first_pair >= 0 && (rc = frames_as_now_range(c, first_slot + b, now_first_pair + b, nc))) return rc;
+        if (ln.parallel) {
+            if ((rc = lanes_join(c, n_levels, ln))) return rc;
+            if ((rc = upload_consumed(c, ub))) return rc;
+        }
     }
     for (int f = 0; f < count; f++) { c->fs.valid[first_slot + f] = 1; c->fs.has_depth[first_slot + f] = depth_m ? 1 : 0; }
     if (!(flags & DVO_UPLOAD_ASYNC)) HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1305,21 +1401,24 @@ static int frames_check_use(dvo_ctx *c, int first_slot, int first_pair, int coun
     return DVO_OK;
 }
 
-static int frames_as_now_range(dvo_ctx *c, int first_slot, int first_pair, int count) {
+static int frames_as_now_level(dvo_ctx *c, int l, int first_slot, int first_pair, int count, hipStream_t stream, int *work) {
     int rc;
-    for (int l = 0; l < c->fs.n_levels; l++) {
-        FrameLevel &F = c->fs.lv[l];
-        if ((rc = ensure_texels(c, l, F.rows, F.cols))) return rc;
-        Level &L = c->lv[l];
+    FrameLevel &F = c->fs.lv[l];
+    if ((rc = ensure_texels(c, l, F.rows, F.cols))) return rc;
+    Level &L = c->lv[l];
+    if (work) {
+        HIPCHK(c, launch_edges_to_texels(F.edge + (size_t)first_slot * F.npx, F.npx, ImgBatch{F.rows, F.cols, count}, work,
+                                         L.tex + (size_t)first_pair * L.tex_stride, L.tex_stride, stream));
+    } else {
         const int chunk = chunk_for(sizeof(int) * edt_work_ints(F.rows, F.cols, 1), count);
         if ((rc = ensure_work(c, sizeof(int) * edt_work_ints(F.rows, F.cols, chunk)))) return rc;
         for (int b = 0; b < count; b += chunk) {
             const int nc = std::min(chunk, count - b);
             HIPCHK(c, launch_edges_to_texels(F.edge + (size_t)(first_slot + b) * F.npx, F.npx, ImgBatch{F.rows, F.cols, nc},
-                                             c->work, L.tex + (size_t)(first_pair + b) * L.tex_stride, L.tex_stride, c->stream));
+                                             c->work, L.tex + (size_t)(first_pair + b) * L.tex_stride, L.tex_stride, stream));
         }
-        for (int i = 0; i < count; i++) L.have_now[first_pair + i] = 1;
     }
+    for (int i = 0; i < count; i++) L.have_now[first_pair + i] = 1;
     return DVO_OK;
 }
 
@@ -1327,7 +1426,13 @@ int dvo_frames_as_now(dvo_ctx *c, int first_slot, int first_pair, int count) {
     if (!c) return DVO_ERR_INVALID;
     int rc = frames_check_use(c, first_slot, first_pair, count, false);
     if (rc) return rc;
-    return frames_as_now_range(c, first_slot, first_pair, count);
+    const int nl = c->fs.n_levels;
+    LevelLanes ln;
+    if ((rc = lanes_begin(c, nl, count, true, ln))) return rc;
+    if ((rc = lanes_fork(c, nl, ln))) return rc;
+    for (int l = 0; l < nl; l++)
+        if ((rc = frames_as_now_level(c, l, first_slot, first_pair, count, ln.s[l], ln.work[l]))) return rc;
+    return lanes_join(c, nl, ln);
 }
 
 int dvo_frames_as_ref(dvo_ctx *c, int first_slot, int first_pair, int count, int *N_out) {
