@@ -46,11 +46,14 @@ def test_struct_layout_matches_header():
     import subprocess, tempfile
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "s.c")
-        open(src, "w").write('#include <stdio.h>\n#include "dvo_amd.h"\nint main(){printf("%zu", sizeof(dvo_params));return 0;}')
+        open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "dvo_amd.h"\nint main(){printf("%zu %zu %zu %zu", '
+                             'sizeof(dvo_params), sizeof(dvo_image), offsetof(dvo_image, dtype), offsetof(dvo_params, canny_threshold1));return 0;}')
         exe = os.path.join(d, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
-        size = int(subprocess.check_output([exe]))
+        size, img_size, img_dtype_off, canny_off = (int(x) for x in subprocess.check_output([exe]).split())
     assert ctypes.sizeof(capi.DvoParams) == size
+    assert ctypes.sizeof(capi.DvoImage) == img_size and capi.DvoImage.dtype.offset == img_dtype_off
+    assert capi.DvoParams.canny_threshold1.offset == canny_off
 
 
 def test_no_device_fails_loudly():
