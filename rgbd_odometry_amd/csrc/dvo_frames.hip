@@ -15,7 +15,8 @@
  *                         union-find over the candidate pixels (order-independent, so identical to
  *                         the sequential stack walk of the CPU implementation)
  *   edt_* / dt_*          distanceTransform(L2, PRECISE) -> normalize(0,255,MINMAX) -> [-.5 0 .5]
- *                         gradients -> texels (src/SolveDVO.cpp:1768-1795, :1063-1098)
+ *                         gradients -> texels (src/SolveDVO.cpp:1768-1795, :1063-1098); normalise, gradients
+ *                         and the texel store are one kernel
  *   enlist_*              selectedPts + enlistRefEdgePts (src/SolveDVO.cpp:1230-1264, :224-264)
  */
 #include "dvo_launch.h"
@@ -122,33 +123,56 @@ DVO_DEV float depth_m_to_mm(float d_m) {
     return r == 0.0f ? 1.0f : r;                                     /* setTo(1, depth16==0)           :77 */
 }
 
+/* One 64 (yy) x 16 (xx) output tile per workgroup: the row-major source is read along rows (16 neighbouring lanes =
+ * 16 neighbouring source pixels), the column-major result is written along columns (64 neighbouring lanes = 64
+ * consecutive bytes / floats) -- the transpose goes through LDS instead of through uncoalesced global accesses. */
+constexpr int CAM_TY = 64, CAM_TX = 16;
 __global__ void __launch_bounds__(256)
 camera_level_kernel(const unsigned char *__restrict__ bgr, size_t bgr_stride,
                     const float *__restrict__ depth_m, size_t depth_stride,
-                    int src_rows, int src_cols, int shift,
+                    int src_rows, int src_cols, int shift, int tiles_y,
                     unsigned char *__restrict__ grey, float *__restrict__ depth, size_t stride, int rows, int cols) {
-    const size_t n = (size_t)rows * cols;
+    __shared__ unsigned char sg[CAM_TX][CAM_TY + 4];
+    __shared__ float sd[CAM_TX][CAM_TY + 1];
     bgr += (size_t)blockIdx.y * bgr_stride;
     grey += (size_t)blockIdx.y * stride;
     if (depth_m) { depth_m += (size_t)blockIdx.y * depth_stride; depth += (size_t)blockIdx.y * stride; }
-    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
-        const int xx = (int)(p / rows), yy = (int)(p - (size_t)xx * rows);
-        int sy = yy << shift, sx = xx << shift;                      /* resizeNN: min(floor(x/scale), size-1) */
-        sy = sy > src_rows - 1 ? src_rows - 1 : sy;
-        sx = sx > src_cols - 1 ? src_cols - 1 : sx;
-        const size_t sp = (size_t)sy * src_cols + sx;
-        const int b = bgr[3 * sp], gg = bgr[3 * sp + 1], r = bgr[3 * sp + 2];
-        grey[p] = (unsigned char)((1868 * b + 9617 * gg + 4899 * r + (1 << 13)) >> 14);   /* BGR2GRAY 8u */
-        if (depth_m) depth[p] = depth_m_to_mm(depth_m[sp]);
+    const int y0 = (blockIdx.x % tiles_y) * CAM_TY, x0 = (blockIdx.x / tiles_y) * CAM_TX;
+#pragma unroll
+    for (int k = 0; k < CAM_TY * CAM_TX / 256; k++) {
+        const int p = threadIdx.x + k * 256;
+        const int lx = p % CAM_TX, ly = p / CAM_TX;
+        const int yy = y0 + ly, xx = x0 + lx;
+        if (yy < rows && xx < cols) {
+            int sy = yy << shift, sx = xx << shift;                  /* resizeNN: min(floor(x/scale), size-1) */
+            sy = sy > src_rows - 1 ? src_rows - 1 : sy;
+            sx = sx > src_cols - 1 ? src_cols - 1 : sx;
+            const size_t sp = (size_t)sy * src_cols + sx;
+            const int b = bgr[3 * sp], gg = bgr[3 * sp + 1], r = bgr[3 * sp + 2];
+            sg[lx][ly] = (unsigned char)((1868 * b + 9617 * gg + 4899 * r + (1 << 13)) >> 14);   /* BGR2GRAY 8u */
+            if (depth_m) sd[lx][ly] = depth_m_to_mm(depth_m[sp]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CAM_TY * CAM_TX / 256; k++) {
+        const int p = threadIdx.x + k * 256;
+        const int ly = p % CAM_TY, lx = p / CAM_TY;
+        const int yy = y0 + ly, xx = x0 + lx;
+        if (yy < rows && xx < cols) {
+            const size_t o = (size_t)xx * rows + yy;
+            grey[o] = sg[lx][ly];
+            if (depth_m) depth[o] = sd[lx][ly];
+        }
     }
 }
 
 hipError_t launch_camera_level(const unsigned char *bgr, size_t bgr_stride, const float *depth_m, size_t depth_stride,
                                int src_rows, int src_cols, int shift, unsigned char *grey, float *depth_mm,
                                size_t stride, ImgBatch g, hipStream_t s) {
-    const size_t n = (size_t)g.rows * g.cols;
-    hipLaunchKernelGGL(camera_level_kernel, dim3(grid_x(n), g.count), dim3(256), 0, s, bgr, bgr_stride, depth_m,
-                       depth_stride, src_rows, src_cols, shift, grey, depth_mm, stride, g.rows, g.cols);
+    const int tiles_y = (g.rows + CAM_TY - 1) / CAM_TY, tiles_x = (g.cols + CAM_TX - 1) / CAM_TX;
+    hipLaunchKernelGGL(camera_level_kernel, dim3(tiles_y * tiles_x, g.count), dim3(256), 0, s, bgr, bgr_stride, depth_m,
+                       depth_stride, src_rows, src_cols, shift, tiles_y, grey, depth_mm, stride, g.rows, g.cols);
     return hipGetLastError();
 }
 
@@ -467,14 +491,26 @@ edt_rows_kernel(const int *__restrict__ g, int rows, int cols, int *__restrict__
     if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = mx;
 }
 
-/* raw distance -> normalised [0,255] float, in place (the int buffer is reused as float).  An image without any
- * edge pixel (every distance "infinite") normalises to all zeros, as cv::normalize does for a constant image. */
+DVO_DEV int reflect101(int i, int n) { return (n == 1) ? 0 : (i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i)); }
+
+/* squared distances -> texels in one pass: min-max normalise to [0,255] (cv::normalize NORM_MINMAX, :1774; an image
+ * without any edge pixel -- every distance "infinite" -- normalises to all zeros, as a constant image does), central
+ * differences with a reflect-101 border (:1077-1090), weight, tiled store.  One 64 (yy) x 16 (xx) tile per workgroup:
+ * the normalised values of the tile and its 1-pixel halo are computed once into LDS (one double sqrt per pixel); the
+ * lanes are then mapped so that 8 consecutive lanes write one whole 128-byte texel tile. */
+constexpr int NP_TY = 64, NP_TX = 16;
+static_assert(DVO_TILE_Y_LOG2 == 2 && DVO_TILE_X_LOG2 == 1, "the store mapping below assumes 4 x 2 texel tiles");
 __global__ void __launch_bounds__(256)
-dt_normalize_kernel(int *__restrict__ d2_inout, int rows, int cols, const int *__restrict__ partial, int n_partial) {
-    const size_t n = (size_t)rows * cols;
-    d2_inout += (size_t)blockIdx.y * n;
-    partial += (size_t)blockIdx.y * n_partial;
+dt_normalize_gradient_pack_kernel(const int *__restrict__ d2, int rows, int cols, int tiles_y,
+                                  const int *__restrict__ partial, int n_partial,
+                                  float4 *__restrict__ out, size_t tex_stride) {
+    constexpr int SH = NP_TY + 2, SW = NP_TX + 2;
+    __shared__ float sn[SW * SH];                            /* [x][y], halo 1 */
     __shared__ int s_max;
+    const size_t n = (size_t)rows * cols;
+    d2 += (size_t)blockIdx.y * n;
+    partial += (size_t)blockIdx.y * n_partial;
+    out += (size_t)blockIdx.y * tex_stride;
     int m = 0;
     for (int k = threadIdx.x; k < n_partial; k += 256) { const int v = partial[k]; m = v > m ? v : m; }
     m = block_reduce_256<true>(m);
@@ -483,28 +519,33 @@ dt_normalize_kernel(int *__restrict__ d2_inout, int rows, int cols, const int *_
     const int INF = DVO_EDT_INF(rows, cols);
     const int m2 = s_max;
     const float mxf = (float)sqrt((double)m2), mnf = 0.0f;
-    const double scale = (mxf > mnf && m2 < INF * INF) ? 255.0 / ((double)mxf - (double)mnf) : 0.0;   /* cv::normalize NORM_MINMAX, :1774 */
-    float *out = reinterpret_cast<float *>(d2_inout);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float raw = (float)sqrt((double)d2_inout[i]);
-        out[i] = (float)(((double)raw - (double)mnf) * scale);
+    const double scale = (mxf > mnf && m2 < INF * INF) ? 255.0 / ((double)mxf - (double)mnf) : 0.0;
+    const int y0 = (blockIdx.x % tiles_y) * NP_TY, x0 = (blockIdx.x / tiles_y) * NP_TX;
+    for (int idx = threadIdx.x; idx < SW * SH; idx += 256) {
+        const int lx = idx / SH, ly = idx - lx * SH;
+        int yy = y0 + ly - 1, xx = x0 + lx - 1;
+        float v = 0.0f;
+        if (yy <= rows && xx <= cols) {                      /* one pixel beyond the image is the reflected neighbour */
+            yy = reflect101(yy, rows); xx = reflect101(xx, cols);
+            const float raw = (float)sqrt((double)d2[(size_t)xx * rows + yy]);
+            v = (float)(((double)raw - (double)mnf) * scale);
+        }
+        sn[idx] = v;
     }
-}
-
-DVO_DEV int reflect101(int i, int n) { return (n == 1) ? 0 : (i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i)); }
-
-__global__ void __launch_bounds__(256)
-dt_gradient_pack_kernel(const float *__restrict__ dt, int rows, int cols, float4 *__restrict__ out, size_t tex_stride) {
-    const size_t n = (size_t)rows * cols;
-    dt += (size_t)blockIdx.y * n;
-    out += (size_t)blockIdx.y * tex_stride;
+    __syncthreads();
     const int tpc = texel_tiles_per_col(rows);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int xx = (int)(i / rows), yy = (int)(i - (size_t)xx * rows);
-        const float l_ = dt[(size_t)reflect101(xx - 1, cols) * rows + yy], r_ = dt[(size_t)reflect101(xx + 1, cols) * rows + yy];
-        const float u_ = dt[(size_t)xx * rows + reflect101(yy - 1, rows)], b_ = dt[(size_t)xx * rows + reflect101(yy + 1, rows)];
-        const float v = dt[i];
-        out[texel_index(yy, xx, tpc)] = make_float4(v, 0.5f * r_ - 0.5f * l_, 0.5f * b_ - 0.5f * u_, weight_of(v));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int t = it * 32 + wave * 8 + (lane >> 3);     /* texel tile of this 8-lane group: 8 column pairs x 16 row groups */
+        const int cp = t >> 4, rg = t & 15;
+        const int ly = rg * 4 + (lane & 3), lx = cp * 2 + ((lane >> 2) & 1);
+        const int yy = y0 + ly, xx = x0 + lx;
+        if (yy < rows && xx < cols) {
+            const float *c = sn + (lx + 1) * SH + (ly + 1);
+            const float v = c[0];
+            out[texel_index(yy, xx, tpc)] = make_float4(v, 0.5f * c[SH] - 0.5f * c[-SH], 0.5f * c[1] - 0.5f * c[-1], weight_of(v));
+        }
     }
 }
 
@@ -534,9 +575,9 @@ hipError_t launch_edges_to_texels(const unsigned char *edge, size_t edge_stride,
     else if (R == 8) hipLaunchKernelGGL(edt_rows_lds_kernel<8>, dim3(nblk, gb.count), dim3(256), lds, s, g, gb.rows, gb.cols, d2, partial);
     else if (R == 4) hipLaunchKernelGGL(edt_rows_lds_kernel<4>, dim3(nblk, gb.count), dim3(256), lds, s, g, gb.rows, gb.cols, d2, partial);
     else hipLaunchKernelGGL(edt_rows_kernel, grid, dim3(256), 0, s, g, gb.rows, gb.cols, d2, partial);
-    hipLaunchKernelGGL(dt_normalize_kernel, grid, dim3(256), 0, s, d2, gb.rows, gb.cols, partial, (int)nblk);
-    hipLaunchKernelGGL(dt_gradient_pack_kernel, grid, dim3(256), 0, s,
-                       reinterpret_cast<const float *>(d2), gb.rows, gb.cols, tex_out, tex_stride);
+    const int tiles_y = (gb.rows + NP_TY - 1) / NP_TY, tiles_x = (gb.cols + NP_TX - 1) / NP_TX;
+    hipLaunchKernelGGL(dt_normalize_gradient_pack_kernel, dim3(tiles_y * tiles_x, gb.count), dim3(256), 0, s, d2, gb.rows, gb.cols,
+                       tiles_y, partial, (int)nblk, tex_out, tex_stride);
     return hipGetLastError();
 }
 hipError_t launch_now_level_from_edges(const unsigned char *edge, int rows, int cols, int *work, float4 *tex_out, hipStream_t s) {
