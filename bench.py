@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--inflight", type=int, default=0, help="points in flight per lane (1/2/4; 0 = default)")
     ap.add_argument("--lds-point-bytes", type=int, default=0, help="LDS bytes per workgroup for resident points (0 auto, <0 none)")
     ap.add_argument("--debug-alias", type=int, default=0, help="diagnostics: pair p reads data of pair p %% N")
+    ap.add_argument("--no-frames-leg", action="store_true",
+                    help="skip the extra (never `value`) measurement of camera frames in host memory -> poses out")
     return ap.parse_args()
 
 
@@ -112,6 +114,57 @@ def cpu_baseline_all_cores(args, iters, budget_s):
     rate = sum(n / t for n, t in res)
     return dict(value=rate, unit="aligns/s", cores=cores, kind="port",
                 sample=f"{sum(n for n, _ in res)} alignments, one oracle process per host core for {budget_s:.0f} s each")
+
+
+def frames_leg(args, iters):
+    """Rows f1+f2, reported next to the headline and never as `value`: the same workload fed from camera frames in
+    (pinned) HOST memory -- BGR8 + depth uploaded over PCIe, pyramid / Canny / distance transform / point extraction
+    on the GPU -- to poses on the host.  Bounded: 256 pairs, 3 repetitions."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import frame_gen
+    from rgbd_odometry_amd import DvoContext
+    from rgbd_odometry_amd.capi import DVO_FLAG_IDENTITY_START, DVO_UPLOAD_ASYNC
+    B, D = 256, 8
+
+    def pin(a):
+        t = torch.empty(a.shape, dtype=torch.from_numpy(a).dtype, pin_memory=True)
+        t.numpy()[...] = a
+        return t.numpy()
+    ref = [tuple(pin(x) for x in frame_gen.camera_frame(100 + i, args.height, args.width)) for i in range(D)]
+    now = [pin(frame_gen.camera_frame(100 + i, args.height, args.width, shift=(1 + i % 2, -2))[0]) for i in range(D)]
+    ref_b, ref_d = [ref[i % D][0] for i in range(B)], [ref[i % D][1] for i in range(B)]
+    now_b = [now[i % D] for i in range(B)]
+    ctx = DvoContext(B)
+    s = args.width / 640.0
+    ctx.set_intrinsics(525.0 * s, 525.0 * s, 319.5 * s, 239.5 * args.height / 480.0)
+    ctx.frames_reserve(2 * B)
+    kw = dict(n_levels=args.levels, first_shift=0, flags=DVO_UPLOAD_ASYNC)
+
+    def pair_step():
+        ctx.frames_upload_cameras(ref_b, ref_d, first_slot=0, **kw)
+        ctx.frames_upload_cameras(now_b, None, first_slot=B, **kw)
+        ctx.frames_as_ref(0, 0, B)
+        ctx.frames_as_now(B, 0, B)
+        ctx.enqueue(iters, flags=DVO_FLAG_IDENTITY_START)
+        return ctx.get_poses()
+
+    def now_step():
+        ctx.frames_upload_cameras(now_b, None, first_slot=B, **kw)
+        ctx.frames_as_now(B, 0, B)
+        ctx.enqueue(iters, flags=DVO_FLAG_IDENTITY_START)
+        return ctx.get_poses()
+    out = {}
+    for name, fn in (("frame_pairs_per_s", pair_step), ("now_frames_per_s_reference_resident", now_step)):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fn()
+        out[name] = 3 * B / (time.perf_counter() - t0)
+    out["note"] = ("PCIe-inclusive, never `value`: %dx%d BGR8 (+ depth f32 for reference frames) in pinned host memory -> "
+                   "pyramid, Canny, distance transform, edge points on the GPU -> %s iterations -> poses on the host; "
+                   "batches of %d" % (args.width, args.height, iters, B))
+    ctx.close()
+    return out
 
 
 def main():
@@ -223,6 +276,12 @@ def main():
                 "trans_err_m": float(np.linalg.norm(ref["t"] - t[0])),
                 "tolerance": "1e-5 rad / 1e-4 m",
             }
+        if world == 1 and not args.no_frames_leg:
+            ctx.close()                                  # release the resident batch before the extra leg
+            try:
+                out["frames_in"] = frames_leg(args, iters)
+            except Exception as e:                       # the extra leg must never cost the headline line
+                out["frames_in"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:
