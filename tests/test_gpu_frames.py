@@ -85,6 +85,33 @@ def test_extreme_aspect_ratios_through_every_row_pass_variant(oracle, shape):
             assert np.array_equal(got, want)
 
 
+def test_canny_random_stress(oracle):
+    """many random sizes and textures, batched, so that the tile-local and the cross-tile union-find meet every border case"""
+    rng = np.random.default_rng(2024)
+    for trial in range(12):
+        rows, cols = int(rng.integers(2, 200)), int(rng.integers(2, 260))
+        batch = []
+        for k in range(6):
+            kind = (trial + k) % 4
+            if kind == 0:
+                img = rng.integers(0, 256, (rows, cols))
+            elif kind == 1:                                        # blocky: long chains across tiles
+                b = int(rng.integers(2, 9))
+                img = np.kron(rng.integers(0, 2, ((rows + b - 1) // b, (cols + b - 1) // b)) * 200 + 20, np.ones((b, b), np.int64))[:rows, :cols]
+            elif kind == 2:                                        # smooth + noise near the thresholds
+                yy, xx = np.mgrid[0:rows, 0:cols]
+                img = 128 + 60 * np.sin(xx / 3.0) * np.cos(yy / 2.5) + rng.integers(-12, 13, (rows, cols))
+            else:                                                  # sparse spikes
+                img = np.full((rows, cols), 40); img[rng.random((rows, cols)) < 0.05] = 255
+            batch.append(np.clip(img, 0, 255).astype(np.uint8))
+        with _ctx(6) as ctx:
+            ctx.frames_reserve(6)
+            ctx.frames_upload_pyramids([[(im, None)] for im in batch])
+            for k, im in enumerate(batch):
+                edge = ctx.frame_level(k, 0, want_depth=False)[2]
+                assert np.array_equal(edge, oracle.canny(im)), (trial, k, rows, cols)
+
+
 def test_canny_thresholds_from_params(oracle):
     img = oracle.bgr2gray(frame_gen.camera_frame(5, 120, 160)[0])
     with _ctx(canny_threshold1=40, canny_threshold2=90) as ctx:
