@@ -211,6 +211,28 @@ def test_batched_calls_equal_single_calls(oracle):
                 assert np.array_equal(ea["reproj"], eb["reproj"]) and np.array_equal(ea["eps"], eb["eps"])
 
 
+def test_uploads_spanning_several_landing_buffers(oracle):
+    """40 camera frames of 2.15 MB cross the 32 MB landing buffers three times (copy streams, events, both buffers)"""
+    distinct = [frame_gen.camera_frame(60 + i, 480, 640) for i in range(4)]
+    n = 40
+    with _ctx(n) as ctx, _ctx(1) as one:
+        ctx.frames_reserve(n)
+        ctx.frames_upload_cameras([distinct[i % 4][0] for i in range(n)], [distinct[i % 4][1] for i in range(n)],
+                                  n_levels=3, first_shift=0, now_first_pair=0)
+        want = {}
+        for i in range(4):
+            one.frames_upload_cameras([distinct[i][0]], [distinct[i][1]], n_levels=3, first_shift=0)
+            one.frames_as_now(0, 0, 1)
+            want[i] = ([one.frame_level(0, l)[:3] for l in range(3)], [one.get_now_level(l) for l in range(3)])
+        for slot in (0, 1, 13, 14, 15, 16, 28, 29, 30, 39):
+            lv, nw = want[slot % 4]
+            for l in range(3):
+                for x, y in zip(ctx.frame_level(slot, l)[:3], lv[l]):
+                    assert np.array_equal(x, y), (slot, l)
+                for x, y in zip(ctx.get_now_level(l, pair=slot), nw[l]):
+                    assert np.array_equal(x, y), (slot, l)
+
+
 def test_prev_now_frame_becomes_reference_without_upload(oracle):
     """setPrevFrameAsRefFrame (SolveDVO.cpp:559-583): a stored frame serves as now frame, then as reference"""
     K = tuple(float(k) * 0.5 for k in K640)
