@@ -260,6 +260,15 @@ def main():
                 if key in rec and default_knobs:
                     out["roofline"]["traffic"] = rec[key]["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = rec[key].get("source")
+                    if rec[key].get("l2_read_requests"):
+                        # the ceiling this kernel actually sits at: L2 -> fabric read requests
+                        rate = rec[key]["l2_read_requests"] / (kernel_ms * 1e-3) / 1e9
+                        out["roofline"]["request_rate"] = {
+                            "achieved_G_req_per_s": rate, "calibrated_ceiling_G_req_per_s": [44.0, 50.0],
+                            "frac_of_ceiling": rate / 47.0,
+                            "note": "TCC_EA0_RDREQ per launch (PMC profile) / live kernel time; ceiling measured by "
+                                    "tools/exhaustive/fetch_calib.hip (profiles/r01_fetch_size_calibration), same for 64- and 128-byte requests",
+                        }
             except Exception:
                 pass
         if world == 1 and args.cpu_seconds > 0:
