@@ -455,11 +455,19 @@ edt_rows_lds_kernel(const int *__restrict__ g, int rows, int cols, int *__restri
         if (yy >= rows) continue;
         const int g0 = tile[idx];
         int best = g0 * g0;                                   /* (rows+cols+1)^2 < 2^31 for every supported size */
-        for (int i = 1; i * i < best; i++) {
-            const bool l = xx - i >= 0, rr = xx + i < cols;
-            if (!l && !rr) break;
-            if (l) { const int gl = tile[idx - i * R]; const int c = i * i + gl * gl; best = c < best ? c : best; }
-            if (rr) { const int gr = tile[idx + i * R]; const int c = i * i + gr * gr; best = c < best ? c : best; }
+        /* Branch-free steps: an index that leaves the row is clamped to its end.  The clamped candidate
+         * i^2 + g(end)^2 can only exceed the one the end pixel produced at its true distance, so the minimum is
+         * unchanged, and the loop needs no per-side exec masking. */
+        const int imax = (xx > cols - 1 - xx) ? xx : cols - 1 - xx;
+        const int base = idx - xx * R;                        /* LDS index of (column 0, this row) */
+        int i2 = 1;
+        for (int i = 1; i2 < best && i <= imax; i++) {
+            const int xl = (xx - i > 0) ? xx - i : 0, xr = (xx + i < cols - 1) ? xx + i : cols - 1;
+            const int gl = tile[base + xl * R], gr = tile[base + xr * R];
+            const int cl = i2 + gl * gl, cr = i2 + gr * gr;
+            best = cl < best ? cl : best;
+            best = cr < best ? cr : best;
+            i2 += 2 * i + 1;
         }
         d2[(size_t)xx * rows + yy] = best;
         mx = best > mx ? best : mx;
