@@ -237,7 +237,7 @@ def main():
                             (args.width, args.height, args.levels, args.iters, args.batch, len(scenes)),
                 "pairs_per_gpu": args.batch, "iters_per_level": iters,
                 "final_outputs": not args.no_final_outputs,
-                "block_threads": args.block or "auto (512 when a level's point list exceeds 77 KB, else 256)",
+                "block_threads": args.block or "auto (256 for short point lists in large batches, 1024 for lists over 620 KB, else 512)",
                 "points_in_flight": args.inflight or 1,
                 **({"debug_alias_mod": args.debug_alias} if args.debug_alias else {}),
                 "point_iterations_per_launch": point_iters,
