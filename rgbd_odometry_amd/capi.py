@@ -193,6 +193,7 @@ class DvoContext:
         self.n_pairs = int(n_pairs)
         self._N = {}      # (pair, level) -> N
         self._dims = {}   # level -> (rows, cols)
+        self._frame_keep = []   # host buffers borrowed by DVO_UPLOAD_ASYNC uploads, released at the next synchronisation
 
     # -- plumbing -----------------------------------------------------------
     def _chk(self, rc: int):
@@ -224,6 +225,7 @@ class DvoContext:
 
     def synchronize(self):
         self._chk(self.lib.dvo_synchronize(self._h))
+        self._frame_keep.clear()
 
     # -- inputs -------------------------------------------------------------
     def set_intrinsics(self, fx, fy, cx, cy):
@@ -337,6 +339,7 @@ class DvoContext:
         Rc = np.zeros((n_pairs, 3, 3))
         tc = np.zeros((n_pairs, 3))
         self._chk(self.lib.dvo_get_poses(self._h, first_pair, n_pairs, _ptr(Rc), _ptr(tc)))
+        self._frame_keep.clear()          # dvo_get_poses synchronises the context stream
         return np.transpose(Rc, (0, 2, 1)).copy(), tc
 
     def level_report(self, pair: int, level: int, n_energy: int):
@@ -387,7 +390,8 @@ class DvoContext:
                     D[f * nl + l], b = self._image(d, "depth", layout); keep.append(b)
         self._chk(self.lib.dvo_frames_upload_pyramids(self._h, first_slot, count, nl, G, D if have_depth else None,
                                                       now_first_pair, flags))
-        self._frame_keep = keep if flags & DVO_UPLOAD_ASYNC else None
+        if flags & DVO_UPLOAD_ASYNC:
+            self._frame_keep.append(keep)
         for l, (g, _) in enumerate(frames[0]):
             self._dims[l] = tuple(np.asarray(g).shape)
 
@@ -406,7 +410,8 @@ class DvoContext:
                                                      now_first_pair, flags))
         if now_first_pair >= 0:
             self._note_dims(first_slot)
-        self._frame_keep = (bl, dl) if flags & DVO_UPLOAD_ASYNC else None
+        if flags & DVO_UPLOAD_ASYNC:
+            self._frame_keep.append((bl, dl))
 
     def frames_as_now(self, first_slot: int = 0, first_pair: int = 0, count: int = 1):
         self._chk(self.lib.dvo_frames_as_now(self._h, first_slot, first_pair, count))
