@@ -32,6 +32,8 @@ struct Level {
     float4 *tex = nullptr;
     size_t tex_stride = 0;
     float *pts = nullptr;
+    uint2 *cpts = nullptr;          /* compact twin of pts (8 B / point), same capacity; valid where compact_ok */
+    std::vector<char> compact_ok;   /* per pair: the list came from the engine's enlist kernels */
     int pt_cap = 0;
     int *dN = nullptr;
     std::vector<int> hN;            /* 0 = not set */
@@ -138,6 +140,7 @@ bool level_ok(int level) { return level >= 0 && level < DVO_LEVELS; }
 int ensure_points(dvo_ctx *c, int level, int N) {
     Level &L = c->lv[level];
     if (L.hN.empty()) { L.hN.assign(c->n_pairs, 0); }
+    if (L.compact_ok.empty()) L.compact_ok.assign(c->n_pairs, 0);
     if (!L.dN) {
         HIPCHK(c, hipMalloc((void **)&L.dN, sizeof(int) * c->n_pairs));
         HIPCHK(c, hipMemsetAsync(L.dN, 0, sizeof(int) * c->n_pairs, c->stream));
@@ -146,16 +149,22 @@ int ensure_points(dvo_ctx *c, int level, int N) {
     int new_cap = std::max(N, L.pt_cap + L.pt_cap / 4);
     new_cap = (new_cap + 255) / 256 * 256;
     float *np = nullptr;
+    uint2 *ncp = nullptr;
     HIPCHK(c, hipMalloc((void **)&np, sizeof(float) * 3 * (size_t)new_cap * c->n_pairs));
+    HIPCHK(c, hipMalloc((void **)&ncp, sizeof(uint2) * (size_t)new_cap * c->n_pairs));
     if (L.pts) {
         HIPCHK(c, hipMemcpy2DAsync(np, sizeof(float) * 3 * (size_t)new_cap, L.pts,
                                    sizeof(float) * 3 * (size_t)L.pt_cap,
                                    sizeof(float) * 3 * (size_t)L.pt_cap, c->n_pairs,
                                    hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(ncp, sizeof(uint2) * (size_t)new_cap, L.cpts, sizeof(uint2) * (size_t)L.pt_cap,
+                                   sizeof(uint2) * (size_t)L.pt_cap, c->n_pairs, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipFree(L.pts));
+        HIPCHK(c, hipFree(L.cpts));
     }
     L.pts = np;
+    L.cpts = ncp;
     L.pt_cap = new_cap;
     return DVO_OK;
 }
@@ -181,7 +190,7 @@ int ensure_texels(dvo_ctx *c, int level, int rows, int cols) {
 LevelSlab slab_of(const dvo_ctx *c, int level) {
     const Level &L = c->lv[level];
     LevelSlab s;
-    s.tex = L.tex; s.pts = L.pts; s.N = L.dN;
+    s.tex = L.tex; s.pts = L.pts; s.cpts = L.cpts; s.N = L.dN;
     s.tex_stride = L.tex_stride; s.pt_cap = L.pt_cap; s.rows = L.rows; s.cols = L.cols;
     return s;
 }
@@ -293,7 +302,14 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         /* auto: one workgroup per CU for >= 512 threads (it owns the CU's LDS), two for 256 */
         if (bytes == 0) bytes = auto_lds ? auto_lds : ((block >= 512) ? 155000 : 77000);
         if (bytes > 156 * 1024) bytes = 156 * 1024;
-        sc.lds_points = bytes / 12;
+        /* compact (8-byte) point lists when every list of this launch was built by the engine's own enlist kernels */
+        sc.compact = fused_uses_compact(c->prm.points_in_flight, c->prm.interpolate_dt) ? 1 : 0;
+        for (int l = 0; l < n_levels && sc.compact; l++) {
+            if (sc.iters[l] <= 0) continue;
+            for (int p = first_pair; p < first_pair + n_pairs && sc.compact; p++)
+                if (c->lv[l].compact_ok.empty() || !c->lv[l].compact_ok[sc.alias_mod > 0 ? p % sc.alias_mod : p]) sc.compact = 0;
+        }
+        sc.lds_points = bytes / (sc.compact ? 8 : 12);
         if (c->prm.lds_point_bytes < 0) sc.lds_points = 0;
     }
     int u = c->prm.points_in_flight;
@@ -397,6 +413,7 @@ int dvo_destroy(dvo_ctx *c) {
     for (int l = 0; l < DVO_LEVELS; l++) {
         if (c->lv[l].tex) (void)hipFree(c->lv[l].tex);
         if (c->lv[l].pts) (void)hipFree(c->lv[l].pts);
+        if (c->lv[l].cpts) (void)hipFree(c->lv[l].cpts);
         if (c->lv[l].dN) (void)hipFree(c->lv[l].dN);
     }
     for (int l = 0; l < DVO_LEVELS; l++) {
@@ -453,6 +470,9 @@ int dvo_synchronize(dvo_ctx *c) {
 int dvo_set_intrinsics(dvo_ctx *c, float fx, float fy, float cx, float cy) {
     if (!c) return DVO_ERR_INVALID;
     if (!(fx > 0.0f) || !(fy > 0.0f)) return fail(c, DVO_ERR_INVALID, "fx, fy must be positive");
+    if (c->have_K && (c->K.fx != fx || c->K.fy != fy || c->K.cx != cx || c->K.cy != cy))
+        for (int l = 0; l < DVO_LEVELS; l++)          /* compact lists are expanded with K at run time: those built under the old K lose the short form */
+            std::fill(c->lv[l].compact_ok.begin(), c->lv[l].compact_ok.end(), 0);
     c->K = Intrinsics{fx, fy, cx, cy, c->prm.interpolate_dt ? 1 : 0};
     c->have_K = true;
     return DVO_OK;
@@ -470,6 +490,7 @@ static int set_ref_common(dvo_ctx *c, int pair, int level, const float *xyz, int
     HIPCHK(c, hipMemcpyAsync(dst, xyz, sizeof(float) * 3 * (size_t)N,
                              device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     L.hN[pair] = N;
+    L.compact_ok[pair] = 0;                                         /* arbitrary X, Y: no 8-byte form */
     HIPCHK(c, hipMemcpyAsync(L.dN + pair, &L.hN[pair], sizeof(int), hipMemcpyHostToDevice, c->stream));
     if (!device_src) HIPCHK(c, hipStreamSynchronize(c->stream));   /* host buffer is only borrowed */
     return DVO_OK;
@@ -517,8 +538,9 @@ int dvo_set_ref_level_from_images(dvo_ctx *c, int pair, int level, const int32_t
     if ((rc = ensure_points(c, level, N))) return rc;
     Level &L = c->lv[level];
     float *dst = L.pts + (size_t)pair * L.pt_cap * 3;
-    HIPCHK(c, launch_enlist_write(d_edge, 0, 0, d_depth, 0, gb, level, c->K, c->d_colcounts, dst, 0, d_uv, N,
-                                  nullptr, c->stream));
+    HIPCHK(c, launch_enlist_write(d_edge, 0, 0, d_depth, 0, gb, level, c->K, c->d_colcounts, dst, 0,
+                                  L.cpts + (size_t)pair * L.pt_cap, d_uv, N, nullptr, c->stream));
+    L.compact_ok[pair] = 1;
     L.hN[pair] = N;
     HIPCHK(c, hipMemcpyAsync(L.dN + pair, &L.hN[pair], sizeof(int), hipMemcpyHostToDevice, c->stream));
     const int ncopy = std::min(N, capacity);
@@ -638,9 +660,10 @@ int dvo_replicate_pairs(dvo_ctx *c, int n_src, int dst_first, int dst_count) {
             int rc = check_ready(c, p, l);
             if (rc) return rc;
         }
-        HIPCHK(c, launch_replicate_level(L.tex, L.tex_stride, L.pts, L.pt_cap, L.dN, n_src, dst_first, dst_count, c->stream));
+        HIPCHK(c, launch_replicate_level(L.tex, L.tex_stride, L.pts, L.cpts, L.pt_cap, L.dN, n_src, dst_first, dst_count, c->stream));
         for (int p = dst_first; p < dst_first + dst_count; p++) {
             L.hN[p] = L.hN[(p - dst_first) % n_src];
+            L.compact_ok[p] = L.compact_ok[(p - dst_first) % n_src];
             L.have_now[p] = 1;
         }
     }
@@ -1472,8 +1495,8 @@ int dvo_frames_as_ref(dvo_ctx *c, int first_slot, int first_pair, int count, int
         const size_t off = (size_t)first_slot * F.npx;
         HIPCHK(c, launch_enlist_write(F.edge + off, 1, F.npx, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, count}, l, c->K,
                                       c->work + cc_off[l], L.pts + (size_t)first_pair * L.pt_cap * 3, (size_t)L.pt_cap * 3,
-                                      nullptr, L.pt_cap, L.dN + first_pair, c->stream));
-        for (int i = 0; i < count; i++) L.hN[first_pair + i] = hN[(size_t)l * count + i];
+                                      L.cpts + (size_t)first_pair * L.pt_cap, nullptr, L.pt_cap, L.dN + first_pair, c->stream));
+        for (int i = 0; i < count; i++) { L.hN[first_pair + i] = hN[(size_t)l * count + i]; L.compact_ok[first_pair + i] = 1; }
     }
     if (bad_level >= 0)
         return fail(c, DVO_ERR_INVALID, "no reference point selected in frame " + std::to_string(first_slot + bad_frame) +

@@ -44,6 +44,7 @@ struct IterConst {
     int rows, cols;
     int tiles_per_col;          /* texel tiles along yy (see texel_index) */
     int interp;                 /* __INTERPOLATE_DISTANCE_TRANSFORM (SolveDVO.h:97): eps from interpolate() */
+    float pcx, pfx, pcy, pfy;   /* tmpcx, tmpfx, tmpcy, tmpfy of enlistRefEdgePts (:232-235): rebuild X, Y of compact points */
 };
 
 struct PointEval {

@@ -644,11 +644,13 @@ template <typename E>
 __global__ void __launch_bounds__(64)
 enlist_write_kernel(const E *__restrict__ edge, size_t edge_stride, const float *__restrict__ depth, size_t depth_stride,
                     int rows, int cols, int level, Intrinsics K, const int *__restrict__ col_offsets,
-                    float *__restrict__ xyz, size_t xyz_stride, float *__restrict__ uv, int capacity, int *__restrict__ N_dst) {
+                    float *__restrict__ xyz, size_t xyz_stride, uint2 *__restrict__ compact,
+                    float *__restrict__ uv, int capacity, int *__restrict__ N_dst) {
     const int xx = blockIdx.x, lane = threadIdx.x;
     edge += (size_t)blockIdx.y * edge_stride; depth += (size_t)blockIdx.y * depth_stride;
     col_offsets += (size_t)blockIdx.y * (cols + 2);
     xyz += (size_t)blockIdx.y * xyz_stride;
+    if (compact) compact += (size_t)blockIdx.y * (xyz_stride / 3);
     if (N_dst && xx == 0 && lane == 0) { const int N = col_offsets[cols]; N_dst[blockIdx.y] = N < capacity ? N : capacity; }
     const size_t base = (size_t)xx * rows;
     const float scaleFac = pow2_neg_f(level);                           /* :231 */
@@ -670,6 +672,7 @@ enlist_write_kernel(const E *__restrict__ edge, size_t edge_stride, const float 
                 const float X = Z * ((float)xx - tmpcx) * tmpfx;        /* :249 */
                 const float Y = Z * ((float)yy - tmpcy) * tmpfy;        /* :250 */
                 xyz[3 * nC] = X; xyz[3 * nC + 1] = Y; xyz[3 * nC + 2] = Z;   /* :254-256 */
+                if (compact) compact[nC] = make_uint2((unsigned)xx | ((unsigned)yy << 16), __float_as_uint(Z));
                 if (uv) { uv[2 * nC] = (float)xx; uv[2 * nC + 1] = (float)yy; }   /* :244-245 */
             }
         }
@@ -688,9 +691,9 @@ static hipError_t enlist_count_t(const E *edge, size_t edge_stride, const float 
 template <typename E>
 static hipError_t enlist_write_t(const E *edge, size_t edge_stride, const float *depth, size_t depth_stride, ImgBatch g,
                                  int level, const Intrinsics &K, const int *col_counts, float *xyz, size_t xyz_stride,
-                                 float *uv, int capacity, int *N_dst, hipStream_t s) {
+                                 uint2 *compact, float *uv, int capacity, int *N_dst, hipStream_t s) {
     hipLaunchKernelGGL(enlist_write_kernel<E>, dim3(g.cols, g.count), dim3(64), 0, s, edge, edge_stride, depth, depth_stride,
-                       g.rows, g.cols, level, K, col_counts, xyz, xyz_stride, uv, capacity, N_dst);
+                       g.rows, g.cols, level, K, col_counts, xyz, xyz_stride, compact, uv, capacity, N_dst);
     return hipGetLastError();
 }
 
@@ -701,11 +704,11 @@ hipError_t launch_enlist_count(const void *edge, int edge_is_u8, size_t edge_str
 }
 hipError_t launch_enlist_write(const void *edge, int edge_is_u8, size_t edge_stride, const float *depth, size_t depth_stride,
                                ImgBatch g, int level, const Intrinsics &K, const int *col_counts, float *xyz,
-                               size_t xyz_stride, float *uv, int capacity, int *N_dst, hipStream_t s) {
+                               size_t xyz_stride, uint2 *compact, float *uv, int capacity, int *N_dst, hipStream_t s) {
     return edge_is_u8 ? enlist_write_t((const unsigned char *)edge, edge_stride, depth, depth_stride, g, level, K, col_counts,
-                                       xyz, xyz_stride, uv, capacity, N_dst, s)
+                                       xyz, xyz_stride, compact, uv, capacity, N_dst, s)
                       : enlist_write_t((const int32_t *)edge, edge_stride, depth, depth_stride, g, level, K, col_counts,
-                                       xyz, xyz_stride, uv, capacity, N_dst, s);
+                                       xyz, xyz_stride, compact, uv, capacity, N_dst, s);
 }
 
 }  // namespace dvo

@@ -46,6 +46,10 @@ DVO_DEV void level_consts(IterConst &c, const Intrinsics &K, int level, int rows
     c.ncols_f = (float)cols; c.nrows_f = (float)rows;
     c.rows = rows;
     c.tiles_per_col = texel_tiles_per_col(rows);
+    c.pfx = (float)(1. / (double)(s * K.fx));  /* :232 double division, narrowed */
+    c.pfy = (float)(1. / (double)(s * K.fy));  /* :233 */
+    c.pcx = s * K.cx;                          /* :234 */
+    c.pcy = s * K.cy;                          /* :235 */
 }
 
 /* per-lane partial sums of one iteration */
@@ -99,18 +103,35 @@ DVO_DEV void acc_add(Acc &a, const float *J, float eps, float w) {
  * live in LDS as three planes (x | y | z, each `cap` floats; conflict-free
  * ds_read_b32), the rest are read from HBM (3 x N column-major, 12 B / point). */
 struct PointSrc {
-    const float *__restrict__ g;    /* global list */
+    const float *__restrict__ g;    /* global list, 3 x N column-major */
+    const uint2 *__restrict__ gc;   /* global compact list (or nullptr) */
     const float *l;                 /* LDS planes  */
     int n_lds, cap;
 };
+/* Point sources.  XYZ: the reference's 3 x N float list (12 B / point).  COMPACT: what enlistRefEdgePts was given --
+ * pixel (xx, yy) and Z = depth/1000 -- in 8 bytes {xx | yy << 16, Z}; X and Y are rebuilt with the very operations of
+ * :249-250 (X = Z*(xx - tmpcx)*tmpfx), so the bits are those of the 12-byte list.  A third less LDS and stream
+ * traffic per point; only lists built by the engine's own enlist kernels have it. */
+enum { SRC_GLOBAL_XYZ = 0, SRC_LDS_XYZ = 1, SRC_GLOBAL_COMPACT = 2, SRC_LDS_COMPACT = 3 };
+DVO_DEV void expand_compact(const IterConst &c, unsigned pk, float z, float &X, float &Y, float &Z) {
+    const float xx = (float)(pk & 0xffffu), yy = (float)(pk >> 16);
+    Z = z;
+    X = Z * (xx - c.pcx) * c.pfx;                                  /* :249 */
+    Y = Z * (yy - c.pcy) * c.pfy;                                  /* :250 */
+}
 /* branch-free on purpose: a (divergent) LDS-or-HBM choice per point makes the compiler drain all
  * outstanding gathers before it; whole rounds are served from one source instead */
-template <bool USE_LDS>
-DVO_DEV void load_point(const PointSrc &p, int i, float &X, float &Y, float &Z) {
-    if (USE_LDS) {
+template <int SRC>
+DVO_DEV void load_point(const IterConst &c, const PointSrc &p, int i, float &X, float &Y, float &Z) {
+    if (SRC == SRC_LDS_XYZ) {
         X = p.l[i]; Y = p.l[p.cap + i]; Z = p.l[2 * p.cap + i];
-    } else {
+    } else if (SRC == SRC_GLOBAL_XYZ) {
         X = p.g[3 * i]; Y = p.g[3 * i + 1]; Z = p.g[3 * i + 2];
+    } else if (SRC == SRC_LDS_COMPACT) {
+        expand_compact(c, __float_as_uint(p.l[i]), p.l[p.cap + i], X, Y, Z);
+    } else {
+        const uint2 v = p.gc[i];
+        expand_compact(c, v.x, __uint_as_float(v.y), X, Y, Z);
     }
 }
 
@@ -129,7 +150,7 @@ template <int U> struct RoundBuf {
 };
 
 /* stage B: load U points, project, issue the gathers (texel 0 when not visible) */
-template <int U, bool USE_LDS>
+template <int U, int SRC>
 DVO_DEV void round_issue(const IterConst &c, const float4 *__restrict__ tex, const PointSrc &pts,
                          int base, int end, int lane_off, int stride, RoundBuf<U> &b) {
     int idx[U];
@@ -139,7 +160,7 @@ DVO_DEV void round_issue(const IterConst &c, const float4 *__restrict__ tex, con
         const bool valid = i < end;
         const int ii = valid ? i : (end - 1);
         float X, Y, Z, uu, vv;
-        load_point<USE_LDS>(pts, ii, X, Y, Z);
+        load_point<SRC>(c, pts, ii, X, Y, Z);
         const bool vis = project_point(c, X, Y, Z, b.xn[u], b.yn[u], b.zn[u], uu, vv) && valid;
         b.vis[u] = vis;
         idx[u] = vis ? texel_index((int)vv, (int)uu, c.tiles_per_col) : 0;
@@ -174,7 +195,7 @@ DVO_DEV void round_compute(const IterConst &c, const float4 *__restrict__ tex, c
 /* The per-point phase of one iteration over points [first, end) with a lane
  * stride of `stride` (:369-407 + :433-451).  The trip count is wave-uniform, so
  * the visible count can be taken from ballots. */
-template <int U, bool WITH_H, bool USE_LDS, int INTERP>
+template <int U, bool WITH_H, int SRC, int INTERP>
 DVO_DEV void accumulate_points(const IterConst &c, const float4 *__restrict__ tex,
                                const PointSrc &pts, int first, int end, int lane_off,
                                int stride, Acc &a) {
@@ -182,16 +203,16 @@ DVO_DEV void accumulate_points(const IterConst &c, const float4 *__restrict__ te
     const int step = stride * U;
     const int n_rounds = (end - first + step - 1) / step;
     RoundBuf<U> A, B;
-    round_issue<U, USE_LDS>(c, tex, pts, first, end, lane_off, stride, A);
+    round_issue<U, SRC>(c, tex, pts, first, end, lane_off, stride, A);
     int r = 0;
     for (; r + 2 < n_rounds; r += 2) {                       /* steady state: A = round r */
-        round_issue<U, USE_LDS>(c, tex, pts, first + (r + 1) * step, end, lane_off, stride, B);
+        round_issue<U, SRC>(c, tex, pts, first + (r + 1) * step, end, lane_off, stride, B);
         round_compute<U, WITH_H, INTERP>(c, tex, A, a);
-        round_issue<U, USE_LDS>(c, tex, pts, first + (r + 2) * step, end, lane_off, stride, A);
+        round_issue<U, SRC>(c, tex, pts, first + (r + 2) * step, end, lane_off, stride, A);
         round_compute<U, WITH_H, INTERP>(c, tex, B, a);
     }
     if (r + 1 < n_rounds) {                                  /* two rounds left */
-        round_issue<U, USE_LDS>(c, tex, pts, first + (r + 1) * step, end, lane_off, stride, B);
+        round_issue<U, SRC>(c, tex, pts, first + (r + 1) * step, end, lane_off, stride, B);
         round_compute<U, WITH_H, INTERP>(c, tex, A, a);
         round_compute<U, WITH_H, INTERP>(c, tex, B, a);
     } else {
@@ -295,7 +316,7 @@ hipError_t launch_pack_texels(const float *dt, const float *gx, const float *gy,
 /* slot p in [dst_first, dst_first+dst_count) <- copy of slot (p - dst_first) % n_src : one launch per level
  * instead of a pack + copies per pair (bench / throughput set-up, warm replicas) */
 __global__ void __launch_bounds__(256)
-replicate_level_kernel(float4 *tex, size_t tex_stride, float *pts, int pt_cap, int *N,
+replicate_level_kernel(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, int pt_cap, int *N,
                        int n_src, int dst_first, int dst_count) {
     const int p = dst_first + blockIdx.y;
     const int src = blockIdx.y % n_src;
@@ -308,12 +329,17 @@ replicate_level_kernel(float4 *tex, size_t tex_stride, float *pts, int pt_cap, i
     const float *sp = pts + (size_t)src * pt_cap * 3;
     float *dp = pts + (size_t)p * pt_cap * 3;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)3 * n; i += stride) dp[i] = sp[i];
+    if (cpts) {
+        const uint2 *sc_ = cpts + (size_t)src * pt_cap;
+        uint2 *dc = cpts + (size_t)p * pt_cap;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n; i += stride) dc[i] = sc_[i];
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) N[p] = n;
 }
-hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, int pt_cap, int *N,
+hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, int pt_cap, int *N,
                                   int n_src, int dst_first, int dst_count, hipStream_t s) {
     if (dst_count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(replicate_level_kernel, dim3(64, dst_count), dim3(256), 0, s, tex, tex_stride, pts, pt_cap, N,
+    hipLaunchKernelGGL(replicate_level_kernel, dim3(64, dst_count), dim3(256), 0, s, tex, tex_stride, pts, cpts, pt_cap, N,
                        n_src, dst_first, dst_count);
     return hipGetLastError();
 }
@@ -341,7 +367,7 @@ DVO_DEV unsigned long long stamp_now() {
 #ifndef DVO_WAVES_PER_EU
 #define DVO_WAVES_PER_EU 1       /* register budget of the fused kernel: 512 / waves VGPRs */
 #endif
-template <int BLOCK, int U, int INTERP>
+template <int BLOCK, int U, int INTERP, bool CP>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(DVO_WAVES_PER_EU, 8)))
 align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outputs out, int first_pair) {
     const int pair = first_pair + blockIdx.x;
@@ -349,7 +375,7 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
     __shared__ PoseState st;
     __shared__ double red[BLOCK / 64][DVO_NACC_PAD];
     __shared__ double tot[DVO_NACC_PAD];
-    extern __shared__ float lds_points[];     /* 3 planes of sc.lds_points floats: this level's points */
+    extern __shared__ float lds_points[];     /* planes of sc.lds_points words: this level's points (x|y|z, or xy|z when compact) */
 
     if (tid == 0) {
         const double *p = out.poses + (size_t)pair * 12;
@@ -382,12 +408,19 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
          * iteration; here the level's points are staged into LDS once and stay there
          * for all its iterations, so HBM sees them once per level. */
         PointSrc psrc;
-        psrc.g = pts; psrc.l = lds_points; psrc.cap = sc.lds_points;
+        psrc.g = pts; psrc.gc = CP ? (L.cpts + (size_t)dpair * L.pt_cap) : nullptr;
+        psrc.l = lds_points; psrc.cap = sc.lds_points;
         psrc.n_lds = (N < sc.lds_points) ? N : (sc.lds_points / (BLOCK * U)) * (BLOCK * U);   /* whole rounds only */
         for (int i = tid; i < psrc.n_lds; i += BLOCK) {
-            lds_points[i] = pts[3 * i];
-            lds_points[psrc.cap + i] = pts[3 * i + 1];
-            lds_points[2 * psrc.cap + i] = pts[3 * i + 2];
+            if (CP) {
+                const uint2 v = psrc.gc[i];
+                lds_points[i] = __uint_as_float(v.x);
+                lds_points[psrc.cap + i] = __uint_as_float(v.y);
+            } else {
+                lds_points[i] = pts[3 * i];
+                lds_points[psrc.cap + i] = pts[3 * i + 1];
+                lds_points[2 * psrc.cap + i] = pts[3 * i + 2];
+            }
         }
         __syncthreads();
 
@@ -405,8 +438,8 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
 #endif
             Acc a;
             acc_zero(a);
-            accumulate_points<U, false, true, INTERP>(c, tex, psrc, 0, psrc.n_lds, tid, BLOCK, a);    /* :369, :433 */
-            accumulate_points<U, false, false, INTERP>(c, tex, psrc, psrc.n_lds, N, tid, BLOCK, a);  /* beyond the LDS budget */
+            accumulate_points<U, false, CP ? SRC_LDS_COMPACT : SRC_LDS_XYZ, INTERP>(c, tex, psrc, 0, psrc.n_lds, tid, BLOCK, a);    /* :369, :433 */
+            accumulate_points<U, false, CP ? SRC_GLOBAL_COMPACT : SRC_GLOBAL_XYZ, INTERP>(c, tex, psrc, psrc.n_lds, N, tid, BLOCK, a);  /* beyond the LDS budget */
 #ifdef DVO_YOUNG_WAVE_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
@@ -437,8 +470,8 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
                 float *fr = out.final_reproj + (size_t)pair * out.final_cap * 3;
                 for (int i = tid; i < N; i += BLOCK) {
                     float X, Y, Z, xn, yn, zn, u, v;
-                    if (i < psrc.n_lds) load_point<true>(psrc, i, X, Y, Z);
-                    else load_point<false>(psrc, i, X, Y, Z);
+                    if (i < psrc.n_lds) load_point<CP ? SRC_LDS_COMPACT : SRC_LDS_XYZ>(c, psrc, i, X, Y, Z);
+                    else load_point<CP ? SRC_GLOBAL_COMPACT : SRC_GLOBAL_XYZ>(c, psrc, i, X, Y, Z);
                     const bool vis = project_point(c, X, Y, Z, xn, yn, zn, u, v);
                     float e = 0.0f;
                     if (vis) e = (INTERP == 1) ? interpolate_dt(c, tex, v, u) : tex[texel_index((int)v, (int)u, c.tiles_per_col)].x;
@@ -466,21 +499,25 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
     }
 }
 
-template <int BLOCK, int U>
+template <int BLOCK, int U, bool CP>
 static void launch_fused_bu(const LevelSet &lv, const Schedule &sc, const Intrinsics &K,
                             const DevParams &prm, const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {
-    const size_t dyn = (size_t)sc.lds_points * 3 * sizeof(float);
-    auto kern = align_fused_kernel<BLOCK, U, 0>;
+    const size_t dyn = (size_t)sc.lds_points * (CP ? 2 : 3) * sizeof(float);
+    auto kern = align_fused_kernel<BLOCK, U, 0, CP>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     hipLaunchKernelGGL(kern, dim3(n_pairs), dim3(BLOCK), dyn, s, lv, sc, K, prm, out, first_pair);
 }
 template <int BLOCK>
 static void launch_fused_b(int u, const LevelSet &lv, const Schedule &sc, const Intrinsics &K,
                            const DevParams &prm, const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {
-    if (u >= 4) launch_fused_bu<BLOCK, 4>(lv, sc, K, prm, out, first_pair, n_pairs, s);
-    else if (u == 2) launch_fused_bu<BLOCK, 2>(lv, sc, K, prm, out, first_pair, n_pairs, s);
-    else launch_fused_bu<BLOCK, 1>(lv, sc, K, prm, out, first_pair, n_pairs, s);
+    if (u >= 4) launch_fused_bu<BLOCK, 4, false>(lv, sc, K, prm, out, first_pair, n_pairs, s);
+    else if (u == 2) launch_fused_bu<BLOCK, 2, false>(lv, sc, K, prm, out, first_pair, n_pairs, s);
+    else if (sc.compact) launch_fused_bu<BLOCK, 1, true>(lv, sc, K, prm, out, first_pair, n_pairs, s);
+    else launch_fused_bu<BLOCK, 1, false>(lv, sc, K, prm, out, first_pair, n_pairs, s);
 }
+
+/* true if this launch configuration reads the compact point lists (the host sizes sc.lds_points accordingly) */
+bool fused_uses_compact(int points_in_flight, int interp) { return points_in_flight <= 1 && !interp; }
 
 hipError_t launch_align_fused(int block_threads, int points_in_flight, const LevelSet &lv,
                               const Schedule &sc, const Intrinsics &K, const DevParams &prm,
@@ -488,7 +525,7 @@ hipError_t launch_align_fused(int block_threads, int points_in_flight, const Lev
     if (n_pairs <= 0) return hipSuccess;
     if (K.interp) {     /* optional interpolate() lookup: one configuration only, it is not the tuned path */
         const size_t dyn = (size_t)sc.lds_points * 3 * sizeof(float);
-        auto kern = align_fused_kernel<512, 1, 1>;
+        auto kern = align_fused_kernel<512, 1, 1, false>;
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         hipLaunchKernelGGL(kern, dim3(n_pairs), dim3(512), dyn, s, lv, sc, K, prm, out, first_pair);
         return hipGetLastError();
@@ -564,8 +601,8 @@ accumulate_kernel(LevelSlab L, int pair, int level, Intrinsics K, FloatPose P,
     int b1 = b0 + per;
     if (b1 > first + n) b1 = first + n;
     PointSrc psrc;
-    psrc.g = pts; psrc.l = nullptr; psrc.n_lds = 0; psrc.cap = 0;
-    if (b0 < b1) accumulate_points<4, true, false, 2>(c, tex, psrc, b0, b1, threadIdx.x, 256, a);
+    psrc.g = pts; psrc.gc = nullptr; psrc.l = nullptr; psrc.n_lds = 0; psrc.cap = 0;
+    if (b0 < b1) accumulate_points<4, true, SRC_GLOBAL_XYZ, 2>(c, tex, psrc, b0, b1, threadIdx.x, 256, a);
     block_reduce<256, true>(a, red, tot);
     if (threadIdx.x < DVO_NACC_PAD)
         partials[(size_t)blockIdx.x * DVO_NACC_PAD + threadIdx.x] = (threadIdx.x < DVO_NACC) ? tot[threadIdx.x] : 0.0;
@@ -645,8 +682,8 @@ accumulate_state_kernel(LevelSlab L, int pair, int level, Intrinsics K, const Po
     int b1 = b0 + per;
     if (b1 > first + n) b1 = first + n;
     PointSrc psrc;
-    psrc.g = pts; psrc.l = nullptr; psrc.n_lds = 0; psrc.cap = 0;
-    if (b0 < b1) accumulate_points<2, true, false, 2>(c, tex, psrc, b0, b1, threadIdx.x, 256, a);
+    psrc.g = pts; psrc.gc = nullptr; psrc.l = nullptr; psrc.n_lds = 0; psrc.cap = 0;
+    if (b0 < b1) accumulate_points<2, true, SRC_GLOBAL_XYZ, 2>(c, tex, psrc, b0, b1, threadIdx.x, 256, a);
     block_reduce<256, true>(a, red, tot);
     if (threadIdx.x < DVO_NACC_PAD)
         partials[(size_t)blockIdx.x * DVO_NACC_PAD + threadIdx.x] = (threadIdx.x < DVO_NACC) ? tot[threadIdx.x] : 0.0;

@@ -26,6 +26,7 @@ namespace dvo {
 struct LevelSlab {
     const float4 *tex;
     const float *pts;
+    const uint2 *cpts;      /* compact points {xx | yy << 16, Z}, pt_cap per pair; valid where the host says so (Schedule.compact) */
     const int *N;
     size_t tex_stride;      /* texels per pair */
     int pt_cap;             /* points per pair (capacity) */
@@ -41,7 +42,8 @@ struct Schedule {
     int last_level;          /* smallest l with iters[l] > 0 (its outputs survive, SolveDVO.cpp:2102) */
     int flags;
     int alias_mod;           /* diagnostics: data of pair p % alias_mod (0 = off) */
-    int lds_points;          /* reference points kept resident in LDS per workgroup (3 floats each) */
+    int lds_points;          /* reference points kept resident in LDS per workgroup (3 words each, 2 when compact) */
+    int compact;             /* every pair/level of this launch has a compact point list: read 8 B / point instead of 12 */
 };
 
 struct Intrinsics { float fx, fy, cx, cy; int interp; /* dvo_params.interpolate_dt, travels with the camera model to every kernel */ };
@@ -60,7 +62,8 @@ struct Outputs {
 
 hipError_t launch_pack_texels(const float *dt, const float *gx, const float *gy, float4 *out,
                               int rows, int cols, hipStream_t s);
-hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, int pt_cap, int *N,
+bool fused_uses_compact(int points_in_flight, int interp);
+hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, int pt_cap, int *N,
                                   int n_src, int dst_first, int dst_count, hipStream_t s);
 hipError_t launch_align_fused(int block_threads, int points_in_flight, const LevelSet &lv,
                               const Schedule &sc, const Intrinsics &K, const DevParams &prm,
@@ -124,7 +127,8 @@ hipError_t launch_enlist_count(const void *edge, int edge_is_u8, size_t edge_str
                                size_t depth_stride, ImgBatch g, int *col_counts, hipStream_t s);
 hipError_t launch_enlist_write(const void *edge, int edge_is_u8, size_t edge_stride, const float *depth_mm,
                                size_t depth_stride, ImgBatch g, int level, const Intrinsics &K, const int *col_counts,
-                               float *xyz, size_t xyz_stride, float *uv, int capacity, int *N_dst, hipStream_t s);
+                               float *xyz, size_t xyz_stride, uint2 *compact /* same stride in points / 3, or nullptr */,
+                               float *uv, int capacity, int *N_dst, hipStream_t s);
 
 }  // namespace dvo
 #endif

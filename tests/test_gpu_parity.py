@@ -509,3 +509,35 @@ def test_interpolate_distance_transform_flag(scene320, oracle):
         assert rot_angle(ref["R"], Rw) <= ROT_TOL and np.linalg.norm(ref["t"] - tw) <= TRANS_TOL
     finally:
         ctx.close()
+
+
+def test_compact_point_lists_give_the_same_bits(oracle):
+    """lists built by the engine's enlist kernels are read in their 8-byte form {xx | yy << 16, Z}; the same points
+    handed over as a 3 x N float list take the 12-byte path: identical energies, indices, ratios and poses"""
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    from rgbd_odometry_amd.capi import DVO_FLAG_FINAL_OUTPUTS
+    for (W, H, nl, it, seed) in ((640, 480, 4, 10, 5), (1000, 700, 3, 6, 6)):      # the second one exceeds the LDS budget
+        sc = SynthScene(W, H, nl, seed)
+        iters = [it] * nl
+        with DvoContext(1) as a, DvoContext(1) as b:
+            for ctx in (a, b):
+                ctx.set_intrinsics(*sc.intrinsics)
+            for l, L in enumerate(sc.levels):
+                xyz, _ = a.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols)     # compact available
+                b.set_ref_level(l, xyz)                                                              # float list only
+                for ctx in (a, b):
+                    ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols)
+            Ra, ta = a.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)), flags=DVO_FLAG_FINAL_OUTPUTS)
+            Rb, tb = b.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)), flags=DVO_FLAG_FINAL_OUTPUTS)
+            assert np.array_equal(Ra, Rb) and np.array_equal(ta, tb)
+            for l in range(nl):
+                ea, eb = a.level_report(0, l, it), b.level_report(0, l, it)
+                assert np.array_equal(ea[0], eb[0]) and ea[1:] == eb[1:]
+            fa, fb = a.final_outputs(0, a.n_points(0)), b.final_outputs(0, b.n_points(0))
+            assert np.array_equal(fa[0], fb[0]) and np.array_equal(fa[1], fb[1])
+            # new intrinsics invalidate the short form (it is expanded with K at run time); the float list is unaffected
+            a.set_intrinsics(sc.intrinsics[0] * 1.01, sc.intrinsics[1], sc.intrinsics[2], sc.intrinsics[3])
+            b.set_intrinsics(sc.intrinsics[0] * 1.01, sc.intrinsics[1], sc.intrinsics[2], sc.intrinsics[3])
+            Ra, ta = a.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
+            Rb, tb = b.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
+            assert np.array_equal(Ra, Rb) and np.array_equal(ta, tb)
