@@ -11,7 +11,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TC
            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
   cd /tmp
-  timeout 120 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -o pmc -- python3 $REPO/bench.py --steps 3 --warmup 1 --cpu-seconds 0 > $OUT/p$i.log 2>&1
+  timeout 120 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -o pmc -- python3 $REPO/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-frames-leg > $OUT/p$i.log 2>&1
   echo "pass $i ($grp): rc=$?"
   cd $REPO
 done
