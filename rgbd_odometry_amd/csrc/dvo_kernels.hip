@@ -411,12 +411,25 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
         psrc.g = pts; psrc.gc = CP ? (L.cpts + (size_t)dpair * L.pt_cap) : nullptr;
         psrc.l = lds_points; psrc.cap = sc.lds_points;
         psrc.n_lds = (N < sc.lds_points) ? N : (sc.lds_points / (BLOCK * U)) * (BLOCK * U);   /* whole rounds only */
-        for (int i = tid; i < psrc.n_lds; i += BLOCK) {
-            if (CP) {
-                const uint2 v = psrc.gc[i];
-                lds_points[i] = __uint_as_float(v.x);
-                lds_points[psrc.cap + i] = __uint_as_float(v.y);
-            } else {
+        if (CP) {
+            /* two points per lane and load: 16 B x 64 lanes = whole 128-byte lines per request (the request rate, not
+             * the byte rate, is what this kernel is short of; the list base is 16-byte aligned: pt_cap % 256 == 0) */
+            const uint4 *g4 = reinterpret_cast<const uint4 *>(psrc.gc);
+            const int n2 = psrc.n_lds >> 1;
+            for (int i = tid; i < n2; i += BLOCK) {
+                const uint4 v = g4[i];
+                lds_points[2 * i] = __uint_as_float(v.x);
+                lds_points[psrc.cap + 2 * i] = __uint_as_float(v.y);
+                lds_points[2 * i + 1] = __uint_as_float(v.z);
+                lds_points[psrc.cap + 2 * i + 1] = __uint_as_float(v.w);
+            }
+            if ((psrc.n_lds & 1) && tid == 0) {
+                const uint2 v = psrc.gc[psrc.n_lds - 1];
+                lds_points[psrc.n_lds - 1] = __uint_as_float(v.x);
+                lds_points[psrc.cap + psrc.n_lds - 1] = __uint_as_float(v.y);
+            }
+        } else {
+            for (int i = tid; i < psrc.n_lds; i += BLOCK) {
                 lds_points[i] = pts[3 * i];
                 lds_points[psrc.cap + i] = pts[3 * i + 1];
                 lds_points[2 * psrc.cap + i] = pts[3 * i + 2];
