@@ -75,7 +75,8 @@ typedef struct dvo_params {
     int    enable_l2_reg;      /* __ENABLE_L2_REGULARIZATION   SolveDVO.h:112 */
     int    interpolate_dt;     /* __INTERPOLATE_DISTANCE_TRANSFORM (off in the reference, SolveDVO.h:97): eps from
                                   SolveDVO::interpolate (:1285-1308) instead of the nearest lookup (:446) */
-    int    block_threads;      /* engine tuning: threads per workgroup of the fused kernel (256/512/1024; 0 = default 512) */
+    int    block_threads;      /* engine tuning: threads per workgroup of the fused kernel (256/512/1024; 0 = chosen from the
+                                  point-list sizes and the batch size) */
     int    points_in_flight;   /* engine tuning: reference points per lane and pipeline stage (1/2/4; 0 = default 1) */
     int    reserved0;
     int    lds_point_bytes;    /* engine tuning: LDS bytes per workgroup for the level's resident point list
