@@ -564,6 +564,7 @@ struct PoseState {
     int stop;
     float Rf[9], tf[3];          /* cR_32, cT_32 (:673-674) for the next evaluation */
     float bRf[9], btf[3];        /* cR_32, cT_32 of the best iterate (for finalEpsilons/Reprojections) */
+    double creg[6], creg_scale;  /* regulariser of the CURRENT pose, precomputed (fused kernel): log(pose) and lambda/|log| */
 };
 
 /* state from a caller-supplied pose (kernel entry) */
@@ -619,6 +620,29 @@ DVO_DEV void pose_state_finish(PoseState &s) {
 /* Everything runIterations does after the per-point phase of iteration `itr`
  * (:689-920).  g = J^T W eps (:777), sum_eps2 = sum eps^2, n_vis visible points.
  * Returns the energy; sets s.stop on early termination. */
+/* the L2 regulariser's share that depends on the pose only (:734-743): cpsi = log(pose), returns lambda/|cpsi| (0 if the
+ * pose is the identity: nothing is added then).  reg_lambda > 0, so "scale == 0" <=> "n == 0". */
+DVO_DEV double pose_regulariser_terms(const PoseState &s, const DevParams &prm, double *cpsi) {
+    double q[4], t[3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = s.q[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) t[k] = s.t[k];
+    se3_log_q(q, t, cpsi);
+    const double n = norm6(cpsi);
+    return (n > 0.0) ? prm.reg_lambda * d_rcp(n) : 0.0;
+}
+/* fused kernel: lane 0 runs this right after the barrier that releases the other waves into the next iteration */
+DVO_DEV void pose_regulariser_precompute(PoseState &s, const DevParams &prm) {
+    if (!prm.enable_l2_reg) return;
+    double cpsi[6];
+    const double sc = pose_regulariser_terms(s, prm, cpsi);
+#pragma unroll
+    for (int k = 0; k < 6; k++) s.creg[k] = cpsi[k];
+    s.creg_scale = sc;
+}
+
+template <bool PRE_REG>
 #ifndef DVO_NOINLINE_UPDATE
 DVO_DEV
 #else
@@ -626,8 +650,8 @@ DVO_DEV
  * but the update itself takes 1.6-2x longer; measured slower at 512 threads, faster only at 1024. */
 __device__ __noinline__
 #endif
-float pose_update(PoseState &s, const DevParams &prm, int itr, int N,
-                          const double *g_in, double sum_eps2, int n_vis) {
+float pose_update_t(PoseState &s, const DevParams &prm, int itr, int N,
+                            const double *g_in, double sum_eps2, int n_vis) {
     /* ---- phase 1: energy and best-iterate bookkeeping (:689-705) ------------
      * energy narrows to float, so it needs the correctly rounded double sqrt to
      * match the oracle's (float)sqrt(double) bit for bit. */
@@ -651,17 +675,19 @@ float pose_update(PoseState &s, const DevParams &prm, int itr, int N,
 #pragma unroll
         for (int k = 0; k < 6; k++) g[k] = g_in[k];
         if (prm.enable_l2_reg) {                                          /* :734-743, :796 */
-            double q[4], t[3], cpsi[6];
+            if (PRE_REG) {                                                /* log(pose) was taken while the other waves worked */
+                const double lam_n = s.creg_scale;
+                if (lam_n != 0.0) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) q[k] = s.q[k];
+                    for (int k = 0; k < 6; k++) g[k] = fma(lam_n, s.creg[k], g[k]);
+                }
+            } else {
+                double cpsi[6];
+                const double lam_n = pose_regulariser_terms(s, prm, cpsi);
+                if (lam_n != 0.0) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) t[k] = s.t[k];
-            se3_log_q(q, t, cpsi);
-            const double n = norm6(cpsi);
-            if (n > 0.0) {
-                const double lam_n = prm.reg_lambda * d_rcp(n);
-#pragma unroll
-                for (int k = 0; k < 6; k++) g[k] = fma(lam_n, cpsi[k], g[k]);
+                    for (int k = 0; k < 6; k++) g[k] = fma(lam_n, cpsi[k], g[k]);
+                }
             }
         }
         const double step = prm.step_a * prm.step_b *
@@ -711,6 +737,9 @@ float pose_update(PoseState &s, const DevParams &prm, int itr, int N,
         for (int k = 0; k < 9; k++) { s.R[k] = R[k]; s.Rf[k] = (float)R[k]; }
     }
     return energy;
+}
+DVO_DEV float pose_update(PoseState &s, const DevParams &prm, int itr, int N, const double *g_in, double sum_eps2, int n_vis) {
+    return pose_update_t<false>(s, prm, itr, N, g_in, sum_eps2, n_vis);
 }
 
 }  // namespace dvo

@@ -201,7 +201,11 @@ DVO_DEV void accumulate_points(const IterConst &c, const float4 *__restrict__ te
                                int stride, Acc &a) {
     if (first >= end) return;
     const int step = stride * U;
-    const int n_rounds = (end - first + step - 1) / step;
+    /* rounds in which THIS wave still has a point (its lowest lane offset decides; wave-uniform): waves beyond the tail
+     * of the last, partial round skip it instead of processing dummies */
+    const int wave_off = __builtin_amdgcn_readfirstlane(lane_off - (int)(threadIdx.x & 63));
+    const int n_rounds = (end - first - wave_off + step - 1) / step;
+    if (n_rounds <= 0) return;
     RoundBuf<U> A, B;
     round_issue<U, SRC>(c, tex, pts, first, end, lane_off, stride, A);
     int r = 0;
@@ -403,7 +407,7 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
         level_consts(c, K, l, L.rows, L.cols);
 
         for (int i = tid; i < iters; i += BLOCK) energy[i] = 0.0f;          /* :634 */
-        if (tid == 0) pose_state_begin(st);                                  /* :642-657 */
+        if (tid == 0) { pose_state_begin(st); pose_regulariser_precompute(st, prm); }   /* :642-657 */
         /* The reference re-reads (in fact deep-copies, :670) the 3xN point list every
          * iteration; here the level's points are staged into LDS once and stay there
          * for all its iterations, so HBM sees them once per level. */
@@ -451,8 +455,12 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
 #endif
             Acc a;
             acc_zero(a);
-            accumulate_points<U, false, CP ? SRC_LDS_COMPACT : SRC_LDS_XYZ, INTERP>(c, tex, psrc, 0, psrc.n_lds, tid, BLOCK, a);    /* :369, :433 */
-            accumulate_points<U, false, CP ? SRC_GLOBAL_COMPACT : SRC_GLOBAL_XYZ, INTERP>(c, tex, psrc, psrc.n_lds, N, tid, BLOCK, a);  /* beyond the LDS budget */
+            /* waves take the lanes of a round in reverse order: the tail of the last, partial round goes to the high
+             * waves first, so wave 0 -- whose lane 0 still has the regulariser of the new pose to finish (below) -- is the
+             * one that most often has a round less */
+            const int lane_off = BLOCK - 64 - (tid & ~63) + (tid & 63);
+            accumulate_points<U, false, CP ? SRC_LDS_COMPACT : SRC_LDS_XYZ, INTERP>(c, tex, psrc, 0, psrc.n_lds, lane_off, BLOCK, a);    /* :369, :433 */
+            accumulate_points<U, false, CP ? SRC_GLOBAL_COMPACT : SRC_GLOBAL_XYZ, INTERP>(c, tex, psrc, psrc.n_lds, N, lane_off, BLOCK, a);  /* beyond the LDS budget */
 #ifdef DVO_YOUNG_WAVE_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
@@ -460,7 +468,7 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
             block_reduce<BLOCK, false>(a, red, tot);
             DVO_STAMP(t2);
             if (tid == 0) {
-                const float e = pose_update(st, prm, itr, N, &tot[21], tot[27], (int)tot[28]);
+                const float e = pose_update_t<true>(st, prm, itr, N, &tot[21], tot[27], (int)tot[28]);
                 energy[itr] = e;                                             /* :690 */
             }
             DVO_STAMP(t3);
@@ -469,6 +477,9 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
             DVO_STAMP_ADD(0, t0, t1); DVO_STAMP_ADD(1, t1, t2); DVO_STAMP_ADD(2, t2, t3); DVO_STAMP_ADD(3, t3, t4);
             DVO_STAMP_ADD(4, t0, t0 + 1);
             if (st.stop) break;                                              /* :877 */
+            /* log(new pose) for the next iteration's regulariser: only the pose is needed, so lane 0 takes it now,
+             * while the other waves are already in their point phase */
+            if (tid == 0 && itr + 1 < iters) pose_regulariser_precompute(st, prm);
         }
 
         /* finalEpsilons / finalReprojections = those of the best iterate (:703-704,
