@@ -541,3 +541,23 @@ def test_compact_point_lists_give_the_same_bits(oracle):
             Ra, ta = a.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
             Rb, tb = b.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
             assert np.array_equal(Ra, Rb) and np.array_equal(ta, tb)
+
+
+def test_wide_path_graph_is_rebuilt_when_inputs_change(oracle):
+    """dvo_align_pyramid_wide replays a captured hipGraph while its signature is unchanged; new point lists, new now
+    levels or another schedule must rebuild it (results checked against the fused kernel each time)"""
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    scenes = [SynthScene(320, 240, 4, s) for s in (11, 12)]
+    with DvoContext(1) as ctx:
+        ctx.set_intrinsics(*scenes[0].intrinsics)
+        for rep, (sc, iters) in enumerate([(scenes[0], [6, 6, 6, 6]), (scenes[0], [6, 6, 6, 6]), (scenes[1], [6, 6, 6, 6]),
+                                           (scenes[1], [4, 0, 5, 3]), (scenes[0], [4, 0, 5, 3])]):
+            for l, L in enumerate(sc.levels):
+                ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols)
+                ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols)
+            Rw, tw = ctx.align_pyramid_wide(iters, np.eye(3), np.zeros(3))
+            Rf, tf = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
+            assert rot_angle(Rf[0], Rw) <= 1e-12 and np.linalg.norm(tf[0] - tw) <= 1e-12, rep
+            lv = oracle_lib.scene_levels(sc, oracle)
+            want = oracle.align_pyramid(iters, lv, sc.intrinsics, np.eye(3), np.zeros(3))
+            assert rot_angle(want["R"], Rw) <= 1e-5 and np.linalg.norm(want["t"] - tw) <= 1e-4
