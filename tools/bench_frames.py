@@ -72,6 +72,19 @@ def main():
     timed("frames_as_now(EDT+normalise+gradients+texels)", lambda: ctx.frames_as_now(B, 0, B), B)
     timed("align(%s)" % iters, lambda: ctx.enqueue(iters, flags=DVO_FLAG_IDENTITY_START), B)
 
+    # the node's own wire format: mono8 + mono16 pyramids (RGBDFramePyd), row-major; built here by reading the device pyramid back
+    pyr = []
+    for i in range(D):
+        ctx.frames_upload_cameras([ref[i][0]], [ref[i][1]], first_slot=0, n_levels=args.levels, first_shift=args.first_shift)
+        lv = []
+        for l in range(args.levels):
+            g, d, _, _ = ctx.frame_level(0, l)
+            lv.append((hold(np.ascontiguousarray(g)), hold(np.ascontiguousarray(d.astype(np.uint16)))))
+        pyr.append(lv)
+    pyr_b = [pyr[i % D] for i in range(B)]
+    res["config_pyramid_bytes_per_frame"] = int(sum(g.nbytes + d.nbytes for g, d in pyr[0]))
+    timed("upload_pyramids(mono8+mono16 row-major: H2D, import, Canny)", lambda: ctx.frames_upload_pyramids(pyr_b, first_slot=0, flags=DVO_UPLOAD_ASYNC), B)
+
     def tracking_step():                              # every pair gets a fresh now frame against its resident reference
         ctx.frames_upload_cameras(now_b, None, first_slot=B, **kw)
         ctx.frames_as_now(B, 0, B)
@@ -107,7 +120,7 @@ def main():
     out = dict(config=dict(batch=B, width=args.width, height=args.height, levels=args.levels, first_shift=args.first_shift,
                            pinned=args.pinned, host_bytes_per_ref_frame=args.width * args.height * 7,
                            host_bytes_per_now_frame=args.width * args.height * 3),
-               stages=res, mean_translation_m=float(np.linalg.norm(t, axis=1).mean()))
+               stages={k: v for k, v in res.items() if isinstance(v, dict)}, pyramid_bytes_per_frame=res.get("config_pyramid_bytes_per_frame"), mean_translation_m=float(np.linalg.norm(t, axis=1).mean()))
     print(json.dumps(out))
     ctx.close()
 
