@@ -91,6 +91,7 @@ struct dvo_ctx {
     size_t work_bytes = 0;
     /* frame uploads: two landing buffers filled by a copy stream while the context stream preprocesses the other */
     unsigned char *up_buf[2] = {nullptr, nullptr};
+    unsigned char *up_host[2] = {nullptr, nullptr};      /* pinned mirrors: small images are gathered here and go up in one copy */
     size_t up_bytes = 0;
     hipStream_t copy_stream = nullptr, copy_stream2 = nullptr;      /* two SDMA queues: frames alternate between them */
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_copied2[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
@@ -433,6 +434,7 @@ int dvo_destroy(dvo_ctx *c) {
     if (c->copy_stream2) { (void)hipStreamSynchronize(c->copy_stream2); (void)hipStreamDestroy(c->copy_stream2); }
     for (int b = 0; b < 2; b++) {
         if (c->up_buf[b]) (void)hipFree(c->up_buf[b]);
+        if (c->up_host[b]) (void)hipHostFree(c->up_host[b]);
         if (c->ev_copied[b]) (void)hipEventDestroy(c->ev_copied[b]);
         if (c->ev_copied2[b]) (void)hipEventDestroy(c->ev_copied2[b]);
         if (c->ev_done[b]) (void)hipEventDestroy(c->ev_done[b]);
@@ -1194,6 +1196,7 @@ int run_canny(dvo_ctx *c, int level, int first_slot, int count, hipStream_t stre
 }
 
 constexpr size_t kUploadHalf = (size_t)32 << 20;   /* landing buffer per pipeline stage */
+constexpr size_t kSmallImage = (size_t)256 << 10;  /* images up to this size are gathered on the host before they go up */
 
 /* landing buffers of at least `bytes` each + copy stream + events */
 int ensure_upload(dvo_ctx *c, size_t bytes) {
@@ -1212,8 +1215,10 @@ int ensure_upload(dvo_ctx *c, size_t bytes) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int b = 0; b < 2; b++) {
         if (c->up_buf[b]) HIPCHK(c, hipFree(c->up_buf[b]));
-        c->up_buf[b] = nullptr;
+        if (c->up_host[b]) HIPCHK(c, hipHostFree(c->up_host[b]));
+        c->up_buf[b] = nullptr; c->up_host[b] = nullptr;
         HIPCHK(c, hipMalloc((void **)&c->up_buf[b], bytes));
+        HIPCHK(c, hipHostMalloc((void **)&c->up_host[b], bytes, hipHostMallocDefault));
         c->up_used[b] = false;
     }
     c->up_bytes = bytes;
@@ -1305,16 +1310,35 @@ int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_leve
         const int nc = std::min(chunk, count - b);
         unsigned char *buf; int ub;
         if ((rc = upload_begin(c, &buf, &ub))) return rc;
+        /* A sub-megabyte hipMemcpyAsync costs ~10 us of host time however small it is, and a pyramid is mostly small
+         * images (the reference's 320x240 ... 40x30 levels: eight per frame): those are gathered into the pinned mirror
+         * of the landing buffer with memcpy and go up in one copy per run of small levels; big images go up directly. */
+        unsigned char *hbuf = c->up_host[ub];
+        if (c->up_used[ub]) HIPCHK(c, hipEventSynchronize(c->ev_copied[ub]));      /* the mirror's previous copy has left */
+        bool small[DVO_LEVELS];
         for (int l = 0; l < n_levels; l++) {
             const size_t npx = c->fs.lv[l].npx, gb = pix_bytes(grey[l].dtype), db = depth ? pix_bytes(depth[l].dtype) : 0;
+            small[l] = npx * std::max(gb, db) <= kSmallImage;
             for (int i = 0; i < nc; i++) {
-                hipStream_t cs = (i & 1) ? c->copy_stream2 : c->copy_stream;
-                HIPCHK(c, hipMemcpyAsync(buf + g_off[l] + g_img[l] * i, grey[(size_t)(b + i) * n_levels + l].data, npx * gb,
-                                         hipMemcpyHostToDevice, cs));
-                if (depth)
-                    HIPCHK(c, hipMemcpyAsync(buf + d_off[l] + d_img[l] * i, depth[(size_t)(b + i) * n_levels + l].data, npx * db,
-                                             hipMemcpyHostToDevice, cs));
+                const void *gsrc = grey[(size_t)(b + i) * n_levels + l].data;
+                const void *dsrc = depth ? depth[(size_t)(b + i) * n_levels + l].data : nullptr;
+                if (small[l]) {
+                    std::memcpy(hbuf + g_off[l] + g_img[l] * i, gsrc, npx * gb);
+                    if (depth) std::memcpy(hbuf + d_off[l] + d_img[l] * i, dsrc, npx * db);
+                } else {
+                    hipStream_t cs = (i & 1) ? c->copy_stream2 : c->copy_stream;
+                    HIPCHK(c, hipMemcpyAsync(buf + g_off[l] + g_img[l] * i, gsrc, npx * gb, hipMemcpyHostToDevice, cs));
+                    if (depth) HIPCHK(c, hipMemcpyAsync(buf + d_off[l] + d_img[l] * i, dsrc, npx * db, hipMemcpyHostToDevice, cs));
+                }
             }
+        }
+        for (int l = 0; l < n_levels;) {                                  /* one copy per maximal run of small levels */
+            if (!small[l]) { l++; continue; }
+            int e = l;
+            while (e + 1 < n_levels && small[e + 1]) e++;
+            const size_t lo = g_off[l], hi = (e + 1 < n_levels) ? g_off[e + 1] : frame_bytes * chunk;
+            HIPCHK(c, hipMemcpyAsync(buf + lo, hbuf + lo, hi - lo, hipMemcpyHostToDevice, c->copy_stream));
+            l = e + 1;
         }
         LevelLanes ln;
         if ((rc = lanes_begin(c, n_levels, nc, now_first_pair >= 0, ln))) return rc;
