@@ -1,5 +1,6 @@
 /*
- * dvo_capi.cpp -- implementation of the C ABI declared in include/dvo_amd.h.
+ * dvo_capi.cpp -- implementation of the C ABI declared in include/dvo_amd.h: lifecycle, inputs, hot path, inspection
+ * (the frame store -- rows f1 + f2 -- is dvo_capi_frames.cpp; both share dvo_ctx.h).
  *
  * Host side only: context + HBM slab management, uploads, kernel launches.
  * There is deliberately no CPU compute path in this file: every compute entry
@@ -11,112 +12,19 @@
  * dvo_launch.h::LevelSlab), so a 256-pair 640x480x4 batch is 8 large
  * allocations (~1.7 GB of texels) instead of 2048 small ones.
  */
-#include "../../include/dvo_amd.h"
-#include "dvo_launch.h"
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
+#include "dvo_ctx.h"
 
 using namespace dvo;
 
-namespace {
-thread_local std::string g_create_error;
 
-struct Level {
-    int rows = 0, cols = 0;
-    float4 *tex = nullptr;
-    size_t tex_stride = 0;
-    float *pts = nullptr;
-    uint2 *cpts = nullptr;          /* compact twin of pts (8 B / point), same capacity; valid where compact_ok */
-    std::vector<char> compact_ok;   /* per pair: the list came from the engine's enlist kernels */
-    int pt_cap = 0;
-    int *dN = nullptr;
-    std::vector<int> hN;            /* 0 = not set */
-    std::vector<char> have_now;
-};
+namespace { thread_local std::string g_create_error; }
 
-/* frame store (rows f1/f2): per level one slab per plane for all slots, slot s at base + s*npx */
-struct FrameLevel {
-    int rows = 0, cols = 0;
-    size_t npx = 0;
-    unsigned char *grey = nullptr, *edge = nullptr;
-    float *depth = nullptr;
-};
-struct FrameStore {
-    int n_slots = 0, n_levels = 0;
-    FrameLevel lv[DVO_LEVELS];
-    std::vector<char> valid, has_depth;
-};
-}  // namespace
-
-struct dvo_ctx {
-    dvo_params prm;
-    DevParams dprm;
-    int n_pairs = 0;
-    int n_cu = 256;                 /* compute units of the device (auto tuning of launch shapes) */
-    hipStream_t stream = nullptr;
-    hipStream_t own_stream = nullptr;
-    Intrinsics K{0, 0, 0, 0, 0};
-    bool have_K = false;
-    Level lv[DVO_LEVELS];
-    float *staging = nullptr;       /* 3 planes (or one point list) of the largest upload so far */
-    size_t staging_bytes = 0;
-    double *d_poses = nullptr;
-    float *d_energy = nullptr;
-    size_t energy_floats = 0;
-    int *d_best = nullptr;
-    float *d_ratio = nullptr;
-    float *d_final_eps = nullptr, *d_final_reproj = nullptr;
-    int *d_final_N = nullptr;
-    int final_cap = 0;
-    double *d_scratch = nullptr;    /* partials (1024 x 32) + acc (32) + misc doubles */
-    /* dvo_align_pyramid_wide as a replayable hipGraph (the schedule is ~2 dependent launches per iteration) */
-    hipGraphExec_t wide_exec = nullptr;
-    unsigned long long wide_sig = 0;
-    double *h_pose = nullptr;       /* pinned: in/out pose of the graph's copy nodes */
-    unsigned long long *d_dbg = nullptr;
-    char *d_states = nullptr;       /* n_pairs x pose_state_bytes(): host-driven iteration state */
-    float *d_iter_energy = nullptr; /* n_pairs x iter_energy_cap */
-    int iter_energy_cap = 0;
-    std::vector<int> iter_max;      /* per pair: max_iters of the running dvo_iter_begin (0 = none) */
-    int *d_colcounts = nullptr;
-    size_t colcounts_cap = 0;
-    FrameStore fs;
-    int *work = nullptr;            /* preprocessing scratch (Canny / distance transform / point counts) */
-    size_t work_bytes = 0;
-    /* frame uploads: two landing buffers filled by a copy stream while the context stream preprocesses the other */
-    unsigned char *up_buf[2] = {nullptr, nullptr};
-    unsigned char *up_host[2] = {nullptr, nullptr};      /* pinned mirrors: small images are gathered here and go up in one copy */
-    size_t up_bytes = 0;
-    hipStream_t copy_stream = nullptr, copy_stream2 = nullptr;      /* two SDMA queues: frames alternate between them */
-    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_copied2[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
-    bool up_used[2] = {false, false};
-    int up_next = 0;
-    /* small batches (a single camera stream): the pyramid levels are independent kernel chains, run side by side */
-    hipStream_t lvl_stream[DVO_LEVELS] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[DVO_LEVELS] = {};
-    Schedule sched{};
-    bool have_sched = false;
-    std::string err;
-};
-
-namespace {
+namespace dvo_host {
 
 int fail(dvo_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg; else g_create_error = msg;
     return code;
 }
-#define HIPCHK(c, expr)                                                                     \
-    do {                                                                                    \
-        hipError_t e_ = (expr);                                                             \
-        if (e_ != hipSuccess)                                                               \
-            return fail((c), DVO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-    } while (0)
 
 int ensure_staging(dvo_ctx *c, size_t bytes) {
     if (bytes <= c->staging_bytes) return DVO_OK;
@@ -187,6 +95,12 @@ int ensure_texels(dvo_ctx *c, int level, int rows, int cols) {
         HIPCHK(c, hipMemsetAsync(L.tex, 0, sizeof(float4) * L.tex_stride * c->n_pairs, c->stream));
     return DVO_OK;
 }
+
+}  // namespace dvo_host
+
+using namespace dvo_host;
+
+namespace {
 
 LevelSlab slab_of(const dvo_ctx *c, int level) {
     const Level &L = c->lv[level];
@@ -1045,512 +959,6 @@ int dvo_point_iterations(dvo_ctx *c, int pair, int n_levels, const int *iters, u
         n += (uint64_t)sc.iters[l] * (uint64_t)c->lv[l].hN[pair];
     }
     *count = n;
-    return DVO_OK;
-}
-
-/* ---- frame store: rows f1 + f2 ------------------------------------------------------------------------ */
-namespace {
-
-constexpr size_t kWorkBudget = (size_t)1 << 30;     /* scratch per chunk of a batched preprocessing call */
-
-int round_half_even_pos(double v) {                 /* cvRound for the non-negative sizes used here */
-    const double f = std::floor(v);
-    const double d = v - f;
-    int i = (int)f;
-    if (d > 0.5 || (d == 0.5 && (i & 1))) i++;
-    return i;
-}
-
-void canny_thresholds(const dvo_ctx *c, int *low, int *high) {
-    double t1 = c->prm.canny_threshold1, t2 = c->prm.canny_threshold2;
-    if (t1 == 0 && t2 == 0) { t1 = 150; t2 = 100; }               /* SolveDVO.cpp:1704, :1764 */
-    double lo = std::min(t1, t2), hi = std::max(t1, t2);          /* the detector swaps them */
-    lo = std::min(32767.0, lo); hi = std::min(32767.0, hi);
-    if (lo > 0) lo *= lo;                                         /* L2gradient: squared magnitudes */
-    if (hi > 0) hi *= hi;
-    *low = (int)std::floor(lo); *high = (int)std::floor(hi);
-}
-
-int frames_default_slots(const dvo_ctx *c) { return std::min(2 * c->n_pairs + 2, 64); }
-
-void frames_free(dvo_ctx *c) {
-    for (int l = 0; l < DVO_LEVELS; l++) {
-        FrameLevel &F = c->fs.lv[l];
-        void *fp[] = {F.grey, F.edge, F.depth};
-        for (void *p : fp) if (p) (void)hipFree(p);
-        F = FrameLevel();
-    }
-    c->fs.n_levels = 0;
-    std::fill(c->fs.valid.begin(), c->fs.valid.end(), 0);
-}
-
-/* make the store hold `n_levels` levels of the given geometry (drops the stored frames if it changes) */
-int frames_geometry(dvo_ctx *c, int n_levels, const int *rows, const int *cols) {
-    FrameStore &S = c->fs;
-    for (int l = 0; l < n_levels; l++)      /* squared distances are kept in 32-bit integers: (rows+cols+1)^2 < 2^31 */
-        if ((long long)rows[l] + cols[l] + 1 > 46340)
-            return fail(c, DVO_ERR_INVALID, "image too large for the exact distance transform (rows + cols must stay below 46339)");
-    if (S.n_slots == 0) {
-        S.n_slots = frames_default_slots(c);
-        S.valid.assign(S.n_slots, 0); S.has_depth.assign(S.n_slots, 0);
-    }
-    bool same = S.n_levels == n_levels;
-    for (int l = 0; same && l < n_levels; l++) same = S.lv[l].rows == rows[l] && S.lv[l].cols == cols[l];
-    if (same) return DVO_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    frames_free(c);
-    for (int l = 0; l < n_levels; l++) {
-        FrameLevel &F = S.lv[l];
-        F.rows = rows[l]; F.cols = cols[l]; F.npx = (size_t)rows[l] * cols[l];
-        HIPCHK(c, hipMalloc((void **)&F.grey, F.npx * S.n_slots));
-        HIPCHK(c, hipMalloc((void **)&F.edge, F.npx * S.n_slots));
-        HIPCHK(c, hipMalloc((void **)&F.depth, sizeof(float) * F.npx * S.n_slots));
-    }
-    S.n_levels = n_levels;
-    return DVO_OK;
-}
-
-bool slots_ok(const dvo_ctx *c, int first, int count) {
-    return first >= 0 && count >= 1 && first + count <= c->fs.n_slots;
-}
-
-int chunk_for(size_t bytes_per_image, int count) {
-    size_t k = kWorkBudget / std::max<size_t>(bytes_per_image, 1);
-    if (k < 1) k = 1;
-    return (int)std::min<size_t>(k, (size_t)count);
-}
-
-/* Per-level execution lanes.  Large batches: every level on the context stream, scratch shared and chunked.
- * Small batches (one camera stream): each level's kernel chain on its own stream with its own scratch, forked from
- * and joined back into the context stream -- the chains are independent, so a frame costs the longest chain instead
- * of their sum. */
-struct LevelLanes {
-    bool parallel = false;
-    hipStream_t s[DVO_LEVELS];
-    int *work[DVO_LEVELS];          /* nullptr: use c->work with chunking */
-};
-constexpr size_t kParallelPixels = (size_t)4 << 20;
-
-int lanes_begin(dvo_ctx *c, int n_levels, int count, bool with_now, LevelLanes &ln) {
-    int rc;
-    if (with_now)
-        for (int l = 0; l < n_levels; l++)
-            if ((rc = ensure_texels(c, l, c->fs.lv[l].rows, c->fs.lv[l].cols))) return rc;
-    ln.parallel = n_levels > 1 && (size_t)count * c->fs.lv[0].npx <= kParallelPixels;
-    for (int l = 0; l < n_levels; l++) { ln.s[l] = c->stream; ln.work[l] = nullptr; }
-    if (!ln.parallel) return DVO_OK;
-    size_t off[DVO_LEVELS + 1];
-    off[0] = 0;
-    for (int l = 0; l < n_levels; l++) {
-        const FrameLevel &F = c->fs.lv[l];
-        size_t need = canny_work_ints(F.rows, F.cols, count);
-        if (with_now) need = std::max(need, edt_work_ints(F.rows, F.cols, count));
-        off[l + 1] = off[l] + (need + 31) / 32 * 32;
-    }
-    if ((rc = ensure_work(c, sizeof(int) * off[n_levels]))) return rc;
-    if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    for (int l = 0; l < n_levels; l++) {
-        if (!c->lvl_stream[l]) {
-            HIPCHK(c, hipStreamCreateWithFlags(&c->lvl_stream[l], hipStreamNonBlocking));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[l], hipEventDisableTiming));
-        }
-        ln.s[l] = c->lvl_stream[l];
-        ln.work[l] = c->work + off[l];
-    }
-    return DVO_OK;
-}
-int lanes_fork(dvo_ctx *c, int n_levels, const LevelLanes &ln) {
-    if (!ln.parallel) return DVO_OK;
-    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-    for (int l = 0; l < n_levels; l++) HIPCHK(c, hipStreamWaitEvent(ln.s[l], c->ev_fork, 0));
-    return DVO_OK;
-}
-int lanes_join(dvo_ctx *c, int n_levels, const LevelLanes &ln) {
-    if (!ln.parallel) return DVO_OK;
-    for (int l = 0; l < n_levels; l++) {
-        HIPCHK(c, hipEventRecord(c->ev_join[l], ln.s[l]));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[l], 0));
-    }
-    return DVO_OK;
-}
-
-int run_canny(dvo_ctx *c, int level, int first_slot, int count, hipStream_t stream, int *work) {
-    FrameLevel &F = c->fs.lv[level];
-    int low, high;
-    canny_thresholds(c, &low, &high);
-    if (work) {
-        const size_t off = (size_t)first_slot * F.npx;
-        HIPCHK(c, launch_canny(F.grey + off, F.npx, ImgBatch{F.rows, F.cols, count}, low, high, work, F.edge + off, F.npx, stream));
-        return DVO_OK;
-    }
-    const int chunk = chunk_for(sizeof(int) * canny_work_ints(F.rows, F.cols, 1), count);
-    int rc = ensure_work(c, sizeof(int) * canny_work_ints(F.rows, F.cols, chunk));
-    if (rc) return rc;
-    for (int b = 0; b < count; b += chunk) {
-        const int nc = std::min(chunk, count - b);
-        const size_t off = (size_t)(first_slot + b) * F.npx;
-        HIPCHK(c, launch_canny(F.grey + off, F.npx, ImgBatch{F.rows, F.cols, nc}, low, high, c->work,
-                               F.edge + off, F.npx, stream));
-    }
-    return DVO_OK;
-}
-
-constexpr size_t kUploadHalf = (size_t)32 << 20;   /* landing buffer per pipeline stage */
-constexpr size_t kSmallImage = (size_t)256 << 10;  /* images up to this size are gathered on the host before they go up */
-
-/* landing buffers of at least `bytes` each + copy stream + events */
-int ensure_upload(dvo_ctx *c, size_t bytes) {
-    if (!c->copy_stream) {
-        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking));
-        for (int b = 0; b < 2; b++) {
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_copied[b], hipEventDisableTiming));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_copied2[b], hipEventDisableTiming));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_done[b], hipEventDisableTiming));
-        }
-    }
-    if (bytes <= c->up_bytes) return DVO_OK;
-    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
-    HIPCHK(c, hipStreamSynchronize(c->copy_stream2));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int b = 0; b < 2; b++) {
-        if (c->up_buf[b]) HIPCHK(c, hipFree(c->up_buf[b]));
-        if (c->up_host[b]) HIPCHK(c, hipHostFree(c->up_host[b]));
-        c->up_buf[b] = nullptr; c->up_host[b] = nullptr;
-        HIPCHK(c, hipMalloc((void **)&c->up_buf[b], bytes));
-        HIPCHK(c, hipHostMalloc((void **)&c->up_host[b], bytes, hipHostMallocDefault));
-        c->up_used[b] = false;
-    }
-    c->up_bytes = bytes;
-    return DVO_OK;
-}
-/* stage A of a chunk: returns the landing buffer; copies must go to c->copy_stream */
-int upload_begin(dvo_ctx *c, unsigned char **buf, int *slot) {
-    const int b = c->up_next;
-    if (c->up_used[b]) {                                /* its previous consumer finished */
-        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_done[b], 0));
-        HIPCHK(c, hipStreamWaitEvent(c->copy_stream2, c->ev_done[b], 0));
-    }
-    *buf = c->up_buf[b]; *slot = b;
-    return DVO_OK;
-}
-/* stage B: everything enqueued on c->stream after this sees the copies */
-int upload_copied(dvo_ctx *c, int b) {
-    HIPCHK(c, hipEventRecord(c->ev_copied[b], c->copy_stream));
-    HIPCHK(c, hipEventRecord(c->ev_copied2[b], c->copy_stream2));
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copied[b], 0));
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copied2[b], 0));
-    return DVO_OK;
-}
-/* stage C: the kernels reading the landing buffer are enqueued */
-int upload_consumed(dvo_ctx *c, int b) {
-    HIPCHK(c, hipEventRecord(c->ev_done[b], c->stream));
-    c->up_used[b] = true;
-    c->up_next = b ^ 1;
-    return DVO_OK;
-}
-
-size_t pix_bytes(int dtype) { return dtype == DVO_PIX_U8 ? 1 : (dtype == DVO_PIX_U16 ? 2 : 4); }
-
-}  // namespace
-
-static int frames_as_now_level(dvo_ctx *c, int level, int first_slot, int first_pair, int count, hipStream_t stream, int *work);
-
-int dvo_frames_reserve(dvo_ctx *c, int n_slots) {
-    if (!c) return DVO_ERR_INVALID;
-    if (n_slots < 1) return fail(c, DVO_ERR_INVALID, "n_slots must be >= 1");
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    frames_free(c);
-    c->fs.n_slots = n_slots;
-    c->fs.valid.assign(n_slots, 0);
-    c->fs.has_depth.assign(n_slots, 0);
-    return DVO_OK;
-}
-
-int dvo_frames_num_levels(const dvo_ctx *c) { return c ? c->fs.n_levels : 0; }
-
-int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_levels,
-                               const dvo_image *grey, const dvo_image *depth, int now_first_pair, int flags) {
-    if (!c) return DVO_ERR_INVALID;
-    if (!grey || count < 1 || n_levels < 1 || n_levels > DVO_LEVELS) return fail(c, DVO_ERR_INVALID, "bad frame arguments");
-    int rows[DVO_LEVELS], cols[DVO_LEVELS];
-    for (int l = 0; l < n_levels; l++) { rows[l] = grey[l].rows; cols[l] = grey[l].cols; }
-    for (int f = 0; f < count; f++)
-        for (int l = 0; l < n_levels; l++) {
-            const dvo_image &g = grey[(size_t)f * n_levels + l];
-            if (!g.data || g.rows < 1 || g.cols < 1 || g.rows != rows[l] || g.cols != cols[l] ||
-                (g.dtype != DVO_PIX_U8 && g.dtype != DVO_PIX_F32) || g.dtype != grey[l].dtype || g.layout != grey[l].layout)
-                return fail(c, DVO_ERR_INVALID, "grey images of one level must share size, dtype (U8/F32) and layout");
-            if (depth) {
-                const dvo_image &d = depth[(size_t)f * n_levels + l];
-                if (!d.data || d.rows != rows[l] || d.cols != cols[l] || (d.dtype != DVO_PIX_U16 && d.dtype != DVO_PIX_F32) ||
-                    d.dtype != depth[l].dtype || d.layout != depth[l].layout)
-                    return fail(c, DVO_ERR_INVALID, "depth images must match the grey size and share dtype (U16/F32) and layout");
-            }
-        }
-    int rc = frames_geometry(c, n_levels, rows, cols);
-    if (rc) return rc;
-    if (!slots_ok(c, first_slot, count)) return fail(c, DVO_ERR_INVALID, "frame slot range out of bounds (dvo_frames_reserve)");
-    if (now_first_pair >= 0 && (!pair_ok(c, now_first_pair) || now_first_pair + count > c->n_pairs))
-        return fail(c, DVO_ERR_INVALID, "now_first_pair range out of bounds");
-    /* chunks of frames flow through copy (copy stream) -> import + Canny (context stream), double-buffered */
-    size_t g_img[DVO_LEVELS], d_img[DVO_LEVELS], g_off[DVO_LEVELS], d_off[DVO_LEVELS], frame_bytes = 0;
-    for (int l = 0; l < n_levels; l++) {
-        const size_t npx = c->fs.lv[l].npx;
-        g_img[l] = (npx * pix_bytes(grey[l].dtype) + 15) / 16 * 16;           /* 16-byte aligned images */
-        d_img[l] = depth ? (npx * pix_bytes(depth[l].dtype) + 15) / 16 * 16 : 0;
-        frame_bytes += g_img[l] + d_img[l];
-    }
-    const int chunk = (int)std::min<size_t>(std::max<size_t>(kUploadHalf / frame_bytes, 1), (size_t)count);
-    if ((rc = ensure_upload(c, frame_bytes * chunk))) return rc;
-    {   size_t o = 0;                                   /* landing layout: per level, `chunk` grey images then `chunk` depth images */
-        for (int l = 0; l < n_levels; l++) { g_off[l] = o; o += g_img[l] * chunk; d_off[l] = o; o += d_img[l] * chunk; }
-    }
-    for (int b = 0; b < count; b += chunk) {
-        const int nc = std::min(chunk, count - b);
-        unsigned char *buf; int ub;
-        if ((rc = upload_begin(c, &buf, &ub))) return rc;
-        /* A sub-megabyte hipMemcpyAsync costs ~10 us of host time however small it is, and a pyramid is mostly small
-         * images (the reference's 320x240 ... 40x30 levels: eight per frame): those are gathered into the pinned mirror
-         * of the landing buffer with memcpy and go up in one copy per run of small levels; big images go up directly. */
-        unsigned char *hbuf = c->up_host[ub];
-        if (c->up_used[ub]) HIPCHK(c, hipEventSynchronize(c->ev_copied[ub]));      /* the mirror's previous copy has left */
-        bool small[DVO_LEVELS];
-        for (int l = 0; l < n_levels; l++) {
-            const size_t npx = c->fs.lv[l].npx, gb = pix_bytes(grey[l].dtype), db = depth ? pix_bytes(depth[l].dtype) : 0;
-            small[l] = npx * std::max(gb, db) <= kSmallImage;
-            for (int i = 0; i < nc; i++) {
-                const void *gsrc = grey[(size_t)(b + i) * n_levels + l].data;
-                const void *dsrc = depth ? depth[(size_t)(b + i) * n_levels + l].data : nullptr;
-                if (small[l]) {
-                    std::memcpy(hbuf + g_off[l] + g_img[l] * i, gsrc, npx * gb);
-                    if (depth) std::memcpy(hbuf + d_off[l] + d_img[l] * i, dsrc, npx * db);
-                } else {
-                    hipStream_t cs = (i & 1) ? c->copy_stream2 : c->copy_stream;
-                    HIPCHK(c, hipMemcpyAsync(buf + g_off[l] + g_img[l] * i, gsrc, npx * gb, hipMemcpyHostToDevice, cs));
-                    if (depth) HIPCHK(c, hipMemcpyAsync(buf + d_off[l] + d_img[l] * i, dsrc, npx * db, hipMemcpyHostToDevice, cs));
-                }
-            }
-        }
-        for (int l = 0; l < n_levels;) {                                  /* one copy per maximal run of small levels */
-            if (!small[l]) { l++; continue; }
-            int e = l;
-            while (e + 1 < n_levels && small[e + 1]) e++;
-            const size_t lo = g_off[l], hi = (e + 1 < n_levels) ? g_off[e + 1] : frame_bytes * chunk;
-            HIPCHK(c, hipMemcpyAsync(buf + lo, hbuf + lo, hi - lo, hipMemcpyHostToDevice, c->copy_stream));
-            l = e + 1;
-        }
-        LevelLanes ln;
-        if ((rc = lanes_begin(c, n_levels, nc, now_first_pair >= 0, ln))) return rc;
-        if ((rc = upload_copied(c, ub))) return rc;
-        if ((rc = lanes_fork(c, n_levels, ln))) return rc;
-        for (int pass = 0; pass < 2; pass++) {              /* sequential lanes: all imports, then release the landing buffer, then the rest */
-            for (int l = 0; l < n_levels; l++) {
-                FrameLevel &F = c->fs.lv[l];
-                const size_t off = (size_t)(first_slot + b) * F.npx;
-                const ImgBatch ib{F.rows, F.cols, nc};
-                if (pass == 0 || ln.parallel) {
-                    HIPCHK(c, launch_import_grey(buf + g_off[l], grey[l].dtype, grey[l].layout == DVO_LAYOUT_ROW_MAJOR,
-                                                 g_img[l] / pix_bytes(grey[l].dtype), F.grey + off, F.npx, ib, ln.s[l]));
-                    if (depth)
-                        HIPCHK(c, launch_import_depth(buf + d_off[l], depth[l].dtype, depth[l].layout == DVO_LAYOUT_ROW_MAJOR,
-                                                      d_img[l] / pix_bytes(depth[l].dtype), F.depth + off, F.npx, ib, ln.s[l]));
-                }
-                if (pass == 1 || ln.parallel) {
-                    if ((rc = run_canny(c, l, first_slot + b, nc, ln.s[l], ln.work[l]))) return rc;
-                    if (now_first_pair >= 0 &&
-                        (rc = frames_as_now_level(c, l, first_slot + b, now_first_pair + b, nc, ln.s[l], ln.work[l]))) return rc;
-                }
-            }
-            if (ln.parallel) break;
-            if (pass == 0 && (rc = upload_consumed(c, ub))) return rc;
-        }
-        if (ln.parallel) {
-            if ((rc = lanes_join(c, n_levels, ln))) return rc;
-            if ((rc = upload_consumed(c, ub))) return rc;
-        }
-    }
-    for (int f = 0; f < count; f++) { c->fs.valid[first_slot + f] = 1; c->fs.has_depth[first_slot + f] = depth ? 1 : 0; }
-    if (!(flags & DVO_UPLOAD_ASYNC)) HIPCHK(c, hipStreamSynchronize(c->stream));
-    return DVO_OK;
-}
-
-int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsigned char *const *bgr8,
-                              const float *const *depth_m, int rows, int cols, int n_levels, int first_shift,
-                              int now_first_pair, int flags) {
-    if (!c) return DVO_ERR_INVALID;
-    if (!bgr8 || count < 1 || rows < 1 || cols < 1 || n_levels < 1 || n_levels > DVO_LEVELS || first_shift < 0 ||
-        first_shift + n_levels > 16)
-        return fail(c, DVO_ERR_INVALID, "bad camera frame arguments");
-    for (int f = 0; f < count; f++)
-        if (!bgr8[f] || (depth_m && !depth_m[f])) return fail(c, DVO_ERR_INVALID, "NULL camera image");
-    int lr[DVO_LEVELS], lc[DVO_LEVELS];
-    for (int l = 0; l < n_levels; l++) {          /* cv::resize(Size(), s, s): dsize = cvRound(size * s) */
-        const double sc = std::ldexp(1.0, -(first_shift + l));
-        lr[l] = round_half_even_pos(rows * sc); lc[l] = round_half_even_pos(cols * sc);
-        if (lr[l] < 1 || lc[l] < 1) return fail(c, DVO_ERR_INVALID, "pyramid level would be empty");
-    }
-    int rc = frames_geometry(c, n_levels, lr, lc);
-    if (rc) return rc;
-    if (!slots_ok(c, first_slot, count)) return fail(c, DVO_ERR_INVALID, "frame slot range out of bounds (dvo_frames_reserve)");
-    if (now_first_pair >= 0 && (!pair_ok(c, now_first_pair) || now_first_pair + count > c->n_pairs))
-        return fail(c, DVO_ERR_INVALID, "now_first_pair range out of bounds");
-    const size_t npx = (size_t)rows * cols;
-    const size_t b_img = (npx * 3 + 15) / 16 * 16, d_img = depth_m ? npx * 4 : 0;
-    const int chunk = (int)std::min<size_t>(std::max<size_t>(kUploadHalf / (b_img + d_img), 1), (size_t)count);
-    if ((rc = ensure_upload(c, (b_img + d_img) * chunk))) return rc;
-    for (int b = 0; b < count; b += chunk) {            /* copy chunk k+1 (copy stream) while chunk k is preprocessed */
-        const int nc = std::min(chunk, count - b);
-        unsigned char *sb; int ub;
-        if ((rc = upload_begin(c, &sb, &ub))) return rc;
-        float *sd = (float *)(sb + b_img * chunk);
-        for (int i = 0; i < nc; i++) {
-            hipStream_t cs = (i & 1) ? c->copy_stream2 : c->copy_stream;
-            HIPCHK(c, hipMemcpyAsync(sb + b_img * i, bgr8[b + i], npx * 3, hipMemcpyHostToDevice, cs));
-            if (depth_m) HIPCHK(c, hipMemcpyAsync(sd + npx * i, depth_m[b + i], npx * 4, hipMemcpyHostToDevice, cs));
-        }
-        LevelLanes ln;
-        if ((rc = lanes_begin(c, n_levels, nc, now_first_pair >= 0, ln))) return rc;
-        if ((rc = upload_copied(c, ub))) return rc;
-        if ((rc = lanes_fork(c, n_levels, ln))) return rc;
-        for (int pass = 0; pass < 2; pass++) {
-            for (int l = 0; l < n_levels; l++) {
-                FrameLevel &F = c->fs.lv[l];
-                const size_t off = (size_t)(first_slot + b) * F.npx;
-                if (pass == 0 || ln.parallel)
-                    HIPCHK(c, launch_camera_level(sb, b_img, depth_m ? sd : nullptr, npx, rows, cols, first_shift + l,
-                                                  F.grey + off, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, nc}, ln.s[l]));
-                if (pass == 1 || ln.parallel) {
-                    if ((rc = run_canny(c, l, first_slot + b, nc, ln.s[l], ln.work[l]))) return rc;
-                    if (now_first_pair >= 0 &&
-                        (rc = frames_as_now_level(c, l, first_slot + b, now_first_pair + b, nc, ln.s[l], ln.work[l]))) return rc;
-                }
-            }
-            if (ln.parallel) break;
-            if (pass == 0 && (rc = upload_consumed(c, ub))) return rc;
-        }
-        if (ln.parallel) {
-            if ((rc = lanes_join(c, n_levels, ln))) return rc;
-            if ((rc = upload_consumed(c, ub))) return rc;
-        }
-    }
-    for (int f = 0; f < count; f++) { c->fs.valid[first_slot + f] = 1; c->fs.has_depth[first_slot + f] = depth_m ? 1 : 0; }
-    if (!(flags & DVO_UPLOAD_ASYNC)) HIPCHK(c, hipStreamSynchronize(c->stream));
-    return DVO_OK;
-}
-
-static int frames_check_use(dvo_ctx *c, int first_slot, int first_pair, int count, bool need_depth) {
-    if (c->fs.n_levels < 1) return fail(c, DVO_ERR_STATE, "frame store is empty (dvo_frames_upload_*)");
-    if (!slots_ok(c, first_slot, count)) return fail(c, DVO_ERR_INVALID, "frame slot range out of bounds");
-    if (!pair_ok(c, first_pair) || first_pair + count > c->n_pairs) return fail(c, DVO_ERR_INVALID, "pair range out of bounds");
-    for (int f = first_slot; f < first_slot + count; f++) {
-        if (!c->fs.valid[f]) return fail(c, DVO_ERR_STATE, "frame slot " + std::to_string(f) + " holds no frame");
-        if (need_depth && !c->fs.has_depth[f]) return fail(c, DVO_ERR_STATE, "frame slot " + std::to_string(f) + " has no depth");
-    }
-    return DVO_OK;
-}
-
-static int frames_as_now_level(dvo_ctx *c, int l, int first_slot, int first_pair, int count, hipStream_t stream, int *work) {
-    int rc;
-    FrameLevel &F = c->fs.lv[l];
-    if ((rc = ensure_texels(c, l, F.rows, F.cols))) return rc;
-    Level &L = c->lv[l];
-    if (work) {
-        HIPCHK(c, launch_edges_to_texels(F.edge + (size_t)first_slot * F.npx, F.npx, ImgBatch{F.rows, F.cols, count}, work,
-                                         L.tex + (size_t)first_pair * L.tex_stride, L.tex_stride, stream));
-    } else {
-        const int chunk = chunk_for(sizeof(int) * edt_work_ints(F.rows, F.cols, 1), count);
-        if ((rc = ensure_work(c, sizeof(int) * edt_work_ints(F.rows, F.cols, chunk)))) return rc;
-        for (int b = 0; b < count; b += chunk) {
-            const int nc = std::min(chunk, count - b);
-            HIPCHK(c, launch_edges_to_texels(F.edge + (size_t)(first_slot + b) * F.npx, F.npx, ImgBatch{F.rows, F.cols, nc},
-                                             c->work, L.tex + (size_t)(first_pair + b) * L.tex_stride, L.tex_stride, stream));
-        }
-    }
-    for (int i = 0; i < count; i++) L.have_now[first_pair + i] = 1;
-    return DVO_OK;
-}
-
-int dvo_frames_as_now(dvo_ctx *c, int first_slot, int first_pair, int count) {
-    if (!c) return DVO_ERR_INVALID;
-    int rc = frames_check_use(c, first_slot, first_pair, count, false);
-    if (rc) return rc;
-    const int nl = c->fs.n_levels;
-    LevelLanes ln;
-    if ((rc = lanes_begin(c, nl, count, true, ln))) return rc;
-    if ((rc = lanes_fork(c, nl, ln))) return rc;
-    for (int l = 0; l < nl; l++)
-        if ((rc = frames_as_now_level(c, l, first_slot, first_pair, count, ln.s[l], ln.work[l]))) return rc;
-    return lanes_join(c, nl, ln);
-}
-
-int dvo_frames_as_ref(dvo_ctx *c, int first_slot, int first_pair, int count, int *N_out) {
-    if (!c) return DVO_ERR_INVALID;
-    if (!c->have_K) return fail(c, DVO_ERR_STATE, "intrinsics not set (dvo_set_intrinsics)");
-    int rc = frames_check_use(c, first_slot, first_pair, count, true);
-    if (rc) return rc;
-    const int nl = c->fs.n_levels;
-    size_t cc_off[DVO_LEVELS + 1];                      /* per level: count x (cols+2) column counters */
-    cc_off[0] = 0;
-    for (int l = 0; l < nl; l++) cc_off[l + 1] = cc_off[l] + (size_t)count * (c->fs.lv[l].cols + 2);
-    if ((rc = ensure_work(c, sizeof(int) * cc_off[nl]))) return rc;
-    std::vector<int> hN((size_t)count * nl);
-    for (int l = 0; l < nl; l++) {
-        FrameLevel &F = c->fs.lv[l];
-        const size_t off = (size_t)first_slot * F.npx;
-        int *cc = c->work + cc_off[l];
-        HIPCHK(c, launch_enlist_count(F.edge + off, 1, F.npx, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, count}, cc, c->stream));
-        HIPCHK(c, hipMemcpy2DAsync(hN.data() + (size_t)l * count, sizeof(int), cc + F.cols, sizeof(int) * (F.cols + 2),
-                                   sizeof(int), count, hipMemcpyDeviceToHost, c->stream));
-    }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    int bad_level = -1, bad_frame = -1;
-    for (int l = 0; l < nl; l++) {
-        FrameLevel &F = c->fs.lv[l];
-        int maxN = 0;
-        for (int i = 0; i < count; i++) {
-            const int N = hN[(size_t)l * count + i];
-            maxN = std::max(maxN, N);
-            if (N < 1 && bad_level < 0) { bad_level = l; bad_frame = i; }
-            if (N_out) N_out[(size_t)i * nl + l] = N;
-        }
-        if ((rc = ensure_points(c, l, std::max(maxN, 1)))) return rc;
-        Level &L = c->lv[l];
-        const size_t off = (size_t)first_slot * F.npx;
-        HIPCHK(c, launch_enlist_write(F.edge + off, 1, F.npx, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, count}, l, c->K,
-                                      c->work + cc_off[l], L.pts + (size_t)first_pair * L.pt_cap * 3, (size_t)L.pt_cap * 3,
-                                      L.cpts + (size_t)first_pair * L.pt_cap, nullptr, L.pt_cap, L.dN + first_pair, c->stream));
-        for (int i = 0; i < count; i++) { L.hN[first_pair + i] = hN[(size_t)l * count + i]; L.compact_ok[first_pair + i] = 1; }
-    }
-    if (bad_level >= 0)
-        return fail(c, DVO_ERR_INVALID, "no reference point selected in frame " + std::to_string(first_slot + bad_frame) +
-                                            " level " + std::to_string(bad_level) +
-                                            " (reference asserts nSelectedPts > 0, SolveDVO.cpp:282)");
-    return DVO_OK;
-}
-
-int dvo_frame_get_level(dvo_ctx *c, int slot, int level, int *rows, int *cols, unsigned char *grey,
-                        float *depth_mm, unsigned char *edge, int *n_edges) {
-    if (!c) return DVO_ERR_INVALID;
-    if (level < 0 || level >= c->fs.n_levels) return fail(c, DVO_ERR_INVALID, "frame level out of range");
-    if (!slots_ok(c, slot, 1) || !c->fs.valid[slot]) return fail(c, DVO_ERR_STATE, "frame slot holds no frame");
-    FrameLevel &F = c->fs.lv[level];
-    if (rows) *rows = F.rows;
-    if (cols) *cols = F.cols;
-    const size_t off = (size_t)slot * F.npx;
-    if (grey) HIPCHK(c, hipMemcpyAsync(grey, F.grey + off, F.npx, hipMemcpyDeviceToHost, c->stream));
-    if (edge) HIPCHK(c, hipMemcpyAsync(edge, F.edge + off, F.npx, hipMemcpyDeviceToHost, c->stream));
-    if (depth_mm) {
-        if (!c->fs.has_depth[slot]) return fail(c, DVO_ERR_STATE, "frame slot has no depth");
-        HIPCHK(c, hipMemcpyAsync(depth_mm, F.depth + off, sizeof(float) * F.npx, hipMemcpyDeviceToHost, c->stream));
-    }
-    if (n_edges) {
-        int rc = ensure_work(c, sizeof(int));
-        if (rc) return rc;
-        HIPCHK(c, launch_count_edges(F.edge + off, F.npx, c->work, c->stream));
-        HIPCHK(c, hipMemcpyAsync(n_edges, c->work, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     return DVO_OK;
 }
 

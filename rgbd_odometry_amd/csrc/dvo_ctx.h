@@ -1,0 +1,119 @@
+/*
+ * dvo_ctx.h -- the engine context (struct dvo_ctx) and the host helpers shared by the two halves of the C-ABI
+ * implementation: dvo_capi.cpp (lifecycle, inputs, hot path, inspection) and dvo_capi_frames.cpp (frame store,
+ * rows f1 + f2).  Internal; not installed.
+ */
+#ifndef DVO_CTX_H_
+#define DVO_CTX_H_
+
+#include "../../include/dvo_amd.h"
+#include "dvo_launch.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace dvo_host {
+
+struct Level {
+    int rows = 0, cols = 0;
+    float4 *tex = nullptr;
+    size_t tex_stride = 0;
+    float *pts = nullptr;
+    uint2 *cpts = nullptr;          /* compact twin of pts (8 B / point), same capacity; valid where compact_ok */
+    std::vector<char> compact_ok;   /* per pair: the list came from the engine's enlist kernels */
+    int pt_cap = 0;
+    int *dN = nullptr;
+    std::vector<int> hN;            /* 0 = not set */
+    std::vector<char> have_now;
+};
+
+/* frame store (rows f1/f2): per level one slab per plane for all slots, slot s at base + s*npx */
+struct FrameLevel {
+    int rows = 0, cols = 0;
+    size_t npx = 0;
+    unsigned char *grey = nullptr, *edge = nullptr;
+    float *depth = nullptr;
+};
+struct FrameStore {
+    int n_slots = 0, n_levels = 0;
+    FrameLevel lv[DVO_LEVELS];
+    std::vector<char> valid, has_depth;
+};
+}  // namespace dvo_host
+
+struct dvo_ctx {
+    dvo_params prm;
+    dvo::DevParams dprm;
+    int n_pairs = 0;
+    int n_cu = 256;                 /* compute units of the device (auto tuning of launch shapes) */
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    dvo::Intrinsics K{0, 0, 0, 0, 0};
+    bool have_K = false;
+    dvo_host::Level lv[DVO_LEVELS];
+    float *staging = nullptr;       /* 3 planes (or one point list) of the largest upload so far */
+    size_t staging_bytes = 0;
+    double *d_poses = nullptr;
+    float *d_energy = nullptr;
+    size_t energy_floats = 0;
+    int *d_best = nullptr;
+    float *d_ratio = nullptr;
+    float *d_final_eps = nullptr, *d_final_reproj = nullptr;
+    int *d_final_N = nullptr;
+    int final_cap = 0;
+    double *d_scratch = nullptr;    /* partials (1024 x 32) + acc (32) + misc doubles */
+    /* dvo_align_pyramid_wide as a replayable hipGraph (the schedule is ~2 dependent launches per iteration) */
+    hipGraphExec_t wide_exec = nullptr;
+    unsigned long long wide_sig = 0;
+    double *h_pose = nullptr;       /* pinned: in/out pose of the graph's copy nodes */
+    unsigned long long *d_dbg = nullptr;
+    char *d_states = nullptr;       /* n_pairs x pose_state_bytes(): host-driven iteration state */
+    float *d_iter_energy = nullptr; /* n_pairs x iter_energy_cap */
+    int iter_energy_cap = 0;
+    std::vector<int> iter_max;      /* per pair: max_iters of the running dvo_iter_begin (0 = none) */
+    int *d_colcounts = nullptr;
+    size_t colcounts_cap = 0;
+    dvo_host::FrameStore fs;
+    int *work = nullptr;            /* preprocessing scratch (Canny / distance transform / point counts) */
+    size_t work_bytes = 0;
+    /* frame uploads: two landing buffers filled by a copy stream while the context stream preprocesses the other */
+    unsigned char *up_buf[2] = {nullptr, nullptr};
+    unsigned char *up_host[2] = {nullptr, nullptr};      /* pinned mirrors: small images are gathered here and go up in one copy */
+    size_t up_bytes = 0;
+    hipStream_t copy_stream = nullptr, copy_stream2 = nullptr;      /* two SDMA queues: frames alternate between them */
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_copied2[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    bool up_used[2] = {false, false};
+    int up_next = 0;
+    /* small batches (a single camera stream): the pyramid levels are independent kernel chains, run side by side */
+    hipStream_t lvl_stream[DVO_LEVELS] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[DVO_LEVELS] = {};
+    dvo::Schedule sched{};
+    bool have_sched = false;
+    std::string err;
+};
+
+
+namespace dvo_host {
+
+int fail(dvo_ctx *c, int code, const std::string &msg);
+#define HIPCHK(c, expr)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return dvo_host::fail((c), DVO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int ensure_staging(dvo_ctx *c, size_t bytes);
+int ensure_work(dvo_ctx *c, size_t bytes);
+bool pair_ok(const dvo_ctx *c, int pair);
+bool level_ok(int level);
+int ensure_points(dvo_ctx *c, int level, int N);                 /* room for N points per pair at `level` (keeps contents) */
+int ensure_texels(dvo_ctx *c, int level, int rows, int cols);
+
+}  // namespace dvo_host
+#endif
