@@ -120,8 +120,7 @@ def frames_leg(args, iters):
     """Rows f1+f2, reported next to the headline and never as `value`: the same workload fed from camera frames in
     (pinned) HOST memory -- BGR8 + depth uploaded over PCIe, pyramid / Canny / distance transform / point extraction
     on the GPU -- to poses on the host.  Bounded: 256 pairs, 3 repetitions."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import frame_gen
+    from rgbd_odometry_amd import frame_gen
     from rgbd_odometry_amd import DvoContext
     from rgbd_odometry_amd.capi import DVO_FLAG_IDENTITY_START, DVO_UPLOAD_ASYNC
     B, D = 256, 8

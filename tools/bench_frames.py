@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--pinned", action="store_true", help="frames live in pinned host memory (torch pin_memory)")
     args = ap.parse_args()
-    import frame_gen
+    from rgbd_odometry_amd import frame_gen
     from rgbd_odometry_amd import DvoContext
     from rgbd_odometry_amd.capi import DVO_FLAG_IDENTITY_START, DVO_UPLOAD_ASYNC
 

@@ -2,7 +2,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-import frame_gen
+from rgbd_odometry_amd import frame_gen
 from rgbd_odometry_amd import DvoContext
 ctx = DvoContext(1)
 ctx.set_intrinsics(525.0, 525.0, 319.5, 239.5)

@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
 import numpy as np, torch
 from rgbd_odometry_amd import DvoContext, SynthScene
-import frame_gen
+from rgbd_odometry_amd import frame_gen
 sc = SynthScene(320, 240, 4, 3)
 frames = [frame_gen.camera_frame(i, 240, 320) for i in range(3)]
 torch.cuda.init()

@@ -4,7 +4,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-import frame_gen
+from rgbd_odometry_amd import frame_gen
 from rgbd_odometry_amd import DvoContext
 from rgbd_odometry_amd.capi import DVO_FLAG_IDENTITY_START, DVO_UPLOAD_ASYNC
 B, D = 256, 8

@@ -5,7 +5,8 @@ import os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-import frame_gen, frame_io, oracle_lib
+import frame_io, oracle_lib
+from rgbd_odometry_amd import frame_gen
 W, H, nl, it, n = [int(x) for x in (sys.argv[1:6] if len(sys.argv) > 5 else (320, 240, 4, 50, 16))]
 o = oracle_lib.load()
 d = tempfile.mkdtemp()
