@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--no-final-outputs", action="store_true")
     ap.add_argument("--inflight", type=int, default=0, help="points in flight per lane (1/2/4; 0 = default)")
     ap.add_argument("--lds-point-bytes", type=int, default=0, help="LDS bytes per workgroup for resident points (0 auto, <0 none)")
+    ap.add_argument("--variant", type=int, default=0, help="engine_variant (0 auto, 1 = one-point-per-lane fused kernel)")
     ap.add_argument("--debug-alias", type=int, default=0, help="diagnostics: pair p reads data of pair p %% N")
     ap.add_argument("--no-frames-leg", action="store_true",
                     help="skip the extra (never `value`) measurement of camera frames in host memory -> poses out")
@@ -185,7 +186,8 @@ def main():
     iters = [args.iters] * args.levels
     flags = DVO_FLAG_IDENTITY_START | (0 if args.no_final_outputs else DVO_FLAG_FINAL_OUTPUTS)
     ctx = DvoContext(args.batch, block_threads=args.block, debug_alias_mod=args.debug_alias,
-                     points_in_flight=args.inflight, lds_point_bytes=args.lds_point_bytes)
+                     points_in_flight=args.inflight, lds_point_bytes=args.lds_point_bytes,
+                     engine_variant=args.variant)
     scenes = build_batch(ctx, args, rank)
     stream = torch.cuda.Stream()
     ctx.set_stream(stream.cuda_stream)
@@ -239,6 +241,7 @@ def main():
                 "block_threads": args.block or "auto (256 for short point lists in large batches, 1024 for lists over 620 KB, else 512)",
                 "points_in_flight": args.inflight or 1,
                 **({"debug_alias_mod": args.debug_alias} if args.debug_alias else {}),
+                **({"engine_variant": args.variant} if args.variant else {}),
                 "point_iterations_per_launch": point_iters,
             },
             "roofline": {
@@ -255,7 +258,7 @@ def main():
             try:
                 rec = json.load(open(pmc))
                 key = "%dx%dx%dx%d_b%d" % (args.width, args.height, args.levels, args.iters, args.batch)
-                default_knobs = not (args.block or args.inflight or args.lds_point_bytes or args.debug_alias or args.no_final_outputs)
+                default_knobs = not (args.variant or args.block or args.inflight or args.lds_point_bytes or args.debug_alias or args.no_final_outputs)
                 if key in rec and default_knobs:
                     out["roofline"]["traffic"] = rec[key]["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = rec[key].get("source")

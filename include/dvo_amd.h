@@ -78,7 +78,7 @@ typedef struct dvo_params {
     int    block_threads;      /* engine tuning: threads per workgroup of the fused kernel (256/512/1024; 0 = chosen from the
                                   point-list sizes and the batch size) */
     int    points_in_flight;   /* engine tuning: reference points per lane and pipeline stage (1/2/4; 0 = default 1) */
-    int    reserved0;
+    int    engine_variant;    /* engine tuning / diagnostics: 0 = auto; 1 = always the one-point-per-lane fused kernel */
     int    lds_point_bytes;    /* engine tuning: LDS bytes per workgroup for the level's resident point list
                                   (0 = auto from block_threads, < 0 = none) */
     int    debug_alias_mod;    /* diagnostics only: if > 0, pair p reads the inputs of pair p % debug_alias_mod

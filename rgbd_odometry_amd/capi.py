@@ -53,7 +53,7 @@ class DvoParams(C.Structure):
         ("step_decay_after", C.c_int), ("step_decay_offset", C.c_int),
         ("trust_radius", C.c_float), ("psi_norm_stop", C.c_float),
         ("enable_rotationize", C.c_int), ("enable_l2_reg", C.c_int), ("interpolate_dt", C.c_int),
-        ("block_threads", C.c_int), ("points_in_flight", C.c_int), ("reserved0", C.c_int),
+        ("block_threads", C.c_int), ("points_in_flight", C.c_int), ("engine_variant", C.c_int),
         ("lds_point_bytes", C.c_int), ("debug_alias_mod", C.c_int),
         ("canny_threshold1", C.c_int), ("canny_threshold2", C.c_int), ("reserved", C.c_int * 1),
     ]

@@ -229,8 +229,13 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
     }
     int u = c->prm.points_in_flight;
     if (u != 1 && u != 2 && u != 4) u = 1;
-    HIPCHK(c, launch_align_fused(block, u, ls, sc, c->K, c->dprm, outputs_of(c),
-                                 first_pair, n_pairs, c->stream));
+    /* engine_variant: 0 = auto (packed two-points-per-lane kernel whenever every list is compact), 1 = always the
+     * one-point-per-lane kernel of dvo_kernels.hip (A/B measurements, parity tests of both) */
+    if (sc.compact && c->prm.engine_variant != 1)
+        HIPCHK(c, launch_align_fused2(block, ls, sc, c->K, c->dprm, outputs_of(c), first_pair, n_pairs, c->stream));
+    else
+        HIPCHK(c, launch_align_fused(block, u, ls, sc, c->K, c->dprm, outputs_of(c),
+                                     first_pair, n_pairs, c->stream));
     c->sched = sc;
     c->have_sched = true;
     return DVO_OK;

@@ -118,6 +118,15 @@ DVO_DEV bool project_point(const IterConst &c, float X, float Y, float Z,
     return (u >= 0.0f) && (u < c.ncols_f) && (v >= 0.0f) && (v < c.nrows_f);
 }
 
+/* A compact reference point {xx | yy << 16, Z = depth/1000}: X and Y rebuilt with the very operations of
+ * enlistRefEdgePts (:249-250), so the bits are those of the 3 x N float list. */
+DVO_DEV void expand_compact(const IterConst &c, unsigned pk, float z, float &X, float &Y, float &Z) {
+    const float xx = (float)(pk & 0xffffu), yy = (float)(pk >> 16);
+    Z = z;
+    X = Z * (xx - c.pcx) * c.pfx;                                  /* :249 */
+    Y = Z * (yy - c.pcy) * c.pfy;                                  /* :250 */
+}
+
 /* Jacobian row from the gathered gradient (:379-406).  X,Y,Z are the
  * DEHOMOGENISED coordinates (quirk Q1), cR^T is applied a second time (Q2). */
 DVO_DEV void jacobian_row(const IterConst &c, float xn, float yn, float zn,

@@ -1,0 +1,375 @@
+/*
+ * dvo_fused.hip -- the throughput form of the edge-alignment hot path (gfx950 / CDNA4, wave64): the whole
+ * coarse-to-fine schedule of SolveDVO::loop (reference src/SolveDVO.cpp:2097-2104) over runIterations (:619-1017) for
+ * one frame pair per workgroup, with the per-point phase (:306-414, :425-462) on TWO points per lane in packed
+ * float32 arithmetic (dvo_point_pk.h).
+ *
+ * Used for launches whose point lists all have the engine's compact 8-byte form (lists built by the enlist kernels);
+ * anything else (caller-supplied 3xN float lists, the optional interpolate() lookup) runs align_fused_kernel of
+ * dvo_kernels.hip.  Same results bit for bit -- tests/test_gpu_parity.py runs both against the oracle.
+ *
+ * Per level: the compact points {xx | yy << 16, Z} are staged once into LDS; per iteration a lane takes points
+ * i and i + BLOCK of every round of 2*BLOCK points, rebuilds X, Y (:249-250), warps and projects both (:328-345),
+ * gathers their two 16-byte texels {DT, gx, gy, w} (issued one round ahead of the arithmetic that consumes them),
+ * forms the weighted Jacobian rows (:379-406, :716) and accumulates g = J^T W eps (:777) and sum eps^2 (:1312) in double.
+ * Reduction, update and bookkeeping as in dvo_kernels.hip.
+ *
+ * Compile with -ffp-contract=off.
+ */
+#include "dvo_kernel_common.h"
+#include "dvo_point_pk.h"
+
+namespace dvo {
+
+/* per-lane sums of one iteration (the sub-gradient policy of :724-920 needs g and the energy only) */
+struct Acc7 {
+    double g[6];
+    double e2;
+    int nvis;          /* wave-uniform: ballots */
+};
+
+DVO_DEV void acc7_zero(Acc7 &a) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.g[k] = 0.0;
+    a.e2 = 0.0;
+    a.nvis = 0;
+}
+
+/* one round of the software pipeline: two points per lane */
+struct Round2 {
+    v2f xn, yn, zn;    /* dehomogenised coordinates (finite dummies where not visible) */
+    v4f t0, t1;        /* the two texels {DT, gx, gy, w} as loaded */
+    bool vis0, vis1;
+};
+
+/* byte offset of texel (yy, xx) in the tiled 16-byte texel image (texel_index() * 16 in seven instructions) */
+DVO_DEV unsigned texel_byte_offset(int yy, int xx, unsigned tile_col_bytes /* tiles_per_col * 128 */) {
+    static_assert(DVO_TILE_Y_LOG2 == 2 && DVO_TILE_X_LOG2 == 1, "written for 4x2 tiles");
+    /* ((xx>>1)*tpc + (yy>>2))*128 + (xx&1)*64 + (yy&3)*16  ==  (xx>>1)*tpc*128 + yy*32 - (yy&3)*16 + (xx&1)*64 */
+    return (unsigned)(xx >> 1) * tile_col_bytes + ((unsigned)yy << 5) - (((unsigned)yy & 3u) << 4) + (((unsigned)xx & 1u) << 6);
+}
+
+struct LdsPoints {
+    const unsigned *pk;    /* xx | yy << 16 */
+    const float *z;
+};
+
+template <bool LDS_SRC>
+DVO_DEV void load_compact(const LdsPoints &lp, const uint2 *__restrict__ gpts, int j, unsigned &k, float &z) {
+    if (LDS_SRC) {
+        k = lp.pk[j]; z = lp.z[j];
+    } else {
+        const uint2 a = gpts[j];
+        k = a.x; z = __uint_as_float(a.y);
+    }
+}
+
+/* stage 1 of a round: load, decode, project, issue the two gathers.  Straight-line code: a point whose z is outside the
+ * range in which the fast reciprocal is proven exact (|z| < 2^-126, > 2^126, 0, inf, nan -- never in practice) is
+ * treated as not visible here and reported through `any_odd` (wave-uniform); the caller then redoes the wave's whole
+ * share of the iteration with the literal-division scalar code (accumulate_points_exact). */
+template <bool LDS_SRC>
+DVO_DEV void round2_issue(const IterConst &c, const char *__restrict__ tex, unsigned tile_col_bytes,
+                          const LdsPoints &lp, const uint2 *__restrict__ gpts,
+                          int i0, int i1, int end, Round2 &b, bool &any_odd) {
+    const bool valid0 = i0 < end, valid1 = i1 < end;
+    const int j0 = valid0 ? i0 : (end - 1), j1 = valid1 ? i1 : (end - 1);
+    unsigned k0, k1;
+    float z0, z1;
+    load_compact<LDS_SRC>(lp, gpts, j0, k0, z0);
+    load_compact<LDS_SRC>(lp, gpts, j1, k1, z1);
+    v2f xx, yy, Z;
+    xx.x = (float)(k0 & 0xffffu); xx.y = (float)(k1 & 0xffffu);
+    yy.x = (float)(k0 >> 16);     yy.y = (float)(k1 >> 16);
+    Z.x = z0; Z.y = z1;
+    const v2f X = (Z * (xx - c.pcx)) * c.pfx;                               /* :249 */
+    const v2f Y = (Z * (yy - c.pcy)) * c.pfy;                               /* :250 */
+    v2f xn, yn, zn, u, v;
+    bool odd0, odd1;
+    project_point2(c, X, Y, Z, xn, yn, zn, u, v, odd0, odd1);
+    any_odd |= (__builtin_amdgcn_ballot_w64((odd0 && valid0) || (odd1 && valid1)) != 0ull);       /* scalar: no branch */
+    int px0, py0, px1, py1;
+    const bool inx0 = pixel_in_range(u.x, c.cols, px0), iny0 = pixel_in_range(v.x, c.rows, py0);
+    const bool inx1 = pixel_in_range(u.y, c.cols, px1), iny1 = pixel_in_range(v.y, c.rows, py1);
+    const bool vis0 = inx0 && iny0 && valid0 && !odd0;
+    const bool vis1 = inx1 && iny1 && valid1 && !odd1;
+    b.vis0 = vis0; b.vis1 = vis1;
+    unsigned o0 = texel_byte_offset(py0, px0, tile_col_bytes);
+    unsigned o1 = texel_byte_offset(py1, px1, tile_col_bytes);
+    o0 = vis0 ? o0 : 0u;
+    o1 = vis1 ? o1 : 0u;
+    /* finite dummies for lanes without a visible point: they then add exact zeros (w = eps = 0) */
+    b.xn.x = vis0 ? xn.x : 0.0f; b.yn.x = vis0 ? yn.x : 0.0f; b.zn.x = vis0 ? zn.x : 1.0f;
+    b.xn.y = vis1 ? xn.y : 0.0f; b.yn.y = vis1 ? yn.y : 0.0f; b.zn.y = vis1 ? zn.y : 1.0f;
+    b.t0 = *reinterpret_cast<const v4f *>(tex + o0);
+    b.t1 = *reinterpret_cast<const v4f *>(tex + o1);
+}
+
+/* (double)(float)(J_k w) * (double)eps is exact, so fma(a,b,c) == c + a*b bit for bit (:719-720, :777) */
+DVO_DEV void acc7_add(Acc7 &a, const float *jw, float eps) {
+    const double e = (double)eps;
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.g[k] = fma((double)jw[k], e, a.g[k]);
+    a.e2 = fma(e, e, a.e2);
+}
+
+/* stage 2: weighted Jacobian rows + accumulation */
+DVO_DEV void round2_compute(const IterConst &c, const Round2 &b, Acc7 &a) {
+    a.nvis += __popcll(__builtin_amdgcn_ballot_w64(b.vis0)) + __popcll(__builtin_amdgcn_ballot_w64(b.vis1));
+    const float eps0 = b.vis0 ? b.t0.x : 0.0f, eps1 = b.vis1 ? b.t1.x : 0.0f;
+    const float w0 = b.vis0 ? b.t0.w : 0.0f, w1 = b.vis1 ? b.t1.w : 0.0f;
+    v2f jw[6];
+    jacobian_weighted2(c, b.xn, b.yn, b.zn, b.t0.y, b.t1.y, b.t0.z, b.t1.z, w0, w1, jw);
+    const double e0 = (double)eps0, e1 = (double)eps1;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        a.g[k] = fma((double)jw[k].x, e0, a.g[k]);
+        a.g[k] = fma((double)jw[k].y, e1, a.g[k]);
+    }
+    a.e2 = fma(e0, e0, a.e2);
+    a.e2 = fma(e1, e1, a.e2);
+}
+
+/* the per-point phase of one iteration over points [first, end): rounds of 2*BLOCK points, lane `lane_off` of the
+ * round takes points lane_off and BLOCK + lane_off; software-pipelined over rounds with two named buffers */
+template <int BLOCK, bool LDS_SRC>
+DVO_DEV void accumulate_points2(const IterConst &c, const char *__restrict__ tex, unsigned tile_col_bytes,
+                                const LdsPoints &lp, const uint2 *__restrict__ gpts,
+                                int first, int end, int lane_off, Acc7 &a, bool &any_odd) {
+    if (first >= end) return;
+    constexpr int STEP = 2 * BLOCK;
+    /* rounds in which THIS wave still has a point (wave-uniform) */
+    const int wave_off = __builtin_amdgcn_readfirstlane(lane_off - (int)(threadIdx.x & 63));
+    const int n_rounds = (end - first - wave_off + STEP - 1) / STEP;
+    if (n_rounds <= 0) return;
+    Round2 A, B;
+    int base = first + lane_off;
+    round2_issue<LDS_SRC>(c, tex, tile_col_bytes, lp, gpts, base, base + BLOCK, end, A, any_odd);
+    int r = 0;
+    for (; r + 2 < n_rounds; r += 2) {
+        round2_issue<LDS_SRC>(c, tex, tile_col_bytes, lp, gpts, base + STEP, base + STEP + BLOCK, end, B, any_odd);
+        round2_compute(c, A, a);
+        round2_issue<LDS_SRC>(c, tex, tile_col_bytes, lp, gpts, base + 2 * STEP, base + 2 * STEP + BLOCK, end, A, any_odd);
+        round2_compute(c, B, a);
+        base += 2 * STEP;
+    }
+    if (r + 1 < n_rounds) {
+        round2_issue<LDS_SRC>(c, tex, tile_col_bytes, lp, gpts, base + STEP, base + STEP + BLOCK, end, B, any_odd);
+        round2_compute(c, A, a);
+        round2_compute(c, B, a);
+    } else {
+        round2_compute(c, A, a);
+    }
+}
+
+/* The same sums with the literal-division scalar code (dvo_device_math.h: project_point, jacobian_row) over THIS wave's
+ * points of [first, end) -- taken only when one of them has a degenerate z.  Plain loop, not pipelined: never hot. */
+template <int BLOCK, bool LDS_SRC>
+DVO_DEV void accumulate_points_exact(const IterConst &c, const char *__restrict__ tex, const LdsPoints &lp,
+                                                     const uint2 *__restrict__ gpts, int first, int end, int lane_off, Acc7 &a) {
+    for (int i = first + lane_off; __builtin_amdgcn_ballot_w64(i < end) != 0ull; i += BLOCK) {
+        const bool valid = i < end;
+        unsigned k; float z;
+        load_compact<LDS_SRC>(lp, gpts, valid ? i : (end - 1), k, z);
+        float X, Y, Z, xn, yn, zn, u, v;
+        expand_compact(c, k, z, X, Y, Z);
+        const bool vis = project_point(c, X, Y, Z, xn, yn, zn, u, v) && valid;
+        a.nvis += __popcll(__builtin_amdgcn_ballot_w64(vis));
+        if (vis) {
+            const float4 t = reinterpret_cast<const float4 *>(tex)[texel_index((int)v, (int)u, c.tiles_per_col)];
+            float J[6], jw[6];
+            jacobian_row(c, xn, yn, zn, t.y, t.z, J);
+#pragma unroll
+            for (int q = 0; q < 6; q++) jw[q] = J[q] * t.w;
+            acc7_add(a, jw, t.x);
+        }
+    }
+}
+
+/* fixed-shape reduction of the 7 double sums + the visible count over the workgroup: tot[0..5] g, [6] sum eps^2,
+ * [7] visible points (valid after the trailing barrier) */
+template <int BLOCK>
+DVO_DEV void block_reduce7(const Acc7 &a, double (*red)[8], double *tot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double d[8];
+#pragma unroll
+    for (int k = 0; k < 6; k++) d[k] = a.g[k];
+    d[6] = a.e2;
+    d[7] = 0.0;
+    wave_reduce_scatter<double, 8>(d);
+    const int idx = lane >> 3;
+    if ((lane & 7) == 0 && idx < 7) red[wave][idx] = d[0];
+    if (lane == 1) red[wave][7] = (double)a.nvis;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; w++) s += red[w][threadIdx.x];
+        tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 8)))
+align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outputs out, int first_pair) {
+    const int pair = first_pair + blockIdx.x;
+    const int tid = threadIdx.x;
+    __shared__ PoseState st;
+    __shared__ double red[BLOCK / 64][8];
+    __shared__ double tot[8];
+    extern __shared__ float lds_dyn[];          /* two planes of sc.lds_points words: xx|yy<<16 and Z of this level's points */
+
+    if (tid == 0) {
+        const double *p = out.poses + (size_t)pair * 12;
+        const bool ident = (sc.flags & 2) != 0;                  /* DVO_FLAG_IDENTITY_START (:2210-2211) */
+        double R0[9], t0[3];
+#pragma unroll
+        for (int k = 0; k < 9; k++) R0[k] = ident ? ((k % 4 == 0) ? 1.0 : 0.0) : p[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) t0[k] = ident ? 0.0 : p[9 + k];
+        pose_state_load(st, R0, t0);
+    }
+    __syncthreads();
+
+    for (int l = sc.n_levels - 1; l >= 0; --l) {                 /* SolveDVO.cpp:2097 */
+        const int iters = sc.iters[l];
+        if (iters <= 0) continue;                                 /* :2099 */
+        const LevelSlab &L = lv.l[l];
+        const int dpair = (sc.alias_mod > 0) ? (pair % sc.alias_mod) : pair;
+        const int N = L.N[dpair];
+        const char *__restrict__ tex = reinterpret_cast<const char *>(L.tex + (size_t)dpair * L.tex_stride);
+        const uint2 *__restrict__ gpts = L.cpts + (size_t)dpair * L.pt_cap;
+        float *energy = out.energy + (size_t)pair * sc.e_stride + sc.e_off[l];
+
+        IterConst c;
+        level_consts(c, K, l, L.rows, L.cols);
+        const unsigned tile_col_bytes = (unsigned)c.tiles_per_col * 128u;
+
+        for (int i = tid; i < iters; i += BLOCK) energy[i] = 0.0f;          /* :634 */
+        if (tid == 0) { pose_state_begin(st); pose_regulariser_precompute(st, prm); }   /* :642-657 */
+        /* The reference deep-copies the 3xN point list every iteration (:670); here the level's compact list is
+         * staged into LDS once (16-byte loads: whole 128-byte lines per request) and HBM sees it once per level. */
+        const int cap = sc.lds_points;
+        const int n_lds = (N < cap) ? N : (cap / (2 * BLOCK)) * (2 * BLOCK);      /* whole rounds only */
+        {
+            const uint4 *g4 = reinterpret_cast<const uint4 *>(gpts);
+            const int n2 = n_lds >> 1;
+            for (int i = tid; i < n2; i += BLOCK) {
+                const uint4 v = g4[i];
+                lds_dyn[2 * i] = __uint_as_float(v.x);
+                lds_dyn[cap + 2 * i] = __uint_as_float(v.y);
+                lds_dyn[2 * i + 1] = __uint_as_float(v.z);
+                lds_dyn[cap + 2 * i + 1] = __uint_as_float(v.w);
+            }
+            if ((n_lds & 1) && tid == 0) {
+                const uint2 v = gpts[n_lds - 1];
+                lds_dyn[n_lds - 1] = __uint_as_float(v.x);
+                lds_dyn[cap + n_lds - 1] = __uint_as_float(v.y);
+            }
+        }
+        LdsPoints lp;
+        lp.pk = reinterpret_cast<const unsigned *>(lds_dyn);
+        lp.z = lds_dyn + cap;
+        __syncthreads();
+
+        for (int itr = 0; itr < iters; ++itr) {                              /* :658 */
+#pragma unroll
+            for (int k = 0; k < 9; k++) c.r[k] = uniform_f(st.Rf[k]);        /* :673 */
+#pragma unroll
+            for (int k = 0; k < 3; k++) c.t[k] = uniform_f(st.tf[k]);        /* :674 */
+
+            Acc7 a;
+            acc7_zero(a);
+            bool any_odd = false;
+            /* waves take the lanes of a round in reverse order: the tail of the last, partial round goes to the high
+             * waves first, so wave 0 -- whose lane 0 still has the regulariser of the new pose to finish -- most often
+             * has a round less */
+            const int lane_off = BLOCK - 64 - (tid & ~63) + (tid & 63);
+            accumulate_points2<BLOCK, true>(c, tex, tile_col_bytes, lp, gpts, 0, n_lds, lane_off, a, any_odd);      /* :369, :433 */
+            accumulate_points2<BLOCK, false>(c, tex, tile_col_bytes, lp, gpts, n_lds, N, lane_off, a, any_odd);     /* beyond the LDS budget */
+            if (any_odd) {      /* wave-uniform; a point with a degenerate z: this wave's share again, literal divisions */
+                acc7_zero(a);
+                accumulate_points_exact<BLOCK, true>(c, tex, lp, gpts, 0, n_lds, lane_off, a);
+                accumulate_points_exact<BLOCK, false>(c, tex, lp, gpts, n_lds, N, lane_off, a);
+            }
+            block_reduce7<BLOCK>(a, red, tot);
+            if (tid == 0) {
+                const float e = pose_update_t<true>(st, prm, itr, N, &tot[0], tot[6], (int)tot[7]);
+                energy[itr] = e;                                             /* :690 */
+            }
+            __syncthreads();
+            if (st.stop) break;                                              /* :877 */
+            /* log(new pose) for the next iteration's regulariser: lane 0 takes it now, while the other waves are
+             * already in their point phase */
+            if (tid == 0 && itr + 1 < iters) pose_regulariser_precompute(st, prm);
+        }
+
+        /* finalEpsilons / finalReprojections = those of the best iterate (:703-704, :1002-1003); recomputed once from
+         * the same float pose -> same bits */
+        if ((sc.flags & 1) && l == sc.last_level) {
+            if (st.bestItr >= 0) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) c.r[k] = uniform_f(st.bRf[k]);
+#pragma unroll
+                for (int k = 0; k < 3; k++) c.t[k] = uniform_f(st.btf[k]);
+                float *fe = out.final_eps + (size_t)pair * out.final_cap;
+                float *fr = out.final_reproj + (size_t)pair * out.final_cap * 3;
+                for (int i = tid; i < N; i += BLOCK) {
+                    unsigned pk; float z;
+                    if (i < n_lds) { pk = lp.pk[i]; z = lp.z[i]; }
+                    else { const uint2 v = gpts[i]; pk = v.x; z = __uint_as_float(v.y); }
+                    float X, Y, Z, xn, yn, zn, u, v;
+                    expand_compact(c, pk, z, X, Y, Z);
+                    const bool vis = project_point(c, X, Y, Z, xn, yn, zn, u, v);
+                    float e = 0.0f;
+                    if (vis) e = reinterpret_cast<const float4 *>(tex)[texel_index((int)v, (int)u, c.tiles_per_col)].x;
+                    fe[i] = e;
+                    fr[3 * i] = u; fr[3 * i + 1] = v; fr[3 * i + 2] = zn;
+                }
+            }
+            if (tid == 0) out.final_N[pair] = (st.bestItr >= 0) ? N : 0;
+        }
+        __syncthreads();
+        if (tid == 0) {                                                      /* :997-1005 */
+            pose_state_finish(st);
+            out.best_idx[pair * DVO_LEVELS + l] = st.bestItr;
+            out.ratio[pair * DVO_LEVELS + l] = st.bestRatio;
+        }
+        __syncthreads();
+    }
+
+    if (tid == 0) {
+        double *p = out.poses + (size_t)pair * 12;
+#pragma unroll
+        for (int k = 0; k < 9; k++) p[k] = st.R[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) p[9 + k] = st.t[k];
+    }
+}
+
+template <int BLOCK>
+static hipError_t launch_fused2_b(const LevelSet &lv, const Schedule &sc, const Intrinsics &K, const DevParams &prm,
+                                  const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {
+    const size_t dyn = (size_t)sc.lds_points * 2 * sizeof(float);
+    auto kern = align_fused2_kernel<BLOCK>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n_pairs), dim3(BLOCK), dyn, s, lv, sc, K, prm, out, first_pair);
+    return hipGetLastError();
+}
+
+/* static LDS of align_fused2_kernel<BLOCK> (the host sizes the dynamic part against the CU's 160 KiB) */
+size_t fused2_static_lds(int block_threads) { return sizeof(PoseState) + (size_t)(block_threads / 64) * 64 + 64 + 64; }
+
+hipError_t launch_align_fused2(int block_threads, const LevelSet &lv, const Schedule &sc, const Intrinsics &K,
+                               const DevParams &prm, const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {
+    if (n_pairs <= 0) return hipSuccess;
+    switch (block_threads) {
+    case 256: return launch_fused2_b<256>(lv, sc, K, prm, out, first_pair, n_pairs, s);
+    case 1024: return launch_fused2_b<1024>(lv, sc, K, prm, out, first_pair, n_pairs, s);
+    default: return launch_fused2_b<512>(lv, sc, K, prm, out, first_pair, n_pairs, s);
+    }
+}
+
+}  // namespace dvo
