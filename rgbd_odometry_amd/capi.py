@@ -29,7 +29,7 @@ C_ABI_SYMBOLS = [
     "dvo_set_poses", "dvo_align_batch_enqueue", "dvo_get_poses", "dvo_get_level_report",
     "dvo_get_final_outputs", "dvo_eval_points", "dvo_accumulate", "dvo_device_se3_exp",
     "dvo_device_se3_log", "dvo_device_rotationize", "dvo_algorithmic_bytes", "dvo_point_iterations",
-    "dvo_debug_stamps", "dvo_replicate_pairs", "dvo_set_now_level_from_edges", "dvo_get_now_level", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
+    "dvo_debug_stamps", "dvo_get_level_texel_mode", "dvo_replicate_pairs", "dvo_set_now_level_from_edges", "dvo_get_now_level", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
     "dvo_align_pyramid_wide",
     "dvo_get_ref_level", "dvo_frames_reserve", "dvo_frames_upload_pyramids", "dvo_frames_upload_cameras", "dvo_frames_as_now",
     "dvo_frames_as_ref", "dvo_frame_get_level", "dvo_frames_num_levels",
@@ -132,6 +132,7 @@ def load_library() -> C.CDLL:
         "dvo_device_se3_log": [vp, vp, vp, vp],
         "dvo_device_rotationize": [vp, vp],
         "dvo_debug_stamps": [vp, i, vp],
+        "dvo_get_level_texel_mode": [vp, i, i, ip],
         "dvo_replicate_pairs": [vp, i, i, i],
         "dvo_set_now_level_from_edges": [vp, i, i, vp, i, i],
         "dvo_get_now_level": [vp, i, i, vp, vp, vp],
@@ -517,6 +518,12 @@ class DvoContext:
         out = np.zeros(64, np.uint64)
         self._chk(self.lib.dvo_debug_stamps(self._h, pair, _ptr(out)))
         return out.reshape(8, 8)
+
+    def level_texel_mode(self, pair: int, level: int) -> int:
+        """0 = 16-byte texels from HBM/L2, 1 = level staged in LDS (16-byte texels), 2 = DT plane staged in LDS, -1 = not run"""
+        m = C.c_int(-2)
+        self._chk(self.lib.dvo_get_level_texel_mode(self._h, pair, level, C.byref(m)))
+        return m.value
 
     # -- measurement ----------------------------------------------------------
     def algorithmic_bytes(self, iters: Sequence[int], pair: int = 0, flags: int = 0) -> int:

@@ -88,6 +88,10 @@ int ensure_texels(dvo_ctx *c, int level, int rows, int cols) {
         L.tex = nullptr;
         std::fill(L.have_now.begin(), L.have_now.end(), 0);
     }
+    if (!L.d_nonderived) {
+        HIPCHK(c, hipMalloc((void **)&L.d_nonderived, sizeof(int) * c->n_pairs));
+        HIPCHK(c, hipMemsetAsync(L.d_nonderived, 0xff, sizeof(int) * c->n_pairs, c->stream));
+    }
     L.rows = rows; L.cols = cols;
     L.tex_stride = texel_count(rows, cols);
     HIPCHK(c, hipMalloc((void **)&L.tex, sizeof(float4) * L.tex_stride * c->n_pairs));
@@ -105,7 +109,7 @@ namespace {
 LevelSlab slab_of(const dvo_ctx *c, int level) {
     const Level &L = c->lv[level];
     LevelSlab s;
-    s.tex = L.tex; s.pts = L.pts; s.cpts = L.cpts; s.N = L.dN;
+    s.tex = L.tex; s.pts = L.pts; s.cpts = L.cpts; s.N = L.dN; s.nonderived = L.d_nonderived;
     s.tex_stride = L.tex_stride; s.pt_cap = L.pt_cap; s.rows = L.rows; s.cols = L.cols;
     return s;
 }
@@ -169,6 +173,7 @@ Outputs outputs_of(const dvo_ctx *c) {
     o.final_eps = c->d_final_eps; o.final_reproj = c->d_final_reproj; o.final_N = c->d_final_N;
     o.final_cap = c->final_cap;
     o.dbg = c->d_dbg;
+    o.tex_mode = c->d_tex_mode;
     return o;
 }
 
@@ -216,7 +221,6 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         int bytes = c->prm.lds_point_bytes;
         /* auto: one workgroup per CU for >= 512 threads (it owns the CU's LDS), two for 256 */
         if (bytes == 0) bytes = auto_lds ? auto_lds : ((block >= 512) ? 155000 : 77000);
-        if (bytes > 156 * 1024) bytes = 156 * 1024;
         /* compact (8-byte) point lists when every list of this launch was built by the engine's own enlist kernels */
         sc.compact = fused_uses_compact(c->prm.points_in_flight, c->prm.interpolate_dt) ? 1 : 0;
         for (int l = 0; l < n_levels && sc.compact; l++) {
@@ -224,8 +228,17 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
             for (int p = first_pair; p < first_pair + n_pairs && sc.compact; p++)
                 if (c->lv[l].compact_ok.empty() || !c->lv[l].compact_ok[sc.alias_mod > 0 ? p % sc.alias_mod : p]) sc.compact = 0;
         }
+        /* the CU has 160 KiB of LDS; the static part of the chosen kernel comes off the top */
+        const bool packed = sc.compact && c->prm.engine_variant != 1;
+        const int static_lds = packed ? (int)fused2_static_lds(block) : (int)(sizeof(double) * (block / 64) * DVO_NACC_PAD + 256 + pose_state_bytes());
+        const int max_dyn = 160 * 1024 - static_lds - 64;
+        if (bytes > max_dyn) bytes = max_dyn;
+        if (bytes < 0) bytes = 0;
+        bytes &= ~63;
+        sc.lds_bytes = bytes;
+        sc.no_lds_tex = (c->prm.engine_variant == 2) ? 1 : 0;
         sc.lds_points = bytes / (sc.compact ? 8 : 12);
-        if (c->prm.lds_point_bytes < 0) sc.lds_points = 0;
+        if (c->prm.lds_point_bytes < 0) { sc.lds_points = 0; sc.lds_bytes = 0; }
     }
     int u = c->prm.points_in_flight;
     if (u != 1 && u != 2 && u != 4) u = 1;
@@ -307,6 +320,8 @@ int dvo_create_batch(const dvo_params *p, int n_pairs, dvo_ctx **out) {
     CRCHK(hipMalloc((void **)&c->d_best, sizeof(int) * DVO_LEVELS * n_pairs));
     CRCHK(hipMalloc((void **)&c->d_ratio, sizeof(float) * DVO_LEVELS * n_pairs));
     CRCHK(hipMalloc((void **)&c->d_final_N, sizeof(int) * n_pairs));
+    CRCHK(hipMalloc((void **)&c->d_tex_mode, sizeof(int) * DVO_LEVELS * n_pairs));
+    CRCHK(hipMemset(c->d_tex_mode, 0xff, sizeof(int) * DVO_LEVELS * n_pairs));
     CRCHK(hipMalloc((void **)&c->d_scratch, sizeof(double) * (1024 * DVO_NACC_PAD + 64)));
 #ifdef DVO_STAMPS
     CRCHK(hipMalloc((void **)&c->d_dbg, sizeof(unsigned long long) * 64 * n_pairs));
@@ -335,6 +350,7 @@ int dvo_destroy(dvo_ctx *c) {
         if (c->lv[l].pts) (void)hipFree(c->lv[l].pts);
         if (c->lv[l].cpts) (void)hipFree(c->lv[l].cpts);
         if (c->lv[l].dN) (void)hipFree(c->lv[l].dN);
+        if (c->lv[l].d_nonderived) (void)hipFree(c->lv[l].d_nonderived);
     }
     for (int l = 0; l < DVO_LEVELS; l++) {
         FrameLevel &F = c->fs.lv[l];
@@ -360,7 +376,7 @@ int dvo_destroy(dvo_ctx *c) {
     }
     void *ptrs[] = {c->staging, c->d_poses, c->d_energy, c->d_best, c->d_ratio, c->d_final_eps,
                     c->d_final_reproj, c->d_final_N, c->d_scratch, c->d_colcounts, c->d_dbg,
-                    c->d_states, c->d_iter_energy};
+                    c->d_states, c->d_iter_energy, c->d_tex_mode};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -492,6 +508,9 @@ static int set_now_common(dvo_ctx *c, int pair, int level, const float *dt, cons
         s_dt = c->staging; s_gx = c->staging + npx; s_gy = c->staging + 2 * npx;
     }
     HIPCHK(c, launch_pack_texels(s_dt, s_gx, s_gy, L.tex + (size_t)pair * L.tex_stride, rows, cols, c->stream));
+    /* are gx, gy the reference's own imageGradient(DT)?  (decides whether coarse levels may live in LDS as DT planes) */
+    HIPCHK(c, hipMemsetAsync(L.d_nonderived + pair, 0, sizeof(int), c->stream));
+    HIPCHK(c, launch_verify_derived(L.tex + (size_t)pair * L.tex_stride, rows, cols, L.d_nonderived + pair, c->stream));
     L.have_now[pair] = 1;
     if (!device_src) HIPCHK(c, hipStreamSynchronize(c->stream));
     return DVO_OK;
@@ -529,6 +548,7 @@ int dvo_set_now_level_from_edges(dvo_ctx *c, int pair, int level, const unsigned
     HIPCHK(c, hipMemcpyAsync(d_edge, edge, npx, hipMemcpyHostToDevice, c->stream));
     Level &L = c->lv[level];
     HIPCHK(c, launch_now_level_from_edges(d_edge, rows, cols, work, L.tex + (size_t)pair * L.tex_stride, c->stream));
+    HIPCHK(c, hipMemsetAsync(L.d_nonderived + pair, 0, sizeof(int), c->stream));      /* derived by construction, DT in [0, 255] */
     L.have_now[pair] = 1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return DVO_OK;
@@ -581,7 +601,7 @@ int dvo_replicate_pairs(dvo_ctx *c, int n_src, int dst_first, int dst_count) {
             int rc = check_ready(c, p, l);
             if (rc) return rc;
         }
-        HIPCHK(c, launch_replicate_level(L.tex, L.tex_stride, L.pts, L.cpts, L.pt_cap, L.dN, n_src, dst_first, dst_count, c->stream));
+        HIPCHK(c, launch_replicate_level(L.tex, L.tex_stride, L.pts, L.cpts, L.pt_cap, L.dN, L.d_nonderived, n_src, dst_first, dst_count, c->stream));
         for (int p = dst_first; p < dst_first + dst_count; p++) {
             L.hN[p] = L.hN[(p - dst_first) % n_src];
             L.compact_ok[p] = L.compact_ok[(p - dst_first) % n_src];
@@ -929,6 +949,15 @@ int dvo_debug_stamps(dvo_ctx *c, int pair, unsigned long long *out64) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out64, c->d_dbg + (size_t)pair * 64, sizeof(unsigned long long) * 64, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemset(c->d_dbg + (size_t)pair * 64, 0, sizeof(unsigned long long) * 64));
+    return DVO_OK;
+}
+
+/* inspection: where the packed fused kernel read the now level of (pair, level) from during the last launch that ran it */
+int dvo_get_level_texel_mode(dvo_ctx *c, int pair, int level, int *mode) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair) || !level_ok(level) || !mode) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(mode, c->d_tex_mode + (size_t)pair * DVO_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
     return DVO_OK;
 }
 

@@ -28,6 +28,7 @@ struct Level {
     std::vector<char> compact_ok;   /* per pair: the list came from the engine's enlist kernels */
     int pt_cap = 0;
     int *dN = nullptr;
+    int *d_nonderived = nullptr;    /* per pair: 0 = gradients verified to be imageGradient(DT) (see dvo_launch.h) */
     std::vector<int> hN;            /* 0 = not set */
     std::vector<char> have_now;
 };
@@ -65,6 +66,7 @@ struct dvo_ctx {
     float *d_ratio = nullptr;
     float *d_final_eps = nullptr, *d_final_reproj = nullptr;
     int *d_final_N = nullptr;
+    int *d_tex_mode = nullptr;      /* n_pairs x DVO_LEVELS, written by the packed fused kernel */
     int final_cap = 0;
     double *d_scratch = nullptr;    /* partials (1024 x 32) + acc (32) + misc doubles */
     /* dvo_align_pyramid_wide as a replayable hipGraph (the schedule is ~2 dependent launches per iteration) */

@@ -14,6 +14,8 @@
 #define DVO_LEVELS 8          /* == DVO_MAX_LEVELS of include/dvo_amd.h */
 #define DVO_NACC 29           /* == DVO_NUM_ACC */
 #define DVO_NACC_PAD 32
+/* where the fused kernel reads the now level of a (pair, level) from */
+enum { DVO_TEXMODE_GLOBAL16 = 0, DVO_TEXMODE_LDS16 = 1, DVO_TEXMODE_LDS_DT = 2 };
 
 namespace dvo {
 
@@ -28,6 +30,8 @@ struct LevelSlab {
     const float *pts;
     const uint2 *cpts;      /* compact points {xx | yy << 16, Z}, pt_cap per pair; valid where the host says so (Schedule.compact) */
     const int *N;
+    const int *nonderived;  /* per pair: 0 = the gradients of this level ARE imageGradient(DT) (SolveDVO.cpp:1063-1098) bit for bit and
+                               |DT| <= 2^20, so kernels may rebuild them (and the weight) from DT alone; else 1 */
     size_t tex_stride;      /* texels per pair */
     int pt_cap;             /* points per pair (capacity) */
     int rows, cols;
@@ -43,6 +47,8 @@ struct Schedule {
     int flags;
     int alias_mod;           /* diagnostics: data of pair p % alias_mod (0 = off) */
     int lds_points;          /* reference points kept resident in LDS per workgroup (3 words each, 2 when compact) */
+    int lds_bytes;           /* dynamic LDS of the launch (dvo_fused.hip splits it per level between points and the now level) */
+    int no_lds_tex;          /* diagnostics: never stage the now level into LDS */
     int compact;             /* every pair/level of this launch has a compact point list: read 8 B / point instead of 12 */
 };
 
@@ -58,13 +64,16 @@ struct Outputs {
     int *final_N;            /* n_pairs */
     int final_cap;
     unsigned long long *dbg; /* diagnostics (DVO_STAMPS builds): n_pairs x 64 counters, else NULL */
+    int *tex_mode;           /* n_pairs x DVO_LEVELS: where the fused kernel read the now level from (DVO_TEXMODE_*), inspection */
 };
 
 hipError_t launch_pack_texels(const float *dt, const float *gx, const float *gy, float4 *out,
                               int rows, int cols, hipStream_t s);
 bool fused_uses_compact(int points_in_flight, int interp);
-hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, int pt_cap, int *N,
+hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, int pt_cap, int *N, int *nonderived,
                                   int n_src, int dst_first, int dst_count, hipStream_t s);
+/* *nonderived |= 1 unless gx, gy of the packed level equal imageGradient(DT) bit for bit and every |DT| <= 2^20 */
+hipError_t launch_verify_derived(const float4 *tex, int rows, int cols, int *nonderived, hipStream_t s);
 hipError_t launch_align_fused(int block_threads, int points_in_flight, const LevelSet &lv,
                               const Schedule &sc, const Intrinsics &K, const DevParams &prm,
                               const Outputs &out, int first_pair, int n_pairs, hipStream_t s);
