@@ -79,7 +79,8 @@ typedef struct dvo_params {
                                   point-list sizes and the batch size) */
     int    points_in_flight;   /* engine tuning: reference points per lane and pipeline stage (1/2/4; 0 = default 1) */
     int    engine_variant;     /* engine tuning / diagnostics: 0 = auto; 1 = always the one-point-per-lane fused kernel;
-                                  2 = packed kernel, but never stage a now level into LDS */
+                                  2 = packed kernel, but never stage a now level into LDS; 3 = packed kernel with every wave
+                                  forced through its literal-division fallback (tests) */
     int    lds_point_bytes;    /* engine tuning: LDS bytes per workgroup for the level's resident point list
                                   (0 = auto from block_threads, < 0 = none) */
     int    debug_alias_mod;    /* diagnostics only: if > 0, pair p reads the inputs of pair p % debug_alias_mod
@@ -233,10 +234,9 @@ int  dvo_device_se3_log(dvo_ctx *ctx, const double *R, const double *t, double *
 int  dvo_device_rotationize(dvo_ctx *ctx, double *R);
 
 /* Where the fused kernel read the now level of (pair, level) from in the last batch launch that used the packed kernel:
- * 0 = 16-byte texels gathered from HBM/L2, 1 = the level's 16-byte texels staged once per level into LDS ("LDS-staged
- * image tiles": the reference re-copies the three images every iteration, SolveDVO.cpp:310,316-317,427), 2 = the level's
- * DT plane alone staged into LDS, gradients and weight rebuilt per point (only when the level's gradients were verified to
- * be imageGradient(DT), SolveDVO.cpp:1063-1098); -1 = not run.  Inspection / tests. */
+ * 0 = 16-byte texels gathered from HBM/L2, 1 = the level's texels staged once per level into LDS ("LDS-staged image
+ * tiles": the reference re-copies the three images every iteration, SolveDVO.cpp:310,316-317,427) -- taken when the whole
+ * level fits beside its point list; -1 = not run.  Inspection / tests. */
 int  dvo_get_level_texel_mode(dvo_ctx *ctx, int pair, int level, int *mode);
 
 /* Diagnostic builds only (make STAMPS=1): per-level phase cycle counters of `pair`,

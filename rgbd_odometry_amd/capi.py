@@ -520,7 +520,7 @@ class DvoContext:
         return out.reshape(8, 8)
 
     def level_texel_mode(self, pair: int, level: int) -> int:
-        """0 = 16-byte texels from HBM/L2, 1 = level staged in LDS (16-byte texels), 2 = DT plane staged in LDS, -1 = not run"""
+        """0 = 16-byte texels gathered from HBM/L2, 1 = the level's texels staged in LDS, -1 = not run"""
         m = C.c_int(-2)
         self._chk(self.lib.dvo_get_level_texel_mode(self._h, pair, level, C.byref(m)))
         return m.value

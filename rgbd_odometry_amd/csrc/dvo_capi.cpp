@@ -88,10 +88,7 @@ int ensure_texels(dvo_ctx *c, int level, int rows, int cols) {
         L.tex = nullptr;
         std::fill(L.have_now.begin(), L.have_now.end(), 0);
     }
-    if (!L.d_nonderived) {
-        HIPCHK(c, hipMalloc((void **)&L.d_nonderived, sizeof(int) * c->n_pairs));
-        HIPCHK(c, hipMemsetAsync(L.d_nonderived, 0xff, sizeof(int) * c->n_pairs, c->stream));
-    }
+
     L.rows = rows; L.cols = cols;
     L.tex_stride = texel_count(rows, cols);
     HIPCHK(c, hipMalloc((void **)&L.tex, sizeof(float4) * L.tex_stride * c->n_pairs));
@@ -109,7 +106,7 @@ namespace {
 LevelSlab slab_of(const dvo_ctx *c, int level) {
     const Level &L = c->lv[level];
     LevelSlab s;
-    s.tex = L.tex; s.pts = L.pts; s.cpts = L.cpts; s.N = L.dN; s.nonderived = L.d_nonderived;
+    s.tex = L.tex; s.pts = L.pts; s.cpts = L.cpts; s.N = L.dN;
     s.tex_stride = L.tex_stride; s.pt_cap = L.pt_cap; s.rows = L.rows; s.cols = L.cols;
     return s;
 }
@@ -237,6 +234,7 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         bytes &= ~63;
         sc.lds_bytes = bytes;
         sc.no_lds_tex = (c->prm.engine_variant == 2) ? 1 : 0;
+        sc.force_exact = (c->prm.engine_variant == 3) ? 1 : 0;
         sc.lds_points = bytes / (sc.compact ? 8 : 12);
         if (c->prm.lds_point_bytes < 0) { sc.lds_points = 0; sc.lds_bytes = 0; }
     }
@@ -350,7 +348,6 @@ int dvo_destroy(dvo_ctx *c) {
         if (c->lv[l].pts) (void)hipFree(c->lv[l].pts);
         if (c->lv[l].cpts) (void)hipFree(c->lv[l].cpts);
         if (c->lv[l].dN) (void)hipFree(c->lv[l].dN);
-        if (c->lv[l].d_nonderived) (void)hipFree(c->lv[l].d_nonderived);
     }
     for (int l = 0; l < DVO_LEVELS; l++) {
         FrameLevel &F = c->fs.lv[l];
@@ -508,9 +505,6 @@ static int set_now_common(dvo_ctx *c, int pair, int level, const float *dt, cons
         s_dt = c->staging; s_gx = c->staging + npx; s_gy = c->staging + 2 * npx;
     }
     HIPCHK(c, launch_pack_texels(s_dt, s_gx, s_gy, L.tex + (size_t)pair * L.tex_stride, rows, cols, c->stream));
-    /* are gx, gy the reference's own imageGradient(DT)?  (decides whether coarse levels may live in LDS as DT planes) */
-    HIPCHK(c, hipMemsetAsync(L.d_nonderived + pair, 0, sizeof(int), c->stream));
-    HIPCHK(c, launch_verify_derived(L.tex + (size_t)pair * L.tex_stride, rows, cols, L.d_nonderived + pair, c->stream));
     L.have_now[pair] = 1;
     if (!device_src) HIPCHK(c, hipStreamSynchronize(c->stream));
     return DVO_OK;
@@ -548,7 +542,6 @@ int dvo_set_now_level_from_edges(dvo_ctx *c, int pair, int level, const unsigned
     HIPCHK(c, hipMemcpyAsync(d_edge, edge, npx, hipMemcpyHostToDevice, c->stream));
     Level &L = c->lv[level];
     HIPCHK(c, launch_now_level_from_edges(d_edge, rows, cols, work, L.tex + (size_t)pair * L.tex_stride, c->stream));
-    HIPCHK(c, hipMemsetAsync(L.d_nonderived + pair, 0, sizeof(int), c->stream));      /* derived by construction, DT in [0, 255] */
     L.have_now[pair] = 1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return DVO_OK;
@@ -601,7 +594,7 @@ int dvo_replicate_pairs(dvo_ctx *c, int n_src, int dst_first, int dst_count) {
             int rc = check_ready(c, p, l);
             if (rc) return rc;
         }
-        HIPCHK(c, launch_replicate_level(L.tex, L.tex_stride, L.pts, L.cpts, L.pt_cap, L.dN, L.d_nonderived, n_src, dst_first, dst_count, c->stream));
+        HIPCHK(c, launch_replicate_level(L.tex, L.tex_stride, L.pts, L.cpts, L.pt_cap, L.dN, n_src, dst_first, dst_count, c->stream));
         for (int p = dst_first; p < dst_first + dst_count; p++) {
             L.hN[p] = L.hN[(p - dst_first) % n_src];
             L.compact_ok[p] = L.compact_ok[(p - dst_first) % n_src];

@@ -429,7 +429,6 @@ static int frames_as_now_level(dvo_ctx *c, int l, int first_slot, int first_pair
                                              c->work, L.tex + (size_t)(first_pair + b) * L.tex_stride, L.tex_stride, stream));
         }
     }
-    HIPCHK(c, hipMemsetAsync(L.d_nonderived + first_pair, 0, sizeof(int) * count, stream));   /* derived by construction */
     for (int i = 0; i < count; i++) L.have_now[first_pair + i] = 1;
     return DVO_OK;
 }

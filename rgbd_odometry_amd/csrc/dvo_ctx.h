@@ -28,7 +28,6 @@ struct Level {
     std::vector<char> compact_ok;   /* per pair: the list came from the engine's enlist kernels */
     int pt_cap = 0;
     int *dN = nullptr;
-    int *d_nonderived = nullptr;    /* per pair: 0 = gradients verified to be imageGradient(DT) (see dvo_launch.h) */
     std::vector<int> hN;            /* 0 = not set */
     std::vector<char> have_now;
 };

@@ -35,44 +35,23 @@ DVO_DEV void acc7_zero(Acc7 &a) {
     a.nvis = 0;
 }
 
-/* Where a level's now-frame data is read from (chosen per level and pair, wave-uniform):
+/* Where a level's now-frame texels are read from (chosen per level and pair, wave-uniform):
  *   TEX_G16  16-byte texels {DT, gx, gy, w} gathered from HBM / L2
  *   TEX_L16  the same texels, staged once per level into LDS ("LDS-staged image tiles"; the reference re-copies the three
- *            now images every iteration, SolveDVO.cpp:310,316-317,427)
- *   TEX_LDT  only the DT plane staged into LDS (4 B / pixel, one-pixel reflect-101 apron); gx, gy are rebuilt per point
- *            as imageGradient does (0.5f*a - 0.5f*b, :1077-1090) and w with weight_fast() -- allowed only when the level's
- *            gradient images were verified to be exactly that (LevelSlab::nonderived == 0) */
-enum { TEX_G16 = DVO_TEXMODE_GLOBAL16, TEX_L16 = DVO_TEXMODE_LDS16, TEX_LDT = DVO_TEXMODE_LDS_DT, TEX_GDT = 3 };
+ *            now images every iteration, SolveDVO.cpp:310,316-317,427) -- taken when the whole level fits beside its points */
+enum { TEX_G16 = DVO_TEXMODE_GLOBAL16, TEX_L16 = DVO_TEXMODE_LDS16 };
 
 struct TexSrc {
     const char *g16;           /* this pair's level in HBM, tiled 16-byte texels */
     unsigned tile_col_bytes;   /* tiles_per_col * 128 */
     const char *l16;           /* LDS copy of the same bytes (TEX_L16) */
-    const float *ldt;          /* LDS DT plane, element (yp, xp) at xp*ldt_stride + yp, yp = yy+1, xp = xx+1 (TEX_LDT) */
-    int ldt_stride;            /* rows + 2 */
-    const char *gdt;           /* DT plane in HBM (TEX_GDT): padded like ldt, in tiles of 8 rows x 4 columns (one 128-byte line), rows fastest */
-    unsigned gdt_col_bytes;    /* bytes per tile column = ceil((rows+2)/8) * 128 */
 };
 
 /* one round of the software pipeline: two points per lane */
-template <int TEX> struct Round2 {
+struct Round2 {
     v2f xn, yn, zn;    /* dehomogenised coordinates (finite dummies where not visible) */
     v4f t0, t1;        /* the two texels {DT, gx, gy, w} as loaded */
     bool vis0, vis1;
-};
-template <> struct Round2<TEX_LDT> {
-    v2f xn, yn, zn;
-    float c0, n0, s0, w0, e0;   /* DT at the pixel and its four neighbours, point 0 */
-    float c1, n1, s1, w1, e1;
-    bool vis0, vis1;
-};
-typedef float v3f __attribute__((ext_vector_type(3)));
-template <> struct Round2<TEX_GDT> {
-    v2f xn, yn, zn;
-    v3f v0, v1;                 /* {above, centre, below} of the two points as loaded (above / below wrong at a tile edge) */
-    float w0, e0, f0, w1, e1, f1;   /* left, right, and the fix-up value of the tile-edge lanes */
-    bool vis0, vis1;
-    bool top0, bot0, top1, bot1;    /* the centre is in the first / last row of its tile */
 };
 
 /* byte offset of texel (yy, xx) in the tiled 16-byte texel image (texel_index() * 16 in seven instructions) */
@@ -103,7 +82,7 @@ DVO_DEV void load_compact(const LdsPoints &lp, const uint2 *__restrict__ gpts, i
  * share of the iteration with the literal-division scalar code (accumulate_points_exact). */
 template <bool LDS_SRC, int TEX>
 DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints &lp, const uint2 *__restrict__ gpts,
-                          int i0, int i1, int end, Round2<TEX> &b, bool &any_odd) {
+                          int i0, int i1, int end, Round2 &b, bool &any_odd) {
     const bool valid0 = i0 < end, valid1 = i1 < end;
     const int j0 = valid0 ? i0 : (end - 1), j1 = valid1 ? i1 : (end - 1);
     unsigned k0, k1;
@@ -129,37 +108,13 @@ DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints 
     /* finite dummies for lanes without a visible point: they then add exact zeros (w = eps = 0) */
     b.xn.x = vis0 ? xn.x : 0.0f; b.yn.x = vis0 ? yn.x : 0.0f; b.zn.x = vis0 ? zn.x : 1.0f;
     b.xn.y = vis1 ? xn.y : 0.0f; b.yn.y = vis1 ? yn.y : 0.0f; b.zn.y = vis1 ? zn.y : 1.0f;
-    if constexpr (TEX == TEX_GDT) {
-        auto stencil = [&](bool vis, int px, int py, v3f &v, float &wv, float &ev, float &fv, bool &top, bool &bot) {
-            const unsigned xp = vis ? (unsigned)px + 1u : 1u, yp = vis ? (unsigned)py + 1u : 1u;
-            const unsigned b = xp & 3u, c7 = yp & 7u;
-            /* (xp>>2)*col_bytes + (yp>>3)*128 + (xp&3)*32 + (yp&7)*4 */
-            const unsigned off = (xp >> 2) * ts.gdt_col_bytes + (yp << 4) - 12u * c7 + (b << 5);
-            top = (c7 == 0u); bot = (c7 == 7u);
-            v = *reinterpret_cast<const v3f *>(ts.gdt + (off - 4u));
-            wv = *reinterpret_cast<const float *>(ts.gdt + (off + ((b == 0u) ? (96u - ts.gdt_col_bytes) : (unsigned)-32)));
-            ev = *reinterpret_cast<const float *>(ts.gdt + (off + ((b == 3u) ? (ts.gdt_col_bytes - 96u) : 32u)));
-            fv = 0.0f;
-            if (top || bot) fv = *reinterpret_cast<const float *>(ts.gdt + (off + (top ? (unsigned)-100 : 100u)));
-        };
-        stencil(vis0, px0, py0, b.v0, b.w0, b.e0, b.f0, b.top0, b.bot0);
-        stencil(vis1, px1, py1, b.v1, b.w1, b.e1, b.f1, b.top1, b.bot1);
-    } else if constexpr (TEX == TEX_LDT) {
-        /* centre of the stencil in the padded plane; pixel (0,0) for lanes without a visible point */
-        const int q0 = vis0 ? ((px0 + 1) * ts.ldt_stride + (py0 + 1)) : (ts.ldt_stride + 1);
-        const int q1 = vis1 ? ((px1 + 1) * ts.ldt_stride + (py1 + 1)) : (ts.ldt_stride + 1);
-        const float *p0 = ts.ldt + q0, *p1 = ts.ldt + q1;
-        b.c0 = p0[0]; b.n0 = p0[-1]; b.s0 = p0[1]; b.w0 = p0[-ts.ldt_stride]; b.e0 = p0[ts.ldt_stride];
-        b.c1 = p1[0]; b.n1 = p1[-1]; b.s1 = p1[1]; b.w1 = p1[-ts.ldt_stride]; b.e1 = p1[ts.ldt_stride];
-    } else {
-        unsigned o0 = texel_byte_offset(py0, px0, ts.tile_col_bytes);
-        unsigned o1 = texel_byte_offset(py1, px1, ts.tile_col_bytes);
-        o0 = vis0 ? o0 : 0u;
-        o1 = vis1 ? o1 : 0u;
-        const char *base = (TEX == TEX_L16) ? ts.l16 : ts.g16;
-        b.t0 = *reinterpret_cast<const v4f *>(base + o0);
-        b.t1 = *reinterpret_cast<const v4f *>(base + o1);
-    }
+    unsigned o0 = texel_byte_offset(py0, px0, ts.tile_col_bytes);
+    unsigned o1 = texel_byte_offset(py1, px1, ts.tile_col_bytes);
+    o0 = vis0 ? o0 : 0u;
+    o1 = vis1 ? o1 : 0u;
+    const char *base = (TEX == TEX_L16) ? ts.l16 : ts.g16;
+    b.t0 = *reinterpret_cast<const v4f *>(base + o0);
+    b.t1 = *reinterpret_cast<const v4f *>(base + o1);
 }
 
 /* (double)(float)(J_k w) * (double)eps is exact, so fma(a,b,c) == c + a*b bit for bit (:719-720, :777) */
@@ -171,29 +126,11 @@ DVO_DEV void acc7_add(Acc7 &a, const float *jw, float eps) {
 }
 
 /* stage 2: weighted Jacobian rows + accumulation */
-template <int TEX>
-DVO_DEV void round2_compute(const IterConst &c, const Round2<TEX> &b, Acc7 &a) {
+DVO_DEV void round2_compute(const IterConst &c, const Round2 &b, Acc7 &a) {
     a.nvis += __popcll(__builtin_amdgcn_ballot_w64(b.vis0)) + __popcll(__builtin_amdgcn_ballot_w64(b.vis1));
-    float eps0, eps1, w0, w1, gx0, gx1, gy0, gy1;
-    if constexpr (TEX == TEX_GDT) {
-        const float n0 = b.top0 ? b.f0 : b.v0.x, s0 = b.bot0 ? b.f0 : b.v0.z;
-        const float n1 = b.top1 ? b.f1 : b.v1.x, s1 = b.bot1 ? b.f1 : b.v1.z;
-        gx0 = 0.5f * b.e0 - 0.5f * b.w0; gy0 = 0.5f * s0 - 0.5f * n0;
-        gx1 = 0.5f * b.e1 - 0.5f * b.w1; gy1 = 0.5f * s1 - 0.5f * n1;
-        eps0 = b.vis0 ? b.v0.y : 0.0f; eps1 = b.vis1 ? b.v1.y : 0.0f;
-        w0 = b.vis0 ? weight_fast(b.v0.y) : 0.0f; w1 = b.vis1 ? weight_fast(b.v1.y) : 0.0f;
-    } else if constexpr (TEX == TEX_LDT) {
-        /* imageGradient (:1077-1090): kernX = [-.5 0 .5] -> 0.5f*right - 0.5f*left, kernY likewise (same operations as
-         * the oracle's dvo_oracle_now_level_from_edges and the engine's own frame kernels) */
-        gx0 = 0.5f * b.e0 - 0.5f * b.w0; gy0 = 0.5f * b.s0 - 0.5f * b.n0;
-        gx1 = 0.5f * b.e1 - 0.5f * b.w1; gy1 = 0.5f * b.s1 - 0.5f * b.n1;
-        eps0 = b.vis0 ? b.c0 : 0.0f; eps1 = b.vis1 ? b.c1 : 0.0f;
-        w0 = b.vis0 ? weight_fast(b.c0) : 0.0f; w1 = b.vis1 ? weight_fast(b.c1) : 0.0f;     /* getWeightOf :1047-1053 */
-    } else {
-        gx0 = b.t0.y; gx1 = b.t1.y; gy0 = b.t0.z; gy1 = b.t1.z;
-        eps0 = b.vis0 ? b.t0.x : 0.0f; eps1 = b.vis1 ? b.t1.x : 0.0f;
-        w0 = b.vis0 ? b.t0.w : 0.0f; w1 = b.vis1 ? b.t1.w : 0.0f;
-    }
+    const float gx0 = b.t0.y, gx1 = b.t1.y, gy0 = b.t0.z, gy1 = b.t1.z;
+    const float eps0 = b.vis0 ? b.t0.x : 0.0f, eps1 = b.vis1 ? b.t1.x : 0.0f;
+    const float w0 = b.vis0 ? b.t0.w : 0.0f, w1 = b.vis1 ? b.t1.w : 0.0f;
     v2f jw[6];
     jacobian_weighted2(c, b.xn, b.yn, b.zn, gx0, gx1, gy0, gy1, w0, w1, jw);
     const double e0 = (double)eps0, e1 = (double)eps1;
@@ -217,23 +154,23 @@ DVO_DEV void accumulate_points2(const IterConst &c, const TexSrc &ts, const LdsP
     const int wave_off = __builtin_amdgcn_readfirstlane(lane_off - (int)(threadIdx.x & 63));
     const int n_rounds = (end - first - wave_off + STEP - 1) / STEP;
     if (n_rounds <= 0) return;
-    Round2<TEX> A, B;
+    Round2 A, B;
     int base = first + lane_off;
     round2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base, base + BLOCK, end, A, any_odd);
     int r = 0;
     for (; r + 2 < n_rounds; r += 2) {
         round2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + STEP, base + STEP + BLOCK, end, B, any_odd);
-        round2_compute<TEX>(c, A, a);
+        round2_compute(c, A, a);
         round2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + 2 * STEP, base + 2 * STEP + BLOCK, end, A, any_odd);
-        round2_compute<TEX>(c, B, a);
+        round2_compute(c, B, a);
         base += 2 * STEP;
     }
     if (r + 1 < n_rounds) {
         round2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + STEP, base + STEP + BLOCK, end, B, any_odd);
-        round2_compute<TEX>(c, A, a);
-        round2_compute<TEX>(c, B, a);
+        round2_compute(c, A, a);
+        round2_compute(c, B, a);
     } else {
-        round2_compute<TEX>(c, A, a);
+        round2_compute(c, A, a);
     }
 }
 
@@ -344,27 +281,32 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
 
         /* ---- what lives in LDS for this level (wave-uniform decisions) --------------------------------------------
          * Always the compact point list (the reference deep-copies the 3xN list every iteration, :670; here HBM sees it once
-         * per level).  If the whole list AND the level's now data fit, the now data is staged too and the level's 10
-         * iterations never touch HBM again: as 16-byte texels when they fit, else -- for levels whose gradients are
-         * imageGradient(DT) -- as the DT plane alone. */
+         * per level).  If the whole list AND the level's texels fit, the texels are staged too ("LDS-staged image tiles")
+         * and the level's iterations never leave the CU again. */
         const int lds_words = sc.lds_bytes >> 2;
         const int n_pad = (N + 3) & ~3;
         const int tex16_words = (int)(L.tex_stride * 4);
-        const int ldt_stride = L.rows + 2;
-        const int ldt_words = (ldt_stride * (L.cols + 2) + 3) & ~3;
-        int mode = TEX_G16;
-        if (!sc.no_lds_tex && L.rows >= 2 && L.cols >= 2) {
-            if (2 * n_pad + tex16_words <= lds_words) mode = TEX_L16;
-            else if (L.nonderived[dpair] == 0 && 2 * n_pad + ldt_words <= lds_words) mode = TEX_LDT;
-        }
+        const int mode = (!sc.no_lds_tex && 2 * n_pad + tex16_words <= lds_words) ? TEX_L16 : TEX_G16;
         const int cap = (mode == TEX_G16) ? (lds_words >> 1) : n_pad;          /* words per point plane */
         const int n_lds = (N <= cap) ? N : (cap / (2 * BLOCK)) * (2 * BLOCK);      /* whole rounds only */
         float *const lds_tex = lds_dyn + 2 * cap;
         if (tid == 0) out.tex_mode[pair * DVO_LEVELS + l] = mode;
-        {   /* 16-byte loads: whole 128-byte lines per request */
+        {   /* 16-byte loads (whole 128-byte lines per request), four in flight per lane */
             const uint4 *g4 = reinterpret_cast<const uint4 *>(gpts);
             const int n2 = n_lds >> 1;
-            for (int i = tid; i < n2; i += BLOCK) {
+            int i = tid;
+            for (; i + 3 * BLOCK < n2; i += 4 * BLOCK) {
+                uint4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = g4[i + q * BLOCK];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int k = 2 * (i + q * BLOCK);
+                    lds_dyn[k] = __uint_as_float(v[q].x); lds_dyn[cap + k] = __uint_as_float(v[q].y);
+                    lds_dyn[k + 1] = __uint_as_float(v[q].z); lds_dyn[cap + k + 1] = __uint_as_float(v[q].w);
+                }
+            }
+            for (; i < n2; i += BLOCK) {
                 const uint4 v = g4[i];
                 lds_dyn[2 * i] = __uint_as_float(v.x);
                 lds_dyn[cap + 2 * i] = __uint_as_float(v.y);
@@ -380,27 +322,16 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         if (mode == TEX_L16) {
             const v4f *g = reinterpret_cast<const v4f *>(tex);
             v4f *d = reinterpret_cast<v4f *>(lds_tex);
-            for (int i = tid; i < (int)L.tex_stride; i += BLOCK) d[i] = g[i];
-        } else if (mode == TEX_LDT) {
-            /* the DT of every texel, read in memory order (whole lines), scattered to (yy+1, xx+1) of the padded plane;
-             * the apron repeats row/column 1 and rows-2 / cols-2 (BORDER_REFLECT_101, :1077-1090) */
-            const v4f *g = reinterpret_cast<const v4f *>(tex);
-            const int per_col = c.tiles_per_col * 8;                  /* texels per tile column (two image columns) */
-            const int n_tc = (L.cols + 1) >> 1;
-            for (int tc = tid >> 6; tc < n_tc; tc += BLOCK / 64) {
-                for (int j = tid & 63; j < per_col; j += 64) {
-                    const int yy = ((j >> 3) << 2) + (j & 3), xx = 2 * tc + ((j >> 2) & 1);
-                    if (yy < L.rows && xx < L.cols) {
-                        const float dtv = g[tc * per_col + j].x;
-                        float *col = lds_tex + (xx + 1) * ldt_stride;
-                        col[yy + 1] = dtv;
-                        if (yy == 1) col[0] = dtv;
-                        if (yy == L.rows - 2) col[L.rows + 1] = dtv;
-                        if (xx == 1) lds_tex[yy + 1] = dtv;
-                        if (xx == L.cols - 2) lds_tex[(L.cols + 1) * ldt_stride + yy + 1] = dtv;
-                    }
-                }
+            const int n16 = (int)L.tex_stride;
+            int i = tid;
+            for (; i + 3 * BLOCK < n16; i += 4 * BLOCK) {
+                v4f v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = g[i + q * BLOCK];
+#pragma unroll
+                for (int q = 0; q < 4; q++) d[i + q * BLOCK] = v[q];
             }
+            for (; i < n16; i += BLOCK) d[i] = g[i];
         }
         LdsPoints lp;
         lp.pk = reinterpret_cast<const unsigned *>(lds_dyn);
@@ -408,8 +339,6 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         TexSrc ts;
         ts.g16 = tex; ts.tile_col_bytes = (unsigned)c.tiles_per_col * 128u;
         ts.l16 = reinterpret_cast<const char *>(lds_tex);
-        ts.ldt = lds_tex; ts.ldt_stride = ldt_stride;
-        ts.gdt = tex + 4096; ts.gdt_col_bytes = (unsigned)((L.rows + 2 + 7) >> 3) * 128u;       /* (what-if builds only) */
         __syncthreads();
         DVO_STAMP(ts1);
         DVO_STAMP_ADD(5, ts0, ts1);
@@ -430,18 +359,11 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             const int lane_off = BLOCK - 64 - (tid & ~63) + (tid & 63);
             if (mode == TEX_L16) {                 /* staged levels hold every point in LDS */
                 accumulate_points2<BLOCK, true, TEX_L16>(c, ts, lp, gpts, 0, N, lane_off, a, any_odd);             /* :369, :433 */
-            } else if (mode == TEX_LDT) {
-                accumulate_points2<BLOCK, true, TEX_LDT>(c, ts, lp, gpts, 0, N, lane_off, a, any_odd);
             } else {
-#ifdef DVO_WHATIF_GDT     /* measurement only (wrong results): request / L1 behaviour of a 4-byte DT plane in HBM, 8x4 tiles */
-                accumulate_points2<BLOCK, true, TEX_GDT>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
-                accumulate_points2<BLOCK, false, TEX_GDT>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);
-#else
                 accumulate_points2<BLOCK, true, TEX_G16>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
                 accumulate_points2<BLOCK, false, TEX_G16>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);       /* beyond the LDS budget */
-#endif
             }
-            if (any_odd) {      /* wave-uniform; a point with a degenerate z: this wave's share again, literal divisions */
+            if (any_odd || sc.force_exact) {      /* wave-uniform; a point with a degenerate z: this wave's share again, literal divisions */
                 acc7_zero(a);
                 accumulate_points_exact<BLOCK, true>(c, tex, lp, gpts, 0, n_lds, lane_off, a);
                 accumulate_points_exact<BLOCK, false>(c, tex, lp, gpts, n_lds, N, lane_off, a);

@@ -182,7 +182,7 @@ hipError_t launch_pack_texels(const float *dt, const float *gx, const float *gy,
 /* slot p in [dst_first, dst_first+dst_count) <- copy of slot (p - dst_first) % n_src : one launch per level
  * instead of a pack + copies per pair (bench / throughput set-up, warm replicas) */
 __global__ void __launch_bounds__(256)
-replicate_level_kernel(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, int pt_cap, int *N, int *nonderived,
+replicate_level_kernel(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, int pt_cap, int *N,
                        int n_src, int dst_first, int dst_count) {
     const int p = dst_first + blockIdx.y;
     const int src = blockIdx.y % n_src;
@@ -200,44 +200,13 @@ replicate_level_kernel(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, 
         uint2 *dc = cpts + (size_t)p * pt_cap;
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n; i += stride) dc[i] = sc_[i];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { N[p] = n; nonderived[p] = nonderived[src]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) N[p] = n;
 }
-hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, int pt_cap, int *N, int *nonderived,
+hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, int pt_cap, int *N,
                                   int n_src, int dst_first, int dst_count, hipStream_t s) {
     if (dst_count <= 0) return hipSuccess;
     hipLaunchKernelGGL(replicate_level_kernel, dim3(64, dst_count), dim3(256), 0, s, tex, tex_stride, pts, cpts, pt_cap, N,
-                       nonderived, n_src, dst_first, dst_count);
-    return hipGetLastError();
-}
-
-/* Are the gradient images of a packed level exactly imageGradient(DT) -- filter2D with [-.5 0 .5] and the default
- * BORDER_REFLECT_101 (SolveDVO.cpp:1063-1098), evaluated as 0.5f*a - 0.5f*b like the oracle -- and is every |DT| <= 2^20
- * (the range in which weight_fast() is proven exact)?  The reference always derives them that way (:1771-1795), so in
- * practice yes; then the fused kernel may keep only the DT plane of a coarse level in LDS and rebuild gx, gy, w per
- * point with the same operations.  Caller-supplied images that differ anywhere keep the 16-byte texel path. */
-__global__ void __launch_bounds__(256)
-verify_derived_kernel(const float4 *__restrict__ tex, int rows, int cols, int *nonderived) {
-    const size_t n = (size_t)rows * cols;
-    const int tpc = texel_tiles_per_col(rows);
-    bool bad = false;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int xx = (int)(i / rows), yy = (int)(i - (size_t)xx * rows);
-        const int xl = (cols == 1) ? 0 : ((xx == 0) ? 1 : xx - 1), xr = (cols == 1) ? 0 : ((xx == cols - 1) ? cols - 2 : xx + 1);
-        const int yu = (rows == 1) ? 0 : ((yy == 0) ? 1 : yy - 1), yb = (rows == 1) ? 0 : ((yy == rows - 1) ? rows - 2 : yy + 1);
-        const float4 t = tex[texel_index(yy, xx, tpc)];
-        const float l_ = tex[texel_index(yy, xl, tpc)].x, r_ = tex[texel_index(yy, xr, tpc)].x;
-        const float u_ = tex[texel_index(yu, xx, tpc)].x, b_ = tex[texel_index(yb, xx, tpc)].x;
-        const float gx = 0.5f * r_ - 0.5f * l_, gy = 0.5f * b_ - 0.5f * u_;
-        bad = bad || (__float_as_uint(gx) != __float_as_uint(t.y)) || (__float_as_uint(gy) != __float_as_uint(t.z)) ||
-              !(fabsf(t.x) <= 1048576.0f);
-    }
-    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(nonderived, 1);
-}
-hipError_t launch_verify_derived(const float4 *tex, int rows, int cols, int *nonderived, hipStream_t s) {
-    const size_t n = (size_t)rows * cols;
-    size_t blocks = (n + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(verify_derived_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tex, rows, cols, nonderived);
+                       n_src, dst_first, dst_count);
     return hipGetLastError();
 }
 

@@ -15,7 +15,7 @@
 #define DVO_NACC 29           /* == DVO_NUM_ACC */
 #define DVO_NACC_PAD 32
 /* where the fused kernel reads the now level of a (pair, level) from */
-enum { DVO_TEXMODE_GLOBAL16 = 0, DVO_TEXMODE_LDS16 = 1, DVO_TEXMODE_LDS_DT = 2 };
+enum { DVO_TEXMODE_GLOBAL16 = 0, DVO_TEXMODE_LDS16 = 1 };
 
 namespace dvo {
 
@@ -30,8 +30,6 @@ struct LevelSlab {
     const float *pts;
     const uint2 *cpts;      /* compact points {xx | yy << 16, Z}, pt_cap per pair; valid where the host says so (Schedule.compact) */
     const int *N;
-    const int *nonderived;  /* per pair: 0 = the gradients of this level ARE imageGradient(DT) (SolveDVO.cpp:1063-1098) bit for bit and
-                               |DT| <= 2^20, so kernels may rebuild them (and the weight) from DT alone; else 1 */
     size_t tex_stride;      /* texels per pair */
     int pt_cap;             /* points per pair (capacity) */
     int rows, cols;
@@ -49,6 +47,7 @@ struct Schedule {
     int lds_points;          /* reference points kept resident in LDS per workgroup (3 words each, 2 when compact) */
     int lds_bytes;           /* dynamic LDS of the launch (dvo_fused.hip splits it per level between points and the now level) */
     int no_lds_tex;          /* diagnostics: never stage the now level into LDS */
+    int force_exact;         /* tests: every wave takes the literal-division fallback of the packed kernel (accumulate_points_exact) */
     int compact;             /* every pair/level of this launch has a compact point list: read 8 B / point instead of 12 */
 };
 
@@ -70,10 +69,8 @@ struct Outputs {
 hipError_t launch_pack_texels(const float *dt, const float *gx, const float *gy, float4 *out,
                               int rows, int cols, hipStream_t s);
 bool fused_uses_compact(int points_in_flight, int interp);
-hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, int pt_cap, int *N, int *nonderived,
+hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, int pt_cap, int *N,
                                   int n_src, int dst_first, int dst_count, hipStream_t s);
-/* *nonderived |= 1 unless gx, gy of the packed level equal imageGradient(DT) bit for bit and every |DT| <= 2^20 */
-hipError_t launch_verify_derived(const float4 *tex, int rows, int cols, int *nonderived, hipStream_t s);
 hipError_t launch_align_fused(int block_threads, int points_in_flight, const LevelSet &lv,
                               const Schedule &sc, const Intrinsics &K, const DevParams &prm,
                               const Outputs &out, int first_pair, int n_pairs, hipStream_t s);

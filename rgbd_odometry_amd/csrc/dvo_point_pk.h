@@ -37,16 +37,6 @@ DVO_DEV v2f pk_splat(float s) { v2f r; r.x = s; r.y = s; return r; }
 #define DVO_C23 0x1.000002p-23f    /* 2^-23 + 2^-46  (0x34000001) */
 #define DVO_C24 0x1.000002p-24f    /* (1 + 2^-23) 2^-24  (0x33800001) */
 
-/* getWeightOf (:1047-1053) without the IEEE division sequence: 6/(6+4 r^2) through v_rcp_f64 + one Newton step.
- * Bit-identical to weight_of() for |r| <= 2^20 (checked over every such float by tools/exhaustive/div_tricks.hip; the
- * exact quotient is never closer than 2^-49 relative to a float rounding boundary). */
-DVO_DEV float weight_fast(float r) {
-    const double D = fma(4.0, (double)(r * r), 6.0);
-    double y = __builtin_amdgcn_rcp(D);
-    y = fma(fma(-D, y, 1.0), y, y);
-    return (float)(6.0 * y);
-}
-
 /* floor to int32 (saturating); NaN -> callers guard with max(u,-1) */
 DVO_DEV int cvt_floor_i32(float u) {
     int i;
