@@ -50,6 +50,7 @@ def _check(ctx, oracle, sc, lv, iters, pair=0, R0=None, t0=None):
     dict(),                                          # auto: 512 threads, coarse levels staged into LDS
     dict(engine_variant=2),                          # never stage texels into LDS
     dict(engine_variant=1),                          # the one-point-per-lane kernel on the same compact lists
+    dict(engine_variant=3),                          # every wave through the literal-division fallback of the packed kernel
     dict(block_threads=256), dict(block_threads=1024),
     dict(lds_point_bytes=-1),                        # every point streamed from HBM
     dict(lds_point_bytes=16 * 1024),                 # 2048 points resident, the rest streamed (both passes run)
