@@ -28,6 +28,18 @@ import torch  # imported before the HIP library on purpose: one HIP runtime per 
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak ~6290
 
+#: the sources the fused alignment kernels are built from: their hash ties profiles/pmc_traffic.json to a kernel build
+KERNEL_SOURCES = ["dvo_fused.hip", "dvo_point_pk.h", "dvo_kernels.hip", "dvo_kernel_common.h", "dvo_device_math.h", "dvo_launch.h"]
+
+
+def kernel_source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "rgbd_odometry_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
 
 def parse_args():
     ap = argparse.ArgumentParser()
@@ -253,39 +265,66 @@ def main():
                 "algorithmic_bytes_per_alignment": bytes_per_launch / args.batch,
             },
         }
+        # HBM-side traffic of this launch shape from the PMC passes (profiles/pmc_traffic.json, written by
+        # tools/update_pmc_traffic.py): only valid for the kernel build it was measured on -- the record carries the hash
+        # of the kernel sources, and a stale record is reported as null with the reason instead of being pasted in
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc))
-                key = "%dx%dx%dx%d_b%d" % (args.width, args.height, args.levels, args.iters, args.batch)
-                default_knobs = not (args.variant or args.block or args.inflight or args.lds_point_bytes or args.debug_alias or args.no_final_outputs)
-                if key in rec and default_knobs:
-                    out["roofline"]["traffic"] = rec[key]["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = rec[key].get("source")
-                    if rec[key].get("l2_read_requests"):
-                        # the ceiling this kernel actually sits at: L2 -> fabric read requests
-                        rate = rec[key]["l2_read_requests"] / (kernel_ms * 1e-3) / 1e9
-                        out["roofline"]["request_rate"] = {
-                            "achieved_G_req_per_s": rate, "calibrated_ceiling_G_req_per_s": [44.0, 50.0],
-                            "frac_of_ceiling": rate / 47.0,
-                            "note": "TCC_EA0_RDREQ per launch (PMC profile) / live kernel time; ceiling measured by "
-                                    "tools/exhaustive/fetch_calib.hip (profiles/r01_fetch_size_calibration), same for 64- and 128-byte requests",
-                        }
-            except Exception:
-                pass
+        key = "%dx%dx%dx%d_b%d" % (args.width, args.height, args.levels, args.iters, args.batch)
+        default_knobs = not (args.variant or args.block or args.inflight or args.lds_point_bytes or args.debug_alias or args.no_final_outputs)
+        reason = None
+        try:
+            rec = json.load(open(pmc)).get(key)
+        except Exception as e:
+            rec, reason = None, "profiles/pmc_traffic.json unreadable: %r" % (e,)
+        if rec is None:
+            reason = reason or "no PMC record for workload %s" % key
+        elif not default_knobs:
+            reason = "non-default engine knobs: the PMC record describes the default launch"
+        elif rec.get("kernel_source_sha256") != kernel_source_hash():
+            reason = "PMC record was measured on another kernel build (source hash %s, now %s): re-run tools/pmc_traffic.sh" % (
+                rec.get("kernel_source_sha256"), kernel_source_hash())
+        if reason is None:
+            out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = rec.get("source")
+            if rec.get("l2_read_requests"):
+                # the ceiling this kernel actually sits at: L2 -> fabric read requests
+                rate = rec["l2_read_requests"] / (kernel_ms * 1e-3) / 1e9
+                out["roofline"]["request_rate"] = {
+                    "achieved_G_req_per_s": rate, "calibrated_ceiling_G_req_per_s": [44.0, 50.0],
+                    "frac_of_ceiling": rate / 47.0,
+                    "requests_per_alignment": rec["l2_read_requests"] / args.batch,
+                    "note": "TCC_EA0_RDREQ per launch (PMC profile) / live kernel time; ceiling measured by "
+                            "tools/exhaustive/fetch_calib.hip (profiles/r01_fetch_size_calibration), same for 64- and 128-byte requests",
+                }
+        else:
+            out["roofline"]["traffic"] = None
+            out["roofline"]["traffic_reason"] = reason
         if world == 1 and args.cpu_seconds > 0:
             base, oracle, lvs = cpu_baseline(args, scenes, iters, args.cpu_seconds)
             out["cpu_baseline"] = base
             if args.cpu_all_cores:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args, iters, args.cpu_seconds)
-            # parity spot check in the same run: pair 0 against the oracle on the same inputs
+            # parity check in the same run: EVERY distinct scene of the batch against the oracle on the same inputs
+            # (pairs 0..D-1 are the distinct ones, the rest of the batch are device copies of them)
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib
-            ref = oracle.align_pyramid(iters, lvs[0], scenes[0].intrinsics, np.eye(3), np.zeros(3))
+            worst_r = worst_t = 0.0
+            bit_equal = True
+            for i, sc_i in enumerate(scenes):
+                lv_i = lvs[i] if i < len(lvs) else oracle_lib.scene_levels(sc_i, oracle)
+                ref = oracle.align_pyramid(iters, lv_i, sc_i.intrinsics, np.eye(3), np.zeros(3))
+                worst_r = max(worst_r, oracle_lib.rot_angle(ref["R"], R[i]))
+                worst_t = max(worst_t, float(np.linalg.norm(ref["t"] - t[i])))
+                for l, rep in ref["levels"].items():
+                    e, bi, ratio = ctx.level_report(i, l, iters[l])
+                    bit_equal = bit_equal and bool(np.array_equal(e, rep["energy"])) and bi == rep["best_idx"] and ratio == rep["visible_ratio"]
+                # a replica far down the batch must carry the same bits as its source
+                j = i + len(scenes) * ((args.batch - 1 - i) // len(scenes))
+                bit_equal = bit_equal and bool(np.array_equal(R[i], R[j])) and bool(np.array_equal(t[i], t[j]))
             out["parity_check"] = {
-                "rot_err_rad": oracle_lib.rot_angle(ref["R"], R[0]),
-                "trans_err_m": float(np.linalg.norm(ref["t"] - t[0])),
-                "tolerance": "1e-5 rad / 1e-4 m",
+                "pairs_checked": len(scenes), "max_rot_err_rad": worst_r, "max_trans_err_m": worst_t,
+                "energies_bit_equal": bit_equal, "tolerance": "1e-5 rad / 1e-4 m; energies, best index, visible ratio bit-equal",
+                "pass": bool(bit_equal and worst_r <= 1e-5 and worst_t <= 1e-4),
             }
         if world == 1 and not args.no_frames_leg:
             ctx.close()                                  # release the resident batch before the extra leg

@@ -74,9 +74,24 @@ _lib = None
 
 
 def _build_native():
-    """make -C rgbd_odometry_amd/csrc: builds lib/libdvo_amd.so (gfx950), lib/libdvo_synth.so and the helper binaries"""
+    """make -C rgbd_odometry_amd/csrc: builds lib/libdvo_amd.so (gfx950), lib/libdvo_synth.so and the helper binaries.
+
+    Serialised across processes with a file lock (N ranks of one torch.distributed launch on a fresh checkout would
+    otherwise all run make at once and could dlopen a half-written library): whoever gets the lock builds, the others
+    wait and find the library present.  A failed build raises with make's own output."""
+    import fcntl
     import subprocess
-    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    csrc = os.path.join(_HERE, "csrc")
+    with open(os.path.join(csrc, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if os.path.exists(library_path()):
+                return
+            r = subprocess.run(["make", "-C", csrc], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("building the HIP extension failed (make -C %s):\n%s" % (csrc, r.stdout[-4000:]))
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def load_library() -> C.CDLL:

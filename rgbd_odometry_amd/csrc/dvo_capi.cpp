@@ -147,6 +147,7 @@ int ensure_outputs(dvo_ctx *c, const Schedule &sc) {
         if (c->d_energy) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->d_energy)); }
         HIPCHK(c, hipMalloc((void **)&c->d_energy, sizeof(float) * need));
         c->energy_floats = need;
+        c->sched_gen++;              /* earlier energies are gone */
     }
     if (sc.flags & DVO_FLAG_FINAL_OUTPUTS) {
         const int cap = c->lv[sc.last_level].pt_cap;
@@ -159,9 +160,24 @@ int ensure_outputs(dvo_ctx *c, const Schedule &sc) {
             HIPCHK(c, hipMalloc((void **)&c->d_final_eps, sizeof(float) * (size_t)cap * c->n_pairs));
             HIPCHK(c, hipMalloc((void **)&c->d_final_reproj, sizeof(float) * 3 * (size_t)cap * c->n_pairs));
             c->final_cap = cap;
+            c->sched_gen++;          /* earlier final outputs are gone */
         }
     }
     return DVO_OK;
+}
+
+/* the outputs of pairs [first, first+n) now follow schedule `sc`; a schedule with another layout invalidates what
+ * other pairs reported before (their energies sit at other offsets) */
+void stamp_outputs(dvo_ctx *c, const Schedule &sc, int first, int n) {
+    const bool same_layout = c->have_sched && c->sched.n_levels == sc.n_levels && c->sched.e_stride == sc.e_stride &&
+                             std::memcmp(c->sched.iters, sc.iters, sizeof(sc.iters)) == 0 &&
+                             ((c->sched.flags ^ sc.flags) & DVO_FLAG_FINAL_OUTPUTS) == 0 && c->sched.last_level == sc.last_level;
+    if (!same_layout || c->sched_gen == 0) c->sched_gen++;
+    if (c->pair_gen.empty()) c->pair_gen.assign(c->n_pairs, 0);
+    for (int p = first; p < first + n; p++) c->pair_gen[p] = c->sched_gen;
+}
+bool outputs_valid(const dvo_ctx *c, int pair) {
+    return c->have_sched && !c->pair_gen.empty() && c->pair_gen[pair] == c->sched_gen;
 }
 
 Outputs outputs_of(const dvo_ctx *c) {
@@ -247,6 +263,7 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
     else
         HIPCHK(c, launch_align_fused(block, u, ls, sc, c->K, c->dprm, outputs_of(c),
                                      first_pair, n_pairs, c->stream));
+    stamp_outputs(c, sc, first_pair, n_pairs);
     c->sched = sc;
     c->have_sched = true;
     return DVO_OK;
@@ -659,6 +676,9 @@ int dvo_get_level_report(dvo_ctx *c, int pair, int level, float *energy, int n_e
     if (!c) return DVO_ERR_INVALID;
     if (!pair_ok(c, pair) || !level_ok(level)) return fail(c, DVO_ERR_INVALID, "pair/level out of range");
     if (!c->have_sched || level >= c->sched.n_levels) return fail(c, DVO_ERR_STATE, "no alignment has been run for this level");
+    if (!outputs_valid(c, pair))
+        return fail(c, DVO_ERR_STATE, "pair " + std::to_string(pair) + " was not aligned under the current schedule (its report was "
+                                      "overwritten or laid out by an earlier, different schedule): align it again");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (energy) {
         const int n = std::min(n_energy, c->sched.iters[level]);
@@ -676,6 +696,8 @@ int dvo_get_final_outputs(dvo_ctx *c, int pair, float *final_eps, float *final_r
     if (!pair_ok(c, pair)) return fail(c, DVO_ERR_INVALID, "pair out of range");
     if (!c->have_sched || !(c->sched.flags & DVO_FLAG_FINAL_OUTPUTS) || !c->d_final_eps)
         return fail(c, DVO_ERR_STATE, "last alignment did not request DVO_FLAG_FINAL_OUTPUTS");
+    if (!outputs_valid(c, pair))
+        return fail(c, DVO_ERR_STATE, "pair " + std::to_string(pair) + " was not aligned under the current schedule: align it again");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     int N = 0;
     HIPCHK(c, hipMemcpy(&N, c->d_final_N + pair, sizeof(int), hipMemcpyDeviceToHost));
@@ -853,6 +875,7 @@ int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters,
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::memcpy(R, h, sizeof(double) * 9);
     std::memcpy(t, h + 9, sizeof(double) * 3);
+    stamp_outputs(c, sc, pair, 1);
     c->sched = sc;
     c->have_sched = true;
     return DVO_OK;

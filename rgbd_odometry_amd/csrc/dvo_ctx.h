@@ -95,6 +95,11 @@ struct dvo_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[DVO_LEVELS] = {};
     dvo::Schedule sched{};
     bool have_sched = false;
+    /* which pairs the per-pair outputs (energies, final outputs) currently describe: the output buffers are laid out by
+     * the schedule of the enqueue that wrote them, so a pair aligned under an older, differently shaped schedule (or before
+     * the buffers were re-allocated) has nothing valid to report */
+    int sched_gen = 0;
+    std::vector<int> pair_gen;      /* per pair: sched_gen of the enqueue that last aligned it (0 = never) */
     std::string err;
 };
 

@@ -386,20 +386,22 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
 }
 
 template <int BLOCK, int U, bool CP>
-static void launch_fused_bu(const LevelSet &lv, const Schedule &sc, const Intrinsics &K,
-                            const DevParams &prm, const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {
+static hipError_t launch_fused_bu(const LevelSet &lv, const Schedule &sc, const Intrinsics &K,
+                                  const DevParams &prm, const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {
     const size_t dyn = (size_t)sc.lds_points * (CP ? 2 : 3) * sizeof(float);
     auto kern = align_fused_kernel<BLOCK, U, 0, CP>;
-    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_pairs), dim3(BLOCK), dyn, s, lv, sc, K, prm, out, first_pair);
+    return hipGetLastError();
 }
 template <int BLOCK>
-static void launch_fused_b(int u, const LevelSet &lv, const Schedule &sc, const Intrinsics &K,
-                           const DevParams &prm, const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {
-    if (u >= 4) launch_fused_bu<BLOCK, 4, false>(lv, sc, K, prm, out, first_pair, n_pairs, s);
-    else if (u == 2) launch_fused_bu<BLOCK, 2, false>(lv, sc, K, prm, out, first_pair, n_pairs, s);
-    else if (sc.compact) launch_fused_bu<BLOCK, 1, true>(lv, sc, K, prm, out, first_pair, n_pairs, s);
-    else launch_fused_bu<BLOCK, 1, false>(lv, sc, K, prm, out, first_pair, n_pairs, s);
+static hipError_t launch_fused_b(int u, const LevelSet &lv, const Schedule &sc, const Intrinsics &K,
+                                 const DevParams &prm, const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {
+    if (u >= 4) return launch_fused_bu<BLOCK, 4, false>(lv, sc, K, prm, out, first_pair, n_pairs, s);
+    if (u == 2) return launch_fused_bu<BLOCK, 2, false>(lv, sc, K, prm, out, first_pair, n_pairs, s);
+    if (sc.compact) return launch_fused_bu<BLOCK, 1, true>(lv, sc, K, prm, out, first_pair, n_pairs, s);
+    return launch_fused_bu<BLOCK, 1, false>(lv, sc, K, prm, out, first_pair, n_pairs, s);
 }
 
 /* true if this launch configuration reads the compact point lists (the host sizes sc.lds_points accordingly) */
@@ -412,16 +414,16 @@ hipError_t launch_align_fused(int block_threads, int points_in_flight, const Lev
     if (K.interp) {     /* optional interpolate() lookup: one configuration only, it is not the tuned path */
         const size_t dyn = (size_t)sc.lds_points * 3 * sizeof(float);
         auto kern = align_fused_kernel<512, 1, 1, false>;
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(n_pairs), dim3(512), dyn, s, lv, sc, K, prm, out, first_pair);
         return hipGetLastError();
     }
     switch (block_threads) {
-    case 256: launch_fused_b<256>(points_in_flight, lv, sc, K, prm, out, first_pair, n_pairs, s); break;
-    case 1024: launch_fused_b<1024>(points_in_flight, lv, sc, K, prm, out, first_pair, n_pairs, s); break;
-    default: launch_fused_b<512>(points_in_flight, lv, sc, K, prm, out, first_pair, n_pairs, s); break;
+    case 256: return launch_fused_b<256>(points_in_flight, lv, sc, K, prm, out, first_pair, n_pairs, s);
+    case 1024: return launch_fused_b<1024>(points_in_flight, lv, sc, K, prm, out, first_pair, n_pairs, s);
+    default: return launch_fused_b<512>(points_in_flight, lv, sc, K, prm, out, first_pair, n_pairs, s);
     }
-    return hipGetLastError();
 }
 
 /* ------------------------------------------------------------------------- */

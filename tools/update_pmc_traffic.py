@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""HBM-side traffic of the default bench launch from rocprofv3 PMC passes -> profiles/pmc_traffic.json.
+
+Run on the GPU box (python3 tools/update_pmc_traffic.py [tag]).  Three separate, guarded --pmc passes (FETCH_SIZE,
+WRITE_SIZE, TCC_EA0_RDREQ + TCC hit/req) over `bench.py --steps 3`, as MI355X_MICROARCH.md prescribes (counters in
+their own runs, --kernel-trace only).  The record carries the hash of the kernel sources (bench.kernel_source_hash), so
+bench.py reports `traffic: null` instead of a stale number once the kernel changes.
+FETCH_SIZE is used as reported: for this kernel's sparse 16-byte gathers it was calibrated exact
+(profiles/r01_fetch_size_calibration); the guide's x2 correction applies to wide coalesced streaming reads only.
+"""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+out_dir = os.path.join(ROOT, "gpurun_out", "pmc_traffic_" + tag)
+os.makedirs(out_dir, exist_ok=True)
+os.environ["TMPDIR"] = "/tmp"
+groups = {"fetch": "FETCH_SIZE", "write": "WRITE_SIZE", "req": "TCC_EA0_RDREQ_sum TCC_REQ_sum TCC_HIT_sum"}
+vals = {}
+for name, cnt in groups.items():
+    d = os.path.join(out_dir, name)
+    cmd = ["timeout", "150", "rocprofv3", "--pmc"] + cnt.split() + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc",
+           "--", "python3", os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-frames-leg"]
+    r = subprocess.run(cmd, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    open(os.path.join(out_dir, name + ".log"), "w").write(r.stdout)
+    print(name, "rc", r.returncode)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "align_fused" in row["Kernel_Name"]:
+                vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+avg = {k: sum(v) / len(v) for k, v in vals.items()}
+print(avg)
+import bench
+fetch, write = avg["FETCH_SIZE"] * 1024.0, avg["WRITE_SIZE"] * 1024.0      # rocprofv3 reports KiB
+rec = {
+    "hbm_bytes_per_launch": int(fetch + write), "fetch_bytes": int(fetch), "write_bytes": int(write),
+    "l2_read_requests": int(avg["TCC_EA0_RDREQ_sum"]), "l2_requests": int(avg.get("TCC_REQ_sum", 0)), "l2_hits": int(avg.get("TCC_HIT_sum", 0)),
+    "kernel_source_sha256": bench.kernel_source_hash(),
+    "source": "tools/update_pmc_traffic.py %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_EA0_RDREQ, separate passes over bench.py "
+              "--steps 3; FETCH_SIZE calibrated for sparse 16-byte gathers in profiles/r01_fetch_size_calibration: exact, no 2x correction)" % tag,
+}
+path = os.path.join(ROOT, "gpurun_out", "pmc_traffic.json")
+try:
+    allrec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+except Exception:
+    allrec = {}
+allrec["640x480x4x10_b1024"] = rec
+json.dump(allrec, open(path, "w"), indent=2)
+print("wrote", path, "(copy to profiles/pmc_traffic.json)")
+print(json.dumps(rec, indent=2))
