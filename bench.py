@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time the CPU oracle with one alignment per host core (extra ~cpu-seconds)")
     ap.add_argument("--no-final-outputs", action="store_true")
+    ap.add_argument("--normal-matrix", action="store_true", help="DVO_FLAG_NORMAL_MATRIX: also accumulate H = sum w J^T J per iterate (cost measurement)")
     ap.add_argument("--inflight", type=int, default=0, help="points in flight per lane (1/2/4; 0 = default)")
     ap.add_argument("--lds-point-bytes", type=int, default=0, help="LDS bytes per workgroup for resident points (0 auto, <0 none)")
     ap.add_argument("--variant", type=int, default=0, help="engine_variant (0 auto, 1 = one-point-per-lane fused kernel)")
@@ -193,10 +194,10 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from rgbd_odometry_amd import DvoContext
-    from rgbd_odometry_amd.capi import DVO_FLAG_FINAL_OUTPUTS, DVO_FLAG_IDENTITY_START
+    from rgbd_odometry_amd.capi import DVO_FLAG_FINAL_OUTPUTS, DVO_FLAG_IDENTITY_START, DVO_FLAG_NORMAL_MATRIX
 
     iters = [args.iters] * args.levels
-    flags = DVO_FLAG_IDENTITY_START | (0 if args.no_final_outputs else DVO_FLAG_FINAL_OUTPUTS)
+    flags = DVO_FLAG_IDENTITY_START | (0 if args.no_final_outputs else DVO_FLAG_FINAL_OUTPUTS) | (DVO_FLAG_NORMAL_MATRIX if args.normal_matrix else 0)
     ctx = DvoContext(args.batch, block_threads=args.block, debug_alias_mod=args.debug_alias,
                      points_in_flight=args.inflight, lds_point_bytes=args.lds_point_bytes,
                      engine_variant=args.variant)
@@ -254,6 +255,7 @@ def main():
                 "points_in_flight": args.inflight or 1,
                 **({"debug_alias_mod": args.debug_alias} if args.debug_alias else {}),
                 **({"engine_variant": args.variant} if args.variant else {}),
+                **({"normal_matrix": True} if args.normal_matrix else {}),
                 "point_iterations_per_launch": point_iters,
             },
             "roofline": {
@@ -270,7 +272,7 @@ def main():
         # of the kernel sources, and a stale record is reported as null with the reason instead of being pasted in
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         key = "%dx%dx%dx%d_b%d" % (args.width, args.height, args.levels, args.iters, args.batch)
-        default_knobs = not (args.variant or args.block or args.inflight or args.lds_point_bytes or args.debug_alias or args.no_final_outputs)
+        default_knobs = not (args.normal_matrix or args.variant or args.block or args.inflight or args.lds_point_bytes or args.debug_alias or args.no_final_outputs)
         reason = None
         try:
             rec = json.load(open(pmc)).get(key)

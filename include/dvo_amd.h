@@ -55,8 +55,12 @@ enum {
 /* flags for the align entry points */
 enum {
     DVO_FLAG_FINAL_OUTPUTS = 1,   /* also produce finalEpsilons / finalReprojections (SolveDVO.cpp:1002-1003) */
-    DVO_FLAG_IDENTITY_START = 2   /* start from cR=I, cT=0 instead of the stored pose: what the reference does
+    DVO_FLAG_IDENTITY_START = 2,  /* start from cR=I, cT=0 instead of the stored pose: what the reference does
                                      on a keyframe switch (SolveDVO.cpp:2210-2211); enqueue form only */
+    DVO_FLAG_NORMAL_MATRIX = 4    /* also accumulate H = sum_i w_i J_i^T J_i (21 sums, double) in every iteration of the fused launch
+                                     and keep it per iterate (dvo_get_level_normal_matrix): the other 21 of the "21+6" normal-equation
+                                     accumulators.  The reference's update never forms H (SolveDVO.cpp:777 uses g only; the pattern is
+                                     SolvePnP.cpp:168-182), so poses / energies are unchanged; costs throughput */
 };
 
 /* Every literal of SolveDVO::runIterations as a runtime parameter; defaults are
@@ -189,6 +193,11 @@ int  dvo_get_poses(dvo_ctx *ctx, int first_pair, int n_pairs, double *R, double 
  * energy: iters[level] floats; any pointer may be NULL. */
 int  dvo_get_level_report(dvo_ctx *ctx, int pair, int level, float *energy, int n_energy,
                           int *best_idx, float *visible_ratio);
+/* H = sum_i w_i J_i^T J_i (6x6 symmetric, row-major, tangent order [translation(3), rotation(3)] like psi) at iterate
+ * `itr` of `level` of the last align call made with DVO_FLAG_NORMAL_MATRIX; itr < 0 = the best iterate (:696).  With g
+ * (not kept) it is the Gauss-Newton system of the reference's residual; H^-1 scaled by the residual variance is the usual
+ * covariance estimate of the aligned pose. */
+int  dvo_get_level_normal_matrix(dvo_ctx *ctx, int pair, int level, int itr, double *H36);
 /* finalEpsilons / finalReprojections of the last level run (needs DVO_FLAG_FINAL_OUTPUTS). */
 int  dvo_get_final_outputs(dvo_ctx *ctx, int pair, float *final_eps, float *final_reproj, int capacity,
                            int *N_out);

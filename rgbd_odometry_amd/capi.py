@@ -16,6 +16,7 @@ DVO_NUM_ACC = 29
 DVO_OK, DVO_ERR_INVALID, DVO_ERR_NO_DEVICE, DVO_ERR_HIP, DVO_ERR_STATE, DVO_ERR_NOMEM = range(6)
 DVO_FLAG_FINAL_OUTPUTS = 1
 DVO_FLAG_IDENTITY_START = 2
+DVO_FLAG_NORMAL_MATRIX = 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -27,7 +28,7 @@ C_ABI_SYMBOLS = [
     "dvo_set_ref_level_device", "dvo_set_now_level_device", "dvo_set_ref_level_from_images",
     "dvo_run_iterations", "dvo_run_iterations_pair", "dvo_align_pyramid", "dvo_align_batch",
     "dvo_set_poses", "dvo_align_batch_enqueue", "dvo_get_poses", "dvo_get_level_report",
-    "dvo_get_final_outputs", "dvo_eval_points", "dvo_accumulate", "dvo_device_se3_exp",
+    "dvo_get_final_outputs", "dvo_get_level_normal_matrix", "dvo_eval_points", "dvo_accumulate", "dvo_device_se3_exp",
     "dvo_device_se3_log", "dvo_device_rotationize", "dvo_algorithmic_bytes", "dvo_point_iterations",
     "dvo_debug_stamps", "dvo_get_level_texel_mode", "dvo_replicate_pairs", "dvo_set_now_level_from_edges", "dvo_get_now_level", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
     "dvo_align_pyramid_wide",
@@ -141,6 +142,7 @@ def load_library() -> C.CDLL:
         "dvo_get_poses": [vp, i, i, vp, vp],
         "dvo_get_level_report": [vp, i, i, vp, i, ip, fp],
         "dvo_get_final_outputs": [vp, i, vp, vp, i, ip],
+        "dvo_get_level_normal_matrix": [vp, i, i, i, vp],
         "dvo_eval_points": [vp, i, i, vp, vp, vp, vp, vp, vp, vp],
         "dvo_accumulate": [vp, i, i, vp, vp, vp],
         "dvo_device_se3_exp": [vp, vp, vp, vp],
@@ -533,6 +535,12 @@ class DvoContext:
         out = np.zeros(64, np.uint64)
         self._chk(self.lib.dvo_debug_stamps(self._h, pair, _ptr(out)))
         return out.reshape(8, 8)
+
+    def level_normal_matrix(self, pair: int, level: int, itr: int = -1) -> np.ndarray:
+        """H = sum w J^T J (6x6) of iterate `itr` (default: the best) of the last align made with DVO_FLAG_NORMAL_MATRIX"""
+        H = np.zeros(36, np.float64)
+        self._chk(self.lib.dvo_get_level_normal_matrix(self._h, pair, level, itr, _ptr(H)))
+        return H.reshape(6, 6)
 
     def level_texel_mode(self, pair: int, level: int) -> int:
         """0 = 16-byte texels gathered from HBM/L2, 1 = the level's texels staged in LDS, -1 = not run"""

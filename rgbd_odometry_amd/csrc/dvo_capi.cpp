@@ -149,6 +149,15 @@ int ensure_outputs(dvo_ctx *c, const Schedule &sc) {
         c->energy_floats = need;
         c->sched_gen++;              /* earlier energies are gone */
     }
+    if (sc.flags & DVO_FLAG_NORMAL_MATRIX) {
+        const size_t needH = need * 21;
+        if (needH > c->H_doubles) {
+            if (c->d_H) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->d_H)); }
+            HIPCHK(c, hipMalloc((void **)&c->d_H, sizeof(double) * needH));
+            c->H_doubles = needH;
+            c->sched_gen++;
+        }
+    }
     if (sc.flags & DVO_FLAG_FINAL_OUTPUTS) {
         const int cap = c->lv[sc.last_level].pt_cap;
         if (cap > c->final_cap) {
@@ -171,7 +180,8 @@ int ensure_outputs(dvo_ctx *c, const Schedule &sc) {
 void stamp_outputs(dvo_ctx *c, const Schedule &sc, int first, int n) {
     const bool same_layout = c->have_sched && c->sched.n_levels == sc.n_levels && c->sched.e_stride == sc.e_stride &&
                              std::memcmp(c->sched.iters, sc.iters, sizeof(sc.iters)) == 0 &&
-                             ((c->sched.flags ^ sc.flags) & DVO_FLAG_FINAL_OUTPUTS) == 0 && c->sched.last_level == sc.last_level;
+                             ((c->sched.flags ^ sc.flags) & (DVO_FLAG_FINAL_OUTPUTS | DVO_FLAG_NORMAL_MATRIX)) == 0 &&
+                             c->sched.last_level == sc.last_level;
     if (!same_layout || c->sched_gen == 0) c->sched_gen++;
     if (c->pair_gen.empty()) c->pair_gen.assign(c->n_pairs, 0);
     for (int p = first; p < first + n; p++) c->pair_gen[p] = c->sched_gen;
@@ -187,6 +197,7 @@ Outputs outputs_of(const dvo_ctx *c) {
     o.final_cap = c->final_cap;
     o.dbg = c->d_dbg;
     o.tex_mode = c->d_tex_mode;
+    o.H = c->d_H;
     return o;
 }
 
@@ -242,7 +253,7 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
                 if (c->lv[l].compact_ok.empty() || !c->lv[l].compact_ok[sc.alias_mod > 0 ? p % sc.alias_mod : p]) sc.compact = 0;
         }
         /* the CU has 160 KiB of LDS; the static part of the chosen kernel comes off the top */
-        const bool packed = sc.compact && c->prm.engine_variant != 1;
+        const bool packed = sc.compact && c->prm.engine_variant != 1 && !(sc.flags & DVO_FLAG_NORMAL_MATRIX);
         const int static_lds = packed ? (int)fused2_static_lds(block) : (int)(sizeof(double) * (block / 64) * DVO_NACC_PAD + 256 + pose_state_bytes());
         const int max_dyn = 160 * 1024 - static_lds - 64;
         if (bytes > max_dyn) bytes = max_dyn;
@@ -258,7 +269,7 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
     if (u != 1 && u != 2 && u != 4) u = 1;
     /* engine_variant: 0 = auto (packed two-points-per-lane kernel whenever every list is compact), 1 = always the
      * one-point-per-lane kernel of dvo_kernels.hip (A/B measurements, parity tests of both) */
-    if (sc.compact && c->prm.engine_variant != 1)
+    if (sc.compact && c->prm.engine_variant != 1 && !(sc.flags & DVO_FLAG_NORMAL_MATRIX))
         HIPCHK(c, launch_align_fused2(block, ls, sc, c->K, c->dprm, outputs_of(c), first_pair, n_pairs, c->stream));
     else
         HIPCHK(c, launch_align_fused(block, u, ls, sc, c->K, c->dprm, outputs_of(c),
@@ -390,7 +401,7 @@ int dvo_destroy(dvo_ctx *c) {
     }
     void *ptrs[] = {c->staging, c->d_poses, c->d_energy, c->d_best, c->d_ratio, c->d_final_eps,
                     c->d_final_reproj, c->d_final_N, c->d_scratch, c->d_colcounts, c->d_dbg,
-                    c->d_states, c->d_iter_energy, c->d_tex_mode};
+                    c->d_states, c->d_iter_energy, c->d_tex_mode, c->d_H};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -688,6 +699,24 @@ int dvo_get_level_report(dvo_ctx *c, int pair, int level, float *energy, int n_e
     }
     if (best_idx) HIPCHK(c, hipMemcpy(best_idx, c->d_best + pair * DVO_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
     if (visible_ratio) HIPCHK(c, hipMemcpy(visible_ratio, c->d_ratio + pair * DVO_LEVELS + level, sizeof(float), hipMemcpyDeviceToHost));
+    return DVO_OK;
+}
+
+/* H = sum_i w_i J_i^T J_i of iterate `itr` of `level` (itr < 0: the best iterate), as the 6x6 symmetric matrix, row-major */
+int dvo_get_level_normal_matrix(dvo_ctx *c, int pair, int level, int itr, double *H36) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair) || !level_ok(level) || !H36) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    if (!c->have_sched || level >= c->sched.n_levels || !(c->sched.flags & DVO_FLAG_NORMAL_MATRIX) || !c->d_H)
+        return fail(c, DVO_ERR_STATE, "last alignment did not request DVO_FLAG_NORMAL_MATRIX");
+    if (!outputs_valid(c, pair)) return fail(c, DVO_ERR_STATE, "pair was not aligned under the current schedule: align it again");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (itr < 0) HIPCHK(c, hipMemcpy(&itr, c->d_best + pair * DVO_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
+    if (itr < 0 || itr >= c->sched.iters[level]) return fail(c, DVO_ERR_STATE, "no such iterate");
+    double h[21];
+    HIPCHK(c, hipMemcpy(h, c->d_H + ((size_t)pair * c->sched.e_stride + c->sched.e_off[level] + itr) * 21, sizeof(h), hipMemcpyDeviceToHost));
+    int k = 0;
+    for (int i = 0; i < 6; i++)
+        for (int j = i; j < 6; j++) { H36[i * 6 + j] = h[k]; H36[j * 6 + i] = h[k]; k++; }
     return DVO_OK;
 }
 

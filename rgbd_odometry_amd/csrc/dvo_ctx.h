@@ -65,6 +65,8 @@ struct dvo_ctx {
     float *d_ratio = nullptr;
     float *d_final_eps = nullptr, *d_final_reproj = nullptr;
     int *d_final_N = nullptr;
+    double *d_H = nullptr;          /* DVO_FLAG_NORMAL_MATRIX output, n_pairs x e_stride x 21 */
+    size_t H_doubles = 0;
     int *d_tex_mode = nullptr;      /* n_pairs x DVO_LEVELS, written by the packed fused kernel */
     int final_cap = 0;
     double *d_scratch = nullptr;    /* partials (1024 x 32) + acc (32) + misc doubles */

@@ -39,8 +39,9 @@ DVO_DEV void level_consts(IterConst &c, const Intrinsics &K, int level, int rows
 struct Acc {
     double g[6];        /* J^T W eps          (:777)   exact products, double fma */
     double e2;          /* sum eps^2          (:1312) */
-    float H[21];        /* sum w J J^T upper triangle (accumulate_kernel only; the fused kernel runs the
-                           reference's sub-gradient policy, which never forms H -- SolveDVO.cpp:777) */
+    double H[21];       /* sum w J J^T upper triangle, row-major (the 21 normal-equation accumulators; pattern SolvePnP.cpp:168-182).
+                           Exact float x float products summed in double, like g.  Only the kernels instantiated WITH_H carry
+                           them: the reference's sub-gradient policy never forms H (SolveDVO.cpp:777) */
     int nvis;           /* visible points, counted per WAVE with ballots (uniform) */
 };
 DVO_DEV void acc_zero(Acc &a) {
@@ -48,7 +49,7 @@ DVO_DEV void acc_zero(Acc &a) {
     for (int k = 0; k < 6; k++) a.g[k] = 0.0;
     a.e2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < 21; k++) a.H[k] = 0.0f;
+    for (int k = 0; k < 21; k++) a.H[k] = 0.0;
     a.nvis = 0;
 }
 /* visible point -> accumulators.  jw = (float)(J_k*w) (:716) widened, times eps
@@ -71,7 +72,7 @@ DVO_DEV void acc_add(Acc &a, const float *J, float eps, float w) {
         for (int i = 0; i < 6; i++)
 #pragma unroll
             for (int j = 0; j < 6; j++)
-                if (j >= i) a.H[i * 6 - (i * (i - 1)) / 2 + (j - i)] = fmaf(jw[i], J[j], a.H[i * 6 - (i * (i - 1)) / 2 + (j - i)]);
+                if (j >= i) a.H[i * 6 - (i * (i - 1)) / 2 + (j - i)] = fma((double)jw[i], (double)J[j], a.H[i * 6 - (i * (i - 1)) / 2 + (j - i)]);
     }
 }
 
@@ -112,12 +113,12 @@ template <int BLOCK, bool WITH_H>
 DVO_DEV void block_reduce(const Acc &a, double (*red)[DVO_NACC_PAD], double *tot) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (WITH_H) {
-        float h[32];
+        double h[32];
 #pragma unroll
-        for (int k = 0; k < 32; k++) h[k] = (k < 21) ? a.H[k] : 0.0f;
-        wave_reduce_scatter<float, 32>(h);
+        for (int k = 0; k < 32; k++) h[k] = (k < 21) ? a.H[k] : 0.0;
+        wave_reduce_scatter<double, 32>(h);
         const int idx = lane >> 1;
-        if ((lane & 1) == 0 && idx < 21) red[wave][idx] = (double)h[0];
+        if ((lane & 1) == 0 && idx < 21) red[wave][idx] = h[0];
     } else if (lane < 21) {
         red[wave][lane] = 0.0;
     }

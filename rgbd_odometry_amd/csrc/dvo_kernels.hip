@@ -233,7 +233,7 @@ DVO_DEV unsigned long long stamp_now() {
 #ifndef DVO_WAVES_PER_EU
 #define DVO_WAVES_PER_EU 1       /* register budget of the fused kernel: 512 / waves VGPRs */
 #endif
-template <int BLOCK, int U, int INTERP, bool CP>
+template <int BLOCK, int U, int INTERP, bool CP, bool WITH_H = false>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(DVO_WAVES_PER_EU, 8)))
 align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outputs out, int first_pair) {
     const int pair = first_pair + blockIdx.x;
@@ -321,13 +321,15 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
              * waves first, so wave 0 -- whose lane 0 still has the regulariser of the new pose to finish (below) -- is the
              * one that most often has a round less */
             const int lane_off = BLOCK - 64 - (tid & ~63) + (tid & 63);
-            accumulate_points<U, false, CP ? SRC_LDS_COMPACT : SRC_LDS_XYZ, INTERP>(c, tex, psrc, 0, psrc.n_lds, lane_off, BLOCK, a);    /* :369, :433 */
-            accumulate_points<U, false, CP ? SRC_GLOBAL_COMPACT : SRC_GLOBAL_XYZ, INTERP>(c, tex, psrc, psrc.n_lds, N, lane_off, BLOCK, a);  /* beyond the LDS budget */
+            accumulate_points<U, WITH_H, CP ? SRC_LDS_COMPACT : SRC_LDS_XYZ, INTERP>(c, tex, psrc, 0, psrc.n_lds, lane_off, BLOCK, a);    /* :369, :433 */
+            accumulate_points<U, WITH_H, CP ? SRC_GLOBAL_COMPACT : SRC_GLOBAL_XYZ, INTERP>(c, tex, psrc, psrc.n_lds, N, lane_off, BLOCK, a);  /* beyond the LDS budget */
 #ifdef DVO_YOUNG_WAVE_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
             DVO_STAMP(t1);
-            block_reduce<BLOCK, false>(a, red, tot);
+            block_reduce<BLOCK, WITH_H>(a, red, tot);
+            if (WITH_H && tid < 21)     /* DVO_FLAG_NORMAL_MATRIX: H = sum w J J^T of this iterate (the 21 of the "21+6" accumulators) */
+                out.H[((size_t)pair * sc.e_stride + sc.e_off[l] + itr) * 21 + tid] = tot[tid];
             DVO_STAMP(t2);
             if (tid == 0) {
                 const float e = pose_update_t<true>(st, prm, itr, N, &tot[21], tot[27], (int)tot[28]);
@@ -411,6 +413,20 @@ hipError_t launch_align_fused(int block_threads, int points_in_flight, const Lev
                               const Schedule &sc, const Intrinsics &K, const DevParams &prm,
                               const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {
     if (n_pairs <= 0) return hipSuccess;
+    if ((sc.flags & 4) && !K.interp) {     /* DVO_FLAG_NORMAL_MATRIX: the 21 H sums ride along (one configuration, 512 threads) */
+        const size_t dyn = (size_t)sc.lds_points * (sc.compact ? 2 : 3) * sizeof(float);
+        hipError_t e;
+        if (sc.compact) {
+            auto kern = align_fused_kernel<512, 1, 0, true, true>;
+            if ((e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)) != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(n_pairs), dim3(512), dyn, s, lv, sc, K, prm, out, first_pair);
+        } else {
+            auto kern = align_fused_kernel<512, 1, 0, false, true>;
+            if ((e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)) != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(n_pairs), dim3(512), dyn, s, lv, sc, K, prm, out, first_pair);
+        }
+        return hipGetLastError();
+    }
     if (K.interp) {     /* optional interpolate() lookup: one configuration only, it is not the tuned path */
         const size_t dyn = (size_t)sc.lds_points * 3 * sizeof(float);
         auto kern = align_fused_kernel<512, 1, 1, false>;

@@ -63,6 +63,7 @@ struct Outputs {
     int *final_N;            /* n_pairs */
     int final_cap;
     unsigned long long *dbg; /* diagnostics (DVO_STAMPS builds): n_pairs x 64 counters, else NULL */
+    double *H;               /* DVO_FLAG_NORMAL_MATRIX: n_pairs x e_stride x 21 (upper triangle of sum w J J^T per iterate), else NULL */
     int *tex_mode;           /* n_pairs x DVO_LEVELS: where the fused kernel read the now level from (DVO_TEXMODE_*), inspection */
 };
 

@@ -84,8 +84,47 @@ def test_accumulators(scene320, ctx320, oracle):
             assert int(acc[28]) == tr["n_visible"]
             np.testing.assert_allclose(acc[27], tr["sum_eps2"], rtol=1e-13)
             np.testing.assert_allclose(acc[21:27], tr["g"], rtol=1e-11, atol=1e-9 * np.abs(tr["g"]).max())
-            # H: per-lane float partial sums, double tree -> float-level agreement
-            np.testing.assert_allclose(acc[:21], tr["H"], rtol=2e-4, atol=2e-5 * np.abs(tr["H"]).max())
+            # H: exact float x float products summed in double on both sides; only the summation order differs
+            np.testing.assert_allclose(acc[:21], tr["H"], rtol=1e-12, atol=1e-12 * np.abs(tr["H"]).max())
+
+
+def test_normal_matrix_of_every_iterate(scene320, oracle):
+    """DVO_FLAG_NORMAL_MATRIX: the fused launch also keeps H = sum w J^T J (the 21 of the "21+6" accumulators) per
+    iterate, in double; poses and energies are those of the plain launch"""
+    from rgbd_odometry_amd import DvoContext
+    from rgbd_odometry_amd.capi import DVO_FLAG_NORMAL_MATRIX
+    sc, lv = scene320
+    iters = [6, 0, 5, 4]
+    for compact in (False, True):
+        with DvoContext(1) as ctx:
+            ctx.set_intrinsics(*sc.intrinsics)
+            for l, L in enumerate(lv):
+                if compact:
+                    S = sc.levels[l]
+                    ctx.set_ref_level_from_images(l, S.ref_edge, S.ref_depth, S.rows, S.cols)
+                else:
+                    ctx.set_ref_level(l, L["xyz"])
+                ctx.set_now_level(l, L["dt"], L["gx"], L["gy"], L["rows"], L["cols"])
+            R, t = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)), flags=DVO_FLAG_NORMAL_MATRIX)
+            Rp, tp = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
+            assert np.array_equal(R, Rp) and np.array_equal(t, tp)
+            ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)), flags=DVO_FLAG_NORMAL_MATRIX)
+            Rc, tc = np.eye(3), np.zeros(3)
+            for l in (3, 2, 0):
+                L = lv[l]
+                r = oracle.run_iterations(l, iters[l], L["xyz"], L["dt"], L["gx"], L["gy"], L["rows"], L["cols"],
+                                          sc.intrinsics, Rc, tc, trace=True)
+                for itr, tr in enumerate(r["trace"]):
+                    H = ctx.level_normal_matrix(0, l, itr)
+                    want = np.zeros((6, 6)); k = 0
+                    for i in range(6):
+                        for j in range(i, 6):
+                            want[i, j] = want[j, i] = tr["H"][k]; k += 1
+                    np.testing.assert_allclose(H, want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+                Hb = ctx.level_normal_matrix(0, l)          # best iterate
+                assert np.array_equal(Hb, ctx.level_normal_matrix(0, l, r["best_idx"]))
+                assert np.all(np.linalg.eigvalsh(Hb) > -1e-9 * np.abs(Hb).max())      # positive semi-definite
+                Rc, tc = r["R"], r["t"]
 
 
 def test_device_se3_matches_oracle(ctx320, oracle):
