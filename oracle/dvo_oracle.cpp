@@ -730,7 +730,11 @@ int dvo_oracle_run_iterations(const dvo_oracle_params *prm_in, int level, int ma
  * cv::distanceTransform(CV_DIST_L2, CV_DIST_MASK_PRECISE), :1768-1771).  OpenCV 2.4 is not available here
  * (PARITY UNPINNED for this step as well); the definition restated is: exact Euclidean distance
  * (Felzenszwalb-Huttenlocher lower envelopes, as DIST_MASK_PRECISE does), narrowed to float;
- * cv::normalize(0,255,NORM_MINMAX) as dst = (src-min)*(255/(max-min)) evaluated in double (:1774);
+ * cv::normalize(src, dst, 0, 255, NORM_MINMAX) (:1774) with OpenCV 2.4's own arithmetic (core/src/convert.cpp): in double
+ *   scale = (255 - 0) * (smax - smin > DBL_EPSILON ? 1./(smax - smin) : 0),  shift = 0 - smin*scale
+ * (smin, smax from minMaxLoc, doubles), then Mat::convertTo(CV_32F, scale, shift), whose 32F -> 32F kernel cvtScale32f
+ * (DEF_CVT_SCALE_FUNC(32f, float, float, float)) works in FLOAT: dst = src*(float)scale + (float)shift, one rounding per
+ * operation.  (Round 1 evaluated (src-min)*(255/(max-min)) in double: differs in the last bit on many pixels.)
  * filter2D with [-.5 0 .5] kernels and the default BORDER_REFLECT_101 (:1077-1090). */
 static void fh_1d(const double *f, int n, double *d, int *v, double *z) {
     const double INF = 1e20;
@@ -777,8 +781,11 @@ void dvo_oracle_now_level_from_edges(const unsigned char *edge, int rows, int co
         if (i == 0 || dt[i] < mn) mn = dt[i];
         if (i == 0 || dt[i] > mx) mx = dt[i];
     }
-    const double scale = (mx > mn) ? 255.0 / ((double)mx - (double)mn) : 0.0;
-    for (size_t i = 0; i < n; i++) dt[i] = (float)(((double)dt[i] - (double)mn) * scale);       /* :1774 */
+    const double smin = (double)mn, smax = (double)mx;                                           /* minMaxLoc */
+    const double scale = (255.0 - 0.0) * ((smax - smin > 2.2204460492503131e-16) ? 1. / (smax - smin) : 0.);
+    const double shift = 0.0 - smin * scale;
+    const float scale_f = (float)scale, shift_f = (float)shift;                                 /* cvtScale32f: float working type */
+    for (size_t i = 0; i < n; i++) dt[i] = dt[i] * scale_f + shift_f;                           /* :1774 */
     auto r101 = [](int i, int len) { if (len == 1) return 0; if (i < 0) return -i; if (i >= len) return 2 * len - 2 - i; return i; };
     for (int x = 0; x < cols; x++)
         for (int y = 0; y < rows; y++) {

@@ -147,7 +147,13 @@ int dvo_oracle_align_pyramid(const dvo_oracle_params *prm, int n_levels, const i
 
 /* Now-frame preprocessing after Canny (computeDistTransfrmOfNow :1768-1795, imageGradient :1063-1098):
  * edge mask (uint8, >0 = edge, column-major) -> exact EDT -> min-max normalise to [0,255] -> central
- * differences with reflect-101 border.  OpenCV 2.4 semantics restated, unpinned (see the .cpp). */
+ * differences with reflect-101 border.  OpenCV 2.4 semantics restated, unpinned (see the .cpp).
+ * DECISION (round 2) on cv::normalize(src, dst, 0, 255, NORM_MINMAX) for a CV_32F image: OpenCV 2.4 computes
+ * scale = 255*(1./(smax-smin)) and shift = 0 - smin*scale in double (cv::normalize, core/src/convert.cpp) and hands
+ * them to Mat::convertTo, whose 32F -> 32F kernel (cvtScale32f = cvtScale_<float, float, float>) evaluates
+ * dst = src*(float)scale + (float)shift in FLOAT.  The oracle, the GPU frame path and the synthetic scene generator
+ * all use that form; the round-1 double evaluation (src-min)*(255/(max-min)) differed by one ulp on many pixels.
+ * scipy.ndimage.distance_transform_edt cross-checks the EDT itself (tests/test_oracle_pins.py). */
 void dvo_oracle_now_level_from_edges(const unsigned char *edge, int rows, int cols,
                                      float *dt, float *gx, float *gy);
 

@@ -527,7 +527,11 @@ dt_normalize_gradient_pack_kernel(const int *__restrict__ d2, int rows, int cols
     const int INF = DVO_EDT_INF(rows, cols);
     const int m2 = s_max;
     const float mxf = (float)sqrt((double)m2), mnf = 0.0f;
-    const double scale = (mxf > mnf && m2 < INF * INF) ? 255.0 / ((double)mxf - (double)mnf) : 0.0;
+    /* cv::normalize(0, 255, NORM_MINMAX) with OpenCV 2.4's arithmetic: scale and shift in double, then convertTo's 32F -> 32F
+     * kernel (cvtScale32f, core/src/convert.cpp) in FLOAT: dst = src*(float)scale + (float)shift */
+    const double smin = (double)mnf, smax = (double)mxf;
+    const double scale_d = (m2 < INF * INF) ? 255.0 * ((smax - smin > 2.2204460492503131e-16) ? 1. / (smax - smin) : 0.) : 0.;
+    const float scale_f = (float)scale_d, shift_f = (float)(0.0 - smin * scale_d);
     const int y0 = (blockIdx.x % tiles_y) * NP_TY, x0 = (blockIdx.x / tiles_y) * NP_TX;
     for (int idx = threadIdx.x; idx < SW * SH; idx += 256) {
         const int lx = idx / SH, ly = idx - lx * SH;
@@ -536,7 +540,7 @@ dt_normalize_gradient_pack_kernel(const int *__restrict__ d2, int rows, int cols
         if (yy <= rows && xx <= cols) {                      /* one pixel beyond the image is the reflected neighbour */
             yy = reflect101(yy, rows); xx = reflect101(xx, cols);
             const float raw = (float)sqrt((double)d2[(size_t)xx * rows + yy]);
-            v = (float)(((double)raw - (double)mnf) * scale);
+            v = raw * scale_f + shift_f;
         }
         sn[idx] = v;
     }

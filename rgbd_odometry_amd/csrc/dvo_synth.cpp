@@ -229,8 +229,11 @@ dvo_synth_scene *dvo_synth_create(int W, int H, int n_levels, uint64_t seed) {
             if (L.now_dt[i] < mn) mn = L.now_dt[i];
             if (L.now_dt[i] > mx) mx = L.now_dt[i];
         }
-        const double scale = (mx > mn) ? 255.0 / ((double)mx - (double)mn) : 0.0;
-        for (size_t i = 0; i < n; i++) L.now_dt[i] = (float)(((double)L.now_dt[i] - (double)mn) * scale);
+        /* cv::normalize(0,255,NORM_MINMAX) as OpenCV 2.4 evaluates it: scale, shift in double, the conversion in float */
+        const double smin = (double)mn, smax = (double)mx;
+        const double scale = 255.0 * ((smax - smin > 2.2204460492503131e-16) ? 1. / (smax - smin) : 0.);
+        const float scale_f = (float)scale, shift_f = (float)(0.0 - smin * scale);
+        for (size_t i = 0; i < n; i++) L.now_dt[i] = L.now_dt[i] * scale_f + shift_f;
         /* gradients: kernels [-.5 0 .5], BORDER_REFLECT_101 (SolveDVO.cpp:1077-1090) */
         L.now_gx.resize(n);
         L.now_gy.resize(n);

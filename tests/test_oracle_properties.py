@@ -207,10 +207,16 @@ def test_now_level_from_edges_brute_force(oracle):
     Y, X = np.mgrid[0:rows, 0:cols]
     d2 = ((Y[..., None] - ys) ** 2 + (X[..., None] - xs) ** 2).min(axis=-1)
     raw = np.sqrt(d2.astype(np.float64)).astype(np.float32)
-    want = ((raw.astype(np.float64) - 0.0) * (255.0 / float(raw.max()))).astype(np.float32)
+    # cv::normalize(0,255,NORM_MINMAX), :1774, in OpenCV 2.4's arithmetic: scale in double, the 32F->32F conversion in float
+    scale_f = np.float32(255.0 * (1.0 / float(raw.max())))
+    want = raw * scale_f + np.float32(0.0)
     got = dt.reshape(rows, cols, order="F")
+    assert got.dtype == np.float32 and want.dtype == np.float32
     assert np.array_equal(got, want)
-    assert got.min() == 0.0 and got.max() == 255.0                       # cv::normalize(0,255,NORM_MINMAX), :1774
+    assert got.min() == 0.0 and abs(float(got.max()) - 255.0) <= 255.0 * 2.0 ** -23
+    # ... which is NOT the double-precision evaluation (src-min)*(255/(max-min)) on every pixel
+    dbl = ((raw.astype(np.float64) - 0.0) * (255.0 / float(raw.max()))).astype(np.float32)
+    assert np.abs(got - dbl).max() <= 255.0 * 2.0 ** -22
     # central differences with reflect-101 (:1077-1090): zero at the first/last column/row
     GX = gx.reshape(rows, cols, order="F")
     assert np.all(GX[:, 0] == 0) and np.all(GX[:, -1] == 0)
