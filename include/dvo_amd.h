@@ -226,6 +226,21 @@ int  dvo_iter_end(dvo_ctx *ctx, int pair, int level, double *R, double *t, float
  * energies / best index / ratio afterwards through dvo_get_level_report. */
 int  dvo_align_pyramid_wide(dvo_ctx *ctx, int pair, int n_levels, const int *iters, double *R, double *t);
 
+/* ---- tiled mode from C: one large frame sharded over the GPUs of a node (BASELINE configs[4]) ----------
+ * The same loop with the all-reduce done by RCCL over xGMI and everything enqueued from C on the context stream -- what a
+ * C++ node calls (one process or thread per GPU, each with its own context and its rank's ncclComm_t):
+ *     dvo_tiled_attach(ctx, comm, rank, world, NULL);           once
+ *     dvo_align_pyramid_tiled(ctx, 0, n_levels, iters, R, t);   per frame pair; every rank gets the same pose
+ * Each rank must hold the SAME inputs for `pair` (full reference lists and now pyramid); rank r processes the contiguous
+ * index range r of every level's list, the 32 sums are all-reduced (ncclDouble, ncclSum) per iteration, and every rank
+ * executes the identical update.  nccl_comm: the caller's ncclComm_t.  rccl_library: path of the RCCL library the
+ * communicator was created with; NULL = the RCCL already loaded in the process, else librccl.so.1.  libdvo_amd.so has no
+ * link-time dependency on RCCL.  Replaces the reference seam include/SolveDVO.h:228-230 for frames one GPU cannot hold
+ * or does not finish fast enough (break-even: DESIGN.md section 5). */
+int  dvo_tiled_attach(dvo_ctx *ctx, void *nccl_comm, int rank, int world, const char *rccl_library);
+int  dvo_tiled_detach(dvo_ctx *ctx);
+int  dvo_align_pyramid_tiled(dvo_ctx *ctx, int pair, int n_levels, const int *iters, double *R, double *t);
+
 /* ---- inspection (used by the parity tests) ---------------------------------
  * One evaluation of computeJacobianOfNowFrame + getReprojectedEpsilons at the
  * given pose (cast to float exactly as SolveDVO.cpp:673-674).  Host outputs, any

@@ -31,7 +31,7 @@ C_ABI_SYMBOLS = [
     "dvo_get_final_outputs", "dvo_get_level_normal_matrix", "dvo_eval_points", "dvo_accumulate", "dvo_device_se3_exp",
     "dvo_device_se3_log", "dvo_device_rotationize", "dvo_algorithmic_bytes", "dvo_point_iterations",
     "dvo_debug_stamps", "dvo_get_level_texel_mode", "dvo_replicate_pairs", "dvo_set_now_level_from_edges", "dvo_get_now_level", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
-    "dvo_align_pyramid_wide",
+    "dvo_align_pyramid_wide", "dvo_tiled_attach", "dvo_tiled_detach", "dvo_align_pyramid_tiled",
     "dvo_get_ref_level", "dvo_frames_reserve", "dvo_frames_upload_pyramids", "dvo_frames_upload_cameras", "dvo_frames_as_now",
     "dvo_frames_as_ref", "dvo_frame_get_level", "dvo_frames_num_levels",
 ]
@@ -58,6 +58,47 @@ class DvoParams(C.Structure):
         ("lds_point_bytes", C.c_int), ("debug_alias_mod", C.c_int),
         ("canny_threshold1", C.c_int), ("canny_threshold2", C.c_int), ("reserved", C.c_int * 1),
     ]
+
+
+class RcclComm:
+    """A raw RCCL communicator made through ctypes (tests / tools of the C-driven tiled mode; a C++ node creates its
+    ncclComm_t itself).  unique_id: 128 bytes from RcclComm.unique_id() of rank 0, distributed by the launcher."""
+    RCCL = "/opt/rocm/lib/librccl.so.1"
+
+    class _Id(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    @classmethod
+    def _lib(cls):
+        import torch  # noqa: F401  (one HIP runtime per process, see load_library)
+        lib = C.CDLL(cls.RCCL, mode=C.RTLD_GLOBAL)
+        lib.ncclGetUniqueId.argtypes = [C.POINTER(cls._Id)]
+        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, cls._Id, C.c_int]
+        lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        return lib
+
+    @classmethod
+    def unique_id(cls) -> bytes:
+        uid = cls._Id()
+        rc = cls._lib().ncclGetUniqueId(C.byref(uid))
+        if rc != 0:
+            raise RuntimeError("ncclGetUniqueId failed: %d" % rc)
+        return bytes(uid)
+
+    def __init__(self, unique_id: bytes, rank: int, world: int):
+        self.lib = self._lib()
+        uid = self._Id.from_buffer_copy(unique_id)
+        self.comm = C.c_void_p()
+        rc = self.lib.ncclCommInitRank(C.byref(self.comm), world, uid, rank)
+        if rc != 0:
+            raise RuntimeError("ncclCommInitRank failed: %d" % rc)
+        self.comm = self.comm.value
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if self.comm:
+            self.lib.ncclCommDestroy(C.c_void_p(self.comm))
+            self.comm = None
 
 
 class DvoError(RuntimeError):
@@ -158,6 +199,9 @@ def load_library() -> C.CDLL:
         "dvo_iter_update": [vp, i, i, i, i, vp],
         "dvo_iter_end": [vp, i, i, vp, vp, vp, ip, fp],
         "dvo_align_pyramid_wide": [vp, i, i, ip, vp, vp],
+        "dvo_tiled_attach": [vp, vp, i, i, C.c_char_p],
+        "dvo_tiled_detach": [vp],
+        "dvo_align_pyramid_tiled": [vp, i, i, ip, vp, vp],
         "dvo_get_ref_level": [vp, i, i, vp, i, ip],
         "dvo_frames_reserve": [vp, i],
         "dvo_frames_upload_pyramids": [vp, i, i, i, C.POINTER(DvoImage), C.POINTER(DvoImage), i, i],
@@ -492,6 +536,22 @@ class DvoContext:
         R = np.array(R, dtype=np.float64, order="F").copy(order="F")
         t = np.array(t, dtype=np.float64).copy()
         self._chk(self.lib.dvo_align_pyramid_wide(self._h, pair, len(iters), _iters(iters), _ptr(R), _ptr(t)))
+        return R, t
+
+    # -- tiled mode driven from C (RCCL) ---------------------------------------
+    def tiled_attach(self, comm, rank: int, world: int, rccl_library: Optional[str] = None):
+        """comm: the rank's ncclComm_t (integer / c_void_p), e.g. RcclComm(...).comm"""
+        lib = rccl_library.encode() if rccl_library else None
+        self._chk(self.lib.dvo_tiled_attach(self._h, C.c_void_p(int(comm)), rank, world, lib))
+
+    def tiled_detach(self):
+        self._chk(self.lib.dvo_tiled_detach(self._h))
+
+    def align_pyramid_tiled(self, iters: Sequence[int], R, t, pair: int = 0):
+        """dvo_align_pyramid_tiled: this rank's share of every iteration + ncclAllReduce of the 32 sums + identical update"""
+        R = np.array(R, dtype=np.float64, order="F").copy(order="F")
+        t = np.array(t, dtype=np.float64).copy()
+        self._chk(self.lib.dvo_align_pyramid_tiled(self._h, pair, len(iters), _iters(iters), _ptr(R), _ptr(t)))
         return R, t
 
     # -- inspection -----------------------------------------------------------

@@ -101,7 +101,7 @@ int ensure_texels(dvo_ctx *c, int level, int rows, int cols) {
 
 using namespace dvo_host;
 
-namespace {
+namespace dvo_host {       /* shared with dvo_capi_tiled.cpp (declared in dvo_ctx.h) */
 
 LevelSlab slab_of(const dvo_ctx *c, int level) {
     const Level &L = c->lv[level];
@@ -280,7 +280,7 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
     return DVO_OK;
 }
 
-}  // namespace
+}  // namespace dvo_host
 
 extern "C" {
 
@@ -377,6 +377,7 @@ int dvo_destroy(dvo_ctx *c) {
         if (c->lv[l].cpts) (void)hipFree(c->lv[l].cpts);
         if (c->lv[l].dN) (void)hipFree(c->lv[l].dN);
     }
+    tiled_forget(c);
     for (int l = 0; l < DVO_LEVELS; l++) {
         FrameLevel &F = c->fs.lv[l];
         void *fp[] = {F.grey, F.edge, F.depth};

@@ -1,0 +1,158 @@
+/*
+ * dvo_capi_tiled.cpp -- the tiled mode of SURVEY.md 8(e) behind the C ABI: ONE large frame whose reference point lists are
+ * sharded over the GPUs of a node, the per-iteration all-reduce of the 32 accumulator doubles done by RCCL over xGMI, the
+ * whole level schedule of SolveDVO::loop (reference src/SolveDVO.cpp:2097-2104) enqueued from C on the context stream:
+ *
+ *     per iteration:  accumulate(own point range) -> reduce partials -> ncclAllReduce(32, ncclDouble, ncclSum)
+ *                     -> the reference's 6-DoF update (:724-920), executed identically on every rank
+ *
+ * No Python in the loop (rgbd_odometry_amd/distributed.py::TiledAligner is the torch.distributed twin used by the CPU/gloo
+ * tests).  RCCL is NOT a link-time dependency of libdvo_amd.so: the communicator is created by the caller (a C++ ROS node
+ * links RCCL itself), and ncclAllReduce is resolved when the communicator is attached -- from the library the caller names,
+ * else from what is already loaded in the process, else from librccl.so.1.
+ *
+ * Every rank holds the full now pyramid (replicated) and the full point lists; rank r works on the contiguous index range
+ * shard(N_level, r, world) (= a vertical strip of the reference image, :237-239).  All ranks receive the same reduced
+ * bits from the all-reduce, hence take identical pose steps; best-iterate bookkeeping is replicated, not communicated.
+ */
+#include "dvo_ctx.h"
+
+#include <dlfcn.h>
+
+using namespace dvo;
+using namespace dvo_host;
+
+namespace {
+
+enum { kNcclSum = 0, kNcclDouble = 8 };     /* rccl.h: ncclRedOp_t ncclSum = 0, ncclDataType_t ncclDouble = ncclFloat64 = 8 */
+typedef int (*nccl_allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef const char *(*nccl_errstr_fn)(int);
+
+struct Tiled {
+    void *comm = nullptr;
+    int rank = 0, world = 1;
+    nccl_allreduce_fn all_reduce = nullptr;
+    nccl_errstr_fn errstr = nullptr;
+    void *lib = nullptr;            /* dlopen handle we own (or nullptr) */
+    double *d_acc = nullptr;        /* 32 doubles on the device: the all-reduce buffer */
+};
+
+/* one record per context, kept outside struct dvo_ctx (only this file knows RCCL) */
+struct Entry { dvo_ctx *ctx; Tiled t; };
+std::vector<Entry> &registry() { static std::vector<Entry> r; return r; }
+Tiled *find(dvo_ctx *c) {
+    for (auto &e : registry()) if (e.ctx == c) return &e.t;
+    return nullptr;
+}
+
+void shard(int n, int rank, int world, int &first, int &count) {      /* same decomposition as distributed.py::shard_range */
+    const int base = n / world, rem = n % world;
+    count = base + (rank < rem ? 1 : 0);
+    first = rank * base + (rank < rem ? rank : rem);
+}
+
+}  // namespace
+
+namespace dvo_host {
+void tiled_forget(dvo_ctx *c) {           /* called by dvo_destroy */
+    auto &r = registry();
+    for (size_t i = 0; i < r.size(); i++)
+        if (r[i].ctx == c) {
+            if (r[i].t.d_acc) (void)hipFree(r[i].t.d_acc);
+            if (r[i].t.lib) dlclose(r[i].t.lib);
+            r.erase(r.begin() + i);
+            return;
+        }
+}
+}  // namespace dvo_host
+
+extern "C" {
+
+int dvo_tiled_attach(dvo_ctx *c, void *nccl_comm, int rank, int world, const char *rccl_library) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!nccl_comm || world < 1 || rank < 0 || rank >= world) return fail(c, DVO_ERR_INVALID, "bad communicator / rank / world size");
+    tiled_forget(c);
+    Tiled t;
+    t.comm = nccl_comm; t.rank = rank; t.world = world;
+    void *sym = nullptr;
+    if (rccl_library && *rccl_library) {
+        t.lib = dlopen(rccl_library, RTLD_NOW | RTLD_GLOBAL);
+        if (!t.lib) return fail(c, DVO_ERR_INVALID, std::string("cannot load ") + rccl_library + ": " + dlerror());
+        sym = dlsym(t.lib, "ncclAllReduce");
+    } else {
+        sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");             /* the RCCL the caller's process already uses */
+        if (!sym) {
+            t.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (t.lib) sym = dlsym(t.lib, "ncclAllReduce");
+        }
+    }
+    if (!sym) {
+        if (t.lib) dlclose(t.lib);
+        return fail(c, DVO_ERR_INVALID, "ncclAllReduce not found: link/load RCCL (librccl.so.1) or pass its path");
+    }
+    t.all_reduce = (nccl_allreduce_fn)sym;
+    t.errstr = (nccl_errstr_fn)(t.lib ? dlsym(t.lib, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
+    HIPCHK(c, hipMalloc((void **)&t.d_acc, sizeof(double) * DVO_NACC_PAD));
+    registry().push_back(Entry{c, t});
+    return DVO_OK;
+}
+
+int dvo_tiled_detach(dvo_ctx *c) {
+    if (!c) return DVO_ERR_INVALID;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    tiled_forget(c);
+    return DVO_OK;
+}
+
+int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters, double *R, double *t) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair) || !R || !t) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    Tiled *T = find(c);
+    if (!T) return fail(c, DVO_ERR_STATE, "no communicator attached (dvo_tiled_attach)");
+    Schedule sc;
+    int rc = dvo_host::build_schedule(c, n_levels, iters, 0, sc);
+    if (rc) return rc;
+    for (int l = 0; l < n_levels; l++)
+        if (sc.iters[l] > 0 && (rc = dvo_host::check_ready(c, pair, l))) return rc;
+    if ((rc = dvo_host::ensure_outputs(c, sc))) return rc;
+    if (!c->d_states) {
+        HIPCHK(c, hipMalloc((void **)&c->d_states, pose_state_bytes() * c->n_pairs));
+        c->iter_max.assign(c->n_pairs, 0);
+    }
+    if (!c->h_pose) HIPCHK(c, hipHostMalloc((void **)&c->h_pose, sizeof(double) * 12, hipHostMallocDefault));
+    double *h = c->h_pose;
+    std::memcpy(h, R, sizeof(double) * 9);
+    std::memcpy(h + 9, t, sizeof(double) * 3);
+    double *d_pose = c->d_poses + (size_t)12 * pair;
+    void *state = c->d_states + pose_state_bytes() * pair;
+    double *partials = c->d_scratch;
+    HIPCHK(c, hipMemcpyAsync(d_pose, h, sizeof(double) * 12, hipMemcpyHostToDevice, c->stream));
+    for (int l = n_levels - 1; l >= 0; --l) {                       /* :2097 */
+        if (sc.iters[l] <= 0) continue;                             /* :2099 */
+        const int N = c->lv[l].hN[pair];
+        int first = 0, count = 0;
+        shard(N, T->rank, T->world, first, count);
+        float *energy = c->d_energy + (size_t)pair * sc.e_stride + sc.e_off[l];
+        HIPCHK(c, launch_iter_begin(state, d_pose, energy, sc.iters[l], c->stream));
+        const int nb = accumulate_blocks_for(count);
+        const LevelSlab sl = dvo_host::slab_of(c, l);
+        for (int itr = 0; itr < sc.iters[l]; itr++) {
+            HIPCHK(c, launch_iter_accumulate(sl, pair, l, c->K, state, first, count, partials, nb, T->d_acc, c->stream));
+            const int nrc = T->all_reduce(T->d_acc, T->d_acc, DVO_NACC_PAD, kNcclDouble, kNcclSum, T->comm, c->stream);
+            if (nrc != 0)
+                return fail(c, DVO_ERR_HIP, std::string("ncclAllReduce: ") + (T->errstr ? T->errstr(nrc) : "error " + std::to_string(nrc)));
+            HIPCHK(c, launch_iter_update(state, c->dprm, itr, N, T->d_acc, energy, c->stream));
+        }
+        HIPCHK(c, launch_iter_end(state, d_pose, c->d_best + pair * DVO_LEVELS + l, c->d_ratio + pair * DVO_LEVELS + l, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(h, d_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(R, h, sizeof(double) * 9);
+    std::memcpy(t, h + 9, sizeof(double) * 3);
+    dvo_host::stamp_outputs(c, sc, pair, 1);
+    c->sched = sc;
+    c->have_sched = true;
+    return DVO_OK;
+}
+
+}  // extern "C"

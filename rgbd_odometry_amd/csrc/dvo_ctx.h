@@ -122,6 +122,13 @@ bool pair_ok(const dvo_ctx *c, int pair);
 bool level_ok(int level);
 int ensure_points(dvo_ctx *c, int level, int N);                 /* room for N points per pair at `level` (keeps contents) */
 int ensure_texels(dvo_ctx *c, int level, int rows, int cols);
+/* schedule / readiness / output bookkeeping of the align entry points (dvo_capi.cpp) */
+dvo::LevelSlab slab_of(const dvo_ctx *c, int level);
+int check_ready(dvo_ctx *c, int pair, int level);
+int build_schedule(dvo_ctx *c, int n_levels, const int *iters, int flags, dvo::Schedule &sc);
+int ensure_outputs(dvo_ctx *c, const dvo::Schedule &sc);
+void stamp_outputs(dvo_ctx *c, const dvo::Schedule &sc, int first, int n);
+void tiled_forget(dvo_ctx *c);          /* dvo_capi_tiled.cpp: drop the RCCL attachment of a context */
 
 }  // namespace dvo_host
 #endif
