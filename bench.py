@@ -46,7 +46,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="frame pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="frame pairs per GPU per step (weak scaling: fixed per GPU)")
+    ap.add_argument("--total-pairs", type=int, default=0,
+                    help="strong scaling: this many pairs IN TOTAL per step, split over the GPUs by shard_range "
+                         "(BASELINE configs[3]: --total-pairs 256); overrides --batch")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--levels", type=int, default=4)
@@ -61,6 +64,7 @@ def parse_args():
     ap.add_argument("--inflight", type=int, default=0, help="points in flight per lane (1/2/4; 0 = default)")
     ap.add_argument("--lds-point-bytes", type=int, default=0, help="LDS bytes per workgroup for resident points (0 auto, <0 none)")
     ap.add_argument("--variant", type=int, default=0, help="engine_variant (0 auto, 1 = one-point-per-lane fused kernel)")
+    ap.add_argument("--team", type=int, default=0, help="team_size: workgroups per pair for small batches (0 auto, 1 off)")
     ap.add_argument("--debug-alias", type=int, default=0, help="diagnostics: pair p reads data of pair p %% N")
     ap.add_argument("--no-frames-leg", action="store_true",
                     help="skip the extra (never `value`) measurement of camera frames in host memory -> poses out")
@@ -195,12 +199,18 @@ def main():
 
     from rgbd_odometry_amd import DvoContext
     from rgbd_odometry_amd.capi import DVO_FLAG_FINAL_OUTPUTS, DVO_FLAG_IDENTITY_START, DVO_FLAG_NORMAL_MATRIX
+    from rgbd_odometry_amd.distributed import shard_range
+    total_pairs = args.total_pairs
+    if total_pairs > 0:
+        if total_pairs < world:
+            raise SystemExit("--total-pairs must be at least the number of GPUs")
+        args.batch = shard_range(total_pairs, rank, world)[1]      # this rank's contiguous block of pairs
 
     iters = [args.iters] * args.levels
     flags = DVO_FLAG_IDENTITY_START | (0 if args.no_final_outputs else DVO_FLAG_FINAL_OUTPUTS) | (DVO_FLAG_NORMAL_MATRIX if args.normal_matrix else 0)
     ctx = DvoContext(args.batch, block_threads=args.block, debug_alias_mod=args.debug_alias,
                      points_in_flight=args.inflight, lds_point_bytes=args.lds_point_bytes,
-                     engine_variant=args.variant)
+                     engine_variant=args.variant, team_size=args.team)
     scenes = build_batch(ctx, args, rank)
     stream = torch.cuda.Stream()
     ctx.set_stream(stream.cuda_stream)
@@ -230,6 +240,8 @@ def main():
     elapsed_local = time.perf_counter() - t0
     from rgbd_odometry_amd.distributed import whole_job_throughput
     value, elapsed = whole_job_throughput(args.batch, args.steps, elapsed_local, device="cuda")   # MAX over ranks
+    if total_pairs > 0:
+        value = total_pairs * args.steps / elapsed            # the blocks differ by at most one pair: count the real total
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
     bytes_per_launch = sum(ctx.algorithmic_bytes(iters, pair=p, flags=flags & DVO_FLAG_FINAL_OUTPUTS)
@@ -242,7 +254,7 @@ def main():
         out = {
             "metric": "frame-pair aligns/sec (%dx%d, %d-lvl pyr)" % (args.width, args.height, args.levels),
             "value": value, "unit": "aligns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if total_pairs > 0 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": "%dx%d edge-alignment, %d-level pyramid, %d iters/level, batch of %d independent "
@@ -250,6 +262,7 @@ def main():
                             "sub-gradient policy of SolveDVO::runIterations" %
                             (args.width, args.height, args.levels, args.iters, args.batch, len(scenes)),
                 "pairs_per_gpu": args.batch, "iters_per_level": iters,
+                **({"total_pairs": total_pairs} if total_pairs > 0 else {}),
                 "final_outputs": not args.no_final_outputs,
                 "block_threads": args.block or "auto (256 for short point lists in large batches, 1024 for lists over 620 KB, else 512)",
                 "points_in_flight": args.inflight or 1,
@@ -272,7 +285,7 @@ def main():
         # of the kernel sources, and a stale record is reported as null with the reason instead of being pasted in
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         key = "%dx%dx%dx%d_b%d" % (args.width, args.height, args.levels, args.iters, args.batch)
-        default_knobs = not (args.normal_matrix or args.variant or args.block or args.inflight or args.lds_point_bytes or args.debug_alias or args.no_final_outputs)
+        default_knobs = not (args.team or args.normal_matrix or args.variant or args.block or args.inflight or args.lds_point_bytes or args.debug_alias or args.no_final_outputs)
         reason = None
         try:
             rec = json.load(open(pmc)).get(key)

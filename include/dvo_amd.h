@@ -91,7 +91,10 @@ typedef struct dvo_params {
                                   (shrinks the HBM working set without changing the arithmetic); 0 = off */
     int    canny_threshold1;   /* cv::Canny(img, edge, 150, 100, 3, true): the two thresholds (order-free, the detector */
     int    canny_threshold2;   /* swaps them), SolveDVO.cpp:1704,1764; used by the dvo_frame* entry points; 0,0 = 150,100 */
-    int    reserved[1];
+    int    team_size;          /* engine tuning: workgroups per frame pair of the fused launch when there are fewer pairs than compute
+                                  units (each takes a contiguous share of every level's points; sums exchanged through L2 once per
+                                  iteration, identical update on every member).  0 = auto (largest power of two that fits the GPU,
+                                  at most 16), 1 = off, k = force k */
 } dvo_params;
 
 typedef struct dvo_ctx dvo_ctx;

@@ -56,7 +56,7 @@ class DvoParams(C.Structure):
         ("enable_rotationize", C.c_int), ("enable_l2_reg", C.c_int), ("interpolate_dt", C.c_int),
         ("block_threads", C.c_int), ("points_in_flight", C.c_int), ("engine_variant", C.c_int),
         ("lds_point_bytes", C.c_int), ("debug_alias_mod", C.c_int),
-        ("canny_threshold1", C.c_int), ("canny_threshold2", C.c_int), ("reserved", C.c_int * 1),
+        ("canny_threshold1", C.c_int), ("canny_threshold2", C.c_int), ("team_size", C.c_int),
     ]
 
 

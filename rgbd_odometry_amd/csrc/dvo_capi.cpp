@@ -198,6 +198,9 @@ Outputs outputs_of(const dvo_ctx *c) {
     o.dbg = c->d_dbg;
     o.tex_mode = c->d_tex_mode;
     o.H = c->d_H;
+    o.team_buf = c->d_team_buf;
+    o.team_cnt = c->d_team_cnt;
+    o.team_err = reinterpret_cast<int *>(c->d_team_cnt ? c->d_team_cnt + c->n_pairs : nullptr);
     return o;
 }
 
@@ -267,6 +270,37 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
     }
     int u = c->prm.points_in_flight;
     if (u != 1 && u != 2 && u != 4) u = 1;
+    /* team mode (packed kernel only): with fewer pairs than half the compute units, G workgroups share each pair so that
+     * the launch fills the GPU -- G = the largest power of two with 8*ceil(pairs/8)*G <= CUs (at most 16), all of them
+     * resident at once (one 512-thread workgroup per CU).  dvo_params.team_size: 0 = auto, 1 = off, k = force k. */
+    sc.team = 1;
+    sc.n_pairs_launch = n_pairs;
+    c->team_used = false;
+    if (sc.compact && c->prm.engine_variant != 1 && !(sc.flags & DVO_FLAG_NORMAL_MATRIX) && block == 512 && c->prm.team_size != 1) {
+        const int slots8 = 8 * ((n_pairs + 7) / 8);
+        /* a member needs ~1000 points of the finest level to pay for the exchange (measured: 640x480, 14.8 k points: 8 members
+         * 0.237 ms, 4: 0.254, 16: 0.251, none: 0.395; 320x240 x 50 iterations, 4.2 k points: no team size beats none) */
+        int n_fine = 0;
+        for (int p = first_pair; p < first_pair + n_pairs; p++) n_fine = std::max(n_fine, c->lv[sc.last_level].hN[p]);
+        const int g_cap = (n_fine >= 65536) ? 16 : 8;
+        int g = 1;
+        while (g * 2 <= g_cap && slots8 * g * 2 <= c->n_cu && n_fine >= 1024 * g * 2) g *= 2;
+        if (c->prm.team_size > 1) {
+            g = c->prm.team_size;
+            if (g > 16 || slots8 * g > c->n_cu)
+                return fail(c, DVO_ERR_INVALID, "team_size: the launch would need more workgroups than compute units (members must be co-resident)");
+        }
+        if (g > 1) {
+            if (!c->d_team_buf) {
+                HIPCHK(c, hipMalloc((void **)&c->d_team_buf, 16 * 2 * 16 * 8 * (size_t)c->n_pairs));     /* 16-byte records */
+                HIPCHK(c, hipMalloc((void **)&c->d_team_cnt, sizeof(unsigned) * ((size_t)c->n_pairs + 1)));
+            }
+            HIPCHK(c, hipMemsetAsync(c->d_team_cnt, 0, sizeof(unsigned) * ((size_t)c->n_pairs + 1), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_team_buf, 0, 16 * 2 * 16 * 8 * (size_t)n_pairs, c->stream));       /* tags of an earlier launch */
+            sc.team = g;
+            c->team_used = true;
+        }
+    }
     /* engine_variant: 0 = auto (packed two-points-per-lane kernel whenever every list is compact), 1 = always the
      * one-point-per-lane kernel of dvo_kernels.hip (A/B measurements, parity tests of both) */
     if (sc.compact && c->prm.engine_variant != 1 && !(sc.flags & DVO_FLAG_NORMAL_MATRIX))
@@ -402,7 +436,7 @@ int dvo_destroy(dvo_ctx *c) {
     }
     void *ptrs[] = {c->staging, c->d_poses, c->d_energy, c->d_best, c->d_ratio, c->d_final_eps,
                     c->d_final_reproj, c->d_final_N, c->d_scratch, c->d_colcounts, c->d_dbg,
-                    c->d_states, c->d_iter_energy, c->d_tex_mode, c->d_H};
+                    c->d_states, c->d_iter_energy, c->d_tex_mode, c->d_H, c->d_team_buf, c->d_team_cnt};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -657,7 +691,13 @@ int dvo_get_poses(dvo_ctx *c, int first_pair, int n_pairs, double *R, double *t)
     std::vector<double> h((size_t)12 * n_pairs);
     HIPCHK(c, hipMemcpyAsync(h.data(), c->d_poses + (size_t)12 * first_pair, sizeof(double) * h.size(),
                              hipMemcpyDeviceToHost, c->stream));
+    int team_err = 0;
+    if (c->team_used)
+        HIPCHK(c, hipMemcpyAsync(&team_err, c->d_team_cnt + c->n_pairs, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (team_err)
+        return fail(c, DVO_ERR_HIP, "team mode: a workgroup gave up waiting for its team (members were not resident together); "
+                                    "set dvo_params.team_size = 1");
     for (int p = 0; p < n_pairs; p++) {
         std::memcpy(R + 9 * p, &h[12 * p], sizeof(double) * 9);
         std::memcpy(t + 3 * p, &h[12 * p + 9], sizeof(double) * 3);

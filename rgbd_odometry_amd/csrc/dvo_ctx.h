@@ -67,7 +67,11 @@ struct dvo_ctx {
     int *d_final_N = nullptr;
     double *d_H = nullptr;          /* DVO_FLAG_NORMAL_MATRIX output, n_pairs x e_stride x 21 */
     size_t H_doubles = 0;
-    int *d_tex_mode = nullptr;      /* n_pairs x DVO_LEVELS, written by the packed fused kernel */
+    int *d_tex_mode = nullptr;
+    /* team mode of the packed kernel (G workgroups per pair for small batches): exchange slots, arrival counters, error flag */
+    double *d_team_buf = nullptr;
+    unsigned *d_team_cnt = nullptr;      /* n_pairs counters followed by one int error flag */
+    bool team_used = false;              /* the last enqueue ran in team mode: dvo_get_poses checks the error flag */      /* n_pairs x DVO_LEVELS, written by the packed fused kernel */
     int final_cap = 0;
     double *d_scratch = nullptr;    /* partials (1024 x 32) + acc (32) + misc doubles */
     /* dvo_align_pyramid_wide as a replayable hipGraph (the schedule is ~2 dependent launches per iteration) */

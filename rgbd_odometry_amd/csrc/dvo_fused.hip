@@ -222,6 +222,73 @@ DVO_DEV void block_reduce7(const Acc7 &a, double (*red)[8], double *tot) {
     __syncthreads();
 }
 
+/* ---- teams: G workgroups share ONE frame pair (small batches) ------------------------------------------------------
+ * With fewer pairs than compute units a launch of one workgroup per pair leaves most of the GPU idle (C4's per-GPU share
+ * is 32 pairs on 256 CUs).  In team mode G workgroups take contiguous index ranges of every level's point list; after
+ * its own block reduction each member publishes its 8 sums in the team's slot (HBM/L2), a counter tells when all G are
+ * there, and EVERY member then adds the G partials in the same fixed order and runs the same double-precision update:
+ * identical bits on all members, no broadcast step, one synchronisation per iteration.  The members of a team are placed
+ * on ONE XCD (workgroups are dispatched round-robin over the 8 XCDs, so workgroups b, b+8, b+16, ... share an L2): the
+ * exchange stays inside that XCD's L2.  Slots are double-buffered by the parity of the exchange index: a member can
+ * only reach exchange e+2 after all members have passed e+1, i.e. after everybody has read the slots of e.
+ * All G*pairs workgroups must be resident at once (the host launches at most one per CU); a bounded spin turns a broken
+ * assumption into an error flag instead of a hang. */
+#define DVO_TEAM_MAX 16
+/* One exchange, executed by wave 0 of every member.  Each of a member's 8 sums travels as a 16-byte record {value, tag}
+ * (tag = exchange index + 1) written with ONE 16-byte store, so a reader that sees the tag sees the value: no separate
+ * arrival counter, no wait for store acknowledgements, no fences.  All accesses are agent-scope atomics (sc1: coherent
+ * per location across the XCDs' L2s).  Agent-scope release / acquire FENCES are what must be avoided here: on gfx950 they
+ * are buffer_wbl2 / buffer_inv of the whole L2, per poll (measured: batch 32 ran 2x slower than without teams, and the
+ * other workgroups' texels were thrown out of the L2).  The wave polls all G*8 records at once (lane m*8+k reads record k
+ * of member m) until every tag matches, parks the values in LDS, and lane 0 adds them in member order. */
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+/* record = {value lo32, tag, value hi32, tag}: each 8-byte half carries the tag, so the record is consistent even if the
+ * 16-byte store were performed as two 8-byte pieces */
+DVO_DEV void team_store_rec(v4u *p, v4u r) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(r) : "memory"); }
+DVO_DEV v4u team_load_rec(const v4u *p) {
+    v4u r;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+DVO_DEV void team_exchange(double *tot, v4u *buf /* this pair's [2][DVO_TEAM_MAX][8] records */, double (*stage)[8] /* LDS [DVO_TEAM_MAX][8] */,
+                           int member, int G, unsigned epoch, int *err) {
+    const int lane = threadIdx.x & 63;
+    v4u *base = buf + (size_t)(epoch & 1u) * DVO_TEAM_MAX * 8;
+    const unsigned tag = epoch + 1u;
+    if (lane < 8) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(tot[lane]);
+        v4u rec;
+        rec.x = (unsigned)bits; rec.y = tag; rec.z = (unsigned)(bits >> 32); rec.w = tag;
+        team_store_rec(base + member * 8 + lane, rec);
+    }
+    const int n_rec = G * 8;                       /* <= 128: lane L polls records L and L + 64 */
+    const bool has0 = lane < n_rec, has1 = lane + 64 < n_rec;
+    v4u r0 = {0u, tag, 0u, tag}, r1 = {0u, tag, 0u, tag};
+    int spins = 0;
+    for (;;) {
+        if (has0) r0 = team_load_rec(base + lane);
+        if (has1) r1 = team_load_rec(base + lane + 64);
+        const bool ok = (r0.y == tag) && (r0.w == tag) && (r1.y == tag) && (r1.w == tag);
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+        if (++spins > (1 << 21)) { if (lane == 0) *err = 1; break; }       /* seconds: a member is not resident -- report, do not hang */
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (has0) stage[lane >> 3][lane & 7] = __longlong_as_double((long long)(((unsigned long long)r0.z << 32) | r0.x));
+    if (has1) stage[(lane >> 3) + 8][lane & 7] = __longlong_as_double((long long)(((unsigned long long)r1.z << 32) | r1.x));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      /* same wave: the LDS writes are done */
+    if (lane == 0) {
+        double s[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[k] = 0.0;
+        for (int m = 0; m < G; m++) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) s[k] += stage[m][k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) tot[k] = s[k];
+    }
+}
+
 /* DVO_STAMPS: diagnostic build only (make STAMPS=1 -> libdvo_amd_stamps.so): lane 0 of wave 0 accumulates s_memtime
  * differences of the phases of every iteration into out.dbg[pair*64 + level*8 + {0 points, 1 reduce, 2 update, 3 barrier,
  * 4 iterations, 5 level set-up (staging)}] */
@@ -240,14 +307,25 @@ DVO_DEV unsigned long long stamp_now2() {
 #define DVO_STAMP_ADD(slot, a, b) do {} while (0)
 #endif
 
-template <int BLOCK>
+template <int BLOCK, bool TEAM>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 8)))
 align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outputs out, int first_pair) {
-    const int pair = first_pair + blockIdx.x;
+    /* team mode: workgroup b -> XCD b % 8; the G members of pair (q*8 + x) are the workgroups x + 8*(q*G + j) */
+    const int G = TEAM ? sc.team : 1;
+    int pair_local = blockIdx.x, member = 0;
+    if (TEAM) {
+        const int x = blockIdx.x & 7, k = blockIdx.x >> 3, q = k / G;
+        member = k - q * G;
+        pair_local = q * 8 + x;
+        if (pair_local >= sc.n_pairs_launch) return;
+    }
+    const int pair = first_pair + pair_local;
     const int tid = threadIdx.x;
+    unsigned epoch = 0;                          /* exchanges done so far (team mode) */
     __shared__ PoseState st;
     __shared__ double red[BLOCK / 64][8];
     __shared__ double tot[8];
+    __shared__ double team_stage[TEAM ? DVO_TEAM_MAX : 1][8];
     extern __shared__ float lds_dyn[];          /* sc.lds_bytes: per level two planes of point words (xx|yy<<16 and Z) and, when it fits, the now level */
 
     if (tid == 0) {
@@ -267,16 +345,24 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         if (iters <= 0) continue;                                 /* :2099 */
         const LevelSlab &L = lv.l[l];
         const int dpair = (sc.alias_mod > 0) ? (pair % sc.alias_mod) : pair;
-        const int N = L.N[dpair];
+        const int Nall = L.N[dpair];
+        /* this workgroup's share of the list: all of it, or member `member`'s contiguous even-sized chunk of a team */
+        int pfirst = 0, N = Nall;
+        if (TEAM) {
+            const int chunk = (((Nall + G - 1) / G) + 1) & ~1;
+            pfirst = min(Nall, member * chunk);
+            N = min(Nall, pfirst + chunk) - pfirst;
+        }
         const char *__restrict__ tex = reinterpret_cast<const char *>(L.tex + (size_t)dpair * L.tex_stride);
-        const uint2 *__restrict__ gpts = L.cpts + (size_t)dpair * L.pt_cap;
+        const uint2 *__restrict__ gpts = L.cpts + (size_t)dpair * L.pt_cap + pfirst;
         float *energy = out.energy + (size_t)pair * sc.e_stride + sc.e_off[l];
 
         IterConst c;
         level_consts(c, K, l, L.rows, L.cols);
         DVO_STAMP(ts0);
 
-        for (int i = tid; i < iters; i += BLOCK) energy[i] = 0.0f;          /* :634 */
+        if (member == 0)
+            for (int i = tid; i < iters; i += BLOCK) energy[i] = 0.0f;      /* :634 */
         if (tid == 0) { pose_state_begin(st); pose_regulariser_precompute(st, prm); }   /* :642-657 */
 
         /* ---- what lives in LDS for this level (wave-uniform decisions) --------------------------------------------
@@ -286,11 +372,11 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         const int lds_words = sc.lds_bytes >> 2;
         const int n_pad = (N + 3) & ~3;
         const int tex16_words = (int)(L.tex_stride * 4);
-        const int mode = (!sc.no_lds_tex && 2 * n_pad + tex16_words <= lds_words) ? TEX_L16 : TEX_G16;
+        const int mode = (!TEAM && !sc.no_lds_tex && 2 * n_pad + tex16_words <= lds_words) ? TEX_L16 : TEX_G16;
         const int cap = (mode == TEX_G16) ? (lds_words >> 1) : n_pad;          /* words per point plane */
         const int n_lds = (N <= cap) ? N : (cap / (2 * BLOCK)) * (2 * BLOCK);      /* whole rounds only */
         float *const lds_tex = lds_dyn + 2 * cap;
-        if (tid == 0) out.tex_mode[pair * DVO_LEVELS + l] = mode;
+        if (tid == 0 && member == 0) out.tex_mode[pair * DVO_LEVELS + l] = mode;
         {   /* 16-byte loads (whole 128-byte lines per request), four in flight per lane */
             const uint4 *g4 = reinterpret_cast<const uint4 *>(gpts);
             const int n2 = n_lds >> 1;
@@ -371,10 +457,14 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             DVO_STAMP(t1);
             block_reduce7<BLOCK>(a, red, tot);
             DVO_STAMP(t2);
+            if (TEAM && tid < 64)      /* wave 0: the sums of the other members; identical bits on every member */
+                team_exchange(tot, reinterpret_cast<v4u *>(out.team_buf) + (size_t)pair_local * 2 * DVO_TEAM_MAX * 8, team_stage, member, G,
+                              epoch, out.team_err);
             if (tid == 0) {
-                const float e = pose_update_t<true>(st, prm, itr, N, &tot[0], tot[6], (int)tot[7]);
-                energy[itr] = e;                                             /* :690 */
+                const float e = pose_update_t<true>(st, prm, itr, Nall, &tot[0], tot[6], (int)tot[7]);
+                if (member == 0) energy[itr] = e;                            /* :690 */
             }
+            epoch++;
             DVO_STAMP(t3);
             __syncthreads();
             DVO_STAMP(t4);
@@ -405,22 +495,25 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
                     const bool vis = project_point(c, X, Y, Z, xn, yn, zn, u, v);
                     float e = 0.0f;
                     if (vis) e = reinterpret_cast<const float4 *>(tex)[texel_index((int)v, (int)u, c.tiles_per_col)].x;
-                    fe[i] = e;
-                    fr[3 * i] = u; fr[3 * i + 1] = v; fr[3 * i + 2] = zn;
+                    const int gi = pfirst + i;
+                    fe[gi] = e;
+                    fr[3 * gi] = u; fr[3 * gi + 1] = v; fr[3 * gi + 2] = zn;
                 }
             }
-            if (tid == 0) out.final_N[pair] = (st.bestItr >= 0) ? N : 0;
+            if (tid == 0 && member == 0) out.final_N[pair] = (st.bestItr >= 0) ? Nall : 0;
         }
         __syncthreads();
         if (tid == 0) {                                                      /* :997-1005 */
             pose_state_finish(st);
-            out.best_idx[pair * DVO_LEVELS + l] = st.bestItr;
-            out.ratio[pair * DVO_LEVELS + l] = st.bestRatio;
+            if (member == 0) {
+                out.best_idx[pair * DVO_LEVELS + l] = st.bestItr;
+                out.ratio[pair * DVO_LEVELS + l] = st.bestRatio;
+            }
         }
         __syncthreads();
     }
 
-    if (tid == 0) {
+    if (tid == 0 && member == 0) {
         double *p = out.poses + (size_t)pair * 12;
 #pragma unroll
         for (int k = 0; k < 9; k++) p[k] = st.R[k];
@@ -433,19 +526,27 @@ template <int BLOCK>
 static hipError_t launch_fused2_b(const LevelSet &lv, const Schedule &sc, const Intrinsics &K, const DevParams &prm,
                                   const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {
     const size_t dyn = (size_t)sc.lds_bytes;
-    auto kern = align_fused2_kernel<BLOCK>;
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(n_pairs), dim3(BLOCK), dyn, s, lv, sc, K, prm, out, first_pair);
+    hipError_t e;
+    if (sc.team > 1) {
+        auto kern = align_fused2_kernel<BLOCK, true>;
+        if ((e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)) != hipSuccess) return e;
+        const int grid = 8 * ((n_pairs + 7) / 8) * sc.team;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), dyn, s, lv, sc, K, prm, out, first_pair);
+    } else {
+        auto kern = align_fused2_kernel<BLOCK, false>;
+        if ((e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)) != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(n_pairs), dim3(BLOCK), dyn, s, lv, sc, K, prm, out, first_pair);
+    }
     return hipGetLastError();
 }
 
 /* static LDS of align_fused2_kernel<BLOCK> (the host sizes the dynamic part against the CU's 160 KiB) */
-size_t fused2_static_lds(int block_threads) { return sizeof(PoseState) + (size_t)(block_threads / 64) * 64 + 64 + 64; }
+size_t fused2_static_lds(int block_threads) { return sizeof(PoseState) + (size_t)(block_threads / 64) * 64 + 64 + 64 + DVO_TEAM_MAX * 64; }
 
 hipError_t launch_align_fused2(int block_threads, const LevelSet &lv, const Schedule &sc, const Intrinsics &K,
                                const DevParams &prm, const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {
     if (n_pairs <= 0) return hipSuccess;
+    if (sc.team > DVO_TEAM_MAX) return hipErrorInvalidValue;
     switch (block_threads) {
     case 256: return launch_fused2_b<256>(lv, sc, K, prm, out, first_pair, n_pairs, s);
     case 1024: return launch_fused2_b<1024>(lv, sc, K, prm, out, first_pair, n_pairs, s);

@@ -47,6 +47,8 @@ struct Schedule {
     int lds_points;          /* reference points kept resident in LDS per workgroup (3 words each, 2 when compact) */
     int lds_bytes;           /* dynamic LDS of the launch (dvo_fused.hip splits it per level between points and the now level) */
     int no_lds_tex;          /* diagnostics: never stage the now level into LDS */
+    int team;                /* workgroups per pair of the packed kernel (1 = none; > 1: team mode, see dvo_fused.hip) */
+    int n_pairs_launch;      /* pairs of this launch (team mode maps workgroups to pairs itself) */
     int force_exact;         /* tests: every wave takes the literal-division fallback of the packed kernel (accumulate_points_exact) */
     int compact;             /* every pair/level of this launch has a compact point list: read 8 B / point instead of 12 */
 };
@@ -64,6 +66,9 @@ struct Outputs {
     int final_cap;
     unsigned long long *dbg; /* diagnostics (DVO_STAMPS builds): n_pairs x 64 counters, else NULL */
     double *H;               /* DVO_FLAG_NORMAL_MATRIX: n_pairs x e_stride x 21 (upper triangle of sum w J J^T per iterate), else NULL */
+    double *team_buf;        /* team mode: n_pairs x 2 x 16 x 8 records of 16 bytes {value, tag} (partial sums of the members, double-buffered; zero before the launch) */
+    unsigned *team_cnt;      /* (unused by the kernel; the int after n_pairs entries is the error flag) */
+    int *team_err;           /* set to 1 by a member that gave up waiting (members not co-resident) */
     int *tex_mode;           /* n_pairs x DVO_LEVELS: where the fused kernel read the now level from (DVO_TEXMODE_*), inspection */
 };
 

@@ -47,10 +47,12 @@ def _check(ctx, oracle, sc, lv, iters, pair=0, R0=None, t0=None):
 
 
 @pytest.mark.parametrize("kw", [
-    dict(),                                          # auto: 512 threads, coarse levels staged into LDS
+    dict(),                                          # auto: a single pair -> a team of 8 workgroups
+    dict(team_size=1),                               # one 512-thread workgroup, coarse levels staged into LDS
     dict(engine_variant=2),                          # never stage texels into LDS
     dict(engine_variant=1),                          # the one-point-per-lane kernel on the same compact lists
     dict(engine_variant=3),                          # every wave through the literal-division fallback of the packed kernel
+    dict(engine_variant=3, team_size=1), dict(engine_variant=2, team_size=1),
     dict(block_threads=256), dict(block_threads=1024),
     dict(lds_point_bytes=-1),                        # every point streamed from HBM
     dict(lds_point_bytes=16 * 1024),                 # 2048 points resident, the rest streamed (both passes run)
@@ -66,10 +68,12 @@ def test_packed_kernel_variants_640x480(oracle, kw):
         _load(ctx, sc)
         _check(ctx, oracle, sc, lv, [10, 10, 10, 10])
         modes = [ctx.level_texel_mode(0, l) for l in range(4)]
-        if kw.get("engine_variant") == 1:
+        variant = kw.get("engine_variant", 0)
+        team_on = variant != 1 and kw.get("team_size", 0) != 1 and kw.get("block_threads", 0) in (0, 512)
+        if variant == 1:
             pass                                      # the other kernel: modes untouched
-        elif kw.get("engine_variant") == 2 or kw.get("lds_point_bytes", 0) != 0:
-            assert modes == [0, 0, 0, 0], modes
+        elif team_on or variant == 2 or kw.get("lds_point_bytes", 0) != 0:
+            assert modes == [0, 0, 0, 0], modes       # teams read their texels through L2; no LDS budget / staging switched off
         elif kw.get("block_threads") == 256:
             assert modes[0] == 0 and modes[1] == 0, modes     # 77 KB per workgroup: level 3 (80x60 texels = 77 KB) does not fit beside its points
         else:
@@ -81,7 +85,7 @@ def test_lds_staged_levels_reference_default(oracle):
     from rgbd_odometry_amd import DvoContext, SynthScene
     sc = SynthScene(320, 240, 4, 9)
     lv = oracle_lib.scene_levels(sc, oracle)
-    with DvoContext(1, block_threads=512) as ctx:
+    with DvoContext(1, block_threads=512, team_size=1) as ctx:
         ctx.set_intrinsics(*sc.intrinsics)
         _load(ctx, sc)
         _check(ctx, oracle, sc, lv, [50, 50, 50, 50])
@@ -188,3 +192,48 @@ def test_config4_batch_of_distinct_640x480_pairs(oracle):
         assert worst_r <= ROT_TOL and worst_t <= TRANS_TOL
         R2, t2 = ctx.align_batch(iters, np.tile(np.eye(3), (n, 1, 1)), np.zeros((n, 3)))      # run-to-run determinism
         assert np.array_equal(R, R2) and np.array_equal(t, t2)
+
+
+@pytest.mark.parametrize("n_pairs,team", [(1, 0), (1, 2), (3, 4), (5, 8), (9, 16), (12, 0), (32, 0), (8, 16)])
+def test_team_mode_small_batches(oracle, n_pairs, team):
+    """small batches: G workgroups share each pair (contiguous shares of every level's points, sums exchanged through L2,
+    identical update on every member) -- same bits as the oracle, for every team size and for pair counts that are not
+    multiples of the 8 XCDs"""
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    from rgbd_odometry_amd.capi import DVO_FLAG_FINAL_OUTPUTS
+    scenes = [SynthScene(640, 480, 4, 2000 + (i % 3)) for i in range(min(n_pairs, 3))]
+    lvs = [oracle_lib.scene_levels(s, oracle) for s in scenes]
+    iters = [10, 10, 10, 10]
+    refs = [oracle.align_pyramid(iters, lv, s.intrinsics, np.eye(3), np.zeros(3)) for s, lv in zip(scenes, lvs)]
+    with DvoContext(n_pairs, team_size=team) as ctx:
+        ctx.set_intrinsics(*scenes[0].intrinsics)
+        for p in range(n_pairs):
+            _load(ctx, scenes[p % len(scenes)], pair=p)
+        R, t = ctx.align_batch(iters, np.tile(np.eye(3), (n_pairs, 1, 1)), np.zeros((n_pairs, 3)), flags=DVO_FLAG_FINAL_OUTPUTS)
+        for p in range(n_pairs):
+            ref = refs[p % len(scenes)]
+            for l, rep in ref["levels"].items():
+                e, b, ratio = ctx.level_report(p, l, iters[l])
+                assert np.array_equal(e, rep["energy"]) and b == rep["best_idx"] and ratio == rep["visible_ratio"], (p, l)
+            assert rot_angle(ref["R"], R[p]) <= ROT_TOL and np.linalg.norm(ref["t"] - t[p]) <= TRANS_TOL
+            last = ref["levels"][ref["last_level"]]
+            feps, frep = ctx.final_outputs(p, len(last["final_eps"]))
+            assert _same(feps, last["final_eps"]) and _same(frep, last["final_reproj"]), p
+        # the one-workgroup-per-pair launch: the double sums are added in another order, so ~1e-16, not bit-identical
+        with DvoContext(n_pairs, team_size=1) as solo:
+            solo.set_intrinsics(*scenes[0].intrinsics)
+            for p in range(n_pairs):
+                _load(solo, scenes[p % len(scenes)], pair=p)
+            Rs, ts = solo.align_batch(iters, np.tile(np.eye(3), (n_pairs, 1, 1)), np.zeros((n_pairs, 3)))
+            assert np.abs(R - Rs).max() <= 1e-12 and np.abs(t - ts).max() <= 1e-12
+
+
+def test_team_size_that_cannot_be_resident_is_refused():
+    from rgbd_odometry_amd import DvoContext, DvoError, SynthScene
+    sc = SynthScene(160, 120, 2, 1)
+    with DvoContext(64, team_size=16) as ctx:
+        ctx.set_intrinsics(*sc.intrinsics)
+        for p in range(64):
+            _load(ctx, sc, pair=p)
+        with pytest.raises(DvoError):
+            ctx.align_batch([2, 2], np.tile(np.eye(3), (64, 1, 1)), np.zeros((64, 3)))

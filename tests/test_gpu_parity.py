@@ -107,7 +107,8 @@ def test_normal_matrix_of_every_iterate(scene320, oracle):
                 ctx.set_now_level(l, L["dt"], L["gx"], L["gy"], L["rows"], L["cols"])
             R, t = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)), flags=DVO_FLAG_NORMAL_MATRIX)
             Rp, tp = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
-            assert np.array_equal(R, Rp) and np.array_equal(t, tp)
+            # same policy, same per-point bits; another kernel may add the double sums in another order (~1e-16)
+            assert np.abs(R - Rp).max() <= 1e-12 and np.abs(t - tp).max() <= 1e-12
             ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)), flags=DVO_FLAG_NORMAL_MATRIX)
             Rc, tc = np.eye(3), np.zeros(3)
             for l in (3, 2, 0):
@@ -551,8 +552,10 @@ def test_interpolate_distance_transform_flag(scene320, oracle):
 
 
 def test_compact_point_lists_give_the_same_bits(oracle):
-    """lists built by the engine's enlist kernels are read in their 8-byte form {xx | yy << 16, Z}; the same points
-    handed over as a 3 x N float list take the 12-byte path: identical energies, indices, ratios and poses"""
+    """lists built by the engine's enlist kernels are read in their 8-byte form {xx | yy << 16, Z} (packed kernel, a team
+    of workgroups for a single pair); the same points handed over as a 3 x N float list take the 12-byte path of the
+    one-point-per-lane kernel: bit-identical energies, indices, ratios and final outputs; poses to ~1e-16 (the double
+    sums are added in another order)"""
     from rgbd_odometry_amd import DvoContext, SynthScene
     from rgbd_odometry_amd.capi import DVO_FLAG_FINAL_OUTPUTS
     for (W, H, nl, it, seed) in ((640, 480, 4, 10, 5), (1000, 700, 3, 6, 6)):      # the second one exceeds the LDS budget
@@ -568,7 +571,7 @@ def test_compact_point_lists_give_the_same_bits(oracle):
                     ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols)
             Ra, ta = a.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)), flags=DVO_FLAG_FINAL_OUTPUTS)
             Rb, tb = b.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)), flags=DVO_FLAG_FINAL_OUTPUTS)
-            assert np.array_equal(Ra, Rb) and np.array_equal(ta, tb)
+            assert np.abs(Ra - Rb).max() <= 1e-12 and np.abs(ta - tb).max() <= 1e-12
             for l in range(nl):
                 ea, eb = a.level_report(0, l, it), b.level_report(0, l, it)
                 assert np.array_equal(ea[0], eb[0]) and ea[1:] == eb[1:]
@@ -579,7 +582,7 @@ def test_compact_point_lists_give_the_same_bits(oracle):
             b.set_intrinsics(sc.intrinsics[0] * 1.01, sc.intrinsics[1], sc.intrinsics[2], sc.intrinsics[3])
             Ra, ta = a.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
             Rb, tb = b.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
-            assert np.array_equal(Ra, Rb) and np.array_equal(ta, tb)
+            assert np.abs(Ra - Rb).max() <= 1e-12 and np.abs(ta - tb).max() <= 1e-12
 
 
 def test_wide_path_graph_is_rebuilt_when_inputs_change(oracle):
