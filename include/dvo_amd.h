@@ -313,6 +313,13 @@ int  dvo_frames_reserve(dvo_ctx *ctx, int n_slots);
  * dvo_frames_as_now would), chunk by chunk in the shadow of the next chunk's host-to-device copies; -1: no. */
 int  dvo_frames_upload_pyramids(dvo_ctx *ctx, int first_slot, int count, int n_levels,
                                 const dvo_image *grey, const dvo_image *depth, int now_first_pair, int flags);
+/* cv::undistort of the pyramid publisher (camTopic2PublisherPyD.cpp:88-107, :306-308), applied to BOTH images of every
+ * frame given to dvo_frames_upload_cameras from now on (the depth image after its conversion to 16-bit millimetres, as the
+ * publisher does): K4 = fx, fy, cx, cy and D5 = k1, k2, p1, p2, k3 of the sensor_msgs/CameraInfo the publisher listens to
+ * (:52-61), rows x cols = the camera's resolution.  OpenCV 2.4 semantics: fixed-point bilinear remap (5 fraction bits),
+ * zero outside the source.  K4 = D5 = NULL switches it off again (the publisher's behaviour without a camera-info topic).
+ * The map is built once per call on the host. */
+int  dvo_frames_set_undistort(dvo_ctx *ctx, int rows, int cols, const double *K4, const double *D5);
 /* camera frames: full-resolution BGR8 (rows x cols x 3, row-major) + depth in metres (F32 row-major, may be NULL);
  * level l is decimated by 2^(first_shift + l) (the reference publishes first_shift = 1: 320x240 .. 40x30).
  * Builds the pyramid on the device, then as above. */

@@ -174,6 +174,10 @@ void dvo_oracle_resize_nn_size(int rows, int cols, double scale, int *drows, int
 void dvo_oracle_resize_nn(const void *src, int rows, int cols, int elem_bytes, double scale, void *dst);
 /* depthRcvd (camTopic2PublisherPyD.cpp:73-77): 1000.0*depth -> CV_16U -> 0 becomes 1 */
 void dvo_oracle_depth_m_to_mm16(const float *depth_m, size_t npx, unsigned short *out);
+/* cv::undistort (camTopic2PublisherPyD.cpp:88-107): bgr8 (rows x cols x 3) and mono16 images, row-major; K4 = fx fy cx cy,
+ * D5 = k1 k2 p1 p2 k3 (sensor_msgs/CameraInfo K and D, :52-61) */
+void dvo_oracle_undistort_bgr8(const unsigned char *src, int rows, int cols, const double *K4, const double *D5, unsigned char *dst);
+void dvo_oracle_undistort_u16(const unsigned short *src, int rows, int cols, const double *K4, const double *D5, unsigned short *dst);
 
 /* Helpers exported for property tests. */
 float dvo_oracle_weight(float r);                                   /* :1047-1053 */

@@ -162,4 +162,129 @@ void dvo_oracle_depth_m_to_mm16(const float *depth_m, size_t npx, unsigned short
     }
 }
 
+/* ---- cv::undistort(src, dst, cameraMatrix, distCoeffs) of the pyramid publisher (camTopic2PublisherPyD.cpp:88-107,
+ * :306-308), OpenCV 2.4 (imgproc/src/undistort.cpp, imgwarp.cpp), restated -- PARITY UNPINNED like the other OpenCV steps:
+ *   undistort()               processes the image in horizontal stripes of stripe0 = min(max(1, 4096/cols), rows) rows; for the
+ *                             stripe starting at row y0 it builds a fixed-point map with newCameraMatrix = cameraMatrix but
+ *                             cy' = cy - y0, R = I, and remaps with INTER_LINEAR, BORDER_CONSTANT (value 0)
+ *   initUndistortRectifyMap() iR = inv(Ar*R) -- for a 3x3 cv::invert(DECOMP_LU) is the adjugate times 1/det --; per map row i:
+ *                             _x = i*ir[1]+ir[2], _y = i*ir[4]+ir[5], _w = i*ir[7]+ir[8], advanced by (ir[0], ir[3], ir[6]) per
+ *                             column (running sums, in double); x = _x/_w ...; radial/tangential model with k1 k2 p1 p2 k3
+ *                             (k4..k6 = 0 for the 5-coefficient camera_info D); u, v in double;
+ *                             CV_16SC2 map: iu = cvRound(u*32), m1 = (short)(iu >> 5), fraction index (iv & 31)*32 + (iu & 31)
+ *   remap() INTER_LINEAR      8-bit: weights from BilinearTab_i = saturate_cast<short>(w*32768) -- exact for 1/32 fractions,
+ *                             except weight 1.0 -> 32767 with the missing 1 added to tap (1,1) --, pixel = (sum + 2^14) >> 15;
+ *                             16-bit: float weights, v0*w0 + v1*w1 + v2*w2 + v3*w3 in float left to right, cvRound, saturate;
+ *                             a tap outside the image contributes the border value 0 */
+namespace {
+struct UndistortMap { std::vector<short> sx, sy; std::vector<unsigned short> frac; };
+
+void invert3_adjugate(const double *S, double *t) {      /* cv::invert, n == 3, CV_64F; row-major */
+    auto m = [&](int i, int j) { return S[i * 3 + j]; };
+    double d = m(0, 0) * (m(1, 1) * m(2, 2) - m(1, 2) * m(2, 1)) - m(0, 1) * (m(1, 0) * m(2, 2) - m(1, 2) * m(2, 0)) +
+               m(0, 2) * (m(1, 0) * m(2, 1) - m(1, 1) * m(2, 0));
+    d = 1. / d;
+    t[0] = (m(1, 1) * m(2, 2) - m(1, 2) * m(2, 1)) * d;
+    t[1] = (m(0, 2) * m(2, 1) - m(0, 1) * m(2, 2)) * d;
+    t[2] = (m(0, 1) * m(1, 2) - m(0, 2) * m(1, 1)) * d;
+    t[3] = (m(1, 2) * m(2, 0) - m(1, 0) * m(2, 2)) * d;
+    t[4] = (m(0, 0) * m(2, 2) - m(0, 2) * m(2, 0)) * d;
+    t[5] = (m(0, 2) * m(1, 0) - m(0, 0) * m(1, 2)) * d;
+    t[6] = (m(1, 0) * m(2, 1) - m(1, 1) * m(2, 0)) * d;
+    t[7] = (m(0, 1) * m(2, 0) - m(0, 0) * m(2, 1)) * d;
+    t[8] = (m(0, 0) * m(1, 1) - m(0, 1) * m(1, 0)) * d;
+}
+
+void build_undistort_map(int rows, int cols, const double *K4, const double *D5, UndistortMap &M) {
+    const double fx = K4[0], fy = K4[1], u0 = K4[2], v0 = K4[3];
+    const double k1 = D5[0], k2 = D5[1], p1 = D5[2], p2 = D5[3], k3 = D5[4], k4 = 0, k5 = 0, k6 = 0;
+    M.sx.assign((size_t)rows * cols, 0); M.sy.assign((size_t)rows * cols, 0); M.frac.assign((size_t)rows * cols, 0);
+    int stripe0 = (1 << 12) / (cols > 1 ? cols : 1);
+    if (stripe0 < 1) stripe0 = 1;
+    if (stripe0 > rows) stripe0 = rows;
+    for (int y0 = 0; y0 < rows; y0 += stripe0) {
+        const int stripe = (stripe0 < rows - y0) ? stripe0 : rows - y0;
+        const double Ar[9] = {fx, 0, u0, 0, fy, v0 - y0, 0, 0, 1};           /* Ar(1,2) = v0 - y; Ar*I is Ar exactly */
+        double ir[9];
+        invert3_adjugate(Ar, ir);
+        for (int i = 0; i < stripe; i++) {
+            double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+            for (int j = 0; j < cols; j++, _x += ir[0], _y += ir[3], _w += ir[6]) {
+                const double w = 1. / _w, x = _x * w, y = _y * w;
+                const double x2 = x * x, y2 = y * y;
+                const double r2 = x2 + y2, _2xy = 2 * x * y;
+                const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
+                const double u = fx * (x * kr + p1 * _2xy + p2 * (r2 + 2 * x2)) + u0;
+                const double v = fy * (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy) + v0;
+                const int iu = cv_round(u * 32), iv = cv_round(v * 32);        /* saturate_cast<int>(double) */
+                const size_t o = (size_t)(y0 + i) * cols + j;
+                M.sx[o] = (short)(iu >> 5);
+                M.sy[o] = (short)(iv >> 5);
+                M.frac[o] = (unsigned short)((iv & 31) * 32 + (iu & 31));
+            }
+        }
+    }
+}
+
+void bilinear_itab(int fi, short *w) {                  /* BilinearTab_i[fi], fi = fy*32 + fx */
+    const int fy = fi >> 5, fx = fi & 31;
+    const float ty[2] = {1.f - fy * (1.f / 32), fy * (1.f / 32)}, tx[2] = {1.f - fx * (1.f / 32), fx * (1.f / 32)};
+    int isum = 0;
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 2; b++) {
+            const float v = ty[a] * tx[b];
+            int iv = cv_round((double)(v * 32768.f));
+            if (iv > 32767) iv = 32767;                  /* saturate_cast<short> */
+            w[a * 2 + b] = (short)iv;
+            isum += iv;
+        }
+    if (isum != 32768) w[3] = (short)(w[3] - (isum - 32768));   /* only fi == 0: {32767,0,0,0} -> the missing 1 lands on tap (1,1) */
+}
+}  // namespace
+
+void dvo_oracle_undistort_bgr8(const unsigned char *src, int rows, int cols, const double *K4, const double *D5, unsigned char *dst) {
+    UndistortMap M;
+    build_undistort_map(rows, cols, K4, D5, M);
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            const size_t o = (size_t)y * cols + x;
+            const int sx = M.sx[o], sy = M.sy[o];
+            short w[4];
+            bilinear_itab(M.frac[o], w);
+            for (int ch = 0; ch < 3; ch++) {
+                int sum = 0;
+                for (int a = 0; a < 2; a++)
+                    for (int b = 0; b < 2; b++) {
+                        const int yy = sy + a, xx = sx + b;
+                        const int v = (yy >= 0 && yy < rows && xx >= 0 && xx < cols) ? src[((size_t)yy * cols + xx) * 3 + ch] : 0;
+                        sum += v * w[a * 2 + b];
+                    }
+                int r = (sum + (1 << 14)) >> 15;          /* FixedPtCast<int, uchar, 15> */
+                dst[o * 3 + ch] = (unsigned char)(r < 0 ? 0 : (r > 255 ? 255 : r));
+            }
+        }
+}
+
+void dvo_oracle_undistort_u16(const unsigned short *src, int rows, int cols, const double *K4, const double *D5, unsigned short *dst) {
+    UndistortMap M;
+    build_undistort_map(rows, cols, K4, D5, M);
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            const size_t o = (size_t)y * cols + x;
+            const int sx = M.sx[o], sy = M.sy[o];
+            const int fy = M.frac[o] >> 5, fx = M.frac[o] & 31;
+            const float ty[2] = {1.f - fy * (1.f / 32), fy * (1.f / 32)}, tx[2] = {1.f - fx * (1.f / 32), fx * (1.f / 32)};
+            float acc = 0.f;
+            for (int a = 0; a < 2; a++)
+                for (int b = 0; b < 2; b++) {
+                    const int yy = sy + a, xx = sx + b;
+                    const float v = (yy >= 0 && yy < rows && xx >= 0 && xx < cols) ? (float)src[(size_t)yy * cols + xx] : 0.f;
+                    const float wt = ty[a] * tx[b];       /* BilinearTab_f */
+                    acc = (a == 0 && b == 0) ? v * wt : acc + v * wt;
+                }
+            const int r = cv_round((double)acc);
+            dst[o] = (unsigned short)(r < 0 ? 0 : (r > 65535 ? 65535 : r));
+        }
+}
+
 }  // extern "C"

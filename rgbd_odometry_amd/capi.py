@@ -32,7 +32,7 @@ C_ABI_SYMBOLS = [
     "dvo_device_se3_log", "dvo_device_rotationize", "dvo_algorithmic_bytes", "dvo_point_iterations",
     "dvo_debug_stamps", "dvo_get_level_texel_mode", "dvo_replicate_pairs", "dvo_set_now_level_from_edges", "dvo_get_now_level", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
     "dvo_align_pyramid_wide", "dvo_tiled_attach", "dvo_tiled_detach", "dvo_align_pyramid_tiled",
-    "dvo_get_ref_level", "dvo_frames_reserve", "dvo_frames_upload_pyramids", "dvo_frames_upload_cameras", "dvo_frames_as_now",
+    "dvo_get_ref_level", "dvo_frames_reserve", "dvo_frames_upload_pyramids", "dvo_frames_upload_cameras", "dvo_frames_set_undistort", "dvo_frames_as_now",
     "dvo_frames_as_ref", "dvo_frame_get_level", "dvo_frames_num_levels",
 ]
 
@@ -199,6 +199,7 @@ def load_library() -> C.CDLL:
         "dvo_iter_update": [vp, i, i, i, i, vp],
         "dvo_iter_end": [vp, i, i, vp, vp, vp, ip, fp],
         "dvo_align_pyramid_wide": [vp, i, i, ip, vp, vp],
+        "dvo_frames_set_undistort": [vp, i, i, vp, vp],
         "dvo_tiled_attach": [vp, vp, i, i, C.c_char_p],
         "dvo_tiled_detach": [vp],
         "dvo_align_pyramid_tiled": [vp, i, i, ip, vp, vp],
@@ -537,6 +538,15 @@ class DvoContext:
         t = np.array(t, dtype=np.float64).copy()
         self._chk(self.lib.dvo_align_pyramid_wide(self._h, pair, len(iters), _iters(iters), _ptr(R), _ptr(t)))
         return R, t
+
+    def frames_set_undistort(self, rows: int, cols: int, K4=None, D5=None):
+        """cv::undistort with the camera-info calibration on every camera frame uploaded from now on; None, None = off"""
+        if K4 is None and D5 is None:
+            self._chk(self.lib.dvo_frames_set_undistort(self._h, rows, cols, None, None))
+            return
+        K = np.asarray(K4, np.float64).copy(); D = np.asarray(D5, np.float64).copy()
+        assert K.size == 4 and D.size == 5
+        self._chk(self.lib.dvo_frames_set_undistort(self._h, rows, cols, _ptr(K), _ptr(D)))
 
     # -- tiled mode driven from C (RCCL) ---------------------------------------
     def tiled_attach(self, comm, rank: int, world: int, rccl_library: Optional[str] = None):

@@ -418,6 +418,8 @@ int dvo_destroy(dvo_ctx *c) {
         for (void *p : fp) if (p) (void)hipFree(p);
     }
     if (c->work) (void)hipFree(c->work);
+    if (c->d_umap_xy) (void)hipFree(c->d_umap_xy);
+    if (c->d_umap_frac) (void)hipFree(c->d_umap_frac);
     if (c->wide_exec) (void)hipGraphExecDestroy(c->wide_exec);
     if (c->h_pose) (void)hipHostFree(c->h_pose);
     for (int l = 0; l < DVO_LEVELS; l++) {

@@ -337,6 +337,59 @@ int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_leve
     return DVO_OK;
 }
 
+/* cv::undistort's map for this camera (OpenCV 2.4 undistort.cpp: undistort() + initUndistortRectifyMap(), CV_16SC2 maps).
+ * Built on the host in double precision exactly as OpenCV's CPU code does -- per stripe of min(max(1, 4096/cols), rows) rows
+ * the new camera matrix is the camera matrix with cy moved by the stripe's first row, inverted by the 3x3 adjugate formula
+ * cv::invert uses; the normalised coordinates advance by running sums along a row -- and uploaded once. */
+int dvo_frames_set_undistort(dvo_ctx *c, int rows, int cols, const double *K4, const double *D5) {
+    if (!c) return DVO_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->d_umap_xy) { (void)hipFree(c->d_umap_xy); (void)hipFree(c->d_umap_frac); c->d_umap_xy = nullptr; c->d_umap_frac = nullptr; }
+    c->umap_rows = c->umap_cols = 0;
+    if (!K4 && !D5) return DVO_OK;                         /* switched off: frames are taken as already undistorted */
+    if (!K4 || !D5 || rows < 1 || cols < 1 || !(K4[0] != 0.0) || !(K4[1] != 0.0)) return fail(c, DVO_ERR_INVALID, "bad calibration");
+    const size_t npx = (size_t)rows * cols;
+    std::vector<short> xy(2 * npx);
+    std::vector<unsigned short> fr(npx);
+    const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
+    const double k1 = D5[0], k2 = D5[1], p1 = D5[2], p2 = D5[3], k3 = D5[4];
+    int stripe0 = std::min(std::max(1, (1 << 12) / std::max(cols, 1)), rows);
+    auto cvround = [](double v) { return (int)std::lrint(v); };          /* round half to even, like cvRound */
+    for (int y0 = 0; y0 < rows; y0 += stripe0) {
+        const int n = std::min(stripe0, rows - y0);
+        /* inverse of [[fx 0 cx][0 fy cy'][0 0 1]], cy' = cy - y0, by cofactors: every entry is (minor) * (1/det) */
+        const double m[3][3] = {{fx, 0, cx}, {0, fy, cy - y0}, {0, 0, 1}};
+        const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                           m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+        const double d = 1. / det;
+        double ir[9];
+        ir[0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) * d; ir[1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) * d; ir[2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) * d;
+        ir[3] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) * d; ir[4] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) * d; ir[5] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) * d;
+        ir[6] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) * d; ir[7] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) * d; ir[8] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) * d;
+        for (int i = 0; i < n; i++) {
+            double X = i * ir[1] + ir[2], Y = i * ir[4] + ir[5], W = i * ir[7] + ir[8];
+            short *pxy = xy.data() + 2 * ((size_t)(y0 + i) * cols);
+            unsigned short *pf = fr.data() + (size_t)(y0 + i) * cols;
+            for (int j = 0; j < cols; j++, X += ir[0], Y += ir[3], W += ir[6]) {
+                const double w = 1. / W, x = X * w, y = Y * w;
+                const double x2 = x * x, y2 = y * y, r2 = x2 + y2, two_xy = 2 * x * y;
+                const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((0 * r2 + 0) * r2 + 0) * r2);
+                const double u = fx * (x * kr + p1 * two_xy + p2 * (r2 + 2 * x2)) + cx;
+                const double v = fy * (y * kr + p1 * (r2 + 2 * y2) + p2 * two_xy) + cy;
+                const int iu = cvround(u * 32), iv = cvround(v * 32);
+                pxy[2 * j] = (short)(iu >> 5); pxy[2 * j + 1] = (short)(iv >> 5);
+                pf[j] = (unsigned short)((iv & 31) * 32 + (iu & 31));
+            }
+        }
+    }
+    HIPCHK(c, hipMalloc((void **)&c->d_umap_xy, sizeof(short) * 2 * npx));
+    HIPCHK(c, hipMalloc((void **)&c->d_umap_frac, sizeof(unsigned short) * npx));
+    HIPCHK(c, hipMemcpy(c->d_umap_xy, xy.data(), sizeof(short) * 2 * npx, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_umap_frac, fr.data(), sizeof(unsigned short) * npx, hipMemcpyHostToDevice));
+    c->umap_rows = rows; c->umap_cols = cols;
+    return DVO_OK;
+}
+
 int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsigned char *const *bgr8,
                               const float *const *depth_m, int rows, int cols, int n_levels, int first_shift,
                               int now_first_pair, int flags) {
@@ -357,6 +410,8 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
     if (!slots_ok(c, first_slot, count)) return fail(c, DVO_ERR_INVALID, "frame slot range out of bounds (dvo_frames_reserve)");
     if (now_first_pair >= 0 && (!pair_ok(c, now_first_pair) || now_first_pair + count > c->n_pairs))
         return fail(c, DVO_ERR_INVALID, "now_first_pair range out of bounds");
+    if (c->d_umap_xy && (c->umap_rows != rows || c->umap_cols != cols))
+        return fail(c, DVO_ERR_INVALID, "the undistortion map was built for another image size (dvo_frames_set_undistort)");
     const size_t npx = (size_t)rows * cols;
     const size_t b_img = (npx * 3 + 15) / 16 * 16, d_img = depth_m ? npx * 4 : 0;
     const int chunk = (int)std::min<size_t>(std::max<size_t>(kUploadHalf / (b_img + d_img), 1), (size_t)count);
@@ -381,6 +436,7 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
                 const size_t off = (size_t)(first_slot + b) * F.npx;
                 if (pass == 0 || ln.parallel)
                     HIPCHK(c, launch_camera_level(sb, b_img, depth_m ? sd : nullptr, npx, rows, cols, first_shift + l,
+                                                  c->d_umap_xy, c->d_umap_frac,
                                                   F.grey + off, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, nc}, ln.s[l]));
                 if (pass == 1 || ln.parallel) {
                     if ((rc = run_canny(c, l, first_slot + b, nc, ln.s[l], ln.work[l]))) return rc;

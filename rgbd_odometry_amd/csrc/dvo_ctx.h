@@ -86,6 +86,10 @@ struct dvo_ctx {
     int *d_colcounts = nullptr;
     size_t colcounts_cap = 0;
     dvo_host::FrameStore fs;
+    /* cv::undistort of the publisher: fixed-point map of the camera's full resolution (dvo_frames_set_undistort) */
+    short2 *d_umap_xy = nullptr;
+    unsigned short *d_umap_frac = nullptr;
+    int umap_rows = 0, umap_cols = 0;
     int *work = nullptr;            /* preprocessing scratch (Canny / distance transform / point counts) */
     size_t work_bytes = 0;
     /* frame uploads: two landing buffers filled by a copy stream while the context stream preprocesses the other */

@@ -126,11 +126,28 @@ DVO_DEV float depth_m_to_mm(float d_m) {
 /* One 64 (yy) x 16 (xx) output tile per workgroup: the row-major source is read along rows (16 neighbouring lanes =
  * 16 neighbouring source pixels), the column-major result is written along columns (64 neighbouring lanes = 64
  * consecutive bytes / floats) -- the transpose goes through LDS instead of through uncoalesced global accesses. */
+/* cv::undistort of the publisher (camTopic2PublisherPyD.cpp:88-107, :306-308) folded into the level kernel: only the
+ * pixels a level keeps are remapped.  The fixed-point map (integer source pixel + 5-bit fractions, what
+ * initUndistortRectifyMap writes for CV_16SC2) is built once per calibration on the host (dvo_frames_set_undistort);
+ * here the INTER_LINEAR remap with BORDER_CONSTANT 0: 8-bit channels with the 15-bit integer weights of OpenCV's
+ * BilinearTab_i ((32-fx)(32-fy)*32 ..., weight 1.0 stored as 32767 with the missing 1 on tap (1,1)) and (sum + 2^14) >> 15;
+ * 16-bit depth with float weights, v0*w0 + v1*w1 + v2*w2 + v3*w3 left to right, cvRound. */
+struct UndistortMaps { const short2 *xy; const unsigned short *frac; };
+DVO_DEV void undistort_taps(int sx, int sy, int src_rows, int src_cols, size_t (&at)[4], bool (&in)[4]) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int yy = sy + a, xx = sx + b;
+            in[a * 2 + b] = (yy >= 0) && (yy < src_rows) && (xx >= 0) && (xx < src_cols);
+            at[a * 2 + b] = in[a * 2 + b] ? (size_t)yy * src_cols + xx : 0;
+        }
+}
 constexpr int CAM_TY = 64, CAM_TX = 16;
 __global__ void __launch_bounds__(256)
 camera_level_kernel(const unsigned char *__restrict__ bgr, size_t bgr_stride,
                     const float *__restrict__ depth_m, size_t depth_stride,
-                    int src_rows, int src_cols, int shift, int tiles_y,
+                    int src_rows, int src_cols, int shift, int tiles_y, UndistortMaps um,
                     unsigned char *__restrict__ grey, float *__restrict__ depth, size_t stride, int rows, int cols) {
     __shared__ unsigned char sg[CAM_TX][CAM_TY + 4];
     __shared__ float sd[CAM_TX][CAM_TY + 1];
@@ -148,9 +165,38 @@ camera_level_kernel(const unsigned char *__restrict__ bgr, size_t bgr_stride,
             sy = sy > src_rows - 1 ? src_rows - 1 : sy;
             sx = sx > src_cols - 1 ? src_cols - 1 : sx;
             const size_t sp = (size_t)sy * src_cols + sx;
-            const int b = bgr[3 * sp], gg = bgr[3 * sp + 1], r = bgr[3 * sp + 2];
+            int b, gg, r;
+            float dmm = 0.0f;
+            if (um.xy) {                                             /* pixel (sy, sx) of the UNDISTORTED image */
+                const short2 m = um.xy[sp];
+                const int fi = um.frac[sp], fy = fi >> 5, fx = fi & 31;
+                size_t at[4]; bool in[4];
+                undistort_taps(m.x, m.y, src_rows, src_cols, at, in);
+                int w[4] = {(32 - fy) * (32 - fx) * 32, (32 - fy) * fx * 32, fy * (32 - fx) * 32, fy * fx * 32};
+                if (fi == 0) { w[0] = 32767; w[3] = 1; }
+                int acc[3] = {0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (in[k]) { acc[0] += bgr[3 * at[k]] * w[k]; acc[1] += bgr[3 * at[k] + 1] * w[k]; acc[2] += bgr[3 * at[k] + 2] * w[k]; }
+                b = (acc[0] + (1 << 14)) >> 15; gg = (acc[1] + (1 << 14)) >> 15; r = (acc[2] + (1 << 14)) >> 15;
+                if (depth_m) {
+                    const float ty[2] = {1.0f - fy * (1.0f / 32), fy * (1.0f / 32)}, tx[2] = {1.0f - fx * (1.0f / 32), fx * (1.0f / 32)};
+                    float a4 = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float v = in[k] ? depth_m_to_mm(depth_m[at[k]]) : 0.0f;        /* depth16 is converted BEFORE it is undistorted */
+                        const float pw = v * (ty[k >> 1] * tx[k & 1]);
+                        a4 = (k == 0) ? pw : a4 + pw;
+                    }
+                    float rr = rintf(a4);
+                    dmm = rr < 0.0f ? 0.0f : (rr > 65535.0f ? 65535.0f : rr);
+                }
+            } else {
+                b = bgr[3 * sp]; gg = bgr[3 * sp + 1]; r = bgr[3 * sp + 2];
+                if (depth_m) dmm = depth_m_to_mm(depth_m[sp]);
+            }
             sg[lx][ly] = (unsigned char)((1868 * b + 9617 * gg + 4899 * r + (1 << 13)) >> 14);   /* BGR2GRAY 8u */
-            if (depth_m) sd[lx][ly] = depth_m_to_mm(depth_m[sp]);
+            if (depth_m) sd[lx][ly] = dmm;
         }
     }
     __syncthreads();
@@ -168,11 +214,12 @@ camera_level_kernel(const unsigned char *__restrict__ bgr, size_t bgr_stride,
 }
 
 hipError_t launch_camera_level(const unsigned char *bgr, size_t bgr_stride, const float *depth_m, size_t depth_stride,
-                               int src_rows, int src_cols, int shift, unsigned char *grey, float *depth_mm,
-                               size_t stride, ImgBatch g, hipStream_t s) {
+                               int src_rows, int src_cols, int shift, const short2 *umap_xy, const unsigned short *umap_frac,
+                               unsigned char *grey, float *depth_mm, size_t stride, ImgBatch g, hipStream_t s) {
     const int tiles_y = (g.rows + CAM_TY - 1) / CAM_TY, tiles_x = (g.cols + CAM_TX - 1) / CAM_TX;
+    UndistortMaps um{umap_xy, umap_frac};
     hipLaunchKernelGGL(camera_level_kernel, dim3(tiles_y * tiles_x, g.count), dim3(256), 0, s, bgr, bgr_stride, depth_m,
-                       depth_stride, src_rows, src_cols, shift, tiles_y, grey, depth_mm, stride, g.rows, g.cols);
+                       depth_stride, src_rows, src_cols, shift, tiles_y, um, grey, depth_mm, stride, g.rows, g.cols);
     return hipGetLastError();
 }
 

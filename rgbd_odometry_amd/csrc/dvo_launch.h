@@ -122,8 +122,8 @@ hipError_t launch_import_depth(const void *src, int dtype, int row_major, size_t
                                float *depth_mm, size_t stride, ImgBatch g, hipStream_t s);
 /* row f2: full-resolution BGR8 (+ depth in metres, may be NULL) row-major -> pyramid level decimated by 2^shift */
 hipError_t launch_camera_level(const unsigned char *bgr, size_t bgr_stride, const float *depth_m, size_t depth_stride,
-                               int src_rows, int src_cols, int shift, unsigned char *grey, float *depth_mm,
-                               size_t stride, ImgBatch g, hipStream_t s);
+                               int src_rows, int src_cols, int shift, const short2 *umap_xy, const unsigned short *umap_frac,
+                               unsigned char *grey, float *depth_mm, size_t stride, ImgBatch g, hipStream_t s);
 /* row f1: cv::Canny(grey, low/high as squared integer thresholds, 3, L2).  work: canny_work_ints() ints;
  * edge out: 0/255 u8 */
 size_t canny_work_ints(int rows, int cols, int count);

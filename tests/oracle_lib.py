@@ -217,10 +217,31 @@ class Oracle:
         self.lib.dvo_oracle_depth_m_to_mm16(_p(d), d.size, _p(out))
         return out
 
-    def build_pyramid(self, bgr, depth_m, n_levels=4, first_shift=1):
-        """camTopic2PublisherPyD.cpp:73-77,322-347 (no camera-info topic => undistort is a copy): per level
-        (mono8 row-major, mono16 row-major); level i is decimated by 2^(first_shift+i) from full resolution."""
+    def undistort_bgr8(self, bgr, K4, D5):
+        """cv::undistort of a rows x cols x 3 uint8 image (camTopic2PublisherPyD.cpp:88-107)"""
+        src = np.ascontiguousarray(bgr, dtype=np.uint8)
+        rows, cols = src.shape[:2]
+        out = np.zeros_like(src)
+        K, D = np.asarray(K4, np.float64).copy(), np.asarray(D5, np.float64).copy()
+        self.lib.dvo_oracle_undistort_bgr8(_p(src), rows, cols, _p(K), _p(D), _p(out))
+        return out
+
+    def undistort_u16(self, img, K4, D5):
+        src = np.ascontiguousarray(img, dtype=np.uint16)
+        rows, cols = src.shape
+        out = np.zeros_like(src)
+        K, D = np.asarray(K4, np.float64).copy(), np.asarray(D5, np.float64).copy()
+        self.lib.dvo_oracle_undistort_u16(_p(src), rows, cols, _p(K), _p(D), _p(out))
+        return out
+
+    def build_pyramid(self, bgr, depth_m, n_levels=4, first_shift=1, undistort=None):
+        """camTopic2PublisherPyD.cpp:73-77,322-347: per level (mono8 row-major, mono16 row-major); level i is decimated by
+        2^(first_shift+i) from full resolution.  undistort = (K4, D5): the camera-info topic was received, so both images
+        go through cv::undistort first (:306-308); None: undistort is a copy (:90-95)."""
         d16 = self.depth_m_to_mm16(depth_m)
+        if undistort is not None:
+            bgr = self.undistort_bgr8(bgr, *undistort)
+            d16 = self.undistort_u16(d16.reshape(np.asarray(depth_m).shape), *undistort)
         out = []
         for i in range(n_levels):
             s = 0.5 ** (first_shift + i)
@@ -320,6 +341,10 @@ def load() -> Oracle:
         lib.dvo_oracle_resize_nn.restype = None
         lib.dvo_oracle_depth_m_to_mm16.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         lib.dvo_oracle_depth_m_to_mm16.restype = None
+        lib.dvo_oracle_undistort_bgr8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.dvo_oracle_undistort_bgr8.restype = None
+        lib.dvo_oracle_undistort_u16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.dvo_oracle_undistort_u16.restype = None
         for n in ("se3_exp", "se3_log"):
             getattr(lib, "dvo_oracle_" + n).argtypes = [C.c_void_p] * 3
         lib.dvo_oracle_rotationize.argtypes = [C.c_void_p]

@@ -98,3 +98,33 @@ def test_gpu_reproduces_frames_golden(golden):
                 for got, key in zip(ctx.get_now_level(l), ("dt", "gx", "gy")):
                     assert np.array_equal(got, golden[f"{name}_L{l}_{key}"]), (name, l, key)
                 assert np.array_equal(ctx.get_ref_level(l), golden[f"{name}_L{l}_xyz"])
+
+
+def test_undistort_restatement(oracle):
+    """cv::undistort restated (OpenCV 2.4: stripes, adjugate inverse, running sums, 5-bit fixed-point map, BilinearTab_i / _f):
+    zero distortion is the identity; with distortion the result equals a float bilinear interpolation (scipy) taken at the
+    map's own 1/32-pixel coordinates, to within the final rounding"""
+    from scipy.ndimage import map_coordinates
+    rows, cols = 96, 128
+    ys, xs = np.mgrid[0:rows, 0:cols].astype(float)
+    img = np.stack([128 + 100 * np.sin(xs / 9) * np.cos(ys / 7), xs + ys, 128 + 60 * np.cos(xs / 13 + ys / 5)], -1).clip(0, 255).astype(np.uint8)
+    d16 = (1000 + 500 * np.sin(xs / 20) + 300 * np.cos(ys / 15)).astype(np.uint16)
+    K = (120.0, 118.0, 63.5, 47.5)
+    assert np.array_equal(oracle.undistort_bgr8(img, K, (0, 0, 0, 0, 0)), img)
+    assert np.array_equal(oracle.undistort_u16(d16, K, (0, 0, 0, 0, 0)), d16)
+    D = (0.1, -0.05, 0.001, -0.002, 0.01)
+    x = (xs - K[2]) / K[0]; y = (ys - K[3]) / K[1]; r2 = x * x + y * y
+    kr = 1 + ((D[4] * r2 + D[1]) * r2 + D[0]) * r2
+    u = K[0] * (x * kr + D[2] * 2 * x * y + D[3] * (r2 + 2 * x * x)) + K[2]
+    v = K[1] * (y * kr + D[2] * (r2 + 2 * y * y) + D[3] * 2 * x * y) + K[3]
+    uq, vq = np.round(u * 32) / 32, np.round(v * 32) / 32
+    inside = (uq >= 0) & (uq <= cols - 1) & (vq >= 0) & (vq <= rows - 1)
+    out = oracle.undistort_bgr8(img, K, D).astype(float)
+    ref = np.stack([map_coordinates(img[..., c].astype(float), [vq, uq], order=1, mode="constant", cval=0) for c in range(3)], -1)
+    assert inside.mean() > 0.9 and np.abs(out - ref)[inside].max() <= 0.5 + 1e-3
+    o16 = oracle.undistort_u16(d16, K, D).astype(float)
+    r16 = map_coordinates(d16.astype(float), [vq, uq], order=1, mode="constant", cval=0)
+    assert np.abs(o16 - r16)[inside].max() <= 0.5 + 1e-2
+    # where the map leaves the source the constant border 0 comes out (strong pincushion: the corners sample far outside)
+    far = oracle.undistort_bgr8(np.full_like(img, 200), K, (5.0, 0, 0, 0, 0))
+    assert far[0, 0].max() == 0 and far[-1, -1].max() == 0 and far[rows // 2, cols // 2].min() == 200

@@ -37,6 +37,41 @@ def test_camera_pyramid_matches_oracle(oracle, shape, first_shift, levels):
             assert ne == int((edge > 0).sum())
 
 
+@pytest.mark.parametrize("shape,first_shift,levels,K,D", [
+    ((480, 640), 1, 4, (525.0, 525.0, 319.5, 239.5), (0.12, -0.25, 0.0012, -0.0009, 0.11)),       # Xtion-like calibration
+    ((480, 640), 0, 3, (517.3, 516.5, 318.6, 255.3), (0.2624, -0.9531, -0.0054, 0.0026, 1.1633)),  # TUM freiburg1 camera_info
+    ((241, 323), 1, 3, (260.0, 262.0, 160.2, 119.1), (-0.3, 0.1, 0.002, 0.001, -0.02)),            # barrel, odd size, stripes of 12 rows
+    ((97, 131), 0, 2, (100.0, 101.0, 65.0, 48.0), (0.0, 0.0, 0.0, 0.0, 0.0)),                      # zero distortion = identity map
+])
+def test_undistorted_camera_pyramid_matches_oracle(oracle, shape, first_shift, levels, K, D):
+    """cv::undistort of the publisher (camTopic2PublisherPyD.cpp:88-107, :306-308) folded into the pyramid kernel: bgr and
+    the 16-bit depth are remapped with OpenCV's fixed-point bilinear tables; bit-equal to the oracle's restatement"""
+    bgr, depth = frame_gen.camera_frame(5, *shape)
+    ref = oracle.build_pyramid(bgr, depth, levels, first_shift, undistort=(K, D))
+    plain = oracle.build_pyramid(bgr, depth, levels, first_shift)
+    with _ctx() as ctx:
+        ctx.frames_set_undistort(shape[0], shape[1], K, D)
+        ctx.frames_upload_cameras([bgr], [depth], n_levels=levels, first_shift=first_shift)
+        for l, (g, d16) in enumerate(ref):
+            grey, dep, edge, ne = ctx.frame_level(0, l)
+            assert np.array_equal(grey, g), f"grey level {l}: {np.abs(grey.astype(int) - g.astype(int)).max()}"
+            assert np.array_equal(dep, d16.astype(np.float32)), f"depth level {l}"
+            assert np.array_equal(edge, oracle.canny(g)), f"canny level {l}"
+        if any(D):
+            assert not np.array_equal(ref[0][0], plain[0][0])          # the map really moves pixels
+        else:
+            assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(ref, plain))
+        # another image size is refused; switching off restores the plain pyramid
+        from rgbd_odometry_amd import DvoError
+        with pytest.raises(DvoError):
+            ctx.frames_upload_cameras([bgr[:-2]], [depth[:-2]], n_levels=levels, first_shift=first_shift)
+        ctx.frames_set_undistort(0, 0, None, None)
+        ctx.frames_upload_cameras([bgr], [depth], n_levels=levels, first_shift=first_shift)
+        for l, (g, d16) in enumerate(plain):
+            grey, dep, _, _ = ctx.frame_level(0, l)
+            assert np.array_equal(grey, g) and np.array_equal(dep, d16.astype(np.float32))
+
+
 def _canny_images():
     rng = np.random.default_rng(7)
     yield "noise", rng.integers(0, 256, (75, 101)).astype(np.uint8)
