@@ -294,7 +294,9 @@ int  dvo_point_iterations(dvo_ctx *ctx, int pair, int n_levels, const int *iters
 enum { DVO_PIX_U8 = 0, DVO_PIX_U16 = 1, DVO_PIX_F32 = 2 };
 enum { DVO_LAYOUT_COL_MAJOR = 0,    /* Eigen (im_n[level].data()): (yy,xx) at yy + xx*rows */
        DVO_LAYOUT_ROW_MAJOR = 1 };  /* cv::Mat / sensor_msgs::Image: (yy,xx) at yy*cols + xx */
-enum { DVO_UPLOAD_ASYNC = 1 };      /* do not wait for the copies: host buffers stay borrowed until dvo_synchronize() */
+enum { DVO_UPLOAD_ASYNC = 1,        /* do not wait for the copies: host buffers stay borrowed until dvo_synchronize() */
+       DVO_UPLOAD_DEPTH_RAW = 2 };  /* dvo_frames_upload_cameras: the depth images are already in sensor units (what a mono16 depth topic
+                                       carries, as float): no x1000, no rounding, no 0 -> 1 -- what the rgbdSubsc node works on */
 
 typedef struct dvo_image {          /* one single-channel host image */
     const void *data;
@@ -337,6 +339,42 @@ int  dvo_frames_as_ref(dvo_ctx *ctx, int first_slot, int first_pair, int count, 
 int  dvo_frame_get_level(dvo_ctx *ctx, int slot, int level, int *rows, int *cols, unsigned char *grey,
                          float *depth_mm, unsigned char *edge, int *n_edges);
 int  dvo_frames_num_levels(const dvo_ctx *ctx);
+
+/* ---- the legacy photometric Gauss-Newton odometry: the engine behind RGBDOdometry -----------
+ * RGBDOdometry (include/RGBDOdometry.h:41-43, src/RGBDOdometry.cpp) aligns intensities instead of edge distances: per
+ * reference frame a semi-dense Jacobian J (pixels with x-gradient >= 5) and A = J^T J per pyramid level (:363-508); per new
+ * frame and level up to three iterations of eps_i = I_ref(i) - I_now(warp(i, T)), b = -J^T eps, A psi = b by
+ * colPivHouseholderQr, T = T exp(psi)^-1 (:514-700), levels 3 then 2 (:162-163).  All in double, like the reference.
+ *
+ * The reference code has defects.  `fixed` = 0 (default) REPRODUCES its arithmetic as written, so that a user
+ * of the rgbdSubsc node gets that node's numbers; `fixed` = 1 corrects: D1 tJ(0) = fx*fx/Z -> fx*gx/Z (:485); D2 tJ(5)'s
+ * second term fx*gy*Y/Z -> fx*gx*Y/Z (:490); D4 level-0 intrinsics at every level -> scaled by 2^-level (:475-476);
+ * D7 exponentialMap dropping the translation when |w| < 1e-12 (:727-731).  Kept in both modes: D3 the transposed image
+ * convention (X from the row index with cx, fx, :475/:661/:683 -- self-consistent), D5 depth and translation in sensor units
+ * (mm), D6 the selection rule gx >= 5, D8 the absolute stop threshold |eps| < 200 (:556).
+ * Frames live in the frame store: upload them with dvo_frames_upload_cameras(..., n_levels = 4, first_shift = 0,
+ * flags | DVO_UPLOAD_DEPTH_RAW) -- the node's own INTER_NEAREST pyramid of the full-resolution frame (:316-318, :347-350). */
+typedef struct dvo_photo_params {
+    double fx, fy, cx, cy;        /* cameraMatrix of params.xml, level 0                       RGBDOdometry.cpp:59-62 */
+    int    gradient_threshold;    /* const_gradientThreshold = 5                               :32 */
+    int    max_jacobian_size;     /* const_maxJacobianSize = 50000 (more selected pixels: error, the reference asserts :464) */
+    int    min_required_pts;      /* const_minimumRequiredPts = 100 (fewer: error, :500)        :34 */
+    int    iterations;            /* 3                                                          :545 */
+    double eps_norm_stop;         /* 200.0                                                      :556 */
+    int    fixed;                 /* 0 = the reference's arithmetic, 1 = defects D1 D2 D4 D7 corrected */
+    int    reserved;
+} dvo_photo_params;
+int  dvo_photo_params_default(dvo_photo_params *p);
+int  dvo_photo_configure(dvo_ctx *ctx, const dvo_photo_params *p);
+/* setRefFrame + computeJacobianAllLevels (:296-327, :363-398) for levels first_level .. n_levels-1 of stored frame `slot`
+ * (the reference: first_level = 1).  n_selected[n_levels] (may be NULL) receives the rows of J per level. */
+int  dvo_photo_set_ref(dvo_ctx *ctx, int slot, int first_level, int *n_selected);
+/* gaussNewtonIterations(level, T) (:514-597) for levels[0], levels[1], ... in that order (the reference: {3, 2}, :162-163) on
+ * stored frame `now_slot`.  T16: TransformRep::matrix(), 4x4 row-major, in/out.  eps_norms[n_run * iterations]: |eps| of every
+ * iteration (-1 where not run); updates[n_run]: iterations that changed T.  Both may be NULL. */
+int  dvo_photo_align(dvo_ctx *ctx, int now_slot, const int *levels, int n_run, double *T16, double *eps_norms, int *updates);
+/* inspection: J (n x 6 row-major), selected pixels (row, column) and A = J^T J (6x6) of a reference level */
+int  dvo_photo_get_jacobian(dvo_ctx *ctx, int level, double *J, int *sel_i, int *sel_j, int capacity, double *A36, int *n_out);
 
 #ifdef __cplusplus
 }

@@ -179,6 +179,22 @@ void dvo_oracle_depth_m_to_mm16(const float *depth_m, size_t npx, unsigned short
 void dvo_oracle_undistort_bgr8(const unsigned char *src, int rows, int cols, const double *K4, const double *D5, unsigned char *dst);
 void dvo_oracle_undistort_u16(const unsigned short *src, int rows, int cols, const double *K4, const double *D5, unsigned short *dst);
 
+/* ---- row f4 / A14: the legacy photometric Gauss-Newton odometry, RGBDOdometry (src/RGBDOdometry.cpp:363-746), restated in
+ * dvo_oracle_photo.cpp (PARITY UNPINNED; `fixed` = 0 reproduces the reference's defects, 1 corrects them -- see the .cpp).
+ * Images row-major like cv::Mat; depth in sensor units; T 4x4 row-major (Eigen::Transform<double,3,Affine>::matrix()). */
+int dvo_oracle_photo_jacobian(const unsigned char *grey, const unsigned short *depth, int rows, int cols, int level,
+                              double fx, double fy, double cx, double cy, int fixed, double grad_threshold, int capacity,
+                              double *J, int *sel_i, int *sel_j, double *A36);
+double dvo_oracle_photo_epsilon(const unsigned char *grey_ref, const unsigned short *depth_ref, const unsigned char *grey_now,
+                                int rows, int cols, int level, double fx, double fy, double cx, double cy, int fixed,
+                                const int *sel_i, const int *sel_j, int n, const double *T16, double *eps);
+int dvo_oracle_photo_gauss_newton(const unsigned char *grey_ref, const unsigned short *depth_ref, const unsigned char *grey_now,
+                                  int rows, int cols, int level, double fx, double fy, double cx, double cy, int fixed,
+                                  const double *J, const int *sel_i, const int *sel_j, int n, const double *A36,
+                                  int max_iters, double eps_stop, double *T16, double *eps_norms);
+void dvo_oracle_photo_exponential_map(const double *psi6, int fixed, double *out16);
+void dvo_oracle_photo_solve6(const double *A36, const double *b6, double *x6);
+
 /* Helpers exported for property tests. */
 float dvo_oracle_weight(float r);                                   /* :1047-1053 */
 float dvo_oracle_interpolate(const float *F, int rows, int cols, float ry, float rx); /* :1285-1308 */

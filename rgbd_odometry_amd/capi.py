@@ -32,13 +32,15 @@ C_ABI_SYMBOLS = [
     "dvo_device_se3_log", "dvo_device_rotationize", "dvo_algorithmic_bytes", "dvo_point_iterations",
     "dvo_debug_stamps", "dvo_get_level_texel_mode", "dvo_replicate_pairs", "dvo_set_now_level_from_edges", "dvo_get_now_level", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
     "dvo_align_pyramid_wide", "dvo_tiled_attach", "dvo_tiled_detach", "dvo_align_pyramid_tiled",
-    "dvo_get_ref_level", "dvo_frames_reserve", "dvo_frames_upload_pyramids", "dvo_frames_upload_cameras", "dvo_frames_set_undistort", "dvo_frames_as_now",
+    "dvo_get_ref_level", "dvo_frames_reserve", "dvo_frames_upload_pyramids", "dvo_frames_upload_cameras", "dvo_frames_set_undistort",
+    "dvo_photo_params_default", "dvo_photo_configure", "dvo_photo_set_ref", "dvo_photo_align", "dvo_photo_get_jacobian", "dvo_frames_as_now",
     "dvo_frames_as_ref", "dvo_frame_get_level", "dvo_frames_num_levels",
 ]
 
 DVO_PIX_U8, DVO_PIX_U16, DVO_PIX_F32 = 0, 1, 2
 DVO_LAYOUT_COL_MAJOR, DVO_LAYOUT_ROW_MAJOR = 0, 1
 DVO_UPLOAD_ASYNC = 1
+DVO_UPLOAD_DEPTH_RAW = 2
 
 
 class DvoImage(C.Structure):
@@ -58,6 +60,13 @@ class DvoParams(C.Structure):
         ("lds_point_bytes", C.c_int), ("debug_alias_mod", C.c_int),
         ("canny_threshold1", C.c_int), ("canny_threshold2", C.c_int), ("team_size", C.c_int),
     ]
+
+
+class DvoPhotoParams(C.Structure):
+    """Mirror of ``struct dvo_photo_params`` (defaults = the constants of RGBDOdometry.cpp:32-34, :545, :556)."""
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("gradient_threshold", C.c_int), ("max_jacobian_size", C.c_int), ("min_required_pts", C.c_int),
+                ("iterations", C.c_int), ("eps_norm_stop", C.c_double), ("fixed", C.c_int), ("reserved", C.c_int)]
 
 
 class RcclComm:
@@ -200,6 +209,11 @@ def load_library() -> C.CDLL:
         "dvo_iter_end": [vp, i, i, vp, vp, vp, ip, fp],
         "dvo_align_pyramid_wide": [vp, i, i, ip, vp, vp],
         "dvo_frames_set_undistort": [vp, i, i, vp, vp],
+        "dvo_photo_params_default": [C.POINTER(DvoPhotoParams)],
+        "dvo_photo_configure": [vp, C.POINTER(DvoPhotoParams)],
+        "dvo_photo_set_ref": [vp, i, i, ip],
+        "dvo_photo_align": [vp, i, ip, i, vp, vp, ip],
+        "dvo_photo_get_jacobian": [vp, i, vp, vp, vp, i, vp, ip],
         "dvo_tiled_attach": [vp, vp, i, i, C.c_char_p],
         "dvo_tiled_detach": [vp],
         "dvo_align_pyramid_tiled": [vp, i, i, ip, vp, vp],
@@ -547,6 +561,36 @@ class DvoContext:
         K = np.asarray(K4, np.float64).copy(); D = np.asarray(D5, np.float64).copy()
         assert K.size == 4 and D.size == 5
         self._chk(self.lib.dvo_frames_set_undistort(self._h, rows, cols, _ptr(K), _ptr(D)))
+
+    # -- photometric Gauss-Newton (RGBDOdometry's engine) ------------------------
+    def photo_configure(self, K, fixed: bool = False, **overrides):
+        p = DvoPhotoParams()
+        self.lib.dvo_photo_params_default(C.byref(p))
+        p.fx, p.fy, p.cx, p.cy = (float(k) for k in K)
+        p.fixed = int(fixed)
+        for k, v in overrides.items():
+            setattr(p, k, v)
+        self._chk(self.lib.dvo_photo_configure(self._h, C.byref(p)))
+        self._photo_iters = p.iterations
+
+    def photo_set_ref(self, slot: int, first_level: int = 1):
+        n = (C.c_int * DVO_MAX_LEVELS)()
+        self._chk(self.lib.dvo_photo_set_ref(self._h, slot, first_level, n))
+        return list(n)
+
+    def photo_align(self, now_slot: int, T, levels=(3, 2)):
+        T = np.array(T, dtype=np.float64, order="C").copy()
+        lv = (C.c_int * len(levels))(*levels)
+        norms = np.zeros((len(levels), getattr(self, "_photo_iters", 3)), np.float64)
+        upd = (C.c_int * len(levels))()
+        self._chk(self.lib.dvo_photo_align(self._h, now_slot, lv, len(levels), _ptr(T), _ptr(norms), upd))
+        return T, norms, list(upd)
+
+    def photo_jacobian(self, level: int, capacity: int = 50000):
+        J = np.zeros((capacity, 6), np.float64); si = np.zeros(capacity, np.int32); sj = np.zeros(capacity, np.int32)
+        A = np.zeros((6, 6), np.float64); n = C.c_int(0)
+        self._chk(self.lib.dvo_photo_get_jacobian(self._h, level, _ptr(J), _ptr(si), _ptr(sj), capacity, _ptr(A), C.byref(n)))
+        return dict(J=J[:n.value].copy(), sel_i=si[:n.value].copy(), sel_j=sj[:n.value].copy(), A=A, n=n.value)
 
     # -- tiled mode driven from C (RCCL) ---------------------------------------
     def tiled_attach(self, comm, rank: int, world: int, rccl_library: Optional[str] = None):

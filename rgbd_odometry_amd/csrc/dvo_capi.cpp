@@ -412,6 +412,7 @@ int dvo_destroy(dvo_ctx *c) {
         if (c->lv[l].dN) (void)hipFree(c->lv[l].dN);
     }
     tiled_forget(c);
+    photo_forget(c);
     for (int l = 0; l < DVO_LEVELS; l++) {
         FrameLevel &F = c->fs.lv[l];
         void *fp[] = {F.grey, F.edge, F.depth};

@@ -436,7 +436,7 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
                 const size_t off = (size_t)(first_slot + b) * F.npx;
                 if (pass == 0 || ln.parallel)
                     HIPCHK(c, launch_camera_level(sb, b_img, depth_m ? sd : nullptr, npx, rows, cols, first_shift + l,
-                                                  c->d_umap_xy, c->d_umap_frac,
+                                                  c->d_umap_xy, c->d_umap_frac, (flags & DVO_UPLOAD_DEPTH_RAW) ? 1 : 0,
                                                   F.grey + off, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, nc}, ln.s[l]));
                 if (pass == 1 || ln.parallel) {
                     if ((rc = run_canny(c, l, first_slot + b, nc, ln.s[l], ln.work[l]))) return rc;

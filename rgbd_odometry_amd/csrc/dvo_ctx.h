@@ -103,6 +103,7 @@ struct dvo_ctx {
     /* small batches (a single camera stream): the pyramid levels are independent kernel chains, run side by side */
     hipStream_t lvl_stream[DVO_LEVELS] = {};
     hipEvent_t ev_fork = nullptr, ev_join[DVO_LEVELS] = {};
+    struct dvo_photo_state *photo = nullptr;     /* dvo_capi_photo.cpp: the photometric engine's reference data */
     dvo::Schedule sched{};
     bool have_sched = false;
     /* which pairs the per-pair outputs (energies, final outputs) currently describe: the output buffers are laid out by
@@ -136,7 +137,8 @@ int check_ready(dvo_ctx *c, int pair, int level);
 int build_schedule(dvo_ctx *c, int n_levels, const int *iters, int flags, dvo::Schedule &sc);
 int ensure_outputs(dvo_ctx *c, const dvo::Schedule &sc);
 void stamp_outputs(dvo_ctx *c, const dvo::Schedule &sc, int first, int n);
-void tiled_forget(dvo_ctx *c);          /* dvo_capi_tiled.cpp: drop the RCCL attachment of a context */
+void tiled_forget(dvo_ctx *c);
+void photo_forget(dvo_ctx *c);           /* dvo_capi_photo.cpp */          /* dvo_capi_tiled.cpp: drop the RCCL attachment of a context */
 
 }  // namespace dvo_host
 #endif

@@ -132,7 +132,7 @@ DVO_DEV float depth_m_to_mm(float d_m) {
  * here the INTER_LINEAR remap with BORDER_CONSTANT 0: 8-bit channels with the 15-bit integer weights of OpenCV's
  * BilinearTab_i ((32-fx)(32-fy)*32 ..., weight 1.0 stored as 32767 with the missing 1 on tap (1,1)) and (sum + 2^14) >> 15;
  * 16-bit depth with float weights, v0*w0 + v1*w1 + v2*w2 + v3*w3 left to right, cvRound. */
-struct UndistortMaps { const short2 *xy; const unsigned short *frac; };
+struct UndistortMaps { const short2 *xy; const unsigned short *frac; int depth_raw; /* depth already in sensor units: taken as is */ };
 DVO_DEV void undistort_taps(int sx, int sy, int src_rows, int src_cols, size_t (&at)[4], bool (&in)[4]) {
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -184,7 +184,7 @@ camera_level_kernel(const unsigned char *__restrict__ bgr, size_t bgr_stride,
                     float a4 = 0.0f;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const float v = in[k] ? depth_m_to_mm(depth_m[at[k]]) : 0.0f;        /* depth16 is converted BEFORE it is undistorted */
+                        const float v = in[k] ? (um.depth_raw ? depth_m[at[k]] : depth_m_to_mm(depth_m[at[k]])) : 0.0f;   /* depth16 is converted BEFORE it is undistorted */
                         const float pw = v * (ty[k >> 1] * tx[k & 1]);
                         a4 = (k == 0) ? pw : a4 + pw;
                     }
@@ -193,7 +193,7 @@ camera_level_kernel(const unsigned char *__restrict__ bgr, size_t bgr_stride,
                 }
             } else {
                 b = bgr[3 * sp]; gg = bgr[3 * sp + 1]; r = bgr[3 * sp + 2];
-                if (depth_m) dmm = depth_m_to_mm(depth_m[sp]);
+                if (depth_m) dmm = um.depth_raw ? depth_m[sp] : depth_m_to_mm(depth_m[sp]);
             }
             sg[lx][ly] = (unsigned char)((1868 * b + 9617 * gg + 4899 * r + (1 << 13)) >> 14);   /* BGR2GRAY 8u */
             if (depth_m) sd[lx][ly] = dmm;
@@ -215,9 +215,9 @@ camera_level_kernel(const unsigned char *__restrict__ bgr, size_t bgr_stride,
 
 hipError_t launch_camera_level(const unsigned char *bgr, size_t bgr_stride, const float *depth_m, size_t depth_stride,
                                int src_rows, int src_cols, int shift, const short2 *umap_xy, const unsigned short *umap_frac,
-                               unsigned char *grey, float *depth_mm, size_t stride, ImgBatch g, hipStream_t s) {
+                               int depth_raw, unsigned char *grey, float *depth_mm, size_t stride, ImgBatch g, hipStream_t s) {
     const int tiles_y = (g.rows + CAM_TY - 1) / CAM_TY, tiles_x = (g.cols + CAM_TX - 1) / CAM_TX;
-    UndistortMaps um{umap_xy, umap_frac};
+    UndistortMaps um{umap_xy, umap_frac, depth_raw};
     hipLaunchKernelGGL(camera_level_kernel, dim3(tiles_y * tiles_x, g.count), dim3(256), 0, s, bgr, bgr_stride, depth_m,
                        depth_stride, src_rows, src_cols, shift, tiles_y, um, grey, depth_mm, stride, g.rows, g.cols);
     return hipGetLastError();

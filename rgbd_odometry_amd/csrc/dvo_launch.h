@@ -123,7 +123,7 @@ hipError_t launch_import_depth(const void *src, int dtype, int row_major, size_t
 /* row f2: full-resolution BGR8 (+ depth in metres, may be NULL) row-major -> pyramid level decimated by 2^shift */
 hipError_t launch_camera_level(const unsigned char *bgr, size_t bgr_stride, const float *depth_m, size_t depth_stride,
                                int src_rows, int src_cols, int shift, const short2 *umap_xy, const unsigned short *umap_frac,
-                               unsigned char *grey, float *depth_mm, size_t stride, ImgBatch g, hipStream_t s);
+                               int depth_raw, unsigned char *grey, float *depth_mm, size_t stride, ImgBatch g, hipStream_t s);
 /* row f1: cv::Canny(grey, low/high as squared integer thresholds, 3, L2).  work: canny_work_ints() ints;
  * edge out: 0/255 u8 */
 size_t canny_work_ints(int rows, int cols, int count);
@@ -145,6 +145,16 @@ hipError_t launch_enlist_write(const void *edge, int edge_is_u8, size_t edge_str
                                size_t depth_stride, ImgBatch g, int level, const Intrinsics &K, const int *col_counts,
                                float *xyz, size_t xyz_stride, uint2 *compact /* same stride in points / 3, or nullptr */,
                                float *uv, int capacity, int *N_dst, hipStream_t s);
+
+/* ---- photometric Gauss-Newton (dvo_photo.hip): RGBDOdometry's engine ---- */
+hipError_t launch_photo_reference(const unsigned char *grey, const float *depth, int rows, int cols, int level,
+                                  double fx, double fy, double cx, double cy, int fixed, double grad_threshold, int capacity,
+                                  int *col_work /* 2*(cols+1) ints */, double *J, int *sel, double *zref, float *gref, double *A36,
+                                  int *n_out, hipStream_t s);
+hipError_t launch_photo_gauss_newton(const double *J, const int *sel, const double *zref, const float *gref, const int *n_dev,
+                                     const double *A36, const unsigned char *grey_now, int rows, int cols, int level,
+                                     double fx, double fy, double cx, double cy, int fixed, int max_iters, double eps_stop,
+                                     double *T16, double *eps_norms, int *updates, double *eps_dump, hipStream_t s);
 
 }  // namespace dvo
 #endif

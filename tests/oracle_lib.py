@@ -268,6 +268,62 @@ class Oracle:
         xyz, uv = self.enlist_ref_points(level, edge_cm, depth_cm, rows, cols, K)
         return xyz, uv, edge_cm
 
+    # ---- photometric Gauss-Newton (RGBDOdometry, src/RGBDOdometry.cpp:363-746) ----
+    def photo_jacobian(self, grey, depth16, level, K, fixed=False, grad_threshold=5.0, capacity=50000):
+        g = np.ascontiguousarray(grey, np.uint8); d = np.ascontiguousarray(depth16, np.uint16)
+        rows, cols = g.shape
+        J = np.zeros((capacity, 6), np.float64); si = np.zeros(capacity, np.int32); sj = np.zeros(capacity, np.int32)
+        A = np.zeros((6, 6), np.float64)
+        n = self.lib.dvo_oracle_photo_jacobian(_p(g), _p(d), rows, cols, level, *[C.c_double(k) for k in K], int(fixed),
+                                               C.c_double(grad_threshold), capacity, _p(J), _p(si), _p(sj), _p(A))
+        if n < 0:
+            raise RuntimeError("more than %d selected pixels (RGBDOdometry.cpp:464 asserts)" % capacity)
+        return dict(J=J[:n].copy(), sel_i=si[:n].copy(), sel_j=sj[:n].copy(), A=A, n=n)
+
+    def photo_epsilon(self, grey_ref, depth_ref, grey_now, level, K, jac, T, fixed=False):
+        gr = np.ascontiguousarray(grey_ref, np.uint8); dr = np.ascontiguousarray(depth_ref, np.uint16)
+        gn = np.ascontiguousarray(grey_now, np.uint8)
+        rows, cols = gr.shape
+        T = np.ascontiguousarray(T, np.float64)
+        eps = np.zeros(max(jac["n"], 1), np.float64)
+        self.lib.dvo_oracle_photo_epsilon.restype = C.c_double
+        nrm = self.lib.dvo_oracle_photo_epsilon(_p(gr), _p(dr), _p(gn), rows, cols, level, *[C.c_double(k) for k in K], int(fixed),
+                                                _p(jac["sel_i"]), _p(jac["sel_j"]), jac["n"], _p(T), _p(eps))
+        return eps[:jac["n"]], nrm
+
+    def photo_gauss_newton(self, grey_ref, depth_ref, grey_now, level, K, jac, T, fixed=False, max_iters=3, eps_stop=200.0):
+        gr = np.ascontiguousarray(grey_ref, np.uint8); dr = np.ascontiguousarray(depth_ref, np.uint16)
+        gn = np.ascontiguousarray(grey_now, np.uint8)
+        rows, cols = gr.shape
+        T = np.array(T, np.float64, order="C").copy()
+        norms = np.zeros(max_iters, np.float64)
+        J = np.ascontiguousarray(jac["J"], np.float64)
+        nu = self.lib.dvo_oracle_photo_gauss_newton(_p(gr), _p(dr), _p(gn), rows, cols, level, *[C.c_double(k) for k in K], int(fixed),
+                                                    _p(J), _p(jac["sel_i"]), _p(jac["sel_j"]), jac["n"], _p(np.ascontiguousarray(jac["A"])),
+                                                    max_iters, C.c_double(eps_stop), _p(T), _p(norms))
+        return T, norms, nu
+
+    def photo_exponential_map(self, psi, fixed=False):
+        out = np.zeros((4, 4), np.float64)
+        self.lib.dvo_oracle_photo_exponential_map(_p(np.asarray(psi, np.float64).copy()), int(fixed), _p(out))
+        return out
+
+    def photo_solve6(self, A, b):
+        x = np.zeros(6, np.float64)
+        self.lib.dvo_oracle_photo_solve6(_p(np.ascontiguousarray(A, np.float64)), _p(np.asarray(b, np.float64).copy()), _p(x))
+        return x
+
+    def photo_track(self, ref_pyr, now_pyr, K, T0=None, fixed=False):
+        """eventLoop's per-frame work (:162-163): gaussNewtonIterations(3, T); gaussNewtonIterations(2, T) -- pyramids are lists of
+        (grey u8, depth u16) row-major for levels 0..3 (setRefFrame / setNowFrame, :296-357)"""
+        T = np.eye(4) if T0 is None else np.array(T0, np.float64)
+        rep = {}
+        for level in (3, 2):
+            jac = self.photo_jacobian(ref_pyr[level][0], ref_pyr[level][1], level, K, fixed)
+            T, norms, nu = self.photo_gauss_newton(ref_pyr[level][0], ref_pyr[level][1], now_pyr[level][0], level, K, jac, T, fixed)
+            rep[level] = dict(norms=norms, updates=nu, n=jac["n"])
+        return T, rep
+
     def se3_exp(self, psi):
         psi = np.array(psi, dtype=np.float64)
         R, t = np.zeros((3, 3), order="F"), np.zeros(3)
