@@ -226,7 +226,8 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
     for (int l = 0; l < DVO_LEVELS; l++) ls.l[l] = slab_of(c, l);
     int block = c->prm.block_threads;
     int auto_lds = 0;
-    if (block != 256 && block != 512 && block != 1024) {
+    const bool block_auto = (block != 256 && block != 512 && block != 1024);
+    if (block_auto) {
         /* auto: when the longest point list of the launch fits half a CU's LDS, two 256-thread workgroups
          * per CU overlap each other's serial phases (measured: 320x240x4x50 213 k -> 288 k aligns/s); otherwise
          * one 512-thread workgroup owns the CU and its LDS (640x480: 386 k vs 374 k) */
@@ -257,6 +258,9 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         }
         /* the CU has 160 KiB of LDS; the static part of the chosen kernel comes off the top */
         const bool packed = sc.compact && c->prm.engine_variant != 1 && !(sc.flags & DVO_FLAG_NORMAL_MATRIX);
+        /* the packed kernel needs its 256-register budget: 1024 threads would halve it (measured, 1920x1080x5, 256 pairs:
+         * 512 threads 45.2 k aligns/s, 1024 threads 41.3 k; the one-point-per-lane kernel: 43.7 k at 1024) */
+        if (packed && block_auto && block == 1024) block = 512;
         const int static_lds = packed ? (int)fused2_static_lds(block) : (int)(sizeof(double) * (block / 64) * DVO_NACC_PAD + 256 + pose_state_bytes());
         const int max_dyn = 160 * 1024 - static_lds - 64;
         if (bytes > max_dyn) bytes = max_dyn;
