@@ -23,8 +23,8 @@
  *   dvo_amd::GOP<T>                 include/GOP.h, src/GOP.cpp:138-196 (key-frame relative -> global pose chain)
  *   dvo_amd::PyramidalStorageStruct include/PyramidalStorage.h:37-78 (addLevel/getLevel/clearPyramid/printSize):
  *                                   here the per-level container of the now-frame pyramid
- *   dvo_amd::RGBDOdometry           include/RGBDOdometry.h:41-43: the legacy photometric node; only the
- *                                   class surface is kept (its arithmetic is out of scope)
+ *   dvo_amd::RGBDOdometry           include/RGBDOdometry.h:41-43: the legacy photometric Gauss-Newton node, on the engine's
+ *                                   dvo_photo_* entry points (rows A14 / f4)
  *
  * Error behaviour: the reference asserts (NDEBUG is force-undefined, SolveDVO.h:124); these classes
  * throw std::runtime_error carrying dvo_last_error().
@@ -62,21 +62,50 @@ struct ImageI {
     ImageI(int r, int c) : rows(r), cols(c), data((size_t)r * c, 0) {}
 };
 
-/* Per-level container of the now-frame pyramid {DT, dDT/dx, dDT/dy}. */
+/* cv::Mat / Eigen stand-ins of the legacy photometric path (row-major 8/16-bit images like cv::Mat; column-major double
+ * arrays like Eigen::ArrayXXd / MatrixXd) */
+struct ImageU8 { int rows = 0, cols = 0, channels = 1; std::vector<unsigned char> data; };      /* CV_8UC1 / CV_8UC3 */
+struct ImageU16 { int rows = 0, cols = 0; std::vector<unsigned short> data; };                  /* CV_16UC1 */
+struct ArrayD { int rows = 0, cols = 0; std::vector<double> data; };                            /* Eigen::ArrayXXd / MatrixXd */
+
+/* include/PyramidalStorage.h:37-78.  Two uses:
+ *  - the reference's own 11-field per-level record of the photometric estimators (im_r_color, im_r, dim_r, X, Y, Z, J,
+ *    grayVals, redVals, greenVals, blueVals): addLevel pushes deep copies and ignores its level argument
+ *    (PyramidalStorage.cpp:37-65), getLevel copies them back out (:71-102), clearPyramid, printSize (:105-127);
+ *  - the 3-image form {DT, dDT/dx, dDT/dy} SolveDVO::setNowFrame of this header takes (SolveDVO itself keeps
+ *    std::vector<Eigen::MatrixXf> members; the container shape is kept for both). */
 class PyramidalStorageStruct {
 public:
-    void addLevel(int /*level: ignored like the reference, PyramidalStorage.cpp:37*/, const ImageF &dt,
-                  const ImageF &gx, const ImageF &gy) {
-        dt_.push_back(dt); gx_.push_back(gx); gy_.push_back(gy);
+    void addLevel(int /*level: ignored, PyramidalStorage.cpp:37*/, const ImageU8 &im_r_color, const ImageU8 &im_r, const ImageU16 &dim_r,
+                  const ArrayD &X, const ArrayD &Y, const ArrayD &Z, const ArrayD &J,
+                  const ArrayD &grayVals, const ArrayD &redVals, const ArrayD &greenVals, const ArrayD &blueVals) {
+        im_r_color_.push_back(im_r_color); im_r_.push_back(im_r); dim_r_.push_back(dim_r);
+        X_.push_back(X); Y_.push_back(Y); Z_.push_back(Z); J_.push_back(J);
+        gray_.push_back(grayVals); red_.push_back(redVals); green_.push_back(greenVals); blue_.push_back(blueVals);
     }
-    void getLevel(int level, ImageF &dt, ImageF &gx, ImageF &gy) const {
-        dt = dt_.at(level); gx = gx_.at(level); gy = gy_.at(level);
+    void getLevel(int level, ImageU8 &im_r_color, ImageU8 &im_r, ImageU16 &dim_r, ArrayD &X, ArrayD &Y, ArrayD &Z, ArrayD &J,
+                  ArrayD &grayVals, ArrayD &redVals, ArrayD &greenVals, ArrayD &blueVals) const {
+        im_r_color = im_r_color_.at(level); im_r = im_r_.at(level); dim_r = dim_r_.at(level);         /* deep copies, :85-99 */
+        X = X_.at(level); Y = Y_.at(level); Z = Z_.at(level); J = J_.at(level);
+        grayVals = gray_.at(level); redVals = red_.at(level); greenVals = green_.at(level); blueVals = blue_.at(level);
     }
-    void clearPyramid() { dt_.clear(); gx_.clear(); gy_.clear(); }
-    void printSize() const { std::printf("PyramidalStorageStruct: %zu levels\n", dt_.size()); }
+    void addLevel(int /*level*/, const ImageF &dt, const ImageF &gx, const ImageF &gy) { dt_.push_back(dt); gx_.push_back(gx); gy_.push_back(gy); }
+    void getLevel(int level, ImageF &dt, ImageF &gx, ImageF &gy) const { dt = dt_.at(level); gx = gx_.at(level); gy = gy_.at(level); }
+    void clearPyramid() {
+        dt_.clear(); gx_.clear(); gy_.clear();
+        im_r_color_.clear(); im_r_.clear(); dim_r_.clear(); X_.clear(); Y_.clear(); Z_.clear(); J_.clear();
+        gray_.clear(); red_.clear(); green_.clear(); blue_.clear();
+    }
+    void printSize() const {                            /* PyramidalStorage.cpp:125-127 prints the vector sizes */
+        std::printf("PyramidalStorageStruct: %zu DT levels, %zu photometric levels\n", dt_.size(), im_r_.size());
+    }
     size_t size() const { return dt_.size(); }
+    size_t photometricLevels() const { return im_r_.size(); }
 private:
     std::vector<ImageF> dt_, gx_, gy_;
+    std::vector<ImageU8> im_r_color_, im_r_;
+    std::vector<ImageU16> dim_r_;
+    std::vector<ArrayD> X_, Y_, Z_, J_, gray_, red_, green_, blue_;
 };
 
 /* geometry_msgs::Pose stand-in */
@@ -402,6 +431,28 @@ public:
     long nFrame = 0, lastRefFrame = 0;
     int keyFrameEvery = 5;                                                         /* (nFrame - lastRefFrame) == 5  :2156 */
 
+    /* casualTestFunction (:2377-2442), the reference's only two-frame regression of the hot path: frame `refFile` as the
+     * reference frame, `nowFile` as the now frame (TUM_RGBD/fr1_rpy/framemono_0080.xml and _0085.xml there, not shipped),
+     * runIterations(0, 100, ...) from the identity (:2426); returns the 100 energies it prints (:2438-2441) */
+    std::vector<float> casualTestFunction(const char *refFile, const char *nowFile, int level = 0, int iterations = 100,
+                                          bool print = true) {
+        const int nl = (int)iterationsConfig.size();        /* levels per frame file (4 in the reference) */
+        need(loadFromFile(refFile, nl), "casualTestFunction: cannot read the reference frame file");
+        setRcvdFrameAsRefFrame();
+        preProcessRefFrame();
+        need(loadFromFile(nowFile, nl), "casualTestFunction: cannot read the now frame file");
+        setRcvdFrameAsNowFrame();
+        identityPose();
+        std::vector<float> energy, eps, reproj;
+        int best = -1; float ratio = 0;
+        runIterations(level, iterations, cR_64, cT_64, energy, eps, reproj, best, ratio);
+        if (print) {
+            for (size_t i = 0; i < energy.size(); i++) std::printf("%zu: %f\n", i, energy[i]);
+            std::printf("best %d, visible ratio %f\n", best, ratio);
+        }
+        return energy;
+    }
+
     /* frame loop hooks of the reference; the ROS node keeps its own loop() */
     void loopDry() {}
     void loopFromFile() { throw std::runtime_error("loopFromFile: body is commented out in the reference too (SolveDVO.cpp:2444-2678)"); }
@@ -423,14 +474,115 @@ private:
     int rcvd_slot_ = -1, ref_slot_ = -1, now_slot_ = -1, prev_slot_ = -1;
 };
 
-/* Legacy photometric Gauss-Newton node (rgbdSubsc).  Only the class surface is kept; see SURVEY.md 2.1. */
+/* The legacy photometric Gauss-Newton node (rgbdSubsc): include/RGBDOdometry.h:41-43, src/RGBDOdometry.cpp.  Same method names
+ * and per-frame sequence as the reference's eventLoop (:128-211), on the engine's dvo_photo_* entry points; the transport
+ * (ROS topics in, odom / path / pose out) stays with the caller, who feeds frames and receives the pose eventLoop publishes.
+ * The reference's arithmetic -- defects included -- is the default; RGBDOdometry(true) selects the corrected estimator
+ * (the decision per defect: include/dvo_amd.h at dvo_photo_params). */
 class RGBDOdometry {
 public:
-    RGBDOdometry() {}
-    void eventLoop() {
-        throw std::runtime_error("RGBDOdometry::eventLoop: the legacy photometric path is outside the MI355X engine's "
-                                 "scope (SURVEY.md 2.1); use dvo_amd::SolveDVO");
+    typedef double TransformRep[16];                 /* Eigen::Transform<double,3,Affine>::matrix(), row-major (RGBDOdometry.h:33) */
+
+    explicit RGBDOdometry(bool fixedDefects = false) : fixed_(fixedDefects) {
+        if (dvo_create(nullptr, &ctx_) != DVO_OK) throw std::runtime_error(std::string("dvo_create: ") + dvo_last_error(nullptr));
+        identity(T_); identity(base_);
     }
+    ~RGBDOdometry() { dvo_destroy(ctx_); }
+    RGBDOdometry(const RGBDOdometry &) = delete;
+    RGBDOdometry &operator=(const RGBDOdometry &) = delete;
+
+    /* setCameraMatrix (:42-68) keeps fx, fy, cx, cy of params.xml's cameraMatrix */
+    void setCameraMatrix(double fx, double fy, double cx, double cy) {
+        dvo_photo_params p;
+        dvo_photo_params_default(&p);
+        p.fx = fx; p.fy = fy; p.cx = cx; p.cy = cy; p.fixed = fixed_ ? 1 : 0;
+        chk(dvo_photo_configure(ctx_, &p));
+        cameraIntrinsicsReady = true;
+    }
+    /* imageArrivedCallBack: the received colour frame (bgr8, rows x cols x 3 row-major) and depth frame (sensor units) */
+    void setRcvdFrame(const unsigned char *bgr8, const unsigned short *depth, int rows, int cols) {
+        rcvd_bgr_.assign(bgr8, bgr8 + (size_t)rows * cols * 3);
+        rcvd_depth_.assign(depth, depth + (size_t)rows * cols);                  /* -> float, taken as is (DVO_UPLOAD_DEPTH_RAW) */
+        rows_ = rows; cols_ = cols;
+        isFrameAvailable = true;
+    }
+    void setRefFrame() { upload(0); isRefFrameAvailable = isPyramidalRefFrameAvailable = true; isJacobiansAvailable = false; }   /* :296-327 */
+    void setNowFrame() { upload(1); isNowFrameAvailable = isPyramidalNowFrameAvailable = true; }                                /* :329-357 */
+    void computeJacobianAllLevels() {                                            /* :363-398: levels 1..3 */
+        need(isPyramidalRefFrameAvailable && cameraIntrinsicsReady, "computeJacobianAllLevels: reference frame / intrinsics missing");
+        chk(dvo_photo_set_ref(ctx_, 0, 1, nSelected));
+        isJacobiansAvailable = true;
+    }
+    void gaussNewtonIterations(int level, TransformRep &T) {                     /* :514-597 */
+        need(isPyramidalRefFrameAvailable && isPyramidalNowFrameAvailable && isJacobiansAvailable, "gaussNewtonIterations: frames / Jacobians missing");
+        need(level != 0, "Critical error, jacobians at level-0 (base) are not computed for complexity reasons");   /* :518 */
+        chk(dvo_photo_align(ctx_, 1, &level, 1, T, lastEpsNorms, &lastUpdates));
+    }
+    /* the body of eventLoop's while (:138-207) for one received frame; returns what it publishes: position = 1000 * translation
+     * of base*T (:185-187), orientation = the quaternion of its rotation (:182, :188-191) */
+    Pose processFrame() {
+        need(isFrameAvailable, "processFrame: no frame received");
+        if ((nFrame % refEvery) == 0) {                                          /* :146 ("renew ref-frame every 30 frames": % 10000) */
+            mul(base_, T_, base_);                                               /* base = base * T */
+            setRefFrame();
+            identity(T_);
+            computeJacobianAllLevels();
+        }
+        setNowFrame();
+        gaussNewtonIterations(3, T_);                                            /* :162 */
+        gaussNewtonIterations(2, T_);                                            /* :163 */
+        double S[16];
+        mul(base_, T_, S);                                                       /* toSend = base * T :178 */
+        double Rc[9];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rc[i + 3 * j] = S[i * 4 + j];
+        Pose p;
+        quaternionFromMatrix<double>(Rc, p.qx, p.qy, p.qz, p.qw);
+        p.px = 1000 * S[3]; p.py = 1000 * S[7]; p.pz = 1000 * S[11];
+        nFrame++;
+        isFrameAvailable = false;
+        return p;
+    }
+    /* eventLoop (:128-211) without ROS: pull frames from `next` until it returns false, hand every pose to `publish` */
+    template <typename NextFrame, typename Publish>
+    void eventLoop(NextFrame next, Publish publish) {
+        std::vector<unsigned char> bgr; std::vector<unsigned short> depth; int rows = 0, cols = 0;
+        while (next(bgr, depth, rows, cols)) {
+            setRcvdFrame(bgr.data(), depth.data(), rows, cols);
+            publish(processFrame());
+        }
+    }
+    const double *T() const { return T_; }
+    long nFrame = 0;
+    int refEvery = 10000;                            /* :146 */
+    int nSelected[DVO_MAX_LEVELS] = {0};             /* rows of J per level */
+    double lastEpsNorms[64] = {0};
+    int lastUpdates = 0;
+    dvo_ctx *handle() { return ctx_; }
+
+private:
+    void chk(int rc) { if (rc != DVO_OK) throw std::runtime_error(dvo_last_error(ctx_)); }
+    static void need(bool ok, const char *what) { if (!ok) throw std::runtime_error(what); }
+    static void identity(double *T) { for (int k = 0; k < 16; k++) T[k] = (k % 5 == 0) ? 1.0 : 0.0; }
+    static void mul(const double *A, const double *B, double *C) {
+        double t[16];
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { double s = 0; for (int k = 0; k < 4; k++) s += A[i * 4 + k] * B[k * 4 + j]; t[i * 4 + j] = s; }
+        for (int k = 0; k < 16; k++) C[k] = t[k];
+    }
+    void upload(int slot) {                          /* 4 levels, INTER_NEAREST at 1, 1/2, 1/4, 1/8 (:313-324, :346-355) */
+        need(isFrameAvailable, "Frame not retrived");
+        std::vector<float> d(rcvd_depth_.begin(), rcvd_depth_.end());
+        const unsigned char *b = rcvd_bgr_.data();
+        const float *dp = d.data();
+        chk(dvo_frames_upload_cameras(ctx_, slot, 1, &b, &dp, rows_, cols_, 4, 0, -1, DVO_UPLOAD_DEPTH_RAW));
+    }
+    dvo_ctx *ctx_ = nullptr;
+    bool fixed_ = false;
+    double T_[16], base_[16];
+    std::vector<unsigned char> rcvd_bgr_;
+    std::vector<unsigned short> rcvd_depth_;
+    int rows_ = 0, cols_ = 0;
+    bool cameraIntrinsicsReady = false, isFrameAvailable = false, isRefFrameAvailable = false, isNowFrameAvailable = false;
+    bool isPyramidalRefFrameAvailable = false, isPyramidalNowFrameAvailable = false, isJacobiansAvailable = false;
 };
 
 }  // namespace dvo_amd
