@@ -29,7 +29,7 @@ import torch  # imported before the HIP library on purpose: one HIP runtime per 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak ~6290
 
 #: the sources the fused alignment kernels are built from: their hash ties profiles/pmc_traffic.json to a kernel build
-KERNEL_SOURCES = ["dvo_fused.hip", "dvo_point_pk.h", "dvo_kernels.hip", "dvo_kernel_common.h", "dvo_device_math.h", "dvo_launch.h"]
+KERNEL_SOURCES = ["dvo_fused.hip", "dvo_point_pk.h", "dvo_kernels.hip", "dvo_kernel_common.h", "dvo_device_math.h"]
 
 
 def kernel_source_hash():
@@ -275,7 +275,8 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": None,
-                "kernel": "align_fused_kernel", "kernel_ms": kernel_ms,
+                "kernel": "align_fused2_kernel<512,false> (packed, two points per lane; dvo_fused.hip)" if not (args.variant == 1 or args.normal_matrix)
+                          else "align_fused_kernel (one point per lane; dvo_kernels.hip)", "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "algorithmic_bytes_per_alignment": bytes_per_launch / args.batch,
             },
@@ -296,7 +297,7 @@ def main():
         elif not default_knobs:
             reason = "non-default engine knobs: the PMC record describes the default launch"
         elif rec.get("kernel_source_sha256") != kernel_source_hash():
-            reason = "PMC record was measured on another kernel build (source hash %s, now %s): re-run tools/pmc_traffic.sh" % (
+            reason = "PMC record was measured on another kernel build (source hash %s, now %s): re-run tools/update_pmc_traffic.py on the GPU box" % (
                 rec.get("kernel_source_sha256"), kernel_source_hash())
         if reason is None:
             out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
