@@ -282,25 +282,29 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
     c->team_used = false;
     if (sc.compact && c->prm.engine_variant != 1 && !(sc.flags & DVO_FLAG_NORMAL_MATRIX) && block == 512 && c->prm.team_size != 1) {
         const int slots8 = 8 * ((n_pairs + 7) / 8);
-        /* a member needs ~1000 points of the finest level to pay for the exchange (measured: 640x480, 14.8 k points: 8 members
-         * 0.237 ms, 4: 0.254, 16: 0.251, none: 0.395; 320x240 x 50 iterations, 4.2 k points: no team size beats none) */
+        /* a team pays when the point phase it splits is longer than the exchange it adds (~2.2 us per iteration).  Measured,
+         * one pair, ms per alignment by team size (tools/exp_team_single.py): 640x480x4x10 (14.8 k points at level 0) 1: 0.39,
+         * 2: 0.34, 4: 0.30, 8: 0.28, 16: 0.30; 1920x1080x5 (130 k) 8: 0.55, 16: 0.47, 32: 0.49; 4096x3072x5 (629 k) 16: 1.03,
+         * 32: 0.85; 320x240x4x50 (4.2 k) 1: 0.91, 2: 1.00, 4: 0.98.  Hence: no team below 5000 points, then double while every
+         * member keeps >= 1800 points of the finest level; at most 8 (16 from 64 k points, 32 = a whole XCD from 256 k). */
         int n_fine = 0;
         for (int p = first_pair; p < first_pair + n_pairs; p++) n_fine = std::max(n_fine, c->lv[sc.last_level].hN[p]);
-        const int g_cap = (n_fine >= 65536) ? 16 : 8;
+        const int g_cap = (n_fine >= 262144) ? 32 : ((n_fine >= 65536) ? 16 : 8);
         int g = 1;
-        while (g * 2 <= g_cap && slots8 * g * 2 <= c->n_cu && n_fine >= 1024 * g * 2) g *= 2;
+        if (n_fine >= 5000)
+            while (g * 2 <= g_cap && slots8 * g * 2 <= c->n_cu && n_fine >= 1800 * g * 2) g *= 2;
         if (c->prm.team_size > 1) {
             g = c->prm.team_size;
-            if (g > 16 || slots8 * g > c->n_cu)
+            if (g > 32 || slots8 * g > c->n_cu)
                 return fail(c, DVO_ERR_INVALID, "team_size: the launch would need more workgroups than compute units (members must be co-resident)");
         }
         if (g > 1) {
             if (!c->d_team_buf) {
-                HIPCHK(c, hipMalloc((void **)&c->d_team_buf, 16 * 2 * 16 * 8 * (size_t)c->n_pairs));     /* 16-byte records */
+                HIPCHK(c, hipMalloc((void **)&c->d_team_buf, 16 * 2 * 32 * 8 * (size_t)c->n_pairs));     /* 16-byte records, [2][32][8] per pair */
                 HIPCHK(c, hipMalloc((void **)&c->d_team_cnt, sizeof(unsigned) * ((size_t)c->n_pairs + 1)));
             }
             HIPCHK(c, hipMemsetAsync(c->d_team_cnt, 0, sizeof(unsigned) * ((size_t)c->n_pairs + 1), c->stream));
-            HIPCHK(c, hipMemsetAsync(c->d_team_buf, 0, 16 * 2 * 16 * 8 * (size_t)n_pairs, c->stream));       /* tags of an earlier launch */
+            HIPCHK(c, hipMemsetAsync(c->d_team_buf, 0, 16 * 2 * 32 * 8 * (size_t)n_pairs, c->stream));       /* tags of an earlier launch */
             sc.team = g;
             c->team_used = true;
         }

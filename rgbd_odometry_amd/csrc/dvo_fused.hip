@@ -233,7 +233,7 @@ DVO_DEV void block_reduce7(const Acc7 &a, double (*red)[8], double *tot) {
  * only reach exchange e+2 after all members have passed e+1, i.e. after everybody has read the slots of e.
  * All G*pairs workgroups must be resident at once (the host launches at most one per CU); a bounded spin turns a broken
  * assumption into an error flag instead of a hang. */
-#define DVO_TEAM_MAX 16
+#define DVO_TEAM_MAX 32
 /* One exchange, executed by wave 0 of every member.  Each of a member's 8 sums travels as a 16-byte record {value, tag}
  * (tag = exchange index + 1) written with ONE 16-byte store, so a reader that sees the tag sees the value: no separate
  * arrival counter, no wait for store acknowledgements, no fences.  All accesses are agent-scope atomics (sc1: coherent
@@ -261,20 +261,26 @@ DVO_DEV void team_exchange(double *tot, v4u *buf /* this pair's [2][DVO_TEAM_MAX
         rec.x = (unsigned)bits; rec.y = tag; rec.z = (unsigned)(bits >> 32); rec.w = tag;
         team_store_rec(base + member * 8 + lane, rec);
     }
-    const int n_rec = G * 8;                       /* <= 128: lane L polls records L and L + 64 */
-    const bool has0 = lane < n_rec, has1 = lane + 64 < n_rec;
-    v4u r0 = {0u, tag, 0u, tag}, r1 = {0u, tag, 0u, tag};
+    const int n_rec = G * 8;                       /* <= 256: lane L polls records L, L + 64, L + 128, L + 192 */
+    v4u r[4];
     int spins = 0;
     for (;;) {
-        if (has0) r0 = team_load_rec(base + lane);
-        if (has1) r1 = team_load_rec(base + lane + 64);
-        const bool ok = (r0.y == tag) && (r0.w == tag) && (r1.y == tag) && (r1.w == tag);
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (lane + 64 * q < n_rec) {
+                r[q] = team_load_rec(base + lane + 64 * q);
+                ok = ok && (r[q].y == tag) && (r[q].w == tag);
+            }
+        }
         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
         if (++spins > (1 << 21)) { if (lane == 0) *err = 1; break; }       /* seconds: a member is not resident -- report, do not hang */
         __builtin_amdgcn_s_sleep(1);
     }
-    if (has0) stage[lane >> 3][lane & 7] = __longlong_as_double((long long)(((unsigned long long)r0.z << 32) | r0.x));
-    if (has1) stage[(lane >> 3) + 8][lane & 7] = __longlong_as_double((long long)(((unsigned long long)r1.z << 32) | r1.x));
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (lane + 64 * q < n_rec)
+            stage[(lane >> 3) + 8 * q][lane & 7] = __longlong_as_double((long long)(((unsigned long long)r[q].z << 32) | r[q].x));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      /* same wave: the LDS writes are done */
     if (lane == 0) {
         double s[8];

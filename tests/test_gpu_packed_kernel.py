@@ -194,7 +194,7 @@ def test_config4_batch_of_distinct_640x480_pairs(oracle):
         assert np.array_equal(R, R2) and np.array_equal(t, t2)
 
 
-@pytest.mark.parametrize("n_pairs,team", [(1, 0), (1, 2), (3, 4), (5, 8), (9, 16), (12, 0), (32, 0), (8, 16)])
+@pytest.mark.parametrize("n_pairs,team", [(1, 0), (1, 2), (3, 4), (5, 8), (9, 16), (12, 0), (32, 0), (8, 16), (2, 32)])
 def test_team_mode_small_batches(oracle, n_pairs, team):
     """small batches: G workgroups share each pair (contiguous shares of every level's points, sums exchanged through L2,
     identical update on every member) -- same bits as the oracle, for every team size and for pair counts that are not

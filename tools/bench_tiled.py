@@ -58,6 +58,20 @@ if world == 1:
     out["wide_us_per_iteration"] = 1e6 * dtw / sum(iters)
     out["wide_algorithmic_GBps"] = out["algorithmic_bytes"] / dtw / 1e9
     out["wide_vs_tiled_pose_maxdiff"] = float(max(np.abs(Rw - res["R"]).max(), np.abs(tw - res["t"]).max()))
+if world == 1:
+    # the C-driven tiled entry point with a raw RCCL communicator (world size 1: measures the per-iteration cost of the collective
+    # enqueued from C next to the graph-replayed wide path)
+    from rgbd_odometry_amd.capi import RcclComm
+    comm = RcclComm(RcclComm.unique_id(), 0, 1)
+    ctx.tiled_attach(comm.comm, 0, 1, RcclComm.RCCL)
+    Rt, tt = ctx.align_pyramid_tiled(iters, np.eye(3), np.zeros(3))
+    t0 = time.perf_counter()
+    for _ in range(args.steps): Rt, tt = ctx.align_pyramid_tiled(iters, np.eye(3), np.zeros(3))
+    dtc = (time.perf_counter() - t0) / args.steps
+    out["tiled_from_c_ms"] = 1e3 * dtc
+    out["tiled_from_c_us_per_iteration"] = 1e6 * dtc / sum(iters)
+    out["tiled_from_c_vs_wide_pose_maxdiff"] = float(max(np.abs(Rt - Rw).max(), np.abs(tt - tw).max()))
+    ctx.tiled_detach(); comm.close()
 if args.fused and world == 1:
     ctx.use_own_stream()
     R, t = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
