@@ -83,6 +83,7 @@ def build_batch(ctx, args, rank):
             ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols, pair=i)   # GPU enlistRefEdgePts
             ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols, pair=i)
     ctx.replicate_pairs(D)          # slots D.. <- device copies of the D distinct pairs (own HBM each)
+    ctx.now_prepare()               # "inputs resident": the engine's compact form of the now levels is part of residency
     ctx.synchronize()
     return scenes
 

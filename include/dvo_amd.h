@@ -84,7 +84,8 @@ typedef struct dvo_params {
     int    points_in_flight;   /* engine tuning: reference points per lane and pipeline stage (1/2/4; 0 = default 1) */
     int    engine_variant;     /* engine tuning / diagnostics: 0 = auto; 1 = always the one-point-per-lane fused kernel;
                                   2 = packed kernel, but never stage a now level into LDS; 3 = packed kernel with every wave
-                                  forced through its literal-division fallback (tests) */
+                                  forced through its literal-division fallback (tests); 4 = packed kernel, but never the
+                                  compact form of a now level (dvo_now_prepare) */
     int    lds_point_bytes;    /* engine tuning: LDS bytes per workgroup for the level's resident point list
                                   (0 = auto from block_threads, < 0 = none) */
     int    debug_alias_mod;    /* diagnostics only: if > 0, pair p reads the inputs of pair p % debug_alias_mod
@@ -263,8 +264,24 @@ int  dvo_device_rotationize(dvo_ctx *ctx, double *R);
 /* Where the fused kernel read the now level of (pair, level) from in the last batch launch that used the packed kernel:
  * 0 = 16-byte texels gathered from HBM/L2, 1 = the level's texels staged once per level into LDS ("LDS-staged image
  * tiles": the reference re-copies the three images every iteration, SolveDVO.cpp:310,316-317,427) -- taken when the whole
- * level fits beside its point list; -1 = not run.  Inspection / tests. */
+ * level fits beside its point list; 2 = the level's compact form (below); -1 = not run.  Inspection / tests. */
 int  dvo_get_level_texel_mode(dvo_ctx *ctx, int pair, int level, int *mode);
+
+/* Compact form of resident now levels (engine detail, results are bit-identical with or without it).  The three images the
+ * reference keeps per now level (dist transform :1768-1795, its imageGradient :1063-1098; the weight :1047-1053 is a function
+ * of the first) are redundant: a pixel is described by the rank of its distance value among the image's distinct values and
+ * the ranks of its four neighbours.  The engine derives a 4-byte-per-pixel form from that (24 pixels per 128-byte memory
+ * line instead of 8 -> half the memory requests of the alignment kernel), VERIFIES per pixel that it reproduces the resident
+ * {DT, gx, gy, w} bit for bit, and otherwise keeps reading the 16-byte form for that pair and level (caller-supplied
+ * gradients that are not imageGradient(DT), more than 4096 distinct values, ...).  It is built automatically the second time a
+ * resident now level is aligned (a level aligned once does not repay the build, ~50 us per 640x480 level on one compute
+ * unit); dvo_now_prepare builds it now for every resident now level of the given pairs (batch / benchmark set-up:
+ * "inputs resident").  dvo_params.engine_variant = 4 disables it. */
+int  dvo_now_prepare(dvo_ctx *ctx, int first_pair, int count);
+/* palette_size: > 0 number of distinct distance values of the compact form, 0 not built (yet / stale),
+ * < 0 no compact form: -1 negative/inf/nan value, -2 more than 4096 distinct values, -3 rank step beyond +-127,
+ * -4 gradient is not imageGradient(DT), -5 weight is not getWeightOf(DT), -6 image narrower than 2 pixels */
+int  dvo_get_now_compact_info(dvo_ctx *ctx, int pair, int level, int *palette_size);
 
 /* Diagnostic builds only (make STAMPS=1): per-level phase cycle counters of `pair`,
  * out64[level*8 + {0: per-point loop, 1: reduction, 2: pose update, 3: barrier, 4: iterations}];

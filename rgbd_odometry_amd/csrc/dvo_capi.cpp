@@ -13,6 +13,7 @@
  * allocations (~1.7 GB of texels) instead of 2048 small ones.
  */
 #include "dvo_ctx.h"
+#include "dvo_palette.h"
 
 using namespace dvo;
 
@@ -87,6 +88,8 @@ int ensure_texels(dvo_ctx *c, int level, int rows, int cols) {
         HIPCHK(c, hipFree(L.tex));
         L.tex = nullptr;
         std::fill(L.have_now.begin(), L.have_now.end(), 0);
+        if (L.p4) { (void)hipFree(L.p4); (void)hipFree(L.pal); (void)hipFree(L.d_pal_n); L.p4 = nullptr; L.pal = nullptr; L.d_pal_n = nullptr; }
+        L.pal_built.clear(); L.now_uses.clear();
     }
 
     L.rows = rows; L.cols = cols;
@@ -94,6 +97,43 @@ int ensure_texels(dvo_ctx *c, int level, int rows, int cols) {
     HIPCHK(c, hipMalloc((void **)&L.tex, sizeof(float4) * L.tex_stride * c->n_pairs));
     if (L.tex_stride != (size_t)rows * cols)      /* tile padding is never read, but keep it defined */
         HIPCHK(c, hipMemsetAsync(L.tex, 0, sizeof(float4) * L.tex_stride * c->n_pairs, c->stream));
+    return DVO_OK;
+}
+
+int now_written(dvo_ctx *c, int level, int first_pair, int count) {
+    Level &L = c->lv[level];
+    if (L.pal_built.empty()) { L.pal_built.assign(c->n_pairs, 0); L.now_uses.assign(c->n_pairs, 0); }
+    for (int p = first_pair; p < first_pair + count; ) {
+        L.have_now[p] = 1; L.now_uses[p] = 0;
+        if (!L.pal_built[p]) { p++; continue; }
+        int q = p;                                  /* a run of pairs whose compact form just went stale: the kernel must not read it */
+        while (q < first_pair + count && L.pal_built[q]) { L.pal_built[q] = 0; L.have_now[q] = 1; L.now_uses[q] = 0; q++; }
+        HIPCHK(c, hipMemsetAsync(L.d_pal_n + p, 0, sizeof(int) * (size_t)(q - p), c->stream));
+        p = q;
+    }
+    return DVO_OK;
+}
+
+int build_compact_now(dvo_ctx *c, int level, int first_pair, int count, bool only_reused) {
+    Level &L = c->lv[level];
+    if (!L.tex || L.have_now.empty()) return DVO_OK;
+    if (L.pal_built.empty()) { L.pal_built.assign(c->n_pairs, 0); L.now_uses.assign(c->n_pairs, 0); }
+    for (int p = first_pair; p < first_pair + count; ) {
+        auto wanted = [&](int i) { return L.have_now[i] && !L.pal_built[i] && (!only_reused || L.now_uses[i] >= 1); };
+        if (!wanted(p)) { p++; continue; }
+        int q = p;
+        while (q < first_pair + count && wanted(q)) q++;
+        if (!L.p4) {
+            L.p4_stride = p4_count(L.rows, L.cols);
+            HIPCHK(c, hipMalloc((void **)&L.p4, sizeof(unsigned) * L.p4_stride * c->n_pairs));
+            HIPCHK(c, hipMalloc((void **)&L.pal, sizeof(float2) * DVO_PAL_MAX * (size_t)c->n_pairs));
+            HIPCHK(c, hipMalloc((void **)&L.d_pal_n, sizeof(int) * (size_t)c->n_pairs));
+            HIPCHK(c, hipMemsetAsync(L.d_pal_n, 0, sizeof(int) * (size_t)c->n_pairs, c->stream));
+        }
+        HIPCHK(c, launch_palette_build(L.tex, L.tex_stride, L.rows, L.cols, L.p4, L.p4_stride, L.pal, L.d_pal_n, p, q - p, c->stream));
+        for (int i = p; i < q; i++) L.pal_built[i] = 1;
+        p = q;
+    }
     return DVO_OK;
 }
 
@@ -108,6 +148,7 @@ LevelSlab slab_of(const dvo_ctx *c, int level) {
     LevelSlab s;
     s.tex = L.tex; s.pts = L.pts; s.cpts = L.cpts; s.N = L.dN;
     s.tex_stride = L.tex_stride; s.pt_cap = L.pt_cap; s.rows = L.rows; s.cols = L.cols;
+    s.p4 = L.p4; s.pal = L.pal; s.pal_n = L.d_pal_n; s.p4_stride = L.p4_stride;
     return s;
 }
 
@@ -268,6 +309,18 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         bytes &= ~63;
         sc.lds_bytes = bytes;
         sc.no_lds_tex = (c->prm.engine_variant == 2) ? 1 : 0;
+        sc.no_p4 = (c->prm.engine_variant == 4 || !packed || compact_now_policy() == 2) ? 1 : 0;
+        /* compact form of the now levels (dvo_palette.h): built for a level the second time it is aligned (or up front by
+         * dvo_now_prepare) -- a now level aligned once does not repay the build */
+        if (!sc.no_p4) {
+            for (int l = 0; l < n_levels; l++) {
+                if (sc.iters[l] <= 0) continue;
+                if ((rc = build_compact_now(c, l, first_pair, n_pairs, compact_now_policy() != 1))) return rc;
+                Level &L = c->lv[l];
+                for (int p = first_pair; p < first_pair + n_pairs; p++) L.now_uses[p]++;
+            }
+            for (int l = 0; l < DVO_LEVELS; l++) ls.l[l] = slab_of(c, l);       /* the build may have allocated */
+        }
         sc.force_exact = (c->prm.engine_variant == 3) ? 1 : 0;
         sc.lds_points = bytes / (sc.compact ? 8 : 12);
         if (c->prm.lds_point_bytes < 0) { sc.lds_points = 0; sc.lds_bytes = 0; }
@@ -418,6 +471,7 @@ int dvo_destroy(dvo_ctx *c) {
         if (c->lv[l].pts) (void)hipFree(c->lv[l].pts);
         if (c->lv[l].cpts) (void)hipFree(c->lv[l].cpts);
         if (c->lv[l].dN) (void)hipFree(c->lv[l].dN);
+        if (c->lv[l].p4) { (void)hipFree(c->lv[l].p4); (void)hipFree(c->lv[l].pal); (void)hipFree(c->lv[l].d_pal_n); }
     }
     tiled_forget(c);
     photo_forget(c);
@@ -527,17 +581,20 @@ int dvo_set_ref_level_from_images(dvo_ctx *c, int pair, int level, const int32_t
     int32_t *d_edge = (int32_t *)c->staging;
     float *d_depth = c->staging + npx;
     float *d_uv = c->staging + 2 * npx;
-    if ((size_t)cols + 2 > c->colcounts_cap) {
+    const size_t cc_ints = (size_t)cols + 2 + enlist_block_ints(rows, cols);      /* column counters | block-order counters */
+    if (cc_ints > c->colcounts_cap) {
         if (c->d_colcounts) HIPCHK(c, hipFree(c->d_colcounts));
-        HIPCHK(c, hipMalloc((void **)&c->d_colcounts, sizeof(int) * ((size_t)cols + 2)));
-        c->colcounts_cap = (size_t)cols + 2;
+        c->d_colcounts = nullptr; c->colcounts_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_colcounts, sizeof(int) * cc_ints));
+        c->colcounts_cap = cc_ints;
     }
+    int *d_blk = compact_block_order() ? c->d_colcounts + cols + 2 : nullptr;
     HIPCHK(c, hipMemcpyAsync(d_edge, edge, npx * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_depth, depth_mm, npx * 4, hipMemcpyHostToDevice, c->stream));
     /* pass 1: count on the device, read N, grow the slab; pass 2: write */
     const ImgBatch gb{rows, cols, 1};
     int *d_N = c->d_colcounts + cols + 1;
-    HIPCHK(c, launch_enlist_count(d_edge, 0, 0, d_depth, 0, gb, c->d_colcounts, c->stream));
+    HIPCHK(c, launch_enlist_count(d_edge, 0, 0, d_depth, 0, gb, c->d_colcounts, d_blk, c->stream));
     int N = 0;
     HIPCHK(c, hipMemcpyAsync(&N, d_N, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -546,7 +603,7 @@ int dvo_set_ref_level_from_images(dvo_ctx *c, int pair, int level, const int32_t
     if ((rc = ensure_points(c, level, N))) return rc;
     Level &L = c->lv[level];
     float *dst = L.pts + (size_t)pair * L.pt_cap * 3;
-    HIPCHK(c, launch_enlist_write(d_edge, 0, 0, d_depth, 0, gb, level, c->K, c->d_colcounts, dst, 0,
+    HIPCHK(c, launch_enlist_write(d_edge, 0, 0, d_depth, 0, gb, level, c->K, c->d_colcounts, d_blk, dst, 0,
                                   L.cpts + (size_t)pair * L.pt_cap, d_uv, N, nullptr, c->stream));
     L.compact_ok[pair] = 1;
     L.hN[pair] = N;
@@ -579,7 +636,7 @@ static int set_now_common(dvo_ctx *c, int pair, int level, const float *dt, cons
         s_dt = c->staging; s_gx = c->staging + npx; s_gy = c->staging + 2 * npx;
     }
     HIPCHK(c, launch_pack_texels(s_dt, s_gx, s_gy, L.tex + (size_t)pair * L.tex_stride, rows, cols, c->stream));
-    L.have_now[pair] = 1;
+    if ((rc = now_written(c, level, pair, 1))) return rc;
     if (!device_src) HIPCHK(c, hipStreamSynchronize(c->stream));
     return DVO_OK;
 }
@@ -616,7 +673,7 @@ int dvo_set_now_level_from_edges(dvo_ctx *c, int pair, int level, const unsigned
     HIPCHK(c, hipMemcpyAsync(d_edge, edge, npx, hipMemcpyHostToDevice, c->stream));
     Level &L = c->lv[level];
     HIPCHK(c, launch_now_level_from_edges(d_edge, rows, cols, work, L.tex + (size_t)pair * L.tex_stride, c->stream));
-    L.have_now[pair] = 1;
+    if ((rc = now_written(c, level, pair, 1))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return DVO_OK;
 }
@@ -672,9 +729,34 @@ int dvo_replicate_pairs(dvo_ctx *c, int n_src, int dst_first, int dst_count) {
         for (int p = dst_first; p < dst_first + dst_count; p++) {
             L.hN[p] = L.hN[(p - dst_first) % n_src];
             L.compact_ok[p] = L.compact_ok[(p - dst_first) % n_src];
-            L.have_now[p] = 1;
         }
+        if (L.tex && dst_count > 0) { int rc = now_written(c, l, dst_first, dst_count); if (rc) return rc; }
     }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DVO_OK;
+}
+
+/* build the compact form of the resident now levels of these pairs now (instead of at their second alignment) */
+int dvo_now_prepare(dvo_ctx *c, int first_pair, int count) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, first_pair) || count < 1 || first_pair + count > c->n_pairs) return fail(c, DVO_ERR_INVALID, "pair range out of bounds");
+    if (c->prm.engine_variant == 4 || compact_now_policy() == 2) return DVO_OK;
+    for (int l = 0; l < DVO_LEVELS; l++) {
+        int rc = build_compact_now(c, l, first_pair, count, false);
+        if (rc) return rc;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DVO_OK;
+}
+
+/* palette size of the compact form of (pair, level): > 0 size, 0 not built, < 0 the builder's reason for "no compact form" */
+int dvo_get_now_compact_info(dvo_ctx *c, int pair, int level, int *palette_size) {
+    if (!c) return DVO_ERR_INVALID;
+    if (!pair_ok(c, pair) || !level_ok(level) || !palette_size) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    Level &L = c->lv[level];
+    *palette_size = 0;
+    if (!L.d_pal_n) return DVO_OK;
+    HIPCHK(c, hipMemcpyAsync(palette_size, L.d_pal_n + pair, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return DVO_OK;
 }

@@ -485,8 +485,7 @@ static int frames_as_now_level(dvo_ctx *c, int l, int first_slot, int first_pair
                                              c->work, L.tex + (size_t)(first_pair + b) * L.tex_stride, L.tex_stride, stream));
         }
     }
-    for (int i = 0; i < count; i++) L.have_now[first_pair + i] = 1;
-    return DVO_OK;
+    return now_written(c, l, first_pair, count);
 }
 
 int dvo_frames_as_now(dvo_ctx *c, int first_slot, int first_pair, int count) {
@@ -508,16 +507,20 @@ int dvo_frames_as_ref(dvo_ctx *c, int first_slot, int first_pair, int count, int
     int rc = frames_check_use(c, first_slot, first_pair, count, true);
     if (rc) return rc;
     const int nl = c->fs.n_levels;
-    size_t cc_off[DVO_LEVELS + 1];                      /* per level: count x (cols+2) column counters */
+    size_t cc_off[DVO_LEVELS + 1];                      /* per level: count x (cols+2) column counters ... */
+    size_t bc_off[DVO_LEVELS + 1];                      /* ... and count x enlist_block_ints() block-order counters */
     cc_off[0] = 0;
     for (int l = 0; l < nl; l++) cc_off[l + 1] = cc_off[l] + (size_t)count * (c->fs.lv[l].cols + 2);
-    if ((rc = ensure_work(c, sizeof(int) * cc_off[nl]))) return rc;
+    bc_off[0] = cc_off[nl];
+    for (int l = 0; l < nl; l++) bc_off[l + 1] = bc_off[l] + (size_t)count * enlist_block_ints(c->fs.lv[l].rows, c->fs.lv[l].cols);
+    if ((rc = ensure_work(c, sizeof(int) * bc_off[nl]))) return rc;
     std::vector<int> hN((size_t)count * nl);
     for (int l = 0; l < nl; l++) {
         FrameLevel &F = c->fs.lv[l];
         const size_t off = (size_t)first_slot * F.npx;
         int *cc = c->work + cc_off[l];
-        HIPCHK(c, launch_enlist_count(F.edge + off, 1, F.npx, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, count}, cc, c->stream));
+        HIPCHK(c, launch_enlist_count(F.edge + off, 1, F.npx, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, count}, cc,
+                                      compact_block_order() ? c->work + bc_off[l] : nullptr, c->stream));
         HIPCHK(c, hipMemcpy2DAsync(hN.data() + (size_t)l * count, sizeof(int), cc + F.cols, sizeof(int) * (F.cols + 2),
                                    sizeof(int), count, hipMemcpyDeviceToHost, c->stream));
     }
@@ -536,7 +539,7 @@ int dvo_frames_as_ref(dvo_ctx *c, int first_slot, int first_pair, int count, int
         Level &L = c->lv[l];
         const size_t off = (size_t)first_slot * F.npx;
         HIPCHK(c, launch_enlist_write(F.edge + off, 1, F.npx, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, count}, l, c->K,
-                                      c->work + cc_off[l], L.pts + (size_t)first_pair * L.pt_cap * 3, (size_t)L.pt_cap * 3,
+                                      c->work + cc_off[l], compact_block_order() ? c->work + bc_off[l] : nullptr, L.pts + (size_t)first_pair * L.pt_cap * 3, (size_t)L.pt_cap * 3,
                                       L.cpts + (size_t)first_pair * L.pt_cap, nullptr, L.pt_cap, L.dN + first_pair, c->stream));
         for (int i = 0; i < count; i++) { L.hN[first_pair + i] = hN[(size_t)l * count + i]; L.compact_ok[first_pair + i] = 1; }
     }

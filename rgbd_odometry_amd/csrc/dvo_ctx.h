@@ -30,6 +30,13 @@ struct Level {
     int *dN = nullptr;
     std::vector<int> hN;            /* 0 = not set */
     std::vector<char> have_now;
+    /* compact form of the now levels (dvo_palette.h), allocated at the first build */
+    unsigned *p4 = nullptr;         /* n_pairs x p4_stride rank words */
+    float2 *pal = nullptr;          /* n_pairs x DVO_PAL_MAX {DT value, weight} */
+    int *d_pal_n = nullptr;         /* n_pairs: > 0 palette size, <= 0 no compact form (kept 0 while the form is stale) */
+    size_t p4_stride = 0;
+    std::vector<char> pal_built;    /* per pair: the compact form was built from the CURRENT now level */
+    std::vector<int> now_uses;      /* per pair: alignments enqueued since the now level was last written */
 };
 
 /* frame store (rows f1/f2): per level one slab per plane for all slots, slot s at base + s*npx */
@@ -44,6 +51,21 @@ struct FrameStore {
     FrameLevel lv[DVO_LEVELS];
     std::vector<char> valid, has_depth;
 };
+/* diagnostics: DVO_COMPACT_ORDER=colmajor in the environment keeps the compact point lists in the reference's column-major
+ * order (A/B measurement of the block order; results are the same up to the double rounding of the sums) */
+inline bool compact_block_order() {
+    static const bool on = [] { const char *e = std::getenv("DVO_COMPACT_ORDER"); return !(e && std::strcmp(e, "colmajor") == 0); }();
+    return on;
+}
+/* diagnostics / tests: DVO_COMPACT_NOW=eager builds the compact form of a now level (dvo_palette.h) at its FIRST alignment
+ * (so that every test of the suite runs through it), =off never builds it; default: at the second alignment */
+inline int compact_now_policy() {
+    static const int pol = [] {
+        const char *e = std::getenv("DVO_COMPACT_NOW");
+        return (e && std::strcmp(e, "eager") == 0) ? 1 : ((e && std::strcmp(e, "off") == 0) ? 2 : 0);
+    }();
+    return pol;
+}
 }  // namespace dvo_host
 
 struct dvo_ctx {
@@ -131,6 +153,11 @@ bool pair_ok(const dvo_ctx *c, int pair);
 bool level_ok(int level);
 int ensure_points(dvo_ctx *c, int level, int N);                 /* room for N points per pair at `level` (keeps contents) */
 int ensure_texels(dvo_ctx *c, int level, int rows, int cols);
+/* the now level of `pair` at `level` was (re)written: mark it present and its compact form stale */
+int now_written(dvo_ctx *c, int level, int first_pair, int count);
+/* build the compact form of the stale now levels among [first_pair, first_pair+count) at `level`; with only_reused, only
+ * of those that have been aligned before (a level used once does not repay the build) */
+int build_compact_now(dvo_ctx *c, int level, int first_pair, int count, bool only_reused);
 /* schedule / readiness / output bookkeeping of the align entry points (dvo_capi.cpp) */
 dvo::LevelSlab slab_of(const dvo_ctx *c, int level);
 int check_ready(dvo_ctx *c, int pair, int level);

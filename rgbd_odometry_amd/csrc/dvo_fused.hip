@@ -18,6 +18,7 @@
  */
 #include "dvo_kernel_common.h"
 #include "dvo_point_pk.h"
+#include "dvo_palette.h"
 
 namespace dvo {
 
@@ -38,19 +39,34 @@ DVO_DEV void acc7_zero(Acc7 &a) {
 /* Where a level's now-frame texels are read from (chosen per level and pair, wave-uniform):
  *   TEX_G16  16-byte texels {DT, gx, gy, w} gathered from HBM / L2
  *   TEX_L16  the same texels, staged once per level into LDS ("LDS-staged image tiles"; the reference re-copies the three
- *            now images every iteration, SolveDVO.cpp:310,316-317,427) -- taken when the whole level fits beside its points */
-enum { TEX_G16 = DVO_TEXMODE_GLOBAL16, TEX_L16 = DVO_TEXMODE_LDS16 };
+ *            now images every iteration, SolveDVO.cpp:310,316-317,427) -- taken when the whole level fits beside its points
+ *   TEX_P4   the compact form of dvo_palette.h: ONE 12-byte gather per point fetches the rank words of the pixel above, the
+ *            pixel and the pixel below (24 pixels per 128-byte line instead of 8: half the memory requests); DT, w and the
+ *            four neighbour values come from the level's palette in LDS, gx = 0.5*(P[r]-P[l]), gy = 0.5*(P[d]-P[u]) -- the
+ *            builder verified per pixel that this reproduces the 16-byte texel bit for bit */
+enum { TEX_G16 = DVO_TEXMODE_GLOBAL16, TEX_L16 = DVO_TEXMODE_LDS16, TEX_P4 = DVO_TEXMODE_PAL4 };
 
 struct TexSrc {
     const char *g16;           /* this pair's level in HBM, tiled 16-byte texels */
     unsigned tile_col_bytes;   /* tiles_per_col * 128 */
     const char *l16;           /* LDS copy of the same bytes (TEX_L16) */
+    const char *p4;            /* this pair's level in HBM, compact form (TEX_P4) */
+    unsigned p4_col_bytes;     /* p4_tiles_per_col * 128 */
+    const char *pal;           /* the level's palette {P, W} in LDS (TEX_P4) */
 };
 
+/* three consecutive dwords at any 4-byte boundary (one global_load_dwordx3) */
+struct __attribute__((packed, aligned(4))) U3 { unsigned a, b, c; };
+
 /* one round of the software pipeline: two points per lane */
-struct Round2 {
+template <int TEX> struct Round2 {
     v2f xn, yn, zn;    /* dehomogenised coordinates (finite dummies where not visible) */
     v4f t0, t1;        /* the two texels {DT, gx, gy, w} as loaded */
+    bool vis0, vis1;
+};
+template <> struct Round2<TEX_P4> {
+    v2f xn, yn, zn;
+    U3 t0, t1;         /* rank words above / at / below the two pixels */
     bool vis0, vis1;
 };
 
@@ -59,6 +75,15 @@ DVO_DEV unsigned texel_byte_offset(int yy, int xx, unsigned tile_col_bytes /* ti
     static_assert(DVO_TILE_Y_LOG2 == 2 && DVO_TILE_X_LOG2 == 1, "written for 4x2 tiles");
     /* ((xx>>1)*tpc + (yy>>2))*128 + (xx&1)*64 + (yy&3)*16  ==  (xx>>1)*tpc*128 + yy*32 - (yy&3)*16 + (xx&1)*64 */
     return (unsigned)(xx >> 1) * tile_col_bytes + ((unsigned)yy << 5) - (((unsigned)yy & 3u) << 4) + (((unsigned)xx & 1u) << 6);
+}
+
+/* byte offset of the rank word ABOVE pixel (yy, xx) in the compact image (dvo_palette.h): the 12 bytes from there are
+ * above / centre / below.  yy / 6 by multiplication (exact for yy < 98 000). */
+DVO_DEV unsigned p4_byte_offset(int yy, int xx, unsigned p4_col_bytes /* p4_tiles_per_col * 128 */) {
+    static_assert(DVO_P4_ROWS == 6, "written for 6 interior rows per line");
+    const unsigned ty = ((unsigned)yy * 43691u) >> 18;
+    const unsigned ry = (unsigned)yy - 6u * ty;
+    return (unsigned)(xx >> 2) * p4_col_bytes + (ty << 7) + (((unsigned)xx & 3u) << 5) + (ry << 2);
 }
 
 struct LdsPoints {
@@ -82,7 +107,7 @@ DVO_DEV void load_compact(const LdsPoints &lp, const uint2 *__restrict__ gpts, i
  * share of the iteration with the literal-division scalar code (accumulate_points_exact). */
 template <bool LDS_SRC, int TEX>
 DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints &lp, const uint2 *__restrict__ gpts,
-                          int i0, int i1, int end, Round2 &b, bool &any_odd) {
+                          int i0, int i1, int end, Round2<TEX> &b, bool &any_odd) {
     const bool valid0 = i0 < end, valid1 = i1 < end;
     const int j0 = valid0 ? i0 : (end - 1), j1 = valid1 ? i1 : (end - 1);
     unsigned k0, k1;
@@ -108,13 +133,36 @@ DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints 
     /* finite dummies for lanes without a visible point: they then add exact zeros (w = eps = 0) */
     b.xn.x = vis0 ? xn.x : 0.0f; b.yn.x = vis0 ? yn.x : 0.0f; b.zn.x = vis0 ? zn.x : 1.0f;
     b.xn.y = vis1 ? xn.y : 0.0f; b.yn.y = vis1 ? yn.y : 0.0f; b.zn.y = vis1 ? zn.y : 1.0f;
-    unsigned o0 = texel_byte_offset(py0, px0, ts.tile_col_bytes);
-    unsigned o1 = texel_byte_offset(py1, px1, ts.tile_col_bytes);
-    o0 = vis0 ? o0 : 0u;
-    o1 = vis1 ? o1 : 0u;
-    const char *base = (TEX == TEX_L16) ? ts.l16 : ts.g16;
-    b.t0 = *reinterpret_cast<const v4f *>(base + o0);
-    b.t1 = *reinterpret_cast<const v4f *>(base + o1);
+    if constexpr (TEX == TEX_P4) {
+        unsigned o0 = p4_byte_offset(py0, px0, ts.p4_col_bytes);
+        unsigned o1 = p4_byte_offset(py1, px1, ts.p4_col_bytes);
+        o0 = vis0 ? o0 : 0u;                                   /* line 0 of the image: valid ranks whatever the pixel */
+        o1 = vis1 ? o1 : 0u;
+        b.t0 = *reinterpret_cast<const U3 *>(ts.p4 + o0);
+        b.t1 = *reinterpret_cast<const U3 *>(ts.p4 + o1);
+    } else {
+        unsigned o0 = texel_byte_offset(py0, px0, ts.tile_col_bytes);
+        unsigned o1 = texel_byte_offset(py1, px1, ts.tile_col_bytes);
+        o0 = vis0 ? o0 : 0u;
+        o1 = vis1 ? o1 : 0u;
+        const char *base = (TEX == TEX_L16) ? ts.l16 : ts.g16;
+        b.t0 = *reinterpret_cast<const v4f *>(base + o0);
+        b.t1 = *reinterpret_cast<const v4f *>(base + o1);
+    }
+}
+
+/* TEX_P4: {DT, gx, gy, w} of one pixel from its three rank words and the palette in LDS */
+DVO_DEV void p4_decode(const char *pal, const U3 &t, float &dt, float &gx, float &gy, float &w) {
+    const unsigned c8 = t.b & 0xfff8u;
+    const float2 pw = *reinterpret_cast<const float2 *>(pal + c8);
+    const float pu = *reinterpret_cast<const float *>(pal + (t.a & 0xfff8u));
+    const float pd = *reinterpret_cast<const float *>(pal + (t.c & 0xfff8u));
+    const int dr = ((int)(t.b << 8)) >> 24, dl = ((int)t.b) >> 24;
+    const float pr = *reinterpret_cast<const float *>(pal + (c8 + (unsigned)(dr << 3)));
+    const float pl = *reinterpret_cast<const float *>(pal + (c8 + (unsigned)(dl << 3)));
+    dt = pw.x; w = pw.y;
+    gx = 0.5f * (pr - pl);          /* imageGradient, SolveDVO.cpp:1063-1098 */
+    gy = 0.5f * (pd - pu);
 }
 
 /* (double)(float)(J_k w) * (double)eps is exact, so fma(a,b,c) == c + a*b bit for bit (:719-720, :777) */
@@ -126,11 +174,19 @@ DVO_DEV void acc7_add(Acc7 &a, const float *jw, float eps) {
 }
 
 /* stage 2: weighted Jacobian rows + accumulation */
-DVO_DEV void round2_compute(const IterConst &c, const Round2 &b, Acc7 &a) {
+template <int TEX>
+DVO_DEV void round2_compute(const IterConst &c, const TexSrc &ts, const Round2<TEX> &b, Acc7 &a) {
     a.nvis += __popcll(__builtin_amdgcn_ballot_w64(b.vis0)) + __popcll(__builtin_amdgcn_ballot_w64(b.vis1));
-    const float gx0 = b.t0.y, gx1 = b.t1.y, gy0 = b.t0.z, gy1 = b.t1.z;
-    const float eps0 = b.vis0 ? b.t0.x : 0.0f, eps1 = b.vis1 ? b.t1.x : 0.0f;
-    const float w0 = b.vis0 ? b.t0.w : 0.0f, w1 = b.vis1 ? b.t1.w : 0.0f;
+    float gx0, gx1, gy0, gy1, dt0, dt1, wt0, wt1;
+    if constexpr (TEX == TEX_P4) {
+        p4_decode(ts.pal, b.t0, dt0, gx0, gy0, wt0);
+        p4_decode(ts.pal, b.t1, dt1, gx1, gy1, wt1);
+    } else {
+        dt0 = b.t0.x; gx0 = b.t0.y; gy0 = b.t0.z; wt0 = b.t0.w;
+        dt1 = b.t1.x; gx1 = b.t1.y; gy1 = b.t1.z; wt1 = b.t1.w;
+    }
+    const float eps0 = b.vis0 ? dt0 : 0.0f, eps1 = b.vis1 ? dt1 : 0.0f;
+    const float w0 = b.vis0 ? wt0 : 0.0f, w1 = b.vis1 ? wt1 : 0.0f;
     v2f jw[6];
     jacobian_weighted2(c, b.xn, b.yn, b.zn, gx0, gx1, gy0, gy1, w0, w1, jw);
     const double e0 = (double)eps0, e1 = (double)eps1;
@@ -154,23 +210,23 @@ DVO_DEV void accumulate_points2(const IterConst &c, const TexSrc &ts, const LdsP
     const int wave_off = __builtin_amdgcn_readfirstlane(lane_off - (int)(threadIdx.x & 63));
     const int n_rounds = (end - first - wave_off + STEP - 1) / STEP;
     if (n_rounds <= 0) return;
-    Round2 A, B;
+    Round2<TEX> A, B;
     int base = first + lane_off;
     round2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base, base + BLOCK, end, A, any_odd);
     int r = 0;
     for (; r + 2 < n_rounds; r += 2) {
         round2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + STEP, base + STEP + BLOCK, end, B, any_odd);
-        round2_compute(c, A, a);
+        round2_compute<TEX>(c, ts, A, a);
         round2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + 2 * STEP, base + 2 * STEP + BLOCK, end, A, any_odd);
-        round2_compute(c, B, a);
+        round2_compute<TEX>(c, ts, B, a);
         base += 2 * STEP;
     }
     if (r + 1 < n_rounds) {
         round2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + STEP, base + STEP + BLOCK, end, B, any_odd);
-        round2_compute(c, A, a);
-        round2_compute(c, B, a);
+        round2_compute<TEX>(c, ts, A, a);
+        round2_compute<TEX>(c, ts, B, a);
     } else {
-        round2_compute(c, A, a);
+        round2_compute<TEX>(c, ts, A, a);
     }
 }
 
@@ -378,11 +434,21 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         const int lds_words = sc.lds_bytes >> 2;
         const int n_pad = (N + 3) & ~3;
         const int tex16_words = (int)(L.tex_stride * 4);
-        const int mode = (!TEAM && !sc.no_lds_tex && 2 * n_pad + tex16_words <= lds_words) ? TEX_L16 : TEX_G16;
-        const int cap = (mode == TEX_G16) ? (lds_words >> 1) : n_pad;          /* words per point plane */
+        /* the compact form of this pair's level, if the builder could make one (dvo_palette.h): its palette goes first */
+        const int n_pal = (!sc.no_p4 && L.pal_n) ? max(0, __builtin_amdgcn_readfirstlane(L.pal_n[dpair])) : 0;
+        const int mode = (!TEAM && !sc.no_lds_tex && 2 * n_pad + tex16_words <= lds_words) ? TEX_L16
+                         : ((n_pal > 0 && 2 * n_pal + 4 <= lds_words) ? TEX_P4 : TEX_G16);
+        const int pal_words = (mode == TEX_P4) ? ((2 * n_pal + 3) & ~3) : 0;
+        float *const lds_pts = lds_dyn + pal_words;
+        const int cap = (mode == TEX_L16) ? n_pad : (((lds_words - pal_words) >> 1) & ~1);          /* words per point plane */
         const int n_lds = (N <= cap) ? N : (cap / (2 * BLOCK)) * (2 * BLOCK);      /* whole rounds only */
-        float *const lds_tex = lds_dyn + 2 * cap;
+        float *const lds_tex = lds_pts + 2 * cap;
         if (tid == 0 && member == 0) out.tex_mode[pair * DVO_LEVELS + l] = mode;
+        if (mode == TEX_P4) {
+            const float2 *__restrict__ pg = L.pal + (size_t)dpair * DVO_PAL_MAX;
+            float2 *pl = reinterpret_cast<float2 *>(lds_dyn);
+            for (int i = tid; i < n_pal; i += BLOCK) pl[i] = pg[i];
+        }
         {   /* 16-byte loads (whole 128-byte lines per request), four in flight per lane */
             const uint4 *g4 = reinterpret_cast<const uint4 *>(gpts);
             const int n2 = n_lds >> 1;
@@ -394,21 +460,21 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int k = 2 * (i + q * BLOCK);
-                    lds_dyn[k] = __uint_as_float(v[q].x); lds_dyn[cap + k] = __uint_as_float(v[q].y);
-                    lds_dyn[k + 1] = __uint_as_float(v[q].z); lds_dyn[cap + k + 1] = __uint_as_float(v[q].w);
+                    lds_pts[k] = __uint_as_float(v[q].x); lds_pts[cap + k] = __uint_as_float(v[q].y);
+                    lds_pts[k + 1] = __uint_as_float(v[q].z); lds_pts[cap + k + 1] = __uint_as_float(v[q].w);
                 }
             }
             for (; i < n2; i += BLOCK) {
                 const uint4 v = g4[i];
-                lds_dyn[2 * i] = __uint_as_float(v.x);
-                lds_dyn[cap + 2 * i] = __uint_as_float(v.y);
-                lds_dyn[2 * i + 1] = __uint_as_float(v.z);
-                lds_dyn[cap + 2 * i + 1] = __uint_as_float(v.w);
+                lds_pts[2 * i] = __uint_as_float(v.x);
+                lds_pts[cap + 2 * i] = __uint_as_float(v.y);
+                lds_pts[2 * i + 1] = __uint_as_float(v.z);
+                lds_pts[cap + 2 * i + 1] = __uint_as_float(v.w);
             }
             if ((n_lds & 1) && tid == 0) {
                 const uint2 v = gpts[n_lds - 1];
-                lds_dyn[n_lds - 1] = __uint_as_float(v.x);
-                lds_dyn[cap + n_lds - 1] = __uint_as_float(v.y);
+                lds_pts[n_lds - 1] = __uint_as_float(v.x);
+                lds_pts[cap + n_lds - 1] = __uint_as_float(v.y);
             }
         }
         if (mode == TEX_L16) {
@@ -426,11 +492,14 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             for (; i < n16; i += BLOCK) d[i] = g[i];
         }
         LdsPoints lp;
-        lp.pk = reinterpret_cast<const unsigned *>(lds_dyn);
-        lp.z = lds_dyn + cap;
+        lp.pk = reinterpret_cast<const unsigned *>(lds_pts);
+        lp.z = lds_pts + cap;
         TexSrc ts;
         ts.g16 = tex; ts.tile_col_bytes = (unsigned)c.tiles_per_col * 128u;
         ts.l16 = reinterpret_cast<const char *>(lds_tex);
+        ts.p4 = reinterpret_cast<const char *>(L.p4 + (size_t)dpair * L.p4_stride);
+        ts.p4_col_bytes = (unsigned)p4_tiles_per_col(L.rows) * 128u;
+        ts.pal = reinterpret_cast<const char *>(lds_dyn);
         __syncthreads();
         DVO_STAMP(ts1);
         DVO_STAMP_ADD(5, ts0, ts1);
@@ -451,6 +520,9 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             const int lane_off = BLOCK - 64 - (tid & ~63) + (tid & 63);
             if (mode == TEX_L16) {                 /* staged levels hold every point in LDS */
                 accumulate_points2<BLOCK, true, TEX_L16>(c, ts, lp, gpts, 0, N, lane_off, a, any_odd);             /* :369, :433 */
+            } else if (mode == TEX_P4) {
+                accumulate_points2<BLOCK, true, TEX_P4>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
+                accumulate_points2<BLOCK, false, TEX_P4>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);
             } else {
                 accumulate_points2<BLOCK, true, TEX_G16>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
                 accumulate_points2<BLOCK, false, TEX_G16>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);       /* beyond the LDS budget */
@@ -492,16 +564,16 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
                 for (int k = 0; k < 3; k++) c.t[k] = uniform_f(st.btf[k]);
                 float *fe = out.final_eps + (size_t)pair * out.final_cap;
                 float *fr = out.final_reproj + (size_t)pair * out.final_cap * 3;
+                /* these two arrays are indexed like the reference's list (:703-704): the points come from the 3 x N float list,
+                 * which keeps the reference's order (the compact twin is in block order, dvo_frames.hip) -- same X, Y, Z bits */
+                const float *__restrict__ xyz = L.pts + (size_t)dpair * L.pt_cap * 3;
                 for (int i = tid; i < N; i += BLOCK) {
-                    unsigned pk; float z;
-                    if (i < n_lds) { pk = lp.pk[i]; z = lp.z[i]; }
-                    else { const uint2 v = gpts[i]; pk = v.x; z = __uint_as_float(v.y); }
-                    float X, Y, Z, xn, yn, zn, u, v;
-                    expand_compact(c, pk, z, X, Y, Z);
+                    const int gi = pfirst + i;
+                    const float X = xyz[3 * gi], Y = xyz[3 * gi + 1], Z = xyz[3 * gi + 2];
+                    float xn, yn, zn, u, v;
                     const bool vis = project_point(c, X, Y, Z, xn, yn, zn, u, v);
                     float e = 0.0f;
                     if (vis) e = reinterpret_cast<const float4 *>(tex)[texel_index((int)v, (int)u, c.tiles_per_col)].x;
-                    const int gi = pfirst + i;
                     fe[gi] = e;
                     fr[3 * gi] = u; fr[3 * gi + 1] = v; fr[3 * gi + 2] = zn;
                 }

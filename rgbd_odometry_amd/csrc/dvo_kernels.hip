@@ -358,8 +358,9 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
                 float *fr = out.final_reproj + (size_t)pair * out.final_cap * 3;
                 for (int i = tid; i < N; i += BLOCK) {
                     float X, Y, Z, xn, yn, zn, u, v;
-                    if (i < psrc.n_lds) load_point<CP ? SRC_LDS_COMPACT : SRC_LDS_XYZ>(c, psrc, i, X, Y, Z);
-                    else load_point<CP ? SRC_GLOBAL_COMPACT : SRC_GLOBAL_XYZ>(c, psrc, i, X, Y, Z);
+                    /* indexed like the reference's list: with compact points (block order, dvo_frames.hip) read the 3 x N list */
+                    if (!CP && i < psrc.n_lds) load_point<SRC_LDS_XYZ>(c, psrc, i, X, Y, Z);
+                    else load_point<SRC_GLOBAL_XYZ>(c, psrc, i, X, Y, Z);
                     const bool vis = project_point(c, X, Y, Z, xn, yn, zn, u, v);
                     float e = 0.0f;
                     if (vis) e = (INTERP == 1) ? interpolate_dt(c, tex, v, u) : tex[texel_index((int)v, (int)u, c.tiles_per_col)].x;

@@ -15,7 +15,7 @@
 #define DVO_NACC 29           /* == DVO_NUM_ACC */
 #define DVO_NACC_PAD 32
 /* where the fused kernel reads the now level of a (pair, level) from */
-enum { DVO_TEXMODE_GLOBAL16 = 0, DVO_TEXMODE_LDS16 = 1 };
+enum { DVO_TEXMODE_GLOBAL16 = 0, DVO_TEXMODE_LDS16 = 1, DVO_TEXMODE_PAL4 = 2 };
 
 namespace dvo {
 
@@ -33,6 +33,11 @@ struct LevelSlab {
     size_t tex_stride;      /* texels per pair */
     int pt_cap;             /* points per pair (capacity) */
     int rows, cols;
+    /* compact form of the now level (dvo_palette.h); pal_n[p] > 0: pair p has one (its palette size), <= 0: it has not */
+    const unsigned *p4;     /* n_pairs x p4_stride rank words */
+    const float2 *pal;      /* n_pairs x DVO_PAL_MAX palette entries {DT value, weight} */
+    const int *pal_n;       /* n_pairs (NULL: never built) */
+    size_t p4_stride;       /* dwords per pair */
 };
 struct LevelSet { LevelSlab l[DVO_LEVELS]; };
 
@@ -47,6 +52,7 @@ struct Schedule {
     int lds_points;          /* reference points kept resident in LDS per workgroup (3 words each, 2 when compact) */
     int lds_bytes;           /* dynamic LDS of the launch (dvo_fused.hip splits it per level between points and the now level) */
     int no_lds_tex;          /* diagnostics: never stage the now level into LDS */
+    int no_p4;               /* diagnostics: never read the compact form of a now level (dvo_palette.h) */
     int team;                /* workgroups per pair of the packed kernel (1 = none; > 1: team mode, see dvo_fused.hip) */
     int n_pairs_launch;      /* pairs of this launch (team mode maps workgroups to pairs itself) */
     int force_exact;         /* tests: every wave takes the literal-division fallback of the packed kernel (accumulate_points_exact) */
@@ -74,6 +80,9 @@ struct Outputs {
 
 hipError_t launch_pack_texels(const float *dt, const float *gx, const float *gy, float4 *out,
                               int rows, int cols, hipStream_t s);
+/* compact form of now levels [first_pair, first_pair+count) of one pyramid level from their 16-byte texels (dvo_palette.hip) */
+hipError_t launch_palette_build(const float4 *tex, size_t tex_stride, int rows, int cols, unsigned *p4, size_t p4_stride,
+                                float2 *pal, int *pal_n, int first_pair, int count, hipStream_t s);
 bool fused_uses_compact(int points_in_flight, int interp);
 hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, int pt_cap, int *N,
                                   int n_src, int dst_first, int dst_count, hipStream_t s);
@@ -138,12 +147,17 @@ hipError_t launch_edges_to_texels(const unsigned char *edge, size_t edge_stride,
 hipError_t launch_now_level_from_edges(const unsigned char *edge, int rows, int cols, int *work,
                                        float4 *tex_out, hipStream_t s);
 /* selectedPts + enlistRefEdgePts (SolveDVO.cpp:1230-1264, :224-264).  col_counts: (cols+2) ints per image;
- * after the count pass col_counts[cols] and [cols+1] hold N.  edge: int32 or u8 (>0 = edge). */
+ * after the count pass col_counts[cols] and [cols+1] hold N.  edge: int32 or u8 (>0 = edge).
+ * blk_counts (may be NULL): enlist_block_ints(rows, cols) ints per image -- per (pixel column, 16-row segment) counts in
+ * block order; with it the compact twin list is written in 16x16-block order (dvo_frames.hip), the 3xN float list and uv
+ * always in the reference's order. */
+size_t enlist_block_ints(int rows, int cols);
 hipError_t launch_enlist_count(const void *edge, int edge_is_u8, size_t edge_stride, const float *depth_mm,
-                               size_t depth_stride, ImgBatch g, int *col_counts, hipStream_t s);
+                               size_t depth_stride, ImgBatch g, int *col_counts, int *blk_counts, hipStream_t s);
 hipError_t launch_enlist_write(const void *edge, int edge_is_u8, size_t edge_stride, const float *depth_mm,
                                size_t depth_stride, ImgBatch g, int level, const Intrinsics &K, const int *col_counts,
-                               float *xyz, size_t xyz_stride, uint2 *compact /* same stride in points / 3, or nullptr */,
+                               const int *blk_counts, float *xyz, size_t xyz_stride,
+                               uint2 *compact /* same stride in points / 3, or nullptr */,
                                float *uv, int capacity, int *N_dst, hipStream_t s);
 
 /* ---- photometric Gauss-Newton (dvo_photo.hip): RGBDOdometry's engine ---- */

@@ -1,0 +1,51 @@
+/*
+ * dvo_palette.h -- layout of the compact ("P4") form of a now level: 4 bytes per pixel instead of the 16-byte texel
+ * {DT, gx, gy, w} of dvo_device_math.h.  Shared by the builder (dvo_palette.hip), the fused kernel (dvo_fused.hip) and the
+ * host code.  Internal.
+ *
+ * Why: the fused alignment kernel is bound by the number of memory requests that leave the L2: every
+ * iteration touches the distinct 128-byte lines under the reprojected contour once, and with 16-byte texels a line holds
+ * 8 pixels of which a one-pixel-wide contour uses 2-3.  The four floats of a texel are redundant for every now level the
+ * reference can produce: DT is the normalised distance transform (SolveDVO.cpp:1768-1795: few hundred distinct values per
+ * image), gx / gy are imageGradient(DT) (:1063-1098: 0.5*(DT[x+1]-DT[x-1]), 0.5*(DT[y+1]-DT[y-1]), reflect-101 borders) and
+ * w = getWeightOf(DT) (:1047-1053).  So a pixel is fully described by the RANK of its DT value in the image's sorted list of
+ * distinct values (the "palette") and the ranks of its four neighbours.
+ *
+ *   palette : per (pair, level) up to DVO_PAL_MAX entries {P = DT value, W = getWeightOf(P)} (float2), sorted by P;
+ *             copied into LDS at the start of a level
+ *   P4 slab : lines of 128 bytes = 4 pixel columns x 8 stored rows of one dword:  6 interior image rows plus the row above
+ *             and the row below (an apron, so that the vertical neighbours of every interior pixel are in the SAME line and
+ *             one 12-byte load fetches up / centre / down).  Image borders hold the reflect-101 rows.  24 pixels per line
+ *             instead of 8: modelled on the bench scenes, 97 k -> 51 k distinct lines per 640x480x4x10 alignment.
+ *   dword   : bits 3..15  rank * 8   (byte offset of the palette entry; rank < DVO_PAL_MAX = 4096)
+ *             bits 16..23 rank(x+1) - rank, signed     bits 24..31 rank(x-1) - rank, signed
+ *             (apron / border entries carry their pixel's rank only)
+ *
+ * The form is LOSSLESS BY VERIFICATION: the builder re-derives {DT, gx, gy, w} of every pixel from the palette exactly as
+ * the kernel will and compares them bit for bit with the 16-byte texel; one mismatch (a caller-supplied gradient that is not
+ * imageGradient(DT), more than 4096 distinct values, a rank step beyond +-127, NaN / negative DT) and the level keeps
+ * the 16-byte path for that pair.  Results are therefore identical bit for bit whichever form is read.
+ */
+#ifndef DVO_PALETTE_H_
+#define DVO_PALETTE_H_
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+#define DVO_PAL_MAX 4096          /* palette entries per (pair, level): 32 KiB of LDS at most */
+#define DVO_P4_ROWS 6             /* interior image rows per 128-byte line (8 stored rows) */
+
+namespace dvo {
+
+__host__ __device__ inline int p4_tiles_per_col(int rows) { return (rows + DVO_P4_ROWS - 1) / DVO_P4_ROWS; }
+/* dwords of one image */
+__host__ __device__ inline size_t p4_count(int rows, int cols) {
+    return (size_t)p4_tiles_per_col(rows) * (size_t)((cols + 3) >> 2) * 32u;
+}
+/* dword index of stored row `srow` (0 = apron above, 1..6 interior, 7 = apron below) of tile row `ty`, pixel column xx */
+__host__ __device__ inline size_t p4_slot(int ty, int srow, int xx, int tiles_per_col) {
+    return ((size_t)(xx >> 2) * tiles_per_col + ty) * 32u + (size_t)((xx & 3) * 8 + srow);
+}
+
+}  // namespace dvo
+#endif

@@ -1,0 +1,214 @@
+"""GPU parity of the compact ("P4", 4 bytes per pixel) form of resident now levels (rgbd_odometry_amd/csrc/dvo_palette.h,
+dvo_palette.hip, TEX_P4 in dvo_fused.hip) against the CPU oracle.
+
+The compact form replaces the reference's three float images of a now level (distance transform SolveDVO.cpp:1768-1795, its
+imageGradient :1063-1098, the weight :1047-1053) by palette ranks; the builder verifies per pixel that it decodes to the same
+four floats, so every result must stay bit-identical to the oracle: energies / best index / visible ratio / final outputs
+bit-equal, pose within 1e-5 rad / 1e-4 m -- the bars of test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib
+from oracle_lib import rot_angle
+
+pytestmark = pytest.mark.gpu
+
+ROT_TOL, TRANS_TOL = 1e-5, 1e-4
+
+
+def _same(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+def _load(ctx, sc, pair=0):
+    for l, L in enumerate(sc.levels):
+        ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols, pair=pair)
+        ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols, pair=pair)
+
+
+def _check(ctx, ref, iters, pair=0, R0=None, t0=None):
+    from rgbd_odometry_amd.capi import DVO_FLAG_FINAL_OUTPUTS
+    R0 = np.eye(3) if R0 is None else R0
+    t0 = np.zeros(3) if t0 is None else t0
+    R, t = ctx.align_batch(iters, R0[None], t0[None], first_pair=pair, n_pairs=1, flags=DVO_FLAG_FINAL_OUTPUTS)
+    for l, rep in ref["levels"].items():
+        e, b, ratio = ctx.level_report(pair, l, iters[l])
+        assert np.array_equal(e, rep["energy"]), (l, e, rep["energy"])
+        assert b == rep["best_idx"] and ratio == rep["visible_ratio"], l
+    assert rot_angle(ref["R"], R[0]) <= ROT_TOL and np.linalg.norm(ref["t"] - t[0]) <= TRANS_TOL
+    last = ref["levels"][ref["last_level"]]
+    feps, frep = ctx.final_outputs(pair, len(last["final_eps"]))
+    assert _same(feps, last["final_eps"]) and _same(frep, last["final_reproj"])
+    return R[0], t[0]
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),                                          # auto: a single pair -> a team of 8 workgroups, every level compact
+    dict(team_size=1),                               # one 512-thread workgroup; level 3 is staged into LDS as 16-byte texels
+    dict(engine_variant=2, team_size=1),             # no LDS staging: all four levels through the compact form
+    dict(block_threads=256), dict(block_threads=1024),
+    dict(lds_point_bytes=16 * 1024, team_size=1),    # palette + 1 k points resident, the rest streamed (both passes)
+    dict(engine_variant=3, team_size=1),             # every wave redone by the literal-division fallback (16-byte texels)
+])
+def test_compact_now_640x480(oracle, kw):
+    """C2 (640x480, 4 levels, 10 iterations): prepared now levels through every launch shape of the packed kernel"""
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    sc = SynthScene(640, 480, 4, 3)
+    lv = oracle_lib.scene_levels(sc, oracle)
+    iters = [10, 10, 10, 10]
+    ref = oracle.align_pyramid(iters, lv, sc.intrinsics, np.eye(3), np.zeros(3))
+    with DvoContext(1, **kw) as ctx:
+        ctx.set_intrinsics(*sc.intrinsics)
+        _load(ctx, sc)
+        ctx.now_prepare()
+        sizes = [ctx.now_compact_info(0, l) for l in range(4)]
+        assert all(0 < s <= 4096 for s in sizes), sizes
+        assert sizes[0] > sizes[1] > sizes[2] > sizes[3]          # coarser levels have fewer distinct distances
+        R1, t1 = _check(ctx, ref, iters)
+        modes = [ctx.level_texel_mode(0, l) for l in range(4)]
+        one_wg = kw.get("team_size", 0) == 1 or kw.get("block_threads", 0) == 1024      # no team; 256 threads: 77 KB, level 3 does not fit
+        staged3 = one_wg and kw.get("engine_variant", 0) != 2 and "lds_point_bytes" not in kw
+        assert modes == ([2, 2, 2, 1] if staged3 else [2, 2, 2, 2]), modes
+    if kw.get("engine_variant", 0) == 0:
+        # the same alignment with the compact form switched off: same kernel otherwise -> the very same bits
+        with DvoContext(1, **{**kw, "engine_variant": 4}) as ctx2:
+            ctx2.set_intrinsics(*sc.intrinsics)
+            _load(ctx2, sc)
+            ctx2.now_prepare()
+            R2, t2 = _check(ctx2, ref, iters)
+            assert 2 not in [ctx2.level_texel_mode(0, l) for l in range(4)]
+            assert np.array_equal(R1, R2) and np.array_equal(t1, t2)
+
+
+def test_compact_now_is_built_at_the_second_alignment(oracle):
+    """policy: a now level aligned once keeps the 16-byte form; the second alignment builds the compact form; writing the
+    level again makes it stale (and the results follow the new image)"""
+    import os
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    if os.environ.get("DVO_COMPACT_NOW"):
+        pytest.skip("policy overridden by DVO_COMPACT_NOW")
+    sc, sc2 = SynthScene(320, 240, 3, 5), SynthScene(320, 240, 3, 6)
+    iters = [6, 6, 6]
+    ref = oracle.align_pyramid(iters, oracle_lib.scene_levels(sc, oracle), sc.intrinsics, np.eye(3), np.zeros(3))
+    with DvoContext(1, team_size=1, engine_variant=2) as ctx:
+        ctx.set_intrinsics(*sc.intrinsics)
+        _load(ctx, sc)
+        _check(ctx, ref, iters)
+        assert [ctx.level_texel_mode(0, l) for l in range(3)] == [0, 0, 0]
+        assert [ctx.now_compact_info(0, l) for l in range(3)] == [0, 0, 0]
+        _check(ctx, ref, iters)
+        assert [ctx.level_texel_mode(0, l) for l in range(3)] == [2, 2, 2]
+        assert all(ctx.now_compact_info(0, l) > 0 for l in range(3))
+        # a new now frame in the same slot (same reference): compact form stale -> 16-byte form, results of the new image
+        for l, L in enumerate(sc2.levels):
+            ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols)
+        lv_mixed = oracle_lib.scene_levels(sc, oracle)
+        for l, L in enumerate(sc2.levels):
+            lv_mixed[l].update(dt=L.now_dt, gx=L.now_gx, gy=L.now_gy)
+        ref2 = oracle.align_pyramid(iters, lv_mixed, sc.intrinsics, np.eye(3), np.zeros(3))
+        assert [ctx.now_compact_info(0, l) for l in range(3)] == [0, 0, 0]
+        _check(ctx, ref2, iters)
+        assert [ctx.level_texel_mode(0, l) for l in range(3)] == [0, 0, 0]
+        _check(ctx, ref2, iters)
+        assert [ctx.level_texel_mode(0, l) for l in range(3)] == [2, 2, 2]
+
+
+@pytest.mark.parametrize("rows,cols", [(7, 9), (12, 8), (13, 5), (61, 83), (6, 4), (240, 322), (2, 2), (5, 2)])
+def test_compact_now_odd_sizes_from_edges(oracle, rows, cols):
+    """now levels built by the engine from an edge map (exact distance transform + gradient), sizes that are not multiples
+    of the 6 x 4 interior of a line, single-tile images, reflect-101 borders on every side"""
+    from rgbd_odometry_amd import DvoContext
+    rng = np.random.default_rng(rows * 1000 + cols)
+    edge = (rng.random((cols, rows)) < 0.15).astype(np.uint8).reshape(-1) * 255
+    edge[int(rng.integers(0, rows * cols))] = 255
+    dt, gx, gy = oracle.now_level_from_edges(edge, rows, cols)
+    ref_edge = (rng.random(rows * cols) < 0.5).astype(np.int32) * 255
+    ref_edge[0] = 255
+    depth = rng.uniform(400, 3000, rows * cols).astype(np.float32)
+    K = (float(np.float32(0.9 * cols)), float(np.float32(0.9 * cols)), float(np.float32(cols / 2)), float(np.float32(rows / 2)))
+    with DvoContext(1, team_size=1, engine_variant=2) as ctx:
+        ctx.set_intrinsics(*K)
+        xyz, _ = ctx.set_ref_level_from_images(0, ref_edge, depth, rows, cols)
+        ctx.set_now_level_from_edges(0, edge, rows, cols)
+        ctx.now_prepare()
+        n = ctx.now_compact_info(0, 0)
+        assert n > 0, n
+        assert n == len(np.unique(dt)), (n, len(np.unique(dt)))
+        for scale in (0.0, 0.01, 0.2):
+            R0, t0 = oracle.se3_exp(rng.standard_normal(6) * scale)
+            ref = oracle.run_iterations(0, 8, xyz, dt, gx, gy, rows, cols, K, R0, t0)
+            got = ctx.run_iterations(0, 8, R0, t0)
+            assert ctx.level_texel_mode(0, 0) == 2
+            assert _same(ref["energy"], got["energy"]), (scale, ref["energy"], got["energy"])
+            assert ref["best_idx"] == got["best_idx"] and ref["visible_ratio"] == got["visible_ratio"]
+            assert _same(ref["final_eps"], got["final_eps"]) and _same(ref["final_reproj"], got["final_reproj"])
+
+
+def test_compact_now_refused_keeps_the_16_byte_form(oracle):
+    """images the compact form cannot represent: the builder says why, the alignment reads the 16-byte texels, results are
+    those of the oracle all the same"""
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    sc = SynthScene(160, 120, 1, 11)
+    L = sc.levels[0]
+    rows, cols, n = L.rows, L.cols, L.rows * L.cols
+    rng = np.random.default_rng(5)
+    dt, gx, gy = (np.asarray(a, np.float32).copy() for a in (L.now_dt, L.now_gx, L.now_gy))
+    cases = {}
+    g = gx.copy(); g[n // 2] = np.nextafter(g[n // 2], np.float32(1e9)); cases[-4] = (dt, g, gy)                 # one gradient off by 1 ulp
+    g = gy.copy(); g[7] = -g[7] if g[7] != 0 else np.float32(1.0); cases["-4y"] = (dt, gx, g)                    # wrong sign in gy
+    cases[-2] = (rng.uniform(0, 255, n).astype(np.float32), gx, gy)                                             # > 4096 distinct values
+    d = dt.copy(); d[3] = -1.0; cases[-1] = (d, gx, gy)                                                         # negative "distance"
+    d = dt.copy(); d[5] = np.nan; cases["-1n"] = (d, gx, gy)
+    with DvoContext(1, team_size=1, engine_variant=2) as ctx:
+        ctx.set_intrinsics(*sc.intrinsics)
+        xyz, _ = ctx.set_ref_level_from_images(0, L.ref_edge, L.ref_depth, rows, cols)
+        for why, (a, b, c_) in cases.items():
+            ctx.set_now_level(0, a, b, c_, rows, cols)
+            ctx.now_prepare()
+            code = ctx.now_compact_info(0, 0)
+            assert code == int(str(why)[:2]), (why, code)
+            ref = oracle.run_iterations(0, 6, xyz, a, b, c_, rows, cols, sc.intrinsics, np.eye(3), np.zeros(3))
+            got = ctx.run_iterations(0, 6, np.eye(3), np.zeros(3))
+            assert ctx.level_texel_mode(0, 0) == 0
+            assert _same(ref["energy"], got["energy"]), (why, ref["energy"], got["energy"])
+            assert _same(ref["final_eps"], got["final_eps"]) and _same(ref["final_reproj"], got["final_reproj"])
+        # and the derived image again: accepted
+        ctx.set_now_level(0, dt, gx, gy, rows, cols)
+        ctx.now_prepare()
+        assert ctx.now_compact_info(0, 0) > 0
+
+
+def test_compact_now_mixed_batch(oracle):
+    """one launch whose pairs are partly compact (derived now levels) and partly not (arbitrary gradients): per pair and level
+    the kernel takes what exists; replicated pairs get their own compact form"""
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    n = 12
+    scenes = [SynthScene(320, 240, 3, 3000 + i) for i in range(4)]
+    iters = [8, 8, 8]
+    rng = np.random.default_rng(1)
+    with DvoContext(n, engine_variant=2) as ctx:
+        ctx.set_intrinsics(*scenes[0].intrinsics)
+        lvs = []
+        for p, sc in enumerate(scenes):
+            lv = oracle_lib.scene_levels(sc, oracle)
+            for l, L in enumerate(sc.levels):
+                ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols, pair=p)
+                gx = np.asarray(L.now_gx, np.float32).copy()
+                if p % 2:                                     # odd pairs: gradient perturbed -> no compact form
+                    gx += rng.normal(0, 0.01, gx.shape).astype(np.float32)
+                    lv[l]["gx"] = gx
+                ctx.set_now_level(l, L.now_dt, gx, L.now_gy, L.rows, L.cols, pair=p)
+            lvs.append(lv)
+        ctx.replicate_pairs(4)
+        ctx.now_prepare()
+        for p in range(n):
+            assert (ctx.now_compact_info(p, 0) > 0) == (p % 2 == 0), (p, ctx.now_compact_info(p, 0))
+        R, t = ctx.align_batch(iters, np.tile(np.eye(3), (n, 1, 1)), np.zeros((n, 3)))
+        for p in range(n):
+            ref = oracle.align_pyramid(iters, lvs[p % 4], scenes[p % 4].intrinsics, np.eye(3), np.zeros(3))
+            for l, rep in ref["levels"].items():
+                e, b, ratio = ctx.level_report(p, l, iters[l])
+                assert np.array_equal(e, rep["energy"]) and b == rep["best_idx"] and ratio == rep["visible_ratio"], (p, l)
+            assert rot_angle(ref["R"], R[p]) <= ROT_TOL and np.linalg.norm(ref["t"] - t[p]) <= TRANS_TOL
+            assert ctx.level_texel_mode(p, 0) == (2 if p % 2 == 0 else 0)
