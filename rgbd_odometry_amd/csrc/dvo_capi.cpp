@@ -265,6 +265,27 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
     sc.alias_mod = c->prm.debug_alias_mod > 0 ? c->prm.debug_alias_mod : 0;
     LevelSet ls;
     for (int l = 0; l < DVO_LEVELS; l++) ls.l[l] = slab_of(c, l);
+    /* compact (8-byte) point lists when every list of this launch was built by the engine's own enlist kernels */
+    sc.compact = fused_uses_compact(c->prm.points_in_flight, c->prm.interpolate_dt) ? 1 : 0;
+    for (int l = 0; l < n_levels && sc.compact; l++) {
+        if (sc.iters[l] <= 0) continue;
+        for (int p = first_pair; p < first_pair + n_pairs && sc.compact; p++)
+            if (c->lv[l].compact_ok.empty() || !c->lv[l].compact_ok[sc.alias_mod > 0 ? p % sc.alias_mod : p]) sc.compact = 0;
+    }
+    const bool packed = sc.compact && c->prm.engine_variant != 1 && !(sc.flags & DVO_FLAG_NORMAL_MATRIX);
+    sc.no_p4 = (c->prm.engine_variant == 4 || !packed || compact_now_policy() == 2) ? 1 : 0;
+    /* compact form of the now levels (dvo_palette.h): built for a level the second time it is aligned (or up front by
+     * dvo_now_prepare) -- a now level aligned once does not repay the build */
+    bool all_p4 = !sc.no_p4;
+    if (!sc.no_p4) {
+        for (int l = 0; l < n_levels; l++) {
+            if (sc.iters[l] <= 0) continue;
+            if ((rc = build_compact_now(c, l, first_pair, n_pairs, compact_now_policy() != 1))) return rc;
+            Level &L = c->lv[l];
+            for (int p = first_pair; p < first_pair + n_pairs; p++) { L.now_uses[p]++; all_p4 = all_p4 && L.pal_built[p]; }
+        }
+        for (int l = 0; l < DVO_LEVELS; l++) ls.l[l] = slab_of(c, l);       /* the build may have allocated */
+    }
     int block = c->prm.block_threads;
     int auto_lds = 0;
     const bool block_auto = (block != 256 && block != 512 && block != 1024);
@@ -281,6 +302,10 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
          * half the CUs is latency-bound and 512 threads finish an iteration sooner (single pair, 320x240x4x50:
          * 1.20 -> 1.06 ms) */
         if ((size_t)max_n * 12 <= 77000 && !c->prm.interpolate_dt && 2 * n_pairs > c->n_cu) { block = 256; auto_lds = 77000; }
+        /* with the compact now form the loop is no longer request-bound and two workgroups per CU pay even when the lists do
+         * not fit half the LDS (640x480x4x10, 1024 pairs: 510 k aligns/s with one 512-thread workgroup per CU, 593 k with two
+         * of 256; 256 pairs: 466 k vs 387 k -- so only when the launch fills every CU twice) */
+        else if (all_p4 && n_pairs >= 2 * c->n_cu && (size_t)max_n * 8 <= 2 * (size_t)77000) { block = 256; auto_lds = 77000; }
         else if ((size_t)max_n * 12 > 4 * (size_t)155000 && !c->prm.interpolate_dt) { block = 1024; auto_lds = 155000; }   /* lists far beyond the LDS
                                                                        budget are streamed: 16 waves hide that better (1920x1080x5, 256 pairs: 38.3 k -> 41.3 k aligns/s) */
         else { block = 512; auto_lds = 155000; }
@@ -290,15 +315,7 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         int bytes = c->prm.lds_point_bytes;
         /* auto: one workgroup per CU for >= 512 threads (it owns the CU's LDS), two for 256 */
         if (bytes == 0) bytes = auto_lds ? auto_lds : ((block >= 512) ? 155000 : 77000);
-        /* compact (8-byte) point lists when every list of this launch was built by the engine's own enlist kernels */
-        sc.compact = fused_uses_compact(c->prm.points_in_flight, c->prm.interpolate_dt) ? 1 : 0;
-        for (int l = 0; l < n_levels && sc.compact; l++) {
-            if (sc.iters[l] <= 0) continue;
-            for (int p = first_pair; p < first_pair + n_pairs && sc.compact; p++)
-                if (c->lv[l].compact_ok.empty() || !c->lv[l].compact_ok[sc.alias_mod > 0 ? p % sc.alias_mod : p]) sc.compact = 0;
-        }
         /* the CU has 160 KiB of LDS; the static part of the chosen kernel comes off the top */
-        const bool packed = sc.compact && c->prm.engine_variant != 1 && !(sc.flags & DVO_FLAG_NORMAL_MATRIX);
         /* the packed kernel needs its 256-register budget: 1024 threads would halve it (measured, 1920x1080x5, 256 pairs:
          * 512 threads 45.2 k aligns/s, 1024 threads 41.3 k; the one-point-per-lane kernel: 43.7 k at 1024) */
         if (packed && block_auto && block == 1024) block = 512;
@@ -309,19 +326,6 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         bytes &= ~63;
         sc.lds_bytes = bytes;
         sc.no_lds_tex = (c->prm.engine_variant == 2) ? 1 : 0;
-        sc.no_p4 = (c->prm.engine_variant == 4 || !packed || compact_now_policy() == 2) ? 1 : 0;
-        /* compact form of the now levels (dvo_palette.h): built for a level the second time it is aligned (or up front by
-         * dvo_now_prepare) -- a now level aligned once does not repay the build */
-        if (!sc.no_p4) {
-            for (int l = 0; l < n_levels; l++) {
-                if (sc.iters[l] <= 0) continue;
-                if ((rc = build_compact_now(c, l, first_pair, n_pairs, compact_now_policy() != 1))) return rc;
-                Level &L = c->lv[l];
-                for (int p = first_pair; p < first_pair + n_pairs; p++) L.now_uses[p]++;
-            }
-            for (int l = 0; l < DVO_LEVELS; l++) ls.l[l] = slab_of(c, l);       /* the build may have allocated */
-        }
-        sc.force_exact = (c->prm.engine_variant == 3) ? 1 : 0;
         sc.lds_points = bytes / (sc.compact ? 8 : 12);
         if (c->prm.lds_point_bytes < 0) { sc.lds_points = 0; sc.lds_bytes = 0; }
     }

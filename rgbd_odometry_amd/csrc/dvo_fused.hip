@@ -20,6 +20,16 @@
 #include "dvo_point_pk.h"
 #include "dvo_palette.h"
 
+/* rounds of gathers in flight in the compact-form loop.  Measured (640x480x4x10, 1024 pairs): two 256-thread workgroups per
+ * CU 555 k aligns/s at depth 2, 593 k at depth 3; one 512-thread workgroup 517 k / 510 k (its serial phases are exposed, not
+ * its gathers) */
+#ifndef DVO_WPE256
+#define DVO_WPE256 1        /* the compiler takes exactly the 256 registers two waves per SIMD allow (tests/test_kernel_registers.py); forcing 2 costs 5 % */
+#endif
+#ifndef DVO_P4_DEPTH
+#define DVO_P4_DEPTH(BLOCK) ((BLOCK) == 256 ? 3 : 2)
+#endif
+
 namespace dvo {
 
 /* per-lane sums of one iteration (the sub-gradient policy of :724-920 needs g and the energy only) */
@@ -74,16 +84,18 @@ template <> struct Round2<TEX_P4> {
 DVO_DEV unsigned texel_byte_offset(int yy, int xx, unsigned tile_col_bytes /* tiles_per_col * 128 */) {
     static_assert(DVO_TILE_Y_LOG2 == 2 && DVO_TILE_X_LOG2 == 1, "written for 4x2 tiles");
     /* ((xx>>1)*tpc + (yy>>2))*128 + (xx&1)*64 + (yy&3)*16  ==  (xx>>1)*tpc*128 + yy*32 - (yy&3)*16 + (xx&1)*64 */
-    return (unsigned)(xx >> 1) * tile_col_bytes + ((unsigned)yy << 5) - (((unsigned)yy & 3u) << 4) + (((unsigned)xx & 1u) << 6);
+    /* 24-bit multiply: full rate (a 32-bit v_mul_lo_u32 costs four instruction slots); tile columns and their byte size fit 24 bits */
+    return __umul24((unsigned)(xx >> 1), tile_col_bytes) + ((unsigned)yy << 5) - (((unsigned)yy & 3u) << 4) + (((unsigned)xx & 1u) << 6);
 }
 
 /* byte offset of the rank word ABOVE pixel (yy, xx) in the compact image (dvo_palette.h): the 12 bytes from there are
  * above / centre / below.  yy / 6 by multiplication (exact for yy < 98 000). */
 DVO_DEV unsigned p4_byte_offset(int yy, int xx, unsigned p4_col_bytes /* p4_tiles_per_col * 128 */) {
     static_assert(DVO_P4_ROWS == 6, "written for 6 interior rows per line");
-    const unsigned ty = ((unsigned)yy * 43691u) >> 18;
-    const unsigned ry = (unsigned)yy - 6u * ty;
-    return (unsigned)(xx >> 2) * p4_col_bytes + (ty << 7) + (((unsigned)xx & 3u) << 5) + (ry << 2);
+    /* (xx>>2)*col_bytes + ty*128 + (xx&3)*32 + (yy-6ty)*4  ==  (xx>>2)*col_bytes + (xx&3)*32 + yy*4 + ty*104; 24-bit multiplies (full
+     * rate; yy < 2^16, 43691 < 2^16, a level's column of lines < 2^24 bytes) */
+    const unsigned ty = __umul24((unsigned)yy, 43691u) >> 18;
+    return __umul24((unsigned)(xx >> 2), p4_col_bytes) + (((unsigned)xx & 3u) << 5) + ((unsigned)yy << 2) + __umul24(ty, 104u);
 }
 
 struct LdsPoints {
@@ -151,18 +163,26 @@ DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints 
     }
 }
 
-/* TEX_P4: {DT, gx, gy, w} of one pixel from its three rank words and the palette in LDS */
-DVO_DEV void p4_decode(const char *pal, const U3 &t, float &dt, float &gx, float &gy, float &w) {
-    const unsigned c8 = t.b & 0xfff8u;
-    const float2 pw = *reinterpret_cast<const float2 *>(pal + c8);
-    const float pu = *reinterpret_cast<const float *>(pal + (t.a & 0xfff8u));
-    const float pd = *reinterpret_cast<const float *>(pal + (t.c & 0xfff8u));
-    const int dr = ((int)(t.b << 8)) >> 24, dl = ((int)t.b) >> 24;
-    const float pr = *reinterpret_cast<const float *>(pal + (c8 + (unsigned)(dr << 3)));
-    const float pl = *reinterpret_cast<const float *>(pal + (c8 + (unsigned)(dl << 3)));
-    dt = pw.x; w = pw.y;
-    gx = 0.5f * (pr - pl);          /* imageGradient, SolveDVO.cpp:1063-1098 */
-    gy = 0.5f * (pd - pu);
+/* TEX_P4: {DT, gx, gy, w} of the two pixels of a round from their rank words and the palette in LDS; the values arrive in
+ * free registers, so the two pixels are paired and the gradients are packed subtractions / multiplications */
+DVO_DEV void p4_decode2(const char *pal, const U3 &t0, const U3 &t1, v2f &dt, v2f &gx, v2f &gy, v2f &w) {
+    const unsigned c0 = t0.b & 0xfff8u, c1 = t1.b & 0xfff8u;
+    const float2 pw0 = *reinterpret_cast<const float2 *>(pal + c0);
+    const float2 pw1 = *reinterpret_cast<const float2 *>(pal + c1);
+    v2f pu, pd, pr, pl;
+    pu.x = *reinterpret_cast<const float *>(pal + (t0.a & 0xfff8u));
+    pu.y = *reinterpret_cast<const float *>(pal + (t1.a & 0xfff8u));
+    pd.x = *reinterpret_cast<const float *>(pal + (t0.c & 0xfff8u));
+    pd.y = *reinterpret_cast<const float *>(pal + (t1.c & 0xfff8u));
+    const int dr0 = ((int)(t0.b << 8)) >> 24, dl0 = ((int)t0.b) >> 24;
+    const int dr1 = ((int)(t1.b << 8)) >> 24, dl1 = ((int)t1.b) >> 24;
+    pr.x = *reinterpret_cast<const float *>(pal + (c0 + (unsigned)(dr0 << 3)));
+    pr.y = *reinterpret_cast<const float *>(pal + (c1 + (unsigned)(dr1 << 3)));
+    pl.x = *reinterpret_cast<const float *>(pal + (c0 + (unsigned)(dl0 << 3)));
+    pl.y = *reinterpret_cast<const float *>(pal + (c1 + (unsigned)(dl1 << 3)));
+    dt.x = pw0.x; dt.y = pw1.x; w.x = pw0.y; w.y = pw1.y;
+    gx = (pr - pl) * 0.5f;          /* imageGradient, SolveDVO.cpp:1063-1098 */
+    gy = (pd - pu) * 0.5f;
 }
 
 /* (double)(float)(J_k w) * (double)eps is exact, so fma(a,b,c) == c + a*b bit for bit (:719-720, :777) */
@@ -177,18 +197,20 @@ DVO_DEV void acc7_add(Acc7 &a, const float *jw, float eps) {
 template <int TEX>
 DVO_DEV void round2_compute(const IterConst &c, const TexSrc &ts, const Round2<TEX> &b, Acc7 &a) {
     a.nvis += __popcll(__builtin_amdgcn_ballot_w64(b.vis0)) + __popcll(__builtin_amdgcn_ballot_w64(b.vis1));
-    float gx0, gx1, gy0, gy1, dt0, dt1, wt0, wt1;
-    if constexpr (TEX == TEX_P4) {
-        p4_decode(ts.pal, b.t0, dt0, gx0, gy0, wt0);
-        p4_decode(ts.pal, b.t1, dt1, gx1, gy1, wt1);
-    } else {
-        dt0 = b.t0.x; gx0 = b.t0.y; gy0 = b.t0.z; wt0 = b.t0.w;
-        dt1 = b.t1.x; gx1 = b.t1.y; gy1 = b.t1.z; wt1 = b.t1.w;
-    }
-    const float eps0 = b.vis0 ? dt0 : 0.0f, eps1 = b.vis1 ? dt1 : 0.0f;
-    const float w0 = b.vis0 ? wt0 : 0.0f, w1 = b.vis1 ? wt1 : 0.0f;
     v2f jw[6];
-    jacobian_weighted2(c, b.xn, b.yn, b.zn, gx0, gx1, gy0, gy1, w0, w1, jw);
+    float eps0, eps1;
+    if constexpr (TEX == TEX_P4) {
+        v2f dt, gx, gy, wt;
+        p4_decode2(ts.pal, b.t0, b.t1, dt, gx, gy, wt);
+        eps0 = b.vis0 ? dt.x : 0.0f; eps1 = b.vis1 ? dt.y : 0.0f;
+        v2f w;
+        w.x = b.vis0 ? wt.x : 0.0f; w.y = b.vis1 ? wt.y : 0.0f;
+        jacobian_weighted2p(c, b.xn, b.yn, b.zn, gx, gy, w, jw);
+    } else {
+        eps0 = b.vis0 ? b.t0.x : 0.0f; eps1 = b.vis1 ? b.t1.x : 0.0f;
+        const float w0 = b.vis0 ? b.t0.w : 0.0f, w1 = b.vis1 ? b.t1.w : 0.0f;
+        jacobian_weighted2(c, b.xn, b.yn, b.zn, b.t0.y, b.t1.y, b.t0.z, b.t1.z, w0, w1, jw);
+    }
     const double e0 = (double)eps0, e1 = (double)eps1;
 #pragma unroll
     for (int k = 0; k < 6; k++) {
@@ -201,7 +223,7 @@ DVO_DEV void round2_compute(const IterConst &c, const TexSrc &ts, const Round2<T
 
 /* the per-point phase of one iteration over points [first, end): rounds of 2*BLOCK points, lane `lane_off` of the
  * round takes points lane_off and BLOCK + lane_off; software-pipelined over rounds with two named buffers */
-template <int BLOCK, bool LDS_SRC, int TEX>
+template <int BLOCK, bool LDS_SRC, int TEX, int DEPTH = 2>
 DVO_DEV void accumulate_points2(const IterConst &c, const TexSrc &ts, const LdsPoints &lp, const uint2 *__restrict__ gpts,
                                 int first, int end, int lane_off, Acc7 &a, bool &any_odd) {
     if (first >= end) return;
@@ -210,24 +232,54 @@ DVO_DEV void accumulate_points2(const IterConst &c, const TexSrc &ts, const LdsP
     const int wave_off = __builtin_amdgcn_readfirstlane(lane_off - (int)(threadIdx.x & 63));
     const int n_rounds = (end - first - wave_off + STEP - 1) / STEP;
     if (n_rounds <= 0) return;
-    Round2<TEX> A, B;
+#define DVO_ISSUE(buf, k) round2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + (k) * STEP, base + (k) * STEP + BLOCK, end, buf, any_odd)
+#define DVO_COMPUTE(buf) round2_compute<TEX>(c, ts, buf, a)
     int base = first + lane_off;
-    round2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base, base + BLOCK, end, A, any_odd);
-    int r = 0;
-    for (; r + 2 < n_rounds; r += 2) {
-        round2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + STEP, base + STEP + BLOCK, end, B, any_odd);
-        round2_compute<TEX>(c, ts, A, a);
-        round2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + 2 * STEP, base + 2 * STEP + BLOCK, end, A, any_odd);
-        round2_compute<TEX>(c, ts, B, a);
-        base += 2 * STEP;
-    }
-    if (r + 1 < n_rounds) {
-        round2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + STEP, base + STEP + BLOCK, end, B, any_odd);
-        round2_compute<TEX>(c, ts, A, a);
-        round2_compute<TEX>(c, ts, B, a);
+    if constexpr (DEPTH == 3) {
+        /* gathers issued TWO rounds ahead of the arithmetic that consumes them: with half the requests per point (TEX_P4) the
+         * loop is no longer bound by the request rate but by the latency of a gather that misses the L2 (~2 rounds of
+         * arithmetic); three named buffers, branch-free steady state (the wait counters stay exact), branches in the tail */
+        Round2<TEX> A, B, C;
+        DVO_ISSUE(A, 0);
+        if (n_rounds > 1) DVO_ISSUE(B, 1);
+        int r = 0;
+        for (; r + 4 < n_rounds; r += 3) {
+            DVO_ISSUE(C, 2); DVO_COMPUTE(A);
+            DVO_ISSUE(A, 3); DVO_COMPUTE(B);
+            DVO_ISSUE(B, 4); DVO_COMPUTE(C);
+            base += 3 * STEP;
+        }
+        /* A = round r, B = round r+1 (if any); 1..4 rounds left */
+        const int left = n_rounds - r;
+        if (left >= 3) DVO_ISSUE(C, 2);
+        DVO_COMPUTE(A);
+        if (left >= 2) {
+            if (left >= 4) DVO_ISSUE(A, 3);
+            DVO_COMPUTE(B);
+            if (left >= 3) {
+                DVO_COMPUTE(C);
+                if (left >= 4) DVO_COMPUTE(A);
+            }
+        }
     } else {
-        round2_compute<TEX>(c, ts, A, a);
+        Round2<TEX> A, B;
+        DVO_ISSUE(A, 0);
+        int r = 0;
+        for (; r + 2 < n_rounds; r += 2) {
+            DVO_ISSUE(B, 1); DVO_COMPUTE(A);
+            DVO_ISSUE(A, 2); DVO_COMPUTE(B);
+            base += 2 * STEP;
+        }
+        if (r + 1 < n_rounds) {
+            DVO_ISSUE(B, 1);
+            DVO_COMPUTE(A);
+            DVO_COMPUTE(B);
+        } else {
+            DVO_COMPUTE(A);
+        }
     }
+#undef DVO_ISSUE
+#undef DVO_COMPUTE
 }
 
 /* The same sums with the literal-division scalar code (dvo_device_math.h: project_point, jacobian_row) over THIS wave's
@@ -370,7 +422,7 @@ DVO_DEV unsigned long long stamp_now2() {
 #endif
 
 template <int BLOCK, bool TEAM>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 8)))
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK == 256 ? DVO_WPE256 : 1, 8)))
 align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outputs out, int first_pair) {
     /* team mode: workgroup b -> XCD b % 8; the G members of pair (q*8 + x) are the workgroups x + 8*(q*G + j) */
     const int G = TEAM ? sc.team : 1;
@@ -521,8 +573,8 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             if (mode == TEX_L16) {                 /* staged levels hold every point in LDS */
                 accumulate_points2<BLOCK, true, TEX_L16>(c, ts, lp, gpts, 0, N, lane_off, a, any_odd);             /* :369, :433 */
             } else if (mode == TEX_P4) {
-                accumulate_points2<BLOCK, true, TEX_P4>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
-                accumulate_points2<BLOCK, false, TEX_P4>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);
+                accumulate_points2<BLOCK, true, TEX_P4, DVO_P4_DEPTH(BLOCK)>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
+                accumulate_points2<BLOCK, false, TEX_P4, DVO_P4_DEPTH(BLOCK)>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);
             } else {
                 accumulate_points2<BLOCK, true, TEX_G16>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
                 accumulate_points2<BLOCK, false, TEX_G16>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);       /* beyond the LDS budget */

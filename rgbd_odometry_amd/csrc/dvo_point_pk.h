@@ -111,5 +111,29 @@ DVO_DEV void jacobian_weighted2(const IterConst &c, v2f xn, v2f yn, v2f zn, floa
     jw[5].x = j5.x * wt0; jw[5].y = j5.y * wt1;
 }
 
+/* the same with the gradients and weights of the two points already paired (they come from LDS lookups, dvo_palette.h): every
+ * product is packed.  Same operations in the same order per half -> same bits as jacobian_weighted2. */
+DVO_DEV void jacobian_weighted2p(const IterConst &c, v2f xn, v2f yn, v2f zn, v2f gx, v2f gy, v2f wt, v2f *jw) {
+    const v2f n02 = (-c.m00) * xn, n12 = (-c.m11) * yn;
+    const v2f dz = pk_splat(1.0f) - zn;
+    const v2f cz1 = dz * DVO_K24, cz2 = dz * DVO_K23;
+    const v2f a00 = pk_fma(pk_splat(c.m00), cz1, pk_splat(c.m00));          /* :388 */
+    const v2f a11 = pk_fma(pk_splat(c.m11), cz1, pk_splat(c.m11));          /* :392 */
+    const v2f a02 = pk_fma(n02, cz2, n02);                                  /* :390 */
+    const v2f a12 = pk_fma(n12, cz2, n12);                                  /* :393 */
+    const v2f ga0 = gx * a00, ga1 = gy * a11;
+    const v2f ga2 = gx * a02 + gy * a12;
+    const v2f w0 = (c.r[0] * xn + c.r[1] * yn) + c.r[2] * zn;              /* :399 */
+    const v2f w1 = (c.r[3] * xn + c.r[4] * yn) + c.r[5] * zn;
+    const v2f w2 = (c.r[6] * xn + c.r[7] * yn) + c.r[8] * zn;
+    const v2f j0 = -((ga0 * c.r[0] + ga1 * c.r[3]) + ga2 * c.r[6]);
+    const v2f j1 = -((ga0 * c.r[1] + ga1 * c.r[4]) + ga2 * c.r[7]);
+    const v2f j2 = -((ga0 * c.r[2] + ga1 * c.r[5]) + ga2 * c.r[8]);
+    const v2f j3 = ga1 * w2 - ga2 * w1;                                     /* :401-402, :1104-1114 */
+    const v2f j4 = ga2 * w0 - ga0 * w2;
+    const v2f j5 = ga0 * w1 - ga1 * w0;
+    jw[0] = j0 * wt; jw[1] = j1 * wt; jw[2] = j2 * wt; jw[3] = j3 * wt; jw[4] = j4 * wt; jw[5] = j5 * wt;     /* :716 */
+}
+
 }  // namespace dvo
 #endif

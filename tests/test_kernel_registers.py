@@ -1,0 +1,52 @@
+"""The register budget of the fused alignment kernels, read from the code objects inside lib/libdvo_amd.so.
+
+The throughput configuration of the packed kernel (rgbd_odometry_amd/csrc/dvo_fused.hip) runs two waves per SIMD -- one
+512-thread workgroup or two 256-thread workgroups per compute unit -- which gives a wave at most 256 vector registers.  A
+kernel that needs one more silently halves its occupancy (or spills to scratch), so the budget is pinned here.  CPU test: the
+numbers are in the ELF notes of the embedded gfx950 code object (llvm-readelf from the ROCm LLVM).
+"""
+import os
+import re
+import struct
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "rgbd_odometry_amd", "lib", "libdvo_amd.so")
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+def _kernel_resources(tmp_path):
+    data = open(LIB, "rb").read()
+    out = {}
+    for m in re.finditer(b"\x7fELF\x02\x01\x01", data):
+        o = m.start()
+        if o == 0 or struct.unpack_from("<H", data, o + 18)[0] != 224:        # EM_AMDGPU
+            continue
+        shoff = struct.unpack_from("<Q", data, o + 0x28)[0]
+        shentsize, shnum = struct.unpack_from("<HH", data, o + 0x3A)
+        f = tmp_path / ("co_%d.elf" % o)
+        f.write_bytes(data[o:o + shoff + shentsize * shnum])
+        notes = subprocess.run([READELF, "--notes", str(f)], capture_output=True, text=True, check=True).stdout
+        for blk in notes.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            if not name:
+                continue
+            get = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
+            out[name.group(1)] = dict(vgpr=get("vgpr_count"), vgpr_spill=get("vgpr_spill_count"),
+                                      agpr=int(re.match(r"\s*(\d+)", blk).group(1)), scratch=get("private_segment_fixed_size"))
+    return out
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(READELF)), reason="library or llvm-readelf missing")
+def test_packed_kernel_fits_two_waves_per_simd(tmp_path):
+    res = _kernel_resources(tmp_path)
+    fused2 = {k: v for k, v in res.items() if "align_fused2_kernel" in k}
+    assert len(fused2) >= 6, sorted(res)[:10]
+    for block in (256, 512):
+        k = [n for n in fused2 if "ILi%dELb0E" % block in n]
+        assert len(k) == 1, k
+        r = fused2[k[0]]
+        assert r["vgpr"] + r["agpr"] <= 256, (block, r)       # two waves per SIMD (512 registers per lane and SIMD)
+        assert r["vgpr_spill"] == 0 and r["scratch"] == 0, (block, r)
