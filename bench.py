@@ -29,7 +29,7 @@ import torch  # imported before the HIP library on purpose: one HIP runtime per 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak ~6290
 
 #: the sources the fused alignment kernels are built from: their hash ties profiles/pmc_traffic.json to a kernel build
-KERNEL_SOURCES = ["dvo_fused.hip", "dvo_point_pk.h", "dvo_kernels.hip", "dvo_kernel_common.h", "dvo_device_math.h"]
+KERNEL_SOURCES = ["dvo_fused.hip", "dvo_point_pk.h", "dvo_palette.h", "dvo_kernels.hip", "dvo_kernel_common.h", "dvo_device_math.h"]
 
 
 def kernel_source_hash():
@@ -251,6 +251,13 @@ def main():
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
 
 
+    blk, team, packed = ctx.last_launch_shape()
+    modes = [ctx.level_texel_mode(0, l) for l in range(args.levels)]
+    kernel_label = ("align_fused2_kernel<%d,%s> (packed, two points per lane; dvo_fused.hip; %s; now levels read as %s)" %
+                    (blk, "true" if team > 1 else "false",
+                     "teams of %d workgroups per pair" % team if team > 1 else ("two workgroups per CU" if blk == 256 else "one workgroup per CU"),
+                     "/".join({0: "16-byte texels", 1: "LDS-staged texels", 2: "compact 4-byte form"}.get(m, "?") for m in modes))
+                    if packed else "align_fused_kernel<%d> (one point per lane; dvo_kernels.hip)" % blk)
     if rank == 0:
         out = {
             "metric": "frame-pair aligns/sec (%dx%d, %d-lvl pyr)" % (args.width, args.height, args.levels),
@@ -265,7 +272,7 @@ def main():
                 "pairs_per_gpu": args.batch, "iters_per_level": iters,
                 **({"total_pairs": total_pairs} if total_pairs > 0 else {}),
                 "final_outputs": not args.no_final_outputs,
-                "block_threads": args.block or "auto (256 for short point lists in large batches, 1024 for lists over 620 KB, else 512)",
+                "block_threads": args.block or ("auto: %d" % blk),
                 "points_in_flight": args.inflight or 1,
                 **({"debug_alias_mod": args.debug_alias} if args.debug_alias else {}),
                 **({"engine_variant": args.variant} if args.variant else {}),
@@ -276,8 +283,7 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": None,
-                "kernel": "align_fused2_kernel<512,false> (packed, two points per lane; dvo_fused.hip)" if not (args.variant == 1 or args.normal_matrix)
-                          else "align_fused_kernel (one point per lane; dvo_kernels.hip)", "kernel_ms": kernel_ms,
+                "kernel": kernel_label, "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "algorithmic_bytes_per_alignment": bytes_per_launch / args.batch,
             },

@@ -267,6 +267,10 @@ int  dvo_device_rotationize(dvo_ctx *ctx, double *R);
  * level fits beside its point list; 2 = the level's compact form (below); -1 = not run.  Inspection / tests. */
 int  dvo_get_level_texel_mode(dvo_ctx *ctx, int pair, int level, int *mode);
 
+/* Shape the engine chose for the last fused (batch) launch: threads per workgroup (256: two workgroups per compute unit,
+ * 512 / 1024: one), workgroups per frame pair (team mode, 1 = none), packed = 1: the two-points-per-lane kernel.  Inspection. */
+int  dvo_get_last_launch_shape(dvo_ctx *ctx, int *block_threads, int *team_size, int *packed);
+
 /* Compact form of resident now levels (engine detail, results are bit-identical with or without it).  The three images the
  * reference keeps per now level (dist transform :1768-1795, its imageGradient :1063-1098; the weight :1047-1053 is a function
  * of the first) are redundant: a pixel is described by the rank of its distance value among the image's distinct values and

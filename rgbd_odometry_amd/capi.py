@@ -30,7 +30,7 @@ C_ABI_SYMBOLS = [
     "dvo_set_poses", "dvo_align_batch_enqueue", "dvo_get_poses", "dvo_get_level_report",
     "dvo_get_final_outputs", "dvo_get_level_normal_matrix", "dvo_eval_points", "dvo_accumulate", "dvo_device_se3_exp",
     "dvo_device_se3_log", "dvo_device_rotationize", "dvo_algorithmic_bytes", "dvo_point_iterations",
-    "dvo_debug_stamps", "dvo_get_level_texel_mode", "dvo_now_prepare", "dvo_get_now_compact_info", "dvo_replicate_pairs", "dvo_set_now_level_from_edges", "dvo_get_now_level", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
+    "dvo_debug_stamps", "dvo_get_level_texel_mode", "dvo_now_prepare", "dvo_get_now_compact_info", "dvo_get_last_launch_shape", "dvo_replicate_pairs", "dvo_set_now_level_from_edges", "dvo_get_now_level", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
     "dvo_align_pyramid_wide", "dvo_tiled_attach", "dvo_tiled_detach", "dvo_align_pyramid_tiled",
     "dvo_get_ref_level", "dvo_frames_reserve", "dvo_frames_upload_pyramids", "dvo_frames_upload_cameras", "dvo_frames_set_undistort",
     "dvo_photo_params_default", "dvo_photo_configure", "dvo_photo_set_ref", "dvo_photo_align", "dvo_photo_get_jacobian", "dvo_frames_as_now",
@@ -201,6 +201,7 @@ def load_library() -> C.CDLL:
         "dvo_debug_stamps": [vp, i, vp],
         "dvo_get_level_texel_mode": [vp, i, i, ip],
         "dvo_now_prepare": [vp, i, i],
+        "dvo_get_last_launch_shape": [vp, ip, ip, ip],
         "dvo_get_now_compact_info": [vp, i, i, ip],
         "dvo_replicate_pairs": [vp, i, i, i],
         "dvo_set_now_level_from_edges": [vp, i, i, vp, i, i],
@@ -663,6 +664,12 @@ class DvoContext:
         m = C.c_int(-2)
         self._chk(self.lib.dvo_get_level_texel_mode(self._h, pair, level, C.byref(m)))
         return m.value
+
+    def last_launch_shape(self):
+        """(threads per workgroup, workgroups per pair, packed kernel?) of the last fused launch"""
+        b, t, k = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._chk(self.lib.dvo_get_last_launch_shape(self._h, C.byref(b), C.byref(t), C.byref(k)))
+        return b.value, t.value, bool(k.value)
 
     def now_prepare(self, first_pair: int = 0, count: Optional[int] = None):
         """build the compact (4 bytes per pixel) form of the resident now levels of these pairs now"""

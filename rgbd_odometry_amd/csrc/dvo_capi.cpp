@@ -373,6 +373,8 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
     else
         HIPCHK(c, launch_align_fused(block, u, ls, sc, c->K, c->dprm, outputs_of(c),
                                      first_pair, n_pairs, c->stream));
+    c->last_block = block; c->last_team = sc.team;
+    c->last_packed = (sc.compact && c->prm.engine_variant != 1 && !(sc.flags & DVO_FLAG_NORMAL_MATRIX)) ? 1 : 0;
     stamp_outputs(c, sc, first_pair, n_pairs);
     c->sched = sc;
     c->have_sched = true;
@@ -737,6 +739,15 @@ int dvo_replicate_pairs(dvo_ctx *c, int n_src, int dst_first, int dst_count) {
         if (L.tex && dst_count > 0) { int rc = now_written(c, l, dst_first, dst_count); if (rc) return rc; }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DVO_OK;
+}
+
+/* shape of the last fused launch: threads per workgroup, workgroups per pair (team), 1 = packed two-points-per-lane kernel */
+int dvo_get_last_launch_shape(dvo_ctx *c, int *block_threads, int *team_size, int *packed) {
+    if (!c) return DVO_ERR_INVALID;
+    if (block_threads) *block_threads = c->last_block;
+    if (team_size) *team_size = c->last_team;
+    if (packed) *packed = c->last_packed;
     return DVO_OK;
 }
 

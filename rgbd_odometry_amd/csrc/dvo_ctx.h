@@ -93,6 +93,7 @@ struct dvo_ctx {
     /* team mode of the packed kernel (G workgroups per pair for small batches): exchange slots, arrival counters, error flag */
     double *d_team_buf = nullptr;
     unsigned *d_team_cnt = nullptr;      /* n_pairs counters followed by one int error flag */
+    int last_block = 0, last_team = 0, last_packed = 0;   /* shape of the last fused launch (dvo_get_last_launch_shape) */
     bool team_used = false;              /* the last enqueue ran in team mode: dvo_get_poses checks the error flag */      /* n_pairs x DVO_LEVELS, written by the packed fused kernel */
     int final_cap = 0;
     double *d_scratch = nullptr;    /* partials (1024 x 32) + acc (32) + misc doubles */

@@ -62,7 +62,6 @@ struct TexSrc {
     const char *l16;           /* LDS copy of the same bytes (TEX_L16) */
     const char *p4;            /* this pair's level in HBM, compact form (TEX_P4) */
     unsigned p4_col_bytes;     /* p4_tiles_per_col * 128 */
-    const char *pal;           /* the level's palette {P, W} in LDS (TEX_P4) */
 };
 
 /* three consecutive dwords at any 4-byte boundary (one global_load_dwordx3) */
@@ -76,9 +75,12 @@ template <int TEX> struct Round2 {
 };
 template <> struct Round2<TEX_P4> {
     v2f xn, yn, zn;
-    U3 t0, t1;         /* rank words above / at / below the two pixels */
-    bool vis0, vis1;
+    U3 t0, t1;         /* rank words above / at / below the two pixels (the sentinel line for a lane without a visible point) */
 };
+
+/* LDS address of the palette = start of the dynamic LDS = size of the kernel's static block (checked at run time) */
+typedef const __attribute__((address_space(3))) float lds_cfloat;
+typedef const __attribute__((address_space(3))) v2f lds_cv2f;
 
 /* byte offset of texel (yy, xx) in the tiled 16-byte texel image (texel_index() * 16 in seven instructions) */
 DVO_DEV unsigned texel_byte_offset(int yy, int xx, unsigned tile_col_bytes /* tiles_per_col * 128 */) {
@@ -95,22 +97,17 @@ DVO_DEV unsigned p4_byte_offset(int yy, int xx, unsigned p4_col_bytes /* p4_tile
     /* (xx>>2)*col_bytes + ty*128 + (xx&3)*32 + (yy-6ty)*4  ==  (xx>>2)*col_bytes + (xx&3)*32 + yy*4 + ty*104; 24-bit multiplies (full
      * rate; yy < 2^16, 43691 < 2^16, a level's column of lines < 2^24 bytes) */
     const unsigned ty = __umul24((unsigned)yy, 43691u) >> 18;
-    return __umul24((unsigned)(xx >> 2), p4_col_bytes) + (((unsigned)xx & 3u) << 5) + ((unsigned)yy << 2) + __umul24(ty, 104u);
+    return __umul24((unsigned)(xx >> 2), p4_col_bytes) + 128u /* the sentinel line */ + (((unsigned)xx & 3u) << 5) + ((unsigned)yy << 2) + __umul24(ty, 104u);
 }
 
 struct LdsPoints {
-    const unsigned *pk;    /* xx | yy << 16 */
-    const float *z;
+    const uint2 *p;        /* {xx | yy << 16, Z}: 8 bytes per point, one ds_read_b64 */
 };
 
 template <bool LDS_SRC>
 DVO_DEV void load_compact(const LdsPoints &lp, const uint2 *__restrict__ gpts, int j, unsigned &k, float &z) {
-    if (LDS_SRC) {
-        k = lp.pk[j]; z = lp.z[j];
-    } else {
-        const uint2 a = gpts[j];
-        k = a.x; z = __uint_as_float(a.y);
-    }
+    const uint2 a = LDS_SRC ? lp.p[j] : gpts[j];
+    k = a.x; z = __uint_as_float(a.y);
 }
 
 /* stage 1 of a round: load, decode, project, issue the two gathers.  Straight-line code: a point whose z is outside the
@@ -119,7 +116,7 @@ DVO_DEV void load_compact(const LdsPoints &lp, const uint2 *__restrict__ gpts, i
  * share of the iteration with the literal-division scalar code (accumulate_points_exact). */
 template <bool LDS_SRC, int TEX>
 DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints &lp, const uint2 *__restrict__ gpts,
-                          int i0, int i1, int end, Round2<TEX> &b, bool &any_odd) {
+                          int i0, int i1, int end, Round2<TEX> &b, bool &any_odd, int &nvis) {
     const bool valid0 = i0 < end, valid1 = i1 < end;
     const int j0 = valid0 ? i0 : (end - 1), j1 = valid1 ? i1 : (end - 1);
     unsigned k0, k1;
@@ -141,18 +138,21 @@ DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints 
     const bool inx1 = pixel_in_range(u.y, c.cols, px1), iny1 = pixel_in_range(v.y, c.rows, py1);
     const bool vis0 = inx0 && iny0 && valid0 && !odd0;
     const bool vis1 = inx1 && iny1 && valid1 && !odd1;
-    b.vis0 = vis0; b.vis1 = vis1;
-    /* finite dummies for lanes without a visible point: they then add exact zeros (w = eps = 0) */
-    b.xn.x = vis0 ? xn.x : 0.0f; b.yn.x = vis0 ? yn.x : 0.0f; b.zn.x = vis0 ? zn.x : 1.0f;
-    b.xn.y = vis1 ? xn.y : 0.0f; b.yn.y = vis1 ? yn.y : 0.0f; b.zn.y = vis1 ? zn.y : 1.0f;
+    /* finite dummies for lanes without a visible point: they then add exact zeros (w = eps = 0).  zn needs none: it is 1 or
+     * 1-2^-24 on every lane whose z is in the proven range, and a wave with a lane outside it discards its sums (any_odd) */
+    b.xn.x = vis0 ? xn.x : 0.0f; b.yn.x = vis0 ? yn.x : 0.0f;
+    b.xn.y = vis1 ? xn.y : 0.0f; b.yn.y = vis1 ? yn.y : 0.0f;
+    b.zn = zn;
     if constexpr (TEX == TEX_P4) {
+        nvis += __popcll(__builtin_amdgcn_ballot_w64(vis0)) + __popcll(__builtin_amdgcn_ballot_w64(vis1));
         unsigned o0 = p4_byte_offset(py0, px0, ts.p4_col_bytes);
         unsigned o1 = p4_byte_offset(py1, px1, ts.p4_col_bytes);
-        o0 = vis0 ? o0 : 0u;                                   /* line 0 of the image: valid ranks whatever the pixel */
+        o0 = vis0 ? o0 : 0u;                                   /* the sentinel line: DT = gx = gy = w = 0 */
         o1 = vis1 ? o1 : 0u;
         b.t0 = *reinterpret_cast<const U3 *>(ts.p4 + o0);
         b.t1 = *reinterpret_cast<const U3 *>(ts.p4 + o1);
     } else {
+        b.vis0 = vis0; b.vis1 = vis1;
         unsigned o0 = texel_byte_offset(py0, px0, ts.tile_col_bytes);
         unsigned o1 = texel_byte_offset(py1, px1, ts.tile_col_bytes);
         o0 = vis0 ? o0 : 0u;
@@ -163,23 +163,29 @@ DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints 
     }
 }
 
-/* TEX_P4: {DT, gx, gy, w} of the two pixels of a round from their rank words and the palette in LDS; the values arrive in
- * free registers, so the two pixels are paired and the gradients are packed subtractions / multiplications */
-DVO_DEV void p4_decode2(const char *pal, const U3 &t0, const U3 &t1, v2f &dt, v2f &gx, v2f &gy, v2f &w) {
+/* rank * 8 + 8 * (signed rank step) in one instruction */
+DVO_DEV unsigned lshl3_add(int d, unsigned c) {
+    unsigned r;
+    asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(r) : "v"(d), "v"(c));
+    return r;
+}
+/* TEX_P4: {DT, gx, gy, w} of the two pixels of a round from their rank words and the palette in LDS (at the compile-time LDS
+ * address PAL: the look-ups use the instruction's offset field, no address add); the values arrive in free registers, so the
+ * two pixels are paired and the gradients are packed subtractions / multiplications */
+template <unsigned PAL>
+DVO_DEV void p4_decode2(const U3 &t0, const U3 &t1, v2f &dt, v2f &gx, v2f &gy, v2f &w) {
     const unsigned c0 = t0.b & 0xfff8u, c1 = t1.b & 0xfff8u;
-    const float2 pw0 = *reinterpret_cast<const float2 *>(pal + c0);
-    const float2 pw1 = *reinterpret_cast<const float2 *>(pal + c1);
+    const v2f pw0 = *(lds_cv2f *)(PAL + c0);
+    const v2f pw1 = *(lds_cv2f *)(PAL + c1);
     v2f pu, pd, pr, pl;
-    pu.x = *reinterpret_cast<const float *>(pal + (t0.a & 0xfff8u));
-    pu.y = *reinterpret_cast<const float *>(pal + (t1.a & 0xfff8u));
-    pd.x = *reinterpret_cast<const float *>(pal + (t0.c & 0xfff8u));
-    pd.y = *reinterpret_cast<const float *>(pal + (t1.c & 0xfff8u));
-    const int dr0 = ((int)(t0.b << 8)) >> 24, dl0 = ((int)t0.b) >> 24;
-    const int dr1 = ((int)(t1.b << 8)) >> 24, dl1 = ((int)t1.b) >> 24;
-    pr.x = *reinterpret_cast<const float *>(pal + (c0 + (unsigned)(dr0 << 3)));
-    pr.y = *reinterpret_cast<const float *>(pal + (c1 + (unsigned)(dr1 << 3)));
-    pl.x = *reinterpret_cast<const float *>(pal + (c0 + (unsigned)(dl0 << 3)));
-    pl.y = *reinterpret_cast<const float *>(pal + (c1 + (unsigned)(dl1 << 3)));
+    pu.x = *(lds_cfloat *)(PAL + (t0.a & 0xfff8u));
+    pu.y = *(lds_cfloat *)(PAL + (t1.a & 0xfff8u));
+    pd.x = *(lds_cfloat *)(PAL + (t0.c & 0xfff8u));
+    pd.y = *(lds_cfloat *)(PAL + (t1.c & 0xfff8u));
+    pr.x = *(lds_cfloat *)(PAL + lshl3_add(__builtin_amdgcn_sbfe((int)t0.b, 16, 8), c0));
+    pr.y = *(lds_cfloat *)(PAL + lshl3_add(__builtin_amdgcn_sbfe((int)t1.b, 16, 8), c1));
+    pl.x = *(lds_cfloat *)(PAL + lshl3_add(((int)t0.b) >> 24, c0));
+    pl.y = *(lds_cfloat *)(PAL + lshl3_add(((int)t1.b) >> 24, c1));
     dt.x = pw0.x; dt.y = pw1.x; w.x = pw0.y; w.y = pw1.y;
     gx = (pr - pl) * 0.5f;          /* imageGradient, SolveDVO.cpp:1063-1098 */
     gy = (pd - pu) * 0.5f;
@@ -194,19 +200,17 @@ DVO_DEV void acc7_add(Acc7 &a, const float *jw, float eps) {
 }
 
 /* stage 2: weighted Jacobian rows + accumulation */
-template <int TEX>
-DVO_DEV void round2_compute(const IterConst &c, const TexSrc &ts, const Round2<TEX> &b, Acc7 &a) {
-    a.nvis += __popcll(__builtin_amdgcn_ballot_w64(b.vis0)) + __popcll(__builtin_amdgcn_ballot_w64(b.vis1));
+template <int TEX, unsigned PAL>
+DVO_DEV void round2_compute(const IterConst &c, const Round2<TEX> &b, Acc7 &a) {
     v2f jw[6];
     float eps0, eps1;
     if constexpr (TEX == TEX_P4) {
         v2f dt, gx, gy, wt;
-        p4_decode2(ts.pal, b.t0, b.t1, dt, gx, gy, wt);
-        eps0 = b.vis0 ? dt.x : 0.0f; eps1 = b.vis1 ? dt.y : 0.0f;
-        v2f w;
-        w.x = b.vis0 ? wt.x : 0.0f; w.y = b.vis1 ? wt.y : 0.0f;
-        jacobian_weighted2p(c, b.xn, b.yn, b.zn, gx, gy, w, jw);
+        p4_decode2<PAL>(b.t0, b.t1, dt, gx, gy, wt);        /* zeros for a lane without a visible point (sentinel) */
+        eps0 = dt.x; eps1 = dt.y;
+        jacobian_weighted2p(c, b.xn, b.yn, b.zn, gx, gy, wt, jw);
     } else {
+        a.nvis += __popcll(__builtin_amdgcn_ballot_w64(b.vis0)) + __popcll(__builtin_amdgcn_ballot_w64(b.vis1));
         eps0 = b.vis0 ? b.t0.x : 0.0f; eps1 = b.vis1 ? b.t1.x : 0.0f;
         const float w0 = b.vis0 ? b.t0.w : 0.0f, w1 = b.vis1 ? b.t1.w : 0.0f;
         jacobian_weighted2(c, b.xn, b.yn, b.zn, b.t0.y, b.t1.y, b.t0.z, b.t1.z, w0, w1, jw);
@@ -223,7 +227,7 @@ DVO_DEV void round2_compute(const IterConst &c, const TexSrc &ts, const Round2<T
 
 /* the per-point phase of one iteration over points [first, end): rounds of 2*BLOCK points, lane `lane_off` of the
  * round takes points lane_off and BLOCK + lane_off; software-pipelined over rounds with two named buffers */
-template <int BLOCK, bool LDS_SRC, int TEX, int DEPTH = 2>
+template <int BLOCK, bool LDS_SRC, int TEX, int DEPTH = 2, unsigned PAL = 0>
 DVO_DEV void accumulate_points2(const IterConst &c, const TexSrc &ts, const LdsPoints &lp, const uint2 *__restrict__ gpts,
                                 int first, int end, int lane_off, Acc7 &a, bool &any_odd) {
     if (first >= end) return;
@@ -232,8 +236,8 @@ DVO_DEV void accumulate_points2(const IterConst &c, const TexSrc &ts, const LdsP
     const int wave_off = __builtin_amdgcn_readfirstlane(lane_off - (int)(threadIdx.x & 63));
     const int n_rounds = (end - first - wave_off + STEP - 1) / STEP;
     if (n_rounds <= 0) return;
-#define DVO_ISSUE(buf, k) round2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + (k) * STEP, base + (k) * STEP + BLOCK, end, buf, any_odd)
-#define DVO_COMPUTE(buf) round2_compute<TEX>(c, ts, buf, a)
+#define DVO_ISSUE(buf, k) round2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + (k) * STEP, base + (k) * STEP + BLOCK, end, buf, any_odd, a.nvis)
+#define DVO_COMPUTE(buf) round2_compute<TEX, PAL>(c, buf, a)
     int base = first + lane_off;
     if constexpr (DEPTH == 3) {
         /* gathers issued TWO rounds ahead of the arithmetic that consumes them: with half the requests per point (TEX_P4) the
@@ -436,11 +440,17 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
     const int pair = first_pair + pair_local;
     const int tid = threadIdx.x;
     unsigned epoch = 0;                          /* exchanges done so far (team mode) */
-    __shared__ PoseState st;
-    __shared__ double red[BLOCK / 64][8];
-    __shared__ double tot[8];
-    __shared__ double team_stage[TEAM ? DVO_TEAM_MAX : 1][8];
-    extern __shared__ float lds_dyn[];          /* sc.lds_bytes: per level two planes of point words (xx|yy<<16 and Z) and, when it fits, the now level */
+    /* static LDS as ONE block of known size, so that the dynamic part -- which starts with the palette of the compact now
+     * form -- begins at a compile-time LDS address (kStatic; verified below): palette look-ups then need no address add */
+    constexpr unsigned kPose = (unsigned)((sizeof(PoseState) + 15) & ~15u);
+    constexpr unsigned kStatic = kPose + (BLOCK / 64) * 64 + 64 + (TEAM ? DVO_TEAM_MAX : 1) * 64;
+    __shared__ __attribute__((aligned(16))) char s_static[kStatic];
+    PoseState &st = *reinterpret_cast<PoseState *>(s_static);
+    double (*const red)[8] = reinterpret_cast<double (*)[8]>(s_static + kPose);
+    double *const tot = reinterpret_cast<double *>(s_static + kPose + (BLOCK / 64) * 64);
+    double (*const team_stage)[8] = reinterpret_cast<double (*)[8]>(s_static + kPose + (BLOCK / 64) * 64 + 64);
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];   /* sc.lds_bytes: per level [palette |] points [| the now level, when it fits] */
+    const bool pal_base_ok = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds_dyn == kStatic;
 
     if (tid == 0) {
         const double *p = out.poses + (size_t)pair * 12;
@@ -489,20 +499,21 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         /* the compact form of this pair's level, if the builder could make one (dvo_palette.h): its palette goes first */
         const int n_pal = (!sc.no_p4 && L.pal_n) ? max(0, __builtin_amdgcn_readfirstlane(L.pal_n[dpair])) : 0;
         const int mode = (!TEAM && !sc.no_lds_tex && 2 * n_pad + tex16_words <= lds_words) ? TEX_L16
-                         : ((n_pal > 0 && 2 * n_pal + 4 <= lds_words) ? TEX_P4 : TEX_G16);
-        const int pal_words = (mode == TEX_P4) ? ((2 * n_pal + 3) & ~3) : 0;
+                         : ((n_pal > 0 && pal_base_ok && 2 * n_pal + 6 <= lds_words) ? TEX_P4 : TEX_G16);
+        const int pal_words = (mode == TEX_P4) ? ((2 * (n_pal + 1) + 3) & ~3) : 0;           /* + the sentinel entry {0, 0} */
         float *const lds_pts = lds_dyn + pal_words;
-        const int cap = (mode == TEX_L16) ? n_pad : (((lds_words - pal_words) >> 1) & ~1);          /* words per point plane */
+        const int cap = (mode == TEX_L16) ? n_pad : (((lds_words - pal_words) >> 1) & ~1);          /* points the LDS holds (8 bytes each) */
         const int n_lds = (N <= cap) ? N : (cap / (2 * BLOCK)) * (2 * BLOCK);      /* whole rounds only */
         float *const lds_tex = lds_pts + 2 * cap;
         if (tid == 0 && member == 0) out.tex_mode[pair * DVO_LEVELS + l] = mode;
         if (mode == TEX_P4) {
             const float2 *__restrict__ pg = L.pal + (size_t)dpair * DVO_PAL_MAX;
             float2 *pl = reinterpret_cast<float2 *>(lds_dyn);
-            for (int i = tid; i < n_pal; i += BLOCK) pl[i] = pg[i];
+            for (int i = tid; i <= n_pal; i += BLOCK) pl[i] = pg[i];
         }
         {   /* 16-byte loads (whole 128-byte lines per request), four in flight per lane */
             const uint4 *g4 = reinterpret_cast<const uint4 *>(gpts);
+            uint4 *d4 = reinterpret_cast<uint4 *>(lds_pts);
             const int n2 = n_lds >> 1;
             int i = tid;
             for (; i + 3 * BLOCK < n2; i += 4 * BLOCK) {
@@ -510,24 +521,10 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
 #pragma unroll
                 for (int q = 0; q < 4; q++) v[q] = g4[i + q * BLOCK];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int k = 2 * (i + q * BLOCK);
-                    lds_pts[k] = __uint_as_float(v[q].x); lds_pts[cap + k] = __uint_as_float(v[q].y);
-                    lds_pts[k + 1] = __uint_as_float(v[q].z); lds_pts[cap + k + 1] = __uint_as_float(v[q].w);
-                }
+                for (int q = 0; q < 4; q++) d4[i + q * BLOCK] = v[q];
             }
-            for (; i < n2; i += BLOCK) {
-                const uint4 v = g4[i];
-                lds_pts[2 * i] = __uint_as_float(v.x);
-                lds_pts[cap + 2 * i] = __uint_as_float(v.y);
-                lds_pts[2 * i + 1] = __uint_as_float(v.z);
-                lds_pts[cap + 2 * i + 1] = __uint_as_float(v.w);
-            }
-            if ((n_lds & 1) && tid == 0) {
-                const uint2 v = gpts[n_lds - 1];
-                lds_pts[n_lds - 1] = __uint_as_float(v.x);
-                lds_pts[cap + n_lds - 1] = __uint_as_float(v.y);
-            }
+            for (; i < n2; i += BLOCK) d4[i] = g4[i];
+            if ((n_lds & 1) && tid == 0) reinterpret_cast<uint2 *>(lds_pts)[n_lds - 1] = gpts[n_lds - 1];
         }
         if (mode == TEX_L16) {
             const v4f *g = reinterpret_cast<const v4f *>(tex);
@@ -544,14 +541,12 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             for (; i < n16; i += BLOCK) d[i] = g[i];
         }
         LdsPoints lp;
-        lp.pk = reinterpret_cast<const unsigned *>(lds_pts);
-        lp.z = lds_pts + cap;
+        lp.p = reinterpret_cast<const uint2 *>(lds_pts);
         TexSrc ts;
         ts.g16 = tex; ts.tile_col_bytes = (unsigned)c.tiles_per_col * 128u;
         ts.l16 = reinterpret_cast<const char *>(lds_tex);
         ts.p4 = reinterpret_cast<const char *>(L.p4 + (size_t)dpair * L.p4_stride);
         ts.p4_col_bytes = (unsigned)p4_tiles_per_col(L.rows) * 128u;
-        ts.pal = reinterpret_cast<const char *>(lds_dyn);
         __syncthreads();
         DVO_STAMP(ts1);
         DVO_STAMP_ADD(5, ts0, ts1);
@@ -573,8 +568,8 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             if (mode == TEX_L16) {                 /* staged levels hold every point in LDS */
                 accumulate_points2<BLOCK, true, TEX_L16>(c, ts, lp, gpts, 0, N, lane_off, a, any_odd);             /* :369, :433 */
             } else if (mode == TEX_P4) {
-                accumulate_points2<BLOCK, true, TEX_P4, DVO_P4_DEPTH(BLOCK)>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
-                accumulate_points2<BLOCK, false, TEX_P4, DVO_P4_DEPTH(BLOCK)>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);
+                accumulate_points2<BLOCK, true, TEX_P4, DVO_P4_DEPTH(BLOCK), kStatic>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
+                accumulate_points2<BLOCK, false, TEX_P4, DVO_P4_DEPTH(BLOCK), kStatic>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);
             } else {
                 accumulate_points2<BLOCK, true, TEX_G16>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
                 accumulate_points2<BLOCK, false, TEX_G16>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);       /* beyond the LDS budget */
@@ -671,7 +666,7 @@ static hipError_t launch_fused2_b(const LevelSet &lv, const Schedule &sc, const 
 }
 
 /* static LDS of align_fused2_kernel<BLOCK> (the host sizes the dynamic part against the CU's 160 KiB) */
-size_t fused2_static_lds(int block_threads) { return sizeof(PoseState) + (size_t)(block_threads / 64) * 64 + 64 + 64 + DVO_TEAM_MAX * 64; }
+size_t fused2_static_lds(int block_threads) { return ((sizeof(PoseState) + 15) & ~(size_t)15) + (size_t)(block_threads / 64) * 64 + 64 + DVO_TEAM_MAX * 64 + 16; }
 
 hipError_t launch_align_fused2(int block_threads, const LevelSet &lv, const Schedule &sc, const Intrinsics &K,
                                const DevParams &prm, const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {

@@ -20,6 +20,9 @@
  *   dword   : bits 3..15  rank * 8   (byte offset of the palette entry; rank < DVO_PAL_MAX = 4096)
  *             bits 16..23 rank(x+1) - rank, signed     bits 24..31 rank(x-1) - rank, signed
  *             (apron / border entries carry their pixel's rank only)
+ *   sentinel: line 0 of every image is not a tile: its 32 words point at palette entry n (one past the real entries), which
+ *             is {0, 0}.  A lane without a visible point gathers from offset 0 and so decodes DT = gx = gy = w = 0 -- exact
+ *             zeros in every sum -- without a single select.
  *
  * The form is LOSSLESS BY VERIFICATION: the builder re-derives {DT, gx, gy, w} of every pixel from the palette exactly as
  * the kernel will and compares them bit for bit with the 16-byte texel; one mismatch (a caller-supplied gradient that is not
@@ -32,7 +35,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
-#define DVO_PAL_MAX 4096          /* palette entries per (pair, level): 32 KiB of LDS at most */
+#define DVO_PAL_MAX 4096          /* palette entries per (pair, level) incl. the sentinel: 32 KiB of LDS at most */
 #define DVO_P4_ROWS 6             /* interior image rows per 128-byte line (8 stored rows) */
 
 namespace dvo {
@@ -40,11 +43,11 @@ namespace dvo {
 __host__ __device__ inline int p4_tiles_per_col(int rows) { return (rows + DVO_P4_ROWS - 1) / DVO_P4_ROWS; }
 /* dwords of one image */
 __host__ __device__ inline size_t p4_count(int rows, int cols) {
-    return (size_t)p4_tiles_per_col(rows) * (size_t)((cols + 3) >> 2) * 32u;
+    return (size_t)p4_tiles_per_col(rows) * (size_t)((cols + 3) >> 2) * 32u + 32u;      /* + the sentinel line */
 }
 /* dword index of stored row `srow` (0 = apron above, 1..6 interior, 7 = apron below) of tile row `ty`, pixel column xx */
 __host__ __device__ inline size_t p4_slot(int ty, int srow, int xx, int tiles_per_col) {
-    return ((size_t)(xx >> 2) * tiles_per_col + ty) * 32u + (size_t)((xx & 3) * 8 + srow);
+    return 32u + ((size_t)(xx >> 2) * tiles_per_col + ty) * 32u + (size_t)((xx & 3) * 8 + srow);
 }
 
 }  // namespace dvo

@@ -4,7 +4,7 @@
  * Generic builder: works from the 16-byte texels {DT, gx, gy, w} of a level, whoever produced them (the engine's own
  * distance-transform kernels or a caller's float images, reference SolveDVO.cpp:1768-1795, :1063-1098, :1047-1053), and
  * VERIFIES per pixel that the compact form decodes to exactly those four floats.  One 1024-thread workgroup per image:
- *   1. distinct DT bit patterns -> LDS hash set (<= DVO_PAL_MAX, else "no compact form")
+ *   1. distinct DT bit patterns -> LDS hash set (< DVO_PAL_MAX, else "no compact form")
  *   2. compaction + bitonic sort  -> the palette P[0..n) (non-negative floats order like their bit patterns)
  *   3. per pixel: rank of its DT (binary search) written to its interior slot and to the apron slots that stand for it
  *      (row above / below of the neighbouring tiles, reflect-101 rows at the image border, cv::filter2D's default border)
@@ -67,7 +67,7 @@ palette_build_kernel(const float4 *__restrict__ tex, size_t tex_stride, int rows
                 if (cur == key) break;
                 if (cur == PAL_EMPTY) {
                     const unsigned old = atomicCAS(&keys[h], PAL_EMPTY, key);
-                    if (old == PAL_EMPTY) { if (atomicAdd(&cnt, 1) >= DVO_PAL_MAX) bad = PAL_TOO_MANY; break; }
+                    if (old == PAL_EMPTY) { if (atomicAdd(&cnt, 1) >= DVO_PAL_MAX - 1) bad = PAL_TOO_MANY; break; }     /* one entry is the sentinel */
                     if (old == key) break;
                 }
                 if (*(volatile int *)&bad) break;
@@ -105,6 +105,8 @@ palette_build_kernel(const float4 *__restrict__ tex, size_t tex_stride, int rows
         }
     }
 
+    /* the sentinel: line 0 points at entry n = {0, 0} */
+    if (tid < 32) p4[tid] = (unsigned)n << 3;
     /* 3. ranks into the interior slot and into every apron slot that stands for this pixel */
     for (int p = tid; p < npx; p += 1024) {
         const int xx = p / rows, yy = p - xx * rows;
@@ -145,6 +147,7 @@ palette_build_kernel(const float4 *__restrict__ tex, size_t tex_stride, int rows
     }
     __syncthreads();
     for (int k = tid; k < n; k += 1024) pal[k] = make_float2(__uint_as_float(sorted[k]), __uint_as_float(wts[k]));
+    if (tid == 0) pal[n] = make_float2(0.0f, 0.0f);
     if (tid == 0) pal_n[pair] = bad ? -bad : n;
 }
 
