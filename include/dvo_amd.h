@@ -277,10 +277,13 @@ int  dvo_get_last_launch_shape(dvo_ctx *ctx, int *block_threads, int *team_size,
  * the ranks of its four neighbours.  The engine derives a 4-byte-per-pixel form from that (24 pixels per 128-byte memory
  * line instead of 8 -> half the memory requests of the alignment kernel), VERIFIES per pixel that it reproduces the resident
  * {DT, gx, gy, w} bit for bit, and otherwise keeps reading the 16-byte form for that pair and level (caller-supplied
- * gradients that are not imageGradient(DT), more than 4096 distinct values, ...).  It is built automatically the second time a
- * resident now level is aligned (a level aligned once does not repay the build, ~50 us per 640x480 level on one compute
- * unit); dvo_now_prepare builds it now for every resident now level of the given pairs (batch / benchmark set-up:
- * "inputs resident").  dvo_params.engine_variant = 4 disables it. */
+ * gradients that are not imageGradient(DT), more than 4095 distinct values, ...).  Building it reads the level twice and costs
+ * about five alignments of the same pair (measured, 640x480x4: 8.8 us per pair against 1.64 us per alignment; an alignment
+ * then saves ~0.45 us), so the engine builds it by itself only for a now level that has already been aligned
+ * DVO_COMPACT_NOW_AFTER times (a tracker's now frame is aligned once or twice and never pays for it); dvo_now_prepare
+ * builds it now for every resident now level of the given pairs (batch / benchmark set-up: "inputs resident").
+ * dvo_params.engine_variant = 4 disables it. */
+#define DVO_COMPACT_NOW_AFTER 16
 int  dvo_now_prepare(dvo_ctx *ctx, int first_pair, int count);
 /* palette_size: > 0 number of distinct distance values of the compact form, 0 not built (yet / stale),
  * < 0 no compact form: -1 negative/inf/nan value, -2 more than 4096 distinct values, -3 rank step beyond +-127,

@@ -119,7 +119,7 @@ int build_compact_now(dvo_ctx *c, int level, int first_pair, int count, bool onl
     if (!L.tex || L.have_now.empty()) return DVO_OK;
     if (L.pal_built.empty()) { L.pal_built.assign(c->n_pairs, 0); L.now_uses.assign(c->n_pairs, 0); }
     for (int p = first_pair; p < first_pair + count; ) {
-        auto wanted = [&](int i) { return L.have_now[i] && !L.pal_built[i] && (!only_reused || L.now_uses[i] >= 1); };
+        auto wanted = [&](int i) { return L.have_now[i] && !L.pal_built[i] && (!only_reused || L.now_uses[i] >= DVO_COMPACT_NOW_AFTER); };
         if (!wanted(p)) { p++; continue; }
         int q = p;
         while (q < first_pair + count && wanted(q)) q++;
@@ -130,7 +130,15 @@ int build_compact_now(dvo_ctx *c, int level, int first_pair, int count, bool onl
             HIPCHK(c, hipMalloc((void **)&L.d_pal_n, sizeof(int) * (size_t)c->n_pairs));
             HIPCHK(c, hipMemsetAsync(L.d_pal_n, 0, sizeof(int) * (size_t)c->n_pairs, c->stream));
         }
-        HIPCHK(c, launch_palette_build(L.tex, L.tex_stride, L.rows, L.cols, L.p4, L.p4_stride, L.pal, L.d_pal_n, p, q - p, c->stream));
+        for (int b = p; b < q; b += 1024) {                 /* scratch: 32 KiB per image of a launch */
+            const int nb = std::min(1024, q - b);
+            if (palette_work_ints(nb) > c->pal_work_ints) {
+                if (c->pal_work) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->pal_work)); c->pal_work = nullptr; c->pal_work_ints = 0; }
+                HIPCHK(c, hipMalloc((void **)&c->pal_work, sizeof(unsigned) * palette_work_ints(nb)));
+                c->pal_work_ints = palette_work_ints(nb);
+            }
+            HIPCHK(c, launch_palette_build(L.tex, L.tex_stride, L.rows, L.cols, L.p4, L.p4_stride, L.pal, L.d_pal_n, b, nb, c->pal_work, c->stream));
+        }
         for (int i = p; i < q; i++) L.pal_built[i] = 1;
         p = q;
     }
@@ -274,8 +282,8 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
     }
     const bool packed = sc.compact && c->prm.engine_variant != 1 && !(sc.flags & DVO_FLAG_NORMAL_MATRIX);
     sc.no_p4 = (c->prm.engine_variant == 4 || !packed || compact_now_policy() == 2) ? 1 : 0;
-    /* compact form of the now levels (dvo_palette.h): built for a level the second time it is aligned (or up front by
-     * dvo_now_prepare) -- a now level aligned once does not repay the build */
+    /* compact form of the now levels (dvo_palette.h): built for a level that has been aligned DVO_COMPACT_NOW_AFTER times (or
+     * up front by dvo_now_prepare) -- the build costs about five alignments, a now level aligned once or twice never repays it */
     bool all_p4 = !sc.no_p4;
     if (!sc.no_p4) {
         for (int l = 0; l < n_levels; l++) {
@@ -479,6 +487,7 @@ int dvo_destroy(dvo_ctx *c) {
         if (c->lv[l].dN) (void)hipFree(c->lv[l].dN);
         if (c->lv[l].p4) { (void)hipFree(c->lv[l].p4); (void)hipFree(c->lv[l].pal); (void)hipFree(c->lv[l].d_pal_n); }
     }
+    if (c->pal_work) (void)hipFree(c->pal_work);
     tiled_forget(c);
     photo_forget(c);
     for (int l = 0; l < DVO_LEVELS; l++) {

@@ -58,7 +58,7 @@ inline bool compact_block_order() {
     return on;
 }
 /* diagnostics / tests: DVO_COMPACT_NOW=eager builds the compact form of a now level (dvo_palette.h) at its FIRST alignment
- * (so that every test of the suite runs through it), =off never builds it; default: at the second alignment */
+ * (so that every test of the suite runs through it), =off never builds it; default: after DVO_COMPACT_NOW_AFTER alignments */
 inline int compact_now_policy() {
     static const int pol = [] {
         const char *e = std::getenv("DVO_COMPACT_NOW");
@@ -107,6 +107,8 @@ struct dvo_ctx {
     int iter_energy_cap = 0;
     std::vector<int> iter_max;      /* per pair: max_iters of the running dvo_iter_begin (0 = none) */
     int *d_colcounts = nullptr;
+    unsigned *pal_work = nullptr;   /* scratch of the compact-now-form builder (dvo_palette.hip) */
+    size_t pal_work_ints = 0;
     size_t colcounts_cap = 0;
     dvo_host::FrameStore fs;
     /* cv::undistort of the publisher: fixed-point map of the camera's full resolution (dvo_frames_set_undistort) */
@@ -157,7 +159,7 @@ int ensure_texels(dvo_ctx *c, int level, int rows, int cols);
 /* the now level of `pair` at `level` was (re)written: mark it present and its compact form stale */
 int now_written(dvo_ctx *c, int level, int first_pair, int count);
 /* build the compact form of the stale now levels among [first_pair, first_pair+count) at `level`; with only_reused, only
- * of those that have been aligned before (a level used once does not repay the build) */
+ * of those that have been aligned DVO_COMPACT_NOW_AFTER times (the build costs about five alignments) */
 int build_compact_now(dvo_ctx *c, int level, int first_pair, int count, bool only_reused);
 /* schedule / readiness / output bookkeeping of the align entry points (dvo_capi.cpp) */
 dvo::LevelSlab slab_of(const dvo_ctx *c, int level);

@@ -138,11 +138,11 @@ DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints 
     const bool inx1 = pixel_in_range(u.y, c.cols, px1), iny1 = pixel_in_range(v.y, c.rows, py1);
     const bool vis0 = inx0 && iny0 && valid0 && !odd0;
     const bool vis1 = inx1 && iny1 && valid1 && !odd1;
-    /* finite dummies for lanes without a visible point: they then add exact zeros (w = eps = 0).  zn needs none: it is 1 or
-     * 1-2^-24 on every lane whose z is in the proven range, and a wave with a lane outside it discards its sums (any_odd) */
-    b.xn.x = vis0 ? xn.x : 0.0f; b.yn.x = vis0 ? yn.x : 0.0f;
-    b.xn.y = vis1 ? xn.y : 0.0f; b.yn.y = vis1 ? yn.y : 0.0f;
-    b.zn = zn;
+    /* finite dummies for lanes without a visible point: they then add exact zeros (w = eps = 0).  zn too: a lane past the end
+     * of the list re-reads the last point, and if THAT point has a degenerate z the lane holds a NaN without being counted
+     * in any_odd (tests/test_gpu_packed_kernel.py::test_degenerate_depth_takes_the_exact_fallback, team shares) */
+    b.xn.x = vis0 ? xn.x : 0.0f; b.yn.x = vis0 ? yn.x : 0.0f; b.zn.x = vis0 ? zn.x : 1.0f;
+    b.xn.y = vis1 ? xn.y : 0.0f; b.yn.y = vis1 ? yn.y : 0.0f; b.zn.y = vis1 ? zn.y : 1.0f;
     if constexpr (TEX == TEX_P4) {
         nvis += __popcll(__builtin_amdgcn_ballot_w64(vis0)) + __popcll(__builtin_amdgcn_ballot_w64(vis1));
         unsigned o0 = p4_byte_offset(py0, px0, ts.p4_col_bytes);
@@ -175,17 +175,17 @@ DVO_DEV unsigned lshl3_add(int d, unsigned c) {
 template <unsigned PAL>
 DVO_DEV void p4_decode2(const U3 &t0, const U3 &t1, v2f &dt, v2f &gx, v2f &gy, v2f &w) {
     const unsigned c0 = t0.b & 0xfff8u, c1 = t1.b & 0xfff8u;
-    const v2f pw0 = *(lds_cv2f *)(PAL + c0);
-    const v2f pw1 = *(lds_cv2f *)(PAL + c1);
+    const v2f pw0 = *(lds_cv2f *)(size_t)(PAL + c0);
+    const v2f pw1 = *(lds_cv2f *)(size_t)(PAL + c1);
     v2f pu, pd, pr, pl;
-    pu.x = *(lds_cfloat *)(PAL + (t0.a & 0xfff8u));
-    pu.y = *(lds_cfloat *)(PAL + (t1.a & 0xfff8u));
-    pd.x = *(lds_cfloat *)(PAL + (t0.c & 0xfff8u));
-    pd.y = *(lds_cfloat *)(PAL + (t1.c & 0xfff8u));
-    pr.x = *(lds_cfloat *)(PAL + lshl3_add(__builtin_amdgcn_sbfe((int)t0.b, 16, 8), c0));
-    pr.y = *(lds_cfloat *)(PAL + lshl3_add(__builtin_amdgcn_sbfe((int)t1.b, 16, 8), c1));
-    pl.x = *(lds_cfloat *)(PAL + lshl3_add(((int)t0.b) >> 24, c0));
-    pl.y = *(lds_cfloat *)(PAL + lshl3_add(((int)t1.b) >> 24, c1));
+    pu.x = *(lds_cfloat *)(size_t)(PAL + (t0.a & 0xfff8u));
+    pu.y = *(lds_cfloat *)(size_t)(PAL + (t1.a & 0xfff8u));
+    pd.x = *(lds_cfloat *)(size_t)(PAL + (t0.c & 0xfff8u));
+    pd.y = *(lds_cfloat *)(size_t)(PAL + (t1.c & 0xfff8u));
+    pr.x = *(lds_cfloat *)(size_t)(PAL + lshl3_add(__builtin_amdgcn_sbfe((int)t0.b, 16, 8), c0));
+    pr.y = *(lds_cfloat *)(size_t)(PAL + lshl3_add(__builtin_amdgcn_sbfe((int)t1.b, 16, 8), c1));
+    pl.x = *(lds_cfloat *)(size_t)(PAL + lshl3_add(((int)t0.b) >> 24, c0));
+    pl.y = *(lds_cfloat *)(size_t)(PAL + lshl3_add(((int)t1.b) >> 24, c1));
     dt.x = pw0.x; dt.y = pw1.x; w.x = pw0.y; w.y = pw1.y;
     gx = (pr - pl) * 0.5f;          /* imageGradient, SolveDVO.cpp:1063-1098 */
     gy = (pd - pu) * 0.5f;

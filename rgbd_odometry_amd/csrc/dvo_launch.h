@@ -81,8 +81,9 @@ struct Outputs {
 hipError_t launch_pack_texels(const float *dt, const float *gx, const float *gy, float4 *out,
                               int rows, int cols, hipStream_t s);
 /* compact form of now levels [first_pair, first_pair+count) of one pyramid level from their 16-byte texels (dvo_palette.hip) */
+size_t palette_work_ints(int count);        /* scratch of one launch_palette_build over `count` images */
 hipError_t launch_palette_build(const float4 *tex, size_t tex_stride, int rows, int cols, unsigned *p4, size_t p4_stride,
-                                float2 *pal, int *pal_n, int first_pair, int count, hipStream_t s);
+                                float2 *pal, int *pal_n, int first_pair, int count, unsigned *work, hipStream_t s);
 bool fused_uses_compact(int points_in_flight, int interp);
 hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, int pt_cap, int *N,
                                   int n_src, int dst_first, int dst_count, hipStream_t s);

@@ -3,14 +3,17 @@
  *
  * Generic builder: works from the 16-byte texels {DT, gx, gy, w} of a level, whoever produced them (the engine's own
  * distance-transform kernels or a caller's float images, reference SolveDVO.cpp:1768-1795, :1063-1098, :1047-1053), and
- * VERIFIES per pixel that the compact form decodes to exactly those four floats.  One 1024-thread workgroup per image:
- *   1. distinct DT bit patterns -> LDS hash set (< DVO_PAL_MAX, else "no compact form")
- *   2. compaction + bitonic sort  -> the palette P[0..n) (non-negative floats order like their bit patterns)
- *   3. per pixel: rank of its DT (binary search) written to its interior slot and to the apron slots that stand for it
- *      (row above / below of the neighbouring tiles, reflect-101 rows at the image border, cv::filter2D's default border)
- *   4. per pixel: ranks of the four neighbours, the two horizontal rank steps packed into the dword, and the check
- *      P[c] == DT, W[c] == w, 0.5*(P[r]-P[l]) == gx, 0.5*(P[d]-P[u]) == gy  bit for bit
- * Not a hot path: runs once per now level that is aligned more than once (or on request, dvo_now_prepare).
+ * VERIFIES per pixel that the compact form decodes to exactly those four floats.  Three launches over a batch of images:
+ *   1. collect  (several workgroups per image, a range of pixel columns each): distinct DT bit patterns -> LDS hash set ->
+ *               merged into the image's hash set in HBM (< DVO_PAL_MAX values, else "no compact form")
+ *   2. sort     (one workgroup per image): compaction + bitonic sort -> the palette {P, W = getWeightOf(P)} (non-negative
+ *               floats order like their bit patterns), the sentinel entry and the sentinel line
+ *   3. encode   (several workgroups per image, a range of tile columns each): palette -> LDS hash map value -> rank; one
+ *               thread per stored slot: the pixel it stands for (reflect-101 rows at the image border, cv::filter2D's
+ *               default border), its rank; for interior slots the ranks of the four neighbours, the horizontal rank steps
+ *               packed into the dword, and the check  P[c] == DT, W[c] == w, 0.5*(P[r]-P[l]) == gx, 0.5*(P[d]-P[u]) == gy
+ *               bit for bit
+ * Not a hot path: runs once per now level that keeps being aligned (or on request, dvo_now_prepare).
  *
  * Compile with -ffp-contract=off (the gradient formula must stay a subtraction followed by a multiplication).
  */
@@ -21,72 +24,99 @@ namespace dvo {
 
 #define PAL_HASH 8192u
 #define PAL_EMPTY 0xffffffffu
+#define PAL_WORK_INTS (PAL_HASH + 2)      /* per image: hash set | count | reason */
 
 /* reasons for "no compact form" (pal_n = -reason) */
 enum { PAL_BAD_VALUE = 1, PAL_TOO_MANY = 2, PAL_STEP = 3, PAL_GRADIENT = 4, PAL_WEIGHT = 5, PAL_SHAPE = 6 };
 
-DVO_DEV int pal_rank(const unsigned *sorted, int n, unsigned key) {
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (sorted[mid] < key) lo = mid + 1; else hi = mid;
+size_t palette_work_ints(int count) { return (size_t)count * PAL_WORK_INTS; }
+
+DVO_DEV unsigned pal_hash(unsigned key) { return (key * 2654435761u) >> 19; }
+
+/* insert into an open-addressing set; returns true if the key was new.  `stop` (may be NULL) aborts a full table. */
+DVO_DEV bool pal_set_insert(unsigned *keys, unsigned key, const int *stop) {
+    unsigned h = pal_hash(key);
+    for (;;) {
+        const unsigned cur = *(volatile unsigned *)&keys[h];
+        if (cur == key) return false;
+        if (cur == PAL_EMPTY) {
+            const unsigned old = atomicCAS(&keys[h], PAL_EMPTY, key);
+            if (old == PAL_EMPTY) return true;
+            if (old == key) return false;
+        }
+        if (stop && *(volatile const int *)stop) return false;
+        h = (h + 1u) & (PAL_HASH - 1u);
     }
-    return lo;
 }
 
-__global__ void __launch_bounds__(1024)
-palette_build_kernel(const float4 *__restrict__ tex, size_t tex_stride, int rows, int cols, unsigned *p4, size_t p4_stride,
-                     float2 *__restrict__ pal, int *__restrict__ pal_n, int first_pair) {
-    const int pair = first_pair + blockIdx.x;
-    const int tid = threadIdx.x;
+__global__ void __launch_bounds__(256)
+palette_init_kernel(unsigned *__restrict__ work, int *__restrict__ pal_n, int first_pair, int rows, int cols) {
+    unsigned *w = work + (size_t)blockIdx.x * PAL_WORK_INTS;
+    for (unsigned i = threadIdx.x; i < PAL_HASH; i += 256) w[i] = PAL_EMPTY;
+    if (threadIdx.x == 0) { w[PAL_HASH] = 0u; w[PAL_HASH + 1] = (rows < 2 || cols < 2) ? PAL_SHAPE : 0u; pal_n[first_pair + blockIdx.x] = 0; }
+}
+
+/* 1. distinct DT values of pixel columns [x0, x1) of image blockIdx.y */
+__global__ void __launch_bounds__(256)
+palette_collect_kernel(const float4 *__restrict__ tex, size_t tex_stride, int rows, int cols, unsigned *__restrict__ work,
+                       int first_pair, int cols_per_chunk) {
+    const int pair = first_pair + blockIdx.y;
     tex += (size_t)pair * tex_stride;
-    p4 += (size_t)pair * p4_stride;
-    pal += (size_t)pair * DVO_PAL_MAX;
+    unsigned *gkeys = work + (size_t)blockIdx.y * PAL_WORK_INTS;
+    int *gcnt = reinterpret_cast<int *>(gkeys + PAL_HASH), *gbad = gcnt + 1;
     __shared__ unsigned keys[PAL_HASH];
-    __shared__ unsigned sorted[DVO_PAL_MAX];
-    __shared__ unsigned wts[DVO_PAL_MAX];
-    __shared__ int cnt, bad;
-    const int tpc16 = texel_tiles_per_col(rows);
-    const int tpc = p4_tiles_per_col(rows);
-    const int npx = rows * cols;
-
-    for (unsigned i = tid; i < PAL_HASH; i += 1024) keys[i] = PAL_EMPTY;
-    if (tid == 0) { cnt = 0; bad = (rows < 2 || cols < 2) ? PAL_SHAPE : 0; }
-    for (size_t i = tid; i < p4_stride; i += 1024) p4[i] = 0u;          /* slots outside the image: rank 0 */
+    __shared__ int lbad;
+    const int tid = threadIdx.x;
+    for (unsigned i = tid; i < PAL_HASH; i += 256) keys[i] = PAL_EMPTY;
+    if (tid == 0) lbad = *gbad;
     __syncthreads();
-
-    /* 1. the set of distinct DT values */
-    if (!bad) {
-        for (int p = tid; p < npx; p += 1024) {
-            const int xx = p / rows, yy = p - xx * rows;
-            const unsigned key = __float_as_uint(tex[texel_index(yy, xx, tpc16)].x);
-            if (key >= 0x7f800000u) { bad = PAL_BAD_VALUE; break; }        /* negative, inf or nan: not a distance */
-            unsigned h = (key * 2654435761u) >> 19;
-            for (;;) {
-                const unsigned cur = *(volatile unsigned *)&keys[h];
-                if (cur == key) break;
-                if (cur == PAL_EMPTY) {
-                    const unsigned old = atomicCAS(&keys[h], PAL_EMPTY, key);
-                    if (old == PAL_EMPTY) { if (atomicAdd(&cnt, 1) >= DVO_PAL_MAX - 1) bad = PAL_TOO_MANY; break; }     /* one entry is the sentinel */
-                    if (old == key) break;
-                }
-                if (*(volatile int *)&bad) break;
-                h = (h + 1u) & (PAL_HASH - 1u);
+    if (lbad) return;
+    const int tpc16 = texel_tiles_per_col(rows);
+    const int x0 = blockIdx.x * cols_per_chunk, x1 = min(cols, x0 + cols_per_chunk);
+    for (int xx = x0; xx < x1; xx++) {
+        for (int y0 = tid; y0 < rows; y0 += 4 * 256) {          /* four independent loads in flight */
+            unsigned k[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int yy = y0 + q * 256;
+                k[q] = (yy < rows) ? __float_as_uint(tex[texel_index(yy, xx, tpc16)].x) : 0u;
             }
-            if (*(volatile int *)&bad) break;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (y0 + q * 256 >= rows) continue;
+                if (k[q] >= 0x7f800000u) { lbad = PAL_BAD_VALUE; continue; }     /* negative, inf or nan: not a distance */
+                pal_set_insert(keys, k[q], nullptr);         /* cannot fill up: at most rows*cols_per_chunk keys... guarded below */
+            }
         }
     }
     __syncthreads();
-    if (bad) { if (tid == 0) pal_n[pair] = -bad; return; }
-    const int n = cnt;
+    if (lbad) { if (tid == 0) atomicMax(gbad, lbad); return; }
+    for (unsigned i = tid; i < PAL_HASH; i += 256) {
+        const unsigned k = keys[i];
+        if (k == PAL_EMPTY) continue;
+        if (pal_set_insert(gkeys, k, gbad) && atomicAdd(gcnt, 1) >= DVO_PAL_MAX - 1) atomicMax(gbad, (int)PAL_TOO_MANY);   /* one entry is the sentinel */
+    }
+}
+
+/* 2. the sorted palette of image blockIdx.x */
+__global__ void __launch_bounds__(1024)
+palette_sort_kernel(const unsigned *__restrict__ work, unsigned *__restrict__ p4, size_t p4_stride, float2 *__restrict__ pal,
+                    int *__restrict__ pal_n, int first_pair) {
+    const int pair = first_pair + blockIdx.x;
+    const unsigned *gkeys = work + (size_t)blockIdx.x * PAL_WORK_INTS;
+    const int n = (int)gkeys[PAL_HASH], bad = (int)gkeys[PAL_HASH + 1];
+    const int tid = threadIdx.x;
+    if (bad || n < 1 || n > DVO_PAL_MAX - 1) { if (tid == 0) pal_n[pair] = -(bad ? bad : (int)PAL_TOO_MANY); return; }
+    p4 += (size_t)pair * p4_stride;
+    pal += (size_t)pair * DVO_PAL_MAX;
+    __shared__ unsigned sorted[DVO_PAL_MAX];
+    __shared__ int cnt;
     int m = 2;
     while (m < n) m <<= 1;
-
-    /* 2. compaction (any order) + bitonic sort */
     if (tid == 0) cnt = 0;
     __syncthreads();
     for (unsigned i = tid; i < PAL_HASH; i += 1024) {
-        const unsigned k = keys[i];
+        const unsigned k = gkeys[i];
         if (k != PAL_EMPTY) sorted[atomicAdd(&cnt, 1)] = k;
     }
     for (int i = n + tid; i < m; i += 1024) sorted[i] = PAL_EMPTY;
@@ -104,58 +134,134 @@ palette_build_kernel(const float4 *__restrict__ tex, size_t tex_stride, int rows
             __syncthreads();
         }
     }
+    for (int k = tid; k < n; k += 1024) {
+        const float P = __uint_as_float(sorted[k]);
+        pal[k] = make_float2(P, weight_of(P));                   /* getWeightOf, SolveDVO.cpp:1047-1053 */
+    }
+    if (tid == 0) { pal[n] = make_float2(0.0f, 0.0f); pal_n[pair] = n; }       /* the sentinel entry */
+    if (tid < 32) p4[tid] = (unsigned)n << 3;                                   /* the sentinel line */
+}
 
-    /* the sentinel: line 0 points at entry n = {0, 0} */
-    if (tid < 32) p4[tid] = (unsigned)n << 3;
-    /* 3. ranks into the interior slot and into every apron slot that stands for this pixel */
-    for (int p = tid; p < npx; p += 1024) {
-        const int xx = p / rows, yy = p - xx * rows;
-        const float4 t = tex[texel_index(yy, xx, tpc16)];
-        const int c = pal_rank(sorted, n, __float_as_uint(t.x));
-        wts[c] = __float_as_uint(t.w);                                /* the same for every pixel of this rank -- checked in 4 */
-        const unsigned v = (unsigned)c << 3;
-        const int ty = yy / DVO_P4_ROWS, ry = yy - ty * DVO_P4_ROWS;
-        p4[p4_slot(ty, ry + 1, xx, tpc)] = v;
-        if (ry == 0 && ty > 0) p4[p4_slot(ty - 1, 7, xx, tpc)] = v;                         /* row below the tile above */
-        if (ry == DVO_P4_ROWS - 1 && yy + 1 < rows) p4[p4_slot(ty + 1, 0, xx, tpc)] = v;    /* row above the tile below */
-        if (yy == 1) p4[p4_slot(0, 0, xx, tpc)] = v;                                         /* reflect-101: row -1 = row 1 */
-        if (yy == rows - 2) {                                                                /* row `rows` = row rows-2 */
-            const int tl = (rows - 1) / DVO_P4_ROWS;
-            p4[p4_slot(tl, (rows - 1) - tl * DVO_P4_ROWS + 2, xx, tpc)] = v;
+/* 3. rank words of tile columns [c0, c1) of image blockIdx.y.
+ * value -> rank: distance values live in [0, 255] (cv::normalize), so a table of 8192 buckets of width 1/32 gives the rank
+ * range of a value in one look-up and a binary search over the few palette entries of that bucket finishes it (values
+ * beyond 256 -- caller-supplied images -- share the last bucket: still correct, just a longer search). */
+#define PAL_BUCKETS 8192
+DVO_DEV unsigned pal_bucket(unsigned key) {
+    const float f = __uint_as_float(key) * 32.0f;
+    return (f >= (float)(PAL_BUCKETS - 1)) ? (unsigned)(PAL_BUCKETS - 1) : (unsigned)f;
+}
+
+__global__ void __launch_bounds__(256)
+palette_encode_kernel(const float4 *__restrict__ tex, size_t tex_stride, int rows, int cols, unsigned *__restrict__ p4,
+                      size_t p4_stride, const float2 *__restrict__ pal, int *__restrict__ pal_n, int first_pair, int tcols_per_chunk) {
+    const int pair = first_pair + blockIdx.y;
+    const int n = pal_n[pair];
+    if (n <= 0) return;
+    tex += (size_t)pair * tex_stride;
+    p4 += (size_t)pair * p4_stride;
+    pal += (size_t)pair * DVO_PAL_MAX;
+    __shared__ unsigned sorted[DVO_PAL_MAX];                 /* P as bits */
+    __shared__ unsigned wts[DVO_PAL_MAX];                    /* W as bits */
+    __shared__ unsigned short first[PAL_BUCKETS + 2];        /* first[b] = number of palette values below bucket b */
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < n; k += 256) {
+        const float2 e = pal[k];
+        sorted[k] = __float_as_uint(e.x); wts[k] = __float_as_uint(e.y);
+    }
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    for (int b = tid; b <= PAL_BUCKETS; b += 256) {
+        const unsigned edge = __float_as_uint((float)b * (1.0f / 32.0f));      /* exact */
+        int lo = 0, hi = n;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted[mid] < edge) lo = mid + 1; else hi = mid; }
+        first[b] = (unsigned short)((b == PAL_BUCKETS) ? n : lo);
+    }
+    __syncthreads();
+    auto rank_of = [&](unsigned key) -> int {
+        const unsigned b = pal_bucket(key);
+        int lo = first[b], hi = first[b + 1];
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted[mid] < key) lo = mid + 1; else hi = mid; }
+        return (lo < n && sorted[lo] == key) ? lo : -1;       /* -1 cannot happen: every pixel value was collected */
+    };
+    const int tpc16 = texel_tiles_per_col(rows), tpc = p4_tiles_per_col(rows);
+    const int n_tcols = (cols + 3) >> 2;
+    const int c0 = blockIdx.x * tcols_per_chunk, c1 = min(n_tcols, c0 + tcols_per_chunk);
+    const int slots = tpc * 32;
+    int lbad = 0;
+    for (int tc = c0; tc < c1; tc++) {
+        unsigned *__restrict__ col = p4 + 32u + (size_t)tc * slots;
+        for (int s0 = tid; s0 < slots; s0 += 2 * 256) {                    /* two independent slots per trip */
+            unsigned word[2] = {0u, 0u};
+            float4 t[2];
+            unsigned nb[2][4];
+            int yy[2], xx[2];
+            bool use[2], interior[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int s = s0 + q * 256;
+                const int ty = s >> 5, w = s & 31, srow = w & 7;
+                xx[q] = tc * 4 + (w >> 3);
+                int y = ty * DVO_P4_ROWS + srow - 1;
+                interior[q] = srow >= 1 && srow <= DVO_P4_ROWS && y < rows;
+                if (y == -1) y = 1;                          /* reflect-101 */
+                if (y == rows) y = rows - 2;
+                yy[q] = y;
+                use[q] = s < slots && xx[q] < cols && y < rows;
+                if (use[q]) {
+                    t[q] = tex[texel_index(y, xx[q], tpc16)];
+                    if (interior[q]) {
+                        const int xr = (xx[q] + 1 < cols) ? xx[q] + 1 : cols - 2, xl = (xx[q] > 0) ? xx[q] - 1 : 1;
+                        const int yu = (y > 0) ? y - 1 : 1, yd = (y + 1 < rows) ? y + 1 : rows - 2;
+                        nb[q][0] = __float_as_uint(tex[texel_index(y, xr, tpc16)].x);
+                        nb[q][1] = __float_as_uint(tex[texel_index(y, xl, tpc16)].x);
+                        nb[q][2] = __float_as_uint(tex[texel_index(yu, xx[q], tpc16)].x);
+                        nb[q][3] = __float_as_uint(tex[texel_index(yd, xx[q], tpc16)].x);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                if (!use[q]) continue;
+                const int c = rank_of(__float_as_uint(t[q].x));
+                if (c < 0) { lbad = PAL_BAD_VALUE; continue; }
+                word[q] = (unsigned)c << 3;
+                if (!interior[q]) continue;
+                const int rr = rank_of(nb[q][0]), rl = rank_of(nb[q][1]), ru = rank_of(nb[q][2]), rd = rank_of(nb[q][3]);
+                if ((rr | rl | ru | rd) < 0) { lbad = PAL_BAD_VALUE; continue; }
+                const int dr = rr - c, dl = rl - c;
+                if (dr < -127 || dr > 127 || dl < -127 || dl > 127) { lbad = PAL_STEP; continue; }
+                const float gx = 0.5f * (__uint_as_float(sorted[rr]) - __uint_as_float(sorted[rl]));
+                const float gy = 0.5f * (__uint_as_float(sorted[rd]) - __uint_as_float(sorted[ru]));
+                if (__float_as_uint(gx) != __float_as_uint(t[q].y) || __float_as_uint(gy) != __float_as_uint(t[q].z)) { lbad = PAL_GRADIENT; continue; }
+                if (wts[c] != __float_as_uint(t[q].w)) { lbad = PAL_WEIGHT; continue; }
+                word[q] |= (((unsigned)dr & 0xffu) << 16) | (((unsigned)dl & 0xffu) << 24);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                if (s0 + q * 256 < slots) col[s0 + q * 256] = word[q];
         }
     }
+    if (lbad) bad = lbad;
     __syncthreads();
-
-    /* 4. neighbour ranks, horizontal rank steps, verification against the 16-byte texel */
-    for (int p = tid; p < npx; p += 1024) {
-        const int xx = p / rows, yy = p - xx * rows;
-        const float4 t = tex[texel_index(yy, xx, tpc16)];
-        const int ty = yy / DVO_P4_ROWS, ry = yy - ty * DVO_P4_ROWS;
-        const int xr = (xx + 1 < cols) ? xx + 1 : cols - 2, xl = (xx > 0) ? xx - 1 : 1;      /* reflect-101 */
-        const size_t own = p4_slot(ty, ry + 1, xx, tpc);
-        const int c = (int)((p4[own] >> 3) & 0x1fffu);
-        const int ru = (int)((p4[own - 1] >> 3) & 0x1fffu), rd = (int)((p4[own + 1] >> 3) & 0x1fffu);
-        const int rr = (int)((p4[p4_slot(ty, ry + 1, xr, tpc)] >> 3) & 0x1fffu);
-        const int rl = (int)((p4[p4_slot(ty, ry + 1, xl, tpc)] >> 3) & 0x1fffu);
-        const int dr = rr - c, dl = rl - c;
-        if (dr < -127 || dr > 127 || dl < -127 || dl > 127) { bad = PAL_STEP; break; }
-        const float gx = 0.5f * (__uint_as_float(sorted[rr]) - __uint_as_float(sorted[rl]));
-        const float gy = 0.5f * (__uint_as_float(sorted[rd]) - __uint_as_float(sorted[ru]));
-        if (__float_as_uint(gx) != __float_as_uint(t.y) || __float_as_uint(gy) != __float_as_uint(t.z)) { bad = PAL_GRADIENT; break; }
-        if (wts[c] != __float_as_uint(t.w)) { bad = PAL_WEIGHT; break; }
-        p4[own] = ((unsigned)c << 3) | (((unsigned)dr & 0xffu) << 16) | (((unsigned)dl & 0xffu) << 24);
-    }
-    __syncthreads();
-    for (int k = tid; k < n; k += 1024) pal[k] = make_float2(__uint_as_float(sorted[k]), __uint_as_float(wts[k]));
-    if (tid == 0) pal[n] = make_float2(0.0f, 0.0f);
-    if (tid == 0) pal_n[pair] = bad ? -bad : n;
+    if (tid == 0 && bad) atomicMin(&pal_n[pair], -bad);
 }
 
 hipError_t launch_palette_build(const float4 *tex, size_t tex_stride, int rows, int cols, unsigned *p4, size_t p4_stride,
-                                float2 *pal, int *pal_n, int first_pair, int count, hipStream_t s) {
+                                float2 *pal, int *pal_n, int first_pair, int count, unsigned *work, hipStream_t s) {
     if (count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(palette_build_kernel, dim3(count), dim3(1024), 0, s, tex, tex_stride, rows, cols, p4, p4_stride, pal, pal_n,
-                       first_pair);
+    /* enough workgroups per image to fill the GPU for small batches, a few for large ones */
+    int chunks = 2048 / count;
+    chunks = chunks < 4 ? 4 : (chunks > 64 ? 64 : chunks);
+    const int n_tcols = (cols + 3) >> 2;
+    const int cpc = (cols + chunks - 1) / chunks, tpcn = (n_tcols + chunks - 1) / chunks;
+    hipLaunchKernelGGL(palette_init_kernel, dim3(count), dim3(256), 0, s, work, pal_n, first_pair, rows, cols);
+    hipLaunchKernelGGL(palette_collect_kernel, dim3((cols + cpc - 1) / cpc, count), dim3(256), 0, s, tex, tex_stride, rows, cols, work,
+                       first_pair, cpc);
+    hipLaunchKernelGGL(palette_sort_kernel, dim3(count), dim3(1024), 0, s, work, p4, p4_stride, pal, pal_n, first_pair);
+    hipLaunchKernelGGL(palette_encode_kernel, dim3((n_tcols + tpcn - 1) / tpcn, count), dim3(256), 0, s, tex, tex_stride, rows, cols, p4,
+                       p4_stride, pal, pal_n, first_pair, tpcn);
     return hipGetLastError();
 }
 

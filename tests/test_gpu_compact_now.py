@@ -81,25 +81,27 @@ def test_compact_now_640x480(oracle, kw):
             assert np.array_equal(R1, R2) and np.array_equal(t1, t2)
 
 
-def test_compact_now_is_built_at_the_second_alignment(oracle):
-    """policy: a now level aligned once keeps the 16-byte form; the second alignment builds the compact form; writing the
-    level again makes it stale (and the results follow the new image)"""
+def test_compact_now_is_built_for_a_level_that_keeps_being_aligned(oracle):
+    """policy (DVO_COMPACT_NOW_AFTER = 16 in dvo_amd.h): a now level keeps the 16-byte form for its first 16 alignments, the
+    17th builds the compact form; writing the level again makes it stale (and the results follow the new image)"""
     import os
     from rgbd_odometry_amd import DvoContext, SynthScene
     if os.environ.get("DVO_COMPACT_NOW"):
         pytest.skip("policy overridden by DVO_COMPACT_NOW")
-    sc, sc2 = SynthScene(320, 240, 3, 5), SynthScene(320, 240, 3, 6)
-    iters = [6, 6, 6]
+    AFTER = 16
+    sc, sc2 = SynthScene(160, 120, 2, 5), SynthScene(160, 120, 2, 6)
+    iters = [4, 4]
     ref = oracle.align_pyramid(iters, oracle_lib.scene_levels(sc, oracle), sc.intrinsics, np.eye(3), np.zeros(3))
     with DvoContext(1, team_size=1, engine_variant=2) as ctx:
         ctx.set_intrinsics(*sc.intrinsics)
         _load(ctx, sc)
+        for k in range(AFTER):
+            _check(ctx, ref, iters)
+            assert [ctx.level_texel_mode(0, l) for l in range(2)] == [0, 0], k
+            assert [ctx.now_compact_info(0, l) for l in range(2)] == [0, 0], k
         _check(ctx, ref, iters)
-        assert [ctx.level_texel_mode(0, l) for l in range(3)] == [0, 0, 0]
-        assert [ctx.now_compact_info(0, l) for l in range(3)] == [0, 0, 0]
-        _check(ctx, ref, iters)
-        assert [ctx.level_texel_mode(0, l) for l in range(3)] == [2, 2, 2]
-        assert all(ctx.now_compact_info(0, l) > 0 for l in range(3))
+        assert [ctx.level_texel_mode(0, l) for l in range(2)] == [2, 2]
+        assert all(ctx.now_compact_info(0, l) > 0 for l in range(2))
         # a new now frame in the same slot (same reference): compact form stale -> 16-byte form, results of the new image
         for l, L in enumerate(sc2.levels):
             ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols)
@@ -107,11 +109,12 @@ def test_compact_now_is_built_at_the_second_alignment(oracle):
         for l, L in enumerate(sc2.levels):
             lv_mixed[l].update(dt=L.now_dt, gx=L.now_gx, gy=L.now_gy)
         ref2 = oracle.align_pyramid(iters, lv_mixed, sc.intrinsics, np.eye(3), np.zeros(3))
-        assert [ctx.now_compact_info(0, l) for l in range(3)] == [0, 0, 0]
+        assert [ctx.now_compact_info(0, l) for l in range(2)] == [0, 0]
         _check(ctx, ref2, iters)
-        assert [ctx.level_texel_mode(0, l) for l in range(3)] == [0, 0, 0]
+        assert [ctx.level_texel_mode(0, l) for l in range(2)] == [0, 0]
+        ctx.now_prepare()                                  # on request: now
         _check(ctx, ref2, iters)
-        assert [ctx.level_texel_mode(0, l) for l in range(3)] == [2, 2, 2]
+        assert [ctx.level_texel_mode(0, l) for l in range(2)] == [2, 2]
 
 
 @pytest.mark.parametrize("rows,cols", [(7, 9), (12, 8), (13, 5), (61, 83), (6, 4), (240, 322), (2, 2), (5, 2)])
