@@ -312,8 +312,8 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         if ((size_t)max_n * 12 <= 77000 && !c->prm.interpolate_dt && 2 * n_pairs > c->n_cu) { block = 256; auto_lds = 77000; }
         /* with the compact now form the loop is no longer request-bound and two workgroups per CU pay even when the lists do
          * not fit half the LDS (640x480x4x10, 1024 pairs: 510 k aligns/s with one 512-thread workgroup per CU, 593 k with two
-         * of 256; 256 pairs: 466 k vs 387 k -- so only when the launch fills every CU twice) */
-        else if (all_p4 && n_pairs >= 2 * c->n_cu && (size_t)max_n * 8 <= 2 * (size_t)77000) { block = 256; auto_lds = 77000; }
+         * of 256; 768 pairs 538 k vs 575 k, 384 pairs 403 k vs 453 k, 256 pairs 466 k vs 387 k -- so from 1.5 workgroups per CU) */
+        else if (all_p4 && 2 * n_pairs >= 3 * c->n_cu && (size_t)max_n * 8 <= 2 * (size_t)77000) { block = 256; auto_lds = 77000; }
         else if ((size_t)max_n * 12 > 4 * (size_t)155000 && !c->prm.interpolate_dt) { block = 1024; auto_lds = 155000; }   /* lists far beyond the LDS
                                                                        budget are streamed: 16 waves hide that better (1920x1080x5, 256 pairs: 38.3 k -> 41.3 k aligns/s) */
         else { block = 512; auto_lds = 155000; }

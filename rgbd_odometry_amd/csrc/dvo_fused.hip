@@ -110,19 +110,30 @@ DVO_DEV void load_compact(const LdsPoints &lp, const uint2 *__restrict__ gpts, i
     k = a.x; z = __uint_as_float(a.y);
 }
 
+/* points streamed from HBM (beyond the LDS budget) are fetched ONE ROUND AHEAD of the round that projects them: a lane's
+ * gather address depends on its point, so a point loaded inside the round would put two memory latencies in a row */
+struct PointPf { uint2 p0, p1; };
+
 /* stage 1 of a round: load, decode, project, issue the two gathers.  Straight-line code: a point whose z is outside the
  * range in which the fast reciprocal is proven exact (|z| < 2^-126, > 2^126, 0, inf, nan -- never in practice) is
  * treated as not visible here and reported through `any_odd` (wave-uniform); the caller then redoes the wave's whole
  * share of the iteration with the literal-division scalar code (accumulate_points_exact). */
 template <bool LDS_SRC, int TEX>
 DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints &lp, const uint2 *__restrict__ gpts,
-                          int i0, int i1, int end, Round2<TEX> &b, bool &any_odd, int &nvis) {
+                          int i0, int i1, int end, int step, PointPf &pf, Round2<TEX> &b, bool &any_odd, int &nvis) {
     const bool valid0 = i0 < end, valid1 = i1 < end;
-    const int j0 = valid0 ? i0 : (end - 1), j1 = valid1 ? i1 : (end - 1);
     unsigned k0, k1;
     float z0, z1;
-    load_compact<LDS_SRC>(lp, gpts, j0, k0, z0);
-    load_compact<LDS_SRC>(lp, gpts, j1, k1, z1);
+    if constexpr (LDS_SRC) {
+        const int j0 = valid0 ? i0 : (end - 1), j1 = valid1 ? i1 : (end - 1);
+        load_compact<true>(lp, gpts, j0, k0, z0);
+        load_compact<true>(lp, gpts, j1, k1, z1);
+    } else {
+        k0 = pf.p0.x; z0 = __uint_as_float(pf.p0.y);            /* fetched while the previous round was worked on */
+        k1 = pf.p1.x; z1 = __uint_as_float(pf.p1.y);
+        pf.p0 = gpts[min(i0 + step, end - 1)];                  /* the next round's points (the last point again past the end) */
+        pf.p1 = gpts[min(i1 + step, end - 1)];
+    }
     v2f xx, yy, Z;
     xx.x = (float)(k0 & 0xffffu); xx.y = (float)(k1 & 0xffffu);
     yy.x = (float)(k0 >> 16);     yy.y = (float)(k1 >> 16);
@@ -236,9 +247,11 @@ DVO_DEV void accumulate_points2(const IterConst &c, const TexSrc &ts, const LdsP
     const int wave_off = __builtin_amdgcn_readfirstlane(lane_off - (int)(threadIdx.x & 63));
     const int n_rounds = (end - first - wave_off + STEP - 1) / STEP;
     if (n_rounds <= 0) return;
-#define DVO_ISSUE(buf, k) round2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + (k) * STEP, base + (k) * STEP + BLOCK, end, buf, any_odd, a.nvis)
+#define DVO_ISSUE(buf, k) round2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + (k) * STEP, base + (k) * STEP + BLOCK, end, STEP, pf, buf, any_odd, a.nvis)
 #define DVO_COMPUTE(buf) round2_compute<TEX, PAL>(c, buf, a)
     int base = first + lane_off;
+    PointPf pf;
+    if constexpr (!LDS_SRC) { pf.p0 = gpts[min(base, end - 1)]; pf.p1 = gpts[min(base + BLOCK, end - 1)]; }
     if constexpr (DEPTH == 3) {
         /* gathers issued TWO rounds ahead of the arithmetic that consumes them: with half the requests per point (TEX_P4) the
          * loop is no longer bound by the request rate but by the latency of a gather that misses the L2 (~2 rounds of

@@ -17,6 +17,8 @@ for l, L in enumerate(sc.levels):
     ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols, pair=0)
     ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols, pair=0)
 ctx.replicate_pairs(1)
+if os.environ.get('PREP', '1') == '1':
+    ctx.now_prepare()
 iters = [10, 10, 10, 10]
 for rep in range(3):
     ctx.enqueue(iters, flags=DVO_FLAG_IDENTITY_START | DVO_FLAG_FINAL_OUTPUTS); ctx.synchronize()
