@@ -117,6 +117,11 @@ int now_written(dvo_ctx *c, int level, int first_pair, int count) {
 int build_compact_now(dvo_ctx *c, int level, int first_pair, int count, bool only_reused) {
     Level &L = c->lv[level];
     if (!L.tex || L.have_now.empty()) return DVO_OK;
+    /* the kernel addresses a pair's rank words with 32-bit byte offsets built from 24-bit multiplies (dvo_fused.hip,
+     * p4_byte_offset): a level beyond that (> ~800 M pixels) simply keeps the 16-byte form */
+    if (p4_count(L.rows, L.cols) * sizeof(unsigned) >= ((size_t)1 << 32) || L.rows >= (1 << 16) || ((L.cols + 3) >> 2) >= (1 << 24) ||
+        (size_t)p4_tiles_per_col(L.rows) * 128 >= ((size_t)1 << 24))
+        return DVO_OK;
     if (L.pal_built.empty()) { L.pal_built.assign(c->n_pairs, 0); L.now_uses.assign(c->n_pairs, 0); }
     for (int p = first_pair; p < first_pair + count; ) {
         auto wanted = [&](int i) { return L.have_now[i] && !L.pal_built[i] && (!only_reused || L.now_uses[i] >= DVO_COMPACT_NOW_AFTER); };
