@@ -65,10 +65,10 @@ palette_collect_kernel(const float4 *__restrict__ tex, size_t tex_stride, int ro
     unsigned *gkeys = work + (size_t)blockIdx.y * PAL_WORK_INTS;
     int *gcnt = reinterpret_cast<int *>(gkeys + PAL_HASH), *gbad = gcnt + 1;
     __shared__ unsigned keys[PAL_HASH];
-    __shared__ int lbad;
+    __shared__ int lbad, lcnt;
     const int tid = threadIdx.x;
     for (unsigned i = tid; i < PAL_HASH; i += 256) keys[i] = PAL_EMPTY;
-    if (tid == 0) lbad = *gbad;
+    if (tid == 0) { lbad = *gbad; lcnt = 0; }
     __syncthreads();
     if (lbad) return;
     const int tpc16 = texel_tiles_per_col(rows);
@@ -85,9 +85,13 @@ palette_collect_kernel(const float4 *__restrict__ tex, size_t tex_stride, int ro
             for (int q = 0; q < 4; q++) {
                 if (y0 + q * 256 >= rows) continue;
                 if (k[q] >= 0x7f800000u) { lbad = PAL_BAD_VALUE; continue; }     /* negative, inf or nan: not a distance */
-                pal_set_insert(keys, k[q], nullptr);         /* cannot fill up: at most rows*cols_per_chunk keys... guarded below */
+                /* the local set must never fill up (an insert into a full table would not terminate): more than
+                 * DVO_PAL_MAX distinct values in this chunk alone already means "no compact form" -- stop inserting */
+                if (*(volatile int *)&lbad) continue;
+                if (pal_set_insert(keys, k[q], &lbad) && atomicAdd(&lcnt, 1) >= DVO_PAL_MAX - 1) lbad = PAL_TOO_MANY;
             }
         }
+        if (*(volatile int *)&lbad) break;
     }
     __syncthreads();
     if (lbad) { if (tid == 0) atomicMax(gbad, lbad); return; }

@@ -215,3 +215,28 @@ def test_compact_now_mixed_batch(oracle):
                 assert np.array_equal(e, rep["energy"]) and b == rep["best_idx"] and ratio == rep["visible_ratio"], (p, l)
             assert rot_angle(ref["R"], R[p]) <= ROT_TOL and np.linalg.norm(ref["t"] - t[p]) <= TRANS_TOL
             assert ctx.level_texel_mode(p, 0) == (2 if p % 2 == 0 else 0)
+
+
+def test_compact_now_builder_survives_images_of_all_distinct_values(oracle):
+    """a 640x480 level whose every pixel has another value: every chunk of the collect pass alone exceeds the palette limit --
+    the builder must say "too many" (-2), not spin on a full hash set"""
+    from rgbd_odometry_amd import DvoContext
+    rows, cols = 480, 640
+    rng = np.random.default_rng(11)
+    dt = rng.permutation(rows * cols).astype(np.float32) * np.float32(1.0 / 4096.0)
+    g = np.zeros(rows * cols, np.float32)
+    edge = (rng.random(rows * cols) < 0.02).astype(np.int32) * 255
+    depth = rng.uniform(500, 3000, rows * cols).astype(np.float32)
+    K = (525.0, 525.0, 319.5, 239.5)
+    for n_pairs in (1, 3):                     # different chunkings of the image
+        with DvoContext(n_pairs, team_size=1) as ctx:
+            ctx.set_intrinsics(*K)
+            for p in range(n_pairs):
+                xyz, _ = ctx.set_ref_level_from_images(0, edge, depth, rows, cols, pair=p)
+                ctx.set_now_level(0, dt, g, g, rows, cols, pair=p)
+            ctx.now_prepare()
+            assert [ctx.now_compact_info(p, 0) for p in range(n_pairs)] == [-2] * n_pairs
+            ref = oracle.run_iterations(0, 3, xyz, dt, g, g, rows, cols, K, np.eye(3), np.zeros(3))
+            got = ctx.run_iterations(0, 3, np.eye(3), np.zeros(3))
+            assert ctx.level_texel_mode(0, 0) == 0
+            assert _same(ref["energy"], got["energy"])
