@@ -278,8 +278,8 @@ int  dvo_get_last_launch_shape(dvo_ctx *ctx, int *block_threads, int *team_size,
  * line instead of 8 -> half the memory requests of the alignment kernel), VERIFIES per pixel that it reproduces the resident
  * {DT, gx, gy, w} bit for bit, and otherwise keeps reading the 16-byte form for that pair and level (caller-supplied
  * gradients that are not imageGradient(DT), more than 4095 distinct values, ...).  Building it reads the level twice and costs
- * about five alignments of the same pair (measured, 640x480x4: 8.8 us per pair against 1.64 us per alignment; an alignment
- * then saves ~0.45 us), so the engine builds it by itself only for a now level that has already been aligned
+ * about four and a half alignments of the same pair (measured, 640x480x4: 7.0 us per pair against 1.6 us per alignment; an
+ * alignment then saves ~0.45 us: break-even at the 16th), so the engine builds it by itself only for a now level that has already been aligned
  * DVO_COMPACT_NOW_AFTER times (a tracker's now frame is aligned once or twice and never pays for it); dvo_now_prepare
  * builds it now for every resident now level of the given pairs (batch / benchmark set-up: "inputs resident").
  * dvo_params.engine_variant = 4 disables it. */

@@ -159,7 +159,7 @@ int ensure_texels(dvo_ctx *c, int level, int rows, int cols);
 /* the now level of `pair` at `level` was (re)written: mark it present and its compact form stale */
 int now_written(dvo_ctx *c, int level, int first_pair, int count);
 /* build the compact form of the stale now levels among [first_pair, first_pair+count) at `level`; with only_reused, only
- * of those that have been aligned DVO_COMPACT_NOW_AFTER times (the build costs about five alignments) */
+ * of those that have been aligned DVO_COMPACT_NOW_AFTER times (the build costs about 4.4 alignments) */
 int build_compact_now(dvo_ctx *c, int level, int first_pair, int count, bool only_reused);
 /* schedule / readiness / output bookkeeping of the align entry points (dvo_capi.cpp) */
 dvo::LevelSlab slab_of(const dvo_ctx *c, int level);

@@ -147,15 +147,16 @@ palette_sort_kernel(const unsigned *__restrict__ work, unsigned *__restrict__ p4
 }
 
 /* 3. rank words of tile columns [c0, c1) of image blockIdx.y.
- * value -> rank: distance values live in [0, 255] (cv::normalize), so a table of 8192 buckets of width 1/32 gives the rank
+ * value -> rank: distance values live in [0, 255] (cv::normalize), so a table of 2048 buckets of width 1/8 gives the rank
  * range of a value in one look-up and a binary search over the few palette entries of that bucket finishes it (values
  * beyond 256 -- caller-supplied images -- share the last bucket: still correct, just a longer search). */
-#define PAL_BUCKETS 8192
+#define PAL_BUCKETS 2048
 DVO_DEV unsigned pal_bucket(unsigned key) {
-    const float f = __uint_as_float(key) * 32.0f;
+    const float f = __uint_as_float(key) * 8.0f;
     return (f >= (float)(PAL_BUCKETS - 1)) ? (unsigned)(PAL_BUCKETS - 1) : (unsigned)f;
 }
 
+#define PAL_SEG 1020      /* image rows per pass of a tile column (a multiple of DVO_P4_ROWS); LDS holds their ranks + 2 halo rows */
 __global__ void __launch_bounds__(256)
 palette_encode_kernel(const float4 *__restrict__ tex, size_t tex_stride, int rows, int cols, unsigned *__restrict__ p4,
                       size_t p4_stride, const float2 *__restrict__ pal, int *__restrict__ pal_n, int first_pair, int tcols_per_chunk) {
@@ -166,18 +167,18 @@ palette_encode_kernel(const float4 *__restrict__ tex, size_t tex_stride, int row
     p4 += (size_t)pair * p4_stride;
     pal += (size_t)pair * DVO_PAL_MAX;
     __shared__ unsigned sorted[DVO_PAL_MAX];                 /* P as bits */
-    __shared__ unsigned wts[DVO_PAL_MAX];                    /* W as bits */
     __shared__ unsigned short first[PAL_BUCKETS + 2];        /* first[b] = number of palette values below bucket b */
+    __shared__ unsigned short rk[6][PAL_SEG + 2];            /* ranks of pixel columns 4tc-1 .. 4tc+4, rows y0-1 .. y0+PAL_SEG */
     __shared__ int bad;
     const int tid = threadIdx.x;
     for (int k = tid; k < n; k += 256) {
         const float2 e = pal[k];
-        sorted[k] = __float_as_uint(e.x); wts[k] = __float_as_uint(e.y);
+        sorted[k] = __float_as_uint(e.x);
     }
     if (tid == 0) bad = 0;
     __syncthreads();
     for (int b = tid; b <= PAL_BUCKETS; b += 256) {
-        const unsigned edge = __float_as_uint((float)b * (1.0f / 32.0f));      /* exact */
+        const unsigned edge = __float_as_uint((float)b * (1.0f / 8.0f));       /* exact */
         int lo = 0, hi = n;
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted[mid] < edge) lo = mid + 1; else hi = mid; }
         first[b] = (unsigned short)((b == PAL_BUCKETS) ? n : lo);
@@ -192,59 +193,81 @@ palette_encode_kernel(const float4 *__restrict__ tex, size_t tex_stride, int row
     const int tpc16 = texel_tiles_per_col(rows), tpc = p4_tiles_per_col(rows);
     const int n_tcols = (cols + 3) >> 2;
     const int c0 = blockIdx.x * tcols_per_chunk, c1 = min(n_tcols, c0 + tcols_per_chunk);
-    const int slots = tpc * 32;
     int lbad = 0;
     for (int tc = c0; tc < c1; tc++) {
-        unsigned *__restrict__ col = p4 + 32u + (size_t)tc * slots;
-        for (int s0 = tid; s0 < slots; s0 += 2 * 256) {                    /* two independent slots per trip */
-            unsigned word[2] = {0u, 0u};
-            float4 t[2];
-            unsigned nb[2][4];
-            int yy[2], xx[2];
-            bool use[2], interior[2];
+        unsigned *__restrict__ col = p4 + 32u + (size_t)tc * tpc * 32u;
+        for (int y0 = 0; y0 < rows; y0 += PAL_SEG) {             /* rows [y0, y1) = whole tile rows */
+            const int y1 = min(rows, y0 + PAL_SEG), nr = y1 - y0 + 2;
+            /* ranks of the 6 x nr pixels around this strip: every pixel's rank is looked up once (reflect-101 outside the image) */
+            for (int i0 = tid; i0 < 6 * nr; i0 += 4 * 256) {            /* four independent loads in flight per lane */
+                unsigned key[4];
+                int cxs[4], rs[4];
+                bool in[4];
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const int s = s0 + q * 256;
-                const int ty = s >> 5, w = s & 31, srow = w & 7;
-                xx[q] = tc * 4 + (w >> 3);
-                int y = ty * DVO_P4_ROWS + srow - 1;
-                interior[q] = srow >= 1 && srow <= DVO_P4_ROWS && y < rows;
-                if (y == -1) y = 1;                          /* reflect-101 */
-                if (y == rows) y = rows - 2;
-                yy[q] = y;
-                use[q] = s < slots && xx[q] < cols && y < rows;
-                if (use[q]) {
-                    t[q] = tex[texel_index(y, xx[q], tpc16)];
-                    if (interior[q]) {
-                        const int xr = (xx[q] + 1 < cols) ? xx[q] + 1 : cols - 2, xl = (xx[q] > 0) ? xx[q] - 1 : 1;
-                        const int yu = (y > 0) ? y - 1 : 1, yd = (y + 1 < rows) ? y + 1 : rows - 2;
-                        nb[q][0] = __float_as_uint(tex[texel_index(y, xr, tpc16)].x);
-                        nb[q][1] = __float_as_uint(tex[texel_index(y, xl, tpc16)].x);
-                        nb[q][2] = __float_as_uint(tex[texel_index(yu, xx[q], tpc16)].x);
-                        nb[q][3] = __float_as_uint(tex[texel_index(yd, xx[q], tpc16)].x);
+                for (int q = 0; q < 4; q++) {
+                    const int i = i0 + q * 256;
+                    const int cx = i / nr, r = i - cx * nr;
+                    int x = tc * 4 - 1 + cx, y = y0 - 1 + r;
+                    x = (x < 0) ? 1 : ((x >= cols) ? ((x == cols) ? cols - 2 : -1) : x);
+                    y = (y < 0) ? 1 : ((y >= rows) ? ((y == rows) ? rows - 2 : -1) : y);
+                    cxs[q] = cx; rs[q] = r;
+                    in[q] = i < 6 * nr && x >= 0 && y >= 0;
+                    key[q] = in[q] ? __float_as_uint(tex[texel_index(y, x, tpc16)].x) : 0u;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (i0 + q * 256 >= 6 * nr) continue;
+                    int c = 0;
+                    if (in[q]) {
+                        c = rank_of(key[q]);
+                        if (c < 0) { lbad = PAL_BAD_VALUE; c = 0; }
                     }
+                    rk[cxs[q]][rs[q]] = (unsigned short)c;
                 }
             }
+            __syncthreads();
+            /* the stored slots of tile rows y0/6 .. : interior slots get the horizontal rank steps and the bit-exact check */
+            const int ty0 = y0 / DVO_P4_ROWS, ty1 = (y1 + DVO_P4_ROWS - 1) / DVO_P4_ROWS;
+            for (int s0 = ty0 * 32 + tid; s0 < ty1 * 32; s0 += 4 * 256) {      /* four independent texel loads in flight per lane */
+                float4 t[4];
+                int ys[4], xls[4];
+                bool use[4], inter[4];
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-                if (!use[q]) continue;
-                const int c = rank_of(__float_as_uint(t[q].x));
-                if (c < 0) { lbad = PAL_BAD_VALUE; continue; }
-                word[q] = (unsigned)c << 3;
-                if (!interior[q]) continue;
-                const int rr = rank_of(nb[q][0]), rl = rank_of(nb[q][1]), ru = rank_of(nb[q][2]), rd = rank_of(nb[q][3]);
-                if ((rr | rl | ru | rd) < 0) { lbad = PAL_BAD_VALUE; continue; }
-                const int dr = rr - c, dl = rl - c;
-                if (dr < -127 || dr > 127 || dl < -127 || dl > 127) { lbad = PAL_STEP; continue; }
-                const float gx = 0.5f * (__uint_as_float(sorted[rr]) - __uint_as_float(sorted[rl]));
-                const float gy = 0.5f * (__uint_as_float(sorted[rd]) - __uint_as_float(sorted[ru]));
-                if (__float_as_uint(gx) != __float_as_uint(t[q].y) || __float_as_uint(gy) != __float_as_uint(t[q].z)) { lbad = PAL_GRADIENT; continue; }
-                if (wts[c] != __float_as_uint(t[q].w)) { lbad = PAL_WEIGHT; continue; }
-                word[q] |= (((unsigned)dr & 0xffu) << 16) | (((unsigned)dl & 0xffu) << 24);
+                for (int q = 0; q < 4; q++) {
+                    const int s = s0 + q * 256;
+                    const int ty = s >> 5, w = s & 31, srow = w & 7;
+                    xls[q] = w >> 3;
+                    const int xx = tc * 4 + xls[q];
+                    ys[q] = ty * DVO_P4_ROWS + srow - 1;                  /* image row this slot stands for (-1 / rows: reflected) */
+                    use[q] = s < ty1 * 32 && xx < cols && ys[q] <= rows && ys[q] <= y1;
+                    inter[q] = use[q] && srow >= 1 && srow <= DVO_P4_ROWS && ys[q] < rows;
+                    if (inter[q]) t[q] = tex[texel_index(ys[q], xx, tpc16)];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int s = s0 + q * 256;
+                    if (s >= ty1 * 32) continue;
+                    unsigned word = 0u;
+                    if (use[q]) {
+                        const int r = ys[q] - (y0 - 1), xl = xls[q];
+                        const int c = rk[xl + 1][r];
+                        word = (unsigned)c << 3;
+                        if (inter[q]) {
+                            const int rr = rk[xl + 2][r], rl = rk[xl][r], ru = rk[xl + 1][r - 1], rd = rk[xl + 1][r + 1];
+                            const int dr = rr - c, dl = rl - c;
+                            const float gx = 0.5f * (__uint_as_float(sorted[rr]) - __uint_as_float(sorted[rl]));
+                            const float gy = 0.5f * (__uint_as_float(sorted[rd]) - __uint_as_float(sorted[ru]));
+                            if (dr < -127 || dr > 127 || dl < -127 || dl > 127) lbad = PAL_STEP;
+                            else if (sorted[c] != __float_as_uint(t[q].x)) lbad = PAL_BAD_VALUE;
+                            else if (__float_as_uint(gx) != __float_as_uint(t[q].y) || __float_as_uint(gy) != __float_as_uint(t[q].z)) lbad = PAL_GRADIENT;
+                            else if (__float_as_uint(pal[c].y) != __float_as_uint(t[q].w)) lbad = PAL_WEIGHT;       /* W[c] = getWeightOf(P[c]), palette_sort_kernel */
+                            word |= (((unsigned)dr & 0xffu) << 16) | (((unsigned)dl & 0xffu) << 24);
+                        }
+                    }
+                    col[s] = word;
+                }
             }
-#pragma unroll
-            for (int q = 0; q < 2; q++)
-                if (s0 + q * 256 < slots) col[s0 + q * 256] = word[q];
+            __syncthreads();
         }
     }
     if (lbad) bad = lbad;
