@@ -94,8 +94,9 @@ typedef struct dvo_params {
     int    canny_threshold2;   /* swaps them), SolveDVO.cpp:1704,1764; used by the dvo_frame* entry points; 0,0 = 150,100 */
     int    team_size;          /* engine tuning: workgroups per frame pair of the fused launch when there are fewer pairs than compute
                                   units (each takes a contiguous share of every level's points; sums exchanged through L2 once per
-                                  iteration, identical update on every member).  0 = auto (from the point counts and the number of pairs,
-                                  at most 32 = one XCD), 1 = off, k = force k */
+                                  iteration, identical update on every member).  0 = auto (from the point counts and the number of pairs:
+                                  at most 32 = one XCD; a single pair with >= 100 k points: 64 / 128 over all XCDs, two-stage exchange),
+                                  1 = off, k = force k (<= 32, or 64 / 128 / 256 for a single pair) */
 } dvo_params;
 
 typedef struct dvo_ctx dvo_ctx;

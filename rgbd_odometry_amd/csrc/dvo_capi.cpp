@@ -364,18 +364,24 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         int g = 1;
         if (n_fine >= 5000)
             while (g * 2 <= g_cap && slots8 * g * 2 <= c->n_cu && n_fine >= 1800 * g * 2) g *= 2;
+        /* one very large frame: a team over all XCDs (8 x g1 workgroups, two-stage exchange, dvo_fused.hip).  Measured, ms per
+         * alignment by team size: 4096x3072x5 (629 k points at level 0) 32: 0.94, 64: 0.65-0.73, 128: 0.61-0.62, 256: 0.66
+         * (all-CU wide path 0.78-0.80); 1920x1080x5 (130 k) 16: 0.52-0.54, 32: 0.54, 64: 0.48-0.49, 128: 0.50, 256: 0.57 (wide 0.58) */
+        bool super_team = (n_pairs == 1 && n_fine >= 100000 && c->n_cu >= 256);
+        if (super_team) g = (n_fine >= 400000) ? 128 : 64;
         if (c->prm.team_size > 1) {
             g = c->prm.team_size;
-            if (g > 32 || slots8 * g > c->n_cu)
-                return fail(c, DVO_ERR_INVALID, "team_size: the launch would need more workgroups than compute units (members must be co-resident)");
+            super_team = (g == 64 || g == 128 || g == 256) && n_pairs == 1;
+            if (super_team ? (g > c->n_cu) : (g > 32 || slots8 * g > c->n_cu))
+                return fail(c, DVO_ERR_INVALID, "team_size: the launch would need more workgroups than compute units (members must be co-resident; 64 / 128 / 256 only for a single pair)");
         }
         if (g > 1) {
             if (!c->d_team_buf) {
-                HIPCHK(c, hipMalloc((void **)&c->d_team_buf, 16 * 2 * 32 * 8 * (size_t)c->n_pairs));     /* 16-byte records, [2][32][8] per pair */
+                HIPCHK(c, hipMalloc((void **)&c->d_team_buf, 16 * 2 * 32 * 8 * (size_t)std::max(c->n_pairs, 9)));     /* 16-byte records, [2][32][8] per pair (a team over all XCDs: 8 + 1 slots) */
                 HIPCHK(c, hipMalloc((void **)&c->d_team_cnt, sizeof(unsigned) * ((size_t)c->n_pairs + 1)));
             }
             HIPCHK(c, hipMemsetAsync(c->d_team_cnt, 0, sizeof(unsigned) * ((size_t)c->n_pairs + 1), c->stream));
-            HIPCHK(c, hipMemsetAsync(c->d_team_buf, 0, 16 * 2 * 32 * 8 * (size_t)n_pairs, c->stream));       /* tags of an earlier launch */
+            HIPCHK(c, hipMemsetAsync(c->d_team_buf, 0, 16 * 2 * 32 * 8 * (size_t)(g > 32 ? 9 : n_pairs), c->stream));       /* tags of an earlier launch */
             sc.team = g;
             c->team_used = true;
         }

@@ -376,11 +376,11 @@ DVO_DEV v4u team_load_rec(const v4u *p) {
     return r;
 }
 DVO_DEV void team_exchange(double *tot, v4u *buf /* this pair's [2][DVO_TEAM_MAX][8] records */, double (*stage)[8] /* LDS [DVO_TEAM_MAX][8] */,
-                           int member, int G, unsigned epoch, int *err) {
+                           int member, int G, unsigned epoch, int *err, bool publish = true) {
     const int lane = threadIdx.x & 63;
     v4u *base = buf + (size_t)(epoch & 1u) * DVO_TEAM_MAX * 8;
     const unsigned tag = epoch + 1u;
-    if (lane < 8) {
+    if (lane < 8 && publish) {
         const unsigned long long bits = (unsigned long long)__double_as_longlong(tot[lane]);
         v4u rec;
         rec.x = (unsigned)bits; rec.y = tag; rec.z = (unsigned)(bits >> 32); rec.w = tag;
@@ -442,9 +442,17 @@ template <int BLOCK, bool TEAM>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK == 256 ? DVO_WPE256 : 1, 8)))
 align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outputs out, int first_pair) {
     /* team mode: workgroup b -> XCD b % 8; the G members of pair (q*8 + x) are the workgroups x + 8*(q*G + j) */
+    /* teams beyond one XCD (one very large frame, G = 8 x g1 members, g1 of them on every XCD): member = workgroup index;
+     * the sums are exchanged in two stages -- inside each XCD as above (slot `xcd` of the team buffer), then the 8 XCD sums
+     * through slot 8, published by the first member of every XCD and read by everybody.  Same fixed order of additions on all
+     * members -> identical bits; the double-buffering argument above holds per stage. */
     const int G = TEAM ? sc.team : 1;
-    int pair_local = blockIdx.x, member = 0;
-    if (TEAM) {
+    const bool super_team = TEAM && G > DVO_TEAM_MAX;
+    int pair_local = blockIdx.x, member = 0, xcd = 0, local = 0;
+    if (super_team) {
+        if ((int)blockIdx.x >= G) return;
+        member = blockIdx.x; xcd = blockIdx.x & 7; local = blockIdx.x >> 3; pair_local = 0;
+    } else if (TEAM) {
         const int x = blockIdx.x & 7, k = blockIdx.x >> 3, q = k / G;
         member = k - q * G;
         pair_local = q * 8 + x;
@@ -595,9 +603,15 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             DVO_STAMP(t1);
             block_reduce7<BLOCK>(a, red, tot);
             DVO_STAMP(t2);
-            if (TEAM && tid < 64)      /* wave 0: the sums of the other members; identical bits on every member */
-                team_exchange(tot, reinterpret_cast<v4u *>(out.team_buf) + (size_t)pair_local * 2 * DVO_TEAM_MAX * 8, team_stage, member, G,
-                              epoch, out.team_err);
+            if (TEAM && tid < 64) {    /* wave 0: the sums of the other members; identical bits on every member */
+                v4u *tb = reinterpret_cast<v4u *>(out.team_buf);
+                if (super_team) {
+                    team_exchange(tot, tb + (size_t)xcd * 2 * DVO_TEAM_MAX * 8, team_stage, local, G >> 3, epoch, out.team_err);
+                    team_exchange(tot, tb + (size_t)8 * 2 * DVO_TEAM_MAX * 8, team_stage, xcd, 8, epoch, out.team_err, local == 0);
+                } else {
+                    team_exchange(tot, tb + (size_t)pair_local * 2 * DVO_TEAM_MAX * 8, team_stage, member, G, epoch, out.team_err);
+                }
+            }
             if (tid == 0) {
                 const float e = pose_update_t<true>(st, prm, itr, Nall, &tot[0], tot[6], (int)tot[7]);
                 if (member == 0) energy[itr] = e;                            /* :690 */
@@ -696,7 +710,7 @@ static hipError_t launch_fused2_b(const LevelSet &lv, const Schedule &sc, const 
     if (sc.team > 1) {
         auto kern = align_fused2_kernel<BLOCK, true>;
         if ((e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)) != hipSuccess) return e;
-        const int grid = 8 * ((n_pairs + 7) / 8) * sc.team;
+        const int grid = (sc.team > DVO_TEAM_MAX) ? sc.team : 8 * ((n_pairs + 7) / 8) * sc.team;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), dyn, s, lv, sc, K, prm, out, first_pair);
     } else {
         auto kern = align_fused2_kernel<BLOCK, false>;
@@ -712,7 +726,7 @@ size_t fused2_static_lds(int block_threads) { return ((sizeof(PoseState) + 15) &
 hipError_t launch_align_fused2(int block_threads, const LevelSet &lv, const Schedule &sc, const Intrinsics &K,
                                const DevParams &prm, const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {
     if (n_pairs <= 0) return hipSuccess;
-    if (sc.team > DVO_TEAM_MAX) return hipErrorInvalidValue;
+    if (sc.team > DVO_TEAM_MAX && !(n_pairs == 1 && (sc.team == 64 || sc.team == 128 || sc.team == 256))) return hipErrorInvalidValue;
     switch (block_threads) {
     case 256: return launch_fused2_b<256>(lv, sc, K, prm, out, first_pair, n_pairs, s);
     case 1024: return launch_fused2_b<1024>(lv, sc, K, prm, out, first_pair, n_pairs, s);

@@ -55,6 +55,36 @@ def test_config5_wide_path(scene4096, ctx4096):
     assert rot_angle(ref["R"], Rw) <= ROT_TOL and np.linalg.norm(ref["t"] - tw) <= TRANS_TOL
 
 
+@pytest.mark.parametrize("team", [0, 64, 128, 256, 32])
+def test_config5_team_over_all_xcds(scene4096, team):
+    """the fused kernel with ONE pair spread over the whole GPU: a team of 8 x g1 workgroups, sums exchanged inside every XCD
+    and then between the 8 XCDs (auto = 128 for this frame); same bits as the oracle, run-to-run deterministic, final outputs
+    of the best iterate included"""
+    from rgbd_odometry_amd import DvoContext
+    from rgbd_odometry_amd.capi import DVO_FLAG_FINAL_OUTPUTS
+    sc, lv, iters, ref = scene4096
+    with DvoContext(1, team_size=team) as ctx:
+        ctx.set_intrinsics(*sc.intrinsics)
+        for l, L in enumerate(sc.levels):
+            ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols)
+            ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols)
+        R, t = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)), flags=DVO_FLAG_FINAL_OUTPUTS)
+        blk, g, packed = ctx.last_launch_shape()
+        assert packed and blk == 512 and g == (team if team else 128), (blk, g, packed)
+        _check_reports(ctx, ref, iters)
+        assert rot_angle(ref["R"], R[0]) <= ROT_TOL and np.linalg.norm(ref["t"] - t[0]) <= TRANS_TOL
+        last = ref["levels"][ref["last_level"]]
+        feps, frep = ctx.final_outputs(0, len(last["final_eps"]))
+        assert np.array_equal(feps, last["final_eps"]) and np.array_equal(frep, last["final_reproj"], equal_nan=True)
+        R2, t2 = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)), flags=DVO_FLAG_FINAL_OUTPUTS)
+        assert np.array_equal(R, R2) and np.array_equal(t, t2)
+        if team in (0, 256):                      # the same with the now levels in the compact form
+            ctx.now_prepare()
+            R3, t3 = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)), flags=DVO_FLAG_FINAL_OUTPUTS)
+            _check_reports(ctx, ref, iters)
+            assert np.abs(R3 - R).max() <= 1e-12 and np.abs(t3 - t).max() <= 1e-12
+
+
 def test_config5_tiled_loop_with_forced_collective(scene4096, ctx4096):
     """the multi-GPU loop (accumulate -> all_reduce of 32 doubles -> update) with the RCCL collective really issued"""
     import torch

@@ -9,7 +9,7 @@ it = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 sc = SynthScene(W, H, nl, 7)
 iters = [it] * nl
 res = {}
-for team in (1, 2, 4, 8, 16, 32, 0):
+for team in [int(x) for x in os.environ.get("TEAMS", "1,2,4,8,16,32,64,128,256,0").split(",")]:
     with DvoContext(1, team_size=team) as ctx:
         ctx.set_intrinsics(*sc.intrinsics)
         for l, L in enumerate(sc.levels):
@@ -19,7 +19,7 @@ for team in (1, 2, 4, 8, 16, 32, 0):
         t0 = time.perf_counter()
         for _ in range(20): R, t = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
         res[team] = 1e3 * (time.perf_counter() - t0) / 20
-        if team == 0:
+        if team == 0 and "wide" not in res:
             Rw, tw = ctx.align_pyramid_wide(iters, np.eye(3), np.zeros(3))
             t0 = time.perf_counter()
             for _ in range(20): Rw, tw = ctx.align_pyramid_wide(iters, np.eye(3), np.zeros(3))
