@@ -255,6 +255,7 @@ Outputs outputs_of(const dvo_ctx *c) {
     o.team_buf = c->d_team_buf;
     o.team_cnt = c->d_team_cnt;
     o.team_err = reinterpret_cast<int *>(c->d_team_cnt ? c->d_team_cnt + c->n_pairs : nullptr);
+    o.order = nullptr;
     return o;
 }
 
@@ -388,8 +389,33 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
     }
     /* engine_variant: 0 = auto (packed two-points-per-lane kernel whenever every list is compact), 1 = always the
      * one-point-per-lane kernel of dvo_kernels.hip (A/B measurements, parity tests of both) */
-    if (sc.compact && c->prm.engine_variant != 1 && !(sc.flags & DVO_FLAG_NORMAL_MATRIX))
-        HIPCHK(c, launch_align_fused2(block, ls, sc, c->K, c->dprm, outputs_of(c), first_pair, n_pairs, c->stream));
+    if (sc.compact && c->prm.engine_variant != 1 && !(sc.flags & DVO_FLAG_NORMAL_MATRIX)) {
+        Outputs o = outputs_of(c);
+        /* a launch of more pairs than fit the GPU at once ends when its last workgroup ends: start the pairs with the most
+         * point-iterations first (longest-processing-time order), so that the stragglers are the short ones */
+        if (sc.team == 1 && n_pairs > c->n_cu && std::getenv("DVO_NO_LPT") == nullptr) {
+            std::vector<std::pair<long long, int>> work((size_t)n_pairs);
+            for (int p = 0; p < n_pairs; p++) {
+                long long w = 0;
+                for (int l = 0; l < n_levels; l++) w += (long long)sc.iters[l] * c->lv[l].hN[first_pair + p];
+                work[p] = {-w, p};
+            }
+            std::sort(work.begin(), work.end());
+            std::vector<int> order((size_t)n_pairs);
+            for (int p = 0; p < n_pairs; p++) order[p] = work[p].second;
+            if ((size_t)n_pairs > c->order_cap) {
+                if (c->d_order) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->d_order)); c->d_order = nullptr; c->order_cap = 0; }
+                HIPCHK(c, hipMalloc((void **)&c->d_order, sizeof(int) * (size_t)c->n_pairs));
+                c->order_cap = (size_t)c->n_pairs;
+            }
+            if (order != c->h_order) {           /* unchanged between launches of a resident batch: upload once */
+                c->h_order = order;
+                HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order.data(), sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
+            }
+            o.order = c->d_order;
+        }
+        HIPCHK(c, launch_align_fused2(block, ls, sc, c->K, c->dprm, o, first_pair, n_pairs, c->stream));
+    }
     else
         HIPCHK(c, launch_align_fused(block, u, ls, sc, c->K, c->dprm, outputs_of(c),
                                      first_pair, n_pairs, c->stream));
@@ -500,6 +526,7 @@ int dvo_destroy(dvo_ctx *c) {
         if (c->lv[l].p4) { (void)hipFree(c->lv[l].p4); (void)hipFree(c->lv[l].pal); (void)hipFree(c->lv[l].d_pal_n); }
     }
     if (c->pal_work) (void)hipFree(c->pal_work);
+    if (c->d_order) (void)hipFree(c->d_order);
     tiled_forget(c);
     photo_forget(c);
     for (int l = 0; l < DVO_LEVELS; l++) {

@@ -107,6 +107,9 @@ struct dvo_ctx {
     int iter_energy_cap = 0;
     std::vector<int> iter_max;      /* per pair: max_iters of the running dvo_iter_begin (0 = none) */
     int *d_colcounts = nullptr;
+    int *d_order = nullptr;         /* launch order of the pairs of a large batch (longest first) */
+    size_t order_cap = 0;
+    std::vector<int> h_order;
     unsigned *pal_work = nullptr;   /* scratch of the compact-now-form builder (dvo_palette.hip) */
     size_t pal_work_ints = 0;
     size_t colcounts_cap = 0;

@@ -458,6 +458,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         pair_local = q * 8 + x;
         if (pair_local >= sc.n_pairs_launch) return;
     }
+    if (!TEAM && out.order) pair_local = out.order[pair_local];      /* longest pairs first: the launch ends with the short ones */
     const int pair = first_pair + pair_local;
     const int tid = threadIdx.x;
     unsigned epoch = 0;                          /* exchanges done so far (team mode) */

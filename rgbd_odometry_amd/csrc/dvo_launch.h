@@ -76,6 +76,7 @@ struct Outputs {
     unsigned *team_cnt;      /* (unused by the kernel; the int after n_pairs entries is the error flag) */
     int *team_err;           /* set to 1 by a member that gave up waiting (members not co-resident) */
     int *tex_mode;           /* n_pairs x DVO_LEVELS: where the fused kernel read the now level from (DVO_TEXMODE_*), inspection */
+    const int *order;        /* launch order of the pairs (longest first): workgroup b aligns pair first_pair + order[b]; NULL = b */
 };
 
 hipError_t launch_pack_texels(const float *dt, const float *gx, const float *gy, float4 *out,

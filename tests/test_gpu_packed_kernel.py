@@ -247,3 +247,31 @@ def test_team_size_that_cannot_be_resident_is_refused():
             _load(ctx, sc, pair=p)
         with pytest.raises(DvoError):
             ctx.align_batch([2, 2], np.tile(np.eye(3), (64, 1, 1)), np.zeros((64, 3)))
+
+
+def test_large_batch_launch_order(oracle):
+    """more pairs than compute units: the engine starts the pairs with the most point-iterations first (longest-processing-time
+    order, csrc/dvo_capi.cpp) -- a pure permutation of which workgroup aligns which pair: every pair still gets the result of
+    ITS scene, with and without the compact now form"""
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    n = 300
+    scenes = [SynthScene(160, 120, 2, 40 + i) for i in range(5)]             # different point counts
+    iters = [6, 6]
+    refs = [oracle.align_pyramid(iters, oracle_lib.scene_levels(s, oracle), s.intrinsics, np.eye(3), np.zeros(3)) for s in scenes]
+    assert len({len(r["levels"][0]["final_eps"]) for r in refs}) > 1
+    with DvoContext(n) as ctx:
+        ctx.set_intrinsics(*scenes[0].intrinsics)
+        for p, sc in enumerate(scenes):
+            _load(ctx, sc, pair=p)
+        ctx.replicate_pairs(5)
+        for prepared in (False, True):
+            if prepared:
+                ctx.now_prepare()
+            R, t = ctx.align_batch(iters, np.tile(np.eye(3), (n, 1, 1)), np.zeros((n, 3)))
+            assert ctx.last_launch_shape()[1] == 1                            # no team: one workgroup per pair
+            for p in range(n):
+                ref = refs[p % 5]
+                for l, rep in ref["levels"].items():
+                    e, b, ratio = ctx.level_report(p, l, iters[l])
+                    assert np.array_equal(e, rep["energy"]) and b == rep["best_idx"] and ratio == rep["visible_ratio"], (prepared, p, l)
+                assert rot_angle(ref["R"], R[p]) <= ROT_TOL and np.linalg.norm(ref["t"] - t[p]) <= TRANS_TOL, (prepared, p)
