@@ -8,11 +8,18 @@
  * anything else (caller-supplied 3xN float lists, the optional interpolate() lookup) runs align_fused_kernel of
  * dvo_kernels.hip.  Same results bit for bit -- tests/test_gpu_parity.py runs both against the oracle.
  *
- * Per level: the compact points {xx | yy << 16, Z} are staged once into LDS; per iteration a lane takes points
- * i and i + BLOCK of every round of 2*BLOCK points, rebuilds X, Y (:249-250), warps and projects both (:328-345),
- * gathers their two 16-byte texels {DT, gx, gy, w} (issued one round ahead of the arithmetic that consumes them),
- * forms the weighted Jacobian rows (:379-406, :716) and accumulates g = J^T W eps (:777) and sum eps^2 (:1312) in double.
- * Reduction, update and bookkeeping as in dvo_kernels.hip.
+ * Per level: the compact points {xx | yy << 16, Z} are staged once into LDS (those beyond the LDS budget are streamed, fetched
+ * one round ahead); per iteration a lane takes points i and i + BLOCK of every round of 2*BLOCK points, rebuilds X, Y
+ * (:249-250), warps and projects both (:328-345), looks up {DT, gx, gy, w} of the two pixels they fall on, forms the weighted
+ * Jacobian rows (:379-406, :716) and accumulates g = J^T W eps (:777) and sum eps^2 (:1312) in double.  The look-up has
+ * three forms, chosen per level and pair (TexSrc below): a 16-byte texel gathered from HBM / L2, the same texel from an LDS copy
+ * of the whole level, or -- the throughput form -- ONE 12-byte gather of rank words from the level's compact form
+ * (dvo_palette.h: 24 pixels per 128-byte line instead of 8) followed by five palette look-ups in LDS.  Gathers are issued one
+ * or two rounds ahead of the arithmetic that consumes them.  Reduction, update and bookkeeping as in dvo_kernels.hip.
+ *
+ * Launch shapes (chosen by the host, dvo_capi.cpp): two 256-thread workgroups per CU for large batches with a compact form,
+ * one 512-thread workgroup per CU otherwise, teams of 2..32 workgroups of one XCD per pair for small batches, teams of
+ * 64 / 128 / 256 workgroups over all XCDs for one very large frame.
  *
  * Compile with -ffp-contract=off.
  */
