@@ -361,6 +361,38 @@ def main():
                 "energies_bit_equal": bit_equal, "tolerance": "1e-5 rad / 1e-4 m; energies, best index, visible ratio bit-equal",
                 "pass": bool(bit_equal and worst_r <= 1e-5 and worst_t <= 1e-4),
             }
+        # transparency: the same batch with the now levels as plain 16-byte texels (no compact form), measured in this run too --
+        # never `value`; default launch only (extra ~2 s)
+        default_launch = not (args.team or args.normal_matrix or args.variant or args.block or args.inflight or args.lds_point_bytes
+                              or args.debug_alias or args.no_prepare or total_pairs)
+        if world == 1 and default_launch and not args.no_frames_leg:
+            try:
+                ctx.close()
+                ctx = DvoContext(args.batch, engine_variant=4)
+                saved = args.no_prepare
+                args.no_prepare = True
+                build_batch(ctx, args, rank)
+                args.no_prepare = saved
+                ctx.set_stream(stream.cuda_stream)
+                n2 = max(5, args.steps // 2)
+                for _ in range(2):
+                    step()
+                ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n2)]
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for k in range(n2):
+                    step(ev2[k])
+                torch.cuda.synchronize()
+                el2 = time.perf_counter() - t0
+                k2 = float(np.mean([a.elapsed_time(b) for a, b in ev2]))
+                out["without_compact_now_form"] = {
+                    "value": args.batch * n2 / el2, "unit": "aligns/s", "steps": n2, "kernel_ms": k2,
+                    "roofline_frac": bytes_per_launch / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "note": "same batch, now levels read as 16-byte texels {DT, gx, gy, w} (dvo_params.engine_variant = 4): what a "
+                            "now level costs that is aligned once; the compact form is a verified-lossless representation of the "
+                            "resident inputs built at set-up (config.now_prepare_ms)"}
+            except Exception as e:
+                out["without_compact_now_form"] = {"error": repr(e)}
         if world == 1 and not args.no_frames_leg:
             ctx.close()                                  # release the resident batch before the extra leg
             try:
