@@ -393,24 +393,29 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         Outputs o = outputs_of(c);
         /* a launch of more pairs than fit the GPU at once ends when its last workgroup ends: start the pairs with the most
          * point-iterations first (longest-processing-time order), so that the stragglers are the short ones */
-        if (sc.team == 1 && n_pairs > c->n_cu && std::getenv("DVO_NO_LPT") == nullptr) {
-            std::vector<std::pair<long long, int>> work((size_t)n_pairs);
-            for (int p = 0; p < n_pairs; p++) {
-                long long w = 0;
-                for (int l = 0; l < n_levels; l++) w += (long long)sc.iters[l] * c->lv[l].hN[first_pair + p];
-                work[p] = {-w, p};
-            }
-            std::sort(work.begin(), work.end());
-            std::vector<int> order((size_t)n_pairs);
-            for (int p = 0; p < n_pairs; p++) order[p] = work[p].second;
-            if ((size_t)n_pairs > c->order_cap) {
-                if (c->d_order) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->d_order)); c->d_order = nullptr; c->order_cap = 0; }
-                HIPCHK(c, hipMalloc((void **)&c->d_order, sizeof(int) * (size_t)c->n_pairs));
-                c->order_cap = (size_t)c->n_pairs;
-            }
-            if (order != c->h_order) {           /* unchanged between launches of a resident batch: upload once */
-                c->h_order = order;
+        static const bool no_lpt = std::getenv("DVO_NO_LPT") != nullptr;
+        if (sc.team == 1 && n_pairs > c->n_cu && !no_lpt) {
+            unsigned long long sched_hash = 1469598103934665603ull;
+            for (int l = 0; l < n_levels; l++) sched_hash = (sched_hash ^ (unsigned long long)(unsigned)sc.iters[l]) * 1099511628211ull;
+            const unsigned long long key[4] = {c->points_gen, (unsigned long long)first_pair, (unsigned long long)n_pairs, sched_hash};
+            if (!c->d_order || std::memcmp(key, c->order_key, sizeof(key)) != 0) {      /* a resident batch: made and uploaded once */
+                std::vector<std::pair<long long, int>> work((size_t)n_pairs);
+                for (int p = 0; p < n_pairs; p++) {
+                    long long w = 0;
+                    for (int l = 0; l < n_levels; l++) w += (long long)sc.iters[l] * c->lv[l].hN[first_pair + p];
+                    work[p] = {-w, p};
+                }
+                std::sort(work.begin(), work.end());
+                c->h_order.resize((size_t)n_pairs);
+                for (int p = 0; p < n_pairs; p++) c->h_order[p] = work[p].second;
+                if ((size_t)n_pairs > c->order_cap) {
+                    if (c->d_order) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->d_order)); c->d_order = nullptr; c->order_cap = 0; }
+                    HIPCHK(c, hipMalloc((void **)&c->d_order, sizeof(int) * (size_t)c->n_pairs));
+                    c->order_cap = (size_t)c->n_pairs;
+                }
+                HIPCHK(c, hipStreamSynchronize(c->stream));          /* an earlier launch may still read the old order */
                 HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order.data(), sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
+                std::memcpy(c->order_key, key, sizeof(key));
             }
             o.order = c->d_order;
         }
@@ -606,6 +611,7 @@ static int set_ref_common(dvo_ctx *c, int pair, int level, const float *xyz, int
     HIPCHK(c, hipMemcpyAsync(dst, xyz, sizeof(float) * 3 * (size_t)N,
                              device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     L.hN[pair] = N;
+    c->points_gen++;
     L.compact_ok[pair] = 0;                                         /* arbitrary X, Y: no 8-byte form */
     HIPCHK(c, hipMemcpyAsync(L.dN + pair, &L.hN[pair], sizeof(int), hipMemcpyHostToDevice, c->stream));
     if (!device_src) HIPCHK(c, hipStreamSynchronize(c->stream));   /* host buffer is only borrowed */
@@ -661,6 +667,7 @@ int dvo_set_ref_level_from_images(dvo_ctx *c, int pair, int level, const int32_t
                                   L.cpts + (size_t)pair * L.pt_cap, d_uv, N, nullptr, c->stream));
     L.compact_ok[pair] = 1;
     L.hN[pair] = N;
+    c->points_gen++;
     HIPCHK(c, hipMemcpyAsync(L.dN + pair, &L.hN[pair], sizeof(int), hipMemcpyHostToDevice, c->stream));
     const int ncopy = std::min(N, capacity);
     if (xyz_out && ncopy > 0)
@@ -782,6 +789,7 @@ int dvo_replicate_pairs(dvo_ctx *c, int n_src, int dst_first, int dst_count) {
         HIPCHK(c, launch_replicate_level(L.tex, L.tex_stride, L.pts, L.cpts, L.pt_cap, L.dN, n_src, dst_first, dst_count, c->stream));
         for (int p = dst_first; p < dst_first + dst_count; p++) {
             L.hN[p] = L.hN[(p - dst_first) % n_src];
+            c->points_gen++;
             L.compact_ok[p] = L.compact_ok[(p - dst_first) % n_src];
         }
         if (L.tex && dst_count > 0) { int rc = now_written(c, l, dst_first, dst_count); if (rc) return rc; }

@@ -110,6 +110,8 @@ struct dvo_ctx {
     int *d_order = nullptr;         /* launch order of the pairs of a large batch (longest first) */
     size_t order_cap = 0;
     std::vector<int> h_order;
+    unsigned long long points_gen = 1;   /* bumped whenever a reference list changes (its length is the launch-order key) */
+    unsigned long long order_key[4] = {0, 0, 0, 0};   /* points_gen, first_pair, n_pairs, hash of the schedule the resident order was made for */
     unsigned *pal_work = nullptr;   /* scratch of the compact-now-form builder (dvo_palette.hip) */
     size_t pal_work_ints = 0;
     size_t colcounts_cap = 0;
