@@ -39,6 +39,13 @@
 
 namespace dvo {
 
+/* the constant 100 MHz counter: one time base for the whole device (s_memtime counts per XCD) */
+DVO_DEV unsigned long long stamp_real() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+
 /* per-lane sums of one iteration (the sub-gradient policy of :724-920 needs g and the energy only) */
 struct Acc7 {
     double g[6];
@@ -481,6 +488,9 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];   /* sc.lds_bytes: per level [palette |] points [| the now level, when it fits] */
     const bool pal_base_ok = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds_dyn == kStatic;
 
+#ifdef DVO_STAMPS
+    if (tid == 0 && out.dbg) out.dbg[(size_t)pair * 64 + 62] = stamp_real();      /* workgroup start (launch timeline, tools/exp_timeline.py) */
+#endif
     if (tid == 0) {
         const double *p = out.poses + (size_t)pair * 12;
         const bool ident = (sc.flags & 2) != 0;                  /* DVO_FLAG_IDENTITY_START (:2210-2211) */
@@ -581,6 +591,20 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         DVO_STAMP_ADD(5, ts0, ts1);
 
         for (int itr = 0; itr < iters; ++itr) {                              /* :658 */
+            /* Instruction-issue priority falls with progress.  Two workgroups share a CU; the hardware favours the older
+             * one, so of two that start together one ends ~100 us before the other, which then finishes alone on a half-empty
+             * CU (launch timeline, tools/exp_timeline.py: the last 15 % of a 1024-pair launch ran with 256 of 512 slots busy).
+             * With the one that is BEHIND getting the issue slots they finish together: workgroup durations 719 +- 69 us ->
+             * 765 +- 29 us, slots busy until the end; C2 654 k -> 665 k aligns/s, without misses 733 k -> 769 k.
+             * (make EXP=noprio EXPDEFS=-DDVO_NO_PROGRESS_PRIO=1 for the A/B.) */
+#ifndef DVO_NO_PROGRESS_PRIO
+            if (!TEAM) {
+                if (l > 0) __builtin_amdgcn_s_setprio(3);
+                else if (2 * itr < iters) __builtin_amdgcn_s_setprio(2);
+                else if (4 * itr < 3 * iters) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+#endif
 #pragma unroll
             for (int k = 0; k < 9; k++) c.r[k] = uniform_f(st.Rf[k]);        /* :673 */
 #pragma unroll
@@ -701,6 +725,9 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         __syncthreads();
     }
 
+#ifdef DVO_STAMPS
+    if (tid == 0 && out.dbg) out.dbg[(size_t)pair * 64 + 63] = stamp_real();      /* workgroup end */
+#endif
     if (tid == 0 && member == 0) {
         double *p = out.poses + (size_t)pair * 12;
 #pragma unroll
