@@ -347,10 +347,17 @@ DVO_DEV void block_reduce7(const Acc7 &a, double (*red)[8], double *tot) {
     for (int k = 0; k < 6; k++) d[k] = a.g[k];
     d[6] = a.e2;
     d[7] = 0.0;
+#ifndef DVO_NO_DPP_REDUCE
+    wave_reduce_scatter8_dpp(d);
+    const int idx = reduce_scatter8_dpp_index(lane);
+    if (lane < 8 && idx < 7) red[wave][idx] = d[0];
+    if (lane == 8) red[wave][7] = (double)a.nvis;
+#else
     wave_reduce_scatter<double, 8>(d);
     const int idx = lane >> 3;
     if ((lane & 7) == 0 && idx < 7) red[wave][idx] = d[0];
     if (lane == 1) red[wave][7] = (double)a.nvis;
+#endif
     __syncthreads();
     if (threadIdx.x < 8) {
         double s = 0.0;

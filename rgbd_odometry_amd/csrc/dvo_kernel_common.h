@@ -107,6 +107,66 @@ DVO_DEV void wave_reduce_scatter(T (&v)[NV]) {
     ReduceScatterStep<T, NV, NV / 2, 32>::run(v, threadIdx.x & 63);   /* all indices are compile-time */
 }
 
+/* The same reduce-scatter for exactly 8 doubles with the NEAR lane exchanges done by DPP (data-parallel-primitive operand
+ * modifiers: a register move with a lane permutation, a few cycles) instead of ds_bpermute (a round trip through the LDS
+ * crossbar, ~100 cycles each, twenty of them in a row in wave_reduce_scatter<double, 8>): bits 1, 2, 4 scatter the 8 values
+ * (4 + 2 + 1 doubles exchanged), bit 8 folds by DPP too, only bits 16 and 32 go through the crossbar (one double each).
+ * On return lane L holds, in v[0], the wave total of value index  4*(L&1) + 2*((L>>1)&1) + ((L>>2)&1).  Fixed shape:
+ * deterministic. */
+#define DVO_DPP_QUAD_XOR1 0xB1      /* quad_perm [1,0,3,2] */
+#define DVO_DPP_QUAD_XOR2 0x4E      /* quad_perm [2,3,0,1] */
+#define DVO_DPP_ROW_SHL(n) (0x100 + (n))   /* lane i <- lane i+n of its row of 16 */
+#define DVO_DPP_ROW_SHR(n) (0x110 + (n))   /* lane i <- lane i-n */
+template <int CTRL>
+DVO_DEV double dpp_quad(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+/* partner lane L ^ N for N = 4 or 8: lanes whose bit N is clear read lane L+N (row_shl), the others lane L-N (row_shr);
+ * the bank mask (banks = groups of 4 lanes of a row) picks which lanes each of the two moves writes */
+template <int N>
+DVO_DEV double dpp_xor_row(double x) {
+    static_assert(N == 4 || N == 8, "row-local partner");
+    constexpr int LOW = (N == 4) ? 0x5 : 0x3, HIGH = (N == 4) ? 0xA : 0xC;
+    const long long b = __double_as_longlong(x);
+    int lo = __builtin_amdgcn_update_dpp(0, (int)b, DVO_DPP_ROW_SHL(N), 0xF, LOW, false);
+    lo = __builtin_amdgcn_update_dpp(lo, (int)b, DVO_DPP_ROW_SHR(N), 0xF, HIGH, false);
+    int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), DVO_DPP_ROW_SHL(N), 0xF, LOW, false);
+    hi = __builtin_amdgcn_update_dpp(hi, (int)(b >> 32), DVO_DPP_ROW_SHR(N), 0xF, HIGH, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+DVO_DEV void wave_reduce_scatter8_dpp(double (&v)[8]) {
+    const int lane = threadIdx.x & 63;
+    {   /* bit 1: 8 -> 4 values */
+        const bool up = (lane & 1) != 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const double keep = up ? v[j + 4] : v[j], send = up ? v[j] : v[j + 4];
+            v[j] = keep + dpp_quad<DVO_DPP_QUAD_XOR1>(send);
+        }
+    }
+    {   /* bit 2: 4 -> 2 */
+        const bool up = (lane & 2) != 0;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const double keep = up ? v[j + 2] : v[j], send = up ? v[j] : v[j + 2];
+            v[j] = keep + dpp_quad<DVO_DPP_QUAD_XOR2>(send);
+        }
+    }
+    {   /* bit 4: 2 -> 1 */
+        const bool up = (lane & 4) != 0;
+        const double keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+        v[0] = keep + dpp_xor_row<4>(send);
+    }
+    v[0] += dpp_xor_row<8>(v[0]);
+    v[0] += __shfl_xor(v[0], 16, 64);
+    v[0] += __shfl_xor(v[0], 32, 64);
+}
+/* value index held by lane L after wave_reduce_scatter8_dpp */
+DVO_DEV int reduce_scatter8_dpp_index(int lane) { return 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1); }
+
 /* Fixed-shape reduction of the 29 accumulators over a workgroup.
  * Result in tot[0..28] (valid after the trailing barrier). */
 template <int BLOCK, bool WITH_H>
