@@ -228,14 +228,15 @@ int  dvo_iter_end(dvo_ctx *ctx, int pair, int level, double *R, double *t, float
 
 /* The same loop for ONE GPU, enqueued from C: the level schedule of SolveDVO::loop with every iteration
  * spread over all CUs (frames whose point lists are too long for one workgroup).  Synchronous; per-level
- * energies / best index / ratio afterwards through dvo_get_level_report. */
-int  dvo_align_pyramid_wide(dvo_ctx *ctx, int pair, int n_levels, const int *iters, double *R, double *t);
+ * energies / best index / ratio afterwards through dvo_get_level_report.  flags: 0 or DVO_FLAG_FINAL_OUTPUTS
+ * (finalEpsilons / finalReprojections of the last level, SolveDVO.cpp:703-704, :1002-1003 -> dvo_get_final_outputs). */
+int  dvo_align_pyramid_wide(dvo_ctx *ctx, int pair, int n_levels, const int *iters, int flags, double *R, double *t);
 
 /* ---- tiled mode from C: one large frame sharded over the GPUs of a node (BASELINE configs[4]) ----------
  * The same loop with the all-reduce done by RCCL over xGMI and everything enqueued from C on the context stream -- what a
  * C++ node calls (one process or thread per GPU, each with its own context and its rank's ncclComm_t):
  *     dvo_tiled_attach(ctx, comm, rank, world, NULL);           once
- *     dvo_align_pyramid_tiled(ctx, 0, n_levels, iters, R, t);   per frame pair; every rank gets the same pose
+ *     dvo_align_pyramid_tiled(ctx, 0, n_levels, iters, flags, R, t);   per frame pair; every rank gets the same pose
  * Each rank must hold the SAME inputs for `pair` (full reference lists and now pyramid); rank r processes the contiguous
  * index range r of every level's list, the 32 sums are all-reduced (ncclDouble, ncclSum) per iteration, and every rank
  * executes the identical update.  nccl_comm: the caller's ncclComm_t.  rccl_library: path of the RCCL library the
@@ -244,7 +245,15 @@ int  dvo_align_pyramid_wide(dvo_ctx *ctx, int pair, int n_levels, const int *ite
  * or does not finish fast enough (break-even: DESIGN.md section 5). */
 int  dvo_tiled_attach(dvo_ctx *ctx, void *nccl_comm, int rank, int world, const char *rccl_library);
 int  dvo_tiled_detach(dvo_ctx *ctx);
-int  dvo_align_pyramid_tiled(dvo_ctx *ctx, int pair, int n_levels, const int *iters, double *R, double *t);
+/* flags: 0 or DVO_FLAG_FINAL_OUTPUTS.  With it every rank computes finalEpsilons / finalReprojections (SolveDVO.cpp:703-704,
+ * :1002-1003) of ITS shard of the last level's list, at the points' own indices: dvo_get_final_outputs then returns arrays in
+ * which only [first, first + count) of dvo_tiled_shard is filled in on this rank -- the caller concatenates the shards
+ * (SURVEY.md 8e).  Thread safety: contexts of different GPUs may be driven from different host threads of one process
+ * (each entry point makes the context's device current; the attachment registry is locked); one context is still
+ * one-thread-at-a-time. */
+int  dvo_align_pyramid_tiled(dvo_ctx *ctx, int pair, int n_levels, const int *iters, int flags, double *R, double *t);
+/* the contiguous index range of `level`'s reference list this rank works on */
+int  dvo_tiled_shard(dvo_ctx *ctx, int pair, int level, int *first, int *count);
 
 /* ---- inspection (used by the parity tests) ---------------------------------
  * One evaluation of computeJacobianOfNowFrame + getReprojectedEpsilons at the
@@ -267,6 +276,9 @@ int  dvo_device_rotationize(dvo_ctx *ctx, double *R);
  * tiles": the reference re-copies the three images every iteration, SolveDVO.cpp:310,316-317,427) -- taken when the whole
  * level fits beside its point list; 2 = the level's compact form (below); -1 = not run.  Inspection / tests. */
 int  dvo_get_level_texel_mode(dvo_ctx *ctx, int pair, int level, int *mode);
+/* *ran = 1 if, at that level of that launch, a wave of the packed kernel took its literal-division fallback (a reference point
+ * whose reprojected z left the range the fast reciprocal is proven exact on, or dvo_params.engine_variant = 3).  Tests. */
+int  dvo_get_level_exact_fallback(dvo_ctx *ctx, int pair, int level, int *ran);
 
 /* Shape the engine chose for the last fused (batch) launch: threads per workgroup (256: two workgroups per compute unit,
  * 512 / 1024: one), workgroups per frame pair (team mode, 1 = none), packed = 1: the two-points-per-lane kernel.  Inspection. */
@@ -275,20 +287,27 @@ int  dvo_get_last_launch_shape(dvo_ctx *ctx, int *block_threads, int *team_size,
 /* Compact form of resident now levels (engine detail, results are bit-identical with or without it).  The three images the
  * reference keeps per now level (dist transform :1768-1795, its imageGradient :1063-1098; the weight :1047-1053 is a function
  * of the first) are redundant: a pixel is described by the rank of its distance value among the image's distinct values and
- * the ranks of its four neighbours.  The engine derives a 4-byte-per-pixel form from that (24 pixels per 128-byte memory
- * line instead of 8 -> half the memory requests of the alignment kernel), VERIFIES per pixel that it reproduces the resident
- * {DT, gx, gy, w} bit for bit, and otherwise keeps reading the 16-byte form for that pair and level (caller-supplied
- * gradients that are not imageGradient(DT), more than 4095 distinct values, ...).  Building it reads the level twice and costs
- * about four and a half alignments of the same pair (measured, 640x480x4: 7.0 us per pair against 1.6 us per alignment; an
- * alignment then saves ~0.45 us: break-even at the 16th), so the engine builds it by itself only for a now level that has already been aligned
- * DVO_COMPACT_NOW_AFTER times (a tracker's now frame is aligned once or twice and never pays for it); dvo_now_prepare
- * builds it now for every resident now level of the given pairs (batch / benchmark set-up: "inputs resident").
- * dvo_params.engine_variant = 4 disables it. */
+ * the ranks of its four neighbours -- 4 bytes per pixel, 24 pixels per 128-byte memory line instead of 8: half the memory
+ * requests of the alignment kernel.
+ *   NATIVE (round 3): a now level produced by the engine's own distance transform (dvo_set_now_level_from_edges,
+ *     dvo_frames_as_now, the now_first_pair argument of the upload calls) is written in this form and in no other: the integer
+ *     squared distances are ranked through a presence bitmap (no hashing, sorting or verification pass), the 16-byte texels are
+ *     never written (17 instead of 45 bytes of HBM traffic per pixel) and are decoded on demand for the entry points that read
+ *     them (dvo_get_now_level, dvo_eval_points, the host-driven / tiled iteration).  Images the form cannot hold (more than
+ *     8191 distinct distances, a pixel further than 511 pixels from every edge, a rank step beyond +-127) get 16-byte texels
+ *     from the same launch instead.
+ *   GENERIC: for caller-supplied float images (dvo_set_now_level) the engine derives the form from the 16-byte texels and
+ *     VERIFIES per pixel that it reproduces {DT, gx, gy, w} bit for bit, keeping the 16-byte form for that pair and level
+ *     otherwise (gradients that are not imageGradient(DT), more than 4095 distinct values, ...).  That build reads the level
+ *     twice and costs about four and a half alignments of the same pair, so the engine makes it by itself only for a now level
+ *     that has already been aligned DVO_COMPACT_NOW_AFTER times; dvo_now_prepare builds it now for the given pairs.
+ * dvo_params.engine_variant = 4 (or DVO_COMPACT_NOW=off in the environment) disables both: 16-byte texels everywhere. */
 #define DVO_COMPACT_NOW_AFTER 16
 int  dvo_now_prepare(dvo_ctx *ctx, int first_pair, int count);
 /* palette_size: > 0 number of distinct distance values of the compact form, 0 not built (yet / stale),
- * < 0 no compact form: -1 negative/inf/nan value, -2 more than 4096 distinct values, -3 rank step beyond +-127,
- * -4 gradient is not imageGradient(DT), -5 weight is not getWeightOf(DT), -6 image narrower than 2 pixels */
+ * < 0 no compact form: -1 negative/inf/nan value, -2 too many distinct values (native 8191, generic 4095), -3 rank step beyond
+ * +-127, -4 gradient is not imageGradient(DT), -5 weight is not getWeightOf(DT), -6 image narrower than 2 pixels, -7 a pixel
+ * further than 511 pixels from every edge (native builder) */
 int  dvo_get_now_compact_info(dvo_ctx *ctx, int pair, int level, int *palette_size);
 
 /* Diagnostic builds only (make STAMPS=1): per-level phase cycle counters of `pair`,

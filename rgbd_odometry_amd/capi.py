@@ -30,8 +30,8 @@ C_ABI_SYMBOLS = [
     "dvo_set_poses", "dvo_align_batch_enqueue", "dvo_get_poses", "dvo_get_level_report",
     "dvo_get_final_outputs", "dvo_get_level_normal_matrix", "dvo_eval_points", "dvo_accumulate", "dvo_device_se3_exp",
     "dvo_device_se3_log", "dvo_device_rotationize", "dvo_algorithmic_bytes", "dvo_point_iterations",
-    "dvo_debug_stamps", "dvo_get_level_texel_mode", "dvo_now_prepare", "dvo_get_now_compact_info", "dvo_get_last_launch_shape", "dvo_replicate_pairs", "dvo_set_now_level_from_edges", "dvo_get_now_level", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
-    "dvo_align_pyramid_wide", "dvo_tiled_attach", "dvo_tiled_detach", "dvo_align_pyramid_tiled",
+    "dvo_debug_stamps", "dvo_get_level_texel_mode", "dvo_get_level_exact_fallback", "dvo_now_prepare", "dvo_get_now_compact_info", "dvo_get_last_launch_shape", "dvo_replicate_pairs", "dvo_set_now_level_from_edges", "dvo_get_now_level", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
+    "dvo_align_pyramid_wide", "dvo_tiled_attach", "dvo_tiled_detach", "dvo_align_pyramid_tiled", "dvo_tiled_shard",
     "dvo_get_ref_level", "dvo_frames_reserve", "dvo_frames_upload_pyramids", "dvo_frames_upload_cameras", "dvo_frames_set_undistort",
     "dvo_photo_params_default", "dvo_photo_configure", "dvo_photo_set_ref", "dvo_photo_align", "dvo_photo_get_jacobian", "dvo_frames_as_now",
     "dvo_frames_as_ref", "dvo_frame_get_level", "dvo_frames_num_levels",
@@ -200,6 +200,7 @@ def load_library() -> C.CDLL:
         "dvo_device_rotationize": [vp, vp],
         "dvo_debug_stamps": [vp, i, vp],
         "dvo_get_level_texel_mode": [vp, i, i, ip],
+        "dvo_get_level_exact_fallback": [vp, i, i, ip],
         "dvo_now_prepare": [vp, i, i],
         "dvo_get_last_launch_shape": [vp, ip, ip, ip],
         "dvo_get_now_compact_info": [vp, i, i, ip],
@@ -210,7 +211,7 @@ def load_library() -> C.CDLL:
         "dvo_iter_accumulate": [vp, i, i, i, i, vp],
         "dvo_iter_update": [vp, i, i, i, i, vp],
         "dvo_iter_end": [vp, i, i, vp, vp, vp, ip, fp],
-        "dvo_align_pyramid_wide": [vp, i, i, ip, vp, vp],
+        "dvo_align_pyramid_wide": [vp, i, i, ip, i, vp, vp],
         "dvo_frames_set_undistort": [vp, i, i, vp, vp],
         "dvo_photo_params_default": [C.POINTER(DvoPhotoParams)],
         "dvo_photo_configure": [vp, C.POINTER(DvoPhotoParams)],
@@ -219,7 +220,8 @@ def load_library() -> C.CDLL:
         "dvo_photo_get_jacobian": [vp, i, vp, vp, vp, i, vp, ip],
         "dvo_tiled_attach": [vp, vp, i, i, C.c_char_p],
         "dvo_tiled_detach": [vp],
-        "dvo_align_pyramid_tiled": [vp, i, i, ip, vp, vp],
+        "dvo_align_pyramid_tiled": [vp, i, i, ip, i, vp, vp],
+        "dvo_tiled_shard": [vp, i, i, ip, ip],
         "dvo_get_ref_level": [vp, i, i, vp, i, ip],
         "dvo_frames_reserve": [vp, i],
         "dvo_frames_upload_pyramids": [vp, i, i, i, C.POINTER(DvoImage), C.POINTER(DvoImage), i, i],
@@ -549,11 +551,11 @@ class DvoContext:
                                         C.byref(ratio)))
         return dict(R=R, t=t, energy=energy, best_idx=best.value, visible_ratio=ratio.value)
 
-    def align_pyramid_wide(self, iters: Sequence[int], R, t, pair: int = 0):
+    def align_pyramid_wide(self, iters: Sequence[int], R, t, pair: int = 0, flags: int = 0):
         """level schedule with every iteration spread over all CUs (large single frames), driven from C"""
         R = np.array(R, dtype=np.float64, order="F").copy(order="F")
         t = np.array(t, dtype=np.float64).copy()
-        self._chk(self.lib.dvo_align_pyramid_wide(self._h, pair, len(iters), _iters(iters), _ptr(R), _ptr(t)))
+        self._chk(self.lib.dvo_align_pyramid_wide(self._h, pair, len(iters), _iters(iters), flags, _ptr(R), _ptr(t)))
         return R, t
 
     def frames_set_undistort(self, rows: int, cols: int, K4=None, D5=None):
@@ -604,12 +606,18 @@ class DvoContext:
     def tiled_detach(self):
         self._chk(self.lib.dvo_tiled_detach(self._h))
 
-    def align_pyramid_tiled(self, iters: Sequence[int], R, t, pair: int = 0):
+    def align_pyramid_tiled(self, iters: Sequence[int], R, t, pair: int = 0, flags: int = 0):
         """dvo_align_pyramid_tiled: this rank's share of every iteration + ncclAllReduce of the 32 sums + identical update"""
         R = np.array(R, dtype=np.float64, order="F").copy(order="F")
         t = np.array(t, dtype=np.float64).copy()
-        self._chk(self.lib.dvo_align_pyramid_tiled(self._h, pair, len(iters), _iters(iters), _ptr(R), _ptr(t)))
+        self._chk(self.lib.dvo_align_pyramid_tiled(self._h, pair, len(iters), _iters(iters), flags, _ptr(R), _ptr(t)))
         return R, t
+
+    def tiled_shard(self, level: int, pair: int = 0):
+        """(first, count): the index range of `level`'s reference list this rank works on"""
+        f, n = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.dvo_tiled_shard(self._h, pair, level, C.byref(f), C.byref(n)))
+        return f.value, n.value
 
     # -- inspection -----------------------------------------------------------
     def eval_points(self, level: int, R, t, pair: int = 0):
@@ -660,10 +668,16 @@ class DvoContext:
         return H.reshape(6, 6)
 
     def level_texel_mode(self, pair: int, level: int) -> int:
-        """0 = 16-byte texels gathered from HBM/L2, 1 = the level's texels staged in LDS, -1 = not run"""
+        """0 = 16-byte texels gathered from HBM/L2, 1 = the level's texels staged in LDS, 2 = the compact form, -1 = not run"""
         m = C.c_int(-2)
         self._chk(self.lib.dvo_get_level_texel_mode(self._h, pair, level, C.byref(m)))
         return m.value
+
+    def level_exact_fallback(self, pair: int, level: int) -> bool:
+        """True if a wave of the packed kernel took its literal-division fallback at that level of the last launch"""
+        m = C.c_int(0)
+        self._chk(self.lib.dvo_get_level_exact_fallback(self._h, pair, level, C.byref(m)))
+        return bool(m.value)
 
     def last_launch_shape(self):
         """(threads per workgroup, workgroups per pair, packed kernel?) of the last fused launch"""

@@ -89,7 +89,7 @@ int ensure_texels(dvo_ctx *c, int level, int rows, int cols) {
         L.tex = nullptr;
         std::fill(L.have_now.begin(), L.have_now.end(), 0);
         if (L.p4) { (void)hipFree(L.p4); (void)hipFree(L.pal); (void)hipFree(L.d_pal_n); L.p4 = nullptr; L.pal = nullptr; L.d_pal_n = nullptr; }
-        L.pal_built.clear(); L.now_uses.clear();
+        L.pal_built.clear(); L.now_uses.clear(); L.tex16_stale.clear();
     }
 
     L.rows = rows; L.cols = cols;
@@ -100,9 +100,50 @@ int ensure_texels(dvo_ctx *c, int level, int rows, int cols) {
     return DVO_OK;
 }
 
+static void level_flags(dvo_ctx *c, Level &L) {
+    if (L.pal_built.empty()) { L.pal_built.assign(c->n_pairs, 0); L.now_uses.assign(c->n_pairs, 0); }
+    if (L.tex16_stale.empty()) L.tex16_stale.assign(c->n_pairs, 0);
+    if (L.have_now.empty()) L.have_now.assign(c->n_pairs, 0);
+}
+
+bool native_compact_wanted(const dvo_ctx *c) { return c->prm.engine_variant != 4 && compact_now_policy() != 2; }
+
+int ensure_compact_slabs(dvo_ctx *c, int level) {
+    Level &L = c->lv[level];
+    if (L.p4) return DVO_OK;
+    L.p4_stride = p4_count(L.rows, L.cols);
+    HIPCHK(c, hipMalloc((void **)&L.p4, sizeof(unsigned) * L.p4_stride * c->n_pairs));
+    HIPCHK(c, hipMalloc((void **)&L.pal, sizeof(float2) * DVO_PAL_MAX * (size_t)c->n_pairs));
+    HIPCHK(c, hipMalloc((void **)&L.d_pal_n, sizeof(int) * (size_t)c->n_pairs));
+    HIPCHK(c, hipMemsetAsync(L.d_pal_n, 0, sizeof(int) * (size_t)c->n_pairs, c->stream));
+    return DVO_OK;
+}
+
+int now_written_compact(dvo_ctx *c, int level, int first_pair, int count) {
+    Level &L = c->lv[level];
+    level_flags(c, L);
+    for (int p = first_pair; p < first_pair + count; p++) { L.have_now[p] = 1; L.now_uses[p] = 0; L.pal_built[p] = 1; L.tex16_stale[p] = 1; }
+    return DVO_OK;
+}
+
+int ensure_tex16(dvo_ctx *c, int level, int first_pair, int count) {
+    Level &L = c->lv[level];
+    if (L.tex16_stale.empty() || !L.p4) return DVO_OK;
+    for (int p = first_pair; p < first_pair + count; ) {
+        if (!L.tex16_stale[p]) { p++; continue; }
+        int q = p;
+        while (q < first_pair + count && L.tex16_stale[q]) q++;
+        HIPCHK(c, launch_p4_decode_texels(L.p4, L.p4_stride, L.pal, L.d_pal_n, L.tex, L.tex_stride, L.rows, L.cols, p, q - p, c->stream));
+        for (int i = p; i < q; i++) L.tex16_stale[i] = 0;
+        p = q;
+    }
+    return DVO_OK;
+}
+
 int now_written(dvo_ctx *c, int level, int first_pair, int count) {
     Level &L = c->lv[level];
-    if (L.pal_built.empty()) { L.pal_built.assign(c->n_pairs, 0); L.now_uses.assign(c->n_pairs, 0); }
+    level_flags(c, L);
+    for (int p = first_pair; p < first_pair + count; p++) L.tex16_stale[p] = 0;
     for (int p = first_pair; p < first_pair + count; ) {
         L.have_now[p] = 1; L.now_uses[p] = 0;
         if (!L.pal_built[p]) { p++; continue; }
@@ -122,19 +163,13 @@ int build_compact_now(dvo_ctx *c, int level, int first_pair, int count, bool onl
     if (p4_count(L.rows, L.cols) * sizeof(unsigned) >= ((size_t)1 << 32) || L.rows >= (1 << 16) || ((L.cols + 3) >> 2) >= (1 << 24) ||
         (size_t)p4_tiles_per_col(L.rows) * 128 >= ((size_t)1 << 24))
         return DVO_OK;
-    if (L.pal_built.empty()) { L.pal_built.assign(c->n_pairs, 0); L.now_uses.assign(c->n_pairs, 0); }
+    level_flags(c, L);
     for (int p = first_pair; p < first_pair + count; ) {
         auto wanted = [&](int i) { return L.have_now[i] && !L.pal_built[i] && (!only_reused || L.now_uses[i] >= DVO_COMPACT_NOW_AFTER); };
         if (!wanted(p)) { p++; continue; }
         int q = p;
         while (q < first_pair + count && wanted(q)) q++;
-        if (!L.p4) {
-            L.p4_stride = p4_count(L.rows, L.cols);
-            HIPCHK(c, hipMalloc((void **)&L.p4, sizeof(unsigned) * L.p4_stride * c->n_pairs));
-            HIPCHK(c, hipMalloc((void **)&L.pal, sizeof(float2) * DVO_PAL_MAX * (size_t)c->n_pairs));
-            HIPCHK(c, hipMalloc((void **)&L.d_pal_n, sizeof(int) * (size_t)c->n_pairs));
-            HIPCHK(c, hipMemsetAsync(L.d_pal_n, 0, sizeof(int) * (size_t)c->n_pairs, c->stream));
-        }
+        { const int rc = ensure_compact_slabs(c, level); if (rc) return rc; }
         for (int b = p; b < q; b += 1024) {                 /* scratch: 32 KiB per image of a launch */
             const int nb = std::min(1024, q - b);
             if (palette_work_ints(nb) > c->pal_work_ints) {
@@ -303,6 +338,13 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
     }
     int block = c->prm.block_threads;
     int auto_lds = 0;
+    if (sc.flags & DVO_FLAG_NORMAL_MATRIX) {
+        /* the H-carrying instantiation of the one-point-per-lane kernel exists for 512 threads only (dvo_kernels.hip): size the
+         * LDS budget for that, and refuse the combination it has no instantiation for instead of returning unwritten memory */
+        if (c->prm.interpolate_dt)
+            return fail(c, DVO_ERR_INVALID, "DVO_FLAG_NORMAL_MATRIX is not available together with dvo_params.interpolate_dt");
+        block = 512;
+    }
     const bool block_auto = (block != 256 && block != 512 && block != 1024);
     if (block_auto) {
         /* auto: when the longest point list of the launch fits half a CU's LDS, two 256-thread workgroups
@@ -341,8 +383,21 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         bytes &= ~63;
         sc.lds_bytes = bytes;
         sc.no_lds_tex = (c->prm.engine_variant == 2) ? 1 : 0;
+        sc.force_exact = (c->prm.engine_variant == 3) ? 1 : 0;
         sc.lds_points = bytes / (sc.compact ? 8 : 12);
         if (c->prm.lds_point_bytes < 0) { sc.lds_points = 0; sc.lds_bytes = 0; }
+    }
+    /* Who reads 16-byte texels in this launch?  Everything but the packed kernel on a compact form whose palette is certain to
+     * fit the launch's LDS (the kernel decides per pair and level on the device; with less LDS than the largest palette it
+     * could fall back to texels).  Now levels written by the engine's own distance-transform stage exist in the compact form
+     * only (dvo_frames.hip): their texels are decoded first. */
+    if (!packed || sc.no_p4 || (size_t)sc.lds_bytes < sizeof(float2) * DVO_PAL_MAX + 64) {
+        sc.no_p4 = 1;
+        for (int l = 0; l < n_levels; l++) {
+            if (sc.iters[l] <= 0) continue;
+            if ((rc = ensure_tex16(c, l, first_pair, n_pairs))) return rc;
+            if (sc.alias_mod > 0 && (rc = ensure_tex16(c, l, 0, std::min(sc.alias_mod, c->n_pairs)))) return rc;
+        }
     }
     int u = c->prm.points_in_flight;
     if (u != 1 && u != 2 && u != 4) u = 1;
@@ -419,7 +474,15 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
             }
             o.order = c->d_order;
         }
-        HIPCHK(c, launch_align_fused2(block, ls, sc, c->K, c->dprm, o, first_pair, n_pairs, c->stream));
+        hipError_t le = launch_align_fused2(block, ls, sc, c->K, c->dprm, o, first_pair, n_pairs, c->stream);
+        if (le != hipSuccess && sc.team > 1 && c->prm.team_size <= 1) {
+            /* the runtime could not make the whole team launch resident at once (something else holds compute units or LDS):
+             * the same batch without teams -- slower for a small batch, same results up to the order of the double sums */
+            sc.team = 1;
+            c->team_used = false;
+            le = launch_align_fused2(block, ls, sc, c->K, c->dprm, o, first_pair, n_pairs, c->stream);
+        }
+        HIPCHK(c, le);
     }
     else
         HIPCHK(c, launch_align_fused(block, u, ls, sc, c->K, c->dprm, outputs_of(c),
@@ -473,7 +536,8 @@ int dvo_create_batch(const dvo_params *p, int n_pairs, dvo_ctx **out) {
     {
         int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        if (hipGetDevice(&dev) == hipSuccess) c->device = dev;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
             c->n_cu = prop.multiProcessorCount;
     }
     c->dprm.beta = prm.beta; c->dprm.precond_rot = prm.precond_rot; c->dprm.reg_lambda = prm.reg_lambda;
@@ -522,6 +586,7 @@ int dvo_create(const dvo_params *p, dvo_ctx **out) { return dvo_create_batch(p, 
 
 int dvo_destroy(dvo_ctx *c) {
     if (!c) return DVO_OK;
+    DeviceGuard guard(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int l = 0; l < DVO_LEVELS; l++) {
         if (c->lv[l].tex) (void)hipFree(c->lv[l].tex);
@@ -571,25 +636,25 @@ const char *dvo_last_error(const dvo_ctx *c) { return c ? c->err.c_str() : g_cre
 int dvo_num_pairs(const dvo_ctx *c) { return c ? c->n_pairs : 0; }
 
 int dvo_set_stream(dvo_ctx *c, void *hip_stream) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = (hipStream_t)hip_stream;
     return DVO_OK;
 }
 int dvo_use_own_stream(dvo_ctx *c) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = c->own_stream;
     return DVO_OK;
 }
 int dvo_synchronize(dvo_ctx *c) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return DVO_OK;
 }
 
 int dvo_set_intrinsics(dvo_ctx *c, float fx, float fy, float cx, float cy) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!(fx > 0.0f) || !(fy > 0.0f)) return fail(c, DVO_ERR_INVALID, "fx, fy must be positive");
     if (c->have_K && (c->K.fx != fx || c->K.fy != fy || c->K.cx != cx || c->K.cy != cy))
         for (int l = 0; l < DVO_LEVELS; l++)          /* compact lists are expanded with K at run time: those built under the old K lose the short form */
@@ -601,7 +666,7 @@ int dvo_set_intrinsics(dvo_ctx *c, float fx, float fy, float cx, float cy) {
 
 /* ---- reference side -------------------------------------------------------- */
 static int set_ref_common(dvo_ctx *c, int pair, int level, const float *xyz, int N, bool device_src) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, pair) || !level_ok(level)) return fail(c, DVO_ERR_INVALID, "pair/level out of range");
     if (!xyz || N < 1) return fail(c, DVO_ERR_INVALID, "need N >= 1 reference points (reference asserts nSelectedPts > 0, SolveDVO.cpp:282)");
     int rc = ensure_points(c, level, N);
@@ -630,7 +695,7 @@ int dvo_set_ref_level_device(dvo_ctx *c, int pair, int level, const float *d_xyz
 int dvo_set_ref_level_from_images(dvo_ctx *c, int pair, int level, const int32_t *edge,
                                   const float *depth_mm, int rows, int cols,
                                   float *xyz_out, float *uv_out, int capacity, int *N_out) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, pair) || !level_ok(level)) return fail(c, DVO_ERR_INVALID, "pair/level out of range");
     if (!edge || !depth_mm || rows < 1 || cols < 1) return fail(c, DVO_ERR_INVALID, "bad image arguments");
     if (!c->have_K) return fail(c, DVO_ERR_STATE, "intrinsics not set (dvo_set_intrinsics)");
@@ -681,7 +746,7 @@ int dvo_set_ref_level_from_images(dvo_ctx *c, int pair, int level, const int32_t
 /* ---- now side --------------------------------------------------------------- */
 static int set_now_common(dvo_ctx *c, int pair, int level, const float *dt, const float *gx,
                           const float *gy, int rows, int cols, bool device_src) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, pair) || !level_ok(level)) return fail(c, DVO_ERR_INVALID, "pair/level out of range");
     if (!dt || !gx || !gy || rows < 1 || cols < 1) return fail(c, DVO_ERR_INVALID, "bad image arguments");
     int rc = ensure_texels(c, level, rows, cols);
@@ -716,7 +781,7 @@ int dvo_set_now_level_device(dvo_ctx *c, int pair, int level, const float *d_dt,
 
 /* computeDistTransfrmOfNow after Canny (SolveDVO.cpp:1768-1795) on the device */
 int dvo_set_now_level_from_edges(dvo_ctx *c, int pair, int level, const unsigned char *edge, int rows, int cols) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, pair) || !level_ok(level)) return fail(c, DVO_ERR_INVALID, "pair/level out of range");
     if (!edge || rows < 1 || cols < 1) return fail(c, DVO_ERR_INVALID, "bad image arguments");
     if ((long long)rows + cols + 1 > 46340) return fail(c, DVO_ERR_INVALID, "image too large for the exact distance transform (rows + cols must stay below 46339)");
@@ -733,21 +798,25 @@ int dvo_set_now_level_from_edges(dvo_ctx *c, int pair, int level, const unsigned
     int *work = (int *)c->staging + edge_ints;
     HIPCHK(c, hipMemcpyAsync(d_edge, edge, npx, hipMemcpyHostToDevice, c->stream));
     Level &L = c->lv[level];
-    HIPCHK(c, launch_now_level_from_edges(d_edge, rows, cols, work, L.tex + (size_t)pair * L.tex_stride, c->stream));
-    if ((rc = now_written(c, level, pair, 1))) return rc;
+    const bool compact = native_compact_wanted(c);
+    if (compact && (rc = ensure_compact_slabs(c, level))) return rc;
+    HIPCHK(c, launch_edges_to_now(d_edge, 0, ImgBatch{rows, cols, 1}, work, L.tex + (size_t)pair * L.tex_stride, L.tex_stride,
+                                  compact ? L.p4 : nullptr, L.p4_stride, L.pal, L.d_pal_n, pair, c->stream));
+    if ((rc = compact ? now_written_compact(c, level, pair, 1) : now_written(c, level, pair, 1))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return DVO_OK;
 }
 
 /* the three planar images of a resident now level (inspection) */
 int dvo_get_now_level(dvo_ctx *c, int pair, int level, float *dt, float *gx, float *gy) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, pair) || !level_ok(level)) return fail(c, DVO_ERR_INVALID, "pair/level out of range");
     Level &L = c->lv[level];
     if (L.have_now.empty() || !L.have_now[pair]) return fail(c, DVO_ERR_STATE, "now level not set");
     const size_t npx = (size_t)L.rows * L.cols;
     int rc = ensure_staging(c, sizeof(float) * 3 * npx);
     if (rc) return rc;
+    if ((rc = ensure_tex16(c, level, pair, 1))) return rc;
     float *d = c->staging;
     HIPCHK(c, launch_unpack_texels(L.tex + (size_t)pair * L.tex_stride, L.rows, L.cols, d, d + npx, d + 2 * npx, c->stream));
     if (dt) HIPCHK(c, hipMemcpyAsync(dt, d, sizeof(float) * npx, hipMemcpyDeviceToHost, c->stream));
@@ -758,7 +827,7 @@ int dvo_get_now_level(dvo_ctx *c, int pair, int level, float *dt, float *gx, flo
 }
 
 int dvo_get_ref_level(dvo_ctx *c, int pair, int level, float *xyz_out, int capacity, int *N_out) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, pair) || !level_ok(level)) return fail(c, DVO_ERR_INVALID, "pair/level out of range");
     Level &L = c->lv[level];
     if (L.hN.empty() || L.hN[pair] <= 0) return fail(c, DVO_ERR_STATE, "reference level not set");
@@ -775,7 +844,7 @@ int dvo_get_ref_level(dvo_ctx *c, int pair, int level, float *xyz_out, int capac
 
 /* replicate the first n_src pairs over [dst_first, dst_first+dst_count): slot p <- pair (p-dst_first) % n_src */
 int dvo_replicate_pairs(dvo_ctx *c, int n_src, int dst_first, int dst_count) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (n_src < 1 || dst_first < 0 || dst_count < 0 || dst_first + dst_count > c->n_pairs || n_src > c->n_pairs)
         return fail(c, DVO_ERR_INVALID, "bad replicate arguments");
     if (dst_first != 0 && dst_first < n_src) return fail(c, DVO_ERR_INVALID, "destination range overlaps the sources");
@@ -786,13 +855,32 @@ int dvo_replicate_pairs(dvo_ctx *c, int n_src, int dst_first, int dst_count) {
             int rc = check_ready(c, p, l);
             if (rc) return rc;
         }
-        HIPCHK(c, launch_replicate_level(L.tex, L.tex_stride, L.pts, L.cpts, L.pt_cap, L.dN, n_src, dst_first, dst_count, c->stream));
+        /* the now level travels in the form(s) its sources have: 16-byte texels, the compact form, or both */
+        bool any_tex16 = false, any_compact = false;
+        for (int p = 0; p < n_src; p++) {
+            const bool stale = !L.tex16_stale.empty() && L.tex16_stale[p];
+            any_tex16 = any_tex16 || !stale;
+            any_compact = any_compact || (!L.pal_built.empty() && L.pal_built[p]);
+        }
+        HIPCHK(c, launch_replicate_level(any_tex16 ? L.tex : nullptr, L.tex_stride, L.pts, L.cpts, L.pt_cap, L.dN, n_src, dst_first, dst_count, c->stream));
         for (int p = dst_first; p < dst_first + dst_count; p++) {
             L.hN[p] = L.hN[(p - dst_first) % n_src];
             c->points_gen++;
             L.compact_ok[p] = L.compact_ok[(p - dst_first) % n_src];
         }
-        if (L.tex && dst_count > 0) { int rc = now_written(c, l, dst_first, dst_count); if (rc) return rc; }
+        if (L.tex && dst_count > 0) {
+            int rc = now_written(c, l, dst_first, dst_count);       /* marks the destinations' compact form stale ... */
+            if (rc) return rc;
+            if (any_compact) {                                      /* ... and this copies the sources' over it */
+                HIPCHK(c, launch_replicate_compact(L.p4, L.p4_stride, L.pal, L.d_pal_n, n_src, dst_first, dst_count, c->stream));
+                for (int p = dst_first; p < dst_first + dst_count; p++) {
+                    const int src = (p - dst_first) % n_src;
+                    if (p == src) continue;
+                    L.pal_built[p] = L.pal_built[src];
+                    L.tex16_stale[p] = L.tex16_stale[src];
+                }
+            }
+        }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return DVO_OK;
@@ -800,7 +888,7 @@ int dvo_replicate_pairs(dvo_ctx *c, int n_src, int dst_first, int dst_count) {
 
 /* shape of the last fused launch: threads per workgroup, workgroups per pair (team), 1 = packed two-points-per-lane kernel */
 int dvo_get_last_launch_shape(dvo_ctx *c, int *block_threads, int *team_size, int *packed) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (block_threads) *block_threads = c->last_block;
     if (team_size) *team_size = c->last_team;
     if (packed) *packed = c->last_packed;
@@ -809,7 +897,7 @@ int dvo_get_last_launch_shape(dvo_ctx *c, int *block_threads, int *team_size, in
 
 /* build the compact form of the resident now levels of these pairs now (instead of at their second alignment) */
 int dvo_now_prepare(dvo_ctx *c, int first_pair, int count) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, first_pair) || count < 1 || first_pair + count > c->n_pairs) return fail(c, DVO_ERR_INVALID, "pair range out of bounds");
     if (c->prm.engine_variant == 4 || compact_now_policy() == 2) return DVO_OK;
     for (int l = 0; l < DVO_LEVELS; l++) {
@@ -822,7 +910,7 @@ int dvo_now_prepare(dvo_ctx *c, int first_pair, int count) {
 
 /* palette size of the compact form of (pair, level): > 0 size, 0 not built, < 0 the builder's reason for "no compact form" */
 int dvo_get_now_compact_info(dvo_ctx *c, int pair, int level, int *palette_size) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, pair) || !level_ok(level) || !palette_size) return fail(c, DVO_ERR_INVALID, "bad arguments");
     Level &L = c->lv[level];
     *palette_size = 0;
@@ -834,7 +922,7 @@ int dvo_get_now_compact_info(dvo_ctx *c, int pair, int level, int *palette_size)
 
 /* ---- hot path ---------------------------------------------------------------- */
 int dvo_set_poses(dvo_ctx *c, int first_pair, int n_pairs, const double *R, const double *t) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, first_pair) || n_pairs < 1 || first_pair + n_pairs > c->n_pairs || !R || !t)
         return fail(c, DVO_ERR_INVALID, "bad pose arguments");
     std::vector<double> h((size_t)12 * n_pairs);
@@ -848,20 +936,27 @@ int dvo_set_poses(dvo_ctx *c, int first_pair, int n_pairs, const double *R, cons
     return DVO_OK;
 }
 
+/* team mode: a member that gave up waiting for its team leaves a flag; every result of that launch is void */
+static int check_team_err(dvo_ctx *c) {
+    if (!c->team_used) return DVO_OK;
+    int team_err = 0;
+    HIPCHK(c, hipMemcpyAsync(&team_err, c->d_team_cnt + c->n_pairs, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (team_err)
+        return fail(c, DVO_ERR_HIP, "team mode: a workgroup gave up waiting for its team (members were not resident together); "
+                                    "the results of that launch are void -- set dvo_params.team_size = 1");
+    return DVO_OK;
+}
+
 int dvo_get_poses(dvo_ctx *c, int first_pair, int n_pairs, double *R, double *t) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, first_pair) || n_pairs < 1 || first_pair + n_pairs > c->n_pairs || !R || !t)
         return fail(c, DVO_ERR_INVALID, "bad pose arguments");
     std::vector<double> h((size_t)12 * n_pairs);
     HIPCHK(c, hipMemcpyAsync(h.data(), c->d_poses + (size_t)12 * first_pair, sizeof(double) * h.size(),
                              hipMemcpyDeviceToHost, c->stream));
-    int team_err = 0;
-    if (c->team_used)
-        HIPCHK(c, hipMemcpyAsync(&team_err, c->d_team_cnt + c->n_pairs, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (team_err)
-        return fail(c, DVO_ERR_HIP, "team mode: a workgroup gave up waiting for its team (members were not resident together); "
-                                    "set dvo_params.team_size = 1");
+    { const int trc = check_team_err(c); if (trc) return trc; }
     for (int p = 0; p < n_pairs; p++) {
         std::memcpy(R + 9 * p, &h[12 * p], sizeof(double) * 9);
         std::memcpy(t + 3 * p, &h[12 * p + 9], sizeof(double) * 3);
@@ -870,13 +965,13 @@ int dvo_get_poses(dvo_ctx *c, int first_pair, int n_pairs, double *R, double *t)
 }
 
 int dvo_align_batch_enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *iters, int flags) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     return enqueue(c, first_pair, n_pairs, n_levels, iters, flags);
 }
 
 int dvo_align_batch(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *iters,
                     int flags, double *R, double *t) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     int rc = dvo_set_poses(c, first_pair, n_pairs, R, t);
     if (rc) return rc;
     if ((rc = enqueue(c, first_pair, n_pairs, n_levels, iters, flags & ~DVO_FLAG_IDENTITY_START))) return rc;
@@ -889,13 +984,14 @@ int dvo_align_pyramid(dvo_ctx *c, int n_levels, const int *iters, int flags, dou
 
 int dvo_get_level_report(dvo_ctx *c, int pair, int level, float *energy, int n_energy,
                          int *best_idx, float *visible_ratio) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, pair) || !level_ok(level)) return fail(c, DVO_ERR_INVALID, "pair/level out of range");
     if (!c->have_sched || level >= c->sched.n_levels) return fail(c, DVO_ERR_STATE, "no alignment has been run for this level");
     if (!outputs_valid(c, pair))
         return fail(c, DVO_ERR_STATE, "pair " + std::to_string(pair) + " was not aligned under the current schedule (its report was "
                                       "overwritten or laid out by an earlier, different schedule): align it again");
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int trc = check_team_err(c); if (trc) return trc; }
     if (energy) {
         const int n = std::min(n_energy, c->sched.iters[level]);
         if (n > 0)
@@ -909,7 +1005,7 @@ int dvo_get_level_report(dvo_ctx *c, int pair, int level, float *energy, int n_e
 
 /* H = sum_i w_i J_i^T J_i of iterate `itr` of `level` (itr < 0: the best iterate), as the 6x6 symmetric matrix, row-major */
 int dvo_get_level_normal_matrix(dvo_ctx *c, int pair, int level, int itr, double *H36) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, pair) || !level_ok(level) || !H36) return fail(c, DVO_ERR_INVALID, "bad arguments");
     if (!c->have_sched || level >= c->sched.n_levels || !(c->sched.flags & DVO_FLAG_NORMAL_MATRIX) || !c->d_H)
         return fail(c, DVO_ERR_STATE, "last alignment did not request DVO_FLAG_NORMAL_MATRIX");
@@ -926,13 +1022,14 @@ int dvo_get_level_normal_matrix(dvo_ctx *c, int pair, int level, int itr, double
 }
 
 int dvo_get_final_outputs(dvo_ctx *c, int pair, float *final_eps, float *final_reproj, int capacity, int *N_out) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, pair)) return fail(c, DVO_ERR_INVALID, "pair out of range");
     if (!c->have_sched || !(c->sched.flags & DVO_FLAG_FINAL_OUTPUTS) || !c->d_final_eps)
         return fail(c, DVO_ERR_STATE, "last alignment did not request DVO_FLAG_FINAL_OUTPUTS");
     if (!outputs_valid(c, pair))
         return fail(c, DVO_ERR_STATE, "pair " + std::to_string(pair) + " was not aligned under the current schedule: align it again");
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int trc = check_team_err(c); if (trc) return trc; }
     int N = 0;
     HIPCHK(c, hipMemcpy(&N, c->d_final_N + pair, sizeof(int), hipMemcpyDeviceToHost));
     if (N_out) *N_out = N;
@@ -947,7 +1044,7 @@ int dvo_get_final_outputs(dvo_ctx *c, int pair, float *final_eps, float *final_r
 int dvo_run_iterations_pair(dvo_ctx *c, int pair, int level, int max_iters, double *R, double *t,
                             float *energy, float *final_eps, float *final_reproj,
                             int *best_idx, float *visible_ratio) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, pair) || !level_ok(level)) return fail(c, DVO_ERR_INVALID, "pair/level out of range (reference: assert level>=0, SolveDVO.cpp:625)");
     if (max_iters < 1) return fail(c, DVO_ERR_INVALID, "maxIterations must be > 0 (SolveDVO.cpp:626)");
     if (!R || !t) return fail(c, DVO_ERR_INVALID, "R/t are NULL");
@@ -973,10 +1070,11 @@ int dvo_run_iterations(dvo_ctx *c, int level, int max_iters, double *R, double *
 
 /* ---- host-driven iteration ------------------------------------------------------ */
 int dvo_iter_begin(dvo_ctx *c, int pair, int level, int max_iters, const double *R, const double *t) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, pair) || !level_ok(level) || max_iters < 1 || !R || !t) return fail(c, DVO_ERR_INVALID, "bad arguments");
     int rc = check_ready(c, pair, level);
     if (rc) return rc;
+    if ((rc = ensure_tex16(c, level, pair, 1))) return rc;       /* the host-driven kernels read 16-byte texels */
     if (!c->d_states) {
         HIPCHK(c, hipMalloc((void **)&c->d_states, pose_state_bytes() * c->n_pairs));
         c->iter_max.assign(c->n_pairs, 0);
@@ -1000,7 +1098,7 @@ int dvo_iter_begin(dvo_ctx *c, int pair, int level, int max_iters, const double 
 }
 
 int dvo_iter_accumulate(dvo_ctx *c, int pair, int level, int first_point, int n_points, double *d_acc32) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, pair) || !level_ok(level) || !d_acc32) return fail(c, DVO_ERR_INVALID, "bad arguments");
     if (!c->d_states || c->iter_max[pair] == 0) return fail(c, DVO_ERR_STATE, "dvo_iter_begin has not been called for this pair");
     const int N = c->lv[level].hN.empty() ? 0 : c->lv[level].hN[pair];
@@ -1012,7 +1110,7 @@ int dvo_iter_accumulate(dvo_ctx *c, int pair, int level, int first_point, int n_
 }
 
 int dvo_iter_update(dvo_ctx *c, int pair, int level, int itr, int n_total, const double *d_acc32) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, pair) || !level_ok(level) || !d_acc32 || n_total < 1) return fail(c, DVO_ERR_INVALID, "bad arguments");
     if (!c->d_states || c->iter_max[pair] == 0) return fail(c, DVO_ERR_STATE, "dvo_iter_begin has not been called for this pair");
     if (itr < 0 || itr >= c->iter_max[pair]) return fail(c, DVO_ERR_INVALID, "iteration index out of range");
@@ -1023,7 +1121,7 @@ int dvo_iter_update(dvo_ctx *c, int pair, int level, int itr, int n_total, const
 
 int dvo_iter_end(dvo_ctx *c, int pair, int level, double *R, double *t, float *energy, int *best_idx,
                  float *visible_ratio) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, pair) || !level_ok(level) || !R || !t) return fail(c, DVO_ERR_INVALID, "bad arguments");
     if (!c->d_states || c->iter_max[pair] == 0) return fail(c, DVO_ERR_STATE, "dvo_iter_begin has not been called for this pair");
     double *d_pose = c->d_poses + (size_t)12 * pair;
@@ -1045,14 +1143,15 @@ int dvo_iter_end(dvo_ctx *c, int pair, int level, double *R, double *t, float *e
 
 /* The level schedule (SolveDVO.cpp:2097-2104) with every iteration spread over all CUs: the single-GPU
  * form of the host-driven loop, enqueued back to back from C (no collective, one synchronisation). */
-int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters, double *R, double *t) {
-    if (!c) return DVO_ERR_INVALID;
+int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters, int flags, double *R, double *t) {
+    DVO_ENTER(c);
     if (!pair_ok(c, pair) || !R || !t) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    if (flags & ~DVO_FLAG_FINAL_OUTPUTS) return fail(c, DVO_ERR_INVALID, "dvo_align_pyramid_wide takes DVO_FLAG_FINAL_OUTPUTS only");
     Schedule sc;
-    int rc = build_schedule(c, n_levels, iters, 0, sc);
+    int rc = build_schedule(c, n_levels, iters, flags, sc);
     if (rc) return rc;
     for (int l = 0; l < n_levels; l++)
-        if (sc.iters[l] > 0 && (rc = check_ready(c, pair, l))) return rc;
+        if (sc.iters[l] > 0 && ((rc = check_ready(c, pair, l)) || (rc = ensure_tex16(c, l, pair, 1)))) return rc;
     if ((rc = ensure_outputs(c, sc))) return rc;
     if (!c->d_states) {
         HIPCHK(c, hipMalloc((void **)&c->d_states, pose_state_bytes() * c->n_pairs));
@@ -1069,6 +1168,7 @@ int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters,
     unsigned long long sig = 1469598103934665603ull;
     auto mix = [&sig](unsigned long long v) { sig = (sig ^ v) * 1099511628211ull; };
     mix((unsigned long long)pair); mix((unsigned long long)n_levels); mix((unsigned long long)(size_t)c->stream);
+    mix((unsigned long long)flags); mix((unsigned long long)(size_t)c->d_final_eps); mix((unsigned long long)c->final_cap);
     mix((unsigned long long)(size_t)c->d_energy); mix((unsigned long long)sc.e_stride);
     for (int l = 0; l < n_levels; l++) {
         const LevelSlab sl = slab_of(c, l);
@@ -1093,6 +1193,9 @@ int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters,
             const int nb = accumulate_blocks_for(N);
             for (int itr = 0; itr < sc.iters[l]; itr++)
                 rec(launch_iter_step_fused(slab_of(c, l), pair, l, c->K, state, c->dprm, itr, N, partials, nb, energy, c->stream));
+            if ((flags & DVO_FLAG_FINAL_OUTPUTS) && l == sc.last_level)       /* :703-704, :1002-1003 */
+                rec(launch_final_outputs_state(slab_of(c, l), pair, l, c->K, state, 0, N, c->d_final_eps + (size_t)pair * c->final_cap,
+                                               c->d_final_reproj + (size_t)pair * c->final_cap * 3, c->d_final_N + pair, c->stream));
             rec(launch_iter_end(state, d_pose, c->d_best + pair * DVO_LEVELS + l, c->d_ratio + pair * DVO_LEVELS + l, c->stream));
         }
         rec(hipMemcpyAsync(h, d_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, c->stream));
@@ -1112,17 +1215,19 @@ int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters,
     stamp_outputs(c, sc, pair, 1);
     c->sched = sc;
     c->have_sched = true;
+    c->team_used = false;
     return DVO_OK;
 }
 
 /* ---- inspection ------------------------------------------------------------- */
 int dvo_eval_points(dvo_ctx *c, int pair, int level, const double *R, const double *t,
                     float *reproj, float *J, float *eps, float *w, int *visible) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, pair) || !level_ok(level) || !R || !t) return fail(c, DVO_ERR_INVALID, "bad arguments");
     int rc = check_ready(c, pair, level);
     if (rc) return rc;
     const int N = c->lv[level].hN[pair];
+    if ((rc = ensure_tex16(c, level, pair, 1))) return rc;
     /* staging: reproj 3N | J 6N | eps N | w N | vis N  (floats/ints, 4 bytes each) */
     if ((rc = ensure_staging(c, sizeof(float) * 12 * (size_t)N))) return rc;
     float *d_re = c->staging, *d_J = d_re + 3 * (size_t)N, *d_e = d_J + 6 * (size_t)N, *d_w = d_e + N;
@@ -1140,10 +1245,11 @@ int dvo_eval_points(dvo_ctx *c, int pair, int level, const double *R, const doub
 }
 
 int dvo_accumulate(dvo_ctx *c, int pair, int level, const double *R, const double *t, double *acc29) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, pair) || !level_ok(level) || !R || !t || !acc29) return fail(c, DVO_ERR_INVALID, "bad arguments");
     int rc = check_ready(c, pair, level);
     if (rc) return rc;
+    if ((rc = ensure_tex16(c, level, pair, 1))) return rc;
     const int N = c->lv[level].hN[pair];
     float Rf[9], tf[3];
     cast_pose(R, t, Rf, tf);
@@ -1158,7 +1264,8 @@ int dvo_accumulate(dvo_ctx *c, int pair, int level, const double *R, const doubl
 }
 
 int dvo_device_se3_exp(dvo_ctx *c, const double *psi6, double *R, double *t) {
-    if (!c || !psi6 || !R || !t) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
+    if (!psi6 || !R || !t) return DVO_ERR_INVALID;
     double *d = c->d_scratch;
     HIPCHK(c, hipMemcpyAsync(d, psi6, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, launch_se3_exp(d, d + 8, c->stream));
@@ -1170,7 +1277,8 @@ int dvo_device_se3_exp(dvo_ctx *c, const double *psi6, double *R, double *t) {
     return DVO_OK;
 }
 int dvo_device_se3_log(dvo_ctx *c, const double *R, const double *t, double *psi6) {
-    if (!c || !psi6 || !R || !t) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
+    if (!psi6 || !R || !t) return DVO_ERR_INVALID;
     double *d = c->d_scratch;
     double h[12];
     std::memcpy(h, R, sizeof(double) * 9);
@@ -1182,7 +1290,8 @@ int dvo_device_se3_log(dvo_ctx *c, const double *R, const double *t, double *psi
     return DVO_OK;
 }
 int dvo_device_rotationize(dvo_ctx *c, double *R) {
-    if (!c || !R) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
+    if (!R) return DVO_ERR_INVALID;
     double *d = c->d_scratch;
     HIPCHK(c, hipMemcpyAsync(d, R, sizeof(double) * 9, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, launch_rotationize(d, c->stream));
@@ -1193,7 +1302,8 @@ int dvo_device_rotationize(dvo_ctx *c, double *R) {
 
 /* diagnostics: phase cycle counters of a DVO_STAMPS build (zeros otherwise); resets them */
 int dvo_debug_stamps(dvo_ctx *c, int pair, unsigned long long *out64) {
-    if (!c || !out64 || !pair_ok(c, pair)) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
+    if (!out64 || !pair_ok(c, pair)) return DVO_ERR_INVALID;
     std::memset(out64, 0, sizeof(unsigned long long) * 64);
     if (!c->d_dbg) return DVO_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1204,16 +1314,28 @@ int dvo_debug_stamps(dvo_ctx *c, int pair, unsigned long long *out64) {
 
 /* inspection: where the packed fused kernel read the now level of (pair, level) from during the last launch that ran it */
 int dvo_get_level_texel_mode(dvo_ctx *c, int pair, int level, int *mode) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!pair_ok(c, pair) || !level_ok(level) || !mode) return fail(c, DVO_ERR_INVALID, "bad arguments");
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(mode, c->d_tex_mode + (size_t)pair * DVO_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
+    int v = -1;
+    HIPCHK(c, hipMemcpy(&v, c->d_tex_mode + (size_t)pair * DVO_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
+    *mode = (v < 0) ? -1 : (v & 0xff);
+    return DVO_OK;
+}
+int dvo_get_level_exact_fallback(dvo_ctx *c, int pair, int level, int *ran) {
+    DVO_ENTER(c);
+    if (!pair_ok(c, pair) || !level_ok(level) || !ran) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int v = -1;
+    HIPCHK(c, hipMemcpy(&v, c->d_tex_mode + (size_t)pair * DVO_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
+    *ran = (v >= 0 && (v & DVO_TEXMODE_EXACT_RAN)) ? 1 : 0;
     return DVO_OK;
 }
 
 /* ---- measurement support ------------------------------------------------------ */
 int dvo_algorithmic_bytes(dvo_ctx *c, int pair, int n_levels, const int *iters, int flags, uint64_t *bytes) {
-    if (!c || !bytes) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
+    if (!bytes) return DVO_ERR_INVALID;
     if (!pair_ok(c, pair)) return fail(c, DVO_ERR_INVALID, "pair out of range");
     Schedule sc;
     int rc = build_schedule(c, n_levels, iters, flags, sc);
@@ -1231,7 +1353,8 @@ int dvo_algorithmic_bytes(dvo_ctx *c, int pair, int n_levels, const int *iters, 
 }
 
 int dvo_point_iterations(dvo_ctx *c, int pair, int n_levels, const int *iters, uint64_t *count) {
-    if (!c || !count) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
+    if (!count) return DVO_ERR_INVALID;
     if (!pair_ok(c, pair)) return fail(c, DVO_ERR_INVALID, "pair out of range");
     Schedule sc;
     int rc = build_schedule(c, n_levels, iters, 0, sc);

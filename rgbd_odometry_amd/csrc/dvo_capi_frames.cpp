@@ -219,7 +219,7 @@ size_t pix_bytes(int dtype) { return dtype == DVO_PIX_U8 ? 1 : (dtype == DVO_PIX
 static int frames_as_now_level(dvo_ctx *c, int level, int first_slot, int first_pair, int count, hipStream_t stream, int *work);
 
 int dvo_frames_reserve(dvo_ctx *c, int n_slots) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (n_slots < 1) return fail(c, DVO_ERR_INVALID, "n_slots must be >= 1");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     frames_free(c);
@@ -233,7 +233,7 @@ int dvo_frames_num_levels(const dvo_ctx *c) { return c ? c->fs.n_levels : 0; }
 
 int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_levels,
                                const dvo_image *grey, const dvo_image *depth, int now_first_pair, int flags) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!grey || count < 1 || n_levels < 1 || n_levels > DVO_LEVELS) return fail(c, DVO_ERR_INVALID, "bad frame arguments");
     int rows[DVO_LEVELS], cols[DVO_LEVELS];
     for (int l = 0; l < n_levels; l++) { rows[l] = grey[l].rows; cols[l] = grey[l].cols; }
@@ -342,7 +342,7 @@ int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_leve
  * the new camera matrix is the camera matrix with cy moved by the stripe's first row, inverted by the 3x3 adjugate formula
  * cv::invert uses; the normalised coordinates advance by running sums along a row -- and uploaded once. */
 int dvo_frames_set_undistort(dvo_ctx *c, int rows, int cols, const double *K4, const double *D5) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->d_umap_xy) { (void)hipFree(c->d_umap_xy); (void)hipFree(c->d_umap_frac); c->d_umap_xy = nullptr; c->d_umap_frac = nullptr; }
     c->umap_rows = c->umap_cols = 0;
@@ -393,7 +393,7 @@ int dvo_frames_set_undistort(dvo_ctx *c, int rows, int cols, const double *K4, c
 int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsigned char *const *bgr8,
                               const float *const *depth_m, int rows, int cols, int n_levels, int first_shift,
                               int now_first_pair, int flags) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!bgr8 || count < 1 || rows < 1 || cols < 1 || n_levels < 1 || n_levels > DVO_LEVELS || first_shift < 0 ||
         first_shift + n_levels > 16)
         return fail(c, DVO_ERR_INVALID, "bad camera frame arguments");
@@ -472,24 +472,31 @@ static int frames_as_now_level(dvo_ctx *c, int l, int first_slot, int first_pair
     int rc;
     FrameLevel &F = c->fs.lv[l];
     if ((rc = ensure_texels(c, l, F.rows, F.cols))) return rc;
+    /* the now level is written in its compact form (dvo_palette.h) straight from the integer squared distances; 16-byte texels
+     * only for images that form cannot hold, or when the caller switched the compact form off */
+    const bool compact = native_compact_wanted(c);
+    if (compact && (rc = ensure_compact_slabs(c, l))) return rc;
     Level &L = c->lv[l];
+    unsigned *p4 = compact ? L.p4 : nullptr;
     if (work) {
-        HIPCHK(c, launch_edges_to_texels(F.edge + (size_t)first_slot * F.npx, F.npx, ImgBatch{F.rows, F.cols, count}, work,
-                                         L.tex + (size_t)first_pair * L.tex_stride, L.tex_stride, stream));
+        HIPCHK(c, launch_edges_to_now(F.edge + (size_t)first_slot * F.npx, F.npx, ImgBatch{F.rows, F.cols, count}, work,
+                                      L.tex + (size_t)first_pair * L.tex_stride, L.tex_stride, p4, L.p4_stride, L.pal, L.d_pal_n,
+                                      first_pair, stream));
     } else {
         const int chunk = chunk_for(sizeof(int) * edt_work_ints(F.rows, F.cols, 1), count);
         if ((rc = ensure_work(c, sizeof(int) * edt_work_ints(F.rows, F.cols, chunk)))) return rc;
         for (int b = 0; b < count; b += chunk) {
             const int nc = std::min(chunk, count - b);
-            HIPCHK(c, launch_edges_to_texels(F.edge + (size_t)(first_slot + b) * F.npx, F.npx, ImgBatch{F.rows, F.cols, nc},
-                                             c->work, L.tex + (size_t)(first_pair + b) * L.tex_stride, L.tex_stride, stream));
+            HIPCHK(c, launch_edges_to_now(F.edge + (size_t)(first_slot + b) * F.npx, F.npx, ImgBatch{F.rows, F.cols, nc}, c->work,
+                                          L.tex + (size_t)(first_pair + b) * L.tex_stride, L.tex_stride, p4, L.p4_stride, L.pal,
+                                          L.d_pal_n, first_pair + b, stream));
         }
     }
-    return now_written(c, l, first_pair, count);
+    return compact ? now_written_compact(c, l, first_pair, count) : now_written(c, l, first_pair, count);
 }
 
 int dvo_frames_as_now(dvo_ctx *c, int first_slot, int first_pair, int count) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     int rc = frames_check_use(c, first_slot, first_pair, count, false);
     if (rc) return rc;
     const int nl = c->fs.n_levels;
@@ -502,7 +509,7 @@ int dvo_frames_as_now(dvo_ctx *c, int first_slot, int first_pair, int count) {
 }
 
 int dvo_frames_as_ref(dvo_ctx *c, int first_slot, int first_pair, int count, int *N_out) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!c->have_K) return fail(c, DVO_ERR_STATE, "intrinsics not set (dvo_set_intrinsics)");
     int rc = frames_check_use(c, first_slot, first_pair, count, true);
     if (rc) return rc;
@@ -553,7 +560,7 @@ int dvo_frames_as_ref(dvo_ctx *c, int first_slot, int first_pair, int count, int
 
 int dvo_frame_get_level(dvo_ctx *c, int slot, int level, int *rows, int *cols, unsigned char *grey,
                         float *depth_mm, unsigned char *edge, int *n_edges) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (level < 0 || level >= c->fs.n_levels) return fail(c, DVO_ERR_INVALID, "frame level out of range");
     if (!slots_ok(c, slot, 1) || !c->fs.valid[slot]) return fail(c, DVO_ERR_STATE, "frame slot holds no frame");
     FrameLevel &F = c->fs.lv[level];

@@ -71,7 +71,7 @@ int dvo_photo_params_default(dvo_photo_params *p) {
 }
 
 int dvo_photo_configure(dvo_ctx *c, const dvo_photo_params *prm) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!prm || !(prm->fx != 0.0) || !(prm->fy != 0.0) || prm->max_jacobian_size < 1 || prm->iterations < 1 || prm->iterations > 64)
         return fail(c, DVO_ERR_INVALID, "bad photometric parameters (setCameraMatrix: fx, fy, cx, cy of the level-0 camera matrix)");
     dvo_photo_state *p;
@@ -92,7 +92,7 @@ int dvo_photo_configure(dvo_ctx *c, const dvo_photo_params *prm) {
 /* setRefFrame (:296-327) + computeJacobianAllLevels (:363-398): J, the selected pixels and A = J^T J of levels
  * first_level .. n_levels-1 of the stored frame (the reference computes levels 1..3, :373) */
 int dvo_photo_set_ref(dvo_ctx *c, int slot, int first_level, int *n_selected /* [n_levels] or NULL */) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     dvo_photo_state *p;
     photo_state(c, &p);
     if (!(p->prm.fx != 0.0)) return fail(c, DVO_ERR_STATE, "camera matrix not set (dvo_photo_configure)");
@@ -150,7 +150,7 @@ int dvo_photo_set_ref(dvo_ctx *c, int slot, int first_level, int *n_selected /* 
  * T16: 4x4 row-major (TransformRep::matrix()), in/out.  eps_norms: n_run x iterations doubles (|eps| of every iteration,
  * -1 where not run); updates: n_run ints (iterations that changed T).  Both may be NULL. */
 int dvo_photo_align(dvo_ctx *c, int now_slot, const int *levels, int n_run, double *T16, double *eps_norms, int *updates) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     dvo_photo_state *p = c->photo;
     if (!p || p->ref_slot < 0) return fail(c, DVO_ERR_STATE, "no reference frame (dvo_photo_set_ref)");
     if (!levels || n_run < 1 || !T16) return fail(c, DVO_ERR_INVALID, "bad arguments");
@@ -182,7 +182,7 @@ int dvo_photo_align(dvo_ctx *c, int now_slot, const int *levels, int n_run, doub
 
 /* inspection: J (n x 6 row-major), the selected pixels (row i, column j), A (6x6) of a reference level */
 int dvo_photo_get_jacobian(dvo_ctx *c, int level, double *J, int *sel_i, int *sel_j, int capacity, double *A36, int *n_out) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     dvo_photo_state *p = c->photo;
     if (!p || !level_ok(level) || !p->lv[level].ready) return fail(c, DVO_ERR_STATE, "no Jacobian for this level");
     dvo_photo_state::Lvl &L = p->lv[level];

@@ -18,6 +18,7 @@
 #include "dvo_ctx.h"
 
 #include <dlfcn.h>
+#include <mutex>
 
 using namespace dvo;
 using namespace dvo_host;
@@ -39,9 +40,14 @@ struct Tiled {
 
 /* one record per context, kept outside struct dvo_ctx (only this file knows RCCL) */
 struct Entry { dvo_ctx *ctx; Tiled t; };
-std::vector<Entry> &registry() { static std::vector<Entry> r; return r; }
+/* One process may drive several contexts from several host threads (one per GPU): the registry is
+ * the only state they share, so every access takes its lock.  Entries are heap records: the pointer find() returns stays
+ * valid while other threads attach or detach THEIR contexts (a context itself is still one-thread-at-a-time). */
+std::mutex &registry_mutex() { static std::mutex m; return m; }
+std::vector<Entry *> &registry() { static std::vector<Entry *> r; return r; }
 Tiled *find(dvo_ctx *c) {
-    for (auto &e : registry()) if (e.ctx == c) return &e.t;
+    std::lock_guard<std::mutex> lock(registry_mutex());
+    for (Entry *e : registry()) if (e->ctx == c) return &e->t;
     return nullptr;
 }
 
@@ -55,21 +61,24 @@ void shard(int n, int rank, int world, int &first, int &count) {      /* same de
 
 namespace dvo_host {
 void tiled_forget(dvo_ctx *c) {           /* called by dvo_destroy */
-    auto &r = registry();
-    for (size_t i = 0; i < r.size(); i++)
-        if (r[i].ctx == c) {
-            if (r[i].t.d_acc) (void)hipFree(r[i].t.d_acc);
-            if (r[i].t.lib) dlclose(r[i].t.lib);
-            r.erase(r.begin() + i);
-            return;
-        }
+    Entry *gone = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(registry_mutex());
+        auto &r = registry();
+        for (size_t i = 0; i < r.size(); i++)
+            if (r[i]->ctx == c) { gone = r[i]; r.erase(r.begin() + i); break; }
+    }
+    if (!gone) return;
+    if (gone->t.d_acc) (void)hipFree(gone->t.d_acc);
+    if (gone->t.lib) dlclose(gone->t.lib);
+    delete gone;
 }
 }  // namespace dvo_host
 
 extern "C" {
 
 int dvo_tiled_attach(dvo_ctx *c, void *nccl_comm, int rank, int world, const char *rccl_library) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (!nccl_comm || world < 1 || rank < 0 || rank >= world) return fail(c, DVO_ERR_INVALID, "bad communicator / rank / world size");
     tiled_forget(c);
     Tiled t;
@@ -93,27 +102,41 @@ int dvo_tiled_attach(dvo_ctx *c, void *nccl_comm, int rank, int world, const cha
     t.all_reduce = (nccl_allreduce_fn)sym;
     t.errstr = (nccl_errstr_fn)(t.lib ? dlsym(t.lib, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
     HIPCHK(c, hipMalloc((void **)&t.d_acc, sizeof(double) * DVO_NACC_PAD));
-    registry().push_back(Entry{c, t});
+    {
+        std::lock_guard<std::mutex> lock(registry_mutex());
+        registry().push_back(new Entry{c, t});
+    }
     return DVO_OK;
 }
 
 int dvo_tiled_detach(dvo_ctx *c) {
-    if (!c) return DVO_ERR_INVALID;
+    DVO_ENTER(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     tiled_forget(c);
     return DVO_OK;
 }
 
-int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters, double *R, double *t) {
-    if (!c) return DVO_ERR_INVALID;
+int dvo_tiled_shard(dvo_ctx *c, int pair, int level, int *first, int *count) {
+    DVO_ENTER(c);
+    if (!pair_ok(c, pair) || !level_ok(level) || !first || !count) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    Tiled *T = find(c);
+    if (!T) return fail(c, DVO_ERR_STATE, "no communicator attached (dvo_tiled_attach)");
+    const int N = c->lv[level].hN.empty() ? 0 : c->lv[level].hN[pair];
+    shard(N, T->rank, T->world, *first, *count);
+    return DVO_OK;
+}
+
+int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters, int flags, double *R, double *t) {
+    DVO_ENTER(c);
     if (!pair_ok(c, pair) || !R || !t) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    if (flags & ~DVO_FLAG_FINAL_OUTPUTS) return fail(c, DVO_ERR_INVALID, "dvo_align_pyramid_tiled takes DVO_FLAG_FINAL_OUTPUTS only");
     Tiled *T = find(c);
     if (!T) return fail(c, DVO_ERR_STATE, "no communicator attached (dvo_tiled_attach)");
     Schedule sc;
-    int rc = dvo_host::build_schedule(c, n_levels, iters, 0, sc);
+    int rc = dvo_host::build_schedule(c, n_levels, iters, flags, sc);
     if (rc) return rc;
     for (int l = 0; l < n_levels; l++)
-        if (sc.iters[l] > 0 && (rc = dvo_host::check_ready(c, pair, l))) return rc;
+        if (sc.iters[l] > 0 && ((rc = dvo_host::check_ready(c, pair, l)) || (rc = dvo_host::ensure_tex16(c, l, pair, 1)))) return rc;
     if ((rc = dvo_host::ensure_outputs(c, sc))) return rc;
     if (!c->d_states) {
         HIPCHK(c, hipMalloc((void **)&c->d_states, pose_state_bytes() * c->n_pairs));
@@ -143,6 +166,11 @@ int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters
                 return fail(c, DVO_ERR_HIP, std::string("ncclAllReduce: ") + (T->errstr ? T->errstr(nrc) : "error " + std::to_string(nrc)));
             HIPCHK(c, launch_iter_update(state, c->dprm, itr, N, T->d_acc, energy, c->stream));
         }
+        /* finalEpsilons / finalReprojections (:703-704, :1002-1003): this rank's shard, at the points' own indices; the caller
+         * concatenates the shards (dvo_tiled_shard gives the ranges) */
+        if ((flags & DVO_FLAG_FINAL_OUTPUTS) && l == sc.last_level)
+            HIPCHK(c, launch_final_outputs_state(sl, pair, l, c->K, state, first, count, c->d_final_eps + (size_t)pair * c->final_cap,
+                                                 c->d_final_reproj + (size_t)pair * c->final_cap * 3, c->d_final_N + pair, c->stream));
         HIPCHK(c, launch_iter_end(state, d_pose, c->d_best + pair * DVO_LEVELS + l, c->d_ratio + pair * DVO_LEVELS + l, c->stream));
     }
     HIPCHK(c, hipMemcpyAsync(h, d_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, c->stream));
@@ -152,6 +180,7 @@ int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters
     dvo_host::stamp_outputs(c, sc, pair, 1);
     c->sched = sc;
     c->have_sched = true;
+    c->team_used = false;
     return DVO_OK;
 }
 

@@ -35,8 +35,12 @@ struct Level {
     float2 *pal = nullptr;          /* n_pairs x DVO_PAL_MAX {DT value, weight} */
     int *d_pal_n = nullptr;         /* n_pairs: > 0 palette size, <= 0 no compact form (kept 0 while the form is stale) */
     size_t p4_stride = 0;
-    std::vector<char> pal_built;    /* per pair: the compact form was built from the CURRENT now level */
+    std::vector<char> pal_built;    /* per pair: the compact form was built from the CURRENT now level (or IS how it was written) */
     std::vector<int> now_uses;      /* per pair: alignments enqueued since the now level was last written */
+    /* per pair: the now level was written in its compact form only (the engine's own distance-transform stage, round 3) and its
+     * 16-byte texels have not been decoded from it yet.  (A pair whose image the compact form could not hold got its texels
+     * from the same launch; the decode launch skips it on the device: pal_n <= 0.) */
+    std::vector<char> tex16_stale;
 };
 
 /* frame store (rows f1/f2): per level one slab per plane for all slots, slot s at base + s*npx */
@@ -72,6 +76,7 @@ struct dvo_ctx {
     dvo_params prm;
     dvo::DevParams dprm;
     int n_pairs = 0;
+    int device = 0;                 /* HIP device the context was created on: every entry point makes it current (DeviceGuard) */
     int n_cu = 256;                 /* compute units of the device (auto tuning of launch shapes) */
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
@@ -147,6 +152,25 @@ struct dvo_ctx {
 
 namespace dvo_host {
 
+/* A context lives on the device that was current when it was created.  Every C entry point makes that device current for its
+ * duration and restores the caller's afterwards, so a context can be driven from a thread whose current device differs
+ * (one host thread per GPU). */
+struct DeviceGuard {
+    int prev = -1, dev = -1;
+    explicit DeviceGuard(const dvo_ctx *c) {
+        if (!c) return;
+        dev = c->device;
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; return; }
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define DVO_ENTER(c)                         \
+    if (!(c)) return DVO_ERR_INVALID;        \
+    dvo_host::DeviceGuard dvo_device_guard_(c)
+
 int fail(dvo_ctx *c, int code, const std::string &msg);
 #define HIPCHK(c, expr)                                                                     \
     do {                                                                                    \
@@ -163,6 +187,16 @@ int ensure_points(dvo_ctx *c, int level, int N);                 /* room for N p
 int ensure_texels(dvo_ctx *c, int level, int rows, int cols);
 /* the now level of `pair` at `level` was (re)written: mark it present and its compact form stale */
 int now_written(dvo_ctx *c, int level, int first_pair, int count);
+/* the slabs of the compact form of `level` (allocated at first use) */
+int ensure_compact_slabs(dvo_ctx *c, int level);
+/* the now level of these pairs was (re)written in its compact form only (launch_edges_to_now with p4 != NULL) */
+int now_written_compact(dvo_ctx *c, int level, int first_pair, int count);
+/* make the 16-byte texels of these pairs' now level valid (decoded from the compact form where that is all there is): for
+ * every path that reads texels -- everything except the packed fused kernel on the compact form */
+int ensure_tex16(dvo_ctx *c, int level, int first_pair, int count);
+/* true if now levels written by the engine's own distance-transform stage should be compact (false: DVO_COMPACT_NOW=off or
+ * dvo_params.engine_variant = 4 -- plain 16-byte texels) */
+bool native_compact_wanted(const dvo_ctx *c);
 /* build the compact form of the stale now levels among [first_pair, first_pair+count) at `level`; with only_reused, only
  * of those that have been aligned DVO_COMPACT_NOW_AFTER times (the build costs about 4.4 alignments) */
 int build_compact_now(dvo_ctx *c, int level, int first_pair, int count, bool only_reused);

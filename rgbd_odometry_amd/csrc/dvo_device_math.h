@@ -574,6 +574,7 @@ struct PoseState {
     float Rf[9], tf[3];          /* cR_32, cT_32 (:673-674) for the next evaluation */
     float bRf[9], btf[3];        /* cR_32, cT_32 of the best iterate (for finalEpsilons/Reprojections) */
     double creg[6], creg_scale;  /* regulariser of the CURRENT pose, precomputed (fused kernel): log(pose) and lambda/|log| */
+    int exact_ran, pad_;         /* packed kernel, inspection: a wave took the literal-division fallback during this level */
 };
 
 /* state from a caller-supplied pose (kernel entry) */

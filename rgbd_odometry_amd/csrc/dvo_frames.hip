@@ -20,6 +20,7 @@
  *   enlist_*              selectedPts + enlistRefEdgePts (src/SolveDVO.cpp:1230-1264, :224-264)
  */
 #include "dvo_launch.h"
+#include "dvo_palette.h"
 
 namespace dvo {
 
@@ -436,18 +437,53 @@ hipError_t launch_canny(const unsigned char *grey, size_t stride, ImgBatch g, in
 /* ------------------------------------------------------------------------- */
 /* now-frame preprocessing after Canny: computeDistTransfrmOfNow (SolveDVO.cpp:1768-1795) +
  * imageGradient (:1063-1098).  edge mask -> exact squared EDT in integers (two separable passes)
- * -> sqrt -> min-max normalise to [0,255] (:1774) -> central differences with a
- * reflect-101 border (:1077-1090) -> tiled texels {DT,gx,gy,w}.                              */
+ * -> the level's COMPACT form (dvo_palette.h), natively:
+ *
+ *   DT = (float)sqrt(d2) * scale (cv::normalize NORM_MINMAX, :1774) is a non-decreasing function of the integer squared
+ *   distance d2, gx / gy are central differences of DT with a reflect-101 border (:1077-1090) and w = getWeightOf(DT)
+ *   (:1047-1053).  So the sorted list of the d2 values PRESENT in the image is the palette, and a pixel is the rank of its
+ *   d2 in that list.  The row pass records the values it produces in a presence bitmap (LDS, merged into HBM per workgroup);
+ *   the pack pass turns bitmap + prefix popcounts into ranks by one table look-up per pixel and writes the 4-byte rank words.
+ *   No hashing, no sorting, no verification pass -- the palette value, the weight and the gradients are produced by the very
+ *   expressions the 16-byte texel path uses (0.5*a - 0.5*b == 0.5*(a - b) bit for bit: scaling by 0.5 is exact), and the
+ *   16-byte texels {DT, gx, gy, w} are not written at all (17 instead of 45 bytes of HBM traffic per pixel); the inspection and
+ *   host-driven paths decode them from the compact form on demand (p4_decode_texels_kernel).
+ *
+ *   Images the compact form cannot hold -- more than DVO_PAL_MAX - 1 distinct distances, a pixel further than 511 pixels
+ *   from every edge, a rank step between horizontal neighbours beyond +-127 -- get their 16-byte texels from the same d2
+ *   (dt_normalize_gradient_pack_kernel, launched with a per-image predicate) and pal_n = -reason.                           */
 /* ------------------------------------------------------------------------- */
 #define DVO_EDT_INF(rows, cols) ((rows) + (cols) + 1)
+enum { EDT_FLAG_FAR = 1, EDT_FLAG_STEP = 2 };
 
-/* phase 1: per column, distance to the nearest edge pixel of that column; one wave per column,
- * 64 rows per step, nearest set bit of the ballot above / below each lane */
-__global__ void __launch_bounds__(64)
-edt_columns_kernel(const unsigned char *__restrict__ edge, size_t edge_stride, int rows, int cols, int *__restrict__ g) {
-    const int xx = blockIdx.x, lane = threadIdx.x;
+/* 32-bit words of one image's presence bitmap: every possible d2 of a small image, distances below 512 pixels otherwise */
+static inline int edt_bitmap_words(int rows, int cols) {
+    const long long inf = DVO_EDT_INF(rows, cols);
+    long long bits = inf * inf + 1;
+    if (bits > DVO_EDT_BITMAP_BITS) bits = DVO_EDT_BITMAP_BITS;
+    return (int)((bits + 31) / 32);
+}
+
+/* phase 1: per column, distance to the nearest edge pixel of that column (16 bits: <= rows+cols+1 < 46341); one wave per
+ * column, 64 rows per step, nearest set bit of the ballot above / below each lane.  The downward pass parks its result in
+ * LDS (each lane reads back what it wrote itself), so HBM sees one byte read and two bytes written per pixel.  The launch
+ * also clears the image's presence bitmap and flags for the row pass. */
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+edt_columns16_kernel(const unsigned char *__restrict__ edge, size_t edge_stride, int rows, int cols, unsigned short *__restrict__ g,
+                     unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags) {
+    extern __shared__ unsigned short s_da[];            /* [WAVES][rows] */
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        unsigned *bm = bitmap + (size_t)blockIdx.y * bm_words;
+        for (int i = blockIdx.x * (WAVES * 64) + threadIdx.x; i < bm_words; i += gridDim.x * (WAVES * 64)) bm[i] = 0u;
+        if (blockIdx.x == 0 && threadIdx.x == 0) flags[blockIdx.y] = 0;
+    }
+    const int xx = blockIdx.x * WAVES + wave;
+    if (xx >= cols) return;
     edge += (size_t)blockIdx.y * edge_stride;
     g += (size_t)blockIdx.y * rows * cols;
+    unsigned short *da_col = s_da + (size_t)wave * rows;
     const size_t base = (size_t)xx * rows;
     const int INF = DVO_EDT_INF(rows, cols);
     const int nchunk = (rows + 63) / 64;
@@ -460,7 +496,7 @@ edt_columns_kernel(const unsigned char *__restrict__ edge, size_t edge_stride, i
         int da;
         if (low) da = lane - (63 - __clzll((long long)low));
         else da = (carry >= INF) ? INF : carry + lane + 1;
-        if (yy < rows) g[base + yy] = da;
+        if (yy < rows) da_col[yy] = (unsigned short)(da > INF ? INF : da);
         if (m) carry = 63 - (63 - __clzll((long long)m));                 /* from lane 63 up to the highest edge */
         else carry = (carry >= INF) ? INF : carry + 64;
     }
@@ -473,95 +509,229 @@ edt_columns_kernel(const unsigned char *__restrict__ edge, size_t edge_stride, i
         int db;
         if (high) db = (__ffsll((long long)high) - 1) - lane;
         else db = (carry >= INF) ? INF : carry + (63 - lane) + 1;
-        if (yy < rows) { const int da = g[base + yy]; int v = da < db ? da : db; if (v > INF) v = INF; g[base + yy] = v; }
+        if (yy < rows) { const int da = da_col[yy]; int v = da < db ? da : db; if (v > INF) v = INF; g[base + yy] = (unsigned short)v; }
         if (m) carry = __ffsll((long long)m) - 1;                          /* from lane 0 down to the lowest edge */
         else carry = (carry >= INF) ? INF : carry + 64;
     }
 }
 
-/* phase 2: d2(x,y) = min_i (x-i)^2 + g(i,y)^2 along the row, exactly, in integers.  Each pixel scans outwards
- * while i^2 < best: with edges every few pixels that is a few dozen steps, far cheaper on a GPU than the sequential
- * lower-envelope scan (Meijster) a CPU would use -- same minimum.  A workgroup stages R whole rows of g in LDS
- * (16-bit: g <= rows+cols+1) so that the scan runs out of LDS, not L2; per-block maxima go to `partial`. */
+/* phase 2: d2(x,y) = min_i (x-i)^2 + g(i,y)^2 along the row, exactly, in integers (< 2^32 for every supported size).  Each
+ * pixel scans outwards while i^2 < best: with edges every few pixels that is a few dozen steps, far cheaper on a GPU than
+ * the sequential lower-envelope scan (Meijster) a CPU would use -- same minimum.  A workgroup stages R whole rows of g in
+ * LDS so that the scan runs out of LDS, not L2; per-block maxima go to `partial`; the values produced are recorded in the
+ * image's presence bitmap (an LDS copy first -- a bit is only set if it is not there yet, so the atomics die out after the
+ * first few pixels -- merged into HBM once per workgroup). */
+constexpr int EDT_LBITS_WORDS = 2048;               /* d2 < 65536 go through the LDS copy of the bitmap */
 template <int R>
 __global__ void __launch_bounds__(256)
-edt_rows_lds_kernel(const int *__restrict__ g, int rows, int cols, int *__restrict__ d2, int *__restrict__ partial) {
+edt_rows16_kernel(const unsigned short *__restrict__ g, int rows, int cols, unsigned *__restrict__ d2, int *__restrict__ partial,
+                  unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags) {
     extern __shared__ unsigned short tile[];                  /* [cols][R] */
+    __shared__ unsigned lbits[EDT_LBITS_WORDS];
     const size_t n = (size_t)rows * cols;
     g += (size_t)blockIdx.y * n; d2 += (size_t)blockIdx.y * n;
+    unsigned *bm = bitmap + (size_t)blockIdx.y * bm_words;
     const int y0 = blockIdx.x * R;
     const int total = cols * R;
+    for (int i = threadIdx.x; i < EDT_LBITS_WORDS; i += 256) lbits[i] = 0u;
     for (int idx = threadIdx.x; idx < total; idx += 256) {
         const int xx = idx / R, r = idx - xx * R, yy = y0 + r;
-        tile[idx] = (unsigned short)((yy < rows) ? g[(size_t)xx * rows + yy] : 0);
+        tile[idx] = (yy < rows) ? g[(size_t)xx * rows + yy] : (unsigned short)0;
     }
     __syncthreads();
-    int mx = 0;
+    unsigned mx = 0;
+    bool far = false;
     for (int idx = threadIdx.x; idx < total; idx += 256) {
         const int xx = idx / R, r = idx - xx * R, yy = y0 + r;
         if (yy >= rows) continue;
-        const int g0 = tile[idx];
-        int best = g0 * g0;                                   /* (rows+cols+1)^2 < 2^31 for every supported size */
+        const unsigned g0 = tile[idx];
+        unsigned best = g0 * g0;
         /* Branch-free steps: an index that leaves the row is clamped to its end.  The clamped candidate
          * i^2 + g(end)^2 can only exceed the one the end pixel produced at its true distance, so the minimum is
          * unchanged, and the loop needs no per-side exec masking. */
         const int imax = (xx > cols - 1 - xx) ? xx : cols - 1 - xx;
         const int base = idx - xx * R;                        /* LDS index of (column 0, this row) */
-        int i2 = 1;
+        unsigned i2 = 1;
         for (int i = 1; i2 < best && i <= imax; i++) {
             const int xl = (xx - i > 0) ? xx - i : 0, xr = (xx + i < cols - 1) ? xx + i : cols - 1;
-            const int gl = tile[base + xl * R], gr = tile[base + xr * R];
-            const int cl = i2 + gl * gl, cr = i2 + gr * gr;
+            const unsigned gl = tile[base + xl * R], gr = tile[base + xr * R];
+            const unsigned cl = i2 + gl * gl, cr = i2 + gr * gr;
             best = cl < best ? cl : best;
             best = cr < best ? cr : best;
             i2 += 2 * i + 1;
         }
         d2[(size_t)xx * rows + yy] = best;
         mx = best > mx ? best : mx;
-    }
-    mx = block_reduce_256<true>(mx);
-    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = mx;
-}
-
-/* fallback for rows too long for LDS: the same scan out of global memory */
-__global__ void __launch_bounds__(256)
-edt_rows_kernel(const int *__restrict__ g, int rows, int cols, int *__restrict__ d2, int *__restrict__ partial) {
-    const size_t n = (size_t)rows * cols;
-    g += (size_t)blockIdx.y * n; d2 += (size_t)blockIdx.y * n;
-    int mx = 0;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
-        const int xx = (int)(idx / rows);
-        const int g0 = g[idx];
-        int best = g0 * g0;
-        for (int i = 1; i * i < best; i++) {
-            const bool l = xx - i >= 0, r = xx + i < cols;
-            if (!l && !r) break;
-            if (l) { const int gl = g[idx - (size_t)i * rows]; const int c = i * i + gl * gl; best = c < best ? c : best; }
-            if (r) { const int gr = g[idx + (size_t)i * rows]; const int c = i * i + gr * gr; best = c < best ? c : best; }
+        const unsigned w = best >> 5, bit = 1u << (best & 31u);
+        if (w < (unsigned)EDT_LBITS_WORDS) {
+            if (!(*(volatile unsigned *)&lbits[w] & bit)) atomicOr(&lbits[w], bit);
+        } else if (w < (unsigned)bm_words) {
+            if (!(__hip_atomic_load(bm + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(bm + w, bit);
+        } else {
+            far = true;
         }
-        d2[idx] = best;
-        mx = best > mx ? best : mx;
     }
-    mx = block_reduce_256<true>(mx);
-    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = mx;
+    const int m = block_reduce_256<true>((int)(mx > 0x7fffffffu ? 0x7fffffffu : mx));    /* d2 < 2^31 (rows + cols < 46340) */
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = m;
+    __syncthreads();
+    for (int w = threadIdx.x; w < EDT_LBITS_WORDS && w < bm_words; w += 256) {
+        const unsigned v = lbits[w];
+        if (v && (__hip_atomic_load(bm + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v) atomicOr(bm + w, v);
+    }
+    if (__syncthreads_or(far ? 1 : 0) && threadIdx.x == 0) atomicOr(flags + blockIdx.y, (int)EDT_FLAG_FAR);
 }
 
 DVO_DEV int reflect101(int i, int n) { return (n == 1) ? 0 : (i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i)); }
 
-/* squared distances -> texels in one pass: min-max normalise to [0,255] (cv::normalize NORM_MINMAX, :1774; an image
- * without any edge pixel -- every distance "infinite" -- normalises to all zeros, as a constant image does), central
- * differences with a reflect-101 border (:1077-1090), weight, tiled store.  One 64 (yy) x 16 (xx) tile per workgroup:
- * the normalised values of the tile and its 1-pixel halo are computed once into LDS (one double sqrt per pixel); the
- * lanes are then mapped so that 8 consecutive lanes write one whole 128-byte texel tile. */
+/* cv::normalize(0, 255, NORM_MINMAX) of sqrt(d2) with OpenCV 2.4's arithmetic: min = 0 (an edge pixel), max = sqrt(m2);
+ * scale and shift in double, then convertTo's 32F -> 32F kernel (cvtScale32f, core/src/convert.cpp) in FLOAT:
+ * dst = src*(float)scale + (float)shift.  An image without any edge pixel -- every distance "infinite" -- normalises to all
+ * zeros, as a constant image does. */
+struct EdtScale { float scale_f, shift_f; };
+DVO_DEV EdtScale edt_scale(unsigned m2, int rows, int cols) {
+    const long long INF = DVO_EDT_INF(rows, cols);
+    const float mxf = (float)sqrt((double)m2), mnf = 0.0f;
+    const double smin = (double)mnf, smax = (double)mxf;
+    const double scale_d = ((long long)m2 < INF * INF) ? 255.0 * ((smax - smin > 2.2204460492503131e-16) ? 1. / (smax - smin) : 0.) : 0.;
+    EdtScale s;
+    s.scale_f = (float)scale_d; s.shift_f = (float)(0.0 - smin * scale_d);
+    return s;
+}
+DVO_DEV float edt_value(unsigned d2v, const EdtScale &s) {
+    const float raw = (float)sqrt((double)d2v);
+    return raw * s.scale_f + s.shift_f;
+}
+
+/* phase 3: squared distances -> rank words + palette.  One workgroup per tile of PK_LC x PK_LR lines of the compact image
+ * (64 x 48 pixels).  Every workgroup rebuilds the image's rank table from the presence bitmap in LDS (a few hundred words
+ * for ordinary images: prefix popcounts), looks up the rank of every pixel of its tile and of a one-pixel halo (reflect-101 at
+ * the image border: cv::filter2D's default), and writes the tile's words -- own rank, signed rank steps to the horizontal
+ * neighbours, the apron rows above and below.  Workgroup 0 of an image also writes the palette {P, W} (the 16-byte path's
+ * expressions: edt_value, weight_of), the sentinel entry and line, and pal_n. */
+constexpr int PK_LC = 16, PK_LR = 8;
+constexpr int PK_W = PK_LC * 4 + 2, PK_H = PK_LR * DVO_P4_ROWS + 2;
+__global__ void __launch_bounds__(256)
+edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int tiles_y, const int *__restrict__ partial, int n_partial,
+                     const unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags,
+                     unsigned *__restrict__ p4, size_t p4_stride, float2 *__restrict__ pal, int *__restrict__ pal_n, int first_pair) {
+    __shared__ unsigned lbm[DVO_EDT_BITMAP_BITS / 32];
+    __shared__ unsigned short lpre[DVO_EDT_BITMAP_BITS / 32];
+    __shared__ unsigned short rk[PK_W * PK_H];                  /* [x][y], halo 1 */
+    __shared__ int s_scan[256];
+    __shared__ int s_max;
+    const int tid = threadIdx.x;
+    const int pair = first_pair + blockIdx.y;
+    const size_t n = (size_t)rows * cols;
+    d2 += (size_t)blockIdx.y * n;
+    partial += (size_t)blockIdx.y * n_partial;
+    const unsigned *bm = bitmap + (size_t)blockIdx.y * bm_words;
+    p4 += (size_t)pair * p4_stride;
+    pal += (size_t)pair * DVO_PAL_MAX;
+    const bool first_wg = blockIdx.x == 0;
+    if (rows < 2 || cols < 2) { if (first_wg && tid == 0) pal_n[pair] = -(int)PAL_SHAPE; return; }
+    if (flags[blockIdx.y] & EDT_FLAG_FAR) { if (first_wg && tid == 0) pal_n[pair] = -(int)PAL_FAR; return; }
+    int m = 0;
+    for (int k = tid; k < n_partial; k += 256) { const int v = partial[k]; m = v > m ? v : m; }
+    m = block_reduce_256<true>(m);
+    if (tid == 0) s_max = m;
+    __syncthreads();
+    const unsigned m2 = (unsigned)s_max;
+    const int nw = (int)(m2 >> 5) + 1;                          /* <= bm_words: no FAR flag */
+    const int per = (nw + 255) / 256;
+    const int w0 = tid * per, w1 = (w0 + per < nw) ? w0 + per : nw;
+    int cnt = 0;
+    for (int w = w0; w < w1; w++) { const unsigned v = bm[w]; lbm[w] = v; cnt += __popc(v); }
+    s_scan[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {                   /* Hillis-Steele inclusive scan */
+        const int v = (tid >= off) ? s_scan[tid - off] : 0;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    const int n_pal = s_scan[255];
+    if (n_pal > DVO_PAL_MAX - 1) { if (first_wg && tid == 0) pal_n[pair] = -(int)PAL_TOO_MANY; return; }
+    {
+        int run = (tid == 0) ? 0 : s_scan[tid - 1];
+        for (int w = w0; w < w1; w++) { lpre[w] = (unsigned short)run; run += __popc(lbm[w]); }
+    }
+    __syncthreads();
+    if (first_wg) {
+        const EdtScale sc = edt_scale(m2, rows, cols);
+        for (int w = w0; w < w1; w++) {
+            unsigned v = lbm[w];
+            int r = lpre[w];
+            while (v) {
+                const int b = __ffs((int)v) - 1;
+                v &= v - 1u;
+                const float P = edt_value((unsigned)(w * 32 + b), sc);
+                pal[r++] = make_float2(P, weight_of(P));         /* getWeightOf, SolveDVO.cpp:1047-1053 */
+            }
+        }
+        if (tid == 0) pal[n_pal] = make_float2(0.0f, 0.0f);      /* the sentinel entry */
+        if (tid < 32) p4[tid] = (unsigned)n_pal << 3;            /* the sentinel line */
+    }
+    auto rank_of = [&](unsigned v) -> int { return (int)lpre[v >> 5] + __popc(lbm[v >> 5] & ((1u << (v & 31u)) - 1u)); };
+    const int tpc = p4_tiles_per_col(rows);
+    const int ty0 = (blockIdx.x % tiles_y) * PK_LR, tc0 = (blockIdx.x / tiles_y) * PK_LC;
+    const int y0 = ty0 * DVO_P4_ROWS - 1, x0 = tc0 * 4 - 1;     /* image coordinates of rk[0][0] */
+    for (int idx = tid; idx < PK_W * PK_H; idx += 256) {
+        const int lx = idx / PK_H, ly = idx - lx * PK_H;
+        int yy = y0 + ly, xx = x0 + lx;
+        int r = 0;
+        if (yy <= rows && xx <= cols) {                          /* one pixel beyond the image is the reflected neighbour */
+            yy = reflect101(yy, rows); xx = reflect101(xx, cols);
+            r = rank_of(d2[(size_t)xx * rows + yy]);
+        }
+        rk[idx] = (unsigned short)r;
+    }
+    __syncthreads();
+    bool bad_step = false;
+    const int n_tcols = (cols + 3) >> 2;
+    for (int s = tid; s < PK_LC * PK_LR * 32; s += 256) {
+        /* consecutive lanes -> consecutive words of a line, consecutive lines of a column of lines: contiguous in memory */
+        const int lc = s / (PK_LR * 32), rem = s - lc * (PK_LR * 32);
+        const int lr = rem >> 5, wd = rem & 31, xl = wd >> 3, srow = wd & 7;
+        const int tc = tc0 + lc, ty = ty0 + lr;
+        if (tc >= n_tcols || ty >= tpc) continue;
+        const int xx = tc * 4 + xl, ys = ty * DVO_P4_ROWS + srow - 1;    /* image row this slot stands for (-1 / rows: reflected) */
+        unsigned word = 0u;
+        if (xx < cols && ys <= rows) {
+            const int lx = xx - x0, ly = ys - y0;
+            const int c = rk[lx * PK_H + ly];
+            word = (unsigned)c << 3;
+            if (srow >= 1 && srow <= DVO_P4_ROWS && ys < rows) {
+                const int dr = (int)rk[(lx + 1) * PK_H + ly] - c, dl = (int)rk[(lx - 1) * PK_H + ly] - c;
+                if (dr < -127 || dr > 127 || dl < -127 || dl > 127) bad_step = true;
+                word |= (((unsigned)dr & 0xffu) << 16) | (((unsigned)dl & 0xffu) << 24);
+            }
+        }
+        p4[32u + ((size_t)tc * tpc + ty) * 32u + wd] = word;
+    }
+    if (__syncthreads_or(bad_step ? 1 : 0) && tid == 0) atomicOr(flags + blockIdx.y, (int)EDT_FLAG_STEP);
+    if (first_wg && tid == 0) pal_n[pair] = n_pal;               /* EDT_FLAG_STEP overrides it in the fallback launch */
+}
+
+/* squared distances -> 16-byte texels in one pass (images without a compact form; everything when the caller wants no compact
+ * form at all): min-max normalise, central differences with a reflect-101 border (:1077-1090), weight, tiled store.  One
+ * 64 (yy) x 16 (xx) tile per workgroup: the normalised values of the tile and its 1-pixel halo are computed once into LDS
+ * (one double sqrt per pixel); the lanes are then mapped so that 8 consecutive lanes write one whole 128-byte texel tile. */
 constexpr int NP_TY = 64, NP_TX = 16;
 static_assert(DVO_TILE_Y_LOG2 == 2 && DVO_TILE_X_LOG2 == 1, "the store mapping below assumes 4 x 2 texel tiles");
 __global__ void __launch_bounds__(256)
-dt_normalize_gradient_pack_kernel(const int *__restrict__ d2, int rows, int cols, int tiles_y,
+dt_normalize_gradient_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int tiles_y,
                                   const int *__restrict__ partial, int n_partial,
-                                  float4 *__restrict__ out, size_t tex_stride) {
+                                  float4 *__restrict__ out, size_t tex_stride,
+                                  int *__restrict__ pal_n /* NULL: every image */, const int *__restrict__ flags, int first_pair) {
     constexpr int SH = NP_TY + 2, SW = NP_TX + 2;
     __shared__ float sn[SW * SH];                            /* [x][y], halo 1 */
     __shared__ int s_max;
+    if (pal_n) {                                             /* only the images the compact form could not hold */
+        const int pair = first_pair + blockIdx.y;
+        const bool step = (flags[blockIdx.y] & EDT_FLAG_STEP) != 0;
+        if (pal_n[pair] > 0 && !step) return;
+        if (step && blockIdx.x == 0 && threadIdx.x == 0) pal_n[pair] = -(int)PAL_STEP;   /* the other workgroups read the flag, not this */
+    }
     const size_t n = (size_t)rows * cols;
     d2 += (size_t)blockIdx.y * n;
     partial += (size_t)blockIdx.y * n_partial;
@@ -571,14 +741,7 @@ dt_normalize_gradient_pack_kernel(const int *__restrict__ d2, int rows, int cols
     m = block_reduce_256<true>(m);
     if (threadIdx.x == 0) s_max = m;
     __syncthreads();
-    const int INF = DVO_EDT_INF(rows, cols);
-    const int m2 = s_max;
-    const float mxf = (float)sqrt((double)m2), mnf = 0.0f;
-    /* cv::normalize(0, 255, NORM_MINMAX) with OpenCV 2.4's arithmetic: scale and shift in double, then convertTo's 32F -> 32F
-     * kernel (cvtScale32f, core/src/convert.cpp) in FLOAT: dst = src*(float)scale + (float)shift */
-    const double smin = (double)mnf, smax = (double)mxf;
-    const double scale_d = (m2 < INF * INF) ? 255.0 * ((smax - smin > 2.2204460492503131e-16) ? 1. / (smax - smin) : 0.) : 0.;
-    const float scale_f = (float)scale_d, shift_f = (float)(0.0 - smin * scale_d);
+    const EdtScale sc = edt_scale((unsigned)s_max, rows, cols);
     const int y0 = (blockIdx.x % tiles_y) * NP_TY, x0 = (blockIdx.x / tiles_y) * NP_TX;
     for (int idx = threadIdx.x; idx < SW * SH; idx += 256) {
         const int lx = idx / SH, ly = idx - lx * SH;
@@ -586,8 +749,7 @@ dt_normalize_gradient_pack_kernel(const int *__restrict__ d2, int rows, int cols
         float v = 0.0f;
         if (yy <= rows && xx <= cols) {                      /* one pixel beyond the image is the reflected neighbour */
             yy = reflect101(yy, rows); xx = reflect101(xx, cols);
-            const float raw = (float)sqrt((double)d2[(size_t)xx * rows + yy]);
-            v = raw * scale_f + shift_f;
+            v = edt_value(d2[(size_t)xx * rows + yy], sc);
         }
         sn[idx] = v;
     }
@@ -608,39 +770,105 @@ dt_normalize_gradient_pack_kernel(const int *__restrict__ d2, int rows, int cols
     }
 }
 
-static int edt_rows_per_block(int rows, int cols) {   /* LDS rows per workgroup; 0 = row too long, use the global-memory scan */
-    if (rows + cols + 1 > 65535) return 0;            /* g would not fit 16 bits */
-    if ((size_t)cols * 16 * 2 <= 64 * 1024) return 16;
-    if ((size_t)cols * 8 * 2 <= 64 * 1024) return 8;
-    if ((size_t)cols * 4 * 2 <= 64 * 1024) return 4;
-    return 0;
+/* compact form -> 16-byte texels {DT, gx, gy, w} of the images that have one (pal_n > 0), decoded exactly as the fused kernel
+ * decodes a pixel (dvo_fused.hip, p4_decode2).  For the inspection and host-driven paths, which read the texels. */
+__global__ void __launch_bounds__(256)
+p4_decode_texels_kernel(const unsigned *__restrict__ p4, size_t p4_stride, const float2 *__restrict__ pal, const int *__restrict__ pal_n,
+                        float4 *__restrict__ tex, size_t tex_stride, int rows, int cols, int first_pair) {
+    const int pair = first_pair + blockIdx.y;
+    if (pal_n[pair] <= 0) return;
+    p4 += (size_t)pair * p4_stride;
+    pal += (size_t)pair * DVO_PAL_MAX;
+    tex += (size_t)pair * tex_stride;
+    const int tpc = p4_tiles_per_col(rows), tpc16 = texel_tiles_per_col(rows);
+    const size_t n = (size_t)rows * cols;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(p / rows), yy = (int)(p - (size_t)xx * rows);
+        const int ty = yy / DVO_P4_ROWS;
+        const size_t slot = p4_slot(ty, yy - ty * DVO_P4_ROWS + 1, xx, tpc);
+        const unsigned wu = p4[slot - 1], wc = p4[slot], wd = p4[slot + 1];
+        const int c = (int)((wc >> 3) & 0x1fffu);
+        const int r = c + (int)(signed char)((wc >> 16) & 0xffu), l = c + (int)(signed char)(wc >> 24);
+        const float2 pc = pal[c];
+        const float pr = pal[r].x, pl = pal[l].x, pu = pal[(wu >> 3) & 0x1fffu].x, pd = pal[(wd >> 3) & 0x1fffu].x;
+        tex[texel_index(yy, xx, tpc16)] = make_float4(pc.x, (pr - pl) * 0.5f, (pd - pu) * 0.5f, pc.y);
+    }
 }
-static unsigned edt_row_blocks(int rows, int cols) {
-    const int R = edt_rows_per_block(rows, cols);
-    return R ? (unsigned)((rows + R - 1) / R) : grid_x((size_t)rows * cols);
-}
-size_t edt_work_ints(int rows, int cols, int count) { return (2 * (size_t)rows * cols + edt_row_blocks(rows, cols)) * count; }
-
-hipError_t launch_edges_to_texels(const unsigned char *edge, size_t edge_stride, ImgBatch gb, int *work,
-                                  float4 *tex_out, size_t tex_stride, hipStream_t s) {
-    const size_t n = (size_t)gb.rows * gb.cols, nb = n * gb.count;
-    int *g = work, *d2 = work + nb, *partial = work + 2 * nb;
-    const dim3 grid(grid_x(n), gb.count);
-    const int R = edt_rows_per_block(gb.rows, gb.cols);
-    const unsigned nblk = edt_row_blocks(gb.rows, gb.cols);
-    hipLaunchKernelGGL(edt_columns_kernel, dim3(gb.cols, gb.count), dim3(64), 0, s, edge, edge_stride, gb.rows, gb.cols, g);
-    const size_t lds = (size_t)gb.cols * R * 2;
-    if (R == 16) hipLaunchKernelGGL(edt_rows_lds_kernel<16>, dim3(nblk, gb.count), dim3(256), lds, s, g, gb.rows, gb.cols, d2, partial);
-    else if (R == 8) hipLaunchKernelGGL(edt_rows_lds_kernel<8>, dim3(nblk, gb.count), dim3(256), lds, s, g, gb.rows, gb.cols, d2, partial);
-    else if (R == 4) hipLaunchKernelGGL(edt_rows_lds_kernel<4>, dim3(nblk, gb.count), dim3(256), lds, s, g, gb.rows, gb.cols, d2, partial);
-    else hipLaunchKernelGGL(edt_rows_kernel, grid, dim3(256), 0, s, g, gb.rows, gb.cols, d2, partial);
-    const int tiles_y = (gb.rows + NP_TY - 1) / NP_TY, tiles_x = (gb.cols + NP_TX - 1) / NP_TX;
-    hipLaunchKernelGGL(dt_normalize_gradient_pack_kernel, dim3(tiles_y * tiles_x, gb.count), dim3(256), 0, s, d2, gb.rows, gb.cols,
-                       tiles_y, partial, (int)nblk, tex_out, tex_stride);
+hipError_t launch_p4_decode_texels(const unsigned *p4, size_t p4_stride, const float2 *pal, const int *pal_n, float4 *tex,
+                                   size_t tex_stride, int rows, int cols, int first_pair, int count, hipStream_t s) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(p4_decode_texels_kernel, dim3(grid_x((size_t)rows * cols, 256), count), dim3(256), 0, s, p4, p4_stride, pal, pal_n,
+                       tex, tex_stride, rows, cols, first_pair);
     return hipGetLastError();
 }
-hipError_t launch_now_level_from_edges(const unsigned char *edge, int rows, int cols, int *work, float4 *tex_out, hipStream_t s) {
-    return launch_edges_to_texels(edge, 0, ImgBatch{rows, cols, 1}, work, tex_out, 0, s);
+
+static int edt_rows_per_block(int cols) {             /* LDS rows per workgroup of the row pass (16-bit g) */
+    for (int R = 16; R > 1; R >>= 1)
+        if ((size_t)cols * R * 2 <= 64 * 1024) return R;
+    return 1;                                         /* cols < 46340: at most 91 KiB */
+}
+static unsigned edt_row_blocks(int rows, int cols) { const int R = edt_rows_per_block(cols); return (unsigned)((rows + R - 1) / R); }
+/* scratch of one launch_edges_to_now over `count` images, in ints: g (16 bit) | d2 | per-block maxima | bitmaps | flags */
+size_t edt_work_ints(int rows, int cols, int count) {
+    const size_t n = (size_t)rows * cols;
+    return ((n + 1) / 2 + 4 + n + edt_row_blocks(rows, cols) + (size_t)edt_bitmap_words(rows, cols) + 1) * count + 64;
+}
+
+template <int R>
+static hipError_t edt_rows_launch(const unsigned short *g, ImgBatch gb, unsigned nblk, unsigned *d2, int *partial, unsigned *bitmap,
+                                  int bm_words, int *flags, hipStream_t s) {
+    const size_t lds = (size_t)gb.cols * R * 2;
+    auto kern = edt_rows16_kernel<R>;
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblk, gb.count), dim3(256), lds, s, g, gb.rows, gb.cols, d2, partial, bitmap, bm_words, flags);
+    return hipGetLastError();
+}
+
+/* edge masks -> resident now levels of pairs first_pair .. first_pair + count - 1.  With p4 != NULL the compact form is what is
+ * written (16-byte texels only for the images it cannot hold); with p4 == NULL the 16-byte texels of every image. */
+hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, ImgBatch gb, int *work,
+                               float4 *tex_out, size_t tex_stride, unsigned *p4, size_t p4_stride, float2 *pal, int *pal_n,
+                               int first_pair, hipStream_t s) {
+    const size_t n = (size_t)gb.rows * gb.cols;
+    const int R = edt_rows_per_block(gb.cols);
+    const unsigned nblk = edt_row_blocks(gb.rows, gb.cols);
+    const int bm_words = edt_bitmap_words(gb.rows, gb.cols);
+    /* carve the scratch: 4-byte aligned sections */
+    unsigned short *g = reinterpret_cast<unsigned short *>(work);
+    unsigned *d2 = reinterpret_cast<unsigned *>(work) + (((n * gb.count + 1) / 2 + 3) & ~(size_t)3);
+    int *partial = reinterpret_cast<int *>(d2 + n * gb.count);
+    unsigned *bitmap = reinterpret_cast<unsigned *>(partial + (size_t)nblk * gb.count);
+    int *flags = reinterpret_cast<int *>(bitmap + (size_t)bm_words * gb.count);
+    hipError_t e;
+    if (gb.rows <= 8192) {
+        hipLaunchKernelGGL(edt_columns16_kernel<4>, dim3((gb.cols + 3) / 4, gb.count), dim3(256), (size_t)gb.rows * 4 * 2, s, edge, edge_stride,
+                           gb.rows, gb.cols, g, bitmap, bm_words, flags);
+    } else {
+        auto kern = edt_columns16_kernel<1>;
+        if ((e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, gb.rows * 2)) != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(gb.cols, gb.count), dim3(64), (size_t)gb.rows * 2, s, edge, edge_stride, gb.rows, gb.cols, g, bitmap,
+                           bm_words, flags);
+    }
+    switch (R) {
+    case 16: e = edt_rows_launch<16>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
+    case 8: e = edt_rows_launch<8>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
+    case 4: e = edt_rows_launch<4>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
+    case 2: e = edt_rows_launch<2>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
+    default: e = edt_rows_launch<1>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
+    }
+    if (e != hipSuccess) return e;
+    if (p4) {
+        const int ptiles_y = (p4_tiles_per_col(gb.rows) + PK_LR - 1) / PK_LR, ptiles_x = (((gb.cols + 3) >> 2) + PK_LC - 1) / PK_LC;
+        hipLaunchKernelGGL(edt_rank_pack_kernel, dim3(ptiles_y * ptiles_x, gb.count), dim3(256), 0, s, d2, gb.rows, gb.cols, ptiles_y, partial,
+                           (int)nblk, bitmap, bm_words, flags, p4, p4_stride, pal, pal_n, first_pair);
+    }
+    const int tiles_y = (gb.rows + NP_TY - 1) / NP_TY, tiles_x = (gb.cols + NP_TX - 1) / NP_TX;
+    hipLaunchKernelGGL(dt_normalize_gradient_pack_kernel, dim3(tiles_y * tiles_x, gb.count), dim3(256), 0, s, d2, gb.rows, gb.cols,
+                       tiles_y, partial, (int)nblk, tex_out, tex_stride, p4 ? pal_n : nullptr, flags, first_pair);
+    return hipGetLastError();
 }
 
 /* ------------------------------------------------------------------------- */

@@ -27,6 +27,8 @@
 #include "dvo_point_pk.h"
 #include "dvo_palette.h"
 
+#include <cstdlib>
+
 /* rounds of gathers in flight in the compact-form loop.  Measured (640x480x4x10, 1024 pairs): two 256-thread workgroups per
  * CU 555 k aligns/s at depth 2, 593 k at depth 3; one 512-thread workgroup 517 k / 510 k (its serial phases are exposed, not
  * its gathers) */
@@ -238,7 +240,11 @@ DVO_DEV void round2_compute(const IterConst &c, const Round2<TEX> &b, Acc7 &a) {
         a.nvis += __popcll(__builtin_amdgcn_ballot_w64(b.vis0)) + __popcll(__builtin_amdgcn_ballot_w64(b.vis1));
         eps0 = b.vis0 ? b.t0.x : 0.0f; eps1 = b.vis1 ? b.t1.x : 0.0f;
         const float w0 = b.vis0 ? b.t0.w : 0.0f, w1 = b.vis1 ? b.t1.w : 0.0f;
-        jacobian_weighted2(c, b.xn, b.yn, b.zn, b.t0.y, b.t1.y, b.t0.z, b.t1.z, w0, w1, jw);
+        /* a lane without a visible point gathered texel 0 of the level: its gradient must not reach the sums either (a caller-
+         * supplied image may hold Inf / NaN there, and NaN * 0 is NaN; the reference skips such points, :371) */
+        const float gx0 = b.vis0 ? b.t0.y : 0.0f, gx1 = b.vis1 ? b.t1.y : 0.0f;
+        const float gy0 = b.vis0 ? b.t0.z : 0.0f, gy1 = b.vis1 ? b.t1.z : 0.0f;
+        jacobian_weighted2(c, b.xn, b.yn, b.zn, gx0, gx1, gy0, gy1, w0, w1, jw);
     }
     const double e0 = (double)eps0, e1 = (double)eps1;
 #pragma unroll
@@ -313,11 +319,22 @@ DVO_DEV void accumulate_points2(const IterConst &c, const TexSrc &ts, const LdsP
 #undef DVO_COMPUTE
 }
 
+/* {DT, gx, gy, w} of pixel (yy, xx) from the compact form: the scalar twin of p4_decode2 (cold paths only) */
+DVO_DEV float4 p4_texel(const TexSrc &ts, const float2 *pal_lds, int yy, int xx) {
+    const U3 w = *reinterpret_cast<const U3 *>(ts.p4 + p4_byte_offset(yy, xx, ts.p4_col_bytes));
+    const int c = (int)((w.b >> 3) & 0x1fffu);
+    const int cr = c + __builtin_amdgcn_sbfe((int)w.b, 16, 8), cl = c + (((int)w.b) >> 24);
+    const float2 pc = pal_lds[c];
+    const float pr = pal_lds[cr].x, pl = pal_lds[cl].x, pu = pal_lds[(w.a >> 3) & 0x1fffu].x, pd = pal_lds[(w.c >> 3) & 0x1fffu].x;
+    return make_float4(pc.x, (pr - pl) * 0.5f, (pd - pu) * 0.5f, pc.y);
+}
+
 /* The same sums with the literal-division scalar code (dvo_device_math.h: project_point, jacobian_row) over THIS wave's
- * points of [first, end) -- taken only when one of them has a degenerate z.  Plain loop, not pipelined: never hot. */
-template <int BLOCK, bool LDS_SRC>
-DVO_DEV void accumulate_points_exact(const IterConst &c, const char *__restrict__ tex, const LdsPoints &lp,
-                                                     const uint2 *__restrict__ gpts, int first, int end, int lane_off, Acc7 &a) {
+ * points of [first, end) -- taken only when one of them has a degenerate z.  Plain loop, not pipelined: never hot.
+ * P4: the level is read through its compact form (the 16-byte texels of such a level may not exist). */
+template <int BLOCK, bool LDS_SRC, bool P4>
+DVO_DEV void accumulate_points_exact(const IterConst &c, const char *__restrict__ tex, const TexSrc &ts, const float2 *pal_lds,
+                                     const LdsPoints &lp, const uint2 *__restrict__ gpts, int first, int end, int lane_off, Acc7 &a) {
     for (int i = first + lane_off; __builtin_amdgcn_ballot_w64(i < end) != 0ull; i += BLOCK) {
         const bool valid = i < end;
         unsigned k; float z;
@@ -327,7 +344,8 @@ DVO_DEV void accumulate_points_exact(const IterConst &c, const char *__restrict_
         const bool vis = project_point(c, X, Y, Z, xn, yn, zn, u, v) && valid;
         a.nvis += __popcll(__builtin_amdgcn_ballot_w64(vis));
         if (vis) {
-            const float4 t = reinterpret_cast<const float4 *>(tex)[texel_index((int)v, (int)u, c.tiles_per_col)];
+            const float4 t = P4 ? p4_texel(ts, pal_lds, (int)v, (int)u)
+                                : reinterpret_cast<const float4 *>(tex)[texel_index((int)v, (int)u, c.tiles_per_col)];
             float J[6], jw[6];
             jacobian_row(c, xn, yn, zn, t.y, t.z, J);
 #pragma unroll
@@ -409,8 +427,13 @@ DVO_DEV void team_exchange(double *tot, v4u *buf /* this pair's [2][DVO_TEAM_MAX
     }
     const int n_rec = G * 8;                       /* <= 256: lane L polls records L, L + 64, L + 128, L + 192 */
     v4u r[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) r[q] = v4u{0u, 0u, 0u, 0u};
     int spins = 0;
-    for (;;) {
+    /* a member of this launch already gave up (not co-resident): the results are void and reported as such by every output
+     * getter -- do not spin seconds again at each of the remaining exchanges */
+    const bool dead = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    for (; !dead;) {
         bool ok = true;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -544,14 +567,16 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         const int tex16_words = (int)(L.tex_stride * 4);
         /* the compact form of this pair's level, if the builder could make one (dvo_palette.h): its palette goes first */
         const int n_pal = (!sc.no_p4 && L.pal_n) ? max(0, __builtin_amdgcn_readfirstlane(L.pal_n[dpair])) : 0;
-        const int mode = (!TEAM && !sc.no_lds_tex && 2 * n_pad + tex16_words <= lds_words) ? TEX_L16
-                         : ((n_pal > 0 && pal_base_ok && 2 * n_pal + 6 <= lds_words) ? TEX_P4 : TEX_G16);
+        /* the compact form first: a now level written by the engine's own distance-transform stage has no other (its 16-byte
+         * texels exist only once something asked for them, dvo_capi.cpp: ensure_tex16) */
+        const int mode = (n_pal > 0 && pal_base_ok && 2 * n_pal + 6 <= lds_words) ? TEX_P4
+                         : ((!TEAM && !sc.no_lds_tex && 2 * n_pad + tex16_words <= lds_words) ? TEX_L16 : TEX_G16);
         const int pal_words = (mode == TEX_P4) ? ((2 * (n_pal + 1) + 3) & ~3) : 0;           /* + the sentinel entry {0, 0} */
         float *const lds_pts = lds_dyn + pal_words;
         const int cap = (mode == TEX_L16) ? n_pad : (((lds_words - pal_words) >> 1) & ~1);          /* points the LDS holds (8 bytes each) */
         const int n_lds = (N <= cap) ? N : (cap / (2 * BLOCK)) * (2 * BLOCK);      /* whole rounds only */
         float *const lds_tex = lds_pts + 2 * cap;
-        if (tid == 0 && member == 0) out.tex_mode[pair * DVO_LEVELS + l] = mode;
+        if (tid == 0) st.exact_ran = 0;
         if (mode == TEX_P4) {
             const float2 *__restrict__ pg = L.pal + (size_t)dpair * DVO_PAL_MAX;
             float2 *pl = reinterpret_cast<float2 *>(lds_dyn);
@@ -636,8 +661,15 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             }
             if (any_odd || sc.force_exact) {      /* wave-uniform; a point with a degenerate z: this wave's share again, literal divisions */
                 acc7_zero(a);
-                accumulate_points_exact<BLOCK, true>(c, tex, lp, gpts, 0, n_lds, lane_off, a);
-                accumulate_points_exact<BLOCK, false>(c, tex, lp, gpts, n_lds, N, lane_off, a);
+                const float2 *pal_lds = reinterpret_cast<const float2 *>(lds_dyn);
+                if (mode == TEX_P4) {
+                    accumulate_points_exact<BLOCK, true, true>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
+                    accumulate_points_exact<BLOCK, false, true>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
+                } else {
+                    accumulate_points_exact<BLOCK, true, false>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
+                    accumulate_points_exact<BLOCK, false, false>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
+                }
+                if ((tid & 63) == 0) st.exact_ran = 1;          /* inspection: dvo_get_level_texel_mode reports it (tests) */
             }
             DVO_STAMP(t1);
             block_reduce7<BLOCK>(a, red, tot);
@@ -727,6 +759,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             if (member == 0) {
                 out.best_idx[pair * DVO_LEVELS + l] = st.bestItr;
                 out.ratio[pair * DVO_LEVELS + l] = st.bestRatio;
+                out.tex_mode[pair * DVO_LEVELS + l] = mode | (st.exact_ran ? DVO_TEXMODE_EXACT_RAN : 0);
             }
         }
         __syncthreads();
@@ -753,7 +786,22 @@ static hipError_t launch_fused2_b(const LevelSet &lv, const Schedule &sc, const 
         auto kern = align_fused2_kernel<BLOCK, true>;
         if ((e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)) != hipSuccess) return e;
         const int grid = (sc.team > DVO_TEAM_MAX) ? sc.team : 8 * ((n_pairs + 7) / 8) * sc.team;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), dyn, s, lv, sc, K, prm, out, first_pair);
+        /* The members of a team wait for each other inside the kernel, so ALL workgroups of the launch must be resident at
+         * once.  A cooperative launch makes the runtime guarantee exactly that -- or refuse the launch (the host then runs the
+         * batch without teams) -- whatever else the process has on the GPU: another context, another stream, a kernel of
+         * the caller's holding LDS.  (DVO_TEAM_PLAIN_LAUNCH=1: the plain launch of round 2, for A/B measurements; a team
+         * that is not co-resident then ends in the bounded spin's error flag.) */
+        static const bool plain = std::getenv("DVO_TEAM_PLAIN_LAUNCH") != nullptr;
+        if (plain) {
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), dyn, s, lv, sc, K, prm, out, first_pair);
+        } else {
+            LevelSet a0 = lv; Schedule a1 = sc; Intrinsics a2 = K; DevParams a3 = prm; Outputs a4 = out; int a5 = first_pair;
+            void *args[] = {&a0, &a1, &a2, &a3, &a4, &a5};
+            if ((e = hipLaunchCooperativeKernel((const void *)kern, dim3(grid), dim3(BLOCK), args, (unsigned)dyn, s)) != hipSuccess) {
+                (void)hipGetLastError();
+                return e;
+            }
+        }
     } else {
         auto kern = align_fused2_kernel<BLOCK, false>;
         if ((e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)) != hipSuccess) return e;

@@ -24,6 +24,7 @@
  * CPU oracle depends on it.
  */
 #include "dvo_kernel_common.h"
+#include "dvo_palette.h"
 
 namespace dvo {
 
@@ -187,10 +188,12 @@ replicate_level_kernel(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, 
     const int p = dst_first + blockIdx.y;
     const int src = blockIdx.y % n_src;
     if (p == src) return;
-    const float4 *st = tex + (size_t)src * tex_stride;
-    float4 *dt = tex + (size_t)p * tex_stride;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tex_stride; i += stride) dt[i] = st[i];
+    if (tex) {                                       /* NULL: no source holds 16-byte texels (compact form only) */
+        const float4 *st = tex + (size_t)src * tex_stride;
+        float4 *dt = tex + (size_t)p * tex_stride;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tex_stride; i += stride) dt[i] = st[i];
+    }
     const int n = N[src];
     const float *sp = pts + (size_t)src * pt_cap * 3;
     float *dp = pts + (size_t)p * pt_cap * 3;
@@ -207,6 +210,29 @@ hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, ui
     if (dst_count <= 0) return hipSuccess;
     hipLaunchKernelGGL(replicate_level_kernel, dim3(64, dst_count), dim3(256), 0, s, tex, tex_stride, pts, cpts, pt_cap, N,
                        n_src, dst_first, dst_count);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256)
+replicate_compact_kernel(unsigned *p4, size_t p4_stride, float2 *pal, int *pal_n, int n_src, int dst_first) {
+    const int p = dst_first + blockIdx.y;
+    const int src = blockIdx.y % n_src;
+    if (p == src) return;
+    const int n = pal_n[src];
+    if (blockIdx.x == 0 && threadIdx.x == 0) pal_n[p] = n;
+    if (n <= 0) return;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(p4 + (size_t)src * p4_stride);       /* p4_stride % 32 == 0 */
+    uint4 *d4 = reinterpret_cast<uint4 *>(p4 + (size_t)p * p4_stride);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < p4_stride / 4; i += stride) d4[i] = s4[i];
+    const float2 *sp = pal + (size_t)src * DVO_PAL_MAX;
+    float2 *dp = pal + (size_t)p * DVO_PAL_MAX;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i <= (size_t)n; i += stride) dp[i] = sp[i];
+}
+hipError_t launch_replicate_compact(unsigned *p4, size_t p4_stride, float2 *pal, int *pal_n, int n_src, int dst_first,
+                                    int dst_count, hipStream_t s) {
+    if (dst_count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(replicate_compact_kernel, dim3(32, dst_count), dim3(256), 0, s, p4, p4_stride, pal, pal_n, n_src, dst_first);
     return hipGetLastError();
 }
 
@@ -638,6 +664,42 @@ iter_end_kernel(PoseState *st, double *Rt12, int *best_idx, float *ratio) {
         *best_idx = st->bestItr;
         *ratio = st->bestRatio;
     }
+}
+
+/* finalEpsilons / finalReprojections (:703-704, :1002-1003) of points [first, first+n) from the best iterate's float pose kept in
+ * the state -- the host-driven / tiled twin of the fused kernels' final pass (every rank of a tiled run produces its own shard,
+ * at the points' indices in the whole list).  Same float pose, same per-point code -> same bits as the fused kernels. */
+__global__ void __launch_bounds__(256)
+final_outputs_state_kernel(LevelSlab L, int pair, int level, Intrinsics K, const PoseState *st, int first, int n,
+                           float *__restrict__ fe, float *__restrict__ fr, int *__restrict__ final_N) {
+    const int Nall = L.N[pair];
+    const bool have = st->bestItr >= 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *final_N = have ? Nall : 0;
+    if (!have) return;
+    const float4 *__restrict__ tex = L.tex + (size_t)pair * L.tex_stride;
+    const float *__restrict__ pts = L.pts + (size_t)pair * L.pt_cap * 3;
+    IterConst c;
+    level_consts(c, K, level, L.rows, L.cols);
+#pragma unroll
+    for (int k = 0; k < 9; k++) c.r[k] = uniform_f(st->bRf[k]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) c.t[k] = uniform_f(st->btf[k]);
+    for (int i = first + blockIdx.x * blockDim.x + threadIdx.x; i < first + n; i += gridDim.x * blockDim.x) {
+        float xn, yn, zn, u, v;
+        const bool vis = project_point(c, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], xn, yn, zn, u, v);
+        float e = 0.0f;
+        if (vis) e = c.interp ? interpolate_dt(c, tex, v, u) : tex[texel_index((int)v, (int)u, c.tiles_per_col)].x;
+        fe[i] = e;
+        fr[3 * i] = u; fr[3 * i + 1] = v; fr[3 * i + 2] = zn;
+    }
+}
+hipError_t launch_final_outputs_state(const LevelSlab &L, int pair, int level, const Intrinsics &K, const void *state,
+                                      int first_point, int n_points, float *final_eps, float *final_reproj, int *final_N,
+                                      hipStream_t s) {
+    const int nb = accumulate_blocks_for(n_points);
+    hipLaunchKernelGGL(final_outputs_state_kernel, dim3(nb), dim3(256), 0, s, L, pair, level, K, (const PoseState *)state,
+                       first_point, n_points, final_eps, final_reproj, final_N);
+    return hipGetLastError();
 }
 
 hipError_t launch_iter_begin(void *state, const double *Rt12, float *energy, int max_iters, hipStream_t s) {

@@ -15,7 +15,8 @@
 #define DVO_NACC 29           /* == DVO_NUM_ACC */
 #define DVO_NACC_PAD 32
 /* where the fused kernel reads the now level of a (pair, level) from */
-enum { DVO_TEXMODE_GLOBAL16 = 0, DVO_TEXMODE_LDS16 = 1, DVO_TEXMODE_PAL4 = 2 };
+enum { DVO_TEXMODE_GLOBAL16 = 0, DVO_TEXMODE_LDS16 = 1, DVO_TEXMODE_PAL4 = 2,
+       DVO_TEXMODE_EXACT_RAN = 0x100 /* flag: a wave of the packed kernel took the literal-division fallback at this level */ };
 
 namespace dvo {
 
@@ -88,6 +89,9 @@ hipError_t launch_palette_build(const float4 *tex, size_t tex_stride, int rows, 
 bool fused_uses_compact(int points_in_flight, int interp);
 hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, int pt_cap, int *N,
                                   int n_src, int dst_first, int dst_count, hipStream_t s);
+/* the compact now form of slots [dst_first, dst_first+dst_count) <- that of pair (p - dst_first) % n_src */
+hipError_t launch_replicate_compact(unsigned *p4, size_t p4_stride, float2 *pal, int *pal_n, int n_src, int dst_first,
+                                    int dst_count, hipStream_t s);
 hipError_t launch_align_fused(int block_threads, int points_in_flight, const LevelSet &lv,
                               const Schedule &sc, const Intrinsics &K, const DevParams &prm,
                               const Outputs &out, int first_pair, int n_pairs, hipStream_t s);
@@ -116,6 +120,10 @@ hipError_t launch_iter_step_fused(const LevelSlab &L, int pair, int level, const
                                   const DevParams &prm, int itr, int n_points, double *partials, int nblocks,
                                   float *energy, hipStream_t s);
 hipError_t launch_iter_end(void *state, double *Rt12, int *best_idx, float *ratio, hipStream_t s);
+/* finalEpsilons / finalReprojections of points [first, first+n) at the best iterate kept in `state` (host-driven / tiled paths) */
+hipError_t launch_final_outputs_state(const LevelSlab &L, int pair, int level, const Intrinsics &K, const void *state,
+                                      int first_point, int n_points, float *final_eps, float *final_reproj, int *final_N,
+                                      hipStream_t s);
 hipError_t launch_unpack_texels(const float4 *tex, int rows, int cols, float *dt, float *gx, float *gy, hipStream_t s);
 /* SE(3) helpers on one lane (property tests) */
 hipError_t launch_se3_exp(const double *psi, double *Rt12, hipStream_t s);
@@ -141,13 +149,18 @@ size_t canny_work_ints(int rows, int cols, int count);
 hipError_t launch_canny(const unsigned char *grey, size_t stride, ImgBatch g, int low, int high, int *work,
                         unsigned char *edge, size_t edge_stride, hipStream_t s);
 hipError_t launch_count_edges(const unsigned char *edge, size_t n, int *out, hipStream_t s);
-/* edge mask -> distance transform -> normalise -> gradients -> texels (SolveDVO.cpp:1768-1795, :1063-1098).
- * work: edt_work_ints() ints */
+/* edge mask -> distance transform -> the now level's resident form (SolveDVO.cpp:1768-1795, :1063-1098), for pairs
+ * first_pair .. first_pair + g.count - 1.  p4 != NULL: the COMPACT form (dvo_palette.h) is written natively from the integer
+ * squared distances -- p4 / pal / pal_n are the level's slabs (indexed by pair), tex_out (already offset to first_pair) only
+ * receives the 16-byte texels of images the compact form cannot hold (pal_n < 0 then).  p4 == NULL: 16-byte texels of every
+ * image.  work: edt_work_ints() ints */
 size_t edt_work_ints(int rows, int cols, int count);
-hipError_t launch_edges_to_texels(const unsigned char *edge, size_t edge_stride, ImgBatch g, int *work,
-                                  float4 *tex_out, size_t tex_stride, hipStream_t s);
-hipError_t launch_now_level_from_edges(const unsigned char *edge, int rows, int cols, int *work,
-                                       float4 *tex_out, hipStream_t s);
+hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, ImgBatch g, int *work,
+                               float4 *tex_out, size_t tex_stride, unsigned *p4, size_t p4_stride, float2 *pal, int *pal_n,
+                               int first_pair, hipStream_t s);
+/* 16-byte texels of pairs [first_pair, first_pair + count) decoded from their compact form (pairs without one are skipped) */
+hipError_t launch_p4_decode_texels(const unsigned *p4, size_t p4_stride, const float2 *pal, const int *pal_n, float4 *tex,
+                                   size_t tex_stride, int rows, int cols, int first_pair, int count, hipStream_t s);
 /* selectedPts + enlistRefEdgePts (SolveDVO.cpp:1230-1264, :224-264).  col_counts: (cols+2) ints per image;
  * after the count pass col_counts[cols] and [cols+1] hold N.  edge: int32 or u8 (>0 = edge).
  * blk_counts (may be NULL): enlist_block_ints(rows, cols) ints per image -- per (pixel column, 16-row segment) counts in

@@ -17,16 +17,23 @@
  *             and the row below (an apron, so that the vertical neighbours of every interior pixel are in the SAME line and
  *             one 12-byte load fetches up / centre / down).  Image borders hold the reflect-101 rows.  24 pixels per line
  *             instead of 8: modelled on the bench scenes, 97 k -> 51 k distinct lines per 640x480x4x10 alignment.
- *   dword   : bits 3..15  rank * 8   (byte offset of the palette entry; rank < DVO_PAL_MAX = 4096)
+ *   dword   : bits 3..15  rank * 8   (byte offset of the palette entry; rank < DVO_PAL_MAX = 8192)
  *             bits 16..23 rank(x+1) - rank, signed     bits 24..31 rank(x-1) - rank, signed
  *             (apron / border entries carry their pixel's rank only)
  *   sentinel: line 0 of every image is not a tile: its 32 words point at palette entry n (one past the real entries), which
  *             is {0, 0}.  A lane without a visible point gathers from offset 0 and so decodes DT = gx = gy = w = 0 -- exact
  *             zeros in every sum -- without a single select.
  *
- * The form is LOSSLESS BY VERIFICATION: the builder re-derives {DT, gx, gy, w} of every pixel from the palette exactly as
+ * Two builders.  NATIVE (round 3, dvo_frames.hip): the engine's own distance transform knows every pixel's integer squared
+ * distance d2, and DT = (float)sqrt(d2) * scale is a non-decreasing function of it -- the palette is the sorted list of the
+ * d2 values present (a presence bitmap + prefix popcounts: no hashing, no sorting), a pixel's rank one table look-up; the
+ * compact form is then the ONLY form the distance-transform stage writes (16-byte texels are decoded from it on demand for the
+ * inspection / host-driven paths).  Exact by construction: palette value, weight and gradients are produced by the very
+ * expressions the 16-byte path used.  GENERIC (dvo_palette.hip): for caller-supplied float images (dvo_set_now_level):
+ *
+ * The form is LOSSLESS BY VERIFICATION: the generic builder re-derives {DT, gx, gy, w} of every pixel from the palette exactly as
  * the kernel will and compares them bit for bit with the 16-byte texel; one mismatch (a caller-supplied gradient that is not
- * imageGradient(DT), more than 4096 distinct values, a rank step beyond +-127, NaN / negative DT) and the level keeps
+ * imageGradient(DT), more than 4095 distinct values, a rank step beyond +-127, NaN / negative DT) and the level keeps
  * the 16-byte path for that pair.  Results are therefore identical bit for bit whichever form is read.
  */
 #ifndef DVO_PALETTE_H_
@@ -35,10 +42,17 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
-#define DVO_PAL_MAX 4096          /* palette entries per (pair, level) incl. the sentinel: 32 KiB of LDS at most */
+#define DVO_PAL_MAX 8192          /* palette entries per (pair, level) incl. the sentinel: the 13-bit rank field of a word */
+#define DVO_PAL_BUILD_MAX 4096    /* limit of the GENERIC builder (dvo_palette.hip: LDS hash sets); the distance-transform path
+                                     (dvo_frames.hip) ranks by a bitmap of squared distances and fills the whole format */
 #define DVO_P4_ROWS 6             /* interior image rows per 128-byte line (8 stored rows) */
+/* squared distances the native builder can rank: bits of the per-image presence bitmap (distances below 512 pixels) */
+#define DVO_EDT_BITMAP_BITS (1 << 18)
 
 namespace dvo {
+
+/* reasons for "no compact form" (pal_n = -reason) */
+enum { PAL_BAD_VALUE = 1, PAL_TOO_MANY = 2, PAL_STEP = 3, PAL_GRADIENT = 4, PAL_WEIGHT = 5, PAL_SHAPE = 6, PAL_FAR = 7 };
 
 __host__ __device__ inline int p4_tiles_per_col(int rows) { return (rows + DVO_P4_ROWS - 1) / DVO_P4_ROWS; }
 /* dwords of one image */

@@ -5,7 +5,7 @@
  * distance-transform kernels or a caller's float images, reference SolveDVO.cpp:1768-1795, :1063-1098, :1047-1053), and
  * VERIFIES per pixel that the compact form decodes to exactly those four floats.  Three launches over a batch of images:
  *   1. collect  (several workgroups per image, a range of pixel columns each): distinct DT bit patterns -> LDS hash set ->
- *               merged into the image's hash set in HBM (< DVO_PAL_MAX values, else "no compact form")
+ *               merged into the image's hash set in HBM (< DVO_PAL_BUILD_MAX values, else "no compact form")
  *   2. sort     (one workgroup per image): compaction + bitonic sort -> the palette {P, W = getWeightOf(P)} (non-negative
  *               floats order like their bit patterns), the sentinel entry and the sentinel line
  *   3. encode   (several workgroups per image, a range of tile columns each): palette -> LDS hash map value -> rank; one
@@ -25,9 +25,6 @@ namespace dvo {
 #define PAL_HASH 8192u
 #define PAL_EMPTY 0xffffffffu
 #define PAL_WORK_INTS (PAL_HASH + 2)      /* per image: hash set | count | reason */
-
-/* reasons for "no compact form" (pal_n = -reason) */
-enum { PAL_BAD_VALUE = 1, PAL_TOO_MANY = 2, PAL_STEP = 3, PAL_GRADIENT = 4, PAL_WEIGHT = 5, PAL_SHAPE = 6 };
 
 size_t palette_work_ints(int count) { return (size_t)count * PAL_WORK_INTS; }
 
@@ -86,9 +83,9 @@ palette_collect_kernel(const float4 *__restrict__ tex, size_t tex_stride, int ro
                 if (y0 + q * 256 >= rows) continue;
                 if (k[q] >= 0x7f800000u) { lbad = PAL_BAD_VALUE; continue; }     /* negative, inf or nan: not a distance */
                 /* the local set must never fill up (an insert into a full table would not terminate): more than
-                 * DVO_PAL_MAX distinct values in this chunk alone already means "no compact form" -- stop inserting */
+                 * DVO_PAL_BUILD_MAX distinct values in this chunk alone already means "no compact form" -- stop inserting */
                 if (*(volatile int *)&lbad) continue;
-                if (pal_set_insert(keys, k[q], &lbad) && atomicAdd(&lcnt, 1) >= DVO_PAL_MAX - 1) lbad = PAL_TOO_MANY;
+                if (pal_set_insert(keys, k[q], &lbad) && atomicAdd(&lcnt, 1) >= DVO_PAL_BUILD_MAX - 1) lbad = PAL_TOO_MANY;
             }
         }
         if (*(volatile int *)&lbad) break;
@@ -98,7 +95,7 @@ palette_collect_kernel(const float4 *__restrict__ tex, size_t tex_stride, int ro
     for (unsigned i = tid; i < PAL_HASH; i += 256) {
         const unsigned k = keys[i];
         if (k == PAL_EMPTY) continue;
-        if (pal_set_insert(gkeys, k, gbad) && atomicAdd(gcnt, 1) >= DVO_PAL_MAX - 1) atomicMax(gbad, (int)PAL_TOO_MANY);   /* one entry is the sentinel */
+        if (pal_set_insert(gkeys, k, gbad) && atomicAdd(gcnt, 1) >= DVO_PAL_BUILD_MAX - 1) atomicMax(gbad, (int)PAL_TOO_MANY);   /* one entry is the sentinel */
     }
 }
 
@@ -110,10 +107,10 @@ palette_sort_kernel(const unsigned *__restrict__ work, unsigned *__restrict__ p4
     const unsigned *gkeys = work + (size_t)blockIdx.x * PAL_WORK_INTS;
     const int n = (int)gkeys[PAL_HASH], bad = (int)gkeys[PAL_HASH + 1];
     const int tid = threadIdx.x;
-    if (bad || n < 1 || n > DVO_PAL_MAX - 1) { if (tid == 0) pal_n[pair] = -(bad ? bad : (int)PAL_TOO_MANY); return; }
+    if (bad || n < 1 || n > DVO_PAL_BUILD_MAX - 1) { if (tid == 0) pal_n[pair] = -(bad ? bad : (int)PAL_TOO_MANY); return; }
     p4 += (size_t)pair * p4_stride;
     pal += (size_t)pair * DVO_PAL_MAX;
-    __shared__ unsigned sorted[DVO_PAL_MAX];
+    __shared__ unsigned sorted[DVO_PAL_BUILD_MAX];
     __shared__ int cnt;
     int m = 2;
     while (m < n) m <<= 1;
@@ -166,7 +163,7 @@ palette_encode_kernel(const float4 *__restrict__ tex, size_t tex_stride, int row
     tex += (size_t)pair * tex_stride;
     p4 += (size_t)pair * p4_stride;
     pal += (size_t)pair * DVO_PAL_MAX;
-    __shared__ unsigned sorted[DVO_PAL_MAX];                 /* P as bits */
+    __shared__ unsigned sorted[DVO_PAL_BUILD_MAX];                 /* P as bits */
     __shared__ unsigned short first[PAL_BUCKETS + 2];        /* first[b] = number of palette values below bucket b */
     __shared__ unsigned short rk[6][PAL_SEG + 2];            /* ranks of pixel columns 4tc-1 .. 4tc+4, rows y0-1 .. y0+PAL_SEG */
     __shared__ int bad;

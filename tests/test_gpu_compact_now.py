@@ -45,11 +45,12 @@ def _check(ctx, ref, iters, pair=0, R0=None, t0=None):
 
 @pytest.mark.parametrize("kw", [
     dict(),                                          # auto: a single pair -> a team of 8 workgroups, every level compact
-    dict(team_size=1),                               # one 512-thread workgroup; level 3 is staged into LDS as 16-byte texels
+    dict(team_size=1),                               # one 512-thread workgroup (the compact form comes before LDS-staged texels)
     dict(engine_variant=2, team_size=1),             # no LDS staging: all four levels through the compact form
     dict(block_threads=256), dict(block_threads=1024),
     dict(lds_point_bytes=16 * 1024, team_size=1),    # palette + 1 k points resident, the rest streamed (both passes)
-    dict(engine_variant=3, team_size=1),             # every wave redone by the literal-division fallback (16-byte texels)
+    dict(engine_variant=3, team_size=1),             # every wave redone by the literal-division fallback, reading the compact form
+    dict(engine_variant=3),                          # the same in a team
 ])
 def test_compact_now_640x480(oracle, kw):
     """C2 (640x480, 4 levels, 10 iterations): prepared now levels through every launch shape of the packed kernel"""
@@ -67,9 +68,9 @@ def test_compact_now_640x480(oracle, kw):
         assert sizes[0] > sizes[1] > sizes[2] > sizes[3]          # coarser levels have fewer distinct distances
         R1, t1 = _check(ctx, ref, iters)
         modes = [ctx.level_texel_mode(0, l) for l in range(4)]
-        one_wg = kw.get("team_size", 0) == 1 or kw.get("block_threads", 0) == 1024      # no team; 256 threads: 77 KB, level 3 does not fit
-        staged3 = one_wg and kw.get("engine_variant", 0) != 2 and "lds_point_bytes" not in kw
-        assert modes == ([2, 2, 2, 1] if staged3 else [2, 2, 2, 2]), modes
+        assert modes == [2, 2, 2, 2], modes                       # a level that has a compact form is read through it
+        # engine_variant = 3 really runs the literal-division code (it used to be a silent no-op), nothing else does
+        assert [ctx.level_exact_fallback(0, l) for l in range(4)] == [kw.get("engine_variant", 0) == 3] * 4
     if kw.get("engine_variant", 0) == 0:
         # the same alignment with the compact form switched off: same kernel otherwise -> the very same bits
         with DvoContext(1, **{**kw, "engine_variant": 4}) as ctx2:
@@ -79,6 +80,115 @@ def test_compact_now_640x480(oracle, kw):
             R2, t2 = _check(ctx2, ref, iters)
             assert 2 not in [ctx2.level_texel_mode(0, l) for l in range(4)]
             assert np.array_equal(R1, R2) and np.array_equal(t1, t2)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(team_size=1), dict(block_threads=256), dict(engine_variant=3, team_size=1),
+                                dict(lds_point_bytes=16 * 1024, team_size=1), dict(engine_variant=1)])
+def test_native_compact_now_levels_from_edges_640x480(oracle, kw):
+    """round 3: now levels produced by the engine's own distance transform (dvo_set_now_level_from_edges) exist in the compact
+    form ONLY -- ranks straight from the integer squared distances, no dvo_now_prepare, no 16-byte texels written.  C2 through
+    the packed kernel's launch shapes; the paths that read 16-byte texels (one-point-per-lane kernel, a launch whose LDS cannot
+    hold every palette) get them decoded from the compact form on demand.  Same bits as the oracle and as a context with the
+    compact form switched off."""
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    sc = SynthScene(640, 480, 4, 3)
+    lv = oracle_lib.scene_levels(sc, oracle)
+    iters = [10, 10, 10, 10]
+    ref = oracle.align_pyramid(iters, lv, sc.intrinsics, np.eye(3), np.zeros(3))
+
+    def load(ctx):
+        ctx.set_intrinsics(*sc.intrinsics)
+        for l, L in enumerate(sc.levels):
+            ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols)
+            ctx.set_now_level_from_edges(l, (np.asarray(L.now_edge) != 0).astype(np.uint8) * 255, L.rows, L.cols)
+    with DvoContext(1, **kw) as ctx:
+        load(ctx)
+        sizes = [ctx.now_compact_info(0, l) for l in range(4)]
+        assert all(0 < s < 8192 for s in sizes) and sizes[0] > sizes[1] > sizes[2] > sizes[3], sizes
+        for l, L in enumerate(sc.levels):                      # one palette entry per distinct squared distance
+            assert sizes[l] == len(np.unique(L.now_dt)), (l, sizes[l])
+        R1, t1 = _check(ctx, ref, iters)
+        if kw.get("engine_variant", 0) != 1:
+            small_lds = "lds_point_bytes" in kw                # below the largest palette: the kernel may not count on the compact form
+            assert [ctx.level_texel_mode(0, l) for l in range(4)] == ([2, 2, 2, 2] if not small_lds else [2, 2, 2, 2]), kw
+        # the planar images decoded from the compact form are the scene generator's (== the oracle's), bit for bit
+        for l, L in enumerate(sc.levels):
+            dt, gx, gy = ctx.get_now_level(l)
+            assert _same(dt, L.now_dt) and _same(gx, L.now_gx) and _same(gy, L.now_gy), l
+        R1b, t1b = _check(ctx, ref, iters)                      # and the compact form is still what the packed kernel reads
+        assert np.array_equal(R1, R1b) and np.array_equal(t1, t1b)
+    with DvoContext(1, **{**kw, "engine_variant": 4}) as ctx2:  # compact form off: the same stage writes 16-byte texels
+        load(ctx2)
+        assert [ctx2.now_compact_info(0, l) for l in range(4)] == [0, 0, 0, 0]
+        R2, t2 = _check(ctx2, ref, iters)
+        assert 2 not in [ctx2.level_texel_mode(0, l) for l in range(4)]
+        if kw.get("engine_variant", 0) in (0, 3):
+            assert np.array_equal(R1, R2) and np.array_equal(t1, t2)
+
+
+def test_native_compact_replicated_batch_and_overwrite(oracle):
+    """native compact now levels in a batch: replicated slots carry their own copy of the compact form; a slot overwritten by
+    caller-supplied float images falls back to 16-byte texels, one overwritten from edges again gets a fresh compact form"""
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    n = 10
+    scenes = [SynthScene(320, 240, 3, 4000 + i) for i in range(3)]
+    iters = [6, 6, 6]
+    with DvoContext(n) as ctx:
+        ctx.set_intrinsics(*scenes[0].intrinsics)
+        for p, sc in enumerate(scenes):
+            for l, L in enumerate(sc.levels):
+                ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols, pair=p)
+                ctx.set_now_level_from_edges(l, (np.asarray(L.now_edge) != 0).astype(np.uint8) * 255, L.rows, L.cols, pair=p)
+        ctx.replicate_pairs(3)
+        assert all(ctx.now_compact_info(p, l) == ctx.now_compact_info(p % 3, l) > 0 for p in range(n) for l in range(3))
+        # slot 4 (a copy of scene 1) gets scene 2's now frame as float images; slot 5 (scene 2) gets scene 0's from edges
+        for l, L in enumerate(scenes[2].levels):
+            ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols, pair=4)
+        for l, L in enumerate(scenes[0].levels):
+            ctx.set_now_level_from_edges(l, (np.asarray(L.now_edge) != 0).astype(np.uint8) * 255, L.rows, L.cols, pair=5)
+        assert [ctx.now_compact_info(4, l) for l in range(3)] == [0, 0, 0]
+        R, t = ctx.align_batch(iters, np.tile(np.eye(3), (n, 1, 1)), np.zeros((n, 3)))
+        for p in range(n):
+            src, now = p % 3, {4: 2, 5: 0}.get(p, p % 3)
+            lv = oracle_lib.scene_levels(scenes[src], oracle)
+            for l, L in enumerate(scenes[now].levels):
+                lv[l].update(dt=L.now_dt, gx=L.now_gx, gy=L.now_gy)
+            ref = oracle.align_pyramid(iters, lv, scenes[src].intrinsics, np.eye(3), np.zeros(3))
+            for l, rep in ref["levels"].items():
+                e, b, ratio = ctx.level_report(p, l, iters[l])
+                assert np.array_equal(e, rep["energy"]) and b == rep["best_idx"] and ratio == rep["visible_ratio"], (p, l)
+            assert rot_angle(ref["R"], R[p]) <= ROT_TOL and np.linalg.norm(ref["t"] - t[p]) <= TRANS_TOL
+            assert ctx.level_texel_mode(p, 0) == (0 if p == 4 else 2), p
+
+
+def test_native_compact_refusals_fall_back_to_16_byte_texels(oracle):
+    """images the native builder cannot hold: a pixel 512 or more pixels from every edge (-7); the same launch writes their
+    16-byte texels instead, results are the oracle's all the same"""
+    from rgbd_odometry_amd import DvoContext
+    rows, cols = 40, 700
+    edge = np.zeros(rows * cols, np.uint8)
+    edge[5 + 3 * rows] = 255                                    # one edge pixel near the left border: distances up to ~696
+    edge[7 + 20 * rows] = 255
+    dt, gx, gy = oracle.now_level_from_edges(edge, rows, cols)
+    rng = np.random.default_rng(3)
+    ref_edge = (rng.random(rows * cols) < 0.3).astype(np.int32) * 255
+    depth = rng.uniform(400, 3000, rows * cols).astype(np.float32)
+    K = (600.0, 600.0, 350.0, 20.0)
+    with DvoContext(1, team_size=1) as ctx:
+        ctx.set_intrinsics(*K)
+        xyz, _ = ctx.set_ref_level_from_images(0, ref_edge, depth, rows, cols)
+        ctx.set_now_level_from_edges(0, edge, rows, cols)
+        assert ctx.now_compact_info(0, 0) == -7
+        d2, g2, h2 = ctx.get_now_level(0)
+        assert _same(d2, dt) and _same(g2, gx) and _same(h2, gy)
+        ref = oracle.run_iterations(0, 6, xyz, dt, gx, gy, rows, cols, K, np.eye(3), np.zeros(3))
+        got = ctx.run_iterations(0, 6, np.eye(3), np.zeros(3))
+        assert ctx.level_texel_mode(0, 0) in (0, 1)
+        assert _same(ref["energy"], got["energy"])
+        assert _same(ref["final_eps"], got["final_eps"]) and _same(ref["final_reproj"], got["final_reproj"])
+        # an image with no edge pixel at all is refused by the entry point (the distance transform is undefined)
+        with pytest.raises(Exception):
+            ctx.set_now_level_from_edges(0, np.zeros(rows * cols, np.uint8), rows, cols)
 
 
 def test_compact_now_is_built_for_a_level_that_keeps_being_aligned(oracle):
@@ -133,8 +243,7 @@ def test_compact_now_odd_sizes_from_edges(oracle, rows, cols):
     with DvoContext(1, team_size=1, engine_variant=2) as ctx:
         ctx.set_intrinsics(*K)
         xyz, _ = ctx.set_ref_level_from_images(0, ref_edge, depth, rows, cols)
-        ctx.set_now_level_from_edges(0, edge, rows, cols)
-        ctx.now_prepare()
+        ctx.set_now_level_from_edges(0, edge, rows, cols)     # native: the compact form is what this writes (no dvo_now_prepare)
         n = ctx.now_compact_info(0, 0)
         assert n > 0, n
         assert n == len(np.unique(dt)), (n, len(np.unique(dt)))

@@ -101,10 +101,11 @@ def test_canny_matches_oracle(oracle, name, img):
         assert ne == int((ref > 0).sum())
 
 
-@pytest.mark.parametrize("shape", [(37, 3000), (20, 5000), (12, 9000), (6, 40000), (3000, 41), (1100, 700)])
+@pytest.mark.parametrize("shape", [(37, 3000), (20, 5000), (12, 9000), (6, 40000), (3000, 41), (1100, 700), (9000, 12)])
 def test_extreme_aspect_ratios_through_every_row_pass_variant(oracle, shape):
-    """long rows exercise the 8- and 4-row LDS tiles and the global-memory fallback of the exact distance transform
-    (and 16-bit overflow of the column distances), tall images the multi-chunk column pass"""
+    """long rows exercise the 8-, 4-, 2- and 1-row LDS tiles of the exact distance transform's row pass, tall images the
+    multi-chunk column pass (beyond 8192 rows: one wave per workgroup); the large edge-free region puts pixels further than
+    511 pixels from every edge, which the native compact form refuses -- those images take the 16-byte texel fallback"""
     rng = np.random.default_rng(shape[1])
     img = np.kron(rng.integers(0, 2, ((shape[0] + 7) // 8, (shape[1] + 15) // 16)).astype(np.uint8) * 210 + 20,
                   np.ones((8, 16), np.uint8))[:shape[0], :shape[1]]
