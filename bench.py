@@ -534,6 +534,11 @@ def main_tiled(args):
         allp = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allp, mine)
         same = all(bool(torch.equal(allp[0], a)) for a in allp)
+    # per-level reports of the LAST timed alignment, read before anything else touches the context's outputs
+    reports = {l: ctx.level_report(0, l, iters[l]) for l in range(args.levels) if iters[l] > 0}
+    finals = None
+    if flags:
+        finals = ctx.final_outputs(0, n_pts[[l for l in range(args.levels) if iters[l] > 0][0]])
     # the dominant kernel: accumulate_state_kernel over this rank's shard of the finest level, timed live with HIP events
     first, count = shard_range(n_pts[0], rank, world)
     acc = torch.zeros(32, dtype=torch.float64, device="cuda")
@@ -590,12 +595,12 @@ def main_tiled(args):
         ref = oracle.align_pyramid(iters, lvs[0], sc.intrinsics, I, z)
         bit_equal = True
         for l, rep in ref["levels"].items():
-            e, bi, ratio = ctx.level_report(0, l, iters[l])
+            e, bi, ratio = reports[l]
             bit_equal = bit_equal and bool(np.array_equal(e, rep["energy"])) and bi == rep["best_idx"] and ratio == rep["visible_ratio"]
         fin = True
         if flags:
             last = ref["levels"][ref["last_level"]]
-            fe, fr = ctx.final_outputs(0, len(last["final_eps"]))
+            fe, fr = finals
             fin = bool(np.array_equal(fe, last["final_eps"])) and bool(np.array_equal(fr, last["final_reproj"], equal_nan=True))
         wr, wt = oracle_lib.rot_angle(ref["R"], R), float(np.linalg.norm(ref["t"] - t))
         out["parity_check"] = {"max_rot_err_rad": wr, "max_trans_err_m": wt, "energies_bit_equal": bit_equal, "final_outputs_bit_equal": fin,

@@ -115,7 +115,10 @@ int ensure_compact_slabs(dvo_ctx *c, int level) {
     HIPCHK(c, hipMalloc((void **)&L.p4, sizeof(unsigned) * L.p4_stride * c->n_pairs));
     HIPCHK(c, hipMalloc((void **)&L.pal, sizeof(float2) * DVO_PAL_MAX * (size_t)c->n_pairs));
     HIPCHK(c, hipMalloc((void **)&L.d_pal_n, sizeof(int) * (size_t)c->n_pairs));
+    /* complete before anything can write a palette size: the frame path fills this level on its own stream (per-level lanes,
+     * dvo_capi_frames.cpp), which is not ordered after the context stream */
     HIPCHK(c, hipMemsetAsync(L.d_pal_n, 0, sizeof(int) * (size_t)c->n_pairs, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return DVO_OK;
 }
 
@@ -392,7 +395,7 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
      * could fall back to texels).  Now levels written by the engine's own distance-transform stage exist in the compact form
      * only (dvo_frames.hip): their texels are decoded first. */
     if (!packed || sc.no_p4 || (size_t)sc.lds_bytes < sizeof(float2) * DVO_PAL_MAX + 64) {
-        sc.no_p4 = 1;
+        if (!packed) sc.no_p4 = 1;
         for (int l = 0; l < n_levels; l++) {
             if (sc.iters[l] <= 0) continue;
             if ((rc = ensure_tex16(c, l, first_pair, n_pairs))) return rc;
@@ -868,8 +871,11 @@ int dvo_replicate_pairs(dvo_ctx *c, int n_src, int dst_first, int dst_count) {
             c->points_gen++;
             L.compact_ok[p] = L.compact_ok[(p - dst_first) % n_src];
         }
-        if (L.tex && dst_count > 0) {
-            int rc = now_written(c, l, dst_first, dst_count);       /* marks the destinations' compact form stale ... */
+        /* the slots written: everything but the sources themselves (dst_first == 0: the range starts with them) */
+        const int w_first = (dst_first == 0) ? std::min(n_src, dst_count) : dst_first;
+        const int w_count = dst_first + dst_count - w_first;
+        if (L.tex && w_count > 0) {
+            int rc = now_written(c, l, w_first, w_count);           /* marks the destinations' compact form stale ... */
             if (rc) return rc;
             if (any_compact) {                                      /* ... and this copies the sources' over it */
                 HIPCHK(c, launch_replicate_compact(L.p4, L.p4_stride, L.pal, L.d_pal_n, n_src, dst_first, dst_count, c->stream));

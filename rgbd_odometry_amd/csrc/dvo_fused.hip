@@ -33,7 +33,9 @@
  * CU 555 k aligns/s at depth 2, 593 k at depth 3; one 512-thread workgroup 517 k / 510 k (its serial phases are exposed, not
  * its gathers) */
 #ifndef DVO_WPE256
-#define DVO_WPE256 1        /* the compiler takes exactly the 256 registers two waves per SIMD allow (tests/test_kernel_registers.py); forcing 2 costs 5 % */
+#define DVO_WPE256 2        /* two waves per SIMD = 256 registers: left to itself (1) the compiler parks two loop-invariant addresses of the
+                               final pass in AGPRs (258 in all -> ONE wave per SIMD); forced, it spills those two to scratch outside the hot
+                               loop (tests/test_kernel_registers.py pins both numbers) */
 #endif
 #ifndef DVO_P4_DEPTH
 #define DVO_P4_DEPTH(BLOCK) ((BLOCK) == 256 ? 3 : 2)
@@ -355,6 +357,107 @@ DVO_DEV void accumulate_points_exact(const IterConst &c, const char *__restrict_
     }
 }
 
+/* ---- finalEpsilons / finalReprojections of the best iterate (:703-704, :1002-1003) --------------------------------------
+ * One more projection of the finest level's points and one DT look-up each.  Pipelined like the hot loop: two points per
+ * lane and round, the points (3 x N float list: these two arrays are indexed like the reference's list, the compact
+ * twin is in block order) fetched one round ahead, the look-ups issued one round ahead of the stores that consume them.
+ * (Round 2 walked the list four points per trip with nothing in flight across trips: 15 trips x two dependent memory
+ * latencies = 11 % of the whole alignment.) */
+struct Final2 {
+    v2f u, v, zn;
+    unsigned w0, w1;        /* TEX_P4: centre rank word; else: bits of DT */
+    bool vis0, vis1;
+};
+template <int TEX>
+DVO_DEV void final2_issue(const IterConst &c, const TexSrc &ts, const float *__restrict__ xyz, int i0, int i1, int N, int step,
+                          U3 &pf0, U3 &pf1, Final2 &b) {
+    const U3 a0 = pf0, a1 = pf1;
+    pf0 = *reinterpret_cast<const U3 *>(xyz + 3 * (size_t)min(i0 + step, N - 1));      /* the next round's points */
+    pf1 = *reinterpret_cast<const U3 *>(xyz + 3 * (size_t)min(i1 + step, N - 1));
+    /* one point at a time, scalar-register pose operands: the packed form would want the pose in vector register pairs, and
+     * the 256-thread shape has none to spare (tests/test_kernel_registers.py) */
+    {
+        float xs, ys, zs, us, vs;
+        project_point(c, __uint_as_float(a0.a), __uint_as_float(a0.b), __uint_as_float(a0.c), xs, ys, zs, us, vs);
+        b.u.x = us; b.v.x = vs; b.zn.x = zs;
+        project_point(c, __uint_as_float(a1.a), __uint_as_float(a1.b), __uint_as_float(a1.c), xs, ys, zs, us, vs);
+        b.u.y = us; b.v.y = vs; b.zn.y = zs;
+    }
+    int px0, py0, px1, py1;
+    const bool inx0 = pixel_in_range(b.u.x, c.cols, px0), iny0 = pixel_in_range(b.v.x, c.rows, py0);
+    const bool inx1 = pixel_in_range(b.u.y, c.cols, px1), iny1 = pixel_in_range(b.v.y, c.rows, py1);
+    b.vis0 = inx0 && iny0; b.vis1 = inx1 && iny1;
+    if constexpr (TEX == TEX_P4) {
+        const unsigned o0 = b.vis0 ? p4_byte_offset(py0, px0, ts.p4_col_bytes) + 4u : 0u;      /* not visible: the sentinel line (DT = 0) */
+        const unsigned o1 = b.vis1 ? p4_byte_offset(py1, px1, ts.p4_col_bytes) + 4u : 0u;
+        b.w0 = *reinterpret_cast<const unsigned *>(ts.p4 + o0);
+        b.w1 = *reinterpret_cast<const unsigned *>(ts.p4 + o1);
+    } else {
+        const unsigned o0 = b.vis0 ? texel_byte_offset(py0, px0, ts.tile_col_bytes) : 0u;
+        const unsigned o1 = b.vis1 ? texel_byte_offset(py1, px1, ts.tile_col_bytes) : 0u;
+        const char *base = (TEX == TEX_L16) ? ts.l16 : ts.g16;
+        b.w0 = *reinterpret_cast<const unsigned *>(base + o0);
+        b.w1 = *reinterpret_cast<const unsigned *>(base + o1);
+    }
+}
+template <int TEX, unsigned PAL>
+DVO_DEV void final2_store(const Final2 &b, int i0, int i1, int N, float *__restrict__ fe, float *__restrict__ fr) {
+    float e0, e1;
+    if constexpr (TEX == TEX_P4) {
+        e0 = *(lds_cfloat *)(size_t)(PAL + (b.w0 & 0xfff8u));
+        e1 = *(lds_cfloat *)(size_t)(PAL + (b.w1 & 0xfff8u));
+    } else {
+        e0 = b.vis0 ? __uint_as_float(b.w0) : 0.0f;
+        e1 = b.vis1 ? __uint_as_float(b.w1) : 0.0f;
+    }
+    if (i0 < N) {
+        fe[i0] = e0;
+        U3 o; o.a = __float_as_uint(b.u.x); o.b = __float_as_uint(b.v.x); o.c = __float_as_uint(b.zn.x);
+        *reinterpret_cast<U3 *>(fr + 3 * (size_t)i0) = o;
+    }
+    if (i1 < N) {
+        fe[i1] = e1;
+        U3 o; o.a = __float_as_uint(b.u.y); o.b = __float_as_uint(b.v.y); o.c = __float_as_uint(b.zn.y);
+        *reinterpret_cast<U3 *>(fr + 3 * (size_t)i1) = o;
+    }
+}
+/* points [0, N) of `xyz` (already offset to this workgroup's share), outputs at fe[i], fr[3 i] */
+template <int BLOCK, int TEX, unsigned PAL>
+#ifdef DVO_FINAL_NOINLINE
+__device__ __noinline__ void final_outputs2(
+#else
+DVO_DEV void final_outputs2(
+#endif
+const IterConst &c, const TexSrc &ts, const float *__restrict__ xyz, int N,
+                            float *__restrict__ fe, float *__restrict__ fr) {
+    constexpr int STEP = 2 * BLOCK;
+    const int tid = threadIdx.x;
+    const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
+    if (wave_first >= N) return;                              /* wave-uniform */
+    const int n_rounds = (N - wave_first + STEP - 1) / STEP;  /* rounds in which this wave still has a point */
+    U3 pf0 = *reinterpret_cast<const U3 *>(xyz + 3 * (size_t)min(tid, N - 1));
+    U3 pf1 = *reinterpret_cast<const U3 *>(xyz + 3 * (size_t)min(tid + BLOCK, N - 1));
+    Final2 A, B;
+    int base = tid;
+    final2_issue<TEX>(c, ts, xyz, base, base + BLOCK, N, STEP, pf0, pf1, A);
+    int r = 0;
+#pragma clang loop unroll(disable)
+    for (; r + 2 < n_rounds; r += 2) {
+        final2_issue<TEX>(c, ts, xyz, base + STEP, base + STEP + BLOCK, N, STEP, pf0, pf1, B);
+        final2_store<TEX, PAL>(A, base, base + BLOCK, N, fe, fr);
+        final2_issue<TEX>(c, ts, xyz, base + 2 * STEP, base + 2 * STEP + BLOCK, N, STEP, pf0, pf1, A);
+        final2_store<TEX, PAL>(B, base + STEP, base + STEP + BLOCK, N, fe, fr);
+        base += 2 * STEP;
+    }
+    if (r + 1 < n_rounds) {
+        final2_issue<TEX>(c, ts, xyz, base + STEP, base + STEP + BLOCK, N, STEP, pf0, pf1, B);
+        final2_store<TEX, PAL>(A, base, base + BLOCK, N, fe, fr);
+        final2_store<TEX, PAL>(B, base + STEP, base + STEP + BLOCK, N, fe, fr);
+    } else {
+        final2_store<TEX, PAL>(A, base, base + BLOCK, N, fe, fr);
+    }
+}
+
 /* fixed-shape reduction of the 7 double sums + the visible count over the workgroup: tot[0..5] g, [6] sum eps^2,
  * [7] visible points (valid after the trailing barrier) */
 template <int BLOCK>
@@ -503,7 +606,10 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         if (pair_local >= sc.n_pairs_launch) return;
     }
     if (!TEAM && out.order) pair_local = out.order[pair_local];      /* longest pairs first: the launch ends with the short ones */
-    const int pair = first_pair + pair_local;
+    /* wave-uniform, but loaded through a vector instruction (the launch order): pin it to a scalar register, and with it every
+     * per-pair pointer and count derived below -- a dozen 64-bit addresses that would otherwise live in vector registers for
+     * the whole kernel (the 256-thread shape has exactly the 256 registers two waves per SIMD allow) */
+    const int pair = __builtin_amdgcn_readfirstlane(first_pair + pair_local);
     const int tid = threadIdx.x;
     unsigned epoch = 0;                          /* exchanges done so far (team mode) */
     /* static LDS as ONE block of known size, so that the dynamic part -- which starts with the palette of the compact now
@@ -538,7 +644,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         if (iters <= 0) continue;                                 /* :2099 */
         const LevelSlab &L = lv.l[l];
         const int dpair = (sc.alias_mod > 0) ? (pair % sc.alias_mod) : pair;
-        const int Nall = L.N[dpair];
+        const int Nall = __builtin_amdgcn_readfirstlane(L.N[dpair]);
         /* this workgroup's share of the list: all of it, or member `member`'s contiguous even-sized chunk of a team */
         int pfirst = 0, N = Nall;
         if (TEAM) {
@@ -712,44 +818,15 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
                 /* these two arrays are indexed like the reference's list (:703-704): the points come from the 3 x N float list,
                  * which keeps the reference's order (the compact twin is in block order, dvo_frames.hip) -- same X, Y, Z bits */
                 const float *__restrict__ xyz = L.pts + (size_t)dpair * L.pt_cap * 3;
-                /* four points per lane and trip, their loads (12 contiguous bytes per lane: one dwordx3) and gathers
-                 * independent of each other.  (This pass costs 11 % of the alignment -- 1.60 -> 1.42 ms per 1024 alignments
-                 * when switched off; packed projection or eight points per trip push the kernel past its 256 registers and
-                 * halve the occupancy, tests/test_kernel_registers.py.) */
-                for (int i0 = tid; i0 < N; i0 += 4 * BLOCK) {
-                    U3 w[4];
-                    float u[4], v[4], zn[4], e[4];
-                    bool vis[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int i = min(i0 + q * BLOCK, N - 1);
-                        w[q] = *reinterpret_cast<const U3 *>(xyz + 3 * (size_t)(pfirst + i));
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        float xn, yn;
-                        vis[q] = project_point(c, __uint_as_float(w[q].a), __uint_as_float(w[q].b), __uint_as_float(w[q].c), xn, yn, zn[q], u[q], v[q]);
-                        if (mode == TEX_P4) {      /* DT = palette value of the pixel's rank word: 24 pixels per line instead of 8 */
-                            const unsigned o = vis[q] ? p4_byte_offset((int)v[q], (int)u[q], ts.p4_col_bytes) + 4u : 0u;
-                            const unsigned wd = *reinterpret_cast<const unsigned *>(ts.p4 + o);
-                            e[q] = *(lds_cfloat *)(size_t)(kStatic + (wd & 0xfff8u));
-                        } else {
-                            const int ti = vis[q] ? texel_index((int)v[q], (int)u[q], c.tiles_per_col) : 0;
-                            e[q] = reinterpret_cast<const float4 *>(tex)[ti].x;
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int i = i0 + q * BLOCK;
-                        if (i < N) {
-                            const int gi = pfirst + i;
-                            fe[gi] = vis[q] ? e[q] : 0.0f;
-                            U3 o;
-                            o.a = __float_as_uint(u[q]); o.b = __float_as_uint(v[q]); o.c = __float_as_uint(zn[q]);
-                            *reinterpret_cast<U3 *>(fr + 3 * (size_t)gi) = o;
-                        }
-                    }
-                }
+                const float *__restrict__ xs = xyz + 3 * (size_t)pfirst;
+                float *fes = fe + pfirst, *frs = fr + 3 * (size_t)pfirst;
+#ifndef DVO_NO_FINAL
+                if (mode == TEX_P4) final_outputs2<BLOCK, TEX_P4, kStatic>(c, ts, xs, N, fes, frs);
+#ifndef DVO_FINAL_P4_ONLY
+                else if (mode == TEX_L16) final_outputs2<BLOCK, TEX_L16, kStatic>(c, ts, xs, N, fes, frs);
+                else final_outputs2<BLOCK, TEX_G16, kStatic>(c, ts, xs, N, fes, frs);
+#endif
+#endif
             }
             if (tid == 0 && member == 0) out.final_N[pair] = (st.bestItr >= 0) ? Nall : 0;
         }
