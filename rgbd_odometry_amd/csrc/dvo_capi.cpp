@@ -60,8 +60,10 @@ int ensure_points(dvo_ctx *c, int level, int N) {
     new_cap = (new_cap + 255) / 256 * 256;
     float *np = nullptr;
     uint2 *ncp = nullptr;
+    unsigned *nci = nullptr;
     HIPCHK(c, hipMalloc((void **)&np, sizeof(float) * 3 * (size_t)new_cap * c->n_pairs));
     HIPCHK(c, hipMalloc((void **)&ncp, sizeof(uint2) * (size_t)new_cap * c->n_pairs));
+    HIPCHK(c, hipMalloc((void **)&nci, sizeof(unsigned) * (size_t)new_cap * c->n_pairs));
     if (L.pts) {
         HIPCHK(c, hipMemcpy2DAsync(np, sizeof(float) * 3 * (size_t)new_cap, L.pts,
                                    sizeof(float) * 3 * (size_t)L.pt_cap,
@@ -69,12 +71,16 @@ int ensure_points(dvo_ctx *c, int level, int N) {
                                    hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipMemcpy2DAsync(ncp, sizeof(uint2) * (size_t)new_cap, L.cpts, sizeof(uint2) * (size_t)L.pt_cap,
                                    sizeof(uint2) * (size_t)L.pt_cap, c->n_pairs, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(nci, sizeof(unsigned) * (size_t)new_cap, L.cidx, sizeof(unsigned) * (size_t)L.pt_cap,
+                                   sizeof(unsigned) * (size_t)L.pt_cap, c->n_pairs, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipFree(L.pts));
         HIPCHK(c, hipFree(L.cpts));
+        HIPCHK(c, hipFree(L.cidx));
     }
     L.pts = np;
     L.cpts = ncp;
+    L.cidx = nci;
     L.pt_cap = new_cap;
     return DVO_OK;
 }
@@ -197,7 +203,7 @@ namespace dvo_host {       /* shared with dvo_capi_tiled.cpp (declared in dvo_ct
 LevelSlab slab_of(const dvo_ctx *c, int level) {
     const Level &L = c->lv[level];
     LevelSlab s;
-    s.tex = L.tex; s.pts = L.pts; s.cpts = L.cpts; s.N = L.dN;
+    s.tex = L.tex; s.pts = L.pts; s.cpts = L.cpts; s.cidx = L.cidx; s.N = L.dN;
     s.tex_stride = L.tex_stride; s.pt_cap = L.pt_cap; s.rows = L.rows; s.cols = L.cols;
     s.p4 = L.p4; s.pal = L.pal; s.pal_n = L.d_pal_n; s.p4_stride = L.p4_stride;
     return s;
@@ -273,7 +279,7 @@ void stamp_outputs(dvo_ctx *c, const Schedule &sc, int first, int n) {
     const bool same_layout = c->have_sched && c->sched.n_levels == sc.n_levels && c->sched.e_stride == sc.e_stride &&
                              std::memcmp(c->sched.iters, sc.iters, sizeof(sc.iters)) == 0 &&
                              ((c->sched.flags ^ sc.flags) & (DVO_FLAG_FINAL_OUTPUTS | DVO_FLAG_NORMAL_MATRIX)) == 0 &&
-                             c->sched.last_level == sc.last_level;
+                             c->sched.last_level == sc.last_level && c->sched.final_blk == sc.final_blk;
     if (!same_layout || c->sched_gen == 0) c->sched_gen++;
     if (c->pair_gen.empty()) c->pair_gen.assign(c->n_pairs, 0);
     for (int p = first; p < first + n; p++) c->pair_gen[p] = c->sched_gen;
@@ -477,6 +483,7 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
             }
             o.order = c->d_order;
         }
+        sc.final_blk = 1;            /* the packed kernel stores its final outputs in the order of the compact lists */
         hipError_t le = launch_align_fused2(block, ls, sc, c->K, c->dprm, o, first_pair, n_pairs, c->stream);
         if (le != hipSuccess && sc.team > 1 && c->prm.team_size <= 1) {
             /* the runtime could not make the whole team launch resident at once (something else holds compute units or LDS):
@@ -595,6 +602,7 @@ int dvo_destroy(dvo_ctx *c) {
         if (c->lv[l].tex) (void)hipFree(c->lv[l].tex);
         if (c->lv[l].pts) (void)hipFree(c->lv[l].pts);
         if (c->lv[l].cpts) (void)hipFree(c->lv[l].cpts);
+        if (c->lv[l].cidx) (void)hipFree(c->lv[l].cidx);
         if (c->lv[l].dN) (void)hipFree(c->lv[l].dN);
         if (c->lv[l].p4) { (void)hipFree(c->lv[l].p4); (void)hipFree(c->lv[l].pal); (void)hipFree(c->lv[l].d_pal_n); }
     }
@@ -732,7 +740,7 @@ int dvo_set_ref_level_from_images(dvo_ctx *c, int pair, int level, const int32_t
     Level &L = c->lv[level];
     float *dst = L.pts + (size_t)pair * L.pt_cap * 3;
     HIPCHK(c, launch_enlist_write(d_edge, 0, 0, d_depth, 0, gb, level, c->K, c->d_colcounts, d_blk, dst, 0,
-                                  L.cpts + (size_t)pair * L.pt_cap, d_uv, N, nullptr, c->stream));
+                                  L.cpts + (size_t)pair * L.pt_cap, L.cidx + (size_t)pair * L.pt_cap, d_uv, N, nullptr, c->stream));
     L.compact_ok[pair] = 1;
     L.hN[pair] = N;
     c->points_gen++;
@@ -865,7 +873,7 @@ int dvo_replicate_pairs(dvo_ctx *c, int n_src, int dst_first, int dst_count) {
             any_tex16 = any_tex16 || !stale;
             any_compact = any_compact || (!L.pal_built.empty() && L.pal_built[p]);
         }
-        HIPCHK(c, launch_replicate_level(any_tex16 ? L.tex : nullptr, L.tex_stride, L.pts, L.cpts, L.pt_cap, L.dN, n_src, dst_first, dst_count, c->stream));
+        HIPCHK(c, launch_replicate_level(any_tex16 ? L.tex : nullptr, L.tex_stride, L.pts, L.cpts, L.cidx, L.pt_cap, L.dN, n_src, dst_first, dst_count, c->stream));
         for (int p = dst_first; p < dst_first + dst_count; p++) {
             L.hN[p] = L.hN[(p - dst_first) % n_src];
             c->points_gen++;
@@ -1040,10 +1048,19 @@ int dvo_get_final_outputs(dvo_ctx *c, int pair, float *final_eps, float *final_r
     HIPCHK(c, hipMemcpy(&N, c->d_final_N + pair, sizeof(int), hipMemcpyDeviceToHost));
     if (N_out) *N_out = N;
     const int n = std::min(N, capacity);
-    if (n > 0 && final_eps)
-        HIPCHK(c, hipMemcpy(final_eps, c->d_final_eps + (size_t)pair * c->final_cap, sizeof(float) * n, hipMemcpyDeviceToHost));
-    if (n > 0 && final_reproj)
-        HIPCHK(c, hipMemcpy(final_reproj, c->d_final_reproj + (size_t)pair * c->final_cap * 3, sizeof(float) * 3 * n, hipMemcpyDeviceToHost));
+    const float *src_e = c->d_final_eps + (size_t)pair * c->final_cap, *src_r = c->d_final_reproj + (size_t)pair * c->final_cap * 3;
+    if (N > 0 && c->sched.final_blk) {
+        /* the packed kernel keeps them in the order of its compact point list; the reference's order (:703-704) is made here */
+        const Level &L = c->lv[c->sched.last_level];
+        const int dpair = (c->sched.alias_mod > 0) ? pair % c->sched.alias_mod : pair;
+        int rc = ensure_staging(c, sizeof(float) * 4 * (size_t)N);
+        if (rc) return rc;
+        HIPCHK(c, launch_final_permute(L.cidx + (size_t)dpair * L.pt_cap, src_e, src_r, N, c->staging, c->staging + N, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        src_e = c->staging; src_r = c->staging + N;
+    }
+    if (n > 0 && final_eps) HIPCHK(c, hipMemcpy(final_eps, src_e, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (n > 0 && final_reproj) HIPCHK(c, hipMemcpy(final_reproj, src_r, sizeof(float) * 3 * n, hipMemcpyDeviceToHost));
     return DVO_OK;
 }
 

@@ -547,7 +547,8 @@ int dvo_frames_as_ref(dvo_ctx *c, int first_slot, int first_pair, int count, int
         const size_t off = (size_t)first_slot * F.npx;
         HIPCHK(c, launch_enlist_write(F.edge + off, 1, F.npx, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, count}, l, c->K,
                                       c->work + cc_off[l], compact_block_order() ? c->work + bc_off[l] : nullptr, L.pts + (size_t)first_pair * L.pt_cap * 3, (size_t)L.pt_cap * 3,
-                                      L.cpts + (size_t)first_pair * L.pt_cap, nullptr, L.pt_cap, L.dN + first_pair, c->stream));
+                                      L.cpts + (size_t)first_pair * L.pt_cap, L.cidx + (size_t)first_pair * L.pt_cap, nullptr, L.pt_cap,
+                                      L.dN + first_pair, c->stream));
         for (int i = 0; i < count; i++) { L.hN[first_pair + i] = hN[(size_t)l * count + i]; L.compact_ok[first_pair + i] = 1; }
         c->points_gen++;
     }

@@ -25,6 +25,7 @@ struct Level {
     size_t tex_stride = 0;
     float *pts = nullptr;
     uint2 *cpts = nullptr;          /* compact twin of pts (8 B / point), same capacity; valid where compact_ok */
+    unsigned *cidx = nullptr;       /* per compact point: its index in the 3 x N list (the compact twin is in block order) */
     std::vector<char> compact_ok;   /* per pair: the list came from the engine's enlist kernels */
     int pt_cap = 0;
     int *dN = nullptr;

@@ -945,7 +945,7 @@ __global__ void __launch_bounds__(64)
 enlist_write_kernel(const E *__restrict__ edge, size_t edge_stride, const float *__restrict__ depth, size_t depth_stride,
                     int rows, int cols, int level, Intrinsics K, const int *__restrict__ col_offsets,
                     const int *__restrict__ blk_offsets, int nby,
-                    float *__restrict__ xyz, size_t xyz_stride, uint2 *__restrict__ compact,
+                    float *__restrict__ xyz, size_t xyz_stride, uint2 *__restrict__ compact, unsigned *__restrict__ cidx,
                     float *__restrict__ uv, int capacity, int *__restrict__ N_dst) {
     const int xx = blockIdx.x, lane = threadIdx.x;
     edge += (size_t)blockIdx.y * edge_stride; depth += (size_t)blockIdx.y * depth_stride;
@@ -953,6 +953,7 @@ enlist_write_kernel(const E *__restrict__ edge, size_t edge_stride, const float 
     if (blk_offsets) blk_offsets += (size_t)blockIdx.y * (((cols + 15) >> 4) * nby * 16 + 2);
     xyz += (size_t)blockIdx.y * xyz_stride;
     if (compact) compact += (size_t)blockIdx.y * (xyz_stride / 3);
+    if (cidx) cidx += (size_t)blockIdx.y * (xyz_stride / 3);
     const int Nall = col_offsets[cols];
     if (N_dst && xx == 0 && lane == 0) N_dst[blockIdx.y] = Nall < capacity ? Nall : capacity;
     /* a truncated list (never with the engine's own capacity management) keeps the reference order in the compact twin
@@ -986,6 +987,7 @@ enlist_write_kernel(const E *__restrict__ edge, size_t edge_stride, const float 
                              __popcll((m >> (16 * seg)) & ((1ull << (lane & 15)) - 1ull));
                     }
                     compact[bC] = make_uint2((unsigned)xx | ((unsigned)yy << 16), __float_as_uint(Z));
+                    if (cidx) cidx[bC] = (unsigned)nC;          /* where this point sits in the reference's list */
                 }
                 if (uv) { uv[2 * nC] = (float)xx; uv[2 * nC + 1] = (float)yy; }   /* :244-245 */
             }
@@ -1010,9 +1012,9 @@ static hipError_t enlist_count_t(const E *edge, size_t edge_stride, const float 
 template <typename E>
 static hipError_t enlist_write_t(const E *edge, size_t edge_stride, const float *depth, size_t depth_stride, ImgBatch g,
                                  int level, const Intrinsics &K, const int *col_counts, const int *blk_counts, float *xyz,
-                                 size_t xyz_stride, uint2 *compact, float *uv, int capacity, int *N_dst, hipStream_t s) {
+                                 size_t xyz_stride, uint2 *compact, unsigned *cidx, float *uv, int capacity, int *N_dst, hipStream_t s) {
     hipLaunchKernelGGL(enlist_write_kernel<E>, dim3(g.cols, g.count), dim3(64), 0, s, edge, edge_stride, depth, depth_stride,
-                       g.rows, g.cols, level, K, col_counts, blk_counts, (g.rows + 15) >> 4, xyz, xyz_stride, compact, uv, capacity, N_dst);
+                       g.rows, g.cols, level, K, col_counts, blk_counts, (g.rows + 15) >> 4, xyz, xyz_stride, compact, cidx, uv, capacity, N_dst);
     return hipGetLastError();
 }
 
@@ -1023,11 +1025,11 @@ hipError_t launch_enlist_count(const void *edge, int edge_is_u8, size_t edge_str
 }
 hipError_t launch_enlist_write(const void *edge, int edge_is_u8, size_t edge_stride, const float *depth, size_t depth_stride,
                                ImgBatch g, int level, const Intrinsics &K, const int *col_counts, const int *blk_counts, float *xyz,
-                               size_t xyz_stride, uint2 *compact, float *uv, int capacity, int *N_dst, hipStream_t s) {
+                               size_t xyz_stride, uint2 *compact, unsigned *cidx, float *uv, int capacity, int *N_dst, hipStream_t s) {
     return edge_is_u8 ? enlist_write_t((const unsigned char *)edge, edge_stride, depth, depth_stride, g, level, K, col_counts, blk_counts,
-                                       xyz, xyz_stride, compact, uv, capacity, N_dst, s)
+                                       xyz, xyz_stride, compact, cidx, uv, capacity, N_dst, s)
                       : enlist_write_t((const int32_t *)edge, edge_stride, depth, depth_stride, g, level, K, col_counts, blk_counts,
-                                       xyz, xyz_stride, compact, uv, capacity, N_dst, s);
+                                       xyz, xyz_stride, compact, cidx, uv, capacity, N_dst, s);
 }
 
 }  // namespace dvo

@@ -358,29 +358,41 @@ DVO_DEV void accumulate_points_exact(const IterConst &c, const char *__restrict_
 }
 
 /* ---- finalEpsilons / finalReprojections of the best iterate (:703-704, :1002-1003) --------------------------------------
- * One more projection of the finest level's points and one DT look-up each.  Pipelined like the hot loop: two points per
- * lane and round, the points (3 x N float list: these two arrays are indexed like the reference's list, the compact
- * twin is in block order) fetched one round ahead, the look-ups issued one round ahead of the stores that consume them.
- * (Round 2 walked the list four points per trip with nothing in flight across trips: 15 trips x two dependent memory
- * latencies = 11 % of the whole alignment.) */
+ * One more projection of the finest level's points and one DT look-up each, over the COMPACT point list -- the copy the level
+ * already holds in LDS (the streamed tail fetched one round ahead), in its 16 x 16-block order, so that the look-ups of a wave
+ * share memory lines exactly as in the iterations -- with the look-ups issued one round ahead of the stores that consume them.
+ * The two arrays are therefore written in the compact list's order; dvo_get_final_outputs hands them out in the reference's
+ * order (LevelSlab.cidx, final_permute_kernel).  (Round 2 walked the 3 x N float list in the reference's order, four points per
+ * trip with nothing in flight across trips: 11 % of the whole alignment and 8 k of its 61 k memory requests -- the kernel sits
+ * on the request ceiling) */
 struct Final2 {
     v2f u, v, zn;
     unsigned w0, w1;        /* TEX_P4: centre rank word; else: bits of DT */
     bool vis0, vis1;
 };
-template <int TEX>
-DVO_DEV void final2_issue(const IterConst &c, const TexSrc &ts, const float *__restrict__ xyz, int i0, int i1, int N, int step,
-                          U3 &pf0, U3 &pf1, Final2 &b) {
-    const U3 a0 = pf0, a1 = pf1;
-    pf0 = *reinterpret_cast<const U3 *>(xyz + 3 * (size_t)min(i0 + step, N - 1));      /* the next round's points */
-    pf1 = *reinterpret_cast<const U3 *>(xyz + 3 * (size_t)min(i1 + step, N - 1));
+template <bool LDS_SRC, int TEX>
+DVO_DEV void final2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints &lp, const uint2 *__restrict__ gpts,
+                          int i0, int i1, int end, int step, PointPf &pf, Final2 &b) {
+    unsigned k0, k1;
+    float z0, z1;
+    if constexpr (LDS_SRC) {
+        load_compact<true>(lp, gpts, min(i0, end - 1), k0, z0);
+        load_compact<true>(lp, gpts, min(i1, end - 1), k1, z1);
+    } else {
+        k0 = pf.p0.x; z0 = __uint_as_float(pf.p0.y);
+        k1 = pf.p1.x; z1 = __uint_as_float(pf.p1.y);
+        pf.p0 = gpts[min(i0 + step, end - 1)];                  /* the next round's points */
+        pf.p1 = gpts[min(i1 + step, end - 1)];
+    }
     /* one point at a time, scalar-register pose operands: the packed form would want the pose in vector register pairs, and
      * the 256-thread shape has none to spare (tests/test_kernel_registers.py) */
     {
-        float xs, ys, zs, us, vs;
-        project_point(c, __uint_as_float(a0.a), __uint_as_float(a0.b), __uint_as_float(a0.c), xs, ys, zs, us, vs);
+        float X, Y, Z, xs, ys, zs, us, vs;
+        expand_compact(c, k0, z0, X, Y, Z);
+        project_point(c, X, Y, Z, xs, ys, zs, us, vs);
         b.u.x = us; b.v.x = vs; b.zn.x = zs;
-        project_point(c, __uint_as_float(a1.a), __uint_as_float(a1.b), __uint_as_float(a1.c), xs, ys, zs, us, vs);
+        expand_compact(c, k1, z1, X, Y, Z);
+        project_point(c, X, Y, Z, xs, ys, zs, us, vs);
         b.u.y = us; b.v.y = vs; b.zn.y = zs;
     }
     int px0, py0, px1, py1;
@@ -401,7 +413,7 @@ DVO_DEV void final2_issue(const IterConst &c, const TexSrc &ts, const float *__r
     }
 }
 template <int TEX, unsigned PAL>
-DVO_DEV void final2_store(const Final2 &b, int i0, int i1, int N, float *__restrict__ fe, float *__restrict__ fr) {
+DVO_DEV void final2_store(const Final2 &b, int i0, int i1, int end, float *__restrict__ fe, float *__restrict__ fr) {
     float e0, e1;
     if constexpr (TEX == TEX_P4) {
         e0 = *(lds_cfloat *)(size_t)(PAL + (b.w0 & 0xfff8u));
@@ -410,51 +422,46 @@ DVO_DEV void final2_store(const Final2 &b, int i0, int i1, int N, float *__restr
         e0 = b.vis0 ? __uint_as_float(b.w0) : 0.0f;
         e1 = b.vis1 ? __uint_as_float(b.w1) : 0.0f;
     }
-    if (i0 < N) {
+    if (i0 < end) {
         fe[i0] = e0;
         U3 o; o.a = __float_as_uint(b.u.x); o.b = __float_as_uint(b.v.x); o.c = __float_as_uint(b.zn.x);
         *reinterpret_cast<U3 *>(fr + 3 * (size_t)i0) = o;
     }
-    if (i1 < N) {
+    if (i1 < end) {
         fe[i1] = e1;
         U3 o; o.a = __float_as_uint(b.u.y); o.b = __float_as_uint(b.v.y); o.c = __float_as_uint(b.zn.y);
         *reinterpret_cast<U3 *>(fr + 3 * (size_t)i1) = o;
     }
 }
-/* points [0, N) of `xyz` (already offset to this workgroup's share), outputs at fe[i], fr[3 i] */
-template <int BLOCK, int TEX, unsigned PAL>
-#ifdef DVO_FINAL_NOINLINE
-__device__ __noinline__ void final_outputs2(
-#else
-DVO_DEV void final_outputs2(
-#endif
-const IterConst &c, const TexSrc &ts, const float *__restrict__ xyz, int N,
+/* compact points [first, end) of this workgroup's share; outputs at fe[i], fr[3 i] */
+template <int BLOCK, bool LDS_SRC, int TEX, unsigned PAL>
+DVO_DEV void final_outputs2(const IterConst &c, const TexSrc &ts, const LdsPoints &lp, const uint2 *__restrict__ gpts, int first, int end,
                             float *__restrict__ fe, float *__restrict__ fr) {
     constexpr int STEP = 2 * BLOCK;
     const int tid = threadIdx.x;
-    const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
-    if (wave_first >= N) return;                              /* wave-uniform */
-    const int n_rounds = (N - wave_first + STEP - 1) / STEP;  /* rounds in which this wave still has a point */
-    U3 pf0 = *reinterpret_cast<const U3 *>(xyz + 3 * (size_t)min(tid, N - 1));
-    U3 pf1 = *reinterpret_cast<const U3 *>(xyz + 3 * (size_t)min(tid + BLOCK, N - 1));
+    const int wave_first = first + __builtin_amdgcn_readfirstlane(tid & ~63);
+    if (wave_first >= end) return;                              /* wave-uniform */
+    const int n_rounds = (end - wave_first + STEP - 1) / STEP;  /* rounds in which this wave still has a point */
+    int base = first + tid;
+    PointPf pf;
+    if constexpr (!LDS_SRC) { pf.p0 = gpts[min(base, end - 1)]; pf.p1 = gpts[min(base + BLOCK, end - 1)]; }
     Final2 A, B;
-    int base = tid;
-    final2_issue<TEX>(c, ts, xyz, base, base + BLOCK, N, STEP, pf0, pf1, A);
+    final2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base, base + BLOCK, end, STEP, pf, A);
     int r = 0;
 #pragma clang loop unroll(disable)
     for (; r + 2 < n_rounds; r += 2) {
-        final2_issue<TEX>(c, ts, xyz, base + STEP, base + STEP + BLOCK, N, STEP, pf0, pf1, B);
-        final2_store<TEX, PAL>(A, base, base + BLOCK, N, fe, fr);
-        final2_issue<TEX>(c, ts, xyz, base + 2 * STEP, base + 2 * STEP + BLOCK, N, STEP, pf0, pf1, A);
-        final2_store<TEX, PAL>(B, base + STEP, base + STEP + BLOCK, N, fe, fr);
+        final2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + STEP, base + STEP + BLOCK, end, STEP, pf, B);
+        final2_store<TEX, PAL>(A, base, base + BLOCK, end, fe, fr);
+        final2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + 2 * STEP, base + 2 * STEP + BLOCK, end, STEP, pf, A);
+        final2_store<TEX, PAL>(B, base + STEP, base + STEP + BLOCK, end, fe, fr);
         base += 2 * STEP;
     }
     if (r + 1 < n_rounds) {
-        final2_issue<TEX>(c, ts, xyz, base + STEP, base + STEP + BLOCK, N, STEP, pf0, pf1, B);
-        final2_store<TEX, PAL>(A, base, base + BLOCK, N, fe, fr);
-        final2_store<TEX, PAL>(B, base + STEP, base + STEP + BLOCK, N, fe, fr);
+        final2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + STEP, base + STEP + BLOCK, end, STEP, pf, B);
+        final2_store<TEX, PAL>(A, base, base + BLOCK, end, fe, fr);
+        final2_store<TEX, PAL>(B, base + STEP, base + STEP + BLOCK, end, fe, fr);
     } else {
-        final2_store<TEX, PAL>(A, base, base + BLOCK, N, fe, fr);
+        final2_store<TEX, PAL>(A, base, base + BLOCK, end, fe, fr);
     }
 }
 
@@ -815,17 +822,19 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
                 for (int k = 0; k < 3; k++) c.t[k] = uniform_f(st.btf[k]);
                 float *fe = out.final_eps + (size_t)pair * out.final_cap;
                 float *fr = out.final_reproj + (size_t)pair * out.final_cap * 3;
-                /* these two arrays are indexed like the reference's list (:703-704): the points come from the 3 x N float list,
-                 * which keeps the reference's order (the compact twin is in block order, dvo_frames.hip) -- same X, Y, Z bits */
-                const float *__restrict__ xyz = L.pts + (size_t)dpair * L.pt_cap * 3;
-                const float *__restrict__ xs = xyz + 3 * (size_t)pfirst;
+                /* written in the order of the compact list (this workgroup's share starts at pfirst); the host hands them out in
+                 * the reference's order (LevelSlab.cidx) */
                 float *fes = fe + pfirst, *frs = fr + 3 * (size_t)pfirst;
 #ifndef DVO_NO_FINAL
-                if (mode == TEX_P4) final_outputs2<BLOCK, TEX_P4, kStatic>(c, ts, xs, N, fes, frs);
-#ifndef DVO_FINAL_P4_ONLY
-                else if (mode == TEX_L16) final_outputs2<BLOCK, TEX_L16, kStatic>(c, ts, xs, N, fes, frs);
-                else final_outputs2<BLOCK, TEX_G16, kStatic>(c, ts, xs, N, fes, frs);
-#endif
+                if (mode == TEX_P4) {
+                    final_outputs2<BLOCK, true, TEX_P4, kStatic>(c, ts, lp, gpts, 0, n_lds, fes, frs);
+                    final_outputs2<BLOCK, false, TEX_P4, kStatic>(c, ts, lp, gpts, n_lds, N, fes, frs);
+                } else if (mode == TEX_L16) {
+                    final_outputs2<BLOCK, true, TEX_L16, kStatic>(c, ts, lp, gpts, 0, N, fes, frs);
+                } else {
+                    final_outputs2<BLOCK, true, TEX_G16, kStatic>(c, ts, lp, gpts, 0, n_lds, fes, frs);
+                    final_outputs2<BLOCK, false, TEX_G16, kStatic>(c, ts, lp, gpts, n_lds, N, fes, frs);
+                }
 #endif
             }
             if (tid == 0 && member == 0) out.final_N[pair] = (st.bestItr >= 0) ? Nall : 0;

@@ -183,7 +183,7 @@ hipError_t launch_pack_texels(const float *dt, const float *gx, const float *gy,
 /* slot p in [dst_first, dst_first+dst_count) <- copy of slot (p - dst_first) % n_src : one launch per level
  * instead of a pack + copies per pair (bench / throughput set-up, warm replicas) */
 __global__ void __launch_bounds__(256)
-replicate_level_kernel(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, int pt_cap, int *N,
+replicate_level_kernel(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, unsigned *cidx, int pt_cap, int *N,
                        int n_src, int dst_first, int dst_count) {
     const int p = dst_first + blockIdx.y;
     const int src = blockIdx.y % n_src;
@@ -203,13 +203,37 @@ replicate_level_kernel(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, 
         uint2 *dc = cpts + (size_t)p * pt_cap;
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n; i += stride) dc[i] = sc_[i];
     }
+    if (cidx) {
+        const unsigned *si = cidx + (size_t)src * pt_cap;
+        unsigned *di = cidx + (size_t)p * pt_cap;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n; i += stride) di[i] = si[i];
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) N[p] = n;
 }
-hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, int pt_cap, int *N,
+hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, unsigned *cidx, int pt_cap, int *N,
                                   int n_src, int dst_first, int dst_count, hipStream_t s) {
     if (dst_count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(replicate_level_kernel, dim3(64, dst_count), dim3(256), 0, s, tex, tex_stride, pts, cpts, pt_cap, N,
+    hipLaunchKernelGGL(replicate_level_kernel, dim3(64, dst_count), dim3(256), 0, s, tex, tex_stride, pts, cpts, cidx, pt_cap, N,
                        n_src, dst_first, dst_count);
+    return hipGetLastError();
+}
+
+/* The packed kernel writes finalEpsilons / finalReprojections in the order of its compact point list (16 x 16 blocks: the
+ * order it gathers in); callers get them in the reference's order (:703-704): out[cidx[i]] = in[i], at the boundary, on demand. */
+__global__ void __launch_bounds__(256)
+final_permute_kernel(const unsigned *__restrict__ cidx, const float *__restrict__ fe_blk, const float *__restrict__ fr_blk, int n,
+                     float *__restrict__ fe, float *__restrict__ fr) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned j = cidx[i];
+        if (j >= (unsigned)n) continue;
+        fe[j] = fe_blk[i];
+        fr[3 * (size_t)j] = fr_blk[3 * (size_t)i]; fr[3 * (size_t)j + 1] = fr_blk[3 * (size_t)i + 1]; fr[3 * (size_t)j + 2] = fr_blk[3 * (size_t)i + 2];
+    }
+}
+hipError_t launch_final_permute(const unsigned *cidx, const float *fe_blk, const float *fr_blk, int n, float *fe, float *fr, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    int blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(final_permute_kernel, dim3(blocks), dim3(256), 0, s, cidx, fe_blk, fr_blk, n, fe, fr);
     return hipGetLastError();
 }
 

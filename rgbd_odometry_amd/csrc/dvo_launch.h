@@ -30,6 +30,7 @@ struct LevelSlab {
     const float4 *tex;
     const float *pts;
     const uint2 *cpts;      /* compact points {xx | yy << 16, Z}, pt_cap per pair; valid where the host says so (Schedule.compact) */
+    const unsigned *cidx;   /* index of each compact point in the 3 x N list (block order -> reference order), pt_cap per pair */
     const int *N;
     size_t tex_stride;      /* texels per pair */
     int pt_cap;             /* points per pair (capacity) */
@@ -58,6 +59,7 @@ struct Schedule {
     int n_pairs_launch;      /* pairs of this launch (team mode maps workgroups to pairs itself) */
     int force_exact;         /* tests: every wave takes the literal-division fallback of the packed kernel (accumulate_points_exact) */
     int compact;             /* every pair/level of this launch has a compact point list: read 8 B / point instead of 12 */
+    int final_blk;           /* host bookkeeping: the final outputs of this launch are stored in the compact lists' (block) order */
 };
 
 struct Intrinsics { float fx, fy, cx, cy; int interp; /* dvo_params.interpolate_dt, travels with the camera model to every kernel */ };
@@ -87,8 +89,10 @@ size_t palette_work_ints(int count);        /* scratch of one launch_palette_bui
 hipError_t launch_palette_build(const float4 *tex, size_t tex_stride, int rows, int cols, unsigned *p4, size_t p4_stride,
                                 float2 *pal, int *pal_n, int first_pair, int count, unsigned *work, hipStream_t s);
 bool fused_uses_compact(int points_in_flight, int interp);
-hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, int pt_cap, int *N,
+hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, unsigned *cidx, int pt_cap, int *N,
                                   int n_src, int dst_first, int dst_count, hipStream_t s);
+/* final outputs stored in block order -> the reference's order: out[cidx[i]] = in[i] */
+hipError_t launch_final_permute(const unsigned *cidx, const float *fe_blk, const float *fr_blk, int n, float *fe, float *fr, hipStream_t s);
 /* the compact now form of slots [dst_first, dst_first+dst_count) <- that of pair (p - dst_first) % n_src */
 hipError_t launch_replicate_compact(unsigned *p4, size_t p4_stride, float2 *pal, int *pal_n, int n_src, int dst_first,
                                     int dst_count, hipStream_t s);
@@ -172,7 +176,7 @@ hipError_t launch_enlist_count(const void *edge, int edge_is_u8, size_t edge_str
 hipError_t launch_enlist_write(const void *edge, int edge_is_u8, size_t edge_stride, const float *depth_mm,
                                size_t depth_stride, ImgBatch g, int level, const Intrinsics &K, const int *col_counts,
                                const int *blk_counts, float *xyz, size_t xyz_stride,
-                               uint2 *compact /* same stride in points / 3, or nullptr */,
+                               uint2 *compact /* same stride in points / 3, or nullptr */, unsigned *cidx /* likewise */,
                                float *uv, int capacity, int *N_dst, hipStream_t s);
 
 /* ---- photometric Gauss-Newton (dvo_photo.hip): RGBDOdometry's engine ---- */

@@ -17,7 +17,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+extra = sys.argv[2:]          # extra bench.py arguments, e.g. --batch 1024 (the record key follows them)
 out_dir = os.path.join(ROOT, "gpurun_out", "pmc_traffic_" + tag)
 os.makedirs(out_dir, exist_ok=True)
 os.environ["TMPDIR"] = "/tmp"
@@ -25,8 +26,8 @@ groups = {"fetch": "FETCH_SIZE", "write": "WRITE_SIZE", "req": "TCC_EA0_RDREQ_su
 vals = {}
 for name, cnt in groups.items():
     d = os.path.join(out_dir, name)
-    cmd = ["timeout", "150", "rocprofv3", "--pmc"] + cnt.split() + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc",
-           "--", "python3", os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-frames-leg"]
+    cmd = ["timeout", "240", "rocprofv3", "--pmc"] + cnt.split() + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc",
+           "--", "python3", os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-extra-legs"] + extra
     r = subprocess.run(cmd, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     open(os.path.join(out_dir, name + ".log"), "w").write(r.stdout)
     print(name, "rc", r.returncode)
@@ -42,15 +43,19 @@ rec = {
     "hbm_bytes_per_launch": int(fetch + write), "fetch_bytes": int(fetch), "write_bytes": int(write),
     "l2_read_requests": int(avg["TCC_EA0_RDREQ_sum"]), "l2_requests": int(avg.get("TCC_REQ_sum", 0)), "l2_hits": int(avg.get("TCC_HIT_sum", 0)),
     "kernel_source_sha256": bench.kernel_source_hash(),
-    "source": "tools/update_pmc_traffic.py %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_EA0_RDREQ, separate passes over bench.py "
-              "--steps 3; FETCH_SIZE calibrated for sparse 16-byte gathers in profiles/r01_fetch_size_calibration: exact, no 2x correction)" % tag,
+    "source": ("tools/update_pmc_traffic.py %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_EA0_RDREQ, separate passes over bench.py "
+               "--steps 3 %s; FETCH_SIZE calibrated for sparse 16-byte gathers in profiles/r01_fetch_size_calibration: exact, no 2x "
+               "correction)") % (tag, " ".join(extra)),
 }
 path = os.path.join(ROOT, "gpurun_out", "pmc_traffic.json")
 try:
     allrec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
 except Exception:
     allrec = {}
-allrec["640x480x4x10_b1024"] = rec
+sys.argv = ["bench.py"] + extra
+a = bench.parse_args()
+key = "%dx%dx%dx%d_b%d" % (a.width, a.height, a.levels, a.iters, a.batch)
+allrec[key] = rec
 json.dump(allrec, open(path, "w"), indent=2)
 print("wrote", path, "(copy to profiles/pmc_traffic.json)")
 print(json.dumps(rec, indent=2))
