@@ -367,11 +367,11 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         /* ... which only pays when there are enough pairs to put two workgroups on a CU: a launch of fewer pairs than
          * half the CUs is latency-bound and 512 threads finish an iteration sooner (single pair, 320x240x4x50:
          * 1.20 -> 1.06 ms) */
-        if ((size_t)max_n * 12 <= 77000 && !c->prm.interpolate_dt && 2 * n_pairs > c->n_cu) { block = 256; auto_lds = 77000; }
+        if ((size_t)max_n * 12 <= 77000 && !c->prm.interpolate_dt && 2 * n_pairs > c->n_cu) { block = 256; auto_lds = 80 * 1024; }
         /* with the compact now form the loop is no longer request-bound and two workgroups per CU pay even when the lists do
          * not fit half the LDS (640x480x4x10, 1024 pairs: 510 k aligns/s with one 512-thread workgroup per CU, 593 k with two
          * of 256; 768 pairs 538 k vs 575 k, 384 pairs 403 k vs 453 k, 256 pairs 466 k vs 387 k -- so from 1.5 workgroups per CU) */
-        else if (all_p4 && 2 * n_pairs >= 3 * c->n_cu && (size_t)max_n * 8 <= 2 * (size_t)77000) { block = 256; auto_lds = 77000; }
+        else if (all_p4 && 2 * n_pairs >= 3 * c->n_cu && (size_t)max_n * 8 <= 2 * (size_t)77000) { block = 256; auto_lds = 80 * 1024; }
         else if ((size_t)max_n * 12 > 4 * (size_t)155000 && !c->prm.interpolate_dt) { block = 1024; auto_lds = 155000; }   /* lists far beyond the LDS
                                                                        budget are streamed: 16 waves hide that better (1920x1080x5, 256 pairs: 38.3 k -> 41.3 k aligns/s) */
         else { block = 512; auto_lds = 155000; }
@@ -380,13 +380,15 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
     {
         int bytes = c->prm.lds_point_bytes;
         /* auto: one workgroup per CU for >= 512 threads (it owns the CU's LDS), two for 256 */
-        if (bytes == 0) bytes = auto_lds ? auto_lds : ((block >= 512) ? 155000 : 77000);
+        if (bytes == 0) bytes = auto_lds ? auto_lds : ((block >= 512) ? 155000 : 80 * 1024);
         /* the CU has 160 KiB of LDS; the static part of the chosen kernel comes off the top */
         /* the packed kernel needs its 256-register budget: 1024 threads would halve it (measured, 1920x1080x5, 256 pairs:
          * 512 threads 45.2 k aligns/s, 1024 threads 41.3 k; the one-point-per-lane kernel: 43.7 k at 1024) */
         if (packed && block_auto && block == 1024) block = 512;
         const int static_lds = packed ? (int)fused2_static_lds(block) : (int)(sizeof(double) * (block / 64) * DVO_NACC_PAD + 256 + pose_state_bytes());
-        const int max_dyn = 160 * 1024 - static_lds - 64;
+        /* 256 threads: two workgroups share the CU's LDS -- each gets exactly half, down to the last point that fits (at the
+         * request ceiling every point kept out of the per-iteration stream counts: DESIGN.md section 6) */
+        const int max_dyn = ((block == 256) ? 80 * 1024 : 160 * 1024) - static_lds - 64;
         if (bytes > max_dyn) bytes = max_dyn;
         if (bytes < 0) bytes = 0;
         bytes &= ~63;

@@ -517,16 +517,22 @@ edt_columns16_kernel(const unsigned char *__restrict__ edge, size_t edge_stride,
 
 /* phase 2: d2(x,y) = min_i (x-i)^2 + g(i,y)^2 along the row, exactly, in integers (< 2^32 for every supported size).  Each
  * pixel scans outwards while i^2 < best: with edges every few pixels that is a few dozen steps, far cheaper on a GPU than
- * the sequential lower-envelope scan (Meijster) a CPU would use -- same minimum.  A workgroup stages R whole rows of g in
- * LDS so that the scan runs out of LDS, not L2; per-block maxima go to `partial`; the values produced are recorded in the
- * image's presence bitmap (an LDS copy first -- a bit is only set if it is not there yet, so the atomics die out after the
- * first few pixels -- merged into HBM once per workgroup). */
+ * the sequential lower-envelope scan (Meijster) a CPU would use -- same minimum.  A workgroup stages R whole rows of g^2
+ * (32 bit: no multiply in the scan) in LDS so that the scan runs out of LDS, not L2.  The scan has two phases: while both
+ * neighbours i columns away are inside the image, four steps per trip with the LDS addresses in the instructions' offset
+ * fields (a step past i^2 >= best only adds candidates that cannot win, so the exit test runs once per trip); then, for the
+ * pixels that have not finished when one side hits the border, the remaining side alone.  Per-block maxima go to `partial`;
+ * the values produced are recorded in the image's presence bitmap (an LDS copy first -- a bit is only set if it is not there
+ * yet, so the atomics die out after the first few pixels -- merged into HBM once per workgroup). */
 constexpr int EDT_LBITS_WORDS = 2048;               /* d2 < 65536 go through the LDS copy of the bitmap */
-template <int R>
+/* T = unsigned: the tile holds g^2; T = unsigned short (rows too long for that, beyond 16 K columns): g, squared at use */
+template <typename T> DVO_DEV unsigned edt_sq(T v) { return (sizeof(T) == 2) ? (unsigned)v * (unsigned)v : (unsigned)v; }
+template <int R, typename T>
 __global__ void __launch_bounds__(256)
 edt_rows16_kernel(const unsigned short *__restrict__ g, int rows, int cols, unsigned *__restrict__ d2, int *__restrict__ partial,
                   unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags) {
-    extern __shared__ unsigned short tile[];                  /* [cols][R] */
+    extern __shared__ unsigned char tile_raw[];
+    T *tile = reinterpret_cast<T *>(tile_raw);                /* [cols][R]: g^2 (or g) */
     __shared__ unsigned lbits[EDT_LBITS_WORDS];
     const size_t n = (size_t)rows * cols;
     g += (size_t)blockIdx.y * n; d2 += (size_t)blockIdx.y * n;
@@ -536,7 +542,8 @@ edt_rows16_kernel(const unsigned short *__restrict__ g, int rows, int cols, unsi
     for (int i = threadIdx.x; i < EDT_LBITS_WORDS; i += 256) lbits[i] = 0u;
     for (int idx = threadIdx.x; idx < total; idx += 256) {
         const int xx = idx / R, r = idx - xx * R, yy = y0 + r;
-        tile[idx] = (yy < rows) ? g[(size_t)xx * rows + yy] : (unsigned short)0;
+        const unsigned gv = (yy < rows) ? (unsigned)g[(size_t)xx * rows + yy] : 0u;
+        tile[idx] = (T)((sizeof(T) == 2) ? gv : gv * gv);
     }
     __syncthreads();
     unsigned mx = 0;
@@ -544,21 +551,43 @@ edt_rows16_kernel(const unsigned short *__restrict__ g, int rows, int cols, unsi
     for (int idx = threadIdx.x; idx < total; idx += 256) {
         const int xx = idx / R, r = idx - xx * R, yy = y0 + r;
         if (yy >= rows) continue;
-        const unsigned g0 = tile[idx];
-        unsigned best = g0 * g0;
-        /* Branch-free steps: an index that leaves the row is clamped to its end.  The clamped candidate
-         * i^2 + g(end)^2 can only exceed the one the end pixel produced at its true distance, so the minimum is
-         * unchanged, and the loop needs no per-side exec masking. */
-        const int imax = (xx > cols - 1 - xx) ? xx : cols - 1 - xx;
-        const int base = idx - xx * R;                        /* LDS index of (column 0, this row) */
+        unsigned best = edt_sq<T>(tile[idx]);
+        const int near_side = (xx < cols - 1 - xx) ? xx : cols - 1 - xx;      /* steps for which both neighbours exist */
+        const int far_side = (xx > cols - 1 - xx) ? xx : cols - 1 - xx;
+        const T *pl = tile + idx, *pr = tile + idx;
+        int i = 1;
         unsigned i2 = 1;
-        for (int i = 1; i2 < best && i <= imax; i++) {
-            const int xl = (xx - i > 0) ? xx - i : 0, xr = (xx + i < cols - 1) ? xx + i : cols - 1;
-            const unsigned gl = tile[base + xl * R], gr = tile[base + xr * R];
-            const unsigned cl = i2 + gl * gl, cr = i2 + gr * gr;
-            best = cl < best ? cl : best;
-            best = cr < best ? cr : best;
-            i2 += 2 * i + 1;
+        /* both sides, four steps per trip */
+        while (i + 3 <= near_side && i2 < best) {
+            const T a0 = pl[-1 * R], b0 = pr[1 * R], a1 = pl[-2 * R], b1 = pr[2 * R];
+            const T a2 = pl[-3 * R], b2 = pr[3 * R], a3 = pl[-4 * R], b3 = pr[4 * R];
+            const unsigned s1 = i2 + 2u * i + 1u, s2 = s1 + 2u * i + 3u, s3 = s2 + 2u * i + 5u;      /* (i+1)^2, (i+2)^2, (i+3)^2 */
+            unsigned c0 = i2 + edt_sq<T>((T)(a0 < b0 ? a0 : b0)), c1 = s1 + edt_sq<T>((T)(a1 < b1 ? a1 : b1));      /* squaring is monotone: min first */
+            unsigned c2 = s2 + edt_sq<T>((T)(a2 < b2 ? a2 : b2)), c3 = s3 + edt_sq<T>((T)(a3 < b3 ? a3 : b3));
+            c0 = c0 < c1 ? c0 : c1; c2 = c2 < c3 ? c2 : c3;
+            c0 = c0 < c2 ? c0 : c2;
+            best = c0 < best ? c0 : best;
+            pl -= 4 * R; pr += 4 * R;
+            i += 4; i2 = s3 + 2u * i - 1u;                    /* (i+4)^2 = (i+3)^2 + 2(i+3)+1, with i already advanced */
+        }
+        /* the last (fewer than four) two-sided steps */
+        for (; i <= near_side && i2 < best; i++) {
+            pl -= R; pr += R;
+            const T a = *pl, b = *pr;
+            const unsigned c = i2 + edt_sq<T>((T)(a < b ? a : b));
+            best = c < best ? c : best;
+            i2 += 2u * i + 1u;
+        }
+        /* one side left (the pixel sits closer to the other border than its nearest edge found so far) */
+        if (i <= far_side && i2 < best) {
+            const int dir = (xx < cols - 1 - xx) ? R : -R;    /* the side that still has columns */
+            const T *p = tile + idx + dir * (i - 1);
+            for (; i <= far_side && i2 < best; i++) {
+                p += dir;
+                const unsigned c = i2 + edt_sq<T>(*p);
+                best = c < best ? c : best;
+                i2 += 2u * i + 1u;
+            }
         }
         d2[(size_t)xx * rows + yy] = best;
         mx = best > mx ? best : mx;
@@ -602,24 +631,28 @@ DVO_DEV float edt_value(unsigned d2v, const EdtScale &s) {
     return raw * s.scale_f + s.shift_f;
 }
 
-/* phase 3: squared distances -> rank words + palette.  One workgroup per tile of PK_LC x PK_LR lines of the compact image
- * (64 x 48 pixels).  Every workgroup rebuilds the image's rank table from the presence bitmap in LDS (a few hundred words
- * for ordinary images: prefix popcounts), looks up the rank of every pixel of its tile and of a one-pixel halo (reflect-101 at
- * the image border: cv::filter2D's default), and writes the tile's words -- own rank, signed rank steps to the horizontal
- * neighbours, the apron rows above and below.  Workgroup 0 of an image also writes the palette {P, W} (the 16-byte path's
- * expressions: edt_value, weight_of), the sentinel entry and line, and pal_n. */
+/* phase 3: squared distances -> rank words + palette.  A workgroup takes a strip of tiles (PK_LC x PK_LR lines of the compact
+ * image = 64 x 48 pixels each, `strip` of them along yy).  It rebuilds the image's rank table from the presence bitmap in LDS
+ * once (a few hundred words for ordinary images: prefix popcounts), then per tile looks up the rank of every pixel and of a
+ * one-pixel halo (reflect-101 at the image border: cv::filter2D's default) and writes the tile's words -- own rank, signed rank
+ * steps to the horizontal neighbours, the apron rows above and below.  Workgroup 0 of an image also writes the palette {P, W}
+ * (the 16-byte path's expressions: edt_value, weight_of), the sentinel entry and line, and pal_n.
+ * Two instantiations: BM_WORDS = 2048 (squared distances below 65536: 19 KB of LDS, many workgroups per CU -- every ordinary
+ * image) and the full bitmap (54 KB); each skips the images that belong to the other. */
 constexpr int PK_LC = 16, PK_LR = 8;
 constexpr int PK_W = PK_LC * 4 + 2, PK_H = PK_LR * DVO_P4_ROWS + 2;
+constexpr int PK_SMALL_WORDS = 2048;
+template <int BM_WORDS>
 __global__ void __launch_bounds__(256)
-edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int tiles_y, const int *__restrict__ partial, int n_partial,
+edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int tiles_y, int strip, const int *__restrict__ partial, int n_partial,
                      const unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags,
                      unsigned *__restrict__ p4, size_t p4_stride, float2 *__restrict__ pal, int *__restrict__ pal_n, int first_pair) {
-    __shared__ unsigned lbm[DVO_EDT_BITMAP_BITS / 32];
-    __shared__ unsigned short lpre[DVO_EDT_BITMAP_BITS / 32];
+    __shared__ unsigned lbm[BM_WORDS];
+    __shared__ unsigned short lpre[BM_WORDS];
     __shared__ unsigned short rk[PK_W * PK_H];                  /* [x][y], halo 1 */
-    __shared__ int s_scan[256];
+    __shared__ int s_wave[4];
     __shared__ int s_max;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pair = first_pair + blockIdx.y;
     const size_t n = (size_t)rows * cols;
     d2 += (size_t)blockIdx.y * n;
@@ -628,8 +661,9 @@ edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int ti
     p4 += (size_t)pair * p4_stride;
     pal += (size_t)pair * DVO_PAL_MAX;
     const bool first_wg = blockIdx.x == 0;
-    if (rows < 2 || cols < 2) { if (first_wg && tid == 0) pal_n[pair] = -(int)PAL_SHAPE; return; }
-    if (flags[blockIdx.y] & EDT_FLAG_FAR) { if (first_wg && tid == 0) pal_n[pair] = -(int)PAL_FAR; return; }
+    const bool small = BM_WORDS == PK_SMALL_WORDS;
+    if (rows < 2 || cols < 2) { if (first_wg && tid == 0 && small) pal_n[pair] = -(int)PAL_SHAPE; return; }
+    if (flags[blockIdx.y] & EDT_FLAG_FAR) { if (first_wg && tid == 0 && small) pal_n[pair] = -(int)PAL_FAR; return; }
     int m = 0;
     for (int k = tid; k < n_partial; k += 256) { const int v = partial[k]; m = v > m ? v : m; }
     m = block_reduce_256<true>(m);
@@ -637,22 +671,22 @@ edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int ti
     __syncthreads();
     const unsigned m2 = (unsigned)s_max;
     const int nw = (int)(m2 >> 5) + 1;                          /* <= bm_words: no FAR flag */
+    if ((nw <= PK_SMALL_WORDS) != small) return;                /* the other instantiation's image */
     const int per = (nw + 255) / 256;
     const int w0 = tid * per, w1 = (w0 + per < nw) ? w0 + per : nw;
     int cnt = 0;
     for (int w = w0; w < w1; w++) { const unsigned v = bm[w]; lbm[w] = v; cnt += __popc(v); }
-    s_scan[tid] = cnt;
+    int incl = cnt;                                             /* inclusive scan over the workgroup: wave shuffles + 4 wave totals */
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+    if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {                   /* Hillis-Steele inclusive scan */
-        const int v = (tid >= off) ? s_scan[tid - off] : 0;
-        __syncthreads();
-        s_scan[tid] += v;
-        __syncthreads();
-    }
-    const int n_pal = s_scan[255];
+    int wave_off = 0, n_pal = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const int t = s_wave[w]; n_pal += t; if (w < wave) wave_off += t; }
     if (n_pal > DVO_PAL_MAX - 1) { if (first_wg && tid == 0) pal_n[pair] = -(int)PAL_TOO_MANY; return; }
     {
-        int run = (tid == 0) ? 0 : s_scan[tid - 1];
+        int run = wave_off + incl - cnt;
         for (int w = w0; w < w1; w++) { lpre[w] = (unsigned short)run; run += __popc(lbm[w]); }
     }
     __syncthreads();
@@ -673,40 +707,46 @@ edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int ti
     }
     auto rank_of = [&](unsigned v) -> int { return (int)lpre[v >> 5] + __popc(lbm[v >> 5] & ((1u << (v & 31u)) - 1u)); };
     const int tpc = p4_tiles_per_col(rows);
-    const int ty0 = (blockIdx.x % tiles_y) * PK_LR, tc0 = (blockIdx.x / tiles_y) * PK_LC;
-    const int y0 = ty0 * DVO_P4_ROWS - 1, x0 = tc0 * 4 - 1;     /* image coordinates of rk[0][0] */
-    for (int idx = tid; idx < PK_W * PK_H; idx += 256) {
-        const int lx = idx / PK_H, ly = idx - lx * PK_H;
-        int yy = y0 + ly, xx = x0 + lx;
-        int r = 0;
-        if (yy <= rows && xx <= cols) {                          /* one pixel beyond the image is the reflected neighbour */
-            yy = reflect101(yy, rows); xx = reflect101(xx, cols);
-            r = rank_of(d2[(size_t)xx * rows + yy]);
-        }
-        rk[idx] = (unsigned short)r;
-    }
-    __syncthreads();
-    bool bad_step = false;
     const int n_tcols = (cols + 3) >> 2;
-    for (int s = tid; s < PK_LC * PK_LR * 32; s += 256) {
-        /* consecutive lanes -> consecutive words of a line, consecutive lines of a column of lines: contiguous in memory */
-        const int lc = s / (PK_LR * 32), rem = s - lc * (PK_LR * 32);
-        const int lr = rem >> 5, wd = rem & 31, xl = wd >> 3, srow = wd & 7;
-        const int tc = tc0 + lc, ty = ty0 + lr;
-        if (tc >= n_tcols || ty >= tpc) continue;
-        const int xx = tc * 4 + xl, ys = ty * DVO_P4_ROWS + srow - 1;    /* image row this slot stands for (-1 / rows: reflected) */
-        unsigned word = 0u;
-        if (xx < cols && ys <= rows) {
-            const int lx = xx - x0, ly = ys - y0;
-            const int c = rk[lx * PK_H + ly];
-            word = (unsigned)c << 3;
-            if (srow >= 1 && srow <= DVO_P4_ROWS && ys < rows) {
-                const int dr = (int)rk[(lx + 1) * PK_H + ly] - c, dl = (int)rk[(lx - 1) * PK_H + ly] - c;
-                if (dr < -127 || dr > 127 || dl < -127 || dl > 127) bad_step = true;
-                word |= (((unsigned)dr & 0xffu) << 16) | (((unsigned)dl & 0xffu) << 24);
+    const int n_strips = (tiles_y + strip - 1) / strip;
+    const int sy = blockIdx.x % n_strips, tcx = blockIdx.x / n_strips;
+    const int tc0 = tcx * PK_LC, x0 = tc0 * 4 - 1;
+    bool bad_step = false;
+    for (int t = sy * strip; t < tiles_y && t < (sy + 1) * strip; t++) {
+        const int ty0 = t * PK_LR;
+        const int y0 = ty0 * DVO_P4_ROWS - 1;                   /* image coordinates of rk[0][0]: (y0, x0) */
+        for (int idx = tid; idx < PK_W * PK_H; idx += 256) {
+            const int lx = idx / PK_H, ly = idx - lx * PK_H;
+            int yy = y0 + ly, xx = x0 + lx;
+            int r = 0;
+            if (yy <= rows && xx <= cols) {                      /* one pixel beyond the image is the reflected neighbour */
+                yy = reflect101(yy, rows); xx = reflect101(xx, cols);
+                r = rank_of(d2[(size_t)xx * rows + yy]);
             }
+            rk[idx] = (unsigned short)r;
         }
-        p4[32u + ((size_t)tc * tpc + ty) * 32u + wd] = word;
+        __syncthreads();
+        for (int s = tid; s < PK_LC * PK_LR * 32; s += 256) {
+            /* consecutive lanes -> consecutive words of a line, consecutive lines of a column of lines: contiguous in memory */
+            const int lc = s / (PK_LR * 32), rem = s - lc * (PK_LR * 32);
+            const int lr = rem >> 5, wd = rem & 31, xl = wd >> 3, srow = wd & 7;
+            const int tc = tc0 + lc, ty = ty0 + lr;
+            if (tc >= n_tcols || ty >= tpc) continue;
+            const int xx = tc * 4 + xl, ys = ty * DVO_P4_ROWS + srow - 1;    /* image row this slot stands for (-1 / rows: reflected) */
+            unsigned word = 0u;
+            if (xx < cols && ys <= rows) {
+                const int lx = xx - x0, ly = ys - y0;
+                const int c = rk[lx * PK_H + ly];
+                word = (unsigned)c << 3;
+                if (srow >= 1 && srow <= DVO_P4_ROWS && ys < rows) {
+                    const int dr = (int)rk[(lx + 1) * PK_H + ly] - c, dl = (int)rk[(lx - 1) * PK_H + ly] - c;
+                    if (dr < -127 || dr > 127 || dl < -127 || dl > 127) bad_step = true;
+                    word |= (((unsigned)dr & 0xffu) << 16) | (((unsigned)dl & 0xffu) << 24);
+                }
+            }
+            p4[32u + ((size_t)tc * tpc + ty) * 32u + wd] = word;
+        }
+        __syncthreads();
     }
     if (__syncthreads_or(bad_step ? 1 : 0) && tid == 0) atomicOr(flags + blockIdx.y, (int)EDT_FLAG_STEP);
     if (first_wg && tid == 0) pal_n[pair] = n_pal;               /* EDT_FLAG_STEP overrides it in the fallback launch */
@@ -802,10 +842,10 @@ hipError_t launch_p4_decode_texels(const unsigned *p4, size_t p4_stride, const f
     return hipGetLastError();
 }
 
-static int edt_rows_per_block(int cols) {             /* LDS rows per workgroup of the row pass (16-bit g) */
+static int edt_rows_per_block(int cols) {             /* LDS rows per workgroup of the row pass: 32-bit g^2, beyond 16 K columns 16-bit g */
     for (int R = 16; R > 1; R >>= 1)
-        if ((size_t)cols * R * 2 <= 64 * 1024) return R;
-    return 1;                                         /* cols < 46340: at most 91 KiB */
+        if ((size_t)cols * R * 4 <= 64 * 1024) return R;
+    return 1;                                         /* cols < 46340: at most 91 KiB of 16-bit g */
 }
 static unsigned edt_row_blocks(int rows, int cols) { const int R = edt_rows_per_block(cols); return (unsigned)((rows + R - 1) / R); }
 /* scratch of one launch_edges_to_now over `count` images, in ints: g (16 bit) | d2 | per-block maxima | bitmaps | flags */
@@ -814,11 +854,11 @@ size_t edt_work_ints(int rows, int cols, int count) {
     return ((n + 1) / 2 + 4 + n + edt_row_blocks(rows, cols) + (size_t)edt_bitmap_words(rows, cols) + 1) * count + 64;
 }
 
-template <int R>
+template <int R, typename T>
 static hipError_t edt_rows_launch(const unsigned short *g, ImgBatch gb, unsigned nblk, unsigned *d2, int *partial, unsigned *bitmap,
                                   int bm_words, int *flags, hipStream_t s) {
-    const size_t lds = (size_t)gb.cols * R * 2;
-    auto kern = edt_rows16_kernel<R>;
+    const size_t lds = (size_t)gb.cols * R * sizeof(T);
+    auto kern = edt_rows16_kernel<R, T>;
     if (lds > 48 * 1024) {
         const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -853,17 +893,28 @@ hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, Im
                            bm_words, flags);
     }
     switch (R) {
-    case 16: e = edt_rows_launch<16>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
-    case 8: e = edt_rows_launch<8>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
-    case 4: e = edt_rows_launch<4>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
-    case 2: e = edt_rows_launch<2>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
-    default: e = edt_rows_launch<1>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
+    case 16: e = edt_rows_launch<16, unsigned>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
+    case 8: e = edt_rows_launch<8, unsigned>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
+    case 4: e = edt_rows_launch<4, unsigned>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
+    case 2: e = edt_rows_launch<2, unsigned>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
+    default:
+        e = ((size_t)gb.cols * 4 <= 64 * 1024) ? edt_rows_launch<1, unsigned>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s)
+                                               : edt_rows_launch<1, unsigned short>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s);
+        break;
     }
     if (e != hipSuccess) return e;
     if (p4) {
         const int ptiles_y = (p4_tiles_per_col(gb.rows) + PK_LR - 1) / PK_LR, ptiles_x = (((gb.cols + 3) >> 2) + PK_LC - 1) / PK_LC;
-        hipLaunchKernelGGL(edt_rank_pack_kernel, dim3(ptiles_y * ptiles_x, gb.count), dim3(256), 0, s, d2, gb.rows, gb.cols, ptiles_y, partial,
-                           (int)nblk, bitmap, bm_words, flags, p4, p4_stride, pal, pal_n, first_pair);
+        /* tiles per workgroup: whole tile columns for large batches (the rank table is built once per workgroup), single tiles
+         * when the launch would not fill the GPU otherwise (one camera stream) */
+        long long strip = (long long)gb.count * ptiles_y * ptiles_x / 2048;
+        strip = strip < 1 ? 1 : (strip > ptiles_y ? ptiles_y : strip);
+        const int n_strips = (ptiles_y + (int)strip - 1) / (int)strip;
+        hipLaunchKernelGGL(edt_rank_pack_kernel<PK_SMALL_WORDS>, dim3(n_strips * ptiles_x, gb.count), dim3(256), 0, s, d2, gb.rows, gb.cols, ptiles_y,
+                           (int)strip, partial, (int)nblk, bitmap, bm_words, flags, p4, p4_stride, pal, pal_n, first_pair);
+        if (bm_words > PK_SMALL_WORDS)            /* squared distances of 65536 and more are possible at this size: the full-bitmap twin */
+            hipLaunchKernelGGL(edt_rank_pack_kernel<DVO_EDT_BITMAP_BITS / 32>, dim3(n_strips * ptiles_x, gb.count), dim3(256), 0, s, d2, gb.rows,
+                               gb.cols, ptiles_y, (int)strip, partial, (int)nblk, bitmap, bm_words, flags, p4, p4_stride, pal, pal_n, first_pair);
     }
     const int tiles_y = (gb.rows + NP_TY - 1) / NP_TY, tiles_x = (gb.cols + NP_TX - 1) / NP_TX;
     hipLaunchKernelGGL(dt_normalize_gradient_pack_kernel, dim3(tiles_y * tiles_x, gb.count), dim3(256), 0, s, d2, gb.rows, gb.cols,

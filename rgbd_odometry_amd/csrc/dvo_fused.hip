@@ -897,7 +897,9 @@ static hipError_t launch_fused2_b(const LevelSet &lv, const Schedule &sc, const 
 }
 
 /* static LDS of align_fused2_kernel<BLOCK> (the host sizes the dynamic part against the CU's 160 KiB) */
-size_t fused2_static_lds(int block_threads) { return ((sizeof(PoseState) + 15) & ~(size_t)15) + (size_t)(block_threads / 64) * 64 + 64 + DVO_TEAM_MAX * 64 + 16; }
+size_t fused2_static_lds(int block_threads) {      /* 256 threads never run in team mode: one exchange row instead of DVO_TEAM_MAX */
+    return ((sizeof(PoseState) + 15) & ~(size_t)15) + (size_t)(block_threads / 64) * 64 + 64 + (block_threads == 256 ? 1 : DVO_TEAM_MAX) * 64 + 16;
+}
 
 hipError_t launch_align_fused2(int block_threads, const LevelSet &lv, const Schedule &sc, const Intrinsics &K,
                                const DevParams &prm, const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {
