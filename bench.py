@@ -180,7 +180,7 @@ def frames_leg(args, iters):
     form + the alignment, i.e. what one alignment costs INCLUDING the production of its now level.  Bounded: 256 pairs."""
     from rgbd_odometry_amd import frame_gen
     from rgbd_odometry_amd import DvoContext
-    from rgbd_odometry_amd.capi import DVO_FLAG_IDENTITY_START, DVO_UPLOAD_ASYNC
+    from rgbd_odometry_amd.capi import DVO_FLAG_IDENTITY_START, DVO_UPLOAD_ASYNC, DVO_UPLOAD_DIRECT
     B, D = 256, 8
 
     def pin(a):
@@ -195,7 +195,7 @@ def frames_leg(args, iters):
     s = args.width / 640.0
     ctx.set_intrinsics(525.0 * s, 525.0 * s, 319.5 * s, 239.5 * args.height / 480.0)
     ctx.frames_reserve(2 * B)
-    kw = dict(n_levels=args.levels, first_shift=0, flags=DVO_UPLOAD_ASYNC)
+    kw = dict(n_levels=args.levels, first_shift=0, flags=DVO_UPLOAD_ASYNC | DVO_UPLOAD_DIRECT)    # the frames sit in pinned host memory that outlives the context
 
     def pair_step():
         ctx.frames_upload_cameras(ref_b, ref_d, first_slot=0, **kw)

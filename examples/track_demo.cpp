@@ -25,6 +25,7 @@ int main(int argc, char **argv) {
         dvo_amd::SolveDVO dvo;
         dvo.setCameraMatrix((float)std::atof(argv[6]), (float)std::atof(argv[7]), (float)std::atof(argv[8]), (float)std::atof(argv[9]));
         dvo.iterationsConfig.assign(nl, iters);
+        dvo.syncAfterNowFrame = std::getenv("TRACK_DEMO_SYNC") != nullptr;
         std::ofstream poses(argv[11]);
         char name[1024];
         double load_ms = 0, track_ms = 0;

@@ -116,6 +116,15 @@ int  dvo_num_pairs(const dvo_ctx *ctx);
 int  dvo_set_stream(dvo_ctx *ctx, void *hip_stream);
 int  dvo_use_own_stream(dvo_ctx *ctx);
 int  dvo_synchronize(dvo_ctx *ctx);
+/* Single camera stream (the reference's loop: one frame every ~30 ms, SolveDVO.cpp:1945): between frames the GPU is idle.  A
+ * process that only ever submits such sparse work can find the GPU parked at its lowest clocks and never raise them -- every
+ * 0.5 ms alignment then takes 15-30 ms (measured: profiles/r03_single_stream).  dvo_set_keep_warm2 starts a host thread of the
+ * context that keeps ONE wave busy on a stream of its own: launches of busy_us microseconds of real time, pause_us apart
+ * (pause_us = 0: back to back); busy_us = 0 stops it.  dvo_set_keep_warm(period_us) = a 5 us launch every period_us.  Off by
+ * default: a batch workload never idles.  DVO_KEEP_WARM="busy_us,pause_us" in the environment switches it on for every new
+ * context.  (The alternative is an administrator pinning the performance level with rocm-smi; this needs no privileges.) */
+int  dvo_set_keep_warm2(dvo_ctx *ctx, int busy_us, int pause_us);
+int  dvo_set_keep_warm(dvo_ctx *ctx, int period_us);
 
 /* ---- inputs ----------------------------------------------------------------
  * setCameraMatrix (SolveDVO.cpp:88-126): level-0 fx, fy, cx, cy as floats. */
@@ -338,9 +347,16 @@ int  dvo_point_iterations(dvo_ctx *ctx, int pair, int n_levels, const int *iters
 enum { DVO_PIX_U8 = 0, DVO_PIX_U16 = 1, DVO_PIX_F32 = 2 };
 enum { DVO_LAYOUT_COL_MAJOR = 0,    /* Eigen (im_n[level].data()): (yy,xx) at yy + xx*rows */
        DVO_LAYOUT_ROW_MAJOR = 1 };  /* cv::Mat / sensor_msgs::Image: (yy,xx) at yy*cols + xx */
-enum { DVO_UPLOAD_ASYNC = 1,        /* do not wait for the copies: host buffers stay borrowed until dvo_synchronize() */
-       DVO_UPLOAD_DEPTH_RAW = 2 };  /* dvo_frames_upload_cameras: the depth images are already in sensor units (what a mono16 depth topic
+enum { DVO_UPLOAD_ASYNC = 1,        /* do not wait for the copies: with DVO_UPLOAD_DIRECT the host buffers stay borrowed until dvo_synchronize() */
+       DVO_UPLOAD_DEPTH_RAW = 2,    /* dvo_frames_upload_cameras: the depth images are already in sensor units (what a mono16 depth topic
                                        carries, as float): no x1000, no rounding, no 0 -> 1 -- what the rgbdSubsc node works on */
+       DVO_UPLOAD_DIRECT = 4 };     /* DMA straight out of the caller's buffers.  Only for buffers that are pinned, or at least never
+                                       unmapped while the context lives (a pool the caller keeps).  Default (round 3): the images are first
+                                       copied into the engine's own pinned mirror (~0.1 ms per 640x480 frame) and the caller's memory is
+                                       free again when the call returns.  Why: the HIP runtime registers pageable source buffers with the
+                                       driver; when the application later frees them (free -> munmap of a large block), the driver stalls
+                                       the process's GPU queues for 14-33 ms -- measured on the C++ file replay, whose loader allocates
+                                       and frees a pyramid per frame: 24 ms per frame instead of 0.6 (profiles/r03_single_stream) */
 
 typedef struct dvo_image {          /* one single-channel host image */
     const void *data;

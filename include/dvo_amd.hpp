@@ -335,13 +335,19 @@ public:
     bool loadFromFile(const char *xmlFileName, int nLevels = 4) {
         std::FILE *fp = std::fopen(xmlFileName, "rb");
         if (!fp) return false;                                                     /* ROS_ERROR "Cannot Open File" :160 */
-        std::string s; char buf[1 << 16]; size_t n;
+        /* The loader's buffers are members and keep their capacity from frame to frame.  Not a nicety: a host process that
+         * frees multi-megabyte blocks between frames (free -> munmap) was measured to stall its own GPU queues for 14-33 ms per
+         * frame on this pool (profiles/r03_single_stream: 24 ms instead of 0.6 ms per tracked frame, intermittently per
+         * process; gone with glibc told never to return memory, MALLOC_MMAP_THRESHOLD_ / MALLOC_TRIM_THRESHOLD_). */
+        std::string &s = loadText_; char buf[1 << 16]; size_t n;
+        s.clear();
         while ((n = std::fread(buf, 1, sizeof(buf), fp)) > 0) s.append(buf, n);
         std::fclose(fp);
-        RGBDFramePyd f;
+        RGBDFramePyd &f = loadFrame_;
         f.levels.resize(nLevels);
+        std::vector<double> &v = loadV_, &w = loadW_;
         for (int i = 0; i < nLevels; i++) {
-            int r = 0, c = 0, r2 = 0, c2 = 0; std::string dt; std::vector<double> v, w;
+            int r = 0, c = 0, r2 = 0, c2 = 0; std::string dt;
             if (!readOpenCvXmlMatrix(s, "mono_" + std::to_string(i), r, c, dt, v)) return false;
             if (!readOpenCvXmlMatrix(s, "depth_" + std::to_string(i), r2, c2, dt, w) || r2 != r || c2 != c) return false;
             RGBDFramePyd::Level &L = f.levels[i];
@@ -367,7 +373,7 @@ public:
         const int nl = dvo_frames_num_levels(ctx_);
         std::vector<int> N(nl);
         chk(dvo_frames_as_ref(ctx_, ref_slot_, 0, 1, N.data()));
-        ref_points_.assign(nl, {});
+        ref_points_.resize(nl);                      /* keep the capacity (see loadFromFile) */
         for (int l = 0; l < nl; l++) {
             ref_points_[l].resize((size_t)3 * N[l]);
             int n = 0;
@@ -388,6 +394,15 @@ public:
     void processFirstFrame() {
         setRcvdFrameAsRefFrame();
         preProcessRefFrame();
+        if (warmUpOnFirstFrame) {
+            /* one throw-away alignment of the first frame against itself: the first alignment of a process pays for loading the
+             * kernels' code objects and for the engine's lazily allocated buffers (measured 12.5 ms against 0.6 ms for every later
+             * frame, profiles/r03_single_stream) -- paid here, where the reference's loop has no pose to deliver yet (:1972-2021),
+             * instead of on the first tracked frame.  Nothing of it survives: the now level is rewritten by the next frame. */
+            chk(dvo_frames_as_now(ctx_, ref_slot_, 0, 1));
+            double wR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, wT[3] = {0, 0, 0};
+            alignPyramid(wR, wT);
+        }
         lastRefFrame = 0;
         identityPose();
         gop.pushAsKeyFrame((int)nFrame, 1, cR_64, cT_64);
@@ -398,6 +413,7 @@ public:
     Pose processFrame() {
         const auto t0 = std::chrono::steady_clock::now();
         setRcvdFrameAsNowFrame();
+        if (syncAfterNowFrame) chk(dvo_synchronize(ctx_));                          /* diagnostics: separates the two stages' times */
         const auto t1 = std::chrono::steady_clock::now();
         alignPyramid(cR_64, cT_64);                                                /* :2097-2104 (warm start from the last estimate) */
         const auto t2 = std::chrono::steady_clock::now();
@@ -462,12 +478,19 @@ public:
 private:
     void chk(int rc) { if (rc != DVO_OK) throw std::runtime_error(dvo_last_error(ctx_)); }
     static void need(bool ok, const char *what) { if (!ok) throw std::runtime_error(what); }
+public:
+    bool warmUpOnFirstFrame = true;                 /* see processFirstFrame */
+    bool syncAfterNowFrame = false;                 /* diagnostics (tools/track_latency.py): wait for the now-frame stage before timing the alignment */
+private:
     void identityPose() { for (int k = 0; k < 9; k++) cR_64[k] = (k % 4 == 0) ? 1.0 : 0.0; cT_64[0] = cT_64[1] = cT_64[2] = 0.0; }
     int freeSlot() const {                          /* a store slot that holds neither the reference, the now nor the n-1 frame */
         for (int s = 0; s < 4; s++) if (s != ref_slot_ && s != now_slot_ && s != prev_slot_) return s;
         return 3;
     }
     dvo_ctx *ctx_ = nullptr;
+    std::string loadText_;                          /* loadFromFile: reused from frame to frame */
+    std::vector<double> loadV_, loadW_;
+    RGBDFramePyd loadFrame_;
     std::vector<std::vector<float>> ref_points_;
     bool isCameraIntrinsicsAvailable = false, isRefFrameAvailable = false, isNowFrameAvailable = false;
     bool isFrameAvailable = false, refPreprocessed_ = false;

@@ -23,7 +23,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 #: every symbol include/dvo_amd.h declares (checked by tests/test_capi_symbols.py)
 C_ABI_SYMBOLS = [
     "dvo_params_default", "dvo_create", "dvo_create_batch", "dvo_destroy", "dvo_last_error",
-    "dvo_num_pairs", "dvo_set_stream", "dvo_use_own_stream", "dvo_synchronize", "dvo_set_intrinsics",
+    "dvo_num_pairs", "dvo_set_stream", "dvo_use_own_stream", "dvo_synchronize", "dvo_set_keep_warm", "dvo_set_keep_warm2", "dvo_set_intrinsics",
     "dvo_set_ref_level", "dvo_set_ref_level_pair", "dvo_set_now_level", "dvo_set_now_level_pair",
     "dvo_set_ref_level_device", "dvo_set_now_level_device", "dvo_set_ref_level_from_images",
     "dvo_run_iterations", "dvo_run_iterations_pair", "dvo_align_pyramid", "dvo_align_batch",
@@ -41,6 +41,7 @@ DVO_PIX_U8, DVO_PIX_U16, DVO_PIX_F32 = 0, 1, 2
 DVO_LAYOUT_COL_MAJOR, DVO_LAYOUT_ROW_MAJOR = 0, 1
 DVO_UPLOAD_ASYNC = 1
 DVO_UPLOAD_DEPTH_RAW = 2
+DVO_UPLOAD_DIRECT = 4
 
 
 class DvoImage(C.Structure):
@@ -175,6 +176,8 @@ def load_library() -> C.CDLL:
         "dvo_set_stream": [vp, vp],
         "dvo_use_own_stream": [vp],
         "dvo_synchronize": [vp],
+        "dvo_set_keep_warm": [vp, i],
+        "dvo_set_keep_warm2": [vp, i, i],
         "dvo_set_intrinsics": [vp, f, f, f, f],
         "dvo_set_ref_level": [vp, i, vp, i],
         "dvo_set_ref_level_pair": [vp, i, i, vp, i],
@@ -304,6 +307,15 @@ class DvoContext:
 
     def use_own_stream(self):
         self._chk(self.lib.dvo_use_own_stream(self._h))
+
+    def set_keep_warm(self, period_us: int):
+        """launch a no-op kernel every period_us microseconds from a thread of the context (0 = stop): holds the GPU's active
+        clocks between the frames of a single camera stream"""
+        self._chk(self.lib.dvo_set_keep_warm(self._h, int(period_us)))
+
+    def set_keep_warm2(self, busy_us: int, pause_us: int = 0):
+        """one wave busy for busy_us microseconds, pause_us apart (0 = back to back), from a thread of the context; busy_us = 0 stops"""
+        self._chk(self.lib.dvo_set_keep_warm2(self._h, int(busy_us), int(pause_us)))
 
     def synchronize(self):
         self._chk(self.lib.dvo_synchronize(self._h))

@@ -59,7 +59,7 @@ int frames_geometry(dvo_ctx *c, int n_levels, const int *rows, const int *cols) 
     bool same = S.n_levels == n_levels;
     for (int l = 0; same && l < n_levels; l++) same = S.lv[l].rows == rows[l] && S.lv[l].cols == cols[l];
     if (same) return DVO_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_wait(c->stream));
     frames_free(c);
     for (int l = 0; l < n_levels; l++) {
         FrameLevel &F = S.lv[l];
@@ -98,7 +98,13 @@ int lanes_begin(dvo_ctx *c, int n_levels, int count, bool with_now, LevelLanes &
     if (with_now)
         for (int l = 0; l < n_levels; l++)
             if ((rc = ensure_texels(c, l, c->fs.lv[l].rows, c->fs.lv[l].cols))) return rc;
-    ln.parallel = n_levels > 1 && (size_t)count * c->fs.lv[0].npx <= kParallelPixels;
+    /* OFF unless DVO_FRAME_LANES=1 (round 3).  The lanes save ~0.13 ms of a single 640x480 frame when the hardware queues
+     * behind the four extra streams are live, but the fork / join events make every frame wait on cross-queue dependencies,
+     * and a process that is not the first on the GPU can find those waits taking 14-33 ms EACH FRAME (profiles/
+     * r03_single_stream: the C++ file replay as second process of a box, 24 ms per frame with lanes, 0.64 ms without; neither
+     * clocks nor host time -- the alignment itself stayed at 0.4 ms).  One stream, levels back to back, is the robust default. */
+    static const int lanes_env = [] { const char *e = std::getenv("DVO_FRAME_LANES"); return e ? std::atoi(e) : 0; }();
+    ln.parallel = n_levels > 1 && (size_t)count * c->fs.lv[0].npx <= kParallelPixels && lanes_env == 1;
     for (int l = 0; l < n_levels; l++) { ln.s[l] = c->stream; ln.work[l] = nullptr; }
     if (!ln.parallel) return DVO_OK;
     size_t off[DVO_LEVELS + 1];
@@ -174,7 +180,7 @@ int ensure_upload(dvo_ctx *c, size_t bytes) {
     if (bytes <= c->up_bytes) return DVO_OK;
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     HIPCHK(c, hipStreamSynchronize(c->copy_stream2));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_wait(c->stream));
     for (int b = 0; b < 2; b++) {
         if (c->up_buf[b]) HIPCHK(c, hipFree(c->up_buf[b]));
         if (c->up_host[b]) HIPCHK(c, hipHostFree(c->up_host[b]));
@@ -221,7 +227,7 @@ static int frames_as_now_level(dvo_ctx *c, int level, int first_slot, int first_
 int dvo_frames_reserve(dvo_ctx *c, int n_slots) {
     DVO_ENTER(c);
     if (n_slots < 1) return fail(c, DVO_ERR_INVALID, "n_slots must be >= 1");
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_wait(c->stream));
     frames_free(c);
     c->fs.n_slots = n_slots;
     c->fs.valid.assign(n_slots, 0);
@@ -280,7 +286,7 @@ int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_leve
         bool small[DVO_LEVELS];
         for (int l = 0; l < n_levels; l++) {
             const size_t npx = c->fs.lv[l].npx, gb = pix_bytes(grey[l].dtype), db = depth ? pix_bytes(depth[l].dtype) : 0;
-            small[l] = npx * std::max(gb, db) <= kSmallImage;
+            small[l] = !(flags & DVO_UPLOAD_DIRECT) || npx * std::max(gb, db) <= kSmallImage;     /* default: through the pinned mirror */
             for (int i = 0; i < nc; i++) {
                 const void *gsrc = grey[(size_t)(b + i) * n_levels + l].data;
                 const void *dsrc = depth ? depth[(size_t)(b + i) * n_levels + l].data : nullptr;
@@ -333,7 +339,7 @@ int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_leve
         }
     }
     for (int f = 0; f < count; f++) { c->fs.valid[first_slot + f] = 1; c->fs.has_depth[first_slot + f] = depth ? 1 : 0; }
-    if (!(flags & DVO_UPLOAD_ASYNC)) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!(flags & DVO_UPLOAD_ASYNC)) HIPCHK(c, stream_wait(c->stream));
     return DVO_OK;
 }
 
@@ -343,7 +349,7 @@ int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_leve
  * cv::invert uses; the normalised coordinates advance by running sums along a row -- and uploaded once. */
 int dvo_frames_set_undistort(dvo_ctx *c, int rows, int cols, const double *K4, const double *D5) {
     DVO_ENTER(c);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_wait(c->stream));
     if (c->d_umap_xy) { (void)hipFree(c->d_umap_xy); (void)hipFree(c->d_umap_frac); c->d_umap_xy = nullptr; c->d_umap_frac = nullptr; }
     c->umap_rows = c->umap_cols = 0;
     if (!K4 && !D5) return DVO_OK;                         /* switched off: frames are taken as already undistorted */
@@ -421,10 +427,24 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
         unsigned char *sb; int ub;
         if ((rc = upload_begin(c, &sb, &ub))) return rc;
         float *sd = (float *)(sb + b_img * chunk);
-        for (int i = 0; i < nc; i++) {
-            hipStream_t cs = (i & 1) ? c->copy_stream2 : c->copy_stream;
-            HIPCHK(c, hipMemcpyAsync(sb + b_img * i, bgr8[b + i], npx * 3, hipMemcpyHostToDevice, cs));
-            if (depth_m) HIPCHK(c, hipMemcpyAsync(sd + npx * i, depth_m[b + i], npx * 4, hipMemcpyHostToDevice, cs));
+        if (flags & DVO_UPLOAD_DIRECT) {
+            for (int i = 0; i < nc; i++) {
+                hipStream_t cs = (i & 1) ? c->copy_stream2 : c->copy_stream;
+                HIPCHK(c, hipMemcpyAsync(sb + b_img * i, bgr8[b + i], npx * 3, hipMemcpyHostToDevice, cs));
+                if (depth_m) HIPCHK(c, hipMemcpyAsync(sd + npx * i, depth_m[b + i], npx * 4, hipMemcpyHostToDevice, cs));
+            }
+        } else {
+            /* through the engine's pinned mirror of the landing buffer: one memcpy per image on the host, then two DMAs per
+             * chunk; the caller's (pageable) memory is never registered with the driver (include/dvo_amd.h, DVO_UPLOAD_DIRECT) */
+            unsigned char *hb = c->up_host[ub];
+            float *hd = (float *)(hb + b_img * chunk);
+            if (c->up_used[ub]) { HIPCHK(c, hipEventSynchronize(c->ev_copied[ub])); HIPCHK(c, hipEventSynchronize(c->ev_copied2[ub])); }
+            for (int i = 0; i < nc; i++) {
+                std::memcpy(hb + b_img * i, bgr8[b + i], npx * 3);
+                if (depth_m) std::memcpy(hd + npx * i, depth_m[b + i], npx * 4);
+            }
+            HIPCHK(c, hipMemcpyAsync(sb, hb, b_img * (size_t)nc, hipMemcpyHostToDevice, c->copy_stream));
+            if (depth_m) HIPCHK(c, hipMemcpyAsync(sd, hd, npx * 4 * (size_t)nc, hipMemcpyHostToDevice, c->copy_stream2));
         }
         LevelLanes ln;
         if ((rc = lanes_begin(c, n_levels, nc, now_first_pair >= 0, ln))) return rc;
@@ -453,7 +473,7 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
         }
     }
     for (int f = 0; f < count; f++) { c->fs.valid[first_slot + f] = 1; c->fs.has_depth[first_slot + f] = depth_m ? 1 : 0; }
-    if (!(flags & DVO_UPLOAD_ASYNC)) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!(flags & DVO_UPLOAD_ASYNC)) HIPCHK(c, stream_wait(c->stream));
     return DVO_OK;
 }
 
@@ -531,7 +551,7 @@ int dvo_frames_as_ref(dvo_ctx *c, int first_slot, int first_pair, int count, int
         HIPCHK(c, hipMemcpy2DAsync(hN.data() + (size_t)l * count, sizeof(int), cc + F.cols, sizeof(int) * (F.cols + 2),
                                    sizeof(int), count, hipMemcpyDeviceToHost, c->stream));
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_wait(c->stream));
     int bad_level = -1, bad_frame = -1;
     for (int l = 0; l < nl; l++) {
         FrameLevel &F = c->fs.lv[l];
@@ -580,7 +600,7 @@ int dvo_frame_get_level(dvo_ctx *c, int slot, int level, int *rows, int *cols, u
         HIPCHK(c, launch_count_edges(F.edge + off, F.npx, c->work, c->stream));
         HIPCHK(c, hipMemcpyAsync(n_edges, c->work, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_wait(c->stream));
     return DVO_OK;
 }
 

@@ -76,7 +76,7 @@ int dvo_photo_configure(dvo_ctx *c, const dvo_photo_params *prm) {
         return fail(c, DVO_ERR_INVALID, "bad photometric parameters (setCameraMatrix: fx, fy, cx, cy of the level-0 camera matrix)");
     dvo_photo_state *p;
     photo_state(c, &p);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_wait(c->stream));
     if (prm->max_jacobian_size != p->prm.max_jacobian_size)       /* capacity changed: drop the per-level buffers */
         for (auto &L : p->lv) {
             void *ptrs[] = {L.J, L.zref, L.sel, L.gref};
@@ -124,7 +124,7 @@ int dvo_photo_set_ref(dvo_ctx *c, int slot, int first_level, int *n_selected /* 
         }
         const size_t need = 2 * ((size_t)F.cols + 1);
         if (need > p->col_work_ints) {
-            if (p->col_work) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(p->col_work)); }
+            if (p->col_work) { HIPCHK(c, stream_wait(c->stream)); HIPCHK(c, hipFree(p->col_work)); }
             HIPCHK(c, hipMalloc((void **)&p->col_work, sizeof(int) * need));
             p->col_work_ints = need;
         }
@@ -132,7 +132,7 @@ int dvo_photo_set_ref(dvo_ctx *c, int slot, int first_level, int *n_selected /* 
                                          p->prm.fx, p->prm.fy, p->prm.cx, p->prm.cy, p->prm.fixed, (double)p->prm.gradient_threshold,
                                          cap, p->col_work, L.J, L.sel, L.zref, L.gref, L.A, L.n_dev, c->stream));
         HIPCHK(c, hipMemcpyAsync(&L.n, L.n_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));       /* col_work is reused by the next level */
+        HIPCHK(c, stream_wait(c->stream));       /* col_work is reused by the next level */
         L.rows = F.rows; L.cols = F.cols;
         if (n_selected) n_selected[l] = L.n;
         /* the reference asserts on both (NDEBUG is undefined): :464 xc < const_maxJacobianSize, :500 xc > const_minimumRequiredPts */
@@ -175,7 +175,7 @@ int dvo_photo_align(dvo_ctx *c, int now_slot, const int *levels, int n_run, doub
     }
     HIPCHK(c, hipMemcpyAsync(T16, p->d_T, sizeof(double) * 16, hipMemcpyDeviceToHost, c->stream));
     if (eps_norms) HIPCHK(c, hipMemcpyAsync(eps_norms, p->d_norms, sizeof(double) * it * n_run, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_wait(c->stream));
     if (updates) for (int r = 0; r < n_run; r++) updates[r] = upd[r];
     return DVO_OK;
 }
@@ -186,7 +186,7 @@ int dvo_photo_get_jacobian(dvo_ctx *c, int level, double *J, int *sel_i, int *se
     dvo_photo_state *p = c->photo;
     if (!p || !level_ok(level) || !p->lv[level].ready) return fail(c, DVO_ERR_STATE, "no Jacobian for this level");
     dvo_photo_state::Lvl &L = p->lv[level];
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_wait(c->stream));
     const int n = std::min(L.n, capacity);
     if (n_out) *n_out = L.n;
     if (J && n > 0) HIPCHK(c, hipMemcpy(J, L.J, sizeof(double) * 6 * (size_t)n, hipMemcpyDeviceToHost));

@@ -111,7 +111,7 @@ int dvo_tiled_attach(dvo_ctx *c, void *nccl_comm, int rank, int world, const cha
 
 int dvo_tiled_detach(dvo_ctx *c) {
     DVO_ENTER(c);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)stream_wait(c->stream);
     tiled_forget(c);
     return DVO_OK;
 }
@@ -174,7 +174,7 @@ int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters
         HIPCHK(c, launch_iter_end(state, d_pose, c->d_best + pair * DVO_LEVELS + l, c->d_ratio + pair * DVO_LEVELS + l, c->stream));
     }
     HIPCHK(c, hipMemcpyAsync(h, d_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_wait(c->stream));
     std::memcpy(R, h, sizeof(double) * 9);
     std::memcpy(t, h + 9, sizeof(double) * 3);
     dvo_host::stamp_outputs(c, sc, pair, 1);

@@ -107,6 +107,7 @@ struct dvo_ctx {
     hipGraphExec_t wide_exec = nullptr;
     unsigned long long wide_sig = 0;
     double *h_pose = nullptr;       /* pinned: in/out pose of the graph's copy nodes */
+    double *h_poses = nullptr;      /* pinned: dvo_get_poses / dvo_set_poses staging, 12 doubles per pair */
     unsigned long long *d_dbg = nullptr;
     char *d_states = nullptr;       /* n_pairs x pose_state_bytes(): host-driven iteration state */
     float *d_iter_energy = nullptr; /* n_pairs x iter_energy_cap */
@@ -140,6 +141,7 @@ struct dvo_ctx {
     hipStream_t lvl_stream[DVO_LEVELS] = {};
     hipEvent_t ev_fork = nullptr, ev_join[DVO_LEVELS] = {};
     struct dvo_photo_state *photo = nullptr;     /* dvo_capi_photo.cpp: the photometric engine's reference data */
+    struct dvo_keep_warm_state *warm = nullptr;  /* dvo_set_keep_warm: the thread that keeps the GPU at its active clocks */
     dvo::Schedule sched{};
     bool have_sched = false;
     /* which pairs the per-pair outputs (energies, final outputs) currently describe: the output buffers are laid out by
@@ -173,6 +175,12 @@ struct DeviceGuard {
     dvo_host::DeviceGuard dvo_device_guard_(c)
 
 int fail(dvo_ctx *c, int code, const std::string &msg);
+/* Wait for a stream WITHOUT going to sleep on an interrupt first: poll its completion (hipStreamQuery reads the queue's
+ * signal) for up to two milliseconds, only then block in hipStreamSynchronize.  On this pool a process can find the wake-up
+ * from a blocking wait delayed by 14-33 ms (measured on the single-camera-stream path, profiles/r03_single_stream: kernels of
+ * 0.2 ms, waits of 24 ms, intermittently per process); a single stream's frame is over in well under a millisecond, so the
+ * poll costs one busy host thread for that long.  DVO_WAIT=block in the environment restores the plain blocking wait. */
+hipError_t stream_wait(hipStream_t s);
 #define HIPCHK(c, expr)                                                                     \
     do {                                                                                    \
         hipError_t e_ = (expr);                                                             \

@@ -778,6 +778,22 @@ hipError_t launch_unpack_texels(const float4 *tex, int rows, int cols, float *dt
     return hipGetLastError();
 }
 
+/* one wave asleep for `us` microseconds of real time (the constant 100 MHz counter: the duration does not stretch when the
+ * shader clock is low): the activity that keeps the GPU's power management from parking the clocks between the frames of a
+ * single camera stream (dvo_set_keep_warm).  Bounded: a launch always ends by itself. */
+__global__ void __launch_bounds__(64) keep_warm_kernel(unsigned ticks) {
+    unsigned long long t0, t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+    do {
+        __builtin_amdgcn_s_sleep(64);
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    } while (t - t0 < (unsigned long long)ticks);
+}
+hipError_t launch_keep_warm(int us, hipStream_t s) {
+    hipLaunchKernelGGL(keep_warm_kernel, dim3(1), dim3(64), 0, s, (unsigned)(us < 1 ? 1 : (us > 20000 ? 20000 : us)) * 100u);
+    return hipGetLastError();
+}
+
 /* ------------------------------------------------------------------------- */
 /* SE(3) helpers on one lane (property tests of the device math)               */
 /* ------------------------------------------------------------------------- */

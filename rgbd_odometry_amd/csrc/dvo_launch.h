@@ -129,6 +129,8 @@ hipError_t launch_final_outputs_state(const LevelSlab &L, int pair, int level, c
                                       int first_point, int n_points, float *final_eps, float *final_reproj, int *final_N,
                                       hipStream_t s);
 hipError_t launch_unpack_texels(const float4 *tex, int rows, int cols, float *dt, float *gx, float *gy, hipStream_t s);
+/* one wave asleep for `us` microseconds of real time (dvo_set_keep_warm) */
+hipError_t launch_keep_warm(int us, hipStream_t s);
 /* SE(3) helpers on one lane (property tests) */
 hipError_t launch_se3_exp(const double *psi, double *Rt12, hipStream_t s);
 hipError_t launch_se3_log(const double *Rt12, double *psi, hipStream_t s);

@@ -1,0 +1,45 @@
+"""The C-driven tiled mode (dvo_tiled_attach / dvo_align_pyramid_tiled: RCCL called from C between the accumulate and the update
+kernels of every iteration) launched the way the driver launches it: `python -m torch.distributed.run ... bench.py --mode tiled`.
+
+world = 1 always runs (one GPU: RCCL is really called, with a communicator of size one).  world = 2 needs two GPUs and skips
+otherwise: every rank must end with bit-identical poses, equal to the oracle's (checked inside bench.py on rank 0 at world 1,
+across ranks through the all_gather at world 2), and the JSON line must say so."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(world, extra):
+    cmd = [sys.executable]
+    if world > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                "--master-port", "29517"]
+    cmd += [os.path.join(ROOT, "bench.py"), "--mode", "tiled", "--gpus", str(world), "--steps", "3", "--warmup", "1"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_tiled_bench_one_rank_matches_the_oracle():
+    d = _run(1, ["--width", "640", "--height", "480", "--levels", "4", "--cpu-seconds", "1"])
+    assert d["n_gpus"] == 1 and d["config"]["mode"] == "tiled" and d["scaling"] == "strong"
+    assert d["parity_check"]["pass"], d["parity_check"]
+    assert d["parity_check"]["final_outputs_bit_equal"] and d["parity_check"]["energies_bit_equal"]
+    assert d["roofline"]["kernel_ms"] > 0 and "cpu_baseline" in d
+
+
+def test_tiled_bench_two_ranks_bit_identical():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    d1 = _run(1, ["--width", "640", "--height", "480", "--levels", "4", "--cpu-seconds", "0"])
+    d2 = _run(2, ["--width", "640", "--height", "480", "--levels", "4", "--cpu-seconds", "0"])
+    assert d2["n_gpus"] == 2 and d2["config"]["all_ranks_bit_identical"]
+    assert d2["config"]["points_per_level"] == d1["config"]["points_per_level"]

@@ -32,7 +32,7 @@ def main():
     args = ap.parse_args()
     from rgbd_odometry_amd import frame_gen
     from rgbd_odometry_amd import DvoContext
-    from rgbd_odometry_amd.capi import DVO_FLAG_IDENTITY_START, DVO_UPLOAD_ASYNC
+    from rgbd_odometry_amd.capi import DVO_FLAG_IDENTITY_START, DVO_UPLOAD_ASYNC, DVO_UPLOAD_DIRECT
 
     B, D = args.batch, min(args.distinct, args.batch)
     ref = [frame_gen.camera_frame(100 + i, args.height, args.width) for i in range(D)]
@@ -65,7 +65,7 @@ def main():
         dt = (time.perf_counter() - t0) / args.reps
         res[name] = dict(ms=1e3 * dt, per_s=units / dt)
 
-    kw = dict(n_levels=args.levels, first_shift=args.first_shift, flags=DVO_UPLOAD_ASYNC)
+    kw = dict(n_levels=args.levels, first_shift=args.first_shift, flags=DVO_UPLOAD_ASYNC | DVO_UPLOAD_DIRECT)    # the frames sit in pinned host memory that outlives the context
     timed("upload_ref_frames(bgr+depth: H2D, pyramid, Canny)", lambda: ctx.frames_upload_cameras(ref_b, ref_d, first_slot=0, **kw), B)
     timed("upload_now_frames(bgr only: H2D, pyramid, Canny)", lambda: ctx.frames_upload_cameras(now_b, None, first_slot=B, **kw), B)
     timed("frames_as_ref(selectedPts+enlistRefEdgePts)", lambda: ctx.frames_as_ref(0, 0, B), B)
@@ -83,7 +83,7 @@ def main():
         pyr.append(lv)
     pyr_b = [pyr[i % D] for i in range(B)]
     res["config_pyramid_bytes_per_frame"] = int(sum(g.nbytes + d.nbytes for g, d in pyr[0]))
-    timed("upload_pyramids(mono8+mono16 row-major: H2D, import, Canny)", lambda: ctx.frames_upload_pyramids(pyr_b, first_slot=0, flags=DVO_UPLOAD_ASYNC), B)
+    timed("upload_pyramids(mono8+mono16 row-major: H2D, import, Canny)", lambda: ctx.frames_upload_pyramids(pyr_b, first_slot=0, flags=DVO_UPLOAD_ASYNC | DVO_UPLOAD_DIRECT)    # the frames sit in pinned host memory that outlives the context, B)
 
     def tracking_step():                              # every pair gets a fresh now frame against its resident reference
         ctx.frames_upload_cameras(now_b, None, first_slot=B, **kw)
