@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """host-side cost of one bench step: the enqueue call (asynchronous), the pose read-back (synchronises), the kernel"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from rgbd_odometry_amd import DvoContext, SynthScene
 from rgbd_odometry_amd.capi import DVO_FLAG_FINAL_OUTPUTS, DVO_FLAG_IDENTITY_START

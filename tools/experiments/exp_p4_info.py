@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """compact now form: what the builder says for the bench scenes (palette size per level, texel mode per level)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from rgbd_odometry_amd import DvoContext, SynthScene
 W, H, NL = 640, 480, 4

@@ -1,6 +1,6 @@
 """single-pair latency of the fused kernel vs workgroup size / points in flight / LDS budget (C2 synthetic + ref default)"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from rgbd_odometry_amd import DvoContext, SynthScene

@@ -3,7 +3,7 @@
 levels, synchronous), dvo_frames_as_now, dvo_align_pyramid-style align (set poses, enqueue, get poses).  Same library, same
 HIP runtime (DVO_NO_TORCH=1).  usage: DVO_NO_TORCH=1 exp_sparse_pyramids.py [frames] [gap_ms]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import oracle_lib

@@ -4,7 +4,7 @@ Python, once on PyTorch's bundled HIP runtime (default) and once on /opt/rocm's 
 library binds to the system libamdhip64).  Prints the wall time of every frame's  upload + alignment + pose.
 usage: [DVO_NO_TORCH=1] exp_sparse_runtime.py [frames] [gap_ms] [spin]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from rgbd_odometry_amd import DvoContext, frame_gen

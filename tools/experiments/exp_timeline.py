@@ -4,7 +4,7 @@ ramp-up, duration spread, tail.  usage: exp_timeline.py [B]"""
 import os, sys
 os.environ["DVO_LIB_VARIANT"] = os.environ.get("DVO_TL_VARIANT", "_stamps")
 if len(sys.argv) > 2: os.environ["DVO_NO_LPT"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from rgbd_odometry_amd import DvoContext, SynthScene
 from rgbd_odometry_amd.capi import DVO_FLAG_IDENTITY_START, DVO_FLAG_FINAL_OUTPUTS

@@ -1,7 +1,7 @@
 #!/bin/bash
 OUT=$PWD/gpurun_out/fetch_calib; mkdir -p $OUT; REPO=$PWD; export TMPDIR=/tmp
 for grp in "FETCH_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum"; do
-  cd /tmp; timeout 120 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/$(echo $grp | cut -c1-8) -o pmc -- $REPO/rgbd_odometry_amd/lib/fetch_calib > $OUT/log.txt 2>&1; echo "rc=$?"; cd $REPO
+  cd /tmp; timeout 120 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/$(echo $grp | cut -c1-8) -o pmc -- $REPO/tools/exhaustive/bin/fetch_calib > $OUT/log.txt 2>&1; echo "rc=$?"; cd $REPO
 done
 python3 - "$OUT" <<'PY' | tee $OUT/summary.txt
 import csv, glob, sys, os

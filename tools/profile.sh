@@ -6,7 +6,7 @@ TAG=$1; shift
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 1 --cpu-seconds 0 $*"
+ARGS="--steps 5 --warmup 1 --cpu-seconds 0 --no-extra-legs $*"
 REPO=$PWD
 cd /tmp
 # 1) kernel trace + stats

@@ -48,10 +48,12 @@ rec = {
                "correction)") % (tag, " ".join(extra)),
 }
 path = os.path.join(ROOT, "gpurun_out", "pmc_traffic.json")
-try:
-    allrec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-except Exception:
-    allrec = {}
+allrec = {}
+for src in (os.path.join(ROOT, "profiles", "pmc_traffic.json"), path):      # several calls of one GPU session accumulate
+    try:
+        allrec.update(json.load(open(src)))
+    except Exception:
+        pass
 sys.argv = ["bench.py"] + extra
 a = bench.parse_args()
 key = "%dx%dx%dx%d_b%d" % (a.width, a.height, a.levels, a.iters, a.batch)
