@@ -77,10 +77,16 @@ int ensure_points(dvo_ctx *c, int level, int N) {
     new_cap = (new_cap + 255) / 256 * 256;
     float *np = nullptr;
     uint2 *ncp = nullptr;
-    unsigned *nci = nullptr;
+    unsigned *nci = nullptr, *nc4 = nullptr, *nch = nullptr;
     HIPCHK(c, hipMalloc((void **)&np, sizeof(float) * 3 * (size_t)new_cap * c->n_pairs));
     HIPCHK(c, hipMalloc((void **)&ncp, sizeof(uint2) * (size_t)new_cap * c->n_pairs));
     HIPCHK(c, hipMalloc((void **)&nci, sizeof(unsigned) * (size_t)new_cap * c->n_pairs));
+    HIPCHK(c, hipMalloc((void **)&nc4, sizeof(unsigned) * (size_t)new_cap * c->n_pairs));
+    HIPCHK(c, hipMalloc((void **)&nch, sizeof(unsigned) * (size_t)(new_cap / 64) * c->n_pairs));      /* new_cap % 256 == 0 */
+    if (!L.d_pt4_ok) {
+        HIPCHK(c, hipMalloc((void **)&L.d_pt4_ok, sizeof(int) * (size_t)c->n_pairs));
+        HIPCHK(c, hipMemsetAsync(L.d_pt4_ok, 0, sizeof(int) * (size_t)c->n_pairs, c->stream));
+    }
     if (L.pts) {
         HIPCHK(c, hipMemcpy2DAsync(np, sizeof(float) * 3 * (size_t)new_cap, L.pts,
                                    sizeof(float) * 3 * (size_t)L.pt_cap,
@@ -90,14 +96,22 @@ int ensure_points(dvo_ctx *c, int level, int N) {
                                    sizeof(uint2) * (size_t)L.pt_cap, c->n_pairs, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipMemcpy2DAsync(nci, sizeof(unsigned) * (size_t)new_cap, L.cidx, sizeof(unsigned) * (size_t)L.pt_cap,
                                    sizeof(unsigned) * (size_t)L.pt_cap, c->n_pairs, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(nc4, sizeof(unsigned) * (size_t)new_cap, L.cpt4, sizeof(unsigned) * (size_t)L.pt_cap,
+                                   sizeof(unsigned) * (size_t)L.pt_cap, c->n_pairs, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(nch, sizeof(unsigned) * (size_t)(new_cap / 64), L.chdr, sizeof(unsigned) * (size_t)(L.pt_cap / 64),
+                                   sizeof(unsigned) * (size_t)(L.pt_cap / 64), c->n_pairs, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, stream_wait(c->stream));
         HIPCHK(c, hipFree(L.pts));
         HIPCHK(c, hipFree(L.cpts));
         HIPCHK(c, hipFree(L.cidx));
+        HIPCHK(c, hipFree(L.cpt4));
+        HIPCHK(c, hipFree(L.chdr));
     }
     L.pts = np;
     L.cpts = ncp;
     L.cidx = nci;
+    L.cpt4 = nc4;
+    L.chdr = nch;
     L.pt_cap = new_cap;
     return DVO_OK;
 }
@@ -221,6 +235,7 @@ LevelSlab slab_of(const dvo_ctx *c, int level) {
     const Level &L = c->lv[level];
     LevelSlab s;
     s.tex = L.tex; s.pts = L.pts; s.cpts = L.cpts; s.cidx = L.cidx; s.N = L.dN;
+    s.cpt4 = L.cpt4; s.chdr = L.chdr; s.pt4_ok = L.d_pt4_ok;
     s.tex_stride = L.tex_stride; s.pt_cap = L.pt_cap; s.rows = L.rows; s.cols = L.cols;
     s.p4 = L.p4; s.pal = L.pal; s.pal_n = L.d_pal_n; s.p4_stride = L.p4_stride;
     return s;
@@ -412,6 +427,8 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         sc.lds_bytes = bytes;
         sc.no_lds_tex = (c->prm.engine_variant == 2) ? 1 : 0;
         sc.force_exact = (c->prm.engine_variant == 3) ? 1 : 0;
+        static const bool no_pt4_env = [] { const char *e = std::getenv("DVO_POINTS4"); return e && std::strcmp(e, "off") == 0; }();
+        sc.no_pt4 = no_pt4_env ? 1 : 0;
         sc.lds_points = bytes / (sc.compact ? 8 : 12);
         if (c->prm.lds_point_bytes < 0) { sc.lds_points = 0; sc.lds_bytes = 0; }
     }
@@ -673,6 +690,8 @@ int dvo_destroy(dvo_ctx *c) {
         if (c->lv[l].pts) (void)hipFree(c->lv[l].pts);
         if (c->lv[l].cpts) (void)hipFree(c->lv[l].cpts);
         if (c->lv[l].cidx) (void)hipFree(c->lv[l].cidx);
+        if (c->lv[l].cpt4) { (void)hipFree(c->lv[l].cpt4); (void)hipFree(c->lv[l].chdr); }
+        if (c->lv[l].d_pt4_ok) (void)hipFree(c->lv[l].d_pt4_ok);
         if (c->lv[l].dN) (void)hipFree(c->lv[l].dN);
         if (c->lv[l].p4) { (void)hipFree(c->lv[l].p4); (void)hipFree(c->lv[l].pal); (void)hipFree(c->lv[l].d_pal_n); }
     }
@@ -760,6 +779,7 @@ static int set_ref_common(dvo_ctx *c, int pair, int level, const float *xyz, int
     L.hN[pair] = N;
     c->points_gen++;
     L.compact_ok[pair] = 0;                                         /* arbitrary X, Y: no 8-byte form */
+    HIPCHK(c, hipMemsetAsync(L.d_pt4_ok + pair, 0, sizeof(int), c->stream));
     HIPCHK(c, hipMemcpyAsync(L.dN + pair, &L.hN[pair], sizeof(int), hipMemcpyHostToDevice, c->stream));
     if (!device_src) HIPCHK(c, stream_wait(c->stream));   /* host buffer is only borrowed */
     return DVO_OK;
@@ -812,6 +832,9 @@ int dvo_set_ref_level_from_images(dvo_ctx *c, int pair, int level, const int32_t
     float *dst = L.pts + (size_t)pair * L.pt_cap * 3;
     HIPCHK(c, launch_enlist_write(d_edge, 0, 0, d_depth, 0, gb, level, c->K, c->d_colcounts, d_blk, dst, 0,
                                   L.cpts + (size_t)pair * L.pt_cap, L.cidx + (size_t)pair * L.pt_cap, d_uv, N, nullptr, c->stream));
+    L.hN[pair] = N;
+    HIPCHK(c, hipMemcpyAsync(L.dN + pair, &L.hN[pair], sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_points4_build(L.cpts, L.dN, L.pt_cap, rows, L.cpt4, L.chdr, L.d_pt4_ok, pair, 1, c->stream));
     L.compact_ok[pair] = 1;
     L.hN[pair] = N;
     c->points_gen++;
@@ -944,7 +967,7 @@ int dvo_replicate_pairs(dvo_ctx *c, int n_src, int dst_first, int dst_count) {
             any_tex16 = any_tex16 || !stale;
             any_compact = any_compact || (!L.pal_built.empty() && L.pal_built[p]);
         }
-        HIPCHK(c, launch_replicate_level(any_tex16 ? L.tex : nullptr, L.tex_stride, L.pts, L.cpts, L.cidx, L.pt_cap, L.dN, n_src, dst_first, dst_count, c->stream));
+        HIPCHK(c, launch_replicate_level(any_tex16 ? L.tex : nullptr, L.tex_stride, L.pts, L.cpts, L.cidx, L.cpt4, L.chdr, L.d_pt4_ok, L.pt_cap, L.dN, n_src, dst_first, dst_count, c->stream));
         for (int p = dst_first; p < dst_first + dst_count; p++) {
             L.hN[p] = L.hN[(p - dst_first) % n_src];
             c->points_gen++;

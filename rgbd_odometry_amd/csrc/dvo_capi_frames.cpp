@@ -569,6 +569,7 @@ int dvo_frames_as_ref(dvo_ctx *c, int first_slot, int first_pair, int count, int
                                       c->work + cc_off[l], compact_block_order() ? c->work + bc_off[l] : nullptr, L.pts + (size_t)first_pair * L.pt_cap * 3, (size_t)L.pt_cap * 3,
                                       L.cpts + (size_t)first_pair * L.pt_cap, L.cidx + (size_t)first_pair * L.pt_cap, nullptr, L.pt_cap,
                                       L.dN + first_pair, c->stream));
+        HIPCHK(c, launch_points4_build(L.cpts, L.dN, L.pt_cap, F.rows, L.cpt4, L.chdr, L.d_pt4_ok, first_pair, count, c->stream));
         for (int i = 0; i < count; i++) { L.hN[first_pair + i] = hN[(size_t)l * count + i]; L.compact_ok[first_pair + i] = 1; }
         c->points_gen++;
     }

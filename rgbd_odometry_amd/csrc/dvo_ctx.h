@@ -26,6 +26,9 @@ struct Level {
     float *pts = nullptr;
     uint2 *cpts = nullptr;          /* compact twin of pts (8 B / point), same capacity; valid where compact_ok */
     unsigned *cidx = nullptr;       /* per compact point: its index in the 3 x N list (the compact twin is in block order) */
+    unsigned *cpt4 = nullptr;       /* the compact twin again in 4 bytes per point (dvo_device_math.h: pt4_decode), same capacity */
+    unsigned *chdr = nullptr;       /* per chunk of 64 points: linear block index of its first point; pt_cap / 64 per pair */
+    int *d_pt4_ok = nullptr;        /* per pair: the 4-byte list decodes to the 8-byte one bit for bit (written by the builder) */
     std::vector<char> compact_ok;   /* per pair: the list came from the engine's enlist kernels */
     int pt_cap = 0;
     int *dN = nullptr;

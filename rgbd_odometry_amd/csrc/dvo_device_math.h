@@ -45,6 +45,8 @@ struct IterConst {
     int tiles_per_col;          /* texel tiles along yy (see texel_index) */
     int interp;                 /* __INTERPOLATE_DISTANCE_TRANSFORM (SolveDVO.h:97): eps from interpolate() */
     float pcx, pfx, pcy, pfy;   /* tmpcx, tmpfx, tmpcy, tmpfy of enlistRefEdgePts (:232-235): rebuild X, Y of compact points */
+    unsigned nby;               /* 16-row blocks per block column of the level: 4-byte points (pt4_decode) */
+    float inv_nby, half_inv_nby;
 };
 
 struct PointEval {
@@ -125,6 +127,30 @@ DVO_DEV void expand_compact(const IterConst &c, unsigned pk, float z, float &X, 
     Z = z;
     X = Z * (xx - c.pcx) * c.pfx;                                  /* :249 */
     Y = Z * (yy - c.pcy) * c.pfy;                                  /* :250 */
+}
+
+/* A reference point in FOUR bytes (round 3): { pixel inside its 16 x 16 block: xx & 15 | (yy & 15) << 4 ; depth in whole
+ * millimetres << 8 ; block index relative to the point's 64-point chunk << 24 }.  The compact lists are in block order, so a
+ * chunk of 64 consecutive points spans few blocks; `L0` = linear block index (block column * nby + block row) of the chunk's
+ * first point comes from a per-chunk header (one scalar load per wave and round).  Z = depth / 1000.0f (:248) is rebuilt with
+ * a multiply and two fmas; like the pixel it is only trusted because the BUILDER decodes every point of a list with this very
+ * function and compares the bits with the 8-byte form -- a list with one mismatch (fractional depths, depths beyond 65535 mm,
+ * more than 255 blocks inside a chunk) keeps the 8-byte form.  Why: the fused kernel sits on the memory-request ceiling and the
+ * per-iteration stream of the points that do not fit in LDS was 15 % (640x480) to 35 % (1920x1080) of its requests. */
+DVO_DEV void pt4_decode(unsigned nby, float inv_nby, float half_inv_nby, unsigned w, unsigned L0, float &xxf, float &yyf, float &Z) {
+    const unsigned L = L0 + (w >> 24);
+    int bx;
+    {   /* floor((L + 0.5) / nby): exact for L < 2^21 */
+        const float t = __builtin_fmaf((float)L, inv_nby, half_inv_nby);
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(bx) : "v"(t));
+    }
+    const unsigned by = L - __umul24((unsigned)bx, nby);
+    xxf = (float)(((unsigned)bx << 4) + (w & 15u));
+    yyf = (float)((by << 4) + ((w >> 4) & 15u));
+    const float d = (float)((w >> 8) & 0xffffu);
+    const float q = d * 0.001f;
+    const float r = __builtin_fmaf(-q, 1000.0f, d);
+    Z = __builtin_fmaf(r, 0.001f, q);                     /* == d / 1000.0f for every d the builder let through */
 }
 
 /* Jacobian row from the gathered gradient (:379-406).  X,Y,Z are the

@@ -120,6 +120,11 @@ DVO_DEV unsigned p4_byte_offset(int yy, int xx, unsigned p4_col_bytes /* p4_tile
 
 struct LdsPoints {
     const uint2 *p;        /* {xx | yy << 16, Z}: 8 bytes per point, one ds_read_b64 */
+    /* the same list in 4 bytes per point (dvo_device_math.h: pt4_decode), used instead when the level's list has a valid one:
+     * twice as many points stay in LDS, the streamed remainder is half as many bytes */
+    const unsigned *w4;    /* LDS copy (one ds_read_b32 per point) */
+    const unsigned *g4;    /* the whole list in HBM (this workgroup's share) */
+    const unsigned *hdr;   /* chunk headers: linear block index of point 64 k (wave-uniform: one scalar load per wave and round) */
 };
 
 template <bool LDS_SRC>
@@ -130,16 +135,42 @@ DVO_DEV void load_compact(const LdsPoints &lp, const uint2 *__restrict__ gpts, i
 
 /* points streamed from HBM (beyond the LDS budget) are fetched ONE ROUND AHEAD of the round that projects them: a lane's
  * gather address depends on its point, so a point loaded inside the round would put two memory latencies in a row */
-struct PointPf { uint2 p0, p1; };
+struct PointPf { uint2 p0, p1; unsigned h0, h1; /* 4-byte points: the chunk headers of the round's two point groups, loaded a round ahead */ };
 
 /* stage 1 of a round: load, decode, project, issue the two gathers.  Straight-line code: a point whose z is outside the
  * range in which the fast reciprocal is proven exact (|z| < 2^-126, > 2^126, 0, inf, nan -- never in practice) is
  * treated as not visible here and reported through `any_odd` (wave-uniform); the caller then redoes the wave's whole
  * share of the iteration with the literal-division scalar code (accumulate_points_exact). */
-template <bool LDS_SRC, int TEX>
+/* chunk header of the 64-point chunk a wave's lanes sit in (i = the lane's point index: 64-aligned per wave, so wave-uniform) */
+DVO_DEV unsigned pt4_header(const LdsPoints &lp, int i, int end) {
+    const int chunk = __builtin_amdgcn_readfirstlane(min(i, end - 1)) >> 6;
+    return lp.hdr[chunk];
+}
+struct PointPf4 { unsigned w0, w1; };
+
+template <bool LDS_SRC, int TEX, bool PT4 = false>
 DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints &lp, const uint2 *__restrict__ gpts,
                           int i0, int i1, int end, int step, PointPf &pf, Round2<TEX> &b, bool &any_odd, int &nvis) {
     const bool valid0 = i0 < end, valid1 = i1 < end;
+    v2f xx, yy, Z;
+    if constexpr (PT4) {
+        unsigned w0, w1;
+        if constexpr (LDS_SRC) {
+            w0 = lp.w4[valid0 ? i0 : (end - 1)];
+            w1 = lp.w4[valid1 ? i1 : (end - 1)];
+        } else {
+            w0 = pf.p0.x; w1 = pf.p1.x;                         /* fetched while the previous round was worked on */
+            pf.p0.x = lp.g4[min(i0 + step, end - 1)];
+            pf.p1.x = lp.g4[min(i1 + step, end - 1)];
+        }
+        float x0, y0, z0, x1, y1, z1;
+        const unsigned L00 = pf.h0, L01 = pf.h1;                /* scalar loads issued a round ago: no wait here */
+        pf.h0 = pt4_header(lp, i0 + step, end);
+        pf.h1 = pt4_header(lp, i1 + step, end);
+        pt4_decode(c.nby, c.inv_nby, c.half_inv_nby, w0, L00, x0, y0, z0);
+        pt4_decode(c.nby, c.inv_nby, c.half_inv_nby, w1, L01, x1, y1, z1);
+        xx.x = x0; xx.y = x1; yy.x = y0; yy.y = y1; Z.x = z0; Z.y = z1;
+    } else {
     unsigned k0, k1;
     float z0, z1;
     if constexpr (LDS_SRC) {
@@ -152,10 +183,10 @@ DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints 
         pf.p0 = gpts[min(i0 + step, end - 1)];                  /* the next round's points (the last point again past the end) */
         pf.p1 = gpts[min(i1 + step, end - 1)];
     }
-    v2f xx, yy, Z;
     xx.x = (float)(k0 & 0xffffu); xx.y = (float)(k1 & 0xffffu);
     yy.x = (float)(k0 >> 16);     yy.y = (float)(k1 >> 16);
     Z.x = z0; Z.y = z1;
+    }
     const v2f X = (Z * (xx - c.pcx)) * c.pfx;                               /* :249 */
     const v2f Y = (Z * (yy - c.pcy)) * c.pfy;                               /* :250 */
     v2f xn, yn, zn, u, v;
@@ -260,7 +291,7 @@ DVO_DEV void round2_compute(const IterConst &c, const Round2<TEX> &b, Acc7 &a) {
 
 /* the per-point phase of one iteration over points [first, end): rounds of 2*BLOCK points, lane `lane_off` of the
  * round takes points lane_off and BLOCK + lane_off; software-pipelined over rounds with two named buffers */
-template <int BLOCK, bool LDS_SRC, int TEX, int DEPTH = 2, unsigned PAL = 0>
+template <int BLOCK, bool LDS_SRC, int TEX, int DEPTH = 2, unsigned PAL = 0, bool PT4 = false>
 DVO_DEV void accumulate_points2(const IterConst &c, const TexSrc &ts, const LdsPoints &lp, const uint2 *__restrict__ gpts,
                                 int first, int end, int lane_off, Acc7 &a, bool &any_odd) {
     if (first >= end) return;
@@ -269,11 +300,15 @@ DVO_DEV void accumulate_points2(const IterConst &c, const TexSrc &ts, const LdsP
     const int wave_off = __builtin_amdgcn_readfirstlane(lane_off - (int)(threadIdx.x & 63));
     const int n_rounds = (end - first - wave_off + STEP - 1) / STEP;
     if (n_rounds <= 0) return;
-#define DVO_ISSUE(buf, k) round2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + (k) * STEP, base + (k) * STEP + BLOCK, end, STEP, pf, buf, any_odd, a.nvis)
+#define DVO_ISSUE(buf, k) round2_issue<LDS_SRC, TEX, PT4>(c, ts, lp, gpts, base + (k) * STEP, base + (k) * STEP + BLOCK, end, STEP, pf, buf, any_odd, a.nvis)
 #define DVO_COMPUTE(buf) round2_compute<TEX, PAL>(c, buf, a)
     int base = first + lane_off;
     PointPf pf;
-    if constexpr (!LDS_SRC) { pf.p0 = gpts[min(base, end - 1)]; pf.p1 = gpts[min(base + BLOCK, end - 1)]; }
+    if constexpr (PT4) { pf.h0 = pt4_header(lp, base, end); pf.h1 = pt4_header(lp, base + BLOCK, end); }
+    if constexpr (!LDS_SRC) {
+        if constexpr (PT4) { pf.p0.x = lp.g4[min(base, end - 1)]; pf.p1.x = lp.g4[min(base + BLOCK, end - 1)]; }
+        else { pf.p0 = gpts[min(base, end - 1)]; pf.p1 = gpts[min(base + BLOCK, end - 1)]; }
+    }
     if constexpr (DEPTH == 3) {
         /* gathers issued TWO rounds ahead of the arithmetic that consumes them: with half the requests per point (TEX_P4) the
          * loop is no longer bound by the request rate but by the latency of a gather that misses the L2 (~2 rounds of
@@ -334,15 +369,24 @@ DVO_DEV float4 p4_texel(const TexSrc &ts, const float2 *pal_lds, int yy, int xx)
 /* The same sums with the literal-division scalar code (dvo_device_math.h: project_point, jacobian_row) over THIS wave's
  * points of [first, end) -- taken only when one of them has a degenerate z.  Plain loop, not pipelined: never hot.
  * P4: the level is read through its compact form (the 16-byte texels of such a level may not exist). */
-template <int BLOCK, bool LDS_SRC, bool P4>
+template <int BLOCK, bool LDS_SRC, bool P4, bool PT4 = false>
 DVO_DEV void accumulate_points_exact(const IterConst &c, const char *__restrict__ tex, const TexSrc &ts, const float2 *pal_lds,
                                      const LdsPoints &lp, const uint2 *__restrict__ gpts, int first, int end, int lane_off, Acc7 &a) {
     for (int i = first + lane_off; __builtin_amdgcn_ballot_w64(i < end) != 0ull; i += BLOCK) {
         const bool valid = i < end;
+        float X, Y, Z, xn, yn, zn, u, v;
+        if constexpr (PT4) {
+            const int j = valid ? i : (end - 1);
+            const unsigned w = LDS_SRC ? lp.w4[j] : lp.g4[j];
+            float xf, yf;
+            pt4_decode(c.nby, c.inv_nby, c.half_inv_nby, w, pt4_header(lp, i, end), xf, yf, Z);
+            X = Z * (xf - c.pcx) * c.pfx;                            /* :249 */
+            Y = Z * (yf - c.pcy) * c.pfy;                            /* :250 */
+        } else {
         unsigned k; float z;
         load_compact<LDS_SRC>(lp, gpts, valid ? i : (end - 1), k, z);
-        float X, Y, Z, xn, yn, zn, u, v;
         expand_compact(c, k, z, X, Y, Z);
+        }
         const bool vis = project_point(c, X, Y, Z, xn, yn, zn, u, v) && valid;
         a.nvis += __popcll(__builtin_amdgcn_ballot_w64(vis));
         if (vis) {
@@ -370,29 +414,46 @@ struct Final2 {
     unsigned w0, w1;        /* TEX_P4: centre rank word; else: bits of DT */
     bool vis0, vis1;
 };
-template <bool LDS_SRC, int TEX>
+template <bool LDS_SRC, int TEX, bool PT4 = false>
 DVO_DEV void final2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints &lp, const uint2 *__restrict__ gpts,
                           int i0, int i1, int end, int step, PointPf &pf, Final2 &b) {
-    unsigned k0, k1;
-    float z0, z1;
-    if constexpr (LDS_SRC) {
-        load_compact<true>(lp, gpts, min(i0, end - 1), k0, z0);
-        load_compact<true>(lp, gpts, min(i1, end - 1), k1, z1);
+    float X0, Y0, Z0, X1, Y1, Z1;
+    if constexpr (PT4) {
+        unsigned w0, w1;
+        if constexpr (LDS_SRC) {
+            w0 = lp.w4[min(i0, end - 1)]; w1 = lp.w4[min(i1, end - 1)];
+        } else {
+            w0 = pf.p0.x; w1 = pf.p1.x;
+            pf.p0.x = lp.g4[min(i0 + step, end - 1)];
+            pf.p1.x = lp.g4[min(i1 + step, end - 1)];
+        }
+        float xf, yf;
+        pt4_decode(c.nby, c.inv_nby, c.half_inv_nby, w0, pt4_header(lp, i0, end), xf, yf, Z0);
+        X0 = Z0 * (xf - c.pcx) * c.pfx; Y0 = Z0 * (yf - c.pcy) * c.pfy;                 /* :249-250 */
+        pt4_decode(c.nby, c.inv_nby, c.half_inv_nby, w1, pt4_header(lp, i1, end), xf, yf, Z1);
+        X1 = Z1 * (xf - c.pcx) * c.pfx; Y1 = Z1 * (yf - c.pcy) * c.pfy;
     } else {
-        k0 = pf.p0.x; z0 = __uint_as_float(pf.p0.y);
-        k1 = pf.p1.x; z1 = __uint_as_float(pf.p1.y);
-        pf.p0 = gpts[min(i0 + step, end - 1)];                  /* the next round's points */
-        pf.p1 = gpts[min(i1 + step, end - 1)];
+        unsigned k0, k1;
+        float z0, z1;
+        if constexpr (LDS_SRC) {
+            load_compact<true>(lp, gpts, min(i0, end - 1), k0, z0);
+            load_compact<true>(lp, gpts, min(i1, end - 1), k1, z1);
+        } else {
+            k0 = pf.p0.x; z0 = __uint_as_float(pf.p0.y);
+            k1 = pf.p1.x; z1 = __uint_as_float(pf.p1.y);
+            pf.p0 = gpts[min(i0 + step, end - 1)];                  /* the next round's points */
+            pf.p1 = gpts[min(i1 + step, end - 1)];
+        }
+        expand_compact(c, k0, z0, X0, Y0, Z0);
+        expand_compact(c, k1, z1, X1, Y1, Z1);
     }
     /* one point at a time, scalar-register pose operands: the packed form would want the pose in vector register pairs, and
      * the 256-thread shape has none to spare (tests/test_kernel_registers.py) */
     {
-        float X, Y, Z, xs, ys, zs, us, vs;
-        expand_compact(c, k0, z0, X, Y, Z);
-        project_point(c, X, Y, Z, xs, ys, zs, us, vs);
+        float xs, ys, zs, us, vs;
+        project_point(c, X0, Y0, Z0, xs, ys, zs, us, vs);
         b.u.x = us; b.v.x = vs; b.zn.x = zs;
-        expand_compact(c, k1, z1, X, Y, Z);
-        project_point(c, X, Y, Z, xs, ys, zs, us, vs);
+        project_point(c, X1, Y1, Z1, xs, ys, zs, us, vs);
         b.u.y = us; b.v.y = vs; b.zn.y = zs;
     }
     int px0, py0, px1, py1;
@@ -434,7 +495,7 @@ DVO_DEV void final2_store(const Final2 &b, int i0, int i1, int end, float *__res
     }
 }
 /* compact points [first, end) of this workgroup's share; outputs at fe[i], fr[3 i] */
-template <int BLOCK, bool LDS_SRC, int TEX, unsigned PAL>
+template <int BLOCK, bool LDS_SRC, int TEX, unsigned PAL, bool PT4 = false>
 DVO_DEV void final_outputs2(const IterConst &c, const TexSrc &ts, const LdsPoints &lp, const uint2 *__restrict__ gpts, int first, int end,
                             float *__restrict__ fe, float *__restrict__ fr) {
     constexpr int STEP = 2 * BLOCK;
@@ -444,20 +505,23 @@ DVO_DEV void final_outputs2(const IterConst &c, const TexSrc &ts, const LdsPoint
     const int n_rounds = (end - wave_first + STEP - 1) / STEP;  /* rounds in which this wave still has a point */
     int base = first + tid;
     PointPf pf;
-    if constexpr (!LDS_SRC) { pf.p0 = gpts[min(base, end - 1)]; pf.p1 = gpts[min(base + BLOCK, end - 1)]; }
+    if constexpr (!LDS_SRC) {
+        if constexpr (PT4) { pf.p0.x = lp.g4[min(base, end - 1)]; pf.p1.x = lp.g4[min(base + BLOCK, end - 1)]; }
+        else { pf.p0 = gpts[min(base, end - 1)]; pf.p1 = gpts[min(base + BLOCK, end - 1)]; }
+    }
     Final2 A, B;
-    final2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base, base + BLOCK, end, STEP, pf, A);
+    final2_issue<LDS_SRC, TEX, PT4>(c, ts, lp, gpts, base, base + BLOCK, end, STEP, pf, A);
     int r = 0;
 #pragma clang loop unroll(disable)
     for (; r + 2 < n_rounds; r += 2) {
-        final2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + STEP, base + STEP + BLOCK, end, STEP, pf, B);
+        final2_issue<LDS_SRC, TEX, PT4>(c, ts, lp, gpts, base + STEP, base + STEP + BLOCK, end, STEP, pf, B);
         final2_store<TEX, PAL>(A, base, base + BLOCK, end, fe, fr);
-        final2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + 2 * STEP, base + 2 * STEP + BLOCK, end, STEP, pf, A);
+        final2_issue<LDS_SRC, TEX, PT4>(c, ts, lp, gpts, base + 2 * STEP, base + 2 * STEP + BLOCK, end, STEP, pf, A);
         final2_store<TEX, PAL>(B, base + STEP, base + STEP + BLOCK, end, fe, fr);
         base += 2 * STEP;
     }
     if (r + 1 < n_rounds) {
-        final2_issue<LDS_SRC, TEX>(c, ts, lp, gpts, base + STEP, base + STEP + BLOCK, end, STEP, pf, B);
+        final2_issue<LDS_SRC, TEX, PT4>(c, ts, lp, gpts, base + STEP, base + STEP + BLOCK, end, STEP, pf, B);
         final2_store<TEX, PAL>(A, base, base + BLOCK, end, fe, fr);
         final2_store<TEX, PAL>(B, base + STEP, base + STEP + BLOCK, end, fe, fr);
     } else {
@@ -685,8 +749,18 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         const int mode = (n_pal > 0 && pal_base_ok && 2 * n_pal + 6 <= lds_words) ? TEX_P4
                          : ((!TEAM && !sc.no_lds_tex && 2 * n_pad + tex16_words <= lds_words) ? TEX_L16 : TEX_G16);
         const int pal_words = (mode == TEX_P4) ? ((2 * (n_pal + 1) + 3) & ~3) : 0;           /* + the sentinel entry {0, 0} */
+        /* 4-byte points (dvo_device_math.h: pt4_decode): when the builder validated this list's 4-byte twin, the throughput shape
+         * reads that -- twice the points per LDS byte, half the bytes per streamed point.  Not in team mode (a member's share
+         * does not start on a 64-point chunk). */
+        /* ... and only where most of the list is streamed: the 4-byte decode costs ~17 % more vector instructions per point, and
+         * the kernel is as close to its instruction-issue ceiling as to the request ceiling.  Measured A/B (DVO_POINTS4=off):
+         * 640x480 level 0 (14.8 k points, 8.2 k fit as 8-byte points) 723 k vs 731 k aligns/s -- a wash, so not taken;
+         * 1920x1080 (130 k / 67 k points against 19 k that fit) 77.5 k vs 75.0 k.  Taken from three times the LDS capacity. */
+        const bool pt4 = !TEAM && mode == TEX_P4 && !sc.no_pt4 && N >= 3 * (((lds_words - pal_words) >> 1) & ~1) && L.pt4_ok &&
+                         __builtin_amdgcn_readfirstlane(L.pt4_ok[dpair]) != 0;
         float *const lds_pts = lds_dyn + pal_words;
-        const int cap = (mode == TEX_L16) ? n_pad : (((lds_words - pal_words) >> 1) & ~1);          /* points the LDS holds (8 bytes each) */
+        const int cap = (mode == TEX_L16) ? n_pad
+                        : (pt4 ? ((lds_words - pal_words) & ~1) : (((lds_words - pal_words) >> 1) & ~1));      /* points the LDS holds */
         const int n_lds = (N <= cap) ? N : (cap / (2 * BLOCK)) * (2 * BLOCK);      /* whole rounds only */
         float *const lds_tex = lds_pts + 2 * cap;
         if (tid == 0) st.exact_ran = 0;
@@ -695,7 +769,22 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             float2 *pl = reinterpret_cast<float2 *>(lds_dyn);
             for (int i = tid; i <= n_pal; i += BLOCK) pl[i] = pg[i];
         }
-        {   /* 16-byte loads (whole 128-byte lines per request), four in flight per lane */
+        const unsigned *__restrict__ g4pts = L.cpt4 + (size_t)dpair * L.pt_cap + pfirst;
+        if (pt4) {   /* 16-byte loads of four points, four in flight per lane */
+            const uint4 *g4 = reinterpret_cast<const uint4 *>(g4pts);
+            uint4 *d4 = reinterpret_cast<uint4 *>(lds_pts);
+            const int n4 = n_lds >> 2;
+            int i = tid;
+            for (; i + 3 * BLOCK < n4; i += 4 * BLOCK) {
+                uint4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = g4[i + q * BLOCK];
+#pragma unroll
+                for (int q = 0; q < 4; q++) d4[i + q * BLOCK] = v[q];
+            }
+            for (; i < n4; i += BLOCK) d4[i] = g4[i];
+            for (int j = (n4 << 2) + tid; j < n_lds; j += BLOCK) reinterpret_cast<unsigned *>(lds_pts)[j] = g4pts[j];
+        } else {   /* 16-byte loads (whole 128-byte lines per request), four in flight per lane */
             const uint4 *g4 = reinterpret_cast<const uint4 *>(gpts);
             uint4 *d4 = reinterpret_cast<uint4 *>(lds_pts);
             const int n2 = n_lds >> 1;
@@ -726,6 +815,9 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         }
         LdsPoints lp;
         lp.p = reinterpret_cast<const uint2 *>(lds_pts);
+        lp.w4 = reinterpret_cast<const unsigned *>(lds_pts);
+        lp.g4 = g4pts;
+        lp.hdr = L.chdr + (size_t)dpair * (L.pt_cap >> 6);
         TexSrc ts;
         ts.g16 = tex; ts.tile_col_bytes = (unsigned)c.tiles_per_col * 128u;
         ts.l16 = reinterpret_cast<const char *>(lds_tex);
@@ -765,6 +857,9 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             const int lane_off = BLOCK - 64 - (tid & ~63) + (tid & 63);
             if (mode == TEX_L16) {                 /* staged levels hold every point in LDS */
                 accumulate_points2<BLOCK, true, TEX_L16>(c, ts, lp, gpts, 0, N, lane_off, a, any_odd);             /* :369, :433 */
+            } else if (mode == TEX_P4 && pt4) {
+                accumulate_points2<BLOCK, true, TEX_P4, DVO_P4_DEPTH(BLOCK), kStatic, true>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
+                accumulate_points2<BLOCK, false, TEX_P4, DVO_P4_DEPTH(BLOCK), kStatic, true>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);
             } else if (mode == TEX_P4) {
                 accumulate_points2<BLOCK, true, TEX_P4, DVO_P4_DEPTH(BLOCK), kStatic>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
                 accumulate_points2<BLOCK, false, TEX_P4, DVO_P4_DEPTH(BLOCK), kStatic>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);
@@ -775,7 +870,10 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             if (any_odd || sc.force_exact) {      /* wave-uniform; a point with a degenerate z: this wave's share again, literal divisions */
                 acc7_zero(a);
                 const float2 *pal_lds = reinterpret_cast<const float2 *>(lds_dyn);
-                if (mode == TEX_P4) {
+                if (mode == TEX_P4 && pt4) {
+                    accumulate_points_exact<BLOCK, true, true, true>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
+                    accumulate_points_exact<BLOCK, false, true, true>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
+                } else if (mode == TEX_P4) {
                     accumulate_points_exact<BLOCK, true, true>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
                     accumulate_points_exact<BLOCK, false, true>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
                 } else {
@@ -826,7 +924,10 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
                  * the reference's order (LevelSlab.cidx) */
                 float *fes = fe + pfirst, *frs = fr + 3 * (size_t)pfirst;
 #ifndef DVO_NO_FINAL
-                if (mode == TEX_P4) {
+                if (mode == TEX_P4 && pt4) {
+                    final_outputs2<BLOCK, true, TEX_P4, kStatic, true>(c, ts, lp, gpts, 0, n_lds, fes, frs);
+                    final_outputs2<BLOCK, false, TEX_P4, kStatic, true>(c, ts, lp, gpts, n_lds, N, fes, frs);
+                } else if (mode == TEX_P4) {
                     final_outputs2<BLOCK, true, TEX_P4, kStatic>(c, ts, lp, gpts, 0, n_lds, fes, frs);
                     final_outputs2<BLOCK, false, TEX_P4, kStatic>(c, ts, lp, gpts, n_lds, N, fes, frs);
                 } else if (mode == TEX_L16) {
@@ -845,7 +946,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             if (member == 0) {
                 out.best_idx[pair * DVO_LEVELS + l] = st.bestItr;
                 out.ratio[pair * DVO_LEVELS + l] = st.bestRatio;
-                out.tex_mode[pair * DVO_LEVELS + l] = mode | (st.exact_ran ? DVO_TEXMODE_EXACT_RAN : 0);
+                out.tex_mode[pair * DVO_LEVELS + l] = mode | (st.exact_ran ? DVO_TEXMODE_EXACT_RAN : 0) | (pt4 ? DVO_TEXMODE_PT4 : 0);
             }
         }
         __syncthreads();

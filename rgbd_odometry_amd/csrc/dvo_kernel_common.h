@@ -33,6 +33,9 @@ DVO_DEV void level_consts(IterConst &c, const Intrinsics &K, int level, int rows
     c.pfy = (float)(1. / (double)(s * K.fy));  /* :233 */
     c.pcx = s * K.cx;                          /* :234 */
     c.pcy = s * K.cy;                          /* :235 */
+    c.nby = (unsigned)((rows + 15) >> 4);
+    c.inv_nby = 1.0f / (float)c.nby;
+    c.half_inv_nby = 0.5f * c.inv_nby;
 }
 
 /* per-lane partial sums of one iteration */

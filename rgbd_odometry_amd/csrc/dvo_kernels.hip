@@ -183,8 +183,8 @@ hipError_t launch_pack_texels(const float *dt, const float *gx, const float *gy,
 /* slot p in [dst_first, dst_first+dst_count) <- copy of slot (p - dst_first) % n_src : one launch per level
  * instead of a pack + copies per pair (bench / throughput set-up, warm replicas) */
 __global__ void __launch_bounds__(256)
-replicate_level_kernel(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, unsigned *cidx, int pt_cap, int *N,
-                       int n_src, int dst_first, int dst_count) {
+replicate_level_kernel(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, unsigned *cidx, unsigned *cpt4, unsigned *chdr, int *pt4_ok,
+                       int pt_cap, int *N, int n_src, int dst_first, int dst_count) {
     const int p = dst_first + blockIdx.y;
     const int src = blockIdx.y % n_src;
     if (p == src) return;
@@ -208,13 +208,56 @@ replicate_level_kernel(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, 
         unsigned *di = cidx + (size_t)p * pt_cap;
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n; i += stride) di[i] = si[i];
     }
+    if (cpt4) {
+        const unsigned *s4 = cpt4 + (size_t)src * pt_cap, *sh = chdr + (size_t)src * (pt_cap / 64);
+        unsigned *d4 = cpt4 + (size_t)p * pt_cap, *dh = chdr + (size_t)p * (pt_cap / 64);
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n; i += stride) d4[i] = s4[i];
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)(n + 63) / 64; i += stride) dh[i] = sh[i];
+        if (blockIdx.x == 0 && threadIdx.x == 0) pt4_ok[p] = pt4_ok[src];
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) N[p] = n;
 }
-hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, unsigned *cidx, int pt_cap, int *N,
-                                  int n_src, int dst_first, int dst_count, hipStream_t s) {
+hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, unsigned *cidx, unsigned *cpt4, unsigned *chdr,
+                                  int *pt4_ok, int pt_cap, int *N, int n_src, int dst_first, int dst_count, hipStream_t s) {
     if (dst_count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(replicate_level_kernel, dim3(64, dst_count), dim3(256), 0, s, tex, tex_stride, pts, cpts, cidx, pt_cap, N,
-                       n_src, dst_first, dst_count);
+    hipLaunchKernelGGL(replicate_level_kernel, dim3(64, dst_count), dim3(256), 0, s, tex, tex_stride, pts, cpts, cidx, cpt4, chdr, pt4_ok,
+                       pt_cap, N, n_src, dst_first, dst_count);
+    return hipGetLastError();
+}
+
+/* The compact list of one pair again in 4 bytes per point + one header per 64-point chunk (dvo_device_math.h: pt4_decode).
+ * One workgroup per pair.  LOSSLESS BY VERIFICATION: every point is encoded, decoded with the function the fused kernel uses
+ * and compared bit for bit with {xx | yy << 16, Z}; pt4_ok[pair] = 1 only if all of them survive. */
+__global__ void __launch_bounds__(256)
+points4_build_kernel(const uint2 *__restrict__ cpts, const int *__restrict__ N, int pt_cap, int rows, unsigned *__restrict__ cpt4,
+                     unsigned *__restrict__ chdr, int *__restrict__ pt4_ok, int first_pair) {
+    const int pair = first_pair + blockIdx.x;
+    const int n = N[pair];
+    cpts += (size_t)pair * pt_cap; cpt4 += (size_t)pair * pt_cap; chdr += (size_t)pair * (pt_cap / 64);
+    const unsigned nby = (unsigned)((rows + 15) >> 4);
+    const float inv_nby = 1.0f / (float)nby, half_inv = 0.5f * inv_nby;
+    bool bad = false;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const uint2 p = cpts[i], p0 = cpts[i & ~63];          /* the chunk's first point (a 64-lane wave reads it once) */
+        const unsigned xx = p.x & 0xffffu, yy = p.x >> 16;
+        const unsigned L = (xx >> 4) * nby + (yy >> 4), L0 = ((p0.x & 0xffffu) >> 4) * nby + ((p0.x >> 16) >> 4);
+        const float Z = __uint_as_float(p.y);
+        const float dmm = rintf(Z * 1000.0f);
+        const bool enc = (L >= L0) && (L - L0 <= 255u) && (L < (1u << 20)) && (dmm >= 0.0f) && (dmm <= 65535.0f);
+        const unsigned w = enc ? ((xx & 15u) | ((yy & 15u) << 4) | ((unsigned)dmm << 8) | ((L - L0) << 24)) : 0u;
+        float xf, yf, zf;
+        pt4_decode(nby, inv_nby, half_inv, w, L0, xf, yf, zf);
+        if (!enc || xf != (float)xx || yf != (float)yy || __float_as_uint(zf) != p.y) bad = true;
+        cpt4[i] = w;
+        if ((i & 63) == 0) chdr[i >> 6] = L0;
+    }
+    const int any_bad = __syncthreads_or(bad ? 1 : 0);
+    if (threadIdx.x == 0) pt4_ok[pair] = (n > 0 && !any_bad) ? 1 : 0;
+}
+hipError_t launch_points4_build(const uint2 *cpts, const int *N, int pt_cap, int rows, unsigned *cpt4, unsigned *chdr, int *pt4_ok,
+                                int first_pair, int count, hipStream_t s) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(points4_build_kernel, dim3(count), dim3(256), 0, s, cpts, N, pt_cap, rows, cpt4, chdr, pt4_ok, first_pair);
     return hipGetLastError();
 }
 

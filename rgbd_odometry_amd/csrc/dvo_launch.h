@@ -16,7 +16,8 @@
 #define DVO_NACC_PAD 32
 /* where the fused kernel reads the now level of a (pair, level) from */
 enum { DVO_TEXMODE_GLOBAL16 = 0, DVO_TEXMODE_LDS16 = 1, DVO_TEXMODE_PAL4 = 2,
-       DVO_TEXMODE_EXACT_RAN = 0x100 /* flag: a wave of the packed kernel took the literal-division fallback at this level */ };
+       DVO_TEXMODE_EXACT_RAN = 0x100 /* flag: a wave of the packed kernel took the literal-division fallback at this level */,
+       DVO_TEXMODE_PT4 = 0x200       /* flag: the level's reference points were read in their 4-byte form */ };
 
 namespace dvo {
 
@@ -31,6 +32,9 @@ struct LevelSlab {
     const float *pts;
     const uint2 *cpts;      /* compact points {xx | yy << 16, Z}, pt_cap per pair; valid where the host says so (Schedule.compact) */
     const unsigned *cidx;   /* index of each compact point in the 3 x N list (block order -> reference order), pt_cap per pair */
+    const unsigned *cpt4;   /* 4-byte points (pt4_decode), pt_cap per pair */
+    const unsigned *chdr;   /* chunk headers of the 4-byte points, pt_cap / 64 per pair */
+    const int *pt4_ok;      /* per pair: the 4-byte list is valid (NULL: never built) */
     const int *N;
     size_t tex_stride;      /* texels per pair */
     int pt_cap;             /* points per pair (capacity) */
@@ -59,6 +63,7 @@ struct Schedule {
     int n_pairs_launch;      /* pairs of this launch (team mode maps workgroups to pairs itself) */
     int force_exact;         /* tests: every wave takes the literal-division fallback of the packed kernel (accumulate_points_exact) */
     int compact;             /* every pair/level of this launch has a compact point list: read 8 B / point instead of 12 */
+    int no_pt4;              /* diagnostics: never read the 4-byte form of a reference list (DVO_POINTS4=off) */
     int final_blk;           /* host bookkeeping: the final outputs of this launch are stored in the compact lists' (block) order */
 };
 
@@ -89,8 +94,12 @@ size_t palette_work_ints(int count);        /* scratch of one launch_palette_bui
 hipError_t launch_palette_build(const float4 *tex, size_t tex_stride, int rows, int cols, unsigned *p4, size_t p4_stride,
                                 float2 *pal, int *pal_n, int first_pair, int count, unsigned *work, hipStream_t s);
 bool fused_uses_compact(int points_in_flight, int interp);
-hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, unsigned *cidx, int pt_cap, int *N,
-                                  int n_src, int dst_first, int dst_count, hipStream_t s);
+hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, unsigned *cidx, unsigned *cpt4, unsigned *chdr,
+                                  int *pt4_ok, int pt_cap, int *N, int n_src, int dst_first, int dst_count, hipStream_t s);
+/* 4-byte twins of the compact lists of pairs [first_pair, first_pair + count): encode, decode with pt4_decode, compare with the
+ * 8-byte form; pt4_ok[pair] = 1 only if every point survives */
+hipError_t launch_points4_build(const uint2 *cpts, const int *N, int pt_cap, int rows, unsigned *cpt4, unsigned *chdr, int *pt4_ok,
+                                int first_pair, int count, hipStream_t s);
 /* final outputs stored in block order -> the reference's order: out[cidx[i]] = in[i] */
 hipError_t launch_final_permute(const unsigned *cidx, const float *fe_blk, const float *fr_blk, int n, float *fe, float *fr, hipStream_t s);
 /* the compact now form of slots [dst_first, dst_first+dst_count) <- that of pair (p - dst_first) % n_src */

@@ -83,7 +83,7 @@ def main():
         pyr.append(lv)
     pyr_b = [pyr[i % D] for i in range(B)]
     res["config_pyramid_bytes_per_frame"] = int(sum(g.nbytes + d.nbytes for g, d in pyr[0]))
-    timed("upload_pyramids(mono8+mono16 row-major: H2D, import, Canny)", lambda: ctx.frames_upload_pyramids(pyr_b, first_slot=0, flags=DVO_UPLOAD_ASYNC | DVO_UPLOAD_DIRECT)    # the frames sit in pinned host memory that outlives the context, B)
+    timed("upload_pyramids(mono8+mono16 row-major: H2D, import, Canny)", lambda: ctx.frames_upload_pyramids(pyr_b, first_slot=0, flags=DVO_UPLOAD_ASYNC | DVO_UPLOAD_DIRECT), B)
 
     def tracking_step():                              # every pair gets a fresh now frame against its resident reference
         ctx.frames_upload_cameras(now_b, None, first_slot=B, **kw)
