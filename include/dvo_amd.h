@@ -288,6 +288,10 @@ int  dvo_get_level_texel_mode(dvo_ctx *ctx, int pair, int level, int *mode);
 /* *ran = 1 if, at that level of that launch, a wave of the packed kernel took its literal-division fallback (a reference point
  * whose reprojected z left the range the fast reciprocal is proven exact on, or dvo_params.engine_variant = 3).  Tests. */
 int  dvo_get_level_exact_fallback(dvo_ctx *ctx, int pair, int level, int *ran);
+/* *used = 1 if that level's reference points were read in their 4-byte form (engine detail: block-relative pixel + depth in
+ * whole millimetres + chunk headers, validated bit for bit against the 8-byte list when the list is built; taken for lists
+ * of at least three times what fits in LDS, where the per-iteration stream of the rest dominates the memory requests).  Tests. */
+int  dvo_get_level_points4(dvo_ctx *ctx, int pair, int level, int *used);
 
 /* Shape the engine chose for the last fused (batch) launch: threads per workgroup (256: two workgroups per compute unit,
  * 512 / 1024: one), workgroups per frame pair (team mode, 1 = none), packed = 1: the two-points-per-lane kernel.  Inspection. */

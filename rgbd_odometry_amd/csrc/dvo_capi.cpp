@@ -1445,6 +1445,15 @@ int dvo_get_level_texel_mode(dvo_ctx *c, int pair, int level, int *mode) {
     *mode = (v < 0) ? -1 : (v & 0xff);
     return DVO_OK;
 }
+int dvo_get_level_points4(dvo_ctx *c, int pair, int level, int *used) {
+    DVO_ENTER(c);
+    if (!pair_ok(c, pair) || !level_ok(level) || !used) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    HIPCHK(c, stream_wait(c->stream));
+    int v = -1;
+    HIPCHK(c, hipMemcpy(&v, c->d_tex_mode + (size_t)pair * DVO_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
+    *used = (v >= 0 && (v & DVO_TEXMODE_PT4)) ? 1 : 0;
+    return DVO_OK;
+}
 int dvo_get_level_exact_fallback(dvo_ctx *c, int pair, int level, int *ran) {
     DVO_ENTER(c);
     if (!pair_ok(c, pair) || !level_ok(level) || !ran) return fail(c, DVO_ERR_INVALID, "bad arguments");

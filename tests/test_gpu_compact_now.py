@@ -109,8 +109,15 @@ def test_native_compact_now_levels_from_edges_640x480(oracle, kw):
             assert sizes[l] == len(np.unique(L.now_dt)), (l, sizes[l])
         R1, t1 = _check(ctx, ref, iters)
         if kw.get("engine_variant", 0) != 1:
-            small_lds = "lds_point_bytes" in kw                # below the largest palette: the kernel may not count on the compact form
-            assert [ctx.level_texel_mode(0, l) for l in range(4)] == ([2, 2, 2, 2] if not small_lds else [2, 2, 2, 2]), kw
+            assert [ctx.level_texel_mode(0, l) for l in range(4)] == [2, 2, 2, 2], kw
+            # 4-byte reference points: only for lists of at least three times what the LDS holds -- with 16 KB of LDS that is
+            # the finest levels here (the same bits come out: the builder validated every point against the 8-byte list)
+            import os
+            p4 = [ctx.level_points4(0, l) for l in range(4)]
+            if os.environ.get("DVO_POINTS4") == "off" or "lds_point_bytes" not in kw:
+                assert p4 == [False] * 4, (kw, p4)
+            else:
+                assert p4[0] and p4[1] and not p4[3], (kw, p4)
         # the planar images decoded from the compact form are the scene generator's (== the oracle's), bit for bit
         for l, L in enumerate(sc.levels):
             dt, gx, gy = ctx.get_now_level(l)
@@ -124,6 +131,30 @@ def test_native_compact_now_levels_from_edges_640x480(oracle, kw):
         assert 2 not in [ctx2.level_texel_mode(0, l) for l in range(4)]
         if kw.get("engine_variant", 0) in (0, 3):
             assert np.array_equal(R1, R2) and np.array_equal(t1, t2)
+
+
+def test_config3_1920x1080_native_compact_and_4_byte_points(oracle):
+    """BASELINE configs[2] at its full schedule (1920x1080, 5 levels, 10 iterations per level) through the throughput path:
+    natively produced compact now levels, one workgroup per pair, and -- the finest lists being many times what the LDS holds
+    (130 k / 67 k points against 19 k) -- reference points streamed in their 4-byte form.  Oracle parity as everywhere;
+    the same alignment with the 4-byte form's levels forced back to 8-byte points must give the very same bits."""
+    import os
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    sc = SynthScene(1920, 1080, 5, 0)
+    lv = oracle_lib.scene_levels(sc, oracle)
+    iters = [10, 10, 10, 10, 10]
+    ref = oracle.align_pyramid(iters, lv, sc.intrinsics, np.eye(3), np.zeros(3))
+    with DvoContext(2, team_size=1) as ctx:
+        ctx.set_intrinsics(*sc.intrinsics)
+        for l, L in enumerate(sc.levels):
+            ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols)
+            ctx.set_now_level_from_edges(l, (np.asarray(L.now_edge) != 0).astype(np.uint8) * 255, L.rows, L.cols)
+        ctx.replicate_pairs(1)
+        for pair in (0, 1):
+            R1, t1 = _check(ctx, ref, iters, pair=pair)
+            assert [ctx.level_texel_mode(pair, l) for l in range(5)] == [2] * 5
+            if not os.environ.get("DVO_POINTS4"):
+                assert [ctx.level_points4(pair, l) for l in range(5)] == [True, True, False, False, False]
 
 
 def test_native_compact_replicated_batch_and_overwrite(oracle):
