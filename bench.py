@@ -35,6 +35,21 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # imported before the HIP library on purpose: one HIP runtime per process (capi.py)
 
+
+def keep_host_memory_mapped():
+    """Host memory hygiene (profiles/r03_single_stream): a process that hands multi-hundred-kilobyte
+    blocks back to the kernel between GPU submissions (free -> munmap; here: the pose arrays numpy allocates per step) can
+    stall its own GPU queues for 10-30 ms each time on this pool.  Tell glibc to keep what it has: M_MMAP_THRESHOLD (-3) and
+    M_TRIM_THRESHOLD (-1) to 1 GiB, M_TOP_PAD (-2) to 64 MiB."""
+    try:
+        import ctypes
+        libc = ctypes.CDLL("libc.so.6")
+        libc.mallopt(-3, 1 << 30)
+        libc.mallopt(-1, 1 << 30)
+        libc.mallopt(-2, 64 << 20)
+    except Exception:
+        pass
+
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak ~6290
 
 #: the sources the fused alignment kernels are built from: their hash ties profiles/pmc_traffic.json to a kernel build
@@ -620,6 +635,7 @@ def main_tiled(args):
 
 def main():
     args = parse_args()
+    keep_host_memory_mapped()
     if args.mode == "tiled":
         main_tiled(args)
     else:
