@@ -21,6 +21,7 @@
  */
 #include "dvo_launch.h"
 #include "dvo_palette.h"
+#include <stdlib.h>
 
 namespace dvo {
 
@@ -464,15 +465,27 @@ static inline int edt_bitmap_words(int rows, int cols) {
     return (int)((bits + 31) / 32);
 }
 
-/* phase 1: per column, distance to the nearest edge pixel of that column (16 bits: <= rows+cols+1 < 46341); one wave per
- * column, 64 rows per step, nearest set bit of the ballot above / below each lane.  The downward pass parks its result in
- * LDS (each lane reads back what it wrote itself), so HBM sees one byte read and two bytes written per pixel.  The launch
- * also clears the image's presence bitmap and flags for the row pass. */
+/* g, the intermediate between the two passes, is stored in ROW BLOCKS of R rows (R = the row pass's rows per workgroup):
+ * [block][column][R rows] -- the column pass writes 16 contiguous bytes per lane, and a workgroup of the row pass reads its
+ * whole tile as one contiguous chunk in the very layout its LDS tile has.  Rows past the image (the last block's padding) hold 0. */
+__host__ __device__ inline size_t edt_g_index(int xx, int yy, int cols, int R) { return ((size_t)(yy / R) * cols + xx) * R + (yy & (R - 1)); }   /* R: a power of two */
+__host__ __device__ inline size_t edt_g_count(int rows, int cols, int R) { return (size_t)((rows + R - 1) / R) * R * cols; }
+
+/* phase 1: per column, distance to the nearest edge pixel of that column (16 bits: <= rows+cols+1 < 46341).  One wave per
+ * column, EIGHT rows per lane (512 rows per step: a whole column of every ordinary image at once): each lane turns its eight
+ * edge bytes into a bit mask; the nearest edge above / below a lane's rows outside the lane comes from the ballot of the
+ * non-empty masks and one cross-lane read of that lane's mask; inside the lane the distances are counted along the eight rows.
+ * The downward pass parks its result in LDS (each lane reads back what it wrote itself), so HBM sees one byte read and two
+ * bytes written per pixel.  The launch also clears the image's presence bitmap and flags for the row pass. */
+DVO_DEV unsigned edt_nonzero_bytes(unsigned v) {           /* bit k = (byte k of v != 0), k = 0..3 */
+    const unsigned t = ((((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v) & 0x80808080u) >> 7;
+    return (t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xfu;
+}
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
-edt_columns16_kernel(const unsigned char *__restrict__ edge, size_t edge_stride, int rows, int cols, unsigned short *__restrict__ g,
-                     unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags) {
-    extern __shared__ unsigned short s_da[];            /* [WAVES][rows] */
+edt_columns8_kernel(const unsigned char *__restrict__ edge, size_t edge_stride, int rows, int cols, int R, unsigned short *__restrict__ g,
+                    unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags) {
+    extern __shared__ uint4 s_da8[];                    /* [WAVES][nchunk * 64]: the eight upward distances of a lane */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     {
         unsigned *bm = bitmap + (size_t)blockIdx.y * bm_words;
@@ -481,37 +494,76 @@ edt_columns16_kernel(const unsigned char *__restrict__ edge, size_t edge_stride,
     }
     const int xx = blockIdx.x * WAVES + wave;
     if (xx >= cols) return;
-    edge += (size_t)blockIdx.y * edge_stride;
-    g += (size_t)blockIdx.y * rows * cols;
-    unsigned short *da_col = s_da + (size_t)wave * rows;
-    const size_t base = (size_t)xx * rows;
+    const unsigned char *col = edge + (size_t)blockIdx.y * edge_stride + (size_t)xx * rows;
+    g += (size_t)blockIdx.y * edt_g_count(rows, cols, R);
+    const int rows_pad = ((rows + R - 1) / R) * R;
+    const int nchunk = (rows + 511) / 512;
+    uint4 *da_col = s_da8 + (size_t)wave * nchunk * 64;
     const int INF = DVO_EDT_INF(rows, cols);
-    const int nchunk = (rows + 63) / 64;
+    const bool vec = ((rows & 7) == 0) && ((reinterpret_cast<size_t>(col) & 7) == 0);
+    auto load_mask = [&](int y0) -> unsigned {             /* bit j = edge at row y0 + j */
+        if (y0 >= rows) return 0u;
+        if (vec) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(col + y0);
+            return edt_nonzero_bytes(v.x) | (edt_nonzero_bytes(v.y) << 4);
+        }
+        unsigned m = 0;
+        for (int j = 0; j < 8; j++) if (y0 + j < rows && col[y0 + j] != 0) m |= 1u << j;
+        return m;
+    };
     int carry = INF;                                    /* distance from the row above this chunk to the nearest edge above it */
     for (int c = 0; c < nchunk; c++) {
-        const int yy = c * 64 + lane;
-        const bool e = (yy < rows) && (edge[base + yy] != 0);
-        const unsigned long long m = __ballot(e);
-        const unsigned long long low = m & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));   /* bits 0..lane */
-        int da;
-        if (low) da = lane - (63 - __clzll((long long)low));
-        else da = (carry >= INF) ? INF : carry + lane + 1;
-        if (yy < rows) da_col[yy] = (unsigned short)(da > INF ? INF : da);
-        if (m) carry = 63 - (63 - __clzll((long long)m));                 /* from lane 63 up to the highest edge */
-        else carry = (carry >= INF) ? INF : carry + 64;
+        const int y0 = c * 512 + lane * 8;
+        const unsigned m8 = load_mask(y0);
+        const unsigned long long bal = __ballot(m8 != 0u);
+        const unsigned long long lower = bal & ((1ull << lane) - 1ull);                          /* lanes above these rows */
+        const int lpu = lower ? 63 - __clzll((long long)lower) : lane;
+        const unsigned mlu = (unsigned)__shfl((int)m8, lpu);   /* every lane takes part: no cross-lane read under a branch */
+        int d;                                              /* distance from row y0 - 1 to the nearest edge at or above it */
+        if (lower) d = (lane * 8 - 1) - (lpu * 8 + (31 - __clz((int)mlu)));
+        else d = (carry >= INF) ? INF : carry + lane * 8;
+        unsigned short da[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { d = ((m8 >> j) & 1u) ? 0 : d + 1; da[j] = (unsigned short)(d > INF ? INF : d); }
+        uint4 o;
+        o.x = da[0] | ((unsigned)da[1] << 16); o.y = da[2] | ((unsigned)da[3] << 16);
+        o.z = da[4] | ((unsigned)da[5] << 16); o.w = da[6] | ((unsigned)da[7] << 16);
+        da_col[c * 64 + lane] = o;
+        carry = __shfl((int)da[7], 63);                     /* the chunk's last row */
     }
     carry = INF;                                        /* distance from the row below this chunk to the nearest edge below it */
     for (int c = nchunk - 1; c >= 0; c--) {
-        const int yy = c * 64 + lane;
-        const bool e = (yy < rows) && (edge[base + yy] != 0);
-        const unsigned long long m = __ballot(e);
-        const unsigned long long high = m & (~0ull << lane);                                     /* bits lane..63 */
-        int db;
-        if (high) db = (__ffsll((long long)high) - 1) - lane;
-        else db = (carry >= INF) ? INF : carry + (63 - lane) + 1;
-        if (yy < rows) { const int da = da_col[yy]; int v = da < db ? da : db; if (v > INF) v = INF; g[base + yy] = (unsigned short)v; }
-        if (m) carry = __ffsll((long long)m) - 1;                          /* from lane 0 down to the lowest edge */
-        else carry = (carry >= INF) ? INF : carry + 64;
+        const int y0 = c * 512 + lane * 8;
+        const unsigned m8 = load_mask(y0);
+        const unsigned long long bal = __ballot(m8 != 0u);
+        const unsigned long long upper = (lane == 63) ? 0ull : (bal & (~0ull << (lane + 1)));  /* lanes below these rows */
+        const int lpd = upper ? __ffsll((long long)upper) - 1 : lane;
+        const unsigned mld = (unsigned)__shfl((int)m8, lpd);
+        int d;                                              /* distance from row y0 + 8 to the nearest edge at or below it */
+        if (upper) d = (lpd * 8 + (__ffs((int)mld) - 1)) - (lane * 8 + 8);
+        else d = (carry >= INF) ? INF : carry + (63 - lane) * 8;
+        const uint4 up = da_col[c * 64 + lane];
+        const unsigned upw[4] = {up.x, up.y, up.z, up.w};
+        unsigned short v[8];
+#pragma unroll
+        for (int j = 7; j >= 0; j--) {
+            d = ((m8 >> j) & 1u) ? 0 : d + 1;
+            const int da = (int)((upw[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+            int m = da < d ? da : d;
+            m = m > INF ? INF : m;
+            v[j] = (unsigned short)((y0 + j < rows) ? m : 0);
+        }
+        carry = __shfl(d, 0);                               /* the chunk's first row (d after j = 0) */
+        if (y0 < rows_pad) {
+            if ((R & 7) == 0) {                             /* the eight rows are contiguous inside their block */
+                uint4 o;
+                o.x = v[0] | ((unsigned)v[1] << 16); o.y = v[2] | ((unsigned)v[3] << 16);
+                o.z = v[4] | ((unsigned)v[5] << 16); o.w = v[6] | ((unsigned)v[7] << 16);
+                *reinterpret_cast<uint4 *>(g + edt_g_index(xx, y0, cols, R)) = o;
+            } else {
+                for (int j = 0; j < 8; j++) if (y0 + j < rows_pad) g[edt_g_index(xx, y0 + j, cols, R)] = v[j];
+            }
+        }
     }
 }
 
@@ -524,7 +576,7 @@ edt_columns16_kernel(const unsigned char *__restrict__ edge, size_t edge_stride,
  * pixels that have not finished when one side hits the border, the remaining side alone.  Per-block maxima go to `partial`;
  * the values produced are recorded in the image's presence bitmap (an LDS copy first -- a bit is only set if it is not there
  * yet, so the atomics die out after the first few pixels -- merged into HBM once per workgroup). */
-constexpr int EDT_LBITS_WORDS = 2048;               /* d2 < 65536 go through the LDS copy of the bitmap */
+constexpr int EDT_LBITS_WORDS = 1024;               /* d2 < 32768 go through the LDS copy of the bitmap */
 /* T = unsigned: the tile holds g^2; T = unsigned short (rows too long for that, beyond 16 K columns): g, squared at use */
 template <typename T> DVO_DEV unsigned edt_sq(T v) { return (sizeof(T) == 2) ? (unsigned)v * (unsigned)v : (unsigned)v; }
 template <int R, typename T>
@@ -534,43 +586,59 @@ edt_rows16_kernel(const unsigned short *__restrict__ g, int rows, int cols, unsi
     extern __shared__ unsigned char tile_raw[];
     T *tile = reinterpret_cast<T *>(tile_raw);                /* [cols][R]: g^2 (or g) */
     __shared__ unsigned lbits[EDT_LBITS_WORDS];
-    const size_t n = (size_t)rows * cols;
-    g += (size_t)blockIdx.y * n; d2 += (size_t)blockIdx.y * n;
+    g += (size_t)blockIdx.y * edt_g_count(rows, cols, R) + (size_t)blockIdx.x * cols * R;       /* this workgroup's row block: [cols][R] */
+    d2 += (size_t)blockIdx.y * edt_g_count(rows, cols, R);
     unsigned *bm = bitmap + (size_t)blockIdx.y * bm_words;
     const int y0 = blockIdx.x * R;
     const int total = cols * R;
     for (int i = threadIdx.x; i < EDT_LBITS_WORDS; i += 256) lbits[i] = 0u;
     for (int idx = threadIdx.x; idx < total; idx += 256) {
-        const int xx = idx / R, r = idx - xx * R, yy = y0 + r;
-        const unsigned gv = (yy < rows) ? (unsigned)g[(size_t)xx * rows + yy] : 0u;
+        const unsigned gv = (unsigned)g[idx];               /* rows past the image hold 0 */
         tile[idx] = (T)((sizeof(T) == 2) ? gv : gv * gv);
     }
     __syncthreads();
     unsigned mx = 0;
     bool far = false;
-    for (int idx = threadIdx.x; idx < total; idx += 256) {
-        const int xx = idx / R, r = idx - xx * R, yy = y0 + r;
-        if (yy >= rows) continue;
-        unsigned best = edt_sq<T>(tile[idx]);
+    const int lane = threadIdx.x & 63;
+    const int wave_base = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+    for (int base = wave_base; base < total; base += 256) {         /* wave-uniform: 64 consecutive pixels of the tile = 64/R columns */
+        const int idx = base + lane;
+        const int cidx = idx < total ? idx : total - 1;
+        const int xx = cidx / R, r = cidx - xx * R, yy = y0 + r;
+        const bool live = idx < total && yy < rows;
+        unsigned best = live ? edt_sq<T>(tile[cidx]) : 0u;          /* 0: finished before it starts */
         const int near_side = (xx < cols - 1 - xx) ? xx : cols - 1 - xx;      /* steps for which both neighbours exist */
         const int far_side = (xx > cols - 1 - xx) ? xx : cols - 1 - xx;
-        const T *pl = tile + idx, *pr = tile + idx;
+        const T *pl = tile + cidx, *pr = tile + cidx;
+        /* the wave's step counter lives in scalar registers: every lane is at the same distance i, and a lane that has already
+         * finished (i^2 >= best) only sees candidates that cannot win -- no masking, no per-lane loop state.  lim = the steps
+         * for which both neighbours exist for EVERY column of the wave (min(xx, cols-1-xx) is concave: the end columns decide) */
+        const int xf = base / R, xl = ((base + 63 < total) ? base + 63 : total - 1) / R;
+        const int nf = (xf < cols - 1 - xf) ? xf : cols - 1 - xf, nl = (xl < cols - 1 - xl) ? xl : cols - 1 - xl;
+        const int lim = __builtin_amdgcn_readfirstlane(nf < nl ? nf : nl);
         int i = 1;
         unsigned i2 = 1;
-        /* both sides, four steps per trip */
-        while (i + 3 <= near_side && i2 < best) {
-            const T a0 = pl[-1 * R], b0 = pr[1 * R], a1 = pl[-2 * R], b1 = pr[2 * R];
-            const T a2 = pl[-3 * R], b2 = pr[3 * R], a3 = pl[-4 * R], b3 = pr[4 * R];
+        /* the left side is addressed from the FAR end of a trip (LDS instructions take unsigned offsets only); the empty asm
+         * keeps the compiler from re-deriving four negative offsets from the loop-carried address */
+        typedef __attribute__((address_space(3))) const T lds_ct;
+        unsigned la = (unsigned)(size_t)(lds_ct *)tile + (unsigned)((cidx - 4 * R) * (int)sizeof(T));
+        while (i + 3 <= lim && __builtin_amdgcn_ballot_w64(i2 < best) != 0ull) {
+            asm volatile("" : "+v"(la));
+            lds_ct *ql = (lds_ct *)(size_t)la;
+            const T a0 = ql[3 * R], b0 = pr[1 * R], a1 = ql[2 * R], b1 = pr[2 * R];
+            const T a2 = ql[1 * R], b2 = pr[3 * R], a3 = ql[0], b3 = pr[4 * R];
             const unsigned s1 = i2 + 2u * i + 1u, s2 = s1 + 2u * i + 3u, s3 = s2 + 2u * i + 5u;      /* (i+1)^2, (i+2)^2, (i+3)^2 */
             unsigned c0 = i2 + edt_sq<T>((T)(a0 < b0 ? a0 : b0)), c1 = s1 + edt_sq<T>((T)(a1 < b1 ? a1 : b1));      /* squaring is monotone: min first */
             unsigned c2 = s2 + edt_sq<T>((T)(a2 < b2 ? a2 : b2)), c3 = s3 + edt_sq<T>((T)(a3 < b3 ? a3 : b3));
             c0 = c0 < c1 ? c0 : c1; c2 = c2 < c3 ? c2 : c3;
             c0 = c0 < c2 ? c0 : c2;
             best = c0 < best ? c0 : best;
-            pl -= 4 * R; pr += 4 * R;
+            la -= 4 * R * (unsigned)sizeof(T); pr += 4 * R;
             i += 4; i2 = s3 + 2u * i - 1u;                    /* (i+4)^2 = (i+3)^2 + 2(i+3)+1, with i already advanced */
         }
-        /* the last (fewer than four) two-sided steps */
+        pl -= (i - 1) * R;
+        /* the lanes still open when the wave's common range ends (pixels near the left / right border, or far from every
+         * edge): per-lane loops from here.  First the remaining two-sided steps */
         for (; i <= near_side && i2 < best; i++) {
             pl -= R; pr += R;
             const T a = *pl, b = *pr;
@@ -581,7 +649,7 @@ edt_rows16_kernel(const unsigned short *__restrict__ g, int rows, int cols, unsi
         /* one side left (the pixel sits closer to the other border than its nearest edge found so far) */
         if (i <= far_side && i2 < best) {
             const int dir = (xx < cols - 1 - xx) ? R : -R;    /* the side that still has columns */
-            const T *p = tile + idx + dir * (i - 1);
+            const T *p = tile + cidx + dir * (i - 1);
             for (; i <= far_side && i2 < best; i++) {
                 p += dir;
                 const unsigned c = i2 + edt_sq<T>(*p);
@@ -589,7 +657,8 @@ edt_rows16_kernel(const unsigned short *__restrict__ g, int rows, int cols, unsi
                 i2 += 2u * i + 1u;
             }
         }
-        d2[(size_t)xx * rows + yy] = best;
+        if (!live) continue;
+        d2[(size_t)blockIdx.x * cols * R + idx] = best;              /* the same row-block layout as g */
         mx = best > mx ? best : mx;
         const unsigned w = best >> 5, bit = 1u << (best & 31u);
         if (w < (unsigned)EDT_LBITS_WORDS) {
@@ -600,6 +669,159 @@ edt_rows16_kernel(const unsigned short *__restrict__ g, int rows, int cols, unsi
             far = true;
         }
     }
+    const int m = block_reduce_256<true>((int)(mx > 0x7fffffffu ? 0x7fffffffu : mx));    /* d2 < 2^31 (rows + cols < 46340) */
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = m;
+    __syncthreads();
+    for (int w = threadIdx.x; w < EDT_LBITS_WORDS && w < bm_words; w += 256) {
+        const unsigned v = lbits[w];
+        if (v && (__hip_atomic_load(bm + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v) atomicOr(bm + w, v);
+    }
+    if (__syncthreads_or(far ? 1 : 0) && threadIdx.x == 0) atomicOr(flags + blockIdx.y, (int)EDT_FLAG_FAR);
+}
+
+/* phase 2, the kernel every ordinary image takes: the same scan in PACKED 16-bit arithmetic, two image rows per lane.
+ * Squared distances below 65535 -- nearest edge closer than 256 pixels -- are what real frames have, so the tile holds
+ * min(g^2, 65535) as 16-bit halves (rows 2m / 2m+1 of a column share a dword) and a step of the scan is, for TWO pixels, two
+ * LDS dwords, v_pk_min_u16 (left against right), a saturating v_pk_add_u16 of the step's i^2 and v_pk_min_u16 into the best:
+ * a third of the vector instructions and half the LDS traffic per pixel of the 32-bit scan.  The step counter is the wave's
+ * (scalar registers: every lane is at the same distance, a lane that has finished only sees candidates that cannot win);
+ * EDT_PK_PAD columns of "infinity" either side of the tile let it run past the image border.  Saturation is harmless while
+ * the true minimum is below 65535: a clamped candidate is >= 65535 and cannot be it.  What the packed scan cannot finish --
+ * a pixel whose best is still 65535, or still open when the wave's common range (the pad, 252 steps) ends -- is finished by
+ * the exact 32-bit per-lane scan over the second tile (g itself), from scratch if it saturated. */
+constexpr int EDT_PK_PAD = 32;
+typedef unsigned short edt_us2 __attribute__((ext_vector_type(2)));
+DVO_DEV edt_us2 edt_as_us2(unsigned v) { return __builtin_bit_cast(edt_us2, v); }
+DVO_DEV unsigned edt_as_u32(edt_us2 v) { return __builtin_bit_cast(unsigned, v); }
+
+/* exact 32-bit finish of pixel (xx, r) of the tile `tg` ([cols][R], g): steps i.. with `best` found so far */
+template <int R>
+DVO_DEV unsigned edt_finish32(const unsigned short *tg, int cols, int xx, int r, int i, unsigned best) {
+    const int near_side = (xx < cols - 1 - xx) ? xx : cols - 1 - xx;
+    const int far_side = (xx > cols - 1 - xx) ? xx : cols - 1 - xx;
+    const unsigned short *pc = tg + xx * R + r;
+    unsigned i2 = (unsigned)i * (unsigned)i;
+    for (; i <= near_side && i2 < best; i++) {
+        const unsigned a = pc[-i * R], b = pc[i * R];
+        const unsigned m = a < b ? a : b;
+        const unsigned c = i2 + m * m;
+        best = c < best ? c : best;
+        i2 += 2u * i + 1u;
+    }
+    if (i <= far_side && i2 < best) {
+        const int dir = (xx < cols - 1 - xx) ? R : -R;
+        for (; i <= far_side && i2 < best; i++) {
+            const unsigned a = pc[dir * i];
+            const unsigned c = i2 + a * a;
+            best = c < best ? c : best;
+            i2 += 2u * i + 1u;
+        }
+    }
+    return best;
+}
+
+template <int R>
+__global__ void __launch_bounds__(256)
+edt_rows_pk_kernel(const unsigned short *__restrict__ g, int rows, int cols, unsigned *__restrict__ d2, int *__restrict__ partial,
+                   unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags) {
+    static_assert(R >= 2 && (R & 1) == 0, "two rows per lane");
+    constexpr int RP = R / 2;                                  /* row pairs = dwords per tile column */
+    extern __shared__ unsigned char tile_raw[];
+    unsigned *tq = reinterpret_cast<unsigned *>(tile_raw);     /* [PAD + cols + PAD][RP]: min(g^2, 65535), two rows per dword */
+    unsigned short *tg = reinterpret_cast<unsigned short *>(tq + (size_t)(cols + 2 * EDT_PK_PAD) * RP);     /* [cols][R]: g */
+    __shared__ unsigned lbits[EDT_LBITS_WORDS];
+    /* this workgroup's row block of g is one contiguous chunk, [cols][R] like the tile (rows past the image hold 0) */
+    const unsigned *gblk = reinterpret_cast<const unsigned *>(g + (size_t)blockIdx.y * edt_g_count(rows, cols, R) + (size_t)blockIdx.x * cols * R);
+    d2 += (size_t)blockIdx.y * edt_g_count(rows, cols, R) + (size_t)blockIdx.x * cols * R;      /* d2 too is written in row blocks */
+    unsigned *bm = bitmap + (size_t)blockIdx.y * bm_words;
+    const int y0 = blockIdx.x * R;
+    const int totalp = cols * RP;
+    for (int i = threadIdx.x; i < EDT_LBITS_WORDS; i += 256) lbits[i] = 0u;
+    for (int i = threadIdx.x; i < EDT_PK_PAD * RP; i += 256) {
+        tq[i] = 0xffffffffu;
+        tq[(size_t)(EDT_PK_PAD + cols) * RP + i] = 0xffffffffu;
+    }
+    auto stage = [&](int p, unsigned gg) {
+        const unsigned g0 = gg & 0xffffu, g1 = gg >> 16;
+        const unsigned q0 = g0 > 255u ? 65535u : g0 * g0, q1 = g1 > 255u ? 65535u : g1 * g1;       /* 255^2 = 65025 */
+        reinterpret_cast<unsigned *>(tg)[p] = gg;
+        tq[EDT_PK_PAD * RP + p] = q0 | (q1 << 16);
+    };
+    const int n4 = totalp >> 2;
+    for (int q = threadIdx.x; q < n4; q += 256) {
+        const uint4 v = reinterpret_cast<const uint4 *>(gblk)[q];
+        stage(4 * q, v.x); stage(4 * q + 1, v.y); stage(4 * q + 2, v.z); stage(4 * q + 3, v.w);
+    }
+    for (int p = 4 * n4 + threadIdx.x; p < totalp; p += 256) stage(p, gblk[p]);
+    __syncthreads();
+    typedef __attribute__((address_space(3))) const unsigned lds_cu;
+    const unsigned tq_lds = (unsigned)(size_t)(lds_cu *)tq + (unsigned)(EDT_PK_PAD * RP * 4);         /* LDS byte address of column 0 */
+    unsigned mx = 0;
+    bool far = false;
+    const int lane = threadIdx.x & 63;
+    const int wave_base = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+    for (int base = wave_base; base < totalp; base += 256) {    /* wave-uniform: 64 row pairs = 64/RP columns */
+        const int p = base + lane;
+        const int cp = p < totalp ? p : totalp - 1;
+        const int xx = cp / RP, rp = cp - xx * RP, yy = y0 + 2 * rp;
+        const bool live0 = p < totalp && yy < rows, live1 = p < totalp && yy + 1 < rows;
+        edt_us2 best = edt_as_us2(p < totalp ? tq[EDT_PK_PAD * RP + cp] : 0u);      /* rows past the image hold 0: finished */
+        /* steps every column of the wave can take inside image + pad (min(xx, cols-1-xx) is concave: the end columns decide),
+         * capped where i^2 still fits 16 bits */
+        const int xf = base / RP, xl = ((base + 63 < totalp) ? base + 63 : totalp - 1) / RP;
+        const int nf = (xf < cols - 1 - xf) ? xf : cols - 1 - xf, nl = (xl < cols - 1 - xl) ? xl : cols - 1 - xl;
+        int lim = __builtin_amdgcn_readfirstlane((nf < nl ? nf : nl) + EDT_PK_PAD);
+        lim = lim < 255 ? lim : 255;
+        int i = 1;
+        unsigned i2 = 1;
+        unsigned la = tq_lds + (unsigned)((cp - 4 * RP) * 4);   /* far end of a trip's left side: LDS offsets are unsigned */
+        unsigned ra = tq_lds + (unsigned)(cp * 4);
+        while (i + 3 <= lim) {
+            const unsigned s0 = i2, s1 = s0 + 2u * i + 1u, s2 = s1 + 2u * i + 3u, s3 = s2 + 2u * i + 5u;   /* i^2 .. (i+3)^2 */
+            const edt_us2 open = __builtin_elementwise_sub_sat(best, edt_as_us2(s0 | (s0 << 16)));
+            if (__builtin_amdgcn_ballot_w64(edt_as_u32(open) != 0u) == 0ull) break;      /* i^2 >= best everywhere */
+            asm volatile("" : "+v"(la), "+v"(ra));             /* keep the two addresses as they are: offsets go into the instructions */
+            lds_cu *ql = (lds_cu *)(size_t)la, *qr = (lds_cu *)(size_t)ra;
+            const edt_us2 a0 = edt_as_us2(ql[3 * RP]), b0 = edt_as_us2(qr[1 * RP]), a1 = edt_as_us2(ql[2 * RP]), b1 = edt_as_us2(qr[2 * RP]);
+            const edt_us2 a2 = edt_as_us2(ql[1 * RP]), b2 = edt_as_us2(qr[3 * RP]), a3 = edt_as_us2(ql[0]), b3 = edt_as_us2(qr[4 * RP]);
+            const edt_us2 c0 = __builtin_elementwise_add_sat(__builtin_elementwise_min(a0, b0), edt_as_us2(s0 | (s0 << 16)));
+            const edt_us2 c1 = __builtin_elementwise_add_sat(__builtin_elementwise_min(a1, b1), edt_as_us2(s1 | (s1 << 16)));
+            const edt_us2 c2 = __builtin_elementwise_add_sat(__builtin_elementwise_min(a2, b2), edt_as_us2(s2 | (s2 << 16)));
+            const edt_us2 c3 = __builtin_elementwise_add_sat(__builtin_elementwise_min(a3, b3), edt_as_us2(s3 | (s3 << 16)));
+            best = __builtin_elementwise_min(best, __builtin_elementwise_min(__builtin_elementwise_min(c0, c1), __builtin_elementwise_min(c2, c3)));
+            la -= 4u * RP * 4u; ra += 4u * RP * 4u;
+            i += 4; i2 = s3 + 2u * i - 1u;                      /* (i+4)^2 = (i+3)^2 + 2(i+3)+1, with i already advanced */
+        }
+        /* the exact finish of what is still open: rare (a pixel further than the pad from the border AND from every edge found
+         * so far, or further than 255 pixels from every edge) */
+        unsigned b0 = best.x, b1 = best.y;
+        if (live0 && i2 < b0) b0 = (b0 == 65535u) ? edt_finish32<R>(tg, cols, xx, 2 * rp, 1, (unsigned)tg[cp * 2] * (unsigned)tg[cp * 2])
+                                                 : edt_finish32<R>(tg, cols, xx, 2 * rp, i, b0);
+        if (live1 && i2 < b1) b1 = (b1 == 65535u) ? edt_finish32<R>(tg, cols, xx, 2 * rp + 1, 1, (unsigned)tg[cp * 2 + 1] * (unsigned)tg[cp * 2 + 1])
+                                                 : edt_finish32<R>(tg, cols, xx, 2 * rp + 1, i, b1);
+        if (p < totalp) {
+            /* both presence words are requested before anything waits on them; one 8-byte store for the lane's two rows
+             * (rows past the image: 0, never read) */
+            const unsigned w0 = b0 >> 5, bit0 = 1u << (b0 & 31u), w1 = b1 >> 5, bit1 = 1u << (b1 & 31u);
+            const bool in0 = w0 < (unsigned)EDT_LBITS_WORDS, in1 = w1 < (unsigned)EDT_LBITS_WORDS;
+            const unsigned have0 = in0 ? __hip_atomic_load(&lbits[w0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+            const unsigned have1 = in1 ? __hip_atomic_load(&lbits[w1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+            reinterpret_cast<uint2 *>(d2)[cp] = make_uint2(live0 ? b0 : 0u, live1 ? b1 : 0u);
+            const unsigned m01 = (live0 ? b0 : 0u) > (live1 ? b1 : 0u) ? (live0 ? b0 : 0u) : (live1 ? b1 : 0u);
+            mx = m01 > mx ? m01 : mx;
+            if (live0) {
+                if (in0) { if (!(have0 & bit0)) atomicOr(&lbits[w0], bit0); }
+                else if (w0 < (unsigned)bm_words) { if (!(__hip_atomic_load(bm + w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit0)) atomicOr(bm + w0, bit0); }
+                else far = true;
+            }
+            if (live1) {
+                if (in1) { if (!(have1 & bit1)) atomicOr(&lbits[w1], bit1); }
+                else if (w1 < (unsigned)bm_words) { if (!(__hip_atomic_load(bm + w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit1)) atomicOr(bm + w1, bit1); }
+                else far = true;
+            }
+        }
+    }
+
     const int m = block_reduce_256<true>((int)(mx > 0x7fffffffu ? 0x7fffffffu : mx));    /* d2 < 2^31 (rows + cols < 46340) */
     if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = m;
     __syncthreads();
@@ -642,9 +864,10 @@ DVO_DEV float edt_value(unsigned d2v, const EdtScale &s) {
 constexpr int PK_LC = 16, PK_LR = 8;
 constexpr int PK_W = PK_LC * 4 + 2, PK_H = PK_LR * DVO_P4_ROWS + 2;
 constexpr int PK_SMALL_WORDS = 2048;
+static_assert(PK_LC * 4 == 64 && (PK_LR * DVO_P4_ROWS) % 8 == 0 && 2 * PK_W + 2 * (PK_H - 2) <= 256, "the rank look-up walks the tile as 2 x 32 columns by groups of 8 rows, the halo in one step of 256 threads");
 template <int BM_WORDS>
 __global__ void __launch_bounds__(256)
-edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int tiles_y, int strip, const int *__restrict__ partial, int n_partial,
+edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int R, int tiles_y, int strip, const int *__restrict__ partial, int n_partial,
                      const unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags,
                      unsigned *__restrict__ p4, size_t p4_stride, float2 *__restrict__ pal, int *__restrict__ pal_n, int first_pair) {
     __shared__ unsigned lbm[BM_WORDS];
@@ -654,8 +877,7 @@ edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int ti
     __shared__ int s_max;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pair = first_pair + blockIdx.y;
-    const size_t n = (size_t)rows * cols;
-    d2 += (size_t)blockIdx.y * n;
+    d2 += (size_t)blockIdx.y * edt_g_count(rows, cols, R);      /* row blocks of R rows, like g */
     partial += (size_t)blockIdx.y * n_partial;
     const unsigned *bm = bitmap + (size_t)blockIdx.y * bm_words;
     p4 += (size_t)pair * p4_stride;
@@ -705,6 +927,7 @@ edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int ti
         if (tid == 0) pal[n_pal] = make_float2(0.0f, 0.0f);      /* the sentinel entry */
         if (tid < 32) p4[tid] = (unsigned)n_pal << 3;            /* the sentinel line */
     }
+    const int rshift = 31 - __clz(R);                           /* R is a power of two */
     auto rank_of = [&](unsigned v) -> int { return (int)lpre[v >> 5] + __popc(lbm[v >> 5] & ((1u << (v & 31u)) - 1u)); };
     const int tpc = p4_tiles_per_col(rows);
     const int n_tcols = (cols + 3) >> 2;
@@ -715,15 +938,30 @@ edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int ti
     for (int t = sy * strip; t < tiles_y && t < (sy + 1) * strip; t++) {
         const int ty0 = t * PK_LR;
         const int y0 = ty0 * DVO_P4_ROWS - 1;                   /* image coordinates of rk[0][0]: (y0, x0) */
-        for (int idx = tid; idx < PK_W * PK_H; idx += 256) {
-            const int lx = idx / PK_H, ly = idx - lx * PK_H;
+        /* ranks of the tile's pixels and of its one-pixel halo.  d2 lies in row blocks of R rows ([block][column][R]), so the
+         * 64 x 48 interior is walked in groups of 8 rows x 32 columns: eight consecutive lanes read one 32-byte run of a column,
+         * a wave 8 adjacent columns; the halo (2 columns, 2 rows) takes one more step.  32-bit index arithmetic throughout */
+        auto rank_at = [&](int lx, int ly) {
             int yy = y0 + ly, xx = x0 + lx;
             int r = 0;
             if (yy <= rows && xx <= cols) {                      /* one pixel beyond the image is the reflected neighbour */
                 yy = reflect101(yy, rows); xx = reflect101(xx, cols);
-                r = rank_of(d2[(size_t)xx * rows + yy]);
+                r = rank_of(d2[(unsigned)(((yy >> rshift) * cols + xx) << rshift) + (unsigned)(yy & (R - 1))]);
             }
-            rk[idx] = (unsigned short)r;
+            rk[lx * PK_H + ly] = (unsigned short)r;
+        };
+        {
+            const int r8 = tid & 7, cg = tid >> 3;
+#pragma unroll
+            for (int rb = 0; rb < PK_LR * DVO_P4_ROWS / 8; rb++) {
+                rank_at(1 + cg, 1 + rb * 8 + r8);
+                rank_at(33 + cg, 1 + rb * 8 + r8);
+            }
+            if (tid < 2 * PK_W) rank_at(tid < PK_W ? tid : tid - PK_W, tid < PK_W ? 0 : PK_H - 1);            /* halo rows */
+            else if (tid - 2 * PK_W < 2 * (PK_H - 2)) {                                                          /* halo columns */
+                const int k = tid - 2 * PK_W;
+                rank_at(k < PK_H - 2 ? 0 : PK_W - 1, 1 + (k < PK_H - 2 ? k : k - (PK_H - 2)));
+            }
         }
         __syncthreads();
         for (int s = tid; s < PK_LC * PK_LR * 32; s += 256) {
@@ -759,7 +997,7 @@ edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int ti
 constexpr int NP_TY = 64, NP_TX = 16;
 static_assert(DVO_TILE_Y_LOG2 == 2 && DVO_TILE_X_LOG2 == 1, "the store mapping below assumes 4 x 2 texel tiles");
 __global__ void __launch_bounds__(256)
-dt_normalize_gradient_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int tiles_y,
+dt_normalize_gradient_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int R, int tiles_y,
                                   const int *__restrict__ partial, int n_partial,
                                   float4 *__restrict__ out, size_t tex_stride,
                                   int *__restrict__ pal_n /* NULL: every image */, const int *__restrict__ flags, int first_pair) {
@@ -772,8 +1010,7 @@ dt_normalize_gradient_pack_kernel(const unsigned *__restrict__ d2, int rows, int
         if (pal_n[pair] > 0 && !step) return;
         if (step && blockIdx.x == 0 && threadIdx.x == 0) pal_n[pair] = -(int)PAL_STEP;   /* the other workgroups read the flag, not this */
     }
-    const size_t n = (size_t)rows * cols;
-    d2 += (size_t)blockIdx.y * n;
+    d2 += (size_t)blockIdx.y * edt_g_count(rows, cols, R);      /* row blocks of R rows, like g */
     partial += (size_t)blockIdx.y * n_partial;
     out += (size_t)blockIdx.y * tex_stride;
     int m = 0;
@@ -789,7 +1026,7 @@ dt_normalize_gradient_pack_kernel(const unsigned *__restrict__ d2, int rows, int
         float v = 0.0f;
         if (yy <= rows && xx <= cols) {                      /* one pixel beyond the image is the reflected neighbour */
             yy = reflect101(yy, rows); xx = reflect101(xx, cols);
-            v = edt_value(d2[(size_t)xx * rows + yy], sc);
+            v = edt_value(d2[edt_g_index(xx, yy, cols, R)], sc);
         }
         sn[idx] = v;
     }
@@ -842,16 +1079,20 @@ hipError_t launch_p4_decode_texels(const unsigned *p4, size_t p4_stride, const f
     return hipGetLastError();
 }
 
-static int edt_rows_per_block(int cols) {             /* LDS rows per workgroup of the row pass: 32-bit g^2, beyond 16 K columns 16-bit g */
-    for (int R = 16; R > 1; R >>= 1)
-        if ((size_t)cols * R * 4 <= 64 * 1024) return R;
+/* LDS rows per workgroup of the row pass.  R >= 2: the packed kernel (two 16-bit tiles, the scanned one padded); R = 1 (rows of
+ * more than ~8 K columns): the 32-bit kernel on g^2, beyond 16 K columns on 16-bit g */
+static size_t edt_pk_lds_bytes(int cols, int R) { return (size_t)(cols + 2 * EDT_PK_PAD) * (R / 2) * 4 + (size_t)cols * R * 2; }
+static int edt_rows_per_block(int cols) {
+    static const int start = [] { const char *e = getenv("DVO_EDT_ROWS"); const int v = e ? atoi(e) : 0; return (v == 16 || v == 4 || v == 2) ? v : 8; }();
+    for (int R = start; R > 1; R >>= 1)
+        if (edt_pk_lds_bytes(cols, R) <= 64 * 1024) return R;
     return 1;                                         /* cols < 46340: at most 91 KiB of 16-bit g */
 }
 static unsigned edt_row_blocks(int rows, int cols) { const int R = edt_rows_per_block(cols); return (unsigned)((rows + R - 1) / R); }
 /* scratch of one launch_edges_to_now over `count` images, in ints: g (16 bit) | d2 | per-block maxima | bitmaps | flags */
 size_t edt_work_ints(int rows, int cols, int count) {
-    const size_t n = (size_t)rows * cols;
-    return ((n + 1) / 2 + 4 + n + edt_row_blocks(rows, cols) + (size_t)edt_bitmap_words(rows, cols) + 1) * count + 64;
+    const size_t ng = edt_g_count(rows, cols, edt_rows_per_block(cols));
+    return ((ng + 1) / 2 + 4 + ng + edt_row_blocks(rows, cols) + (size_t)edt_bitmap_words(rows, cols) + 1) * count + 64;
 }
 
 template <int R, typename T>
@@ -867,36 +1108,56 @@ static hipError_t edt_rows_launch(const unsigned short *g, ImgBatch gb, unsigned
     return hipGetLastError();
 }
 
+template <int R>
+static hipError_t edt_rows_pk_launch(const unsigned short *g, ImgBatch gb, unsigned nblk, unsigned *d2, int *partial, unsigned *bitmap,
+                                     int bm_words, int *flags, hipStream_t s) {
+    const size_t lds = edt_pk_lds_bytes(gb.cols, R);
+    auto kern = edt_rows_pk_kernel<R>;
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblk, gb.count), dim3(256), lds, s, g, gb.rows, gb.cols, d2, partial, bitmap, bm_words, flags);
+    return hipGetLastError();
+}
+
 /* edge masks -> resident now levels of pairs first_pair .. first_pair + count - 1.  With p4 != NULL the compact form is what is
  * written (16-byte texels only for the images it cannot hold); with p4 == NULL the 16-byte texels of every image. */
 hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, ImgBatch gb, int *work,
                                float4 *tex_out, size_t tex_stride, unsigned *p4, size_t p4_stride, float2 *pal, int *pal_n,
                                int first_pair, hipStream_t s) {
-    const size_t n = (size_t)gb.rows * gb.cols;
     const int R = edt_rows_per_block(gb.cols);
     const unsigned nblk = edt_row_blocks(gb.rows, gb.cols);
     const int bm_words = edt_bitmap_words(gb.rows, gb.cols);
     /* carve the scratch: 4-byte aligned sections */
+    const size_t ng = edt_g_count(gb.rows, gb.cols, R);       /* a multiple of 8 for every R >= 8; 16-byte aligned images then */
     unsigned short *g = reinterpret_cast<unsigned short *>(work);
-    unsigned *d2 = reinterpret_cast<unsigned *>(work) + (((n * gb.count + 1) / 2 + 3) & ~(size_t)3);
-    int *partial = reinterpret_cast<int *>(d2 + n * gb.count);
+    unsigned *d2 = reinterpret_cast<unsigned *>(work) + (((ng * gb.count + 1) / 2 + 3) & ~(size_t)3);
+    int *partial = reinterpret_cast<int *>(d2 + ng * gb.count);
     unsigned *bitmap = reinterpret_cast<unsigned *>(partial + (size_t)nblk * gb.count);
     int *flags = reinterpret_cast<int *>(bitmap + (size_t)bm_words * gb.count);
     hipError_t e;
-    if (gb.rows <= 8192) {
-        hipLaunchKernelGGL(edt_columns16_kernel<4>, dim3((gb.cols + 3) / 4, gb.count), dim3(256), (size_t)gb.rows * 4 * 2, s, edge, edge_stride,
-                           gb.rows, gb.cols, g, bitmap, bm_words, flags);
-    } else {
-        auto kern = edt_columns16_kernel<1>;
-        if ((e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, gb.rows * 2)) != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(gb.cols, gb.count), dim3(64), (size_t)gb.rows * 2, s, edge, edge_stride, gb.rows, gb.cols, g, bitmap,
-                           bm_words, flags);
+    {
+        const size_t lds_wave = (size_t)((gb.rows + 511) / 512) * 64 * sizeof(uint4);      /* 2 bytes per (padded) row */
+        static const bool wide = getenv("DVO_EDT_COLS8") != nullptr;
+        if (wide && lds_wave * 8 <= 48 * 1024) {
+            hipLaunchKernelGGL(edt_columns8_kernel<8>, dim3((gb.cols + 7) / 8, gb.count), dim3(512), lds_wave * 8, s, edge, edge_stride,
+                               gb.rows, gb.cols, R, g, bitmap, bm_words, flags);
+        } else if (lds_wave * 4 <= 48 * 1024) {
+            hipLaunchKernelGGL(edt_columns8_kernel<4>, dim3((gb.cols + 3) / 4, gb.count), dim3(256), lds_wave * 4, s, edge, edge_stride,
+                               gb.rows, gb.cols, R, g, bitmap, bm_words, flags);
+        } else {
+            auto kern = edt_columns8_kernel<1>;
+            if ((e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wave)) != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(gb.cols, gb.count), dim3(64), lds_wave, s, edge, edge_stride, gb.rows, gb.cols, R, g, bitmap,
+                               bm_words, flags);
+        }
     }
     switch (R) {
-    case 16: e = edt_rows_launch<16, unsigned>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
-    case 8: e = edt_rows_launch<8, unsigned>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
-    case 4: e = edt_rows_launch<4, unsigned>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
-    case 2: e = edt_rows_launch<2, unsigned>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
+    case 16: e = edt_rows_pk_launch<16>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
+    case 8: e = edt_rows_pk_launch<8>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
+    case 4: e = edt_rows_pk_launch<4>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
+    case 2: e = edt_rows_pk_launch<2>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
     default:
         e = ((size_t)gb.cols * 4 <= 64 * 1024) ? edt_rows_launch<1, unsigned>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s)
                                                : edt_rows_launch<1, unsigned short>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s);
@@ -910,14 +1171,14 @@ hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, Im
         long long strip = (long long)gb.count * ptiles_y * ptiles_x / 2048;
         strip = strip < 1 ? 1 : (strip > ptiles_y ? ptiles_y : strip);
         const int n_strips = (ptiles_y + (int)strip - 1) / (int)strip;
-        hipLaunchKernelGGL(edt_rank_pack_kernel<PK_SMALL_WORDS>, dim3(n_strips * ptiles_x, gb.count), dim3(256), 0, s, d2, gb.rows, gb.cols, ptiles_y,
+        hipLaunchKernelGGL(edt_rank_pack_kernel<PK_SMALL_WORDS>, dim3(n_strips * ptiles_x, gb.count), dim3(256), 0, s, d2, gb.rows, gb.cols, R, ptiles_y,
                            (int)strip, partial, (int)nblk, bitmap, bm_words, flags, p4, p4_stride, pal, pal_n, first_pair);
         if (bm_words > PK_SMALL_WORDS)            /* squared distances of 65536 and more are possible at this size: the full-bitmap twin */
             hipLaunchKernelGGL(edt_rank_pack_kernel<DVO_EDT_BITMAP_BITS / 32>, dim3(n_strips * ptiles_x, gb.count), dim3(256), 0, s, d2, gb.rows,
-                               gb.cols, ptiles_y, (int)strip, partial, (int)nblk, bitmap, bm_words, flags, p4, p4_stride, pal, pal_n, first_pair);
+                               gb.cols, R, ptiles_y, (int)strip, partial, (int)nblk, bitmap, bm_words, flags, p4, p4_stride, pal, pal_n, first_pair);
     }
     const int tiles_y = (gb.rows + NP_TY - 1) / NP_TY, tiles_x = (gb.cols + NP_TX - 1) / NP_TX;
-    hipLaunchKernelGGL(dt_normalize_gradient_pack_kernel, dim3(tiles_y * tiles_x, gb.count), dim3(256), 0, s, d2, gb.rows, gb.cols,
+    hipLaunchKernelGGL(dt_normalize_gradient_pack_kernel, dim3(tiles_y * tiles_x, gb.count), dim3(256), 0, s, d2, gb.rows, gb.cols, R,
                        tiles_y, partial, (int)nblk, tex_out, tex_stride, p4 ? pal_n : nullptr, flags, first_pair);
     return hipGetLastError();
 }

@@ -148,6 +148,24 @@ DVO_DEV unsigned pt4_header(const LdsPoints &lp, int i, int end) {
 }
 struct PointPf4 { unsigned w0, w1; };
 
+/* streamed reference points / final outputs: loads and stores of data that is touched once per pass.  DVO_NT_POINTS /
+ * DVO_NT_FINAL (experiment builds) mark them non-temporal so that they do not displace the look-up lines in the L2 */
+DVO_DEV uint2 stream_point(const uint2 *__restrict__ p) {
+#if defined(DVO_NT_POINTS)
+    typedef unsigned nt_u2 __attribute__((ext_vector_type(2)));
+    const nt_u2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u2 *>(p));
+    return make_uint2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+DVO_DEV unsigned stream_word(const unsigned *__restrict__ p) {
+#if defined(DVO_NT_POINTS)
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 template <bool LDS_SRC, int TEX, bool PT4 = false>
 DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints &lp, const uint2 *__restrict__ gpts,
                           int i0, int i1, int end, int step, PointPf &pf, Round2<TEX> &b, bool &any_odd, int &nvis) {
@@ -160,8 +178,8 @@ DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints 
             w1 = lp.w4[valid1 ? i1 : (end - 1)];
         } else {
             w0 = pf.p0.x; w1 = pf.p1.x;                         /* fetched while the previous round was worked on */
-            pf.p0.x = lp.g4[min(i0 + step, end - 1)];
-            pf.p1.x = lp.g4[min(i1 + step, end - 1)];
+            pf.p0.x = stream_word(lp.g4 + min(i0 + step, end - 1));
+            pf.p1.x = stream_word(lp.g4 + min(i1 + step, end - 1));
         }
         float x0, y0, z0, x1, y1, z1;
         const unsigned L00 = pf.h0, L01 = pf.h1;                /* scalar loads issued a round ago: no wait here */
@@ -180,8 +198,8 @@ DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints 
     } else {
         k0 = pf.p0.x; z0 = __uint_as_float(pf.p0.y);            /* fetched while the previous round was worked on */
         k1 = pf.p1.x; z1 = __uint_as_float(pf.p1.y);
-        pf.p0 = gpts[min(i0 + step, end - 1)];                  /* the next round's points (the last point again past the end) */
-        pf.p1 = gpts[min(i1 + step, end - 1)];
+        pf.p0 = stream_point(gpts + min(i0 + step, end - 1));                  /* the next round's points (the last point again past the end) */
+        pf.p1 = stream_point(gpts + min(i1 + step, end - 1));
     }
     xx.x = (float)(k0 & 0xffffu); xx.y = (float)(k1 & 0xffffu);
     yy.x = (float)(k0 >> 16);     yy.y = (float)(k1 >> 16);
@@ -306,8 +324,8 @@ DVO_DEV void accumulate_points2(const IterConst &c, const TexSrc &ts, const LdsP
     PointPf pf;
     if constexpr (PT4) { pf.h0 = pt4_header(lp, base, end); pf.h1 = pt4_header(lp, base + BLOCK, end); }
     if constexpr (!LDS_SRC) {
-        if constexpr (PT4) { pf.p0.x = lp.g4[min(base, end - 1)]; pf.p1.x = lp.g4[min(base + BLOCK, end - 1)]; }
-        else { pf.p0 = gpts[min(base, end - 1)]; pf.p1 = gpts[min(base + BLOCK, end - 1)]; }
+        if constexpr (PT4) { pf.p0.x = stream_word(lp.g4 + min(base, end - 1)); pf.p1.x = stream_word(lp.g4 + min(base + BLOCK, end - 1)); }
+        else { pf.p0 = stream_point(gpts + min(base, end - 1)); pf.p1 = stream_point(gpts + min(base + BLOCK, end - 1)); }
     }
     if constexpr (DEPTH == 3) {
         /* gathers issued TWO rounds ahead of the arithmetic that consumes them: with half the requests per point (TEX_P4) the
@@ -424,8 +442,8 @@ DVO_DEV void final2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints 
             w0 = lp.w4[min(i0, end - 1)]; w1 = lp.w4[min(i1, end - 1)];
         } else {
             w0 = pf.p0.x; w1 = pf.p1.x;
-            pf.p0.x = lp.g4[min(i0 + step, end - 1)];
-            pf.p1.x = lp.g4[min(i1 + step, end - 1)];
+            pf.p0.x = stream_word(lp.g4 + min(i0 + step, end - 1));
+            pf.p1.x = stream_word(lp.g4 + min(i1 + step, end - 1));
         }
         float xf, yf;
         pt4_decode(c.nby, c.inv_nby, c.half_inv_nby, w0, pt4_header(lp, i0, end), xf, yf, Z0);
@@ -441,8 +459,8 @@ DVO_DEV void final2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints 
         } else {
             k0 = pf.p0.x; z0 = __uint_as_float(pf.p0.y);
             k1 = pf.p1.x; z1 = __uint_as_float(pf.p1.y);
-            pf.p0 = gpts[min(i0 + step, end - 1)];                  /* the next round's points */
-            pf.p1 = gpts[min(i1 + step, end - 1)];
+            pf.p0 = stream_point(gpts + min(i0 + step, end - 1));                  /* the next round's points */
+            pf.p1 = stream_point(gpts + min(i1 + step, end - 1));
         }
         expand_compact(c, k0, z0, X0, Y0, Z0);
         expand_compact(c, k1, z1, X1, Y1, Z1);
@@ -483,6 +501,18 @@ DVO_DEV void final2_store(const Final2 &b, int i0, int i1, int end, float *__res
         e0 = b.vis0 ? __uint_as_float(b.w0) : 0.0f;
         e1 = b.vis1 ? __uint_as_float(b.w1) : 0.0f;
     }
+#if defined(DVO_NT_FINAL)
+    if (i0 < end) {
+        __builtin_nontemporal_store(e0, fe + i0);
+        float *q = fr + 3 * (size_t)i0;
+        __builtin_nontemporal_store(b.u.x, q); __builtin_nontemporal_store(b.v.x, q + 1); __builtin_nontemporal_store(b.zn.x, q + 2);
+    }
+    if (i1 < end) {
+        __builtin_nontemporal_store(e1, fe + i1);
+        float *q = fr + 3 * (size_t)i1;
+        __builtin_nontemporal_store(b.u.y, q); __builtin_nontemporal_store(b.v.y, q + 1); __builtin_nontemporal_store(b.zn.y, q + 2);
+    }
+#else
     if (i0 < end) {
         fe[i0] = e0;
         U3 o; o.a = __float_as_uint(b.u.x); o.b = __float_as_uint(b.v.x); o.c = __float_as_uint(b.zn.x);
@@ -493,6 +523,7 @@ DVO_DEV void final2_store(const Final2 &b, int i0, int i1, int end, float *__res
         U3 o; o.a = __float_as_uint(b.u.y); o.b = __float_as_uint(b.v.y); o.c = __float_as_uint(b.zn.y);
         *reinterpret_cast<U3 *>(fr + 3 * (size_t)i1) = o;
     }
+#endif
 }
 /* compact points [first, end) of this workgroup's share; outputs at fe[i], fr[3 i] */
 template <int BLOCK, bool LDS_SRC, int TEX, unsigned PAL, bool PT4 = false>
@@ -506,8 +537,8 @@ DVO_DEV void final_outputs2(const IterConst &c, const TexSrc &ts, const LdsPoint
     int base = first + tid;
     PointPf pf;
     if constexpr (!LDS_SRC) {
-        if constexpr (PT4) { pf.p0.x = lp.g4[min(base, end - 1)]; pf.p1.x = lp.g4[min(base + BLOCK, end - 1)]; }
-        else { pf.p0 = gpts[min(base, end - 1)]; pf.p1 = gpts[min(base + BLOCK, end - 1)]; }
+        if constexpr (PT4) { pf.p0.x = stream_word(lp.g4 + min(base, end - 1)); pf.p1.x = stream_word(lp.g4 + min(base + BLOCK, end - 1)); }
+        else { pf.p0 = stream_point(gpts + min(base, end - 1)); pf.p1 = stream_point(gpts + min(base + BLOCK, end - 1)); }
     }
     Final2 A, B;
     final2_issue<LDS_SRC, TEX, PT4>(c, ts, lp, gpts, base, base + BLOCK, end, STEP, pf, A);
