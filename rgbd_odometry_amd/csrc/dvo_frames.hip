@@ -749,7 +749,11 @@ edt_rows_pk_kernel(const unsigned short *__restrict__ g, int rows, int cols, uns
     };
     const int n4 = totalp >> 2;
     for (int q = threadIdx.x; q < n4; q += 256) {
+#if defined(DVO_EDT_X) && DVO_EDT_X == 5
+        const uint4 v = make_uint4(q, q, q, q);
+#else
         const uint4 v = reinterpret_cast<const uint4 *>(gblk)[q];
+#endif
         stage(4 * q, v.x); stage(4 * q + 1, v.y); stage(4 * q + 2, v.z); stage(4 * q + 3, v.w);
     }
     for (int p = 4 * n4 + threadIdx.x; p < totalp; p += 256) stage(p, gblk[p]);
@@ -776,6 +780,9 @@ edt_rows_pk_kernel(const unsigned short *__restrict__ g, int rows, int cols, uns
         unsigned i2 = 1;
         unsigned la = tq_lds + (unsigned)((cp - 4 * RP) * 4);   /* far end of a trip's left side: LDS offsets are unsigned */
         unsigned ra = tq_lds + (unsigned)(cp * 4);
+#if defined(DVO_EDT_X) && DVO_EDT_X == 1
+        lim = 0; best = edt_as_us2(0u);
+#endif
         while (i + 3 <= lim) {
             const unsigned s0 = i2, s1 = s0 + 2u * i + 1u, s2 = s1 + 2u * i + 3u, s3 = s2 + 2u * i + 5u;   /* i^2 .. (i+3)^2 */
             const edt_us2 open = __builtin_elementwise_sub_sat(best, edt_as_us2(s0 | (s0 << 16)));
@@ -806,9 +813,15 @@ edt_rows_pk_kernel(const unsigned short *__restrict__ g, int rows, int cols, uns
             const bool in0 = w0 < (unsigned)EDT_LBITS_WORDS, in1 = w1 < (unsigned)EDT_LBITS_WORDS;
             const unsigned have0 = in0 ? __hip_atomic_load(&lbits[w0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
             const unsigned have1 = in1 ? __hip_atomic_load(&lbits[w1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+#if !(defined(DVO_EDT_X) && DVO_EDT_X == 4)
             reinterpret_cast<uint2 *>(d2)[cp] = make_uint2(live0 ? b0 : 0u, live1 ? b1 : 0u);
+#endif
             const unsigned m01 = (live0 ? b0 : 0u) > (live1 ? b1 : 0u) ? (live0 ? b0 : 0u) : (live1 ? b1 : 0u);
             mx = m01 > mx ? m01 : mx;
+#if defined(DVO_EDT_X) && DVO_EDT_X == 2
+            if (have0 + have1 == 12345u) far = true;
+            continue;
+#endif
             if (live0) {
                 if (in0) { if (!(have0 & bit0)) atomicOr(&lbits[w0], bit0); }
                 else if (w0 < (unsigned)bm_words) { if (!(__hip_atomic_load(bm + w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit0)) atomicOr(bm + w0, bit0); }
@@ -935,34 +948,45 @@ edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int R,
     const int sy = blockIdx.x % n_strips, tcx = blockIdx.x / n_strips;
     const int tc0 = tcx * PK_LC, x0 = tc0 * 4 - 1;
     bool bad_step = false;
-    for (int t = sy * strip; t < tiles_y && t < (sy + 1) * strip; t++) {
+    /* A thread's share of a tile's pixels + one-pixel halo: 12 interior pixels and one of the halo.  d2 lies in row blocks of R
+     * rows ([block][column][R]), so the 64 x 48 interior is walked in groups of 8 rows x 32 columns -- eight consecutive lanes
+     * read one 32-byte run of a column, a wave 8 adjacent columns -- and the halo (2 rows, 2 columns) takes one more step.
+     * The squared distances of the NEXT tile of the strip are fetched into registers before the current tile's words are
+     * assembled and stored, so that their latency hides behind that work.  32-bit index arithmetic throughout. */
+    constexpr int PK_NV = 2 * (PK_LR * DVO_P4_ROWS / 8) + 1;
+    constexpr unsigned PK_NONE = 0xffffffffu;                    /* "outside image + halo": rank 0 (never read) */
+    const int r8 = tid & 7, cg = tid >> 3;
+    int hlx = -1, hly = 0;                                       /* this thread's halo pixel */
+    if (tid < 2 * PK_W) { hlx = tid < PK_W ? tid : tid - PK_W; hly = tid < PK_W ? 0 : PK_H - 1; }
+    else if (tid - 2 * PK_W < 2 * (PK_H - 2)) { const int k = tid - 2 * PK_W; hlx = k < PK_H - 2 ? 0 : PK_W - 1; hly = 1 + (k < PK_H - 2 ? k : k - (PK_H - 2)); }
+    auto fetch_at = [&](int y0, int lx, int ly) -> unsigned {
+        int yy = y0 + ly, xx = x0 + lx;
+        if (yy > rows || xx > cols) return PK_NONE;              /* one pixel beyond the image is the reflected neighbour */
+        yy = reflect101(yy, rows); xx = reflect101(xx, cols);
+        return d2[(unsigned)(((yy >> rshift) * cols + xx) << rshift) + (unsigned)(yy & (R - 1))];
+    };
+    auto fetch_tile = [&](int t, unsigned (&v)[PK_NV]) {
+        const int y0 = t * PK_LR * DVO_P4_ROWS - 1;
+#pragma unroll
+        for (int rb = 0; rb < PK_LR * DVO_P4_ROWS / 8; rb++) {
+            v[2 * rb] = fetch_at(y0, 1 + cg, 1 + rb * 8 + r8);
+            v[2 * rb + 1] = fetch_at(y0, 33 + cg, 1 + rb * 8 + r8);
+        }
+        v[PK_NV - 1] = hlx >= 0 ? fetch_at(y0, hlx, hly) : PK_NONE;
+    };
+    const int t_first = sy * strip, t_end = (tiles_y < (sy + 1) * strip) ? tiles_y : (sy + 1) * strip;
+    unsigned cur[PK_NV];
+    if (t_first < t_end) fetch_tile(t_first, cur);
+    for (int t = t_first; t < t_end; t++) {
         const int ty0 = t * PK_LR;
         const int y0 = ty0 * DVO_P4_ROWS - 1;                   /* image coordinates of rk[0][0]: (y0, x0) */
-        /* ranks of the tile's pixels and of its one-pixel halo.  d2 lies in row blocks of R rows ([block][column][R]), so the
-         * 64 x 48 interior is walked in groups of 8 rows x 32 columns: eight consecutive lanes read one 32-byte run of a column,
-         * a wave 8 adjacent columns; the halo (2 columns, 2 rows) takes one more step.  32-bit index arithmetic throughout */
-        auto rank_at = [&](int lx, int ly) {
-            int yy = y0 + ly, xx = x0 + lx;
-            int r = 0;
-            if (yy <= rows && xx <= cols) {                      /* one pixel beyond the image is the reflected neighbour */
-                yy = reflect101(yy, rows); xx = reflect101(xx, cols);
-                r = rank_of(d2[(unsigned)(((yy >> rshift) * cols + xx) << rshift) + (unsigned)(yy & (R - 1))]);
-            }
-            rk[lx * PK_H + ly] = (unsigned short)r;
-        };
-        {
-            const int r8 = tid & 7, cg = tid >> 3;
 #pragma unroll
-            for (int rb = 0; rb < PK_LR * DVO_P4_ROWS / 8; rb++) {
-                rank_at(1 + cg, 1 + rb * 8 + r8);
-                rank_at(33 + cg, 1 + rb * 8 + r8);
-            }
-            if (tid < 2 * PK_W) rank_at(tid < PK_W ? tid : tid - PK_W, tid < PK_W ? 0 : PK_H - 1);            /* halo rows */
-            else if (tid - 2 * PK_W < 2 * (PK_H - 2)) {                                                          /* halo columns */
-                const int k = tid - 2 * PK_W;
-                rank_at(k < PK_H - 2 ? 0 : PK_W - 1, 1 + (k < PK_H - 2 ? k : k - (PK_H - 2)));
-            }
+        for (int rb = 0; rb < PK_LR * DVO_P4_ROWS / 8; rb++) {
+            rk[(1 + cg) * PK_H + 1 + rb * 8 + r8] = (unsigned short)(cur[2 * rb] == PK_NONE ? 0 : rank_of(cur[2 * rb]));
+            rk[(33 + cg) * PK_H + 1 + rb * 8 + r8] = (unsigned short)(cur[2 * rb + 1] == PK_NONE ? 0 : rank_of(cur[2 * rb + 1]));
         }
+        if (hlx >= 0) rk[hlx * PK_H + hly] = (unsigned short)(cur[PK_NV - 1] == PK_NONE ? 0 : rank_of(cur[PK_NV - 1]));
+        if (t + 1 < t_end) fetch_tile(t + 1, cur);               /* in flight across the barrier and the stores below */
         __syncthreads();
         for (int s = tid; s < PK_LC * PK_LR * 32; s += 256) {
             /* consecutive lanes -> consecutive words of a line, consecutive lines of a column of lines: contiguous in memory */
@@ -982,6 +1006,9 @@ edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int R,
                     word |= (((unsigned)dr & 0xffu) << 16) | (((unsigned)dl & 0xffu) << 24);
                 }
             }
+#if defined(DVO_EDT_X) && DVO_EDT_X == 8
+            if (word == 0x12345u)
+#endif
             p4[32u + ((size_t)tc * tpc + ty) * 32u + wd] = word;
         }
         __syncthreads();
@@ -1139,8 +1166,7 @@ hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, Im
     hipError_t e;
     {
         const size_t lds_wave = (size_t)((gb.rows + 511) / 512) * 64 * sizeof(uint4);      /* 2 bytes per (padded) row */
-        static const bool wide = getenv("DVO_EDT_COLS8") != nullptr;
-        if (wide && lds_wave * 8 <= 48 * 1024) {
+        if (R <= 8 && lds_wave * 8 <= 48 * 1024) {            /* eight adjacent columns complete a 128-byte line of 8-row blocks */
             hipLaunchKernelGGL(edt_columns8_kernel<8>, dim3((gb.cols + 7) / 8, gb.count), dim3(512), lds_wave * 8, s, edge, edge_stride,
                                gb.rows, gb.cols, R, g, bitmap, bm_words, flags);
         } else if (lds_wave * 4 <= 48 * 1024) {

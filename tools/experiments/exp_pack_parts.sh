@@ -1,9 +1,8 @@
 #!/bin/bash
-# where the row pass's time goes: experiment builds that drop one part each (results wrong, timing only)
-#   edtx1 no scan   edtx2 no bitmap recording   edtx4 no d2 store   edtx5 no loads of g
+# where the rank-pack pass's time goes (results wrong, timing only): edtx6 no d2 loads, edtx7 no rank look-up, edtx8 no stores
 cd /tmp; export TMPDIR=/tmp
-for v in "" _edtx1 _edtx2 _edtx4 _edtx5; do
-  rm -rf /tmp/edtprof; DVO_EDT_ROWS=${ROWS:-8} DVO_LIB_VARIANT=$v timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/edtprof -o t -- python3 $GRAFT_REPO_ROOT/tools/bench_frames.py --batch 256 --pinned --reps 3 > /dev/null 2>&1
+for v in "" _edtx6 _edtx7 _edtx8; do
+  rm -rf /tmp/edtprof; DVO_LIB_VARIANT=$v timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/edtprof -o t -- python3 $GRAFT_REPO_ROOT/tools/bench_frames.py --batch 256 --pinned --reps 3 > /dev/null 2>&1
   echo "variant '$v'"; python3 - <<'PY'
 import csv,glob
 for f in glob.glob('/tmp/edtprof/**/*kernel_trace.csv', recursive=True):
