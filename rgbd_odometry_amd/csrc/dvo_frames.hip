@@ -777,28 +777,30 @@ edt_rows_pk_kernel(const unsigned short *__restrict__ g, int rows, int cols, uns
         int lim = __builtin_amdgcn_readfirstlane((nf < nl ? nf : nl) + EDT_PK_PAD);
         lim = lim < 255 ? lim : 255;
         int i = 1;
-        unsigned i2 = 1;
-        unsigned la = tq_lds + (unsigned)((cp - 4 * RP) * 4);   /* far end of a trip's left side: LDS offsets are unsigned */
+        /* i^2 and 2i+1 in both halves of a scalar register each: the next step's pair is two scalar additions away */
+        unsigned S = 0x00010001u, D = 0x00030003u;
+        unsigned la = tq_lds + (unsigned)((cp - 8 * RP) * 4);   /* far end of a trip's left side: LDS offsets are unsigned */
         unsigned ra = tq_lds + (unsigned)(cp * 4);
 #if defined(DVO_EDT_X) && DVO_EDT_X == 1
         lim = 0; best = edt_as_us2(0u);
 #endif
-        while (i + 3 <= lim) {
-            const unsigned s0 = i2, s1 = s0 + 2u * i + 1u, s2 = s1 + 2u * i + 3u, s3 = s2 + 2u * i + 5u;   /* i^2 .. (i+3)^2 */
-            const edt_us2 open = __builtin_elementwise_sub_sat(best, edt_as_us2(s0 | (s0 << 16)));
+        while (i + 7 <= lim) {                                  /* eight steps per trip, one exit test */
+            const edt_us2 open = __builtin_elementwise_sub_sat(best, edt_as_us2(S));
             if (__builtin_amdgcn_ballot_w64(edt_as_u32(open) != 0u) == 0ull) break;      /* i^2 >= best everywhere */
             asm volatile("" : "+v"(la), "+v"(ra));             /* keep the two addresses as they are: offsets go into the instructions */
             lds_cu *ql = (lds_cu *)(size_t)la, *qr = (lds_cu *)(size_t)ra;
-            const edt_us2 a0 = edt_as_us2(ql[3 * RP]), b0 = edt_as_us2(qr[1 * RP]), a1 = edt_as_us2(ql[2 * RP]), b1 = edt_as_us2(qr[2 * RP]);
-            const edt_us2 a2 = edt_as_us2(ql[1 * RP]), b2 = edt_as_us2(qr[3 * RP]), a3 = edt_as_us2(ql[0]), b3 = edt_as_us2(qr[4 * RP]);
-            const edt_us2 c0 = __builtin_elementwise_add_sat(__builtin_elementwise_min(a0, b0), edt_as_us2(s0 | (s0 << 16)));
-            const edt_us2 c1 = __builtin_elementwise_add_sat(__builtin_elementwise_min(a1, b1), edt_as_us2(s1 | (s1 << 16)));
-            const edt_us2 c2 = __builtin_elementwise_add_sat(__builtin_elementwise_min(a2, b2), edt_as_us2(s2 | (s2 << 16)));
-            const edt_us2 c3 = __builtin_elementwise_add_sat(__builtin_elementwise_min(a3, b3), edt_as_us2(s3 | (s3 << 16)));
-            best = __builtin_elementwise_min(best, __builtin_elementwise_min(__builtin_elementwise_min(c0, c1), __builtin_elementwise_min(c2, c3)));
-            la -= 4u * RP * 4u; ra += 4u * RP * 4u;
-            i += 4; i2 = s3 + 2u * i - 1u;                      /* (i+4)^2 = (i+3)^2 + 2(i+3)+1, with i already advanced */
+            edt_us2 acc = best;
+#pragma unroll
+            for (int j = 1; j <= 8; j++) {
+                const edt_us2 a = edt_as_us2(ql[(8 - j) * RP]), b = edt_as_us2(qr[j * RP]);
+                acc = __builtin_elementwise_min(acc, __builtin_elementwise_add_sat(__builtin_elementwise_min(a, b), edt_as_us2(S)));
+                S += D; D += 0x00020002u;
+            }
+            best = acc;
+            la -= 8u * RP * 4u; ra += 8u * RP * 4u;
+            i += 8;
         }
+        const unsigned i2 = S & 0xffffu;
         /* the exact finish of what is still open: rare (a pixel further than the pad from the border AND from every edge found
          * so far, or further than 255 pixels from every edge) */
         unsigned b0 = best.x, b1 = best.y;
