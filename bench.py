@@ -230,8 +230,20 @@ def frames_leg(args, iters):
         ctx.frames_as_now(B, 0, B)
         ctx.enqueue(iters, flags=DVO_FLAG_IDENTITY_START)
         return ctx.get_poses()
+
+    # the same now frames as DEVICE buffers (a decoder / camera driver that lands frames in HBM): everything the GPU does per
+    # now frame -- landing copy, pyramid, Canny, distance transform -> compact now level, alignment -- and no PCIe
+    dev_now = [torch.from_numpy(a).cuda() for a in now]
+    dev_ptrs = [dev_now[i % D].data_ptr() for i in range(B)]
+
+    def device_step():
+        ctx.frames_upload_cameras_device(dev_ptrs, None, args.height, args.width, n_levels=args.levels, first_shift=0,
+                                         first_slot=B, flags=DVO_UPLOAD_ASYNC, now_first_pair=0)
+        ctx.enqueue(iters, flags=DVO_FLAG_IDENTITY_START)
+        return ctx.get_poses()
     out = {}
     for name, fn, reps in (("frame_pairs_per_s", pair_step, 3), ("now_frames_per_s_reference_resident", now_step, 3),
+                           ("now_frames_per_s_camera_frames_in_hbm", device_step, 10),
                            ("now_frames_per_s_frames_resident", resident_step, 10)):
         fn()
         t0 = time.perf_counter()
@@ -241,7 +253,8 @@ def frames_leg(args, iters):
     out["now_level_texel_modes"] = [ctx.level_texel_mode(0, l) for l in range(args.levels)]
     out["note"] = ("never `value`.  frame_pairs / now_frames_per_s_reference_resident are PCIe-inclusive: %dx%d BGR8 (+ depth f32 for "
                    "reference frames) in pinned host memory -> pyramid, Canny, distance transform -> compact now level, edge points on "
-                   "the GPU -> %s iterations -> poses on the host.  now_frames_per_s_frames_resident: the now frames already in the "
+                   "the GPU -> %s iterations -> poses on the host.  now_frames_per_s_camera_frames_in_hbm: the same with the BGR8 frames "
+                   "already in device memory (DVO_UPLOAD_DEVICE): all the GPU work of a now frame, no PCIe.  now_frames_per_s_frames_resident: the now frames already in the "
                    "frame store (pyramid + Canny done): distance transform -> compact now level + alignment per step.  Batches of %d; "
                    "now_level_texel_modes 2 = the alignment read the natively produced compact form" % (args.width, args.height, iters, B))
     ctx.close()

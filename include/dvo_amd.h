@@ -361,6 +361,9 @@ enum { DVO_UPLOAD_ASYNC = 1,        /* do not wait for the copies: with DVO_UPLO
                                        driver; when the application later frees them (free -> munmap of a large block), the driver stalls
                                        the process's GPU queues for 14-33 ms -- measured on the C++ file replay, whose loader allocates
                                        and frees a pyramid per frame: 24 ms per frame instead of 0.6 (profiles/r03_single_stream) */
+enum { DVO_UPLOAD_DEVICE = 8 };     /* dvo_frames_upload_cameras: the image pointers are DEVICE pointers of this context's GPU (a decoder or
+                                       a camera driver that lands frames in HBM): device-to-device copies into the landing buffer, no PCIe.
+                                       The buffers stay borrowed until the call returns (until dvo_synchronize() with DVO_UPLOAD_ASYNC) */
 
 typedef struct dvo_image {          /* one single-channel host image */
     const void *data;

@@ -42,6 +42,7 @@ DVO_LAYOUT_COL_MAJOR, DVO_LAYOUT_ROW_MAJOR = 0, 1
 DVO_UPLOAD_ASYNC = 1
 DVO_UPLOAD_DEPTH_RAW = 2
 DVO_UPLOAD_DIRECT = 4
+DVO_UPLOAD_DEVICE = 8
 
 
 class DvoImage(C.Structure):
@@ -507,6 +508,18 @@ class DvoContext:
             self._note_dims(first_slot)
         if flags & DVO_UPLOAD_ASYNC:
             self._frame_keep.append((bl, dl))
+
+    def frames_upload_cameras_device(self, bgr_ptrs, depth_ptrs, rows: int, cols: int, n_levels: int = 4, first_shift: int = 1,
+                                     first_slot: int = 0, flags: int = 0, now_first_pair: int = -1):
+        """camera frames that already sit in this GPU's memory (DVO_UPLOAD_DEVICE): lists of device addresses (ints) of
+        (rows, cols, 3) uint8 BGR images and, or None, (rows, cols) float32 depth images"""
+        count = len(bgr_ptrs)
+        B = (C.c_void_p * count)(*[int(p) for p in bgr_ptrs])
+        Dp = (C.c_void_p * count)(*[int(p) for p in depth_ptrs]) if depth_ptrs is not None else None
+        self._chk(self.lib.dvo_frames_upload_cameras(self._h, first_slot, count, B, Dp, rows, cols, n_levels, first_shift,
+                                                     now_first_pair, flags | DVO_UPLOAD_DEVICE))
+        if now_first_pair >= 0:
+            self._note_dims(first_slot)
 
     def frames_as_now(self, first_slot: int = 0, first_pair: int = 0, count: int = 1):
         self._chk(self.lib.dvo_frames_as_now(self._h, first_slot, first_pair, count))

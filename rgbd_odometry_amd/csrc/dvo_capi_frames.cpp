@@ -166,8 +166,10 @@ int run_canny(dvo_ctx *c, int level, int first_slot, int count, hipStream_t stre
 constexpr size_t kUploadHalf = (size_t)32 << 20;   /* landing buffer per pipeline stage */
 constexpr size_t kSmallImage = (size_t)256 << 10;  /* images up to this size are gathered on the host before they go up */
 
-/* landing buffers of at least `bytes` each + copy stream + events */
-int ensure_upload(dvo_ctx *c, size_t bytes) {
+constexpr size_t kDeviceHalf = (size_t)512 << 20;  /* landing buffer per stage when the sources are device buffers: whole batches */
+
+/* landing buffers of at least `bytes` each (+ their pinned mirrors when the sources are host buffers) + copy streams + events */
+int ensure_upload(dvo_ctx *c, size_t bytes, bool with_host = true) {
     if (!c->copy_stream) {
         HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking));
@@ -177,19 +179,26 @@ int ensure_upload(dvo_ctx *c, size_t bytes) {
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_done[b], hipEventDisableTiming));
         }
     }
-    if (bytes <= c->up_bytes) return DVO_OK;
+    const bool grow_dev = bytes > c->up_bytes, grow_host = with_host && bytes > c->up_host_bytes;
+    if (!grow_dev && !grow_host) return DVO_OK;
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     HIPCHK(c, hipStreamSynchronize(c->copy_stream2));
     HIPCHK(c, stream_wait(c->stream));
     for (int b = 0; b < 2; b++) {
-        if (c->up_buf[b]) HIPCHK(c, hipFree(c->up_buf[b]));
-        if (c->up_host[b]) HIPCHK(c, hipHostFree(c->up_host[b]));
-        c->up_buf[b] = nullptr; c->up_host[b] = nullptr;
-        HIPCHK(c, hipMalloc((void **)&c->up_buf[b], bytes));
-        HIPCHK(c, hipHostMalloc((void **)&c->up_host[b], bytes, hipHostMallocDefault));
+        if (grow_dev) {
+            if (c->up_buf[b]) HIPCHK(c, hipFree(c->up_buf[b]));
+            c->up_buf[b] = nullptr;
+            HIPCHK(c, hipMalloc((void **)&c->up_buf[b], bytes));
+        }
+        if (grow_host) {
+            if (c->up_host[b]) HIPCHK(c, hipHostFree(c->up_host[b]));
+            c->up_host[b] = nullptr;
+            HIPCHK(c, hipHostMalloc((void **)&c->up_host[b], bytes, hipHostMallocDefault));
+        }
         c->up_used[b] = false;
     }
-    c->up_bytes = bytes;
+    if (grow_dev) c->up_bytes = bytes;
+    if (grow_host) c->up_host_bytes = bytes;
     return DVO_OK;
 }
 /* stage A of a chunk: returns the landing buffer; copies must go to c->copy_stream */
@@ -420,14 +429,18 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
         return fail(c, DVO_ERR_INVALID, "the undistortion map was built for another image size (dvo_frames_set_undistort)");
     const size_t npx = (size_t)rows * cols;
     const size_t b_img = (npx * 3 + 15) / 16 * 16, d_img = depth_m ? npx * 4 : 0;
-    const int chunk = (int)std::min<size_t>(std::max<size_t>(kUploadHalf / (b_img + d_img), 1), (size_t)count);
-    if ((rc = ensure_upload(c, (b_img + d_img) * chunk))) return rc;
+    const bool dev_src = (flags & DVO_UPLOAD_DEVICE) != 0;     /* no PCIe to overlap with: whole batches per stage */
+    const int chunk = (int)std::min<size_t>(std::max<size_t>((dev_src ? kDeviceHalf : kUploadHalf) / (b_img + d_img), 1), (size_t)count);
+    if ((rc = ensure_upload(c, (b_img + d_img) * chunk, !dev_src))) return rc;
     for (int b = 0; b < count; b += chunk) {            /* copy chunk k+1 (copy stream) while chunk k is preprocessed */
         const int nc = std::min(chunk, count - b);
         unsigned char *sb; int ub;
         if ((rc = upload_begin(c, &sb, &ub))) return rc;
         float *sd = (float *)(sb + b_img * chunk);
-        if (flags & DVO_UPLOAD_DIRECT) {
+        if (flags & DVO_UPLOAD_DEVICE) {                     /* the images are in HBM already: gathered into the landing buffer */
+            HIPCHK(c, launch_gather_images(reinterpret_cast<const void *const *>(bgr8 + b), nc, sb, npx * 3, b_img, c->copy_stream));
+            if (depth_m) HIPCHK(c, launch_gather_images(reinterpret_cast<const void *const *>(depth_m + b), nc, sd, npx * 4, npx * 4, c->copy_stream2));
+        } else if (flags & DVO_UPLOAD_DIRECT) {
             for (int i = 0; i < nc; i++) {
                 hipStream_t cs = (i & 1) ? c->copy_stream2 : c->copy_stream;
                 HIPCHK(c, hipMemcpyAsync(sb + b_img * i, bgr8[b + i], npx * 3, hipMemcpyHostToDevice, cs));

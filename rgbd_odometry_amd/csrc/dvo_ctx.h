@@ -135,7 +135,7 @@ struct dvo_ctx {
     /* frame uploads: two landing buffers filled by a copy stream while the context stream preprocesses the other */
     unsigned char *up_buf[2] = {nullptr, nullptr};
     unsigned char *up_host[2] = {nullptr, nullptr};      /* pinned mirrors: small images are gathered here and go up in one copy */
-    size_t up_bytes = 0;
+    size_t up_bytes = 0, up_host_bytes = 0;              /* landing buffers / their pinned mirrors (no mirror for device sources) */
     hipStream_t copy_stream = nullptr, copy_stream2 = nullptr;      /* two SDMA queues: frames alternate between them */
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_copied2[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     bool up_used[2] = {false, false};

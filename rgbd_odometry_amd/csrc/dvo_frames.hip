@@ -215,6 +215,33 @@ camera_level_kernel(const unsigned char *__restrict__ bgr, size_t bgr_stride,
     }
 }
 
+/* DVO_UPLOAD_DEVICE: camera images that already sit in HBM, one pointer each -> the landing buffer (image i at dst + i*stride).
+ * One launch per 32 images (the pointers travel as a kernel argument) instead of one copy call per image. */
+struct GatherPack { const void *src[32]; };
+__global__ void __launch_bounds__(256)
+gather_images_kernel(GatherPack pk, unsigned char *__restrict__ dst, size_t bytes, size_t stride) {
+    const unsigned char *src = static_cast<const unsigned char *>(pk.src[blockIdx.y]);
+    unsigned char *d = dst + (size_t)blockIdx.y * stride;
+    const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+    if (((reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(d)) & 15) == 0) {
+        const size_t n16 = bytes / 16;
+        for (size_t i = t0; i < n16; i += nt) reinterpret_cast<uint4 *>(d)[i] = reinterpret_cast<const uint4 *>(src)[i];
+        for (size_t i = n16 * 16 + t0; i < bytes; i += nt) d[i] = src[i];
+    } else {
+        for (size_t i = t0; i < bytes; i += nt) d[i] = src[i];
+    }
+}
+hipError_t launch_gather_images(const void *const *src, int count, void *dst, size_t bytes, size_t stride, hipStream_t s) {
+    for (int b = 0; b < count; b += 32) {
+        GatherPack pk;
+        const int nc = count - b < 32 ? count - b : 32;
+        for (int i = 0; i < 32; i++) pk.src[i] = src[b + (i < nc ? i : 0)];
+        const unsigned gx = (unsigned)((bytes / 16 + 255) / 256 < 1 ? 1 : ((bytes / 16 + 255) / 256 > 64 ? 64 : (bytes / 16 + 255) / 256));
+        hipLaunchKernelGGL(gather_images_kernel, dim3(gx, nc), dim3(256), 0, s, pk, static_cast<unsigned char *>(dst) + (size_t)b * stride, bytes, stride);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_camera_level(const unsigned char *bgr, size_t bgr_stride, const float *depth_m, size_t depth_stride,
                                int src_rows, int src_cols, int shift, const short2 *umap_xy, const unsigned short *umap_frac,
                                int depth_raw, unsigned char *grey, float *depth_mm, size_t stride, ImgBatch g, hipStream_t s) {
@@ -255,61 +282,74 @@ DVO_DEV void uf_union(int *L, int a, int b) {
 
 /* Canny front end, one 64 x 32 pixel tile per workgroup, everything between the grey load and the candidate
  * map in LDS: 3x3 Sobel (BORDER_REPLICATE) -> squared magnitude -> sector non-maximum suppression ->
- * union-find of the tile's candidates.  Out: cand (0 suppressed, 1 candidate, 2 candidate above `high`), and for
- * candidates label = global index of the tile-local root, flag = 0.  Pairs of candidates in different tiles
- * are joined by canny_border_kernel. */
+ * union-find of the tile's candidates -> hysteresis INSIDE the tile.  Out, per pixel, cand:
+ *     0                 suppressed
+ *     CAND_WEAK (1)     candidate whose tile-local component holds no pixel above `high`: an edge only if a neighbouring
+ *                       tile's part of the component does (border / flag / final kernels decide)
+ *     CAND_SURE (2)     candidate of a component that holds a pixel above `high` in this tile: an edge, nothing to look up
+ *     | CAND_ROOT (16)  the pixel is the root of its tile-local component
+ * and for candidates label = global index of the tile-local root; flag = 0 at the roots.  Pairs of candidates in different
+ * tiles are joined by canny_border_kernel.
+ * Threads walk the tile as (row = tid & 63, column = tid >> 6 + 4k): no divisions; the gradient of a pixel is recomputed from
+ * the grey tile for the few pixels above `low` instead of being parked in LDS for all of them (22 KB of LDS per workgroup). */
 constexpr int CT_Y = 64, CT_X = 32;
+enum { CAND_WEAK = 1, CAND_SURE = 2, CAND_KIND = 3, CAND_ROOT = 16 };
 __global__ void __launch_bounds__(256)
 canny_tile_kernel(const unsigned char *__restrict__ grey, size_t stride, int rows, int cols, int tiles_y, int low, int high,
                   unsigned char *__restrict__ cand, unsigned char *__restrict__ flag, int *__restrict__ label) {
     constexpr int GH = CT_Y + 4, GW = CT_X + 4, MH = CT_Y + 2, MW = CT_X + 2, NT = CT_Y * CT_X;
+    static_assert(CT_Y == 64 && 4 * GW <= 256 && 2 * MW <= 256, "thread mapping: 64 rows per step, the extra halo rows in one more");
     __shared__ unsigned char sg[GW * GH];         /* grey, halo 2, [x][y] */
     __shared__ int smag[MW * MH];                 /* squared magnitude, halo 1 (0 outside the image) */
-    __shared__ short2 sdxy[MW * MH];
     __shared__ int slab[NT];
-    __shared__ unsigned char scand[NT];
+    __shared__ unsigned scand32[NT / 4];          /* one byte per pixel: 0 / 1 candidate / 2 candidate above `high`; bit 2 at a root: strong */
+    unsigned char *scand = reinterpret_cast<unsigned char *>(scand32);
     const size_t n = (size_t)rows * cols;
     grey += (size_t)blockIdx.y * stride;
     cand += (size_t)blockIdx.y * n; flag += (size_t)blockIdx.y * n; label += (size_t)blockIdx.y * n;
     const int ty = blockIdx.x % tiles_y, tx = blockIdx.x / tiles_y;
     const int y0 = ty * CT_Y, x0 = tx * CT_X;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, ry = tid & 63, cx = tid >> 6;
 
-    for (int idx = tid; idx < GW * GH; idx += 256) {
-        const int lx = idx / GH, ly = idx - lx * GH;
+    auto load_grey = [&](int lx, int ly) {
         int gy = y0 + ly - 2, gx = x0 + lx - 2;
         gy = gy < 0 ? 0 : (gy > rows - 1 ? rows - 1 : gy);                      /* BORDER_REPLICATE */
         gx = gx < 0 ? 0 : (gx > cols - 1 ? cols - 1 : gx);
-        sg[idx] = grey[(size_t)gx * rows + gy];
-    }
+        sg[lx * GH + ly] = grey[(unsigned)(gx * rows + gy)];
+    };
+#pragma unroll
+    for (int k = 0; k < GW / 4; k++) load_grey(cx + 4 * k, ry);
+    if (tid < 4 * GW) load_grey(tid >> 2, 64 + (tid & 3));                      /* rows 64..67 of the halo'd tile */
     __syncthreads();
-    for (int idx = tid; idx < MW * MH; idx += 256) {
-        const int lx = idx / MH, ly = idx - lx * MH;
+    auto sobel = [&](int lx, int ly, int &dx, int &dy) {                        /* (lx, ly) in smag coordinates (halo 1) */
+        const unsigned char *c = sg + (lx + 1) * GH + (ly + 1);                 /* the pixel itself */
+        const int a = c[-GH - 1], b = c[-1], cc = c[GH - 1];                    /* row above: x-1, x, x+1 */
+        const int d = c[-GH], f = c[GH];
+        const int g = c[-GH + 1], h = c[1], i = c[GH + 1];
+        dx = (cc - a) + 2 * (f - d) + (i - g);
+        dy = (g - a) + 2 * (h - b) + (i - cc);
+    };
+    auto magnitude = [&](int lx, int ly) {
         const int py = y0 + ly - 1, px = x0 + lx - 1;
-        int m = 0, dx = 0, dy = 0;
-        if (py >= 0 && py < rows && px >= 0 && px < cols) {
-            const unsigned char *c = sg + (lx + 1) * GH + (ly + 1);             /* the pixel itself */
-            const int a = c[-GH - 1], b = c[-1], cc = c[GH - 1];                /* row above: x-1, x, x+1 */
-            const int d = c[-GH], f = c[GH];
-            const int g = c[-GH + 1], h = c[1], i = c[GH + 1];
-            dx = (cc - a) + 2 * (f - d) + (i - g);
-            dy = (g - a) + 2 * (h - b) + (i - cc);
-            m = dx * dx + dy * dy;
-        }
-        smag[idx] = m;
-        sdxy[idx] = make_short2((short)dx, (short)dy);
-    }
+        int m = 0;
+        if (py >= 0 && py < rows && px >= 0 && px < cols) { int dx, dy; sobel(lx, ly, dx, dy); m = dx * dx + dy * dy; }
+        smag[lx * MH + ly] = m;
+    };
+#pragma unroll
+    for (int k = 0; k < (MW + 3) / 4; k++) if (cx + 4 * k < MW) magnitude(cx + 4 * k, ry);
+    if (tid < 2 * MW) magnitude(tid >> 1, 64 + (tid & 1));                      /* rows 64, 65 */
     __syncthreads();
     constexpr int SHIFT = 15;
     constexpr int TG22 = 13573;                                   /* round(tan(22.5 deg) * 2^15) */
-    for (int idx = tid; idx < NT; idx += 256) {
-        const int lx = idx / CT_Y, ly = idx - lx * CT_Y;
+#pragma unroll
+    for (int k = 0; k < CT_X / 4; k++) {
+        const int lx = cx + 4 * k, ly = ry, idx = lx * CT_Y + ly;
         const int mi = (lx + 1) * MH + (ly + 1);
         const int m = smag[mi];
         bool keep = false;
         if (m > low && y0 + ly < rows && x0 + lx < cols) {
-            const short2 d = sdxy[mi];
-            const int xs = d.x, ys = d.y;
+            int xs, ys;
+            sobel(lx + 1, ly + 1, xs, ys);
             const int ax = xs < 0 ? -xs : xs, ay = (ys < 0 ? -ys : ys) << SHIFT;
             const int tg22x = ax * TG22;
             int o1, o2;                                           /* the two neighbours of the sector (offsets in smag) */
@@ -324,9 +364,10 @@ canny_tile_kernel(const unsigned char *__restrict__ grey, size_t stride, int row
         slab[idx] = keep ? idx : -1;
     }
     __syncthreads();
-    for (int idx = tid; idx < NT; idx += 256) {                   /* join with the candidate neighbours of smaller index */
+#pragma unroll
+    for (int k = 0; k < CT_X / 4; k++) {                          /* join with the candidate neighbours of smaller index */
+        const int lx = cx + 4 * k, ly = ry, idx = lx * CT_Y + ly;
         if (!scand[idx]) continue;
-        const int lx = idx / CT_Y, ly = idx - lx * CT_Y;
         if (ly > 0 && scand[idx - 1]) uf_union(slab, idx, idx - 1);
         if (lx > 0) {
             const int q = idx - CT_Y;
@@ -336,19 +377,27 @@ canny_tile_kernel(const unsigned char *__restrict__ grey, size_t stride, int row
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < NT; idx += 256) {
-        const int lx = idx / CT_Y, ly = idx - lx * CT_Y;
+#pragma unroll
+    for (int k = 0; k < CT_X / 4; k++) {                          /* a pixel above `high` makes its component's root strong */
+        const int idx = (cx + 4 * k) * CT_Y + ry;
+        if ((scand[idx] & 3) == 2) { const int r = uf_find(slab, idx); atomicOr(&scand32[r >> 2], 4u << (8 * (r & 3))); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CT_X / 4; k++) {
+        const int lx = cx + 4 * k, ly = ry, idx = lx * CT_Y + ly;
         const int py = y0 + ly, px = x0 + lx;
         if (py >= rows || px >= cols) continue;
-        const size_t p = (size_t)px * rows + py;
-        const unsigned char c = scand[idx];
-        cand[p] = c;
-        if (c) {
+        const unsigned p = (unsigned)(px * rows + py);
+        unsigned char c = 0;
+        if (scand[idx] & 3) {
             const int r = uf_find(slab, idx);
-            const int rx = r / CT_Y, ry = r - rx * CT_Y;
-            label[p] = (x0 + rx) * rows + (y0 + ry);
-            flag[p] = 0;
+            const int rx = r >> 6, rr = r & 63;
+            c = (unsigned char)(((scand[r] & 4) ? CAND_SURE : CAND_WEAK) | (r == idx ? CAND_ROOT : 0));
+            label[p] = (x0 + rx) * rows + (y0 + rr);
+            if (r == idx) flag[p] = 0;
         }
+        cand[p] = c;
     }
 }
 
@@ -384,10 +433,10 @@ canny_flag_kernel(const unsigned char *__restrict__ cand, size_t n, int *__restr
     cand += (size_t)blockIdx.y * n; label += (size_t)blockIdx.y * n; flag += (size_t)blockIdx.y * n;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
         const unsigned char c = cand[p];
-        if (!c) continue;
+        if (!(c & CAND_ROOT)) continue;     /* tile-local roots speak for their components */
         const int r = uf_find(label, (int)p);
         label[p] = r;                       /* racing writers only ever store ancestors: find() stays correct */
-        if (c == 2) flag[r] = 1;
+        if ((c & CAND_KIND) == CAND_SURE) flag[r] = 1;
     }
 }
 
@@ -397,9 +446,45 @@ canny_final_kernel(const unsigned char *__restrict__ cand, const int *__restrict
     cand += (size_t)blockIdx.y * n; label += (size_t)blockIdx.y * n; flag += (size_t)blockIdx.y * n;
     edge += (size_t)blockIdx.y * edge_stride;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
-        bool e = false;
-        if (cand[p]) e = flag[uf_find(label, (int)p)] != 0;
+        const unsigned char c = cand[p];
+        bool e = (c & CAND_KIND) == CAND_SURE;
+        if ((c & CAND_KIND) == CAND_WEAK) e = flag[uf_find(label, (int)p)] != 0;
         edge[p] = e ? 255 : 0;
+    }
+}
+
+/* the same two passes, four pixels per thread: candidates are a few percent of the pixels, so most threads see one zero word
+ * (images whose pixel count is a multiple of four -- every camera format) */
+__global__ void __launch_bounds__(256)
+canny_flag4_kernel(const unsigned char *__restrict__ cand, size_t n, int *__restrict__ label, unsigned char *__restrict__ flag) {
+    cand += (size_t)blockIdx.y * n; label += (size_t)blockIdx.y * n; flag += (size_t)blockIdx.y * n;
+    const unsigned *cand4 = reinterpret_cast<const unsigned *>(cand);
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n / 4; q += (size_t)gridDim.x * blockDim.x) {
+        unsigned w = cand4[q];
+        for (int k = 0; w; k++, w >>= 8) {
+            const unsigned c = w & 0xffu;
+            if (!(c & CAND_ROOT)) continue; /* tile-local roots speak for their components */
+            const int p = (int)(4 * q) + k;
+            const int r = uf_find(label, p);
+            label[p] = r;                   /* racing writers only ever store ancestors: find() stays correct */
+            if ((c & CAND_KIND) == CAND_SURE) flag[r] = 1;
+        }
+    }
+}
+__global__ void __launch_bounds__(256)
+canny_final4_kernel(const unsigned char *__restrict__ cand, const int *__restrict__ label, const unsigned char *__restrict__ flag,
+                    size_t n, unsigned char *__restrict__ edge, size_t edge_stride) {
+    cand += (size_t)blockIdx.y * n; label += (size_t)blockIdx.y * n; flag += (size_t)blockIdx.y * n;
+    edge += (size_t)blockIdx.y * edge_stride;
+    const unsigned *cand4 = reinterpret_cast<const unsigned *>(cand);
+    unsigned *edge4 = reinterpret_cast<unsigned *>(edge);
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n / 4; q += (size_t)gridDim.x * blockDim.x) {
+        unsigned w = cand4[q], out = 0u;
+        for (int k = 0; w; k++, w >>= 8) {
+            const unsigned kind = w & CAND_KIND;
+            if (kind == CAND_SURE || (kind == CAND_WEAK && flag[uf_find(label, (int)(4 * q) + k)] != 0)) out |= 0xffu << (8 * k);
+        }
+        edge4[q] = out;
     }
 }
 
@@ -430,8 +515,14 @@ hipError_t launch_canny(const unsigned char *grey, size_t stride, ImgBatch g, in
     const int n_border = ((g.rows - 1) / CT_Y) * g.cols + ((g.cols - 1) / CT_X) * g.rows;
     if (n_border > 0)
         hipLaunchKernelGGL(canny_border_kernel, dim3(grid_x((size_t)n_border), g.count), blk, 0, s, cand, g.rows, g.cols, label);
-    hipLaunchKernelGGL(canny_flag_kernel, grid, blk, 0, s, cand, n, label, flag);
-    hipLaunchKernelGGL(canny_final_kernel, grid, blk, 0, s, cand, label, flag, n, edge, edge_stride);
+    if ((n & 3) == 0 && (edge_stride & 3) == 0 && (reinterpret_cast<size_t>(edge) & 3) == 0) {
+        const dim3 grid4(grid_x(n / 4), g.count);
+        hipLaunchKernelGGL(canny_flag4_kernel, grid4, blk, 0, s, cand, n, label, flag);
+        hipLaunchKernelGGL(canny_final4_kernel, grid4, blk, 0, s, cand, label, flag, n, edge, edge_stride);
+    } else {
+        hipLaunchKernelGGL(canny_flag_kernel, grid, blk, 0, s, cand, n, label, flag);
+        hipLaunchKernelGGL(canny_final_kernel, grid, blk, 0, s, cand, label, flag, n, edge, edge_stride);
+    }
     return hipGetLastError();
 }
 

@@ -309,3 +309,71 @@ def test_frame_api_errors():
         ctx.frames_as_now(0, 0, 1)                                       # an edge-free now frame is all zeros
         dt, gx, gy = ctx.get_now_level(0)
         assert not dt.any() and not gx.any() and not gy.any()
+
+
+def _sparse_edge_maps():
+    rng = np.random.default_rng(77)
+    def blank(r, c): return np.zeros((r, c), np.uint8)
+    e = blank(480, 640); e[5, 7] = 255                                   # one edge pixel: distances to 800, squared beyond 2^18
+    yield "single_pixel_corner", e
+    e = blank(480, 640); e[200:203, 300:340] = 255                       # one short stroke: every scan is long, < 512 everywhere
+    yield "one_stroke_centre", e
+    e = blank(300, 700); e[:, 0] = 255                                   # left border column only: pure horizontal distances up to 699
+    yield "left_border_line", e
+    e = blank(301, 397); e[150, :] = 255                                 # odd sizes (byte-wise column pass, odd last row pair), pure vertical
+    yield "odd_sizes_middle_row", e
+    e = blank(481, 637); e[rng.integers(0, 481, 40), rng.integers(0, 637, 40)] = 255
+    yield "odd_sizes_40_points", e                                       # distances of a few dozen to ~150 pixels: pad and 8-bit limits
+    e = blank(480, 640); e[rng.integers(0, 480, 6), rng.integers(0, 640, 6)] = 200
+    yield "six_points_non_255", e                                        # any non-zero byte is an edge; squared distances past 65535
+    e = (rng.random((480, 640)) < 0.3).astype(np.uint8) * 255
+    yield "dense_random", e
+    e = blank(1030, 40); e[515, 20] = 255                                 # three 512-row chunks in the column pass
+    yield "tall_three_chunks", e
+
+
+@pytest.mark.parametrize("name,edge", list(_sparse_edge_maps()))
+def test_distance_transform_of_sparse_and_odd_edge_maps(oracle, name, edge):
+    """the exact distance transform behind dvo_set_now_level_from_edges (eight rows per lane in the column pass; packed 16-bit
+    row scan with its exact 32-bit finish for pixels further than the tile's pad or than 255 pixels from every edge): DT, gx, gy
+    bit-equal to the oracle whichever form the level ends up in"""
+    rows, cols = edge.shape
+    want = oracle.now_level_from_edges(_cm(edge), rows, cols)
+    with _ctx() as ctx:
+        ctx.set_intrinsics(500.0, 500.0, cols / 2, rows / 2)
+        ctx.set_now_level_from_edges(0, _cm(edge), rows, cols)
+        got = ctx.get_now_level(0)
+        for g, w, what in zip(got, want, ("DT", "gx", "gy")):
+            assert np.array_equal(g, w), f"{name}: {what} differs in {int((g != w).sum())} pixels"
+
+
+def test_distance_transform_refuses_a_mask_without_edges():
+    from rgbd_odometry_amd import DvoError
+    with _ctx() as ctx:
+        ctx.set_intrinsics(500.0, 500.0, 160.0, 120.0)
+        with pytest.raises(DvoError):
+            ctx.set_now_level_from_edges(0, np.zeros(240 * 320, np.uint8), 240, 320)
+
+
+def test_camera_frames_in_device_memory_equal_host_uploads(oracle):
+    """DVO_UPLOAD_DEVICE: BGR8 + depth images that already sit in HBM (torch tensors here) go through the same pyramid / Canny /
+    distance transform as host uploads; as_now fused into the upload (now_first_pair) as well"""
+    import torch
+    frames = [frame_gen.camera_frame(300 + i, 240, 320) for i in range(3)]
+    with _ctx(3) as a, _ctx(3) as b:
+        for c in (a, b):
+            c.set_intrinsics(262.5, 262.5, 159.75, 119.75)
+            c.frames_reserve(3)
+        a.frames_upload_cameras([f[0] for f in frames], [f[1] for f in frames], n_levels=3, first_shift=0, now_first_pair=0)
+        tb = [torch.from_numpy(np.ascontiguousarray(f[0])).cuda() for f in frames]
+        td = [torch.from_numpy(np.ascontiguousarray(f[1], dtype=np.float32)).cuda() for f in frames]
+        b.frames_upload_cameras_device([t.data_ptr() for t in tb], [t.data_ptr() for t in td], 240, 320, n_levels=3, first_shift=0,
+                                       now_first_pair=0)
+        for slot in range(3):
+            for l in range(3):
+                for x, y in zip(a.frame_level(slot, l)[:3], b.frame_level(slot, l)[:3]):
+                    assert np.array_equal(x, y)
+        for l in range(3):
+            for p in range(3):
+                for x, y in zip(a.get_now_level(l, pair=p), b.get_now_level(l, pair=p)):
+                    assert np.array_equal(x, y)

@@ -108,6 +108,20 @@ def main():
     for ch in (64,):
         timed("now frame in -> pose out, chunks of %d" % ch, lambda ch=ch: tracking_step_chunked(ch), B)
 
+    # the same camera frames as device buffers (DVO_UPLOAD_DEVICE): no PCIe
+    import torch as _torch
+    dev_now = [_torch.from_numpy(np.ascontiguousarray(now_b[i])).cuda() for i in range(D)]
+    dev_ptrs = [dev_now[i % D].data_ptr() for i in range(B)]
+    dkw = dict(n_levels=args.levels, first_shift=args.first_shift, first_slot=B, flags=DVO_UPLOAD_ASYNC)
+    timed("now frames in HBM: gather, pyramid, Canny", lambda: ctx.frames_upload_cameras_device(dev_ptrs, None, args.height, args.width, **dkw), B)
+    timed("now frames in HBM: gather, pyramid, Canny, EDT -> compact form", lambda: ctx.frames_upload_cameras_device(dev_ptrs, None, args.height, args.width, now_first_pair=0, **dkw), B)
+
+    def tracking_step_device():
+        ctx.frames_upload_cameras_device(dev_ptrs, None, args.height, args.width, now_first_pair=0, **dkw)
+        ctx.enqueue(iters, flags=DVO_FLAG_IDENTITY_START)
+        return ctx.get_poses()
+    timed("now frame in HBM -> pose out", tracking_step_device, B)
+
     def pair_step():                                  # both frames of every pair from the host
         ctx.frames_upload_cameras(ref_b, ref_d, first_slot=0, **kw)
         ctx.frames_upload_cameras(now_b, None, first_slot=B, **kw)
