@@ -361,19 +361,28 @@ canny_tile_kernel(const unsigned char *__restrict__ grey, size_t stride, int row
             keep = (m > m1) && (ge2 ? (m >= m2) : (m > m2));
         }
         scand[idx] = keep ? (m > high ? 2 : 1) : 0;
-        slab[idx] = keep ? idx : -1;
+        /* a wave holds the 64 rows of one tile column: the vertical runs of candidates are read off the ballot, and a pixel
+         * starts out labelled with the top pixel of its run -- no union inside a column ever happens */
+        const unsigned long long col = __builtin_amdgcn_ballot_w64(keep);
+        const unsigned long long gaps_above = ~col & ((1ull << ly) - 1ull);
+        const int top = gaps_above ? 64 - __clzll((long long)gaps_above) : 0;
+        slab[idx] = keep ? lx * CT_Y + top : -1;
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < CT_X / 4; k++) {                          /* join with the candidate neighbours of smaller index */
+    for (int k = 0; k < CT_X / 4; k++) {                          /* join the runs of this column with those of the column to the left */
         const int lx = cx + 4 * k, ly = ry, idx = lx * CT_Y + ly;
-        if (!scand[idx]) continue;
-        if (ly > 0 && scand[idx - 1]) uf_union(slab, idx, idx - 1);
-        if (lx > 0) {
-            const int q = idx - CT_Y;
-            if (scand[q]) uf_union(slab, idx, q);
-            if (ly > 0 && scand[q - 1]) uf_union(slab, idx, q - 1);
-            if (ly < CT_Y - 1 && scand[q + 1]) uf_union(slab, idx, q + 1);
+        if (!scand[idx] || lx == 0) continue;
+        /* 8-connectivity: (lx-1, ly-1 .. ly+1).  One union per pair of touching runs is enough, so a pixel leaves the union to
+         * its upper (lower) neighbour in the run whenever that one sees the same left run */
+        const int q = idx - CT_Y;
+        const bool up = ly > 0 && scand[idx - 1], down = ly < CT_Y - 1 && scand[idx + 1];
+        const bool cq = scand[q], cqm = ly > 0 && scand[q - 1], cqp = ly < CT_Y - 1 && scand[q + 1];
+        if (cq) {
+            if (!(up && cqm)) uf_union(slab, idx, q);             /* q-1, q, q+1 are one run */
+        } else {
+            if (cqm && !up) uf_union(slab, idx, q - 1);           /* `up` has q-1 straight to its left */
+            if (cqp && !down) uf_union(slab, idx, q + 1);         /* `down` has q+1 straight to its left */
         }
     }
     __syncthreads();
