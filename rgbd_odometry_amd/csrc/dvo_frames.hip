@@ -268,10 +268,23 @@ DVO_DEV int uf_find(const int *L, int a) {
     while ((p = uf_load(L, a)) != a) a = p;
     return a;
 }
+/* find with path halving for the tile-local (LDS) forest: every node passed on the way is re-hung below its grandparent, so
+ * the chains that column-by-column unions leave behind (as long as the tile is wide) are walked at full length once, not by
+ * every later find.  atomicMin keeps the invariant that labels only decrease, whatever races with it. */
+DVO_DEV int uf_find_halving(int *L, int a) {
+    int p = uf_load(L, a);
+    while (p != a) {
+        const int gp = uf_load(L, p);
+        if (gp != p) atomicMin(L + a, gp);
+        a = p; p = gp;
+    }
+    return a;
+}
+template <bool HALVE = false>
 DVO_DEV void uf_union(int *L, int a, int b) {
     for (;;) {
-        a = uf_find(L, a);
-        b = uf_find(L, b);
+        a = HALVE ? uf_find_halving(L, a) : uf_find(L, a);
+        b = HALVE ? uf_find_halving(L, b) : uf_find(L, b);
         if (a == b) return;
         if (a < b) { const int t = a; a = b; b = t; }            /* a is the larger root: hang it below b */
         const int old = atomicMin(L + a, b);
@@ -369,27 +382,41 @@ canny_tile_kernel(const unsigned char *__restrict__ grey, size_t stride, int row
         slab[idx] = keep ? lx * CT_Y + top : -1;
     }
     __syncthreads();
+    /* join the runs of a column with those of the column to its left.  8-connectivity: (lx-1, ly-1 .. ly+1).  One union per pair
+     * of touching runs is enough, so a pixel leaves the union to its upper (lower) neighbour in the run whenever that one sees the
+     * same left run.  The unions a thread owes are first collected in a bit mask and then worked off in ONE loop: a wave pays
+     * the latency of a union as often as its busiest lane has one, not once per (column, case) slot */
+    unsigned todo = 0u;
 #pragma unroll
-    for (int k = 0; k < CT_X / 4; k++) {                          /* join the runs of this column with those of the column to the left */
+    for (int k = 0; k < CT_X / 4; k++) {
         const int lx = cx + 4 * k, ly = ry, idx = lx * CT_Y + ly;
         if (!scand[idx] || lx == 0) continue;
-        /* 8-connectivity: (lx-1, ly-1 .. ly+1).  One union per pair of touching runs is enough, so a pixel leaves the union to
-         * its upper (lower) neighbour in the run whenever that one sees the same left run */
         const int q = idx - CT_Y;
         const bool up = ly > 0 && scand[idx - 1], down = ly < CT_Y - 1 && scand[idx + 1];
         const bool cq = scand[q], cqm = ly > 0 && scand[q - 1], cqp = ly < CT_Y - 1 && scand[q + 1];
         if (cq) {
-            if (!(up && cqm)) uf_union(slab, idx, q);             /* q-1, q, q+1 are one run */
+            if (!(up && cqm)) todo |= 1u << (3 * k);              /* q-1, q, q+1 are one run */
         } else {
-            if (cqm && !up) uf_union(slab, idx, q - 1);           /* `up` has q-1 straight to its left */
-            if (cqp && !down) uf_union(slab, idx, q + 1);         /* `down` has q+1 straight to its left */
+            if (cqm && !up) todo |= 2u << (3 * k);                /* `up` has q-1 straight to its left */
+            if (cqp && !down) todo |= 4u << (3 * k);              /* `down` has q+1 straight to its left */
         }
     }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < CT_X / 4; k++) {                          /* a pixel above `high` makes its component's root strong */
+    while (todo) {
+        const int b = __ffs((int)todo) - 1;
+        todo &= todo - 1u;
+        const int k = b / 3, which = b - 3 * k;
         const int idx = (cx + 4 * k) * CT_Y + ry;
-        if ((scand[idx] & 3) == 2) { const int r = uf_find(slab, idx); atomicOr(&scand32[r >> 2], 4u << (8 * (r & 3))); }
+        uf_union<true>(slab, idx, idx - CT_Y + (which == 0 ? 0 : (which == 1 ? -1 : 1)));
+    }
+    __syncthreads();
+    unsigned strong = 0u;                                         /* a pixel above `high` makes its component's root strong */
+#pragma unroll
+    for (int k = 0; k < CT_X / 4; k++) if ((scand[(cx + 4 * k) * CT_Y + ry] & 3) == 2) strong |= 1u << k;
+    while (strong) {
+        const int k = __ffs((int)strong) - 1;
+        strong &= strong - 1u;
+        const int r = uf_find_halving(slab, (cx + 4 * k) * CT_Y + ry);
+        atomicOr(&scand32[r >> 2], 4u << (8 * (r & 3)));
     }
     __syncthreads();
 #pragma unroll
@@ -400,7 +427,7 @@ canny_tile_kernel(const unsigned char *__restrict__ grey, size_t stride, int row
         const unsigned p = (unsigned)(px * rows + py);
         unsigned char c = 0;
         if (scand[idx] & 3) {
-            const int r = uf_find(slab, idx);
+            const int r = uf_find_halving(slab, idx);
             const int rx = r >> 6, rr = r & 63;
             c = (unsigned char)(((scand[r] & 4) ? CAND_SURE : CAND_WEAK) | (r == idx ? CAND_ROOT : 0));
             label[p] = (x0 + rx) * rows + (y0 + rr);
