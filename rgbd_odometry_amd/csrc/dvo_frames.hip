@@ -215,6 +215,62 @@ camera_level_kernel(const unsigned char *__restrict__ bgr, size_t bgr_stride,
     }
 }
 
+/* The full-resolution level of an undistortion-free camera frame (shift 0, no map: every pixel is read once): four pixels per
+ * lane -- twelve contiguous BGR bytes as three dwords, four depth floats as one 16-byte load -- 64 x 64 tiles, the transpose to
+ * the column-major result through LDS with 4-byte stores along yy.  Needs cols and rows in multiples of four (every camera
+ * format); everything else takes camera_level_kernel. */
+constexpr int CF_T = 64;
+__global__ void __launch_bounds__(256)
+camera_level0_kernel(const unsigned char *__restrict__ bgr, size_t bgr_stride, const float *__restrict__ depth_m, size_t depth_stride,
+                     int rows, int cols, int tiles_y, int depth_raw,
+                     unsigned char *__restrict__ grey, float *__restrict__ depth, size_t stride) {
+    __shared__ unsigned sg4[CF_T][CF_T / 4 + 1];                /* [x][y / 4]: grey bytes */
+    __shared__ float sd[CF_T][CF_T + 1];
+    unsigned char (*sg)[CF_T + 4] = reinterpret_cast<unsigned char (*)[CF_T + 4]>(sg4);
+    bgr += (size_t)blockIdx.y * bgr_stride;
+    grey += (size_t)blockIdx.y * stride;
+    if (depth_m) { depth_m += (size_t)blockIdx.y * depth_stride; depth += (size_t)blockIdx.y * stride; }
+    const int y0 = (blockIdx.x % tiles_y) * CF_T, x0 = (blockIdx.x / tiles_y) * CF_T;
+    auto to_grey = [](unsigned b, unsigned g, unsigned r) { return (unsigned char)((1868u * b + 9617u * g + 4899u * r + (1u << 13)) >> 14); };   /* BGR2GRAY 8u */
+#pragma unroll
+    for (int k = 0; k < CF_T * CF_T / 4 / 256; k++) {
+        const int p = threadIdx.x + k * 256;
+        const int ly = p >> 4, lx = (p & 15) * 4;
+        const int yy = y0 + ly, xx = x0 + lx;
+        if (yy < rows && xx < cols) {
+            const unsigned sp = (unsigned)(yy * cols + xx);
+            const unsigned *src = reinterpret_cast<const unsigned *>(bgr + (size_t)sp * 3);
+            const unsigned u0 = src[0], u1 = src[1], u2 = src[2];
+            sg[lx][ly] = to_grey(u0 & 255u, (u0 >> 8) & 255u, (u0 >> 16) & 255u);
+            sg[lx + 1][ly] = to_grey(u0 >> 24, u1 & 255u, (u1 >> 8) & 255u);
+            sg[lx + 2][ly] = to_grey((u1 >> 16) & 255u, u1 >> 24, u2 & 255u);
+            sg[lx + 3][ly] = to_grey((u2 >> 8) & 255u, (u2 >> 16) & 255u, u2 >> 24);
+            if (depth_m) {
+                const float4 d = *reinterpret_cast<const float4 *>(depth_m + sp);
+                sd[lx][ly] = depth_raw ? d.x : depth_m_to_mm(d.x); sd[lx + 1][ly] = depth_raw ? d.y : depth_m_to_mm(d.y);
+                sd[lx + 2][ly] = depth_raw ? d.z : depth_m_to_mm(d.z); sd[lx + 3][ly] = depth_raw ? d.w : depth_m_to_mm(d.w);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CF_T * CF_T / 4 / 256; k++) {
+        const int p = threadIdx.x + k * 256;
+        const int ly4 = p & 15, lx = p >> 4;
+        const int yy = y0 + 4 * ly4, xx = x0 + lx;
+        if (yy < rows && xx < cols) *reinterpret_cast<unsigned *>(grey + (size_t)xx * rows + yy) = sg4[lx][ly4];
+    }
+    if (depth_m) {
+#pragma unroll
+        for (int k = 0; k < CF_T * CF_T / 256; k++) {
+            const int p = threadIdx.x + k * 256;
+            const int ly = p & 63, lx = p >> 6;
+            const int yy = y0 + ly, xx = x0 + lx;
+            if (yy < rows && xx < cols) depth[(size_t)xx * rows + yy] = sd[lx][ly];
+        }
+    }
+}
+
 /* DVO_UPLOAD_DEVICE: camera images that already sit in HBM, one pointer each -> the landing buffer (image i at dst + i*stride).
  * One launch per 32 images (the pointers travel as a kernel argument) instead of one copy call per image. */
 struct GatherPack { const void *src[32]; };
@@ -245,6 +301,14 @@ hipError_t launch_gather_images(const void *const *src, int count, void *dst, si
 hipError_t launch_camera_level(const unsigned char *bgr, size_t bgr_stride, const float *depth_m, size_t depth_stride,
                                int src_rows, int src_cols, int shift, const short2 *umap_xy, const unsigned short *umap_frac,
                                int depth_raw, unsigned char *grey, float *depth_mm, size_t stride, ImgBatch g, hipStream_t s) {
+    if (shift == 0 && !umap_xy && g.rows == src_rows && g.cols == src_cols && (g.rows & 3) == 0 && (g.cols & 3) == 0 &&
+        ((reinterpret_cast<size_t>(bgr) | bgr_stride | reinterpret_cast<size_t>(grey) | stride) & 3) == 0 &&
+        (!depth_m || ((reinterpret_cast<size_t>(depth_m) | (depth_stride * 4)) & 15) == 0)) {
+        const int ty = (g.rows + CF_T - 1) / CF_T, tx = (g.cols + CF_T - 1) / CF_T;
+        hipLaunchKernelGGL(camera_level0_kernel, dim3(ty * tx, g.count), dim3(256), 0, s, bgr, bgr_stride, depth_m, depth_stride,
+                           g.rows, g.cols, ty, depth_raw, grey, depth_mm, stride);
+        return hipGetLastError();
+    }
     const int tiles_y = (g.rows + CAM_TY - 1) / CAM_TY, tiles_x = (g.cols + CAM_TX - 1) / CAM_TX;
     UndistortMaps um{umap_xy, umap_frac, depth_raw};
     hipLaunchKernelGGL(camera_level_kernel, dim3(tiles_y * tiles_x, g.count), dim3(256), 0, s, bgr, bgr_stride, depth_m,
@@ -876,11 +940,7 @@ edt_rows_pk_kernel(const unsigned short *__restrict__ g, int rows, int cols, uns
     };
     const int n4 = totalp >> 2;
     for (int q = threadIdx.x; q < n4; q += 256) {
-#if defined(DVO_EDT_X) && DVO_EDT_X == 5
-        const uint4 v = make_uint4(q, q, q, q);
-#else
         const uint4 v = reinterpret_cast<const uint4 *>(gblk)[q];
-#endif
         stage(4 * q, v.x); stage(4 * q + 1, v.y); stage(4 * q + 2, v.z); stage(4 * q + 3, v.w);
     }
     for (int p = 4 * n4 + threadIdx.x; p < totalp; p += 256) stage(p, gblk[p]);
@@ -908,9 +968,6 @@ edt_rows_pk_kernel(const unsigned short *__restrict__ g, int rows, int cols, uns
         unsigned S = 0x00010001u, D = 0x00030003u;
         unsigned la = tq_lds + (unsigned)((cp - 8 * RP) * 4);   /* far end of a trip's left side: LDS offsets are unsigned */
         unsigned ra = tq_lds + (unsigned)(cp * 4);
-#if defined(DVO_EDT_X) && DVO_EDT_X == 1
-        lim = 0; best = edt_as_us2(0u);
-#endif
         while (i + 7 <= lim) {                                  /* eight steps per trip, one exit test */
             const edt_us2 open = __builtin_elementwise_sub_sat(best, edt_as_us2(S));
             if (__builtin_amdgcn_ballot_w64(edt_as_u32(open) != 0u) == 0ull) break;      /* i^2 >= best everywhere */
@@ -942,15 +999,9 @@ edt_rows_pk_kernel(const unsigned short *__restrict__ g, int rows, int cols, uns
             const bool in0 = w0 < (unsigned)EDT_LBITS_WORDS, in1 = w1 < (unsigned)EDT_LBITS_WORDS;
             const unsigned have0 = in0 ? __hip_atomic_load(&lbits[w0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
             const unsigned have1 = in1 ? __hip_atomic_load(&lbits[w1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
-#if !(defined(DVO_EDT_X) && DVO_EDT_X == 4)
             reinterpret_cast<uint2 *>(d2)[cp] = make_uint2(live0 ? b0 : 0u, live1 ? b1 : 0u);
-#endif
             const unsigned m01 = (live0 ? b0 : 0u) > (live1 ? b1 : 0u) ? (live0 ? b0 : 0u) : (live1 ? b1 : 0u);
             mx = m01 > mx ? m01 : mx;
-#if defined(DVO_EDT_X) && DVO_EDT_X == 2
-            if (have0 + have1 == 12345u) far = true;
-            continue;
-#endif
             if (live0) {
                 if (in0) { if (!(have0 & bit0)) atomicOr(&lbits[w0], bit0); }
                 else if (w0 < (unsigned)bm_words) { if (!(__hip_atomic_load(bm + w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit0)) atomicOr(bm + w0, bit0); }
@@ -1135,9 +1186,6 @@ edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int R,
                     word |= (((unsigned)dr & 0xffu) << 16) | (((unsigned)dl & 0xffu) << 24);
                 }
             }
-#if defined(DVO_EDT_X) && DVO_EDT_X == 8
-            if (word == 0x12345u)
-#endif
             p4[32u + ((size_t)tc * tpc + ty) * 32u + wd] = word;
         }
         __syncthreads();
