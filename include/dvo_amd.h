@@ -317,6 +317,15 @@ int  dvo_get_last_launch_shape(dvo_ctx *ctx, int *block_threads, int *team_size,
  * dvo_params.engine_variant = 4 (or DVO_COMPACT_NOW=off in the environment) disables both: 16-byte texels everywhere. */
 #define DVO_COMPACT_NOW_AFTER 16
 int  dvo_now_prepare(dvo_ctx *ctx, int first_pair, int count);
+/* DIRECT (round 3): with on != 0, dvo_set_now_level / _pair / _device build the compact form from the three float images at
+ * installation: the unit of a normalised exact distance transform is its smallest positive value s; d2 = round((DT / s)^2) per
+ * pixel is accepted only if (float)sqrt(d2) * s reproduces DT bit for bit; the native builder's rank pass then writes the words,
+ * and the caller's gx / gy are compared bit for bit with what the kernel will decode.  Any positive scale is accepted; a DT that
+ * is no exact transform (-1) or gradients that are not imageGradient(DT) (-4) leave the pair on its 16-byte texels (written in
+ * any case) and to the policy above.  Four single-image launches, about 40 us per 640x480 level -- against 98 us of PCIe for the
+ * three images, or 4 us for the texels alone when they come from device memory: OFF by default, worth it only for a now level
+ * that is aligned many times (DVO_DIRECT_COMPACT=on / off in the environment overrides the call). */
+int  dvo_set_direct_compact(dvo_ctx *ctx, int on);
 /* palette_size: > 0 number of distinct distance values of the compact form, 0 not built (yet / stale),
  * < 0 no compact form: -1 negative/inf/nan value, -2 too many distinct values (native 8191, generic 4095), -3 rank step beyond
  * +-127, -4 gradient is not imageGradient(DT), -5 weight is not getWeightOf(DT), -6 image narrower than 2 pixels, -7 a pixel

@@ -30,7 +30,7 @@ C_ABI_SYMBOLS = [
     "dvo_set_poses", "dvo_align_batch_enqueue", "dvo_get_poses", "dvo_get_level_report",
     "dvo_get_final_outputs", "dvo_get_level_normal_matrix", "dvo_eval_points", "dvo_accumulate", "dvo_device_se3_exp",
     "dvo_device_se3_log", "dvo_device_rotationize", "dvo_algorithmic_bytes", "dvo_point_iterations",
-    "dvo_debug_stamps", "dvo_get_level_texel_mode", "dvo_get_level_exact_fallback", "dvo_get_level_points4", "dvo_now_prepare", "dvo_get_now_compact_info", "dvo_get_last_launch_shape", "dvo_replicate_pairs", "dvo_set_now_level_from_edges", "dvo_get_now_level", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
+    "dvo_debug_stamps", "dvo_get_level_texel_mode", "dvo_get_level_exact_fallback", "dvo_get_level_points4", "dvo_now_prepare", "dvo_set_direct_compact", "dvo_get_now_compact_info", "dvo_get_last_launch_shape", "dvo_replicate_pairs", "dvo_set_now_level_from_edges", "dvo_get_now_level", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
     "dvo_align_pyramid_wide", "dvo_tiled_attach", "dvo_tiled_detach", "dvo_align_pyramid_tiled", "dvo_tiled_shard",
     "dvo_get_ref_level", "dvo_frames_reserve", "dvo_frames_upload_pyramids", "dvo_frames_upload_cameras", "dvo_frames_set_undistort",
     "dvo_photo_params_default", "dvo_photo_configure", "dvo_photo_set_ref", "dvo_photo_align", "dvo_photo_get_jacobian", "dvo_frames_as_now",
@@ -209,6 +209,7 @@ def load_library() -> C.CDLL:
         "dvo_now_prepare": [vp, i, i],
         "dvo_get_last_launch_shape": [vp, ip, ip, ip],
         "dvo_get_now_compact_info": [vp, i, i, ip],
+        "dvo_set_direct_compact": [vp, i],
         "dvo_replicate_pairs": [vp, i, i, i],
         "dvo_set_now_level_from_edges": [vp, i, i, vp, i, i],
         "dvo_get_now_level": [vp, i, i, vp, vp, vp],
@@ -721,6 +722,10 @@ class DvoContext:
         """build the compact (4 bytes per pixel) form of the resident now levels of these pairs now"""
         count = self.n_pairs - first_pair if count is None else count
         self._chk(self.lib.dvo_now_prepare(self._h, first_pair, count))
+
+    def set_direct_compact(self, on: bool = True):
+        """float now levels (set_now_level*) are turned into the compact form at installation (off by default)"""
+        self._chk(self.lib.dvo_set_direct_compact(self._h, 1 if on else 0))
 
     def now_compact_info(self, pair: int, level: int) -> int:
         """> 0 palette size of the compact form, 0 not built, < 0 the builder's reason for keeping the 16-byte form"""

@@ -144,6 +144,18 @@ static void level_flags(dvo_ctx *c, Level &L) {
 }
 
 bool native_compact_wanted(const dvo_ctx *c) { return c->prm.engine_variant != 4 && compact_now_policy() != 2; }
+/* float images straight to the compact form at dvo_set_now_level: dvo_set_direct_compact, or DVO_DIRECT_COMPACT=on / off in the
+ * environment (which wins) */
+static bool direct_compact_wanted(const dvo_ctx *c) {
+    const char *e = getenv("DVO_DIRECT_COMPACT");
+    const bool on = e ? !strcmp(e, "on") : c->direct_compact != 0;
+    return native_compact_wanted(c) && on;
+}
+/* the kernel addresses a pair's rank words with 32-bit byte offsets built from 24-bit multiplies (dvo_fused.hip, p4_byte_offset) */
+static bool p4_addressable(int rows, int cols) {
+    return !(p4_count(rows, cols) * sizeof(unsigned) >= ((size_t)1 << 32) || rows >= (1 << 16) || ((cols + 3) >> 2) >= (1 << 24) ||
+             (size_t)p4_tiles_per_col(rows) * 128 >= ((size_t)1 << 24));
+}
 
 int ensure_compact_slabs(dvo_ctx *c, int level) {
     Level &L = c->lv[level];
@@ -859,8 +871,14 @@ static int set_now_common(dvo_ctx *c, int pair, int level, const float *dt, cons
     Level &L = c->lv[level];
     const size_t npx = (size_t)rows * cols;
     const float *s_dt = dt, *s_gx = gx, *s_gy = gy;
+    /* the compact form straight from the float images (round 3, dvo_frames.hip: launch_float_level_to_compact): for a normalised
+     * exact distance transform with its imageGradient -- what the reference produces -- the pair is read in the 4-byte form from
+     * its first alignment on; anything else keeps the 16-byte texels (and the generic builder's DVO_COMPACT_NOW_AFTER policy) */
+    const bool direct = direct_compact_wanted(c) && (long long)rows + cols + 1 <= 46340 && p4_addressable(rows, cols);
+    const size_t plane_floats = device_src ? 0 : 3 * npx;
+    if (!device_src || direct)
+        if ((rc = ensure_staging(c, sizeof(float) * plane_floats + (direct ? sizeof(int) * float_level_work_ints(rows, cols) : 0)))) return rc;
     if (!device_src) {
-        if ((rc = ensure_staging(c, npx * 3 * sizeof(float)))) return rc;
         HIPCHK(c, hipMemcpyAsync(c->staging, dt, npx * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->staging + npx, gx, npx * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->staging + 2 * npx, gy, npx * 4, hipMemcpyHostToDevice, c->stream));
@@ -868,7 +886,26 @@ static int set_now_common(dvo_ctx *c, int pair, int level, const float *dt, cons
     }
     HIPCHK(c, launch_pack_texels(s_dt, s_gx, s_gy, L.tex + (size_t)pair * L.tex_stride, rows, cols, c->stream));
     if ((rc = now_written(c, level, pair, 1))) return rc;
-    if (!device_src) HIPCHK(c, stream_wait(c->stream));
+    if (direct) {
+        if ((rc = ensure_compact_slabs(c, level))) return rc;
+        HIPCHK(c, launch_float_level_to_compact(s_dt, s_gx, s_gy, rows, cols, reinterpret_cast<int *>(c->staging + plane_floats), L.p4,
+                                                L.p4_stride, L.pal, L.d_pal_n, pair, c->stream));
+        L.pal_built[pair] = 1;                       /* texels AND compact form are current; pal_n on the device says which one the kernel reads */
+        if (!device_src) {
+            if (!c->h_poses) HIPCHK(c, hipHostMalloc((void **)&c->h_poses, sizeof(double) * (12 * (size_t)c->n_pairs + 2), hipHostMallocDefault));
+            HIPCHK(c, hipMemcpyAsync(c->h_poses, L.d_pal_n + pair, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        }
+    }
+    if (!device_src) {
+        HIPCHK(c, stream_wait(c->stream));
+        /* not an exact distance transform (or its gradients are not imageGradient's): leave the pair to the generic builder's policy */
+        if (direct && *reinterpret_cast<const int *>(c->h_poses) <= 0) L.pal_built[pair] = 0;
+    }
+    return DVO_OK;
+}
+int dvo_set_direct_compact(dvo_ctx *c, int on) {
+    DVO_ENTER(c);
+    c->direct_compact = on ? 1 : 0;
     return DVO_OK;
 }
 int dvo_set_now_level_pair(dvo_ctx *c, int pair, int level, const float *dt, const float *gx,

@@ -110,6 +110,7 @@ struct dvo_ctx {
     hipGraphExec_t wide_exec = nullptr;
     unsigned long long wide_sig = 0;
     double *h_pose = nullptr;       /* pinned: in/out pose of the graph's copy nodes */
+    int direct_compact = 0;         /* dvo_set_direct_compact: float now levels go to the compact form at installation */
     double *h_poses = nullptr;      /* pinned: dvo_get_poses / dvo_set_poses staging, 12 doubles per pair */
     unsigned long long *d_dbg = nullptr;
     char *d_states = nullptr;       /* n_pairs x pose_state_bytes(): host-driven iteration state */

@@ -646,7 +646,7 @@ hipError_t launch_canny(const unsigned char *grey, size_t stride, ImgBatch g, in
  *   (dt_normalize_gradient_pack_kernel, launched with a per-image predicate) and pal_n = -reason.                           */
 /* ------------------------------------------------------------------------- */
 #define DVO_EDT_INF(rows, cols) ((rows) + (cols) + 1)
-enum { EDT_FLAG_FAR = 1, EDT_FLAG_STEP = 2 };
+enum { EDT_FLAG_FAR = 1, EDT_FLAG_STEP = 2, EDT_FLAG_BAD = 4 /* float images only: not an exact distance transform */ };
 
 /* 32-bit words of one image's presence bitmap: every possible d2 of a small image, distances below 512 pixels otherwise */
 static inline int edt_bitmap_words(int rows, int cols) {
@@ -1062,7 +1062,8 @@ template <int BM_WORDS>
 __global__ void __launch_bounds__(256)
 edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int R, int tiles_y, int strip, const int *__restrict__ partial, int n_partial,
                      const unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags,
-                     unsigned *__restrict__ p4, size_t p4_stride, float2 *__restrict__ pal, int *__restrict__ pal_n, int first_pair) {
+                     unsigned *__restrict__ p4, size_t p4_stride, float2 *__restrict__ pal, int *__restrict__ pal_n, int first_pair,
+                     const unsigned *__restrict__ unit_bits /* NULL, or per image: ~bits of the value of distance 1 (float images) */) {
     __shared__ unsigned lbm[BM_WORDS];
     __shared__ unsigned short lpre[BM_WORDS];
     __shared__ unsigned short rk[PK_W * PK_H];                  /* [x][y], halo 1 */
@@ -1078,6 +1079,7 @@ edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int R,
     const bool first_wg = blockIdx.x == 0;
     const bool small = BM_WORDS == PK_SMALL_WORDS;
     if (rows < 2 || cols < 2) { if (first_wg && tid == 0 && small) pal_n[pair] = -(int)PAL_SHAPE; return; }
+    if (flags[blockIdx.y] & EDT_FLAG_BAD) { if (first_wg && tid == 0 && small) pal_n[pair] = -(int)PAL_BAD_VALUE; return; }
     if (flags[blockIdx.y] & EDT_FLAG_FAR) { if (first_wg && tid == 0 && small) pal_n[pair] = -(int)PAL_FAR; return; }
     int m = 0;
     for (int k = tid; k < n_partial; k += 256) { const int v = partial[k]; m = v > m ? v : m; }
@@ -1106,7 +1108,8 @@ edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int R,
     }
     __syncthreads();
     if (first_wg) {
-        const EdtScale sc = edt_scale(m2, rows, cols);
+        EdtScale sc = edt_scale(m2, rows, cols);
+        if (unit_bits) { sc.scale_f = unit_bits[blockIdx.y] ? __uint_as_float(~unit_bits[blockIdx.y]) : 0.0f; sc.shift_f = 0.0f; }
         for (int w = w0; w < w1; w++) {
             unsigned v = lbm[w];
             int r = lpre[w];
@@ -1375,14 +1378,131 @@ hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, Im
         strip = strip < 1 ? 1 : (strip > ptiles_y ? ptiles_y : strip);
         const int n_strips = (ptiles_y + (int)strip - 1) / (int)strip;
         hipLaunchKernelGGL(edt_rank_pack_kernel<PK_SMALL_WORDS>, dim3(n_strips * ptiles_x, gb.count), dim3(256), 0, s, d2, gb.rows, gb.cols, R, ptiles_y,
-                           (int)strip, partial, (int)nblk, bitmap, bm_words, flags, p4, p4_stride, pal, pal_n, first_pair);
+                           (int)strip, partial, (int)nblk, bitmap, bm_words, flags, p4, p4_stride, pal, pal_n, first_pair, nullptr);
         if (bm_words > PK_SMALL_WORDS)            /* squared distances of 65536 and more are possible at this size: the full-bitmap twin */
             hipLaunchKernelGGL(edt_rank_pack_kernel<DVO_EDT_BITMAP_BITS / 32>, dim3(n_strips * ptiles_x, gb.count), dim3(256), 0, s, d2, gb.rows,
-                               gb.cols, R, ptiles_y, (int)strip, partial, (int)nblk, bitmap, bm_words, flags, p4, p4_stride, pal, pal_n, first_pair);
+                               gb.cols, R, ptiles_y, (int)strip, partial, (int)nblk, bitmap, bm_words, flags, p4, p4_stride, pal, pal_n, first_pair, nullptr);
     }
     const int tiles_y = (gb.rows + NP_TY - 1) / NP_TY, tiles_x = (gb.cols + NP_TX - 1) / NP_TX;
     hipLaunchKernelGGL(dt_normalize_gradient_pack_kernel, dim3(tiles_y * tiles_x, gb.count), dim3(256), 0, s, d2, gb.rows, gb.cols, R,
                        tiles_y, partial, (int)nblk, tex_out, tex_stride, p4 ? pal_n : nullptr, flags, first_pair);
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------- */
+/* Caller-supplied float images (dvo_set_now_level: DT, gx, gy as the reference keeps them) -> the compact form, directly.
+ * A normalised exact distance transform is DT = (float)sqrt(d2) * s with integer d2, and its smallest positive value is s itself
+ * (a pixel next to an edge pixel: sqrt(1) * s).  So: (1) s = min positive DT; (2) d2 = round((DT / s)^2) per pixel, accepted
+ * only if (float)sqrt(d2) * s reproduces DT bit for bit, recorded in the presence bitmap like the row pass does; (3) the rank-pack
+ * pass of the native builder, with s as the scale of the palette; (4) the caller's gx / gy are compared bit for bit with what the
+ * kernel will decode from the rank words.  Any mismatch (another distance transform, gradients that are not imageGradient(DT),
+ * too many / too distant values) and pal_n = -reason: the pair keeps its 16-byte texels, which are written in any case.
+ * 35 bytes of HBM traffic per pixel in four launches; the generic hash / sort builder (dvo_palette.hip) reads 16-byte texels
+ * twice and remains for images that are not exact distance transforms. */
+__global__ void __launch_bounds__(256)
+float_level_unit_kernel(const float *__restrict__ dt, size_t n, unsigned *__restrict__ unit_bits, int *__restrict__ flags) {
+    unsigned lo = 0xffffffffu;
+    bool bad = false;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        const float v = dt[p];
+        if (!(v >= 0.0f) || v > 3.0e38f) bad = true;                 /* NaN, negative, infinite */
+        else if (v > 0.0f) { const unsigned b = __float_as_uint(v); lo = b < lo ? b : lo; }     /* positive floats order like their bits */
+    }
+    /* max of ~bits = min of bits; the reduction is signed, so the sign bit is flipped on the way in and out.  One atomic per
+     * workgroup: the unit value sits next to every edge pixel of the image */
+    const int m = block_reduce_256<true>((int)(~lo ^ 0x80000000u));
+    if (threadIdx.x == 0 && m != (int)0x80000000u) atomicMax(unit_bits, (unsigned)m ^ 0x80000000u);
+    if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) atomicOr(flags, (int)EDT_FLAG_BAD);
+}
+__global__ void __launch_bounds__(256)
+float_level_d2_kernel(const float *__restrict__ dt, int rows, int cols, int R, const unsigned *__restrict__ unit_bits,
+                      unsigned *__restrict__ d2, int *__restrict__ partial, unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags) {
+    const unsigned ub = *unit_bits;
+    const float unit = ub ? __uint_as_float(~ub) : 0.0f;              /* no positive value at all: an all-zero image, scale 0 */
+    const EdtScale sc{unit, 0.0f};
+    const size_t n = (size_t)rows * cols;
+    __shared__ unsigned lbits[EDT_LBITS_WORDS];                     /* the workgroup's copy of the presence bitmap, as in the row pass */
+    for (int i = threadIdx.x; i < EDT_LBITS_WORDS; i += 256) lbits[i] = 0u;
+    __syncthreads();
+    unsigned mx = 0;
+    bool bad = false, far = false;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        const float v = dt[p];
+        const int xx = (int)(p / rows), yy = (int)(p - (size_t)xx * rows);
+        unsigned d = 0u;
+        if (v > 0.0f && unit > 0.0f) {
+            const double q = (double)v / (double)unit, dd = rint(q * q);
+            if (dd < 2147483648.0) d = (unsigned)dd; else bad = true;
+        }
+        if (__float_as_uint(edt_value(d, sc)) != __float_as_uint(v)) bad = true;
+        d2[edt_g_index(xx, yy, cols, R)] = d;
+        mx = d > mx ? d : mx;
+        const unsigned w = d >> 5, bit = 1u << (d & 31u);
+        if (w < (unsigned)EDT_LBITS_WORDS) { if (!(__hip_atomic_load(&lbits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & bit)) atomicOr(&lbits[w], bit); }
+        else if (w < (unsigned)bm_words) { if (!(__hip_atomic_load(bitmap + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(bitmap + w, bit); }
+        else far = true;
+    }
+    const int m = block_reduce_256<true>((int)(mx > 0x7fffffffu ? 0x7fffffffu : mx));
+    if (threadIdx.x == 0 && m > 0) atomicMax(partial, m);
+    __syncthreads();
+    for (int w = threadIdx.x; w < EDT_LBITS_WORDS && w < bm_words; w += 256) {
+        const unsigned v = lbits[w];
+        if (v && (__hip_atomic_load(bitmap + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v) atomicOr(bitmap + w, v);
+    }
+    const int f = (bad ? EDT_FLAG_BAD : 0) | (far ? EDT_FLAG_FAR : 0);
+    const int any = __syncthreads_or(f & EDT_FLAG_BAD) ? EDT_FLAG_BAD : 0, anyfar = __syncthreads_or(f & EDT_FLAG_FAR) ? EDT_FLAG_FAR : 0;
+    if (threadIdx.x == 0 && (any | anyfar)) atomicOr(flags, any | anyfar);
+}
+/* what the fused kernel will decode from the rank words against the caller's gradient images (DT was checked value by value) */
+__global__ void __launch_bounds__(256)
+compact_verify_planes_kernel(const unsigned *__restrict__ p4, const float2 *__restrict__ pal, int *__restrict__ pal_n, int pair,
+                             const int *__restrict__ flags, const float *__restrict__ dt, const float *__restrict__ gx,
+                             const float *__restrict__ gy, int rows, int cols) {
+    if (pal_n[pair] <= 0) return;                                     /* refused by the pack pass already */
+    if (*flags & EDT_FLAG_STEP) { if (blockIdx.x == 0 && threadIdx.x == 0) pal_n[pair] = -(int)PAL_STEP; return; }
+    const int tpc = p4_tiles_per_col(rows);
+    const size_t n = (size_t)rows * cols;
+    bool bad = false;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(p / rows), yy = (int)(p - (size_t)xx * rows);
+        const int ty = yy / DVO_P4_ROWS;
+        const size_t slot = p4_slot(ty, yy - ty * DVO_P4_ROWS + 1, xx, tpc);
+        const unsigned wu = p4[slot - 1], wc = p4[slot], wd = p4[slot + 1];
+        const int c = (int)((wc >> 3) & 0x1fffu);
+        const int r = c + (int)(signed char)((wc >> 16) & 0xffu), l = c + (int)(signed char)(wc >> 24);
+        const float pc = pal[c].x, pr = pal[r].x, pl = pal[l].x, pu = pal[(wu >> 3) & 0x1fffu].x, pd = pal[(wd >> 3) & 0x1fffu].x;
+        if (__float_as_uint(pc) != __float_as_uint(dt[p]) || __float_as_uint((pr - pl) * 0.5f) != __float_as_uint(gx[p]) ||
+            __float_as_uint((pd - pu) * 0.5f) != __float_as_uint(gy[p])) bad = true;
+    }
+    if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) pal_n[pair] = -(int)PAL_GRADIENT;
+}
+/* work: float_level_work_ints() ints.  The level's 16-byte texels are written by the caller as before. */
+size_t float_level_work_ints(int rows, int cols) {
+    return edt_g_count(rows, cols, edt_rows_per_block(cols)) + (size_t)edt_bitmap_words(rows, cols) + 8;
+}
+hipError_t launch_float_level_to_compact(const float *dt, const float *gx, const float *gy, int rows, int cols, int *work,
+                                         unsigned *p4, size_t p4_stride, float2 *pal, int *pal_n, int pair, hipStream_t s) {
+    const int R = edt_rows_per_block(cols);
+    const size_t ng = edt_g_count(rows, cols, R), n = (size_t)rows * cols;
+    const int bm_words = edt_bitmap_words(rows, cols);
+    unsigned *d2 = reinterpret_cast<unsigned *>(work);
+    unsigned *bitmap = d2 + ng;
+    int *partial = reinterpret_cast<int *>(bitmap + bm_words);       /* [0] max d2, [1] flags, [2] ~bits of the unit value */
+    int *flags = partial + 1;
+    unsigned *unit_bits = reinterpret_cast<unsigned *>(partial + 2);
+    hipError_t e = hipMemsetAsync(bitmap, 0, sizeof(unsigned) * ((size_t)bm_words + 4), s);
+    if (e != hipSuccess) return e;
+    const unsigned gx_blocks = grid_x(n);
+    hipLaunchKernelGGL(float_level_unit_kernel, dim3(gx_blocks), dim3(256), 0, s, dt, n, unit_bits, flags);
+    hipLaunchKernelGGL(float_level_d2_kernel, dim3(gx_blocks), dim3(256), 0, s, dt, rows, cols, R, unit_bits, d2, partial, bitmap, bm_words, flags);
+    const int ptiles_y = (p4_tiles_per_col(rows) + PK_LR - 1) / PK_LR, ptiles_x = (((cols + 3) >> 2) + PK_LC - 1) / PK_LC;
+    hipLaunchKernelGGL(edt_rank_pack_kernel<PK_SMALL_WORDS>, dim3(ptiles_y * ptiles_x, 1), dim3(256), 0, s, d2, rows, cols, R, ptiles_y, 1,
+                       partial, 1, bitmap, bm_words, flags, p4, p4_stride, pal, pal_n, pair, unit_bits);
+    if (bm_words > PK_SMALL_WORDS)
+        hipLaunchKernelGGL(edt_rank_pack_kernel<DVO_EDT_BITMAP_BITS / 32>, dim3(ptiles_y * ptiles_x, 1), dim3(256), 0, s, d2, rows, cols, R,
+                           ptiles_y, 1, partial, 1, bitmap, bm_words, flags, p4, p4_stride, pal, pal_n, pair, unit_bits);
+    hipLaunchKernelGGL(compact_verify_planes_kernel, dim3(gx_blocks), dim3(256), 0, s, p4 + (size_t)pair * p4_stride, pal + (size_t)pair * DVO_PAL_MAX,
+                       pal_n, pair, flags, dt, gx, gy, rows, cols);
     return hipGetLastError();
 }
 

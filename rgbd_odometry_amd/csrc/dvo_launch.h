@@ -170,6 +170,10 @@ hipError_t launch_count_edges(const unsigned char *edge, size_t n, int *out, hip
  * squared distances -- p4 / pal / pal_n are the level's slabs (indexed by pair), tex_out (already offset to first_pair) only
  * receives the 16-byte texels of images the compact form cannot hold (pal_n < 0 then).  p4 == NULL: 16-byte texels of every
  * image.  work: edt_work_ints() ints */
+/* caller-supplied float images -> compact form (see dvo_frames.hip); work: float_level_work_ints() ints */
+size_t float_level_work_ints(int rows, int cols);
+hipError_t launch_float_level_to_compact(const float *dt, const float *gx, const float *gy, int rows, int cols, int *work,
+                                         unsigned *p4, size_t p4_stride, float2 *pal, int *pal_n, int pair, hipStream_t s);
 size_t edt_work_ints(int rows, int cols, int count);
 hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, ImgBatch g, int *work,
                                float4 *tex_out, size_t tex_stride, unsigned *p4, size_t p4_stride, float2 *pal, int *pal_n,
