@@ -210,17 +210,17 @@ DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints 
     v2f xn, yn, zn, u, v;
     bool odd0, odd1;
     project_point2(c, X, Y, Z, xn, yn, zn, u, v, odd0, odd1);
-    any_odd |= (__builtin_amdgcn_ballot_w64((odd0 && valid0) || (odd1 && valid1)) != 0ull);       /* scalar: no branch */
+    /* a lane past the end of the list re-reads the last point: if THAT one is degenerate the wave takes the exact path as
+     * well -- so nothing non-finite ever sits in a lane of a wave that stays on this path, visible or not */
+    any_odd |= (__builtin_amdgcn_ballot_w64(odd0 || odd1) != 0ull);                               /* scalar: no branch */
     int px0, py0, px1, py1;
     const bool inx0 = pixel_in_range(u.x, c.cols, px0), iny0 = pixel_in_range(v.x, c.rows, py0);
     const bool inx1 = pixel_in_range(u.y, c.cols, px1), iny1 = pixel_in_range(v.y, c.rows, py1);
     const bool vis0 = inx0 && iny0 && valid0 && !odd0;
     const bool vis1 = inx1 && iny1 && valid1 && !odd1;
-    /* finite dummies for lanes without a visible point: they then add exact zeros (w = eps = 0).  zn too: a lane past the end
-     * of the list re-reads the last point, and if THAT point has a degenerate z the lane holds a NaN without being counted
-     * in any_odd (tests/test_gpu_packed_kernel.py::test_degenerate_depth_takes_the_exact_fallback, team shares) */
-    b.xn.x = vis0 ? xn.x : 0.0f; b.yn.x = vis0 ? yn.x : 0.0f; b.zn.x = vis0 ? zn.x : 1.0f;
-    b.xn.y = vis1 ? xn.y : 0.0f; b.yn.y = vis1 ? yn.y : 0.0f; b.zn.y = vis1 ? zn.y : 1.0f;
+    /* a lane without a visible point keeps its (finite: see any_odd) coordinates: its w and eps are exact zeros, so it adds
+     * exact zeros to every sum (tests/test_gpu_packed_kernel.py::test_degenerate_depth_takes_the_exact_fallback, team shares) */
+    b.xn = xn; b.yn = yn; b.zn = zn;
     if constexpr (TEX == TEX_P4) {
         nvis += __popcll(__builtin_amdgcn_ballot_w64(vis0)) + __popcll(__builtin_amdgcn_ballot_w64(vis1));
         unsigned o0 = p4_byte_offset(py0, px0, ts.p4_col_bytes);
