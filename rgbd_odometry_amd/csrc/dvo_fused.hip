@@ -216,8 +216,9 @@ DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints 
     int px0, py0, px1, py1;
     const bool inx0 = pixel_in_range(u.x, c.cols, px0), iny0 = pixel_in_range(v.x, c.rows, py0);
     const bool inx1 = pixel_in_range(u.y, c.cols, px1), iny1 = pixel_in_range(v.y, c.rows, py1);
-    const bool vis0 = inx0 && iny0 && valid0 && !odd0;
-    const bool vis1 = inx1 && iny1 && valid1 && !odd1;
+    /* `odd` is left out of the visibility on purpose: a wave with one odd lane discards everything this path computes */
+    const bool vis0 = inx0 && iny0 && valid0;
+    const bool vis1 = inx1 && iny1 && valid1;
     /* a lane without a visible point keeps its (finite: see any_odd) coordinates: its w and eps are exact zeros, so it adds
      * exact zeros to every sum (tests/test_gpu_packed_kernel.py::test_degenerate_depth_takes_the_exact_fallback, team shares) */
     b.xn = xn; b.yn = yn; b.zn = zn;
