@@ -195,22 +195,25 @@ def frames_leg(args, iters):
     form + the alignment, i.e. what one alignment costs INCLUDING the production of its now level.  Bounded: 256 pairs."""
     from rgbd_odometry_amd import frame_gen
     from rgbd_odometry_amd import DvoContext
-    from rgbd_odometry_amd.capi import DVO_FLAG_IDENTITY_START, DVO_UPLOAD_ASYNC, DVO_UPLOAD_DIRECT
+    from rgbd_odometry_amd.capi import DVO_FLAG_IDENTITY_START, DVO_UPLOAD_ASYNC, DVO_UPLOAD_MAPPED
     B, D = 256, 8
 
     def pin(a):
         t = torch.empty(a.shape, dtype=torch.from_numpy(a).dtype, pin_memory=True)
         t.numpy()[...] = a
         return t.numpy()
-    ref = [tuple(pin(x) for x in frame_gen.camera_frame(100 + i, args.height, args.width)) for i in range(D)]
-    now = [pin(frame_gen.camera_frame(100 + i, args.height, args.width, shift=(1 + i % 2, -2))[0]) for i in range(D)]
-    ref_b, ref_d = [ref[i % D][0] for i in range(B)], [ref[i % D][1] for i in range(B)]
-    now_b = [now[i % D] for i in range(B)]
+    # D distinct scenes, but every one of the B frames in its OWN pinned buffer: the link moves B frames' worth of bytes per step
+    ref = [frame_gen.camera_frame(100 + i, args.height, args.width) for i in range(D)]
+    now = [frame_gen.camera_frame(100 + i, args.height, args.width, shift=(1 + i % 2, -2))[0] for i in range(D)]
+    ref_b, ref_d = [pin(ref[i % D][0]) for i in range(B)], [pin(ref[i % D][1]) for i in range(B)]
+    now_b = [pin(now[i % D]) for i in range(B)]
     ctx = DvoContext(B)
     s = args.width / 640.0
     ctx.set_intrinsics(525.0 * s, 525.0 * s, 319.5 * s, 239.5 * args.height / 480.0)
     ctx.frames_reserve(2 * B)
-    kw = dict(n_levels=args.levels, first_shift=0, flags=DVO_UPLOAD_ASYNC | DVO_UPLOAD_DIRECT)    # the frames sit in pinned host memory that outlives the context
+    # the frames sit in pinned host memory that outlives the context and that the GPU can address (torch pin_memory): the engine
+    # pulls them over PCIe with a kernel (DVO_UPLOAD_MAPPED) instead of one DMA per image
+    kw = dict(n_levels=args.levels, first_shift=0, flags=DVO_UPLOAD_ASYNC | DVO_UPLOAD_MAPPED)
 
     def pair_step():
         ctx.frames_upload_cameras(ref_b, ref_d, first_slot=0, **kw)
@@ -220,9 +223,8 @@ def frames_leg(args, iters):
         ctx.enqueue(iters, flags=DVO_FLAG_IDENTITY_START)
         return ctx.get_poses()
 
-    def now_step():
-        ctx.frames_upload_cameras(now_b, None, first_slot=B, **kw)
-        ctx.frames_as_now(B, 0, B)
+    def now_step():                                  # the now levels are produced inside the upload pipeline (now_first_pair)
+        ctx.frames_upload_cameras(now_b, None, first_slot=B, now_first_pair=0, **kw)
         ctx.enqueue(iters, flags=DVO_FLAG_IDENTITY_START)
         return ctx.get_poses()
 
@@ -233,7 +235,7 @@ def frames_leg(args, iters):
 
     # the same now frames as DEVICE buffers (a decoder / camera driver that lands frames in HBM): everything the GPU does per
     # now frame -- landing copy, pyramid, Canny, distance transform -> compact now level, alignment -- and no PCIe
-    dev_now = [torch.from_numpy(a).cuda() for a in now]
+    dev_now = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in now]
     dev_ptrs = [dev_now[i % D].data_ptr() for i in range(B)]
 
     def device_step():
@@ -252,7 +254,7 @@ def frames_leg(args, iters):
         out[name] = reps * B / (time.perf_counter() - t0)
     out["now_level_texel_modes"] = [ctx.level_texel_mode(0, l) for l in range(args.levels)]
     out["note"] = ("never `value`.  frame_pairs / now_frames_per_s_reference_resident are PCIe-inclusive: %dx%d BGR8 (+ depth f32 for "
-                   "reference frames) in pinned host memory -> pyramid, Canny, distance transform -> compact now level, edge points on "
+                   "reference frames) in pinned host memory, every frame in its own buffer, pulled by a kernel (DVO_UPLOAD_MAPPED) -> pyramid, Canny, distance transform -> compact now level, edge points on "
                    "the GPU -> %s iterations -> poses on the host.  now_frames_per_s_camera_frames_in_hbm: the same with the BGR8 frames "
                    "already in device memory (DVO_UPLOAD_DEVICE): all the GPU work of a now frame, no PCIe.  now_frames_per_s_frames_resident: the now frames already in the "
                    "frame store (pyramid + Canny done): distance transform -> compact now level + alignment per step.  Batches of %d; "

@@ -43,6 +43,7 @@ DVO_UPLOAD_ASYNC = 1
 DVO_UPLOAD_DEPTH_RAW = 2
 DVO_UPLOAD_DIRECT = 4
 DVO_UPLOAD_DEVICE = 8
+DVO_UPLOAD_MAPPED = 16
 
 
 class DvoImage(C.Structure):
@@ -512,13 +513,16 @@ class DvoContext:
 
     def frames_upload_cameras_device(self, bgr_ptrs, depth_ptrs, rows: int, cols: int, n_levels: int = 4, first_shift: int = 1,
                                      first_slot: int = 0, flags: int = 0, now_first_pair: int = -1):
-        """camera frames that already sit in this GPU's memory (DVO_UPLOAD_DEVICE): lists of device addresses (ints) of
-        (rows, cols, 3) uint8 BGR images and, or None, (rows, cols) float32 depth images"""
+        """camera frames by address: in this GPU's memory (DVO_UPLOAD_DEVICE, the default) or, with flags | DVO_UPLOAD_MAPPED, in
+        pinned host memory the GPU addresses (pulled over PCIe by a kernel).  Lists of addresses (ints) of (rows, cols, 3) uint8
+        BGR images and, or None, (rows, cols) float32 depth images"""
         count = len(bgr_ptrs)
         B = (C.c_void_p * count)(*[int(p) for p in bgr_ptrs])
         Dp = (C.c_void_p * count)(*[int(p) for p in depth_ptrs]) if depth_ptrs is not None else None
+        if not flags & DVO_UPLOAD_MAPPED:
+            flags |= DVO_UPLOAD_DEVICE
         self._chk(self.lib.dvo_frames_upload_cameras(self._h, first_slot, count, B, Dp, rows, cols, n_levels, first_shift,
-                                                     now_first_pair, flags | DVO_UPLOAD_DEVICE))
+                                                     now_first_pair, flags))
         if now_first_pair >= 0:
             self._note_dims(first_slot)
 

@@ -166,6 +166,7 @@ int run_canny(dvo_ctx *c, int level, int first_slot, int count, hipStream_t stre
 constexpr size_t kUploadHalf = (size_t)32 << 20;   /* landing buffer per pipeline stage */
 constexpr size_t kSmallImage = (size_t)256 << 10;  /* images up to this size are gathered on the host before they go up */
 
+constexpr size_t kMappedHalf = (size_t)64 << 20;   /* ... when a kernel pulls them out of mapped host memory: chunks of ~70 VGA frames */
 constexpr size_t kDeviceHalf = (size_t)512 << 20;  /* landing buffer per stage when the sources are device buffers: whole batches */
 
 /* landing buffers of at least `bytes` each (+ their pinned mirrors when the sources are host buffers) + copy streams + events */
@@ -430,16 +431,20 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
     const size_t npx = (size_t)rows * cols;
     const size_t b_img = (npx * 3 + 15) / 16 * 16, d_img = depth_m ? npx * 4 : 0;
     const bool dev_src = (flags & DVO_UPLOAD_DEVICE) != 0;     /* no PCIe to overlap with: whole batches per stage */
-    const int chunk = (int)std::min<size_t>(std::max<size_t>((dev_src ? kDeviceHalf : kUploadHalf) / (b_img + d_img), 1), (size_t)count);
-    if ((rc = ensure_upload(c, (b_img + d_img) * chunk, !dev_src))) return rc;
+    const bool pulled = dev_src || (flags & DVO_UPLOAD_MAPPED);  /* device-addressable sources: gathered by a kernel, no pinned mirror */
+    const size_t half = dev_src ? kDeviceHalf : ((flags & DVO_UPLOAD_MAPPED) ? kMappedHalf : kUploadHalf);
+    const int chunk = (int)std::min<size_t>(std::max<size_t>(half / (b_img + d_img), 1), (size_t)count);
+    if ((rc = ensure_upload(c, (b_img + d_img) * chunk, !pulled))) return rc;
     for (int b = 0; b < count; b += chunk) {            /* copy chunk k+1 (copy stream) while chunk k is preprocessed */
         const int nc = std::min(chunk, count - b);
         unsigned char *sb; int ub;
         if ((rc = upload_begin(c, &sb, &ub))) return rc;
         float *sd = (float *)(sb + b_img * chunk);
-        if (flags & DVO_UPLOAD_DEVICE) {                     /* the images are in HBM already: gathered into the landing buffer */
-            HIPCHK(c, launch_gather_images(reinterpret_cast<const void *const *>(bgr8 + b), nc, sb, npx * 3, b_img, c->copy_stream));
-            if (depth_m) HIPCHK(c, launch_gather_images(reinterpret_cast<const void *const *>(depth_m + b), nc, sd, npx * 4, npx * 4, c->copy_stream2));
+        if (pulled) {                                        /* in HBM already, or in pinned host memory the GPU addresses: gathered */
+            static const int pull_wgs = [] { const char *e = getenv("DVO_PULL_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1; }();
+            const int wgs = dev_src ? 64 : pull_wgs;
+            HIPCHK(c, launch_gather_images(reinterpret_cast<const void *const *>(bgr8 + b), nc, sb, npx * 3, b_img, c->copy_stream, wgs));
+            if (depth_m) HIPCHK(c, launch_gather_images(reinterpret_cast<const void *const *>(depth_m + b), nc, sd, npx * 4, npx * 4, c->copy_stream2, wgs));
         } else if (flags & DVO_UPLOAD_DIRECT) {
             for (int i = 0; i < nc; i++) {
                 hipStream_t cs = (i & 1) ? c->copy_stream2 : c->copy_stream;

@@ -287,12 +287,15 @@ gather_images_kernel(GatherPack pk, unsigned char *__restrict__ dst, size_t byte
         for (size_t i = t0; i < bytes; i += nt) d[i] = src[i];
     }
 }
-hipError_t launch_gather_images(const void *const *src, int count, void *dst, size_t bytes, size_t stride, hipStream_t s) {
+hipError_t launch_gather_images(const void *const *src, int count, void *dst, size_t bytes, size_t stride, hipStream_t s, int max_wgs_per_image) {
     for (int b = 0; b < count; b += 32) {
         GatherPack pk;
         const int nc = count - b < 32 ? count - b : 32;
         for (int i = 0; i < 32; i++) pk.src[i] = src[b + (i < nc ? i : 0)];
-        const unsigned gx = (unsigned)((bytes / 16 + 255) / 256 < 1 ? 1 : ((bytes / 16 + 255) / 256 > 64 ? 64 : (bytes / 16 + 255) / 256));
+        /* HBM sources: up to 64 workgroups per image.  Mapped host memory: a few -- the link needs ~100 KB in flight, and a
+         * grid that fills every wave slot with lanes waiting on PCIe would lock the preprocessing kernels of the previous chunk out */
+        const size_t want = (bytes / 16 + 255) / 256;
+        const unsigned gx = (unsigned)(want < 1 ? 1 : (want > (size_t)max_wgs_per_image ? (size_t)max_wgs_per_image : want));
         hipLaunchKernelGGL(gather_images_kernel, dim3(gx, nc), dim3(256), 0, s, pk, static_cast<unsigned char *>(dst) + (size_t)b * stride, bytes, stride);
     }
     return hipGetLastError();

@@ -155,7 +155,7 @@ hipError_t launch_import_grey(const void *src, int dtype, int row_major, size_t 
 hipError_t launch_import_depth(const void *src, int dtype, int row_major, size_t src_stride,
                                float *depth_mm, size_t stride, ImgBatch g, hipStream_t s);
 /* row f2: full-resolution BGR8 (+ depth in metres, may be NULL) row-major -> pyramid level decimated by 2^shift */
-hipError_t launch_gather_images(const void *const *src, int count, void *dst, size_t bytes, size_t stride, hipStream_t s);
+hipError_t launch_gather_images(const void *const *src, int count, void *dst, size_t bytes, size_t stride, hipStream_t s, int max_wgs_per_image = 64);
 hipError_t launch_camera_level(const unsigned char *bgr, size_t bgr_stride, const float *depth_m, size_t depth_stride,
                                int src_rows, int src_cols, int shift, const short2 *umap_xy, const unsigned short *umap_frac,
                                int depth_raw, unsigned char *grey, float *depth_mm, size_t stride, ImgBatch g, hipStream_t s);

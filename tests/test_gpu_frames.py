@@ -377,3 +377,28 @@ def test_camera_frames_in_device_memory_equal_host_uploads(oracle):
             for p in range(3):
                 for x, y in zip(a.get_now_level(l, pair=p), b.get_now_level(l, pair=p)):
                     assert np.array_equal(x, y)
+
+
+def test_camera_frames_pulled_out_of_mapped_host_memory_equal_dma_uploads(oracle):
+    """DVO_UPLOAD_MAPPED: pinned host buffers the GPU addresses are gathered by a kernel in the upload pipeline's own chunks;
+    same frame store as the DMA path, more frames than one chunk holds"""
+    import torch
+    from rgbd_odometry_amd.capi import DVO_UPLOAD_MAPPED
+    n = 5
+    frames = [frame_gen.camera_frame(400 + i, 240, 320) for i in range(n)]
+    pb = [torch.from_numpy(np.ascontiguousarray(f[0])).pin_memory() for f in frames]
+    pd = [torch.from_numpy(np.ascontiguousarray(f[1], dtype=np.float32)).pin_memory() for f in frames]
+    with _ctx(n) as a, _ctx(n) as b:
+        for c in (a, b):
+            c.set_intrinsics(262.5, 262.5, 159.75, 119.75)
+            c.frames_reserve(n)
+        a.frames_upload_cameras([f[0] for f in frames], [f[1] for f in frames], n_levels=3, first_shift=0, now_first_pair=0)
+        b.frames_upload_cameras([t.numpy() for t in pb], [t.numpy() for t in pd], n_levels=3, first_shift=0, now_first_pair=0,
+                                flags=DVO_UPLOAD_MAPPED)
+        for slot in range(n):
+            for l in range(3):
+                for x, y in zip(a.frame_level(slot, l)[:3], b.frame_level(slot, l)[:3]):
+                    assert np.array_equal(x, y)
+            for l in range(3):
+                for x, y in zip(a.get_now_level(l, pair=slot), b.get_now_level(l, pair=slot)):
+                    assert np.array_equal(x, y)

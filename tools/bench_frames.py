@@ -116,6 +116,18 @@ def main():
     timed("now frames in HBM: gather, pyramid, Canny", lambda: ctx.frames_upload_cameras_device(dev_ptrs, None, args.height, args.width, **dkw), B)
     timed("now frames in HBM: gather, pyramid, Canny, EDT -> compact form", lambda: ctx.frames_upload_cameras_device(dev_ptrs, None, args.height, args.width, now_first_pair=0, **dkw), B)
 
+    if args.pinned:      # pinned host buffers are device-accessible: the gather kernel pulls them over PCIe itself (one launch per 32 images)
+        from rgbd_odometry_amd.capi import DVO_UPLOAD_MAPPED
+        host_ptrs = [now_b[i].ctypes.data for i in range(B)]
+        mkw = dict(dkw, flags=DVO_UPLOAD_ASYNC | DVO_UPLOAD_MAPPED)
+        timed("now frames in pinned host memory, pulled by the gather kernel: pyramid, Canny", lambda: ctx.frames_upload_cameras_device(host_ptrs, None, args.height, args.width, **mkw), B)
+
+        def tracking_step_zero_copy():
+            ctx.frames_upload_cameras_device(host_ptrs, None, args.height, args.width, now_first_pair=0, **mkw)
+            ctx.enqueue(iters, flags=DVO_FLAG_IDENTITY_START)
+            return ctx.get_poses()
+        timed("now frame in pinned host memory -> pose out, pulled by the gather kernel", tracking_step_zero_copy, B)
+
     def tracking_step_device():
         ctx.frames_upload_cameras_device(dev_ptrs, None, args.height, args.width, now_first_pair=0, **dkw)
         ctx.enqueue(iters, flags=DVO_FLAG_IDENTITY_START)
