@@ -441,8 +441,10 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
         if ((rc = upload_begin(c, &sb, &ub))) return rc;
         float *sd = (float *)(sb + b_img * chunk);
         if (pulled) {                                        /* in HBM already, or in pinned host memory the GPU addresses: gathered */
-            static const int pull_wgs = [] { const char *e = getenv("DVO_PULL_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1; }();
-            const int wgs = dev_src ? 64 : pull_wgs;
+            /* mapped host memory: ~32 workgroups per launch of up to 32 images keep the link busy (128 KB in flight) without taking
+             * the wave slots the previous chunk's preprocessing needs; a single camera frame gets all 32 */
+            static const int pull_wgs = [] { const char *e = getenv("DVO_PULL_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 32; }();
+            const int wgs = dev_src ? 64 : std::max(1, pull_wgs / std::min(nc, 32));
             HIPCHK(c, launch_gather_images(reinterpret_cast<const void *const *>(bgr8 + b), nc, sb, npx * 3, b_img, c->copy_stream, wgs));
             if (depth_m) HIPCHK(c, launch_gather_images(reinterpret_cast<const void *const *>(depth_m + b), nc, sd, npx * 4, npx * 4, c->copy_stream2, wgs));
         } else if (flags & DVO_UPLOAD_DIRECT) {
