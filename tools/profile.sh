@@ -24,3 +24,7 @@ cd $REPO
 find $OUT -name "*.csv" | head -40
 python3 tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+# keep what profiles/ keeps (summary, kernel stats, the profiled bench line); the raw per-dispatch CSVs are tens of megabytes
+cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/trace_kernel_stats.csv 2>/dev/null
+tail -1 $OUT/trace.log > $OUT/bench_line_profiled.json
+[ -z "${KEEP_RAW:-}" ] && rm -rf $OUT/trace $OUT/pmc[0-9]*
