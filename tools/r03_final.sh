@@ -1,9 +1,6 @@
 #!/bin/bash
 # final record of the round: PMC traffic (ties to the kernel hash), the default bench line, the secondary configurations
-python3 tools/update_pmc_traffic.py r03 > /dev/null 2>&1
-python3 tools/update_pmc_traffic.py r03 --batch 1024 > /dev/null 2>&1
-python3 tools/update_pmc_traffic.py r03 --width 1920 --height 1080 --levels 5 --batch 1024 --distinct 8 > /dev/null 2>&1
-cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json
+# (PMC traffic: tools/r03_profiles.sh)
 mkdir -p gpurun_out/r03_final
 python bench.py --steps 20 --warmup 5 > gpurun_out/r03_final/bench_driver_flags.json 2> gpurun_out/r03_final/bench.err; echo "bench rc=$?"
 python bench.py > gpurun_out/r03_final/bench_defaults.json 2>> gpurun_out/r03_final/bench.err; echo "bench rc=$?"
