@@ -370,7 +370,7 @@ enum { DVO_UPLOAD_ASYNC = 1,        /* do not wait for the copies: with DVO_UPLO
                                        driver; when the application later frees them (free -> munmap of a large block), the driver stalls
                                        the process's GPU queues for 14-33 ms -- measured on the C++ file replay, whose loader allocates
                                        and frees a pyramid per frame: 24 ms per frame instead of 0.6 (profiles/r03_single_stream) */
-enum { DVO_UPLOAD_MAPPED = 16 };    /* dvo_frames_upload_cameras: the images sit in PINNED host memory the GPU can address (hipHostMalloc,
+enum { DVO_UPLOAD_MAPPED = 16 };    /* dvo_frames_upload_cameras / _pyramids: the images sit in PINNED host memory the GPU can address (hipHostMalloc,
                                        hipHostRegister'ed + mapped, torch pin_memory): a kernel pulls them over PCIe -- one launch per 32
                                        images at the full link rate (56 GB/s measured) instead of one DMA per image (38 GB/s: the
                                        per-copy submission cost) -- in the same double-buffered chunks as the DMA path, so the pull of

@@ -113,6 +113,14 @@ class RcclComm:
             self.comm = None
 
 
+def _mapped_ok(flags: int, passed, given):
+    """DVO_UPLOAD_MAPPED hands the GPU the caller's (pinned, mapped) buffer itself: a silent dtype / layout conversion here would
+    hand it a pageable copy instead"""
+    if flags & DVO_UPLOAD_MAPPED and not (isinstance(given, np.ndarray) and np.shares_memory(passed, given)):
+        raise ValueError("DVO_UPLOAD_MAPPED needs the images as contiguous numpy views of pinned memory in their final dtype "
+                         "(uint8 BGR / grey, float32 or uint16 depth): this one would have been copied")
+
+
 class DvoError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"dvo error {code}: {msg}")
@@ -484,8 +492,10 @@ class DvoContext:
         for f, fr in enumerate(frames):
             for l, (g, d) in enumerate(fr):
                 G[f * nl + l], b = self._image(g, "grey", layout); keep.append(b)
+                _mapped_ok(flags, b, g)
                 if have_depth:
                     D[f * nl + l], b = self._image(d, "depth", layout); keep.append(b)
+                    _mapped_ok(flags, b, d)
         self._chk(self.lib.dvo_frames_upload_pyramids(self._h, first_slot, count, nl, G, D if have_depth else None,
                                                       now_first_pair, flags))
         if flags & DVO_UPLOAD_ASYNC:
@@ -498,11 +508,15 @@ class DvoContext:
         """bgr_list: list of (rows, cols, 3) uint8 BGR images; depth_list: list of (rows, cols) float32 metres or None"""
         count = len(bgr_list)
         bl = [np.ascontiguousarray(b, dtype=np.uint8) for b in bgr_list]
+        for b, src in zip(bl, bgr_list):
+            _mapped_ok(flags, b, src)
         rows, cols = bl[0].shape[:2]
         B = (C.c_void_p * count)(*[b.ctypes.data for b in bl])
         Dp, dl = None, None
         if depth_list is not None:
             dl = [np.ascontiguousarray(d, dtype=np.float32) for d in depth_list]
+            for d, src in zip(dl, depth_list):
+                _mapped_ok(flags, d, src)
             Dp = (C.c_void_p * count)(*[d.ctypes.data for d in dl])
         self._chk(self.lib.dvo_frames_upload_cameras(self._h, first_slot, count, B, Dp, rows, cols, n_levels, first_shift,
                                                      now_first_pair, flags))

@@ -279,8 +279,10 @@ int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_leve
         d_img[l] = depth ? (npx * pix_bytes(depth[l].dtype) + 15) / 16 * 16 : 0;
         frame_bytes += g_img[l] + d_img[l];
     }
-    const int chunk = (int)std::min<size_t>(std::max<size_t>(kUploadHalf / frame_bytes, 1), (size_t)count);
-    if ((rc = ensure_upload(c, frame_bytes * chunk))) return rc;
+    const bool mapped = (flags & DVO_UPLOAD_MAPPED) != 0;   /* pinned host memory the GPU addresses: pulled by a kernel (dvo_amd.h) */
+    const int chunk = (int)std::min<size_t>(std::max<size_t>((mapped ? kMappedHalf : kUploadHalf) / frame_bytes, 1), (size_t)count);
+    if ((rc = ensure_upload(c, frame_bytes * chunk, !mapped))) return rc;
+    std::vector<const void *> srcs;
     {   size_t o = 0;                                   /* landing layout: per level, `chunk` grey images then `chunk` depth images */
         for (int l = 0; l < n_levels; l++) { g_off[l] = o; o += g_img[l] * chunk; d_off[l] = o; o += d_img[l] * chunk; }
     }
@@ -292,9 +294,21 @@ int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_leve
          * images (the reference's 320x240 ... 40x30 levels: eight per frame): those are gathered into the pinned mirror
          * of the landing buffer with memcpy and go up in one copy per run of small levels; big images go up directly. */
         unsigned char *hbuf = c->up_host[ub];
-        if (c->up_used[ub]) HIPCHK(c, hipEventSynchronize(c->ev_copied[ub]));      /* the mirror's previous copy has left */
+        if (c->up_used[ub] && !mapped) HIPCHK(c, hipEventSynchronize(c->ev_copied[ub]));      /* the mirror's previous copy has left */
         bool small[DVO_LEVELS];
-        for (int l = 0; l < n_levels; l++) {
+        for (int l = 0; l < n_levels && mapped; l++) {      /* one gather launch per level and 32 images, grey and depth on the two copy streams */
+            const size_t npx = c->fs.lv[l].npx, gb = pix_bytes(grey[l].dtype), db = depth ? pix_bytes(depth[l].dtype) : 0;
+            small[l] = false;
+            const int wgs = std::max(1, 32 / std::min(nc, 32));
+            srcs.resize(nc);
+            for (int i = 0; i < nc; i++) srcs[i] = grey[(size_t)(b + i) * n_levels + l].data;
+            HIPCHK(c, launch_gather_images(srcs.data(), nc, buf + g_off[l], npx * gb, g_img[l], c->copy_stream, wgs));
+            if (depth) {
+                for (int i = 0; i < nc; i++) srcs[i] = depth[(size_t)(b + i) * n_levels + l].data;
+                HIPCHK(c, launch_gather_images(srcs.data(), nc, buf + d_off[l], npx * db, d_img[l], c->copy_stream2, wgs));
+            }
+        }
+        for (int l = 0; l < n_levels && !mapped; l++) {
             const size_t npx = c->fs.lv[l].npx, gb = pix_bytes(grey[l].dtype), db = depth ? pix_bytes(depth[l].dtype) : 0;
             small[l] = !(flags & DVO_UPLOAD_DIRECT) || npx * std::max(gb, db) <= kSmallImage;     /* default: through the pinned mirror */
             for (int i = 0; i < nc; i++) {

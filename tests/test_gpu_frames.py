@@ -402,3 +402,28 @@ def test_camera_frames_pulled_out_of_mapped_host_memory_equal_dma_uploads(oracle
             for l in range(3):
                 for x, y in zip(a.get_now_level(l, pair=slot), b.get_now_level(l, pair=slot)):
                     assert np.array_equal(x, y)
+
+
+def test_pyramid_levels_pulled_out_of_mapped_host_memory_equal_dma_uploads(oracle):
+    """DVO_UPLOAD_MAPPED on the node's wire format (mono8 + mono16 levels): every level gathered by the kernel"""
+    import torch
+    from rgbd_odometry_amd.capi import DVO_UPLOAD_MAPPED
+    n = 4
+    pyrs = []
+    for i in range(n):
+        bgr, depth = frame_gen.camera_frame(500 + i, 240, 320)
+        pyrs.append(oracle.build_pyramid(bgr, depth, 3, 0))
+    keep = []
+    def pinned(a):
+        t = torch.from_numpy(np.ascontiguousarray(a)).pin_memory(); keep.append(t); return t.numpy()
+    pinned_pyrs = [[(pinned(g), pinned(d)) for g, d in p] for p in pyrs]
+    with _ctx(n) as a, _ctx(n) as b:
+        for c in (a, b):
+            c.set_intrinsics(262.5, 262.5, 159.75, 119.75)
+            c.frames_reserve(n)
+        a.frames_upload_pyramids(pyrs)
+        b.frames_upload_pyramids(pinned_pyrs, flags=DVO_UPLOAD_MAPPED)
+        for slot in range(n):
+            for l in range(3):
+                for x, y in zip(a.frame_level(slot, l)[:3], b.frame_level(slot, l)[:3]):
+                    assert np.array_equal(x, y)

@@ -84,6 +84,9 @@ def main():
     pyr_b = [pyr[i % D] for i in range(B)]
     res["config_pyramid_bytes_per_frame"] = int(sum(g.nbytes + d.nbytes for g, d in pyr[0]))
     timed("upload_pyramids(mono8+mono16 row-major: H2D, import, Canny)", lambda: ctx.frames_upload_pyramids(pyr_b, first_slot=0, flags=DVO_UPLOAD_ASYNC | DVO_UPLOAD_DIRECT), B)
+    if args.pinned:
+        from rgbd_odometry_amd.capi import DVO_UPLOAD_MAPPED as _MAPPED
+        timed("upload_pyramids, pinned levels pulled by the gather kernel (DVO_UPLOAD_MAPPED)", lambda: ctx.frames_upload_pyramids(pyr_b, first_slot=0, flags=DVO_UPLOAD_ASYNC | _MAPPED), B)
 
     def tracking_step():                              # every pair gets a fresh now frame against its resident reference
         ctx.frames_upload_cameras(now_b, None, first_slot=B, **kw)
