@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_frames
 mkdir -p $O
-python3 $R/tools/bench_frames.py --batch 256 --pinned > $O/pinned.json 2>&1
+python3 $R/tools/bench_frames.py --batch 256 --distinct 256 --pinned > $O/pinned.json 2>&1
 [ "$1" = "full" ] && python3 $R/tools/bench_frames.py --batch 256 > $O/pageable.json 2>&1
 [ "$1" = "full" ] && python3 $R/tools/bench_frames.py --batch 256 --pinned --width 320 --height 240 > $O/pinned_320.json 2>&1
 rm -rf $O/trace
