@@ -5,6 +5,7 @@ run() { echo "### $*" >> $O; "$@" 2>&1 | grep -v "amdgpu.ids\|RCCL version\|HIP 
 Q="--cpu-seconds 0 --no-extra-legs"
 run python bench.py $Q --width 1920 --height 1080 --levels 5 --batch 256 --distinct 8 --steps 5 --warmup 1
 run python bench.py $Q --width 1920 --height 1080 --levels 5 --batch 1024 --distinct 8 --steps 5 --warmup 1
+run python bench.py $Q --width 1920 --height 1080 --levels 5 --batch 2048 --distinct 8 --steps 4 --warmup 1
 run python bench.py $Q --width 320 --height 240 --iters 50 --batch 1024 --steps 20
 run python bench.py $Q --batch 256 --steps 20
 run python bench.py $Q --batch 1024 --steps 20
