@@ -71,7 +71,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 100 in batch mode, 200 in tiled mode: a timed region of about a second)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8192, help="frame pairs per GPU per step (weak scaling: fixed per GPU)")
+    ap.add_argument("--batch", type=int, default=16384, help="frame pairs per GPU per step (weak scaling: fixed per GPU; 16384 resident pairs = 159 GB of HBM)")
     ap.add_argument("--total-pairs", type=int, default=0,
                     help="strong scaling: this many pairs IN TOTAL per step, split over the GPUs by shard_range "
                          "(BASELINE configs[3]: --total-pairs 256); overrides --batch")
