@@ -4,6 +4,8 @@
  * images), per-level execution lanes, kernel launches of dvo_frames.hip.  No CPU compute path.
  */
 #include "dvo_ctx.h"
+#include <chrono>
+#include <cstdio>
 
 using namespace dvo;
 using namespace dvo_host;
@@ -166,18 +168,27 @@ int run_canny(dvo_ctx *c, int level, int first_slot, int count, hipStream_t stre
 constexpr size_t kUploadHalf = (size_t)32 << 20;   /* landing buffer per pipeline stage */
 constexpr size_t kSmallImage = (size_t)256 << 10;  /* images up to this size are gathered on the host before they go up */
 
-constexpr size_t kMappedHalf = (size_t)64 << 20;   /* ... when a kernel pulls them out of mapped host memory: chunks of ~70 VGA frames */
+static size_t mapped_half() {                     /* ... when a kernel pulls them out of mapped host memory (DVO_MAPPED_CHUNK_MB) */
+    static const size_t v = [] { const char *e = getenv("DVO_MAPPED_CHUNK_MB"); const long m = e ? atol(e) : 0; return (size_t)(m > 0 ? m : 64) << 20; }();
+    return v;
+}
+#define kMappedHalf mapped_half()
 constexpr size_t kDeviceHalf = (size_t)512 << 20;  /* landing buffer per stage when the sources are device buffers: whole batches */
 
 /* landing buffers of at least `bytes` each (+ their pinned mirrors when the sources are host buffers) + copy streams + events */
 int ensure_upload(dvo_ctx *c, size_t bytes, bool with_host = true) {
     if (!c->copy_stream) {
-        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking));
+        /* highest priority: the kernels that pull mapped host memory (DVO_UPLOAD_MAPPED) must not queue behind the
+         * preprocessing of the previous chunk -- the PCIe link is the longer pole */
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        HIPCHK(c, hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, prio_hi));
+        HIPCHK(c, hipStreamCreateWithPriority(&c->copy_stream2, hipStreamNonBlocking, prio_hi));
+        const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;      /* producers and consumers are kernels / DMAs of this device */
         for (int b = 0; b < 2; b++) {
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_copied[b], hipEventDisableTiming));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_copied2[b], hipEventDisableTiming));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_done[b], hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_copied[b], evf));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_copied2[b], evf));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_done[b], evf));
         }
     }
     const bool grow_dev = bytes > c->up_bytes, grow_host = with_host && bytes > c->up_host_bytes;
@@ -447,64 +458,93 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
     const bool dev_src = (flags & DVO_UPLOAD_DEVICE) != 0;     /* no PCIe to overlap with: whole batches per stage */
     const bool pulled = dev_src || (flags & DVO_UPLOAD_MAPPED);  /* device-addressable sources: gathered by a kernel, no pinned mirror */
     const size_t half = dev_src ? kDeviceHalf : ((flags & DVO_UPLOAD_MAPPED) ? kMappedHalf : kUploadHalf);
-    const int chunk = (int)std::min<size_t>(std::max<size_t>(half / (b_img + d_img), 1), (size_t)count);
+    int chunk = (int)std::min<size_t>(std::max<size_t>(half / (b_img + d_img), 1), (size_t)count);
+    if (pulled && chunk > 32) chunk -= chunk % 32;              /* whole gather launches of 32 images: a short tail launch runs far below the link rate */
     if ((rc = ensure_upload(c, (b_img + d_img) * chunk, !pulled))) return rc;
-    for (int b = 0; b < count; b += chunk) {            /* copy chunk k+1 (copy stream) while chunk k is preprocessed */
-        const int nc = std::min(chunk, count - b);
-        unsigned char *sb; int ub;
-        if ((rc = upload_begin(c, &sb, &ub))) return rc;
-        float *sd = (float *)(sb + b_img * chunk);
+    /* chunk k+1 is copied (copy streams) while chunk k is preprocessed (context stream), over two landing buffers.  The copies
+     * of chunk k+1 are SUBMITTED before the kernels of chunk k: measured on this pool (tools/experiments/exp_pull_overlap.sh),
+     * work of two streams that becomes ready at the same moment starts in submission order, and a pull submitted after ~45
+     * preprocessing launches waited for nearly all of them -- the link idled 0.6 ms of every 1.6 */
+    struct Chunk { int b, nc, ub; unsigned char *sb; float *sd; };
+    int next_ub = c->up_next;
+    auto issue_copy = [&](int b, Chunk &k) -> int {
+        k.b = b; k.nc = std::min(chunk, count - b); k.ub = next_ub; next_ub ^= 1;
+        k.sb = c->up_buf[k.ub]; k.sd = (float *)(k.sb + b_img * chunk);
+        if (c->up_used[k.ub]) {                             /* the buffer's previous consumer (two chunks back) has read it */
+            HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_done[k.ub], 0));
+            HIPCHK(c, hipStreamWaitEvent(c->copy_stream2, c->ev_done[k.ub], 0));
+        }
         if (pulled) {                                        /* in HBM already, or in pinned host memory the GPU addresses: gathered */
             /* mapped host memory: ~32 workgroups per launch of up to 32 images keep the link busy (128 KB in flight) without taking
              * the wave slots the previous chunk's preprocessing needs; a single camera frame gets all 32 */
             static const int pull_wgs = [] { const char *e = getenv("DVO_PULL_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 32; }();
-            const int wgs = dev_src ? 64 : std::max(1, pull_wgs / std::min(nc, 32));
-            HIPCHK(c, launch_gather_images(reinterpret_cast<const void *const *>(bgr8 + b), nc, sb, npx * 3, b_img, c->copy_stream, wgs));
-            if (depth_m) HIPCHK(c, launch_gather_images(reinterpret_cast<const void *const *>(depth_m + b), nc, sd, npx * 4, npx * 4, c->copy_stream2, wgs));
+            const int wgs = dev_src ? 64 : std::max(1, pull_wgs / std::min(k.nc, 32));
+            HIPCHK(c, launch_gather_images(reinterpret_cast<const void *const *>(bgr8 + b), k.nc, k.sb, npx * 3, b_img, c->copy_stream, wgs));
+            if (depth_m) HIPCHK(c, launch_gather_images(reinterpret_cast<const void *const *>(depth_m + b), k.nc, k.sd, npx * 4, npx * 4, c->copy_stream2, wgs));
         } else if (flags & DVO_UPLOAD_DIRECT) {
-            for (int i = 0; i < nc; i++) {
+            for (int i = 0; i < k.nc; i++) {
                 hipStream_t cs = (i & 1) ? c->copy_stream2 : c->copy_stream;
-                HIPCHK(c, hipMemcpyAsync(sb + b_img * i, bgr8[b + i], npx * 3, hipMemcpyHostToDevice, cs));
-                if (depth_m) HIPCHK(c, hipMemcpyAsync(sd + npx * i, depth_m[b + i], npx * 4, hipMemcpyHostToDevice, cs));
+                HIPCHK(c, hipMemcpyAsync(k.sb + b_img * i, bgr8[b + i], npx * 3, hipMemcpyHostToDevice, cs));
+                if (depth_m) HIPCHK(c, hipMemcpyAsync(k.sd + npx * i, depth_m[b + i], npx * 4, hipMemcpyHostToDevice, cs));
             }
         } else {
             /* through the engine's pinned mirror of the landing buffer: one memcpy per image on the host, then two DMAs per
              * chunk; the caller's (pageable) memory is never registered with the driver (include/dvo_amd.h, DVO_UPLOAD_DIRECT) */
-            unsigned char *hb = c->up_host[ub];
+            unsigned char *hb = c->up_host[k.ub];
             float *hd = (float *)(hb + b_img * chunk);
-            if (c->up_used[ub]) { HIPCHK(c, hipEventSynchronize(c->ev_copied[ub])); HIPCHK(c, hipEventSynchronize(c->ev_copied2[ub])); }
-            for (int i = 0; i < nc; i++) {
+            if (c->up_used[k.ub]) { HIPCHK(c, hipEventSynchronize(c->ev_copied[k.ub])); HIPCHK(c, hipEventSynchronize(c->ev_copied2[k.ub])); }
+            for (int i = 0; i < k.nc; i++) {
                 std::memcpy(hb + b_img * i, bgr8[b + i], npx * 3);
                 if (depth_m) std::memcpy(hd + npx * i, depth_m[b + i], npx * 4);
             }
-            HIPCHK(c, hipMemcpyAsync(sb, hb, b_img * (size_t)nc, hipMemcpyHostToDevice, c->copy_stream));
-            if (depth_m) HIPCHK(c, hipMemcpyAsync(sd, hd, npx * 4 * (size_t)nc, hipMemcpyHostToDevice, c->copy_stream2));
+            HIPCHK(c, hipMemcpyAsync(k.sb, hb, b_img * (size_t)k.nc, hipMemcpyHostToDevice, c->copy_stream));
+            if (depth_m) HIPCHK(c, hipMemcpyAsync(k.sd, hd, npx * 4 * (size_t)k.nc, hipMemcpyHostToDevice, c->copy_stream2));
         }
+        HIPCHK(c, hipEventRecord(c->ev_copied[k.ub], c->copy_stream));
+        HIPCHK(c, hipEventRecord(c->ev_copied2[k.ub], c->copy_stream2));
+        c->up_used[k.ub] = true;                            /* from here on the buffer has a pending ev_copied and, soon, ev_done */
+        return DVO_OK;
+    };
+    auto issue_compute = [&](const Chunk &k) -> int {
+        int rc2;
         LevelLanes ln;
-        if ((rc = lanes_begin(c, n_levels, nc, now_first_pair >= 0, ln))) return rc;
-        if ((rc = upload_copied(c, ub))) return rc;
-        if ((rc = lanes_fork(c, n_levels, ln))) return rc;
+        if ((rc2 = lanes_begin(c, n_levels, k.nc, now_first_pair >= 0, ln))) return rc2;
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copied[k.ub], 0));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copied2[k.ub], 0));
+        if ((rc2 = lanes_fork(c, n_levels, ln))) return rc2;
         for (int pass = 0; pass < 2; pass++) {
             for (int l = 0; l < n_levels; l++) {
                 FrameLevel &F = c->fs.lv[l];
-                const size_t off = (size_t)(first_slot + b) * F.npx;
+                const size_t off = (size_t)(first_slot + k.b) * F.npx;
                 if (pass == 0 || ln.parallel)
-                    HIPCHK(c, launch_camera_level(sb, b_img, depth_m ? sd : nullptr, npx, rows, cols, first_shift + l,
+                    HIPCHK(c, launch_camera_level(k.sb, b_img, depth_m ? k.sd : nullptr, npx, rows, cols, first_shift + l,
                                                   c->d_umap_xy, c->d_umap_frac, (flags & DVO_UPLOAD_DEPTH_RAW) ? 1 : 0,
-                                                  F.grey + off, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, nc}, ln.s[l]));
+                                                  F.grey + off, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, k.nc}, ln.s[l]));
                 if (pass == 1 || ln.parallel) {
-                    if ((rc = run_canny(c, l, first_slot + b, nc, ln.s[l], ln.work[l]))) return rc;
+                    if ((rc2 = run_canny(c, l, first_slot + k.b, k.nc, ln.s[l], ln.work[l]))) return rc2;
                     if (now_first_pair >= 0 &&
-                        (rc = frames_as_now_level(c, l, first_slot + b, now_first_pair + b, nc, ln.s[l], ln.work[l]))) return rc;
+                        (rc2 = frames_as_now_level(c, l, first_slot + k.b, now_first_pair + k.b, k.nc, ln.s[l], ln.work[l]))) return rc2;
                 }
             }
             if (ln.parallel) break;
-            if (pass == 0 && (rc = upload_consumed(c, ub))) return rc;
+            if (pass == 0) HIPCHK(c, hipEventRecord(c->ev_done[k.ub], c->stream));     /* the landing buffer is free again */
         }
         if (ln.parallel) {
-            if ((rc = lanes_join(c, n_levels, ln))) return rc;
-            if ((rc = upload_consumed(c, ub))) return rc;
+            if ((rc2 = lanes_join(c, n_levels, ln))) return rc2;
+            HIPCHK(c, hipEventRecord(c->ev_done[k.ub], c->stream));
         }
+        return DVO_OK;
+    };
+    {
+        Chunk cur, nxt;
+        if ((rc = issue_copy(0, cur))) return rc;
+        for (int b = 0; b < count; b += chunk) {
+            const bool more = b + chunk < count;
+            if (more && (rc = issue_copy(b + chunk, nxt))) return rc;
+            if ((rc = issue_compute(cur))) return rc;
+            cur = nxt;
+        }
+        c->up_next = next_ub;
     }
     for (int f = 0; f < count; f++) { c->fs.valid[first_slot + f] = 1; c->fs.has_depth[first_slot + f] = depth_m ? 1 : 0; }
     if (!(flags & DVO_UPLOAD_ASYNC)) HIPCHK(c, stream_wait(c->stream));
