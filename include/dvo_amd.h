@@ -375,6 +375,10 @@ enum { DVO_UPLOAD_MAPPED = 16 };    /* dvo_frames_upload_cameras / _pyramids: th
                                        images at the full link rate (56 GB/s measured) instead of one DMA per image (38 GB/s: the
                                        per-copy submission cost) -- in the same double-buffered chunks as the DMA path, so the pull of
                                        chunk k+1 overlaps the preprocessing of chunk k.  Borrowing rules as for DVO_UPLOAD_DIRECT */
+/* Pinned host memory the GPU can address, for callers that do not link the HIP runtime themselves (a ROS node's image pool):
+ * what DVO_UPLOAD_MAPPED wants.  NULL when the allocation fails.  Free with dvo_host_free_mapped, never with free(). */
+void *dvo_host_alloc_mapped(size_t bytes);
+void  dvo_host_free_mapped(void *p);
 enum { DVO_UPLOAD_DEVICE = 8 };     /* dvo_frames_upload_cameras: the image pointers are DEVICE pointers of this context's GPU (a decoder or
                                        a camera driver that lands frames in HBM): device-to-device copies into the landing buffer, no PCIe.
                                        The buffers stay borrowed until the call returns (until dvo_synchronize() with DVO_UPLOAD_ASYNC) */

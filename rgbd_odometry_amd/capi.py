@@ -30,7 +30,7 @@ C_ABI_SYMBOLS = [
     "dvo_set_poses", "dvo_align_batch_enqueue", "dvo_get_poses", "dvo_get_level_report",
     "dvo_get_final_outputs", "dvo_get_level_normal_matrix", "dvo_eval_points", "dvo_accumulate", "dvo_device_se3_exp",
     "dvo_device_se3_log", "dvo_device_rotationize", "dvo_algorithmic_bytes", "dvo_point_iterations",
-    "dvo_debug_stamps", "dvo_get_level_texel_mode", "dvo_get_level_exact_fallback", "dvo_get_level_points4", "dvo_now_prepare", "dvo_set_direct_compact", "dvo_get_now_compact_info", "dvo_get_last_launch_shape", "dvo_replicate_pairs", "dvo_set_now_level_from_edges", "dvo_get_now_level", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
+    "dvo_debug_stamps", "dvo_get_level_texel_mode", "dvo_get_level_exact_fallback", "dvo_get_level_points4", "dvo_now_prepare", "dvo_set_direct_compact", "dvo_host_alloc_mapped", "dvo_host_free_mapped", "dvo_get_now_compact_info", "dvo_get_last_launch_shape", "dvo_replicate_pairs", "dvo_set_now_level_from_edges", "dvo_get_now_level", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
     "dvo_align_pyramid_wide", "dvo_tiled_attach", "dvo_tiled_detach", "dvo_align_pyramid_tiled", "dvo_tiled_shard",
     "dvo_get_ref_level", "dvo_frames_reserve", "dvo_frames_upload_pyramids", "dvo_frames_upload_cameras", "dvo_frames_set_undistort",
     "dvo_photo_params_default", "dvo_photo_configure", "dvo_photo_set_ref", "dvo_photo_align", "dvo_photo_get_jacobian", "dvo_frames_as_now",
@@ -119,6 +119,33 @@ def _mapped_ok(flags: int, passed, given):
     if flags & DVO_UPLOAD_MAPPED and not (isinstance(given, np.ndarray) and np.shares_memory(passed, given)):
         raise ValueError("DVO_UPLOAD_MAPPED needs the images as contiguous numpy views of pinned memory in their final dtype "
                          "(uint8 BGR / grey, float32 or uint16 depth): this one would have been copied")
+
+
+class MappedHostArray:
+    """A numpy array over pinned host memory the GPU can address (dvo_host_alloc_mapped): what DVO_UPLOAD_MAPPED wants, for
+    callers without torch.  Keep the object alive while the array is in use; free() or garbage collection releases it."""
+
+    def __init__(self, shape, dtype):
+        lib = load_library()
+        self._lib = lib
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = lib.dvo_host_alloc_mapped(self.nbytes)
+        if not self._p:
+            raise MemoryError("dvo_host_alloc_mapped(%d) failed" % self.nbytes)
+        buf = (C.c_ubyte * self.nbytes).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self._p:
+            self.array = None
+            self._lib.dvo_host_free_mapped(C.c_void_p(self._p))
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class DvoError(RuntimeError):
@@ -219,6 +246,8 @@ def load_library() -> C.CDLL:
         "dvo_get_last_launch_shape": [vp, ip, ip, ip],
         "dvo_get_now_compact_info": [vp, i, i, ip],
         "dvo_set_direct_compact": [vp, i],
+        "dvo_host_alloc_mapped": [C.c_size_t],
+        "dvo_host_free_mapped": [vp],
         "dvo_replicate_pairs": [vp, i, i, i],
         "dvo_set_now_level_from_edges": [vp, i, i, vp, i, i],
         "dvo_get_now_level": [vp, i, i, vp, vp, vp],
@@ -254,6 +283,8 @@ def load_library() -> C.CDLL:
         fn.restype = C.c_int
     lib.dvo_last_error.argtypes = [vp]
     lib.dvo_last_error.restype = C.c_char_p
+    lib.dvo_host_alloc_mapped.restype = C.c_void_p
+    lib.dvo_host_free_mapped.restype = None
     _lib = lib
     return lib
 

@@ -906,6 +906,13 @@ static int set_now_common(dvo_ctx *c, int pair, int level, const float *dt, cons
     }
     return DVO_OK;
 }
+void *dvo_host_alloc_mapped(size_t bytes) {
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void dvo_host_free_mapped(void *p) { if (p) (void)hipHostFree(p); }
+
 int dvo_set_direct_compact(dvo_ctx *c, int on) {
     DVO_ENTER(c);
     c->direct_compact = on ? 1 : 0;

@@ -427,3 +427,23 @@ def test_pyramid_levels_pulled_out_of_mapped_host_memory_equal_dma_uploads(oracl
             for l in range(3):
                 for x, y in zip(a.frame_level(slot, l)[:3], b.frame_level(slot, l)[:3]):
                     assert np.array_equal(x, y)
+
+
+def test_mapped_host_allocator_of_the_c_abi(oracle):
+    """dvo_host_alloc_mapped: pinned, GPU-addressable host memory for callers without the HIP runtime; frames kept there go up
+    with DVO_UPLOAD_MAPPED"""
+    from rgbd_odometry_amd.capi import DVO_UPLOAD_MAPPED, MappedHostArray
+    bgr, depth = frame_gen.camera_frame(600, 240, 320)
+    mb, md = MappedHostArray(bgr.shape, np.uint8), MappedHostArray(depth.shape, np.float32)
+    mb.array[...] = bgr
+    md.array[...] = depth
+    with _ctx() as a, _ctx() as b:
+        for c in (a, b):
+            c.set_intrinsics(262.5, 262.5, 159.75, 119.75)
+            c.frames_reserve(1)
+        a.frames_upload_cameras([bgr], [depth], n_levels=3, first_shift=0)
+        b.frames_upload_cameras([mb.array], [md.array], n_levels=3, first_shift=0, flags=DVO_UPLOAD_MAPPED)
+        for l in range(3):
+            for x, y in zip(a.frame_level(0, l)[:3], b.frame_level(0, l)[:3]):
+                assert np.array_equal(x, y)
+    mb.free(); md.free()
