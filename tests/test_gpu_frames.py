@@ -447,3 +447,37 @@ def test_mapped_host_allocator_of_the_c_abi(oracle):
             for x, y in zip(a.frame_level(0, l)[:3], b.frame_level(0, l)[:3]):
                 assert np.array_equal(x, y)
     mb.free(); md.free()
+
+
+def test_camera_and_pyramid_uploads_interleaved_over_the_landing_buffers(oracle):
+    """the two upload entry points share the landing buffers, their events and the copy streams: multi-chunk camera uploads
+    (copies of chunk k+1 submitted ahead of the kernels of chunk k), a pyramid upload in between, every path (pinned mirror,
+    DIRECT, MAPPED) -- every stored level equals the one-frame-at-a-time result"""
+    import torch
+    from rgbd_odometry_amd.capi import DVO_UPLOAD_DIRECT, DVO_UPLOAD_MAPPED
+    distinct = [frame_gen.camera_frame(80 + i, 480, 640) for i in range(3)]
+    n = 38
+    with _ctx(1) as one:
+        want = []
+        for b, d in distinct:
+            one.frames_upload_cameras([b], [d], n_levels=3, first_shift=0)
+            want.append([one.frame_level(0, l)[:3] for l in range(3)])
+        pyr = [[tuple(np.ascontiguousarray(x) for x in one.frame_level(0, l)[:2]) for l in range(3)]]     # the last frame as a pyramid
+    pinned = [(torch.from_numpy(np.ascontiguousarray(b)).pin_memory(), torch.from_numpy(np.ascontiguousarray(d)).pin_memory()) for b, d in distinct]
+    with _ctx(1) as ctx:
+        ctx.frames_reserve(n + 2)
+        for flags in (0, DVO_UPLOAD_DIRECT, DVO_UPLOAD_MAPPED, 0):
+            src = pinned if flags else None
+            bl = [(src[i % 3][0].numpy() if src else distinct[i % 3][0]) for i in range(n)]
+            dl = [(src[i % 3][1].numpy() if src else distinct[i % 3][1]) for i in range(n)]
+            ctx.frames_upload_cameras(bl, dl, n_levels=3, first_shift=0, first_slot=0, flags=flags)
+            ctx.frames_upload_pyramids(pyr, first_slot=n)
+            ctx.frames_upload_cameras(bl[:5], dl[:5], n_levels=3, first_shift=0, first_slot=n - 5, flags=flags)
+            for slot in (0, 1, 14, 15, 16, 29, 30, n - 6, n - 5, n - 1):
+                i = slot % 3 if slot < n - 5 else (slot - (n - 5)) % 3
+                for l in range(3):
+                    for x, y in zip(ctx.frame_level(slot, l)[:3], want[i][l]):
+                        assert np.array_equal(x, y), (flags, slot, l)
+            for l in range(3):
+                for x, y in zip(ctx.frame_level(n, l)[:2], want[2][l][:2]):
+                    assert np.array_equal(x, y), (flags, "pyramid slot", l)
