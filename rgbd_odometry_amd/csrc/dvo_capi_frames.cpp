@@ -165,6 +165,36 @@ int run_canny(dvo_ctx *c, int level, int first_slot, int count, hipStream_t stre
     return DVO_OK;
 }
 
+/* Canny of all pyramid levels of `count` stored frames: four launches for all levels when the images allow it, else per level */
+int run_canny_all(dvo_ctx *c, int n_levels, int first_slot, int count, hipStream_t stream) {
+    int rows[DVO_LEVELS], cols[DVO_LEVELS];
+    unsigned char *edge[DVO_LEVELS]; size_t estride[DVO_LEVELS];
+    for (int l = 0; l < n_levels; l++) {
+        const FrameLevel &F = c->fs.lv[l];
+        rows[l] = F.rows; cols[l] = F.cols; estride[l] = F.npx; edge[l] = F.edge + (size_t)first_slot * F.npx;
+    }
+    static const bool per_level = getenv("DVO_CANNY_PER_LEVEL") != nullptr;
+    if (per_level || !canny_levels_ok(n_levels, rows, cols, edge, estride)) {
+        for (int l = 0; l < n_levels; l++) { const int rc = run_canny(c, l, first_slot, count, stream, nullptr); if (rc) return rc; }
+        return DVO_OK;
+    }
+    int low, high;
+    canny_thresholds(c, &low, &high);
+    const int chunk = chunk_for(sizeof(int) * canny_levels_work_ints(n_levels, rows, cols, 1), count);
+    int rc = ensure_work(c, sizeof(int) * canny_levels_work_ints(n_levels, rows, cols, chunk));
+    if (rc) return rc;
+    for (int b = 0; b < count; b += chunk) {
+        const int nc = std::min(chunk, count - b);
+        const unsigned char *grey[DVO_LEVELS]; size_t gstride[DVO_LEVELS]; unsigned char *e[DVO_LEVELS];
+        for (int l = 0; l < n_levels; l++) {
+            const FrameLevel &F = c->fs.lv[l];
+            grey[l] = F.grey + (size_t)(first_slot + b) * F.npx; gstride[l] = F.npx; e[l] = F.edge + (size_t)(first_slot + b) * F.npx;
+        }
+        HIPCHK(c, launch_canny_levels(n_levels, rows, cols, grey, gstride, e, estride, nc, low, high, c->work, stream));
+    }
+    return DVO_OK;
+}
+
 constexpr size_t kUploadHalf = (size_t)32 << 20;   /* landing buffer per pipeline stage */
 constexpr size_t kSmallImage = (size_t)256 << 10;  /* images up to this size are gathered on the host before they go up */
 
@@ -359,8 +389,9 @@ int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_leve
                         HIPCHK(c, launch_import_depth(buf + d_off[l], depth[l].dtype, depth[l].layout == DVO_LAYOUT_ROW_MAJOR,
                                                       d_img[l] / pix_bytes(depth[l].dtype), F.depth + off, F.npx, ib, ln.s[l]));
                 }
+                if (pass == 1 && !ln.parallel && l == 0 && (rc = run_canny_all(c, n_levels, first_slot + b, nc, c->stream))) return rc;
                 if (pass == 1 || ln.parallel) {
-                    if ((rc = run_canny(c, l, first_slot + b, nc, ln.s[l], ln.work[l]))) return rc;
+                    if (ln.parallel && (rc = run_canny(c, l, first_slot + b, nc, ln.s[l], ln.work[l]))) return rc;
                     if (now_first_pair >= 0 &&
                         (rc = frames_as_now_level(c, l, first_slot + b, now_first_pair + b, nc, ln.s[l], ln.work[l]))) return rc;
                 }
@@ -520,8 +551,9 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
                     HIPCHK(c, launch_camera_level(k.sb, b_img, depth_m ? k.sd : nullptr, npx, rows, cols, first_shift + l,
                                                   c->d_umap_xy, c->d_umap_frac, (flags & DVO_UPLOAD_DEPTH_RAW) ? 1 : 0,
                                                   F.grey + off, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, k.nc}, ln.s[l]));
+                if (pass == 1 && !ln.parallel && l == 0 && (rc2 = run_canny_all(c, n_levels, first_slot + k.b, k.nc, c->stream))) return rc2;
                 if (pass == 1 || ln.parallel) {
-                    if ((rc2 = run_canny(c, l, first_slot + k.b, k.nc, ln.s[l], ln.work[l]))) return rc2;
+                    if (ln.parallel && (rc2 = run_canny(c, l, first_slot + k.b, k.nc, ln.s[l], ln.work[l]))) return rc2;
                     if (now_first_pair >= 0 &&
                         (rc2 = frames_as_now_level(c, l, first_slot + k.b, now_first_pair + k.b, k.nc, ln.s[l], ln.work[l]))) return rc2;
                 }

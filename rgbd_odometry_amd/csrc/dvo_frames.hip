@@ -374,9 +374,8 @@ DVO_DEV void uf_union(int *L, int a, int b) {
  * the grey tile for the few pixels above `low` instead of being parked in LDS for all of them (22 KB of LDS per workgroup). */
 constexpr int CT_Y = 64, CT_X = 32;
 enum { CAND_WEAK = 1, CAND_SURE = 2, CAND_KIND = 3, CAND_ROOT = 16 };
-__global__ void __launch_bounds__(256)
-canny_tile_kernel(const unsigned char *__restrict__ grey, size_t stride, int rows, int cols, int tiles_y, int low, int high,
-                  unsigned char *__restrict__ cand, unsigned char *__restrict__ flag, int *__restrict__ label) {
+DVO_DEV void canny_tile_body(const int bx, const int by, const unsigned char *__restrict__ grey, size_t stride, int rows, int cols, int tiles_y,
+                             int low, int high, unsigned char *__restrict__ cand, unsigned char *__restrict__ flag, int *__restrict__ label) {
     constexpr int GH = CT_Y + 4, GW = CT_X + 4, MH = CT_Y + 2, MW = CT_X + 2, NT = CT_Y * CT_X;
     static_assert(CT_Y == 64 && 4 * GW <= 256 && 2 * MW <= 256, "thread mapping: 64 rows per step, the extra halo rows in one more");
     __shared__ unsigned char sg[GW * GH];         /* grey, halo 2, [x][y] */
@@ -385,9 +384,9 @@ canny_tile_kernel(const unsigned char *__restrict__ grey, size_t stride, int row
     __shared__ unsigned scand32[NT / 4];          /* one byte per pixel: 0 / 1 candidate / 2 candidate above `high`; bit 2 at a root: strong */
     unsigned char *scand = reinterpret_cast<unsigned char *>(scand32);
     const size_t n = (size_t)rows * cols;
-    grey += (size_t)blockIdx.y * stride;
-    cand += (size_t)blockIdx.y * n; flag += (size_t)blockIdx.y * n; label += (size_t)blockIdx.y * n;
-    const int ty = blockIdx.x % tiles_y, tx = blockIdx.x / tiles_y;
+    grey += (size_t)by * stride;
+    cand += (size_t)by * n; flag += (size_t)by * n; label += (size_t)by * n;
+    const int ty = bx % tiles_y, tx = bx / tiles_y;
     const int y0 = ty * CT_Y, x0 = tx * CT_X;
     const int tid = threadIdx.x, ry = tid & 63, cx = tid >> 6;
 
@@ -505,12 +504,11 @@ canny_tile_kernel(const unsigned char *__restrict__ grey, size_t stride, int row
 }
 
 /* candidate pairs that straddle a tile boundary: rows r = 64, 128, ... looking up, columns c = 32, 64, ... looking left */
-__global__ void __launch_bounds__(256)
-canny_border_kernel(const unsigned char *__restrict__ cand, int rows, int cols, int *__restrict__ label) {
+DVO_DEV void canny_border_body(const int bx, const int gx, const int by, const unsigned char *__restrict__ cand, int rows, int cols, int *__restrict__ label) {
     const size_t n = (size_t)rows * cols;
-    cand += (size_t)blockIdx.y * n; label += (size_t)blockIdx.y * n;
+    cand += (size_t)by * n; label += (size_t)by * n;
     const int nA = ((rows - 1) / CT_Y) * cols, nB = ((cols - 1) / CT_X) * rows;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nA + nB; i += gridDim.x * blockDim.x) {
+    for (int i = bx * blockDim.x + threadIdx.x; i < nA + nB; i += gx * blockDim.x) {
         if (i < nB) {                                             /* lanes along yy: coalesced */
             const int xx = (i / rows + 1) * CT_X, yy = i % rows;
             const size_t p = (size_t)xx * rows + yy, q = p - rows;
@@ -558,11 +556,10 @@ canny_final_kernel(const unsigned char *__restrict__ cand, const int *__restrict
 
 /* the same two passes, four pixels per thread: candidates are a few percent of the pixels, so most threads see one zero word
  * (images whose pixel count is a multiple of four -- every camera format) */
-__global__ void __launch_bounds__(256)
-canny_flag4_kernel(const unsigned char *__restrict__ cand, size_t n, int *__restrict__ label, unsigned char *__restrict__ flag) {
-    cand += (size_t)blockIdx.y * n; label += (size_t)blockIdx.y * n; flag += (size_t)blockIdx.y * n;
+DVO_DEV void canny_flag4_body(const int bx, const int gx, const int by, const unsigned char *__restrict__ cand, size_t n, int *__restrict__ label, unsigned char *__restrict__ flag) {
+    cand += (size_t)by * n; label += (size_t)by * n; flag += (size_t)by * n;
     const unsigned *cand4 = reinterpret_cast<const unsigned *>(cand);
-    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n / 4; q += (size_t)gridDim.x * blockDim.x) {
+    for (size_t q = (size_t)bx * blockDim.x + threadIdx.x; q < n / 4; q += (size_t)gx * blockDim.x) {
         unsigned w = cand4[q];
         for (int k = 0; w; k++, w >>= 8) {
             const unsigned c = w & 0xffu;
@@ -574,14 +571,13 @@ canny_flag4_kernel(const unsigned char *__restrict__ cand, size_t n, int *__rest
         }
     }
 }
-__global__ void __launch_bounds__(256)
-canny_final4_kernel(const unsigned char *__restrict__ cand, const int *__restrict__ label, const unsigned char *__restrict__ flag,
-                    size_t n, unsigned char *__restrict__ edge, size_t edge_stride) {
-    cand += (size_t)blockIdx.y * n; label += (size_t)blockIdx.y * n; flag += (size_t)blockIdx.y * n;
-    edge += (size_t)blockIdx.y * edge_stride;
+DVO_DEV void canny_final4_body(const int bx, const int gx, const int by, const unsigned char *__restrict__ cand, const int *__restrict__ label,
+                               const unsigned char *__restrict__ flag, size_t n, unsigned char *__restrict__ edge, size_t edge_stride) {
+    cand += (size_t)by * n; label += (size_t)by * n; flag += (size_t)by * n;
+    edge += (size_t)by * edge_stride;
     const unsigned *cand4 = reinterpret_cast<const unsigned *>(cand);
     unsigned *edge4 = reinterpret_cast<unsigned *>(edge);
-    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n / 4; q += (size_t)gridDim.x * blockDim.x) {
+    for (size_t q = (size_t)bx * blockDim.x + threadIdx.x; q < n / 4; q += (size_t)gx * blockDim.x) {
         unsigned w = cand4[q], out = 0u;
         for (int k = 0; w; k++, w >>= 8) {
             const unsigned kind = w & CAND_KIND;
@@ -589,6 +585,61 @@ canny_final4_kernel(const unsigned char *__restrict__ cand, const int *__restric
         }
         edge4[q] = out;
     }
+}
+
+__global__ void __launch_bounds__(256)
+canny_tile_kernel(const unsigned char *__restrict__ grey, size_t stride, int rows, int cols, int tiles_y, int low, int high,
+                  unsigned char *__restrict__ cand, unsigned char *__restrict__ flag, int *__restrict__ label) {
+    canny_tile_body(blockIdx.x, blockIdx.y, grey, stride, rows, cols, tiles_y, low, high, cand, flag, label);
+}
+__global__ void __launch_bounds__(256)
+canny_border_kernel(const unsigned char *__restrict__ cand, int rows, int cols, int *__restrict__ label) {
+    canny_border_body(blockIdx.x, gridDim.x, blockIdx.y, cand, rows, cols, label);
+}
+__global__ void __launch_bounds__(256)
+canny_flag4_kernel(const unsigned char *__restrict__ cand, size_t n, int *__restrict__ label, unsigned char *__restrict__ flag) {
+    canny_flag4_body(blockIdx.x, gridDim.x, blockIdx.y, cand, n, label, flag);
+}
+__global__ void __launch_bounds__(256)
+canny_final4_kernel(const unsigned char *__restrict__ cand, const int *__restrict__ label, const unsigned char *__restrict__ flag,
+                    size_t n, unsigned char *__restrict__ edge, size_t edge_stride) {
+    canny_final4_body(blockIdx.x, gridDim.x, blockIdx.y, cand, label, flag, n, edge, edge_stride);
+}
+
+/* ALL PYRAMID LEVELS OF A STAGE IN ONE LAUNCH.  The levels below the first hold a quarter, a sixteenth, ... of its pixels: their
+ * own launches cost the fixed ~10 us each and leave the GPU mostly empty, which a single camera stream pays per frame and the
+ * chunked upload pipeline per chunk.  The grid is the concatenation of the levels' grids (first[l] = first block of level l); a
+ * workgroup looks its level up in the table it gets as kernel argument and runs that level's unchanged body. */
+struct CannyLevels {
+    int n, low, high;
+    int rows[DVO_LEVELS], cols[DVO_LEVELS];
+    unsigned first[DVO_LEVELS + 1];
+    const unsigned char *grey[DVO_LEVELS]; size_t grey_stride[DVO_LEVELS];
+    unsigned char *cand[DVO_LEVELS], *flag[DVO_LEVELS]; int *label[DVO_LEVELS];
+    unsigned char *edge[DVO_LEVELS]; size_t edge_stride[DVO_LEVELS];
+};
+DVO_DEV int level_of_block(const unsigned *first, int n, unsigned bx) {
+    int l = 0;
+    while (l + 1 < n && bx >= first[l + 1]) l++;
+    return l;
+}
+__global__ void __launch_bounds__(256) canny_tile_levels_kernel(const CannyLevels t) {
+    const int l = level_of_block(t.first, t.n, blockIdx.x);
+    canny_tile_body((int)(blockIdx.x - t.first[l]), blockIdx.y, t.grey[l], t.grey_stride[l], t.rows[l], t.cols[l], (t.rows[l] + CT_Y - 1) / CT_Y,
+                    t.low, t.high, t.cand[l], t.flag[l], t.label[l]);
+}
+__global__ void __launch_bounds__(256) canny_border_levels_kernel(const CannyLevels t) {
+    const int l = level_of_block(t.first, t.n, blockIdx.x);
+    canny_border_body((int)(blockIdx.x - t.first[l]), (int)(t.first[l + 1] - t.first[l]), blockIdx.y, t.cand[l], t.rows[l], t.cols[l], t.label[l]);
+}
+__global__ void __launch_bounds__(256) canny_flag4_levels_kernel(const CannyLevels t) {
+    const int l = level_of_block(t.first, t.n, blockIdx.x);
+    canny_flag4_body((int)(blockIdx.x - t.first[l]), (int)(t.first[l + 1] - t.first[l]), blockIdx.y, t.cand[l], (size_t)t.rows[l] * t.cols[l], t.label[l], t.flag[l]);
+}
+__global__ void __launch_bounds__(256) canny_final4_levels_kernel(const CannyLevels t) {
+    const int l = level_of_block(t.first, t.n, blockIdx.x);
+    canny_final4_body((int)(blockIdx.x - t.first[l]), (int)(t.first[l + 1] - t.first[l]), blockIdx.y, t.cand[l], t.label[l], t.flag[l],
+                      (size_t)t.rows[l] * t.cols[l], t.edge[l], t.edge_stride[l]);
 }
 
 /* number of edge pixels of one image (inspection only: kept out of the per-frame pipeline, thousands of
@@ -626,6 +677,47 @@ hipError_t launch_canny(const unsigned char *grey, size_t stride, ImgBatch g, in
         hipLaunchKernelGGL(canny_flag_kernel, grid, blk, 0, s, cand, n, label, flag);
         hipLaunchKernelGGL(canny_final_kernel, grid, blk, 0, s, cand, label, flag, n, edge, edge_stride);
     }
+    return hipGetLastError();
+}
+
+/* Canny of `n` levels of the same `count` images in four launches.  work: the levels' scratch back to back (canny_work_ints each,
+ * rounded to 4 ints).  False if a level does not meet the four-pixels-per-thread conditions: the caller then launches per level. */
+size_t canny_levels_work_ints(int n, const int *rows, const int *cols, int count) {
+    size_t t = 0;
+    for (int l = 0; l < n; l++) t += (canny_work_ints(rows[l], cols[l], count) + 3) / 4 * 4;
+    return t;
+}
+bool canny_levels_ok(int n, const int *rows, const int *cols, unsigned char *const *edge, const size_t *edge_stride) {
+    if (n < 2 || n > DVO_LEVELS) return false;
+    for (int l = 0; l < n; l++) {
+        const size_t px = (size_t)rows[l] * cols[l];
+        if ((px & 3) || (edge_stride[l] & 3) || (reinterpret_cast<size_t>(edge[l]) & 3)) return false;
+    }
+    return true;
+}
+hipError_t launch_canny_levels(int n, const int *rows, const int *cols, const unsigned char *const *grey, const size_t *grey_stride,
+                               unsigned char *const *edge, const size_t *edge_stride, int count, int low, int high, int *work, hipStream_t s) {
+    CannyLevels t;
+    t.n = n; t.low = low; t.high = high;
+    int *w = work;
+    for (int l = 0; l < n; l++) {
+        const size_t nb = (size_t)rows[l] * cols[l] * count;
+        t.rows[l] = rows[l]; t.cols[l] = cols[l];
+        t.grey[l] = grey[l]; t.grey_stride[l] = grey_stride[l]; t.edge[l] = edge[l]; t.edge_stride[l] = edge_stride[l];
+        t.label[l] = w;
+        t.cand[l] = reinterpret_cast<unsigned char *>(w + nb);
+        t.flag[l] = t.cand[l] + ((nb + 3) / 4) * 4;
+        w += (canny_work_ints(rows[l], cols[l], count) + 3) / 4 * 4;
+    }
+    auto prefix = [&](auto blocks_of) { t.first[0] = 0; for (int l = 0; l < n; l++) t.first[l + 1] = t.first[l] + blocks_of(l); return t.first[n]; };
+    const dim3 blk(256);
+    unsigned g = prefix([&](int l) { return (unsigned)(((rows[l] + CT_Y - 1) / CT_Y) * ((cols[l] + CT_X - 1) / CT_X)); });
+    hipLaunchKernelGGL(canny_tile_levels_kernel, dim3(g, count), blk, 0, s, t);
+    g = prefix([&](int l) { const int nb = ((rows[l] - 1) / CT_Y) * cols[l] + ((cols[l] - 1) / CT_X) * rows[l]; return nb > 0 ? grid_x((size_t)nb) : 0u; });
+    if (g) hipLaunchKernelGGL(canny_border_levels_kernel, dim3(g, count), blk, 0, s, t);
+    g = prefix([&](int l) { return grid_x((size_t)rows[l] * cols[l] / 4); });
+    hipLaunchKernelGGL(canny_flag4_levels_kernel, dim3(g, count), blk, 0, s, t);
+    hipLaunchKernelGGL(canny_final4_levels_kernel, dim3(g, count), blk, 0, s, t);
     return hipGetLastError();
 }
 

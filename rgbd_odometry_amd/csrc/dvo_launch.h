@@ -162,6 +162,11 @@ hipError_t launch_camera_level(const unsigned char *bgr, size_t bgr_stride, cons
 /* row f1: cv::Canny(grey, low/high as squared integer thresholds, 3, L2).  work: canny_work_ints() ints;
  * edge out: 0/255 u8 */
 size_t canny_work_ints(int rows, int cols, int count);
+/* Canny of all pyramid levels of the same images in four launches (dvo_frames.hip) */
+size_t canny_levels_work_ints(int n, const int *rows, const int *cols, int count);
+bool canny_levels_ok(int n, const int *rows, const int *cols, unsigned char *const *edge, const size_t *edge_stride);
+hipError_t launch_canny_levels(int n, const int *rows, const int *cols, const unsigned char *const *grey, const size_t *grey_stride,
+                               unsigned char *const *edge, const size_t *edge_stride, int count, int low, int high, int *work, hipStream_t s);
 hipError_t launch_canny(const unsigned char *grey, size_t stride, ImgBatch g, int low, int high, int *work,
                         unsigned char *edge, size_t edge_stride, hipStream_t s);
 hipError_t launch_count_edges(const unsigned char *edge, size_t n, int *out, hipStream_t s);
