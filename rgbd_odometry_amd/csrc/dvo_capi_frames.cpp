@@ -274,6 +274,7 @@ size_t pix_bytes(int dtype) { return dtype == DVO_PIX_U8 ? 1 : (dtype == DVO_PIX
 }  // namespace
 
 static int frames_as_now_level(dvo_ctx *c, int level, int first_slot, int first_pair, int count, hipStream_t stream, int *work);
+static int frames_as_now_all(dvo_ctx *c, int n_levels, int first_slot, int first_pair, int count, hipStream_t stream);
 
 int dvo_frames_reserve(dvo_ctx *c, int n_slots) {
     DVO_ENTER(c);
@@ -389,9 +390,12 @@ int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_leve
                         HIPCHK(c, launch_import_depth(buf + d_off[l], depth[l].dtype, depth[l].layout == DVO_LAYOUT_ROW_MAJOR,
                                                       d_img[l] / pix_bytes(depth[l].dtype), F.depth + off, F.npx, ib, ln.s[l]));
                 }
-                if (pass == 1 && !ln.parallel && l == 0 && (rc = run_canny_all(c, n_levels, first_slot + b, nc, c->stream))) return rc;
-                if (pass == 1 || ln.parallel) {
-                    if (ln.parallel && (rc = run_canny(c, l, first_slot + b, nc, ln.s[l], ln.work[l]))) return rc;
+                if (pass == 1 && !ln.parallel && l == 0) {         /* one launch per stage for all levels */
+                    if ((rc = run_canny_all(c, n_levels, first_slot + b, nc, c->stream))) return rc;
+                    if (now_first_pair >= 0 && (rc = frames_as_now_all(c, n_levels, first_slot + b, now_first_pair + b, nc, c->stream))) return rc;
+                }
+                if (ln.parallel) {
+                    if ((rc = run_canny(c, l, first_slot + b, nc, ln.s[l], ln.work[l]))) return rc;
                     if (now_first_pair >= 0 &&
                         (rc = frames_as_now_level(c, l, first_slot + b, now_first_pair + b, nc, ln.s[l], ln.work[l]))) return rc;
                 }
@@ -551,9 +555,12 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
                     HIPCHK(c, launch_camera_level(k.sb, b_img, depth_m ? k.sd : nullptr, npx, rows, cols, first_shift + l,
                                                   c->d_umap_xy, c->d_umap_frac, (flags & DVO_UPLOAD_DEPTH_RAW) ? 1 : 0,
                                                   F.grey + off, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, k.nc}, ln.s[l]));
-                if (pass == 1 && !ln.parallel && l == 0 && (rc2 = run_canny_all(c, n_levels, first_slot + k.b, k.nc, c->stream))) return rc2;
-                if (pass == 1 || ln.parallel) {
-                    if (ln.parallel && (rc2 = run_canny(c, l, first_slot + k.b, k.nc, ln.s[l], ln.work[l]))) return rc2;
+                if (pass == 1 && !ln.parallel && l == 0) {         /* one launch per stage for all levels */
+                    if ((rc2 = run_canny_all(c, n_levels, first_slot + k.b, k.nc, c->stream))) return rc2;
+                    if (now_first_pair >= 0 && (rc2 = frames_as_now_all(c, n_levels, first_slot + k.b, now_first_pair + k.b, k.nc, c->stream))) return rc2;
+                }
+                if (ln.parallel) {
+                    if ((rc2 = run_canny(c, l, first_slot + k.b, k.nc, ln.s[l], ln.work[l]))) return rc2;
                     if (now_first_pair >= 0 &&
                         (rc2 = frames_as_now_level(c, l, first_slot + k.b, now_first_pair + k.b, k.nc, ln.s[l], ln.work[l]))) return rc2;
                 }
@@ -621,6 +628,44 @@ static int frames_as_now_level(dvo_ctx *c, int l, int first_slot, int first_pair
     return compact ? now_written_compact(c, l, first_pair, count) : now_written(c, l, first_pair, count);
 }
 
+/* every level of `count` stored frames as now levels of pairs first_pair..: one launch per stage for all levels when the
+ * geometry allows it (dvo_frames.hip, launch_edges_to_now_levels), else level by level */
+static int frames_as_now_all(dvo_ctx *c, int n_levels, int first_slot, int first_pair, int count, hipStream_t stream) {
+    int rc;
+    int rows[DVO_LEVELS], cols[DVO_LEVELS];
+    for (int l = 0; l < n_levels; l++) { rows[l] = c->fs.lv[l].rows; cols[l] = c->fs.lv[l].cols; }
+    static const bool per_level = getenv("DVO_EDT_PER_LEVEL") != nullptr;
+    if (per_level || !edt_levels_ok(n_levels, rows, cols)) {
+        for (int l = 0; l < n_levels; l++)
+            if ((rc = frames_as_now_level(c, l, first_slot, first_pair, count, stream, nullptr))) return rc;
+        return DVO_OK;
+    }
+    const bool compact = native_compact_wanted(c);
+    for (int l = 0; l < n_levels; l++) {
+        if ((rc = ensure_texels(c, l, rows[l], cols[l]))) return rc;
+        if (compact && (rc = ensure_compact_slabs(c, l))) return rc;
+    }
+    const int chunk = chunk_for(sizeof(int) * edt_levels_work_ints(n_levels, rows, cols, 1), count);
+    if ((rc = ensure_work(c, sizeof(int) * edt_levels_work_ints(n_levels, rows, cols, chunk)))) return rc;
+    for (int b = 0; b < count; b += chunk) {
+        const int nc = std::min(chunk, count - b);
+        const unsigned char *edge[DVO_LEVELS]; size_t estride[DVO_LEVELS], tstride[DVO_LEVELS], pstride[DVO_LEVELS];
+        float4 *tex[DVO_LEVELS]; unsigned *p4[DVO_LEVELS]; float2 *pal[DVO_LEVELS]; int *pal_n[DVO_LEVELS];
+        for (int l = 0; l < n_levels; l++) {
+            const FrameLevel &F = c->fs.lv[l];
+            Level &L = c->lv[l];
+            edge[l] = F.edge + (size_t)(first_slot + b) * F.npx; estride[l] = F.npx;
+            tex[l] = L.tex + (size_t)(first_pair + b) * L.tex_stride; tstride[l] = L.tex_stride;
+            p4[l] = compact ? L.p4 : nullptr; pstride[l] = L.p4_stride; pal[l] = L.pal; pal_n[l] = L.d_pal_n;
+        }
+        HIPCHK(c, launch_edges_to_now_levels(n_levels, rows, cols, edge, estride, nc, c->work, tex, tstride, p4, pstride, pal, pal_n,
+                                             first_pair + b, stream));
+    }
+    for (int l = 0; l < n_levels; l++)
+        if ((rc = compact ? now_written_compact(c, l, first_pair, count) : now_written(c, l, first_pair, count))) return rc;
+    return DVO_OK;
+}
+
 int dvo_frames_as_now(dvo_ctx *c, int first_slot, int first_pair, int count) {
     DVO_ENTER(c);
     int rc = frames_check_use(c, first_slot, first_pair, count, false);
@@ -628,6 +673,7 @@ int dvo_frames_as_now(dvo_ctx *c, int first_slot, int first_pair, int count) {
     const int nl = c->fs.n_levels;
     LevelLanes ln;
     if ((rc = lanes_begin(c, nl, count, true, ln))) return rc;
+    if (!ln.parallel) return frames_as_now_all(c, nl, first_slot, first_pair, count, c->stream);
     if ((rc = lanes_fork(c, nl, ln))) return rc;
     for (int l = 0; l < nl; l++)
         if ((rc = frames_as_now_level(c, l, first_slot, first_pair, count, ln.s[l], ln.work[l]))) return rc;

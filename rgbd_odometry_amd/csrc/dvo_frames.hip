@@ -768,20 +768,19 @@ DVO_DEV unsigned edt_nonzero_bytes(unsigned v) {           /* bit k = (byte k of
     return (t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xfu;
 }
 template <int WAVES>
-__global__ void __launch_bounds__(WAVES * 64)
-edt_columns8_kernel(const unsigned char *__restrict__ edge, size_t edge_stride, int rows, int cols, int R, unsigned short *__restrict__ g,
+DVO_DEV void edt_columns8_body(const int bx, const int gx, const int by, const unsigned char *__restrict__ edge, size_t edge_stride, int rows, int cols, int R, unsigned short *__restrict__ g,
                     unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags) {
     extern __shared__ uint4 s_da8[];                    /* [WAVES][nchunk * 64]: the eight upward distances of a lane */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     {
-        unsigned *bm = bitmap + (size_t)blockIdx.y * bm_words;
-        for (int i = blockIdx.x * (WAVES * 64) + threadIdx.x; i < bm_words; i += gridDim.x * (WAVES * 64)) bm[i] = 0u;
-        if (blockIdx.x == 0 && threadIdx.x == 0) flags[blockIdx.y] = 0;
+        unsigned *bm = bitmap + (size_t)by * bm_words;
+        for (int i = bx * (WAVES * 64) + threadIdx.x; i < bm_words; i += gx * (WAVES * 64)) bm[i] = 0u;
+        if (bx == 0 && threadIdx.x == 0) flags[by] = 0;
     }
-    const int xx = blockIdx.x * WAVES + wave;
+    const int xx = bx * WAVES + wave;
     if (xx >= cols) return;
-    const unsigned char *col = edge + (size_t)blockIdx.y * edge_stride + (size_t)xx * rows;
-    g += (size_t)blockIdx.y * edt_g_count(rows, cols, R);
+    const unsigned char *col = edge + (size_t)by * edge_stride + (size_t)xx * rows;
+    g += (size_t)by * edt_g_count(rows, cols, R);
     const int rows_pad = ((rows + R - 1) / R) * R;
     const int nchunk = (rows + 511) / 512;
     uint4 *da_col = s_da8 + (size_t)wave * nchunk * 64;
@@ -1007,8 +1006,7 @@ DVO_DEV unsigned edt_finish32(const unsigned short *tg, int cols, int xx, int r,
 }
 
 template <int R>
-__global__ void __launch_bounds__(256)
-edt_rows_pk_kernel(const unsigned short *__restrict__ g, int rows, int cols, unsigned *__restrict__ d2, int *__restrict__ partial,
+DVO_DEV void edt_rows_pk_body(const int bx, const int gx, const int by, const unsigned short *__restrict__ g, int rows, int cols, unsigned *__restrict__ d2, int *__restrict__ partial,
                    unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags) {
     static_assert(R >= 2 && (R & 1) == 0, "two rows per lane");
     constexpr int RP = R / 2;                                  /* row pairs = dwords per tile column */
@@ -1017,10 +1015,10 @@ edt_rows_pk_kernel(const unsigned short *__restrict__ g, int rows, int cols, uns
     unsigned short *tg = reinterpret_cast<unsigned short *>(tq + (size_t)(cols + 2 * EDT_PK_PAD) * RP);     /* [cols][R]: g */
     __shared__ unsigned lbits[EDT_LBITS_WORDS];
     /* this workgroup's row block of g is one contiguous chunk, [cols][R] like the tile (rows past the image hold 0) */
-    const unsigned *gblk = reinterpret_cast<const unsigned *>(g + (size_t)blockIdx.y * edt_g_count(rows, cols, R) + (size_t)blockIdx.x * cols * R);
-    d2 += (size_t)blockIdx.y * edt_g_count(rows, cols, R) + (size_t)blockIdx.x * cols * R;      /* d2 too is written in row blocks */
-    unsigned *bm = bitmap + (size_t)blockIdx.y * bm_words;
-    const int y0 = blockIdx.x * R;
+    const unsigned *gblk = reinterpret_cast<const unsigned *>(g + (size_t)by * edt_g_count(rows, cols, R) + (size_t)bx * cols * R);
+    d2 += (size_t)by * edt_g_count(rows, cols, R) + (size_t)bx * cols * R;      /* d2 too is written in row blocks */
+    unsigned *bm = bitmap + (size_t)by * bm_words;
+    const int y0 = bx * R;
     const int totalp = cols * RP;
     for (int i = threadIdx.x; i < EDT_LBITS_WORDS; i += 256) lbits[i] = 0u;
     for (int i = threadIdx.x; i < EDT_PK_PAD * RP; i += 256) {
@@ -1111,13 +1109,13 @@ edt_rows_pk_kernel(const unsigned short *__restrict__ g, int rows, int cols, uns
     }
 
     const int m = block_reduce_256<true>((int)(mx > 0x7fffffffu ? 0x7fffffffu : mx));    /* d2 < 2^31 (rows + cols < 46340) */
-    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = m;
+    if (threadIdx.x == 0) partial[(size_t)by * gx + bx] = m;
     __syncthreads();
     for (int w = threadIdx.x; w < EDT_LBITS_WORDS && w < bm_words; w += 256) {
         const unsigned v = lbits[w];
         if (v && (__hip_atomic_load(bm + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v) atomicOr(bm + w, v);
     }
-    if (__syncthreads_or(far ? 1 : 0) && threadIdx.x == 0) atomicOr(flags + blockIdx.y, (int)EDT_FLAG_FAR);
+    if (__syncthreads_or(far ? 1 : 0) && threadIdx.x == 0) atomicOr(flags + by, (int)EDT_FLAG_FAR);
 }
 
 DVO_DEV int reflect101(int i, int n) { return (n == 1) ? 0 : (i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i)); }
@@ -1154,8 +1152,7 @@ constexpr int PK_W = PK_LC * 4 + 2, PK_H = PK_LR * DVO_P4_ROWS + 2;
 constexpr int PK_SMALL_WORDS = 2048;
 static_assert(PK_LC * 4 == 64 && (PK_LR * DVO_P4_ROWS) % 8 == 0 && 2 * PK_W + 2 * (PK_H - 2) <= 256, "the rank look-up walks the tile as 2 x 32 columns by groups of 8 rows, the halo in one step of 256 threads");
 template <int BM_WORDS>
-__global__ void __launch_bounds__(256)
-edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int R, int tiles_y, int strip, const int *__restrict__ partial, int n_partial,
+DVO_DEV void edt_rank_pack_body(const int bx, const int gx, const int by, const unsigned *__restrict__ d2, int rows, int cols, int R, int tiles_y, int strip, const int *__restrict__ partial, int n_partial,
                      const unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags,
                      unsigned *__restrict__ p4, size_t p4_stride, float2 *__restrict__ pal, int *__restrict__ pal_n, int first_pair,
                      const unsigned *__restrict__ unit_bits /* NULL, or per image: ~bits of the value of distance 1 (float images) */) {
@@ -1165,17 +1162,17 @@ edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int R,
     __shared__ int s_wave[4];
     __shared__ int s_max;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pair = first_pair + blockIdx.y;
-    d2 += (size_t)blockIdx.y * edt_g_count(rows, cols, R);      /* row blocks of R rows, like g */
-    partial += (size_t)blockIdx.y * n_partial;
-    const unsigned *bm = bitmap + (size_t)blockIdx.y * bm_words;
+    const int pair = first_pair + by;
+    d2 += (size_t)by * edt_g_count(rows, cols, R);      /* row blocks of R rows, like g */
+    partial += (size_t)by * n_partial;
+    const unsigned *bm = bitmap + (size_t)by * bm_words;
     p4 += (size_t)pair * p4_stride;
     pal += (size_t)pair * DVO_PAL_MAX;
-    const bool first_wg = blockIdx.x == 0;
+    const bool first_wg = bx == 0;
     const bool small = BM_WORDS == PK_SMALL_WORDS;
     if (rows < 2 || cols < 2) { if (first_wg && tid == 0 && small) pal_n[pair] = -(int)PAL_SHAPE; return; }
-    if (flags[blockIdx.y] & EDT_FLAG_BAD) { if (first_wg && tid == 0 && small) pal_n[pair] = -(int)PAL_BAD_VALUE; return; }
-    if (flags[blockIdx.y] & EDT_FLAG_FAR) { if (first_wg && tid == 0 && small) pal_n[pair] = -(int)PAL_FAR; return; }
+    if (flags[by] & EDT_FLAG_BAD) { if (first_wg && tid == 0 && small) pal_n[pair] = -(int)PAL_BAD_VALUE; return; }
+    if (flags[by] & EDT_FLAG_FAR) { if (first_wg && tid == 0 && small) pal_n[pair] = -(int)PAL_FAR; return; }
     int m = 0;
     for (int k = tid; k < n_partial; k += 256) { const int v = partial[k]; m = v > m ? v : m; }
     m = block_reduce_256<true>(m);
@@ -1204,7 +1201,7 @@ edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int R,
     __syncthreads();
     if (first_wg) {
         EdtScale sc = edt_scale(m2, rows, cols);
-        if (unit_bits) { sc.scale_f = unit_bits[blockIdx.y] ? __uint_as_float(~unit_bits[blockIdx.y]) : 0.0f; sc.shift_f = 0.0f; }
+        if (unit_bits) { sc.scale_f = unit_bits[by] ? __uint_as_float(~unit_bits[by]) : 0.0f; sc.shift_f = 0.0f; }
         for (int w = w0; w < w1; w++) {
             unsigned v = lbm[w];
             int r = lpre[w];
@@ -1223,7 +1220,7 @@ edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int R,
     const int tpc = p4_tiles_per_col(rows);
     const int n_tcols = (cols + 3) >> 2;
     const int n_strips = (tiles_y + strip - 1) / strip;
-    const int sy = blockIdx.x % n_strips, tcx = blockIdx.x / n_strips;
+    const int sy = bx % n_strips, tcx = bx / n_strips;
     const int tc0 = tcx * PK_LC, x0 = tc0 * 4 - 1;
     bool bad_step = false;
     /* A thread's share of a tile's pixels + one-pixel halo: 12 interior pixels and one of the halo.  d2 lies in row blocks of R
@@ -1288,7 +1285,7 @@ edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int R,
         }
         __syncthreads();
     }
-    if (__syncthreads_or(bad_step ? 1 : 0) && tid == 0) atomicOr(flags + blockIdx.y, (int)EDT_FLAG_STEP);
+    if (__syncthreads_or(bad_step ? 1 : 0) && tid == 0) atomicOr(flags + by, (int)EDT_FLAG_STEP);
     if (first_wg && tid == 0) pal_n[pair] = n_pal;               /* EDT_FLAG_STEP overrides it in the fallback launch */
 }
 
@@ -1298,8 +1295,7 @@ edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int R,
  * (one double sqrt per pixel); the lanes are then mapped so that 8 consecutive lanes write one whole 128-byte texel tile. */
 constexpr int NP_TY = 64, NP_TX = 16;
 static_assert(DVO_TILE_Y_LOG2 == 2 && DVO_TILE_X_LOG2 == 1, "the store mapping below assumes 4 x 2 texel tiles");
-__global__ void __launch_bounds__(256)
-dt_normalize_gradient_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int R, int tiles_y,
+DVO_DEV void dt_normalize_gradient_pack_body(const int bx, const int gx, const int by, const unsigned *__restrict__ d2, int rows, int cols, int R, int tiles_y,
                                   const int *__restrict__ partial, int n_partial,
                                   float4 *__restrict__ out, size_t tex_stride,
                                   int *__restrict__ pal_n /* NULL: every image */, const int *__restrict__ flags, int first_pair) {
@@ -1307,21 +1303,21 @@ dt_normalize_gradient_pack_kernel(const unsigned *__restrict__ d2, int rows, int
     __shared__ float sn[SW * SH];                            /* [x][y], halo 1 */
     __shared__ int s_max;
     if (pal_n) {                                             /* only the images the compact form could not hold */
-        const int pair = first_pair + blockIdx.y;
-        const bool step = (flags[blockIdx.y] & EDT_FLAG_STEP) != 0;
+        const int pair = first_pair + by;
+        const bool step = (flags[by] & EDT_FLAG_STEP) != 0;
         if (pal_n[pair] > 0 && !step) return;
-        if (step && blockIdx.x == 0 && threadIdx.x == 0) pal_n[pair] = -(int)PAL_STEP;   /* the other workgroups read the flag, not this */
+        if (step && bx == 0 && threadIdx.x == 0) pal_n[pair] = -(int)PAL_STEP;   /* the other workgroups read the flag, not this */
     }
-    d2 += (size_t)blockIdx.y * edt_g_count(rows, cols, R);      /* row blocks of R rows, like g */
-    partial += (size_t)blockIdx.y * n_partial;
-    out += (size_t)blockIdx.y * tex_stride;
+    d2 += (size_t)by * edt_g_count(rows, cols, R);      /* row blocks of R rows, like g */
+    partial += (size_t)by * n_partial;
+    out += (size_t)by * tex_stride;
     int m = 0;
     for (int k = threadIdx.x; k < n_partial; k += 256) { const int v = partial[k]; m = v > m ? v : m; }
     m = block_reduce_256<true>(m);
     if (threadIdx.x == 0) s_max = m;
     __syncthreads();
     const EdtScale sc = edt_scale((unsigned)s_max, rows, cols);
-    const int y0 = (blockIdx.x % tiles_y) * NP_TY, x0 = (blockIdx.x / tiles_y) * NP_TX;
+    const int y0 = (bx % tiles_y) * NP_TY, x0 = (bx / tiles_y) * NP_TX;
     for (int idx = threadIdx.x; idx < SW * SH; idx += 256) {
         const int lx = idx / SH, ly = idx - lx * SH;
         int yy = y0 + ly - 1, xx = x0 + lx - 1;
@@ -1347,6 +1343,72 @@ dt_normalize_gradient_pack_kernel(const unsigned *__restrict__ d2, int rows, int
             out[texel_index(yy, xx, tpc)] = make_float4(v, 0.5f * c[SH] - 0.5f * c[-SH], 0.5f * c[1] - 0.5f * c[-1], weight_of(v));
         }
     }
+}
+
+/* the kernels of the distance-transform stage: one level per launch ... */
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+edt_columns8_kernel(const unsigned char *__restrict__ edge, size_t edge_stride, int rows, int cols, int R, unsigned short *__restrict__ g,
+                    unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags) {
+    edt_columns8_body<WAVES>(blockIdx.x, gridDim.x, blockIdx.y, edge, edge_stride, rows, cols, R, g, bitmap, bm_words, flags);
+}
+template <int R>
+__global__ void __launch_bounds__(256)
+edt_rows_pk_kernel(const unsigned short *__restrict__ g, int rows, int cols, unsigned *__restrict__ d2, int *__restrict__ partial,
+                   unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags) {
+    edt_rows_pk_body<R>(blockIdx.x, gridDim.x, blockIdx.y, g, rows, cols, d2, partial, bitmap, bm_words, flags);
+}
+template <int BM_WORDS>
+__global__ void __launch_bounds__(256)
+edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int R, int tiles_y, int strip, const int *__restrict__ partial, int n_partial,
+                     const unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags,
+                     unsigned *__restrict__ p4, size_t p4_stride, float2 *__restrict__ pal, int *__restrict__ pal_n, int first_pair,
+                     const unsigned *__restrict__ unit_bits) {
+    edt_rank_pack_body<BM_WORDS>(blockIdx.x, gridDim.x, blockIdx.y, d2, rows, cols, R, tiles_y, strip, partial, n_partial, bitmap, bm_words, flags,
+                                 p4, p4_stride, pal, pal_n, first_pair, unit_bits);
+}
+__global__ void __launch_bounds__(256)
+dt_normalize_gradient_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int R, int tiles_y,
+                                  const int *__restrict__ partial, int n_partial, float4 *__restrict__ out, size_t tex_stride,
+                                  int *__restrict__ pal_n, const int *__restrict__ flags, int first_pair) {
+    dt_normalize_gradient_pack_body(blockIdx.x, gridDim.x, blockIdx.y, d2, rows, cols, R, tiles_y, partial, n_partial, out, tex_stride, pal_n, flags, first_pair);
+}
+
+/* ... and all pyramid levels per launch (see CannyLevels): the level table of the distance-transform stage.  One R (rows per
+ * workgroup of the row pass) and one workgroup shape of the column pass for all levels: those of the largest. */
+struct EdtLevels {
+    int n, R, first_pair;
+    int rows[DVO_LEVELS], cols[DVO_LEVELS], bm_words[DVO_LEVELS], n_partial[DVO_LEVELS], ptiles_y[DVO_LEVELS], strip[DVO_LEVELS], ntiles_y[DVO_LEVELS];
+    unsigned first[DVO_LEVELS + 1];
+    const unsigned char *edge[DVO_LEVELS]; size_t edge_stride[DVO_LEVELS];
+    unsigned short *g[DVO_LEVELS]; unsigned *d2[DVO_LEVELS]; int *partial[DVO_LEVELS]; unsigned *bitmap[DVO_LEVELS]; int *flags[DVO_LEVELS];
+    float4 *tex[DVO_LEVELS]; size_t tex_stride[DVO_LEVELS];
+    unsigned *p4[DVO_LEVELS]; size_t p4_stride[DVO_LEVELS]; float2 *pal[DVO_LEVELS]; int *pal_n[DVO_LEVELS];
+};
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) edt_columns8_levels_kernel(const EdtLevels t) {
+    const int l = level_of_block(t.first, t.n, blockIdx.x);
+    edt_columns8_body<WAVES>((int)(blockIdx.x - t.first[l]), (int)(t.first[l + 1] - t.first[l]), blockIdx.y, t.edge[l], t.edge_stride[l], t.rows[l], t.cols[l],
+                             t.R, t.g[l], t.bitmap[l], t.bm_words[l], t.flags[l]);
+}
+template <int R>
+__global__ void __launch_bounds__(256) edt_rows_pk_levels_kernel(const EdtLevels t) {
+    const int l = level_of_block(t.first, t.n, blockIdx.x);
+    edt_rows_pk_body<R>((int)(blockIdx.x - t.first[l]), (int)(t.first[l + 1] - t.first[l]), blockIdx.y, t.g[l], t.rows[l], t.cols[l], t.d2[l], t.partial[l],
+                        t.bitmap[l], t.bm_words[l], t.flags[l]);
+}
+template <int BM_WORDS>
+__global__ void __launch_bounds__(256) edt_rank_pack_levels_kernel(const EdtLevels t) {
+    const int l = level_of_block(t.first, t.n, blockIdx.x);
+    edt_rank_pack_body<BM_WORDS>((int)(blockIdx.x - t.first[l]), (int)(t.first[l + 1] - t.first[l]), blockIdx.y, t.d2[l], t.rows[l], t.cols[l], t.R,
+                                 t.ptiles_y[l], t.strip[l], t.partial[l], t.n_partial[l], t.bitmap[l], t.bm_words[l], t.flags[l],
+                                 t.p4[l], t.p4_stride[l], t.pal[l], t.pal_n[l], t.first_pair, nullptr);
+}
+__global__ void __launch_bounds__(256) dt_normalize_gradient_pack_levels_kernel(const EdtLevels t, int with_p4) {
+    const int l = level_of_block(t.first, t.n, blockIdx.x);
+    dt_normalize_gradient_pack_body((int)(blockIdx.x - t.first[l]), (int)(t.first[l + 1] - t.first[l]), blockIdx.y, t.d2[l], t.rows[l], t.cols[l], t.R,
+                                    t.ntiles_y[l], t.partial[l], t.n_partial[l], t.tex[l], t.tex_stride[l], with_p4 ? t.pal_n[l] : nullptr, t.flags[l],
+                                    t.first_pair);
 }
 
 /* compact form -> 16-byte texels {DT, gx, gy, w} of the images that have one (pal_n > 0), decoded exactly as the fused kernel
@@ -1481,6 +1543,100 @@ hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, Im
     const int tiles_y = (gb.rows + NP_TY - 1) / NP_TY, tiles_x = (gb.cols + NP_TX - 1) / NP_TX;
     hipLaunchKernelGGL(dt_normalize_gradient_pack_kernel, dim3(tiles_y * tiles_x, gb.count), dim3(256), 0, s, d2, gb.rows, gb.cols, R,
                        tiles_y, partial, (int)nblk, tex_out, tex_stride, p4 ? pal_n : nullptr, flags, first_pair);
+    return hipGetLastError();
+}
+
+/* launch_edges_to_now for all pyramid levels of the same `count` images at once: five launches (six when squared distances of
+ * 65536 and more are possible) instead of that many per level.  work: edt_levels_work_ints() ints; p4 all NULL or all set. */
+struct EdtLevelShape { int R, waves; size_t lds_cols, lds_rows; };
+static bool edt_levels_shape(int n, const int *rows, const int *cols, EdtLevelShape &sh) {
+    if (n < 2 || n > DVO_LEVELS) return false;
+    int r0 = 0, c0 = 0;
+    for (int l = 0; l < n; l++) { if (rows[l] < 2 || cols[l] < 2) return false; r0 = rows[l] > r0 ? rows[l] : r0; c0 = cols[l] > c0 ? cols[l] : c0; }
+    sh.R = edt_rows_per_block(c0);
+    if (sh.R < 2) return false;
+    const size_t lds_wave = (size_t)((r0 + 511) / 512) * 64 * sizeof(uint4);
+    sh.waves = (sh.R <= 8 && lds_wave * 8 <= 48 * 1024) ? 8 : ((lds_wave * 4 <= 48 * 1024) ? 4 : 0);
+    if (!sh.waves) return false;
+    sh.lds_cols = lds_wave * sh.waves;
+    sh.lds_rows = edt_pk_lds_bytes(c0, sh.R);
+    return true;
+}
+bool edt_levels_ok(int n, const int *rows, const int *cols) { EdtLevelShape sh; return edt_levels_shape(n, rows, cols, sh); }
+static size_t edt_level_ints(int rows, int cols, int R, int count) {
+    const size_t ng = edt_g_count(rows, cols, R);
+    return (((ng * count + 1) / 2 + 3) & ~(size_t)3) + ng * count + ((size_t)((rows + R - 1) / R) + (size_t)edt_bitmap_words(rows, cols) + 1) * count + 8;
+}
+size_t edt_levels_work_ints(int n, const int *rows, const int *cols, int count) {
+    EdtLevelShape sh;
+    if (!edt_levels_shape(n, rows, cols, sh)) return 0;
+    size_t t = 0;
+    for (int l = 0; l < n; l++) t += (edt_level_ints(rows[l], cols[l], sh.R, count) + 3) & ~(size_t)3;
+    return t + 64;
+}
+template <int R>
+static hipError_t edt_rows_pk_levels_launch(const EdtLevels &t, unsigned g, int count, size_t lds, hipStream_t s) {
+    auto kern = edt_rows_pk_levels_kernel<R>;
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(g, count), dim3(256), lds, s, t);
+    return hipGetLastError();
+}
+hipError_t launch_edges_to_now_levels(int n, const int *rows, const int *cols, const unsigned char *const *edge, const size_t *edge_stride, int count,
+                                      int *work, float4 *const *tex_out, const size_t *tex_stride, unsigned *const *p4, const size_t *p4_stride,
+                                      float2 *const *pal, int *const *pal_n, int first_pair, hipStream_t s) {
+    EdtLevelShape sh;
+    if (!edt_levels_shape(n, rows, cols, sh)) return hipErrorInvalidValue;
+    EdtLevels t;
+    t.n = n; t.R = sh.R; t.first_pair = first_pair;
+    const bool with_p4 = p4 && p4[0];
+    int *w = work;
+    int max_bm = 0;
+    for (int l = 0; l < n; l++) {
+        const size_t ng = edt_g_count(rows[l], cols[l], sh.R);
+        const int nblk = (rows[l] + sh.R - 1) / sh.R;
+        t.rows[l] = rows[l]; t.cols[l] = cols[l]; t.bm_words[l] = edt_bitmap_words(rows[l], cols[l]); t.n_partial[l] = nblk;
+        max_bm = t.bm_words[l] > max_bm ? t.bm_words[l] : max_bm;
+        t.edge[l] = edge[l]; t.edge_stride[l] = edge_stride[l];
+        t.g[l] = reinterpret_cast<unsigned short *>(w);
+        t.d2[l] = reinterpret_cast<unsigned *>(w) + (((ng * count + 1) / 2 + 3) & ~(size_t)3);
+        t.partial[l] = reinterpret_cast<int *>(t.d2[l] + ng * count);
+        t.bitmap[l] = reinterpret_cast<unsigned *>(t.partial[l] + (size_t)nblk * count);
+        t.flags[l] = reinterpret_cast<int *>(t.bitmap[l] + (size_t)t.bm_words[l] * count);
+        w += (edt_level_ints(rows[l], cols[l], sh.R, count) + 3) & ~(size_t)3;
+        t.tex[l] = tex_out[l]; t.tex_stride[l] = tex_stride[l];
+        t.p4[l] = with_p4 ? p4[l] : nullptr; t.p4_stride[l] = p4_stride[l]; t.pal[l] = pal[l]; t.pal_n[l] = pal_n[l];
+        const int pty = (p4_tiles_per_col(rows[l]) + PK_LR - 1) / PK_LR, ptx = (((cols[l] + 3) >> 2) + PK_LC - 1) / PK_LC;
+        long long strip = (long long)count * pty * ptx / 2048;
+        strip = strip < 1 ? 1 : (strip > pty ? pty : strip);
+        t.ptiles_y[l] = pty; t.strip[l] = (int)strip;
+        t.ntiles_y[l] = (rows[l] + NP_TY - 1) / NP_TY;
+    }
+    auto prefix = [&](auto blocks_of) { t.first[0] = 0; for (int l = 0; l < n; l++) t.first[l + 1] = t.first[l] + blocks_of(l); return t.first[n]; };
+    hipError_t e;
+    unsigned g = prefix([&](int l) { return (unsigned)((cols[l] + sh.waves - 1) / sh.waves); });
+    if (sh.waves == 8) hipLaunchKernelGGL(edt_columns8_levels_kernel<8>, dim3(g, count), dim3(512), sh.lds_cols, s, t);
+    else hipLaunchKernelGGL(edt_columns8_levels_kernel<4>, dim3(g, count), dim3(256), sh.lds_cols, s, t);
+    g = prefix([&](int l) { return (unsigned)t.n_partial[l]; });
+    switch (sh.R) {
+    case 16: e = edt_rows_pk_levels_launch<16>(t, g, count, sh.lds_rows, s); break;
+    case 8: e = edt_rows_pk_levels_launch<8>(t, g, count, sh.lds_rows, s); break;
+    case 4: e = edt_rows_pk_levels_launch<4>(t, g, count, sh.lds_rows, s); break;
+    default: e = edt_rows_pk_levels_launch<2>(t, g, count, sh.lds_rows, s); break;
+    }
+    if (e != hipSuccess) return e;
+    if (with_p4) {
+        g = prefix([&](int l) {
+            const int ptx = (((cols[l] + 3) >> 2) + PK_LC - 1) / PK_LC, n_strips = (t.ptiles_y[l] + t.strip[l] - 1) / t.strip[l];
+            return (unsigned)(n_strips * ptx);
+        });
+        hipLaunchKernelGGL(edt_rank_pack_levels_kernel<PK_SMALL_WORDS>, dim3(g, count), dim3(256), 0, s, t);
+        if (max_bm > PK_SMALL_WORDS) hipLaunchKernelGGL(edt_rank_pack_levels_kernel<DVO_EDT_BITMAP_BITS / 32>, dim3(g, count), dim3(256), 0, s, t);
+    }
+    g = prefix([&](int l) { return (unsigned)(t.ntiles_y[l] * ((cols[l] + NP_TX - 1) / NP_TX)); });
+    hipLaunchKernelGGL(dt_normalize_gradient_pack_levels_kernel, dim3(g, count), dim3(256), 0, s, t, with_p4 ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -175,6 +175,12 @@ hipError_t launch_count_edges(const unsigned char *edge, size_t n, int *out, hip
  * squared distances -- p4 / pal / pal_n are the level's slabs (indexed by pair), tex_out (already offset to first_pair) only
  * receives the 16-byte texels of images the compact form cannot hold (pal_n < 0 then).  p4 == NULL: 16-byte texels of every
  * image.  work: edt_work_ints() ints */
+/* launch_edges_to_now for all pyramid levels of the same images at once (dvo_frames.hip) */
+bool edt_levels_ok(int n, const int *rows, const int *cols);
+size_t edt_levels_work_ints(int n, const int *rows, const int *cols, int count);
+hipError_t launch_edges_to_now_levels(int n, const int *rows, const int *cols, const unsigned char *const *edge, const size_t *edge_stride, int count,
+                                      int *work, float4 *const *tex_out, const size_t *tex_stride, unsigned *const *p4, const size_t *p4_stride,
+                                      float2 *const *pal, int *const *pal_n, int first_pair, hipStream_t s);
 /* caller-supplied float images -> compact form (see dvo_frames.hip); work: float_level_work_ints() ints */
 size_t float_level_work_ints(int rows, int cols);
 hipError_t launch_float_level_to_compact(const float *dt, const float *gx, const float *gy, int rows, int cols, int *work,
