@@ -551,10 +551,20 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
             for (int l = 0; l < n_levels; l++) {
                 FrameLevel &F = c->fs.lv[l];
                 const size_t off = (size_t)(first_slot + k.b) * F.npx;
-                if (pass == 0 || ln.parallel)
+                if (ln.parallel || (pass == 0 && (l == 0 || n_levels == 2)))
                     HIPCHK(c, launch_camera_level(k.sb, b_img, depth_m ? k.sd : nullptr, npx, rows, cols, first_shift + l,
                                                   c->d_umap_xy, c->d_umap_frac, (flags & DVO_UPLOAD_DEPTH_RAW) ? 1 : 0,
                                                   F.grey + off, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, k.nc}, ln.s[l]));
+                else if (pass == 0 && l == 1) {                  /* levels 1 .. n-1 in one launch */
+                    int sh[DVO_LEVELS], lr2[DVO_LEVELS], lc2[DVO_LEVELS]; unsigned char *gl[DVO_LEVELS]; float *dl[DVO_LEVELS]; size_t st[DVO_LEVELS];
+                    for (int m = 1; m < n_levels; m++) {
+                        FrameLevel &G = c->fs.lv[m];
+                        sh[m - 1] = first_shift + m; lr2[m - 1] = G.rows; lc2[m - 1] = G.cols; st[m - 1] = G.npx;
+                        gl[m - 1] = G.grey + (size_t)(first_slot + k.b) * G.npx; dl[m - 1] = G.depth + (size_t)(first_slot + k.b) * G.npx;
+                    }
+                    HIPCHK(c, launch_camera_levels(k.sb, b_img, depth_m ? k.sd : nullptr, npx, rows, cols, n_levels - 1, sh, lr2, lc2, c->d_umap_xy,
+                                                   c->d_umap_frac, (flags & DVO_UPLOAD_DEPTH_RAW) ? 1 : 0, gl, dl, st, k.nc, c->stream));
+                }
                 if (pass == 1 && !ln.parallel && l == 0) {         /* one launch per stage for all levels */
                     if ((rc2 = run_canny_all(c, n_levels, first_slot + k.b, k.nc, c->stream))) return rc2;
                     if (now_first_pair >= 0 && (rc2 = frames_as_now_all(c, n_levels, first_slot + k.b, now_first_pair + k.b, k.nc, c->stream))) return rc2;

@@ -146,17 +146,16 @@ DVO_DEV void undistort_taps(int sx, int sy, int src_rows, int src_cols, size_t (
         }
 }
 constexpr int CAM_TY = 64, CAM_TX = 16;
-__global__ void __launch_bounds__(256)
-camera_level_kernel(const unsigned char *__restrict__ bgr, size_t bgr_stride,
+DVO_DEV void camera_level_body(const int bx, const int by, const unsigned char *__restrict__ bgr, size_t bgr_stride,
                     const float *__restrict__ depth_m, size_t depth_stride,
                     int src_rows, int src_cols, int shift, int tiles_y, UndistortMaps um,
                     unsigned char *__restrict__ grey, float *__restrict__ depth, size_t stride, int rows, int cols) {
     __shared__ unsigned char sg[CAM_TX][CAM_TY + 4];
     __shared__ float sd[CAM_TX][CAM_TY + 1];
-    bgr += (size_t)blockIdx.y * bgr_stride;
-    grey += (size_t)blockIdx.y * stride;
-    if (depth_m) { depth_m += (size_t)blockIdx.y * depth_stride; depth += (size_t)blockIdx.y * stride; }
-    const int y0 = (blockIdx.x % tiles_y) * CAM_TY, x0 = (blockIdx.x / tiles_y) * CAM_TX;
+    bgr += (size_t)by * bgr_stride;
+    grey += (size_t)by * stride;
+    if (depth_m) { depth_m += (size_t)by * depth_stride; depth += (size_t)by * stride; }
+    const int y0 = (bx % tiles_y) * CAM_TY, x0 = (bx / tiles_y) * CAM_TX;
 #pragma unroll
     for (int k = 0; k < CAM_TY * CAM_TX / 256; k++) {
         const int p = threadIdx.x + k * 256;
@@ -213,6 +212,28 @@ camera_level_kernel(const unsigned char *__restrict__ bgr, size_t bgr_stride,
             if (depth_m) depth[o] = sd[lx][ly];
         }
     }
+}
+
+__global__ void __launch_bounds__(256)
+camera_level_kernel(const unsigned char *__restrict__ bgr, size_t bgr_stride, const float *__restrict__ depth_m, size_t depth_stride,
+                    int src_rows, int src_cols, int shift, int tiles_y, UndistortMaps um,
+                    unsigned char *__restrict__ grey, float *__restrict__ depth, size_t stride, int rows, int cols) {
+    camera_level_body(blockIdx.x, blockIdx.y, bgr, bgr_stride, depth_m, depth_stride, src_rows, src_cols, shift, tiles_y, um, grey, depth, stride, rows, cols);
+}
+/* several pyramid levels of the same camera frames in one launch (see CannyLevels in the Canny section) */
+struct CameraLevels {
+    int n, src_rows, src_cols;
+    int shift[DVO_LEVELS], rows[DVO_LEVELS], cols[DVO_LEVELS];
+    unsigned first[DVO_LEVELS + 1];
+    unsigned char *grey[DVO_LEVELS]; float *depth[DVO_LEVELS]; size_t stride[DVO_LEVELS];
+};
+__global__ void __launch_bounds__(256)
+camera_levels_kernel(const unsigned char *__restrict__ bgr, size_t bgr_stride, const float *__restrict__ depth_m, size_t depth_stride,
+                     UndistortMaps um, const CameraLevels t) {
+    int l = 0;
+    while (l + 1 < t.n && blockIdx.x >= t.first[l + 1]) l++;
+    camera_level_body((int)(blockIdx.x - t.first[l]), blockIdx.y, bgr, bgr_stride, depth_m, depth_stride, t.src_rows, t.src_cols, t.shift[l],
+                      (t.rows[l] + CAM_TY - 1) / CAM_TY, um, t.grey[l], t.depth[l], t.stride[l], t.rows[l], t.cols[l]);
 }
 
 /* The full-resolution level of an undistortion-free camera frame (shift 0, no map: every pixel is read once): four pixels per
@@ -316,6 +337,22 @@ hipError_t launch_camera_level(const unsigned char *bgr, size_t bgr_stride, cons
     UndistortMaps um{umap_xy, umap_frac, depth_raw};
     hipLaunchKernelGGL(camera_level_kernel, dim3(tiles_y * tiles_x, g.count), dim3(256), 0, s, bgr, bgr_stride, depth_m,
                        depth_stride, src_rows, src_cols, shift, tiles_y, um, grey, depth_mm, stride, g.rows, g.cols);
+    return hipGetLastError();
+}
+/* levels first_level .. n-1 of the same camera frames in one launch (the full-resolution level keeps its own kernel) */
+hipError_t launch_camera_levels(const unsigned char *bgr, size_t bgr_stride, const float *depth_m, size_t depth_stride, int src_rows, int src_cols,
+                                int n, const int *shift, const int *rows, const int *cols, const short2 *umap_xy, const unsigned short *umap_frac,
+                                int depth_raw, unsigned char *const *grey, float *const *depth_mm, const size_t *stride, int count, hipStream_t s) {
+    if (n < 1 || n > DVO_LEVELS) return hipErrorInvalidValue;
+    CameraLevels t;
+    t.n = n; t.src_rows = src_rows; t.src_cols = src_cols;
+    t.first[0] = 0;
+    for (int l = 0; l < n; l++) {
+        t.shift[l] = shift[l]; t.rows[l] = rows[l]; t.cols[l] = cols[l]; t.grey[l] = grey[l]; t.depth[l] = depth_mm[l]; t.stride[l] = stride[l];
+        t.first[l + 1] = t.first[l] + (unsigned)(((rows[l] + CAM_TY - 1) / CAM_TY) * ((cols[l] + CAM_TX - 1) / CAM_TX));
+    }
+    UndistortMaps um{umap_xy, umap_frac, depth_raw};
+    hipLaunchKernelGGL(camera_levels_kernel, dim3(t.first[n], count), dim3(256), 0, s, bgr, bgr_stride, depth_m, depth_stride, um, t);
     return hipGetLastError();
 }
 

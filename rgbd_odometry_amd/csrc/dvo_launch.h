@@ -159,6 +159,9 @@ hipError_t launch_gather_images(const void *const *src, int count, void *dst, si
 hipError_t launch_camera_level(const unsigned char *bgr, size_t bgr_stride, const float *depth_m, size_t depth_stride,
                                int src_rows, int src_cols, int shift, const short2 *umap_xy, const unsigned short *umap_frac,
                                int depth_raw, unsigned char *grey, float *depth_mm, size_t stride, ImgBatch g, hipStream_t s);
+hipError_t launch_camera_levels(const unsigned char *bgr, size_t bgr_stride, const float *depth_m, size_t depth_stride, int src_rows, int src_cols,
+                                int n, const int *shift, const int *rows, const int *cols, const short2 *umap_xy, const unsigned short *umap_frac,
+                                int depth_raw, unsigned char *const *grey, float *const *depth_mm, const size_t *stride, int count, hipStream_t s);
 /* row f1: cv::Canny(grey, low/high as squared integer thresholds, 3, L2).  work: canny_work_ints() ints;
  * edge out: 0/255 u8 */
 size_t canny_work_ints(int rows, int cols, int count);
