@@ -589,8 +589,14 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
         if ((rc = issue_copy(0, cur))) return rc;
         for (int b = 0; b < count; b += chunk) {
             const bool more = b + chunk < count;
-            if (more && (rc = issue_copy(b + chunk, nxt))) return rc;
+            /* pull kernels (few workgroups, latency-bound on the link) go in ahead of the chunk's preprocessing and run beside
+             * it; DMA / blit copies submitted ahead would hold the preprocessing back instead (measured: 14.6 -> 22 ms per 256
+             * frames with depth), so they keep their place behind it */
+            static const int ahead_env = [] { const char *e = getenv("DVO_COPY_AHEAD"); return e ? atoi(e) : -1; }();
+            const bool ahead = ahead_env >= 0 ? ahead_env != 0 : pulled;
+            if (more && ahead && (rc = issue_copy(b + chunk, nxt))) return rc;
             if ((rc = issue_compute(cur))) return rc;
+            if (more && !ahead && (rc = issue_copy(b + chunk, nxt))) return rc;
             cur = nxt;
         }
         c->up_next = next_ub;
