@@ -481,3 +481,22 @@ def test_camera_and_pyramid_uploads_interleaved_over_the_landing_buffers(oracle)
             for l in range(3):
                 for x, y in zip(ctx.frame_level(n, l)[:2], want[2][l][:2]):
                     assert np.array_equal(x, y), (flags, "pyramid slot", l)
+
+
+def test_full_hd_frame_five_levels_through_the_level_tables(oracle):
+    """1920x1080, five levels: the one-launch-per-stage kernels with the row pass's LDS tile beyond 48 KB (function attribute),
+    level sizes that are not multiples of the tiles (1080 / 64, 135, 68 rows), pyramid, Canny and now levels against the oracle"""
+    bgr, depth = frame_gen.camera_frame(700, 1080, 1920)
+    pyr = oracle.build_pyramid(bgr, depth, 5, 0)
+    with _ctx() as ctx:
+        ctx.set_intrinsics(1575.0, 1575.0, 959.5, 539.5)
+        ctx.frames_reserve(1)
+        ctx.frames_upload_cameras([bgr], [depth], n_levels=5, first_shift=0, now_first_pair=0)
+        for l, (g, d16) in enumerate(pyr):
+            grey, dep, edge, _ = ctx.frame_level(0, l)
+            assert np.array_equal(grey, g), f"grey level {l}"
+            assert np.array_equal(dep, d16.astype(np.float32)), f"depth level {l}"
+            assert np.array_equal(edge, oracle.canny(g)), f"canny level {l}"
+            dt, gx, gy, _ = oracle.now_level_from_grey(g)
+            for got, want, what in zip(ctx.get_now_level(l), (dt, gx, gy), ("DT", "gx", "gy")):
+                assert np.array_equal(got, want), f"{what} level {l}"
