@@ -416,9 +416,10 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
          * not fit half the LDS (640x480x4x10, 1024 pairs: 510 k aligns/s with one 512-thread workgroup per CU, 593 k with two
          * of 256; 768 pairs 538 k vs 575 k, 384 pairs 403 k vs 453 k, 256 pairs 466 k vs 387 k -- so from 1.5 workgroups per CU) */
         else if (all_p4 && 2 * n_pairs >= 3 * c->n_cu && (size_t)max_n * 8 <= 2 * (size_t)77000) { block = 256; auto_lds = 80 * 1024; }
-        /* ... and, from 1.25 workgroups per CU on, for lists of any length (round 3; 1920x1080x5 with 4-byte streamed points:
+        /* ... and, as soon as there are more pairs than CUs, for lists of any length (round 3; 1920x1080x5 with 4-byte streamed points:
          * 512 pairs 79.3 k -> 80.4 k aligns/s, 1024 pairs 78.5 k -> 80.1 k, 2048 pairs 81.4 k -> 84.7 k = 0.405 of the roofline) */
-        else if (all_p4 && 4 * n_pairs >= 5 * c->n_cu) { block = 256; auto_lds = 80 * 1024; }   /* 320 pairs 53.1 k -> 58.5 k, 384: 62.8 -> 65.3 k, 448: 72.5 -> 74.3 k */
+        else if (all_p4 && n_pairs > c->n_cu) { block = 256; auto_lds = 80 * 1024; }   /* 320 pairs 53.1 k -> 58.5 k, 384: 62.8 -> 65.3 k, 448: 72.5 -> 74.3 k;
+                                                                                          640x480: 272 pairs 331 k -> 394 k, 288: 347 k -> 414 k (one round of 256-thread workgroups, all resident, instead of two of 512) */
         else if ((size_t)max_n * 12 > 4 * (size_t)155000 && !c->prm.interpolate_dt) { block = 1024; auto_lds = 155000; }   /* lists far beyond the LDS
                                                                        budget are streamed: 16 waves hide that better (1920x1080x5, 256 pairs: 38.3 k -> 41.3 k aligns/s) */
         else { block = 512; auto_lds = 155000; }
