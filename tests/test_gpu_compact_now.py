@@ -486,3 +486,30 @@ def test_float_images_in_device_memory_direct_build(oracle):
         assert all(ctx.now_compact_info(0, l) > 0 for l in range(3))
         _check(ctx, ref, iters)
         assert [ctx.level_texel_mode(0, l) for l in range(3)] == [2, 2, 2]
+
+
+def test_launch_shape_follows_the_number_of_pairs(oracle):
+    """policy (dvo_capi.cpp, enqueue): with compact now levels, up to one pair per CU a pair gets one 512-thread workgroup;
+    as soon as there are more pairs than CUs, 256-thread workgroups (two per CU, all resident in one round); results are the
+    oracle's in both shapes"""
+    import torch
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    sc = SynthScene(640, 480, 2, 21)              # a finest list that does not fit half a CU's LDS (shorter lists take 256 threads earlier)
+    iters = [5, 5]
+    ref = oracle.align_pyramid(iters, oracle_lib.scene_levels(sc, oracle), sc.intrinsics, np.eye(3), np.zeros(3))
+    for n, want_block in ((n_cu, 512), (n_cu + 1, 256)):
+        with DvoContext(n) as ctx:
+            ctx.set_intrinsics(*sc.intrinsics)
+            for l, L in enumerate(sc.levels):
+                ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols)
+                ctx.set_now_level_from_edges(l, (np.asarray(L.now_edge) != 0).astype(np.uint8) * 255, L.rows, L.cols)
+            ctx.replicate_pairs(1)
+            R, t = ctx.align_batch(iters, np.tile(np.eye(3), (n, 1, 1)), np.zeros((n, 3)))
+            block, team, packed = ctx.last_launch_shape()
+            assert (block, team, packed) == (want_block, 1, True), (n, block, team, packed)
+            for p in (0, n - 1):
+                assert rot_angle(ref["R"], R[p]) <= ROT_TOL and np.linalg.norm(ref["t"] - t[p]) <= TRANS_TOL
+                for l, rep in ref["levels"].items():
+                    e, b, ratio = ctx.level_report(p, l, iters[l])
+                    assert np.array_equal(e, rep["energy"]) and b == rep["best_idx"] and ratio == rep["visible_ratio"]
