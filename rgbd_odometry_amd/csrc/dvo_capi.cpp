@@ -78,11 +78,17 @@ int ensure_points(dvo_ctx *c, int level, int N) {
     float *np = nullptr;
     uint2 *ncp = nullptr;
     unsigned *nci = nullptr, *nc4 = nullptr, *nch = nullptr;
-    HIPCHK(c, hipMalloc((void **)&np, sizeof(float) * 3 * (size_t)new_cap * c->n_pairs));
-    HIPCHK(c, hipMalloc((void **)&ncp, sizeof(uint2) * (size_t)new_cap * c->n_pairs));
-    HIPCHK(c, hipMalloc((void **)&nci, sizeof(unsigned) * (size_t)new_cap * c->n_pairs));
-    HIPCHK(c, hipMalloc((void **)&nc4, sizeof(unsigned) * (size_t)new_cap * c->n_pairs));
-    HIPCHK(c, hipMalloc((void **)&nch, sizeof(unsigned) * (size_t)(new_cap / 64) * c->n_pairs));      /* new_cap % 256 == 0 */
+    {   /* all five or none: a failed allocation must not leak the ones before it */
+        hipError_t e = hipMalloc((void **)&np, sizeof(float) * 3 * (size_t)new_cap * c->n_pairs);
+        if (e == hipSuccess) e = hipMalloc((void **)&ncp, sizeof(uint2) * (size_t)new_cap * c->n_pairs);
+        if (e == hipSuccess) e = hipMalloc((void **)&nci, sizeof(unsigned) * (size_t)new_cap * c->n_pairs);
+        if (e == hipSuccess) e = hipMalloc((void **)&nc4, sizeof(unsigned) * (size_t)new_cap * c->n_pairs);
+        if (e == hipSuccess) e = hipMalloc((void **)&nch, sizeof(unsigned) * (size_t)(new_cap / 64) * c->n_pairs);      /* new_cap % 256 == 0 */
+        if (e != hipSuccess) {
+            (void)hipFree(np); (void)hipFree(ncp); (void)hipFree(nci); (void)hipFree(nc4); (void)hipFree(nch);
+            HIPCHK(c, e);
+        }
+    }
     if (!L.d_pt4_ok) {
         HIPCHK(c, hipMalloc((void **)&L.d_pt4_ok, sizeof(int) * (size_t)c->n_pairs));
         HIPCHK(c, hipMemsetAsync(L.d_pt4_ok, 0, sizeof(int) * (size_t)c->n_pairs, c->stream));
@@ -327,6 +333,18 @@ void stamp_outputs(dvo_ctx *c, const Schedule &sc, int first, int n) {
     if (!same_layout || c->sched_gen == 0) c->sched_gen++;
     if (c->pair_gen.empty()) c->pair_gen.assign(c->n_pairs, 0);
     for (int p = first; p < first + n; p++) c->pair_gen[p] = c->sched_gen;
+    if (c->final_list_gen.empty()) c->final_list_gen.assign(c->n_pairs, 0);
+    const Level &Lf = c->lv[sc.last_level];
+    for (int p = first; p < first + n; p++) {
+        const int dp = (sc.alias_mod > 0) ? p % sc.alias_mod : p;
+        c->final_list_gen[p] = Lf.list_gen.empty() ? 0 : Lf.list_gen[dp];
+    }
+}
+void ref_list_written(dvo_ctx *c, int level, int first, int n, int rows) {
+    Level &L = c->lv[level];
+    if (L.list_gen.empty()) { L.list_gen.assign(c->n_pairs, 0); L.pt4_rows.assign(c->n_pairs, 0); }
+    c->points_gen++;
+    for (int p = first; p < first + n; p++) { L.list_gen[p] = c->points_gen; L.pt4_rows[p] = rows; }
 }
 bool outputs_valid(const dvo_ctx *c, int pair) {
     return c->have_sched && !c->pair_gen.empty() && c->pair_gen[pair] == c->sched_gen;
@@ -445,6 +463,17 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         sc.force_exact = (c->prm.engine_variant == 3) ? 1 : 0;
         static const bool no_pt4_env = [] { const char *e = std::getenv("DVO_POINTS4"); return e && std::strcmp(e, "off") == 0; }();
         sc.no_pt4 = no_pt4_env ? 1 : 0;
+        /* pt4_decode rebuilds a point's pixel from its 16 x 16 block index with the number of block rows of the image the list was
+         * ENCODED against; the kernel only knows the now level's rows.  Reference and now levels of different heights (nothing
+         * forbids them) therefore read the 8-byte form, which carries absolute coordinates */
+        for (int l = 0; l < n_levels && !sc.no_pt4; l++) {
+            if (sc.iters[l] <= 0 || c->lv[l].pt4_rows.empty()) continue;
+            const Level &L = c->lv[l];
+            for (int p = first_pair; p < first_pair + n_pairs; p++) {
+                const int dp = sc.alias_mod > 0 ? p % sc.alias_mod : p;
+                if (L.pt4_rows[dp] != 0 && L.pt4_rows[dp] != L.rows) { sc.no_pt4 = 1; break; }
+            }
+        }
         sc.lds_points = bytes / (sc.compact ? 8 : 12);
         if (c->prm.lds_point_bytes < 0) { sc.lds_points = 0; sc.lds_bytes = 0; }
     }
@@ -793,7 +822,7 @@ static int set_ref_common(dvo_ctx *c, int pair, int level, const float *xyz, int
     HIPCHK(c, hipMemcpyAsync(dst, xyz, sizeof(float) * 3 * (size_t)N,
                              device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     L.hN[pair] = N;
-    c->points_gen++;
+    ref_list_written(c, level, pair, 1, 0);
     L.compact_ok[pair] = 0;                                         /* arbitrary X, Y: no 8-byte form */
     HIPCHK(c, hipMemsetAsync(L.d_pt4_ok + pair, 0, sizeof(int), c->stream));
     HIPCHK(c, hipMemcpyAsync(L.dN + pair, &L.hN[pair], sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -853,7 +882,7 @@ int dvo_set_ref_level_from_images(dvo_ctx *c, int pair, int level, const int32_t
     HIPCHK(c, launch_points4_build(L.cpts, L.dN, L.pt_cap, rows, L.cpt4, L.chdr, L.d_pt4_ok, pair, 1, c->stream));
     L.compact_ok[pair] = 1;
     L.hN[pair] = N;
-    c->points_gen++;
+    ref_list_written(c, level, pair, 1, rows);
     HIPCHK(c, hipMemcpyAsync(L.dN + pair, &L.hN[pair], sizeof(int), hipMemcpyHostToDevice, c->stream));
     const int ncopy = std::min(N, capacity);
     if (xyz_out && ncopy > 0)
@@ -1017,9 +1046,11 @@ int dvo_replicate_pairs(dvo_ctx *c, int n_src, int dst_first, int dst_count) {
         }
         HIPCHK(c, launch_replicate_level(any_tex16 ? L.tex : nullptr, L.tex_stride, L.pts, L.cpts, L.cidx, L.cpt4, L.chdr, L.d_pt4_ok, L.pt_cap, L.dN, n_src, dst_first, dst_count, c->stream));
         for (int p = dst_first; p < dst_first + dst_count; p++) {
-            L.hN[p] = L.hN[(p - dst_first) % n_src];
-            c->points_gen++;
-            L.compact_ok[p] = L.compact_ok[(p - dst_first) % n_src];
+            const int src = (p - dst_first) % n_src;
+            if (src == p) continue;                                 /* a source inside the destination range keeps its own list */
+            L.hN[p] = L.hN[src];
+            ref_list_written(c, l, p, 1, L.pt4_rows.empty() ? 0 : L.pt4_rows[src]);
+            L.compact_ok[p] = L.compact_ok[src];
         }
         /* the slots written: everything but the sources themselves (dst_first == 0: the range starts with them) */
         const int w_first = (dst_first == 0) ? std::min(n_src, dst_count) : dst_first;
@@ -1201,6 +1232,12 @@ int dvo_get_final_outputs(dvo_ctx *c, int pair, float *final_eps, float *final_r
         /* the packed kernel keeps them in the order of its compact point list; the reference's order (:703-704) is made here */
         const Level &L = c->lv[c->sched.last_level];
         const int dpair = (c->sched.alias_mod > 0) ? pair % c->sched.alias_mod : pair;
+        /* ... with the index of THAT list: if the pair's reference list was rewritten after the alignment (a key-frame switch, a
+         * replicate, a new dvo_set_ref_level*) the index now describes other points and the outputs cannot be put in order any more */
+        const unsigned long long now_gen = L.list_gen.empty() ? 0 : L.list_gen[dpair];
+        if (c->final_list_gen.empty() || c->final_list_gen[pair] != now_gen || N != L.hN[dpair])
+            return fail(c, DVO_ERR_STATE, "the reference list of pair " + std::to_string(pair) + " was replaced after its alignment: the final "
+                                          "outputs of that alignment are gone (fetch them before installing a new reference, or align again)");
         int rc = ensure_staging(c, sizeof(float) * 4 * (size_t)N);
         if (rc) return rc;
         HIPCHK(c, launch_final_permute(L.cidx + (size_t)dpair * L.pt_cap, src_e, src_r, N, c->staging, c->staging + N, c->stream));

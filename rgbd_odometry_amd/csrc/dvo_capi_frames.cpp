@@ -336,7 +336,10 @@ int dvo_frames_upload_pyramids(dvo_ctx *c, int first_slot, int count, int n_leve
          * images (the reference's 320x240 ... 40x30 levels: eight per frame): those are gathered into the pinned mirror
          * of the landing buffer with memcpy and go up in one copy per run of small levels; big images go up directly. */
         unsigned char *hbuf = c->up_host[ub];
-        if (c->up_used[ub] && !mapped) HIPCHK(c, hipEventSynchronize(c->ev_copied[ub]));      /* the mirror's previous copy has left */
+        if (c->up_used[ub] && !mapped) {      /* the mirror's previous copies have left: both queues (the cameras path sends its depth half on the second) */
+            HIPCHK(c, hipEventSynchronize(c->ev_copied[ub]));
+            HIPCHK(c, hipEventSynchronize(c->ev_copied2[ub]));
+        }
         bool small[DVO_LEVELS];
         for (int l = 0; l < n_levels && mapped; l++) {      /* one gather launch per level and 32 images, grey and depth on the two copy streams */
             const size_t npx = c->fs.lv[l].npx, gb = pix_bytes(grey[l].dtype), db = depth ? pix_bytes(depth[l].dtype) : 0;
@@ -538,6 +541,7 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
         HIPCHK(c, hipEventRecord(c->ev_copied[k.ub], c->copy_stream));
         HIPCHK(c, hipEventRecord(c->ev_copied2[k.ub], c->copy_stream2));
         c->up_used[k.ub] = true;                            /* from here on the buffer has a pending ev_copied and, soon, ev_done */
+        c->up_next = k.ub ^ 1;                              /* committed per chunk: an error further down leaves events and turn consistent */
         return DVO_OK;
     };
     auto issue_compute = [&](const Chunk &k) -> int {
@@ -739,7 +743,7 @@ int dvo_frames_as_ref(dvo_ctx *c, int first_slot, int first_pair, int count, int
                                       L.dN + first_pair, c->stream));
         HIPCHK(c, launch_points4_build(L.cpts, L.dN, L.pt_cap, F.rows, L.cpt4, L.chdr, L.d_pt4_ok, first_pair, count, c->stream));
         for (int i = 0; i < count; i++) { L.hN[first_pair + i] = hN[(size_t)l * count + i]; L.compact_ok[first_pair + i] = 1; }
-        c->points_gen++;
+        ref_list_written(c, l, first_pair, count, F.rows);
     }
     if (bad_level >= 0)
         return fail(c, DVO_ERR_INVALID, "no reference point selected in frame " + std::to_string(first_slot + bad_frame) +

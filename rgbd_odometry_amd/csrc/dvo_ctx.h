@@ -30,6 +30,11 @@ struct Level {
     unsigned *chdr = nullptr;       /* per chunk of 64 points: linear block index of its first point; pt_cap / 64 per pair */
     int *d_pt4_ok = nullptr;        /* per pair: the 4-byte list decodes to the 8-byte one bit for bit (written by the builder) */
     std::vector<char> compact_ok;   /* per pair: the list came from the engine's enlist kernels */
+    /* per pair: a stamp that changes whenever the pair's reference list is rewritten (ref_list_written).  The packed kernel stores
+     * its final outputs in the order of the compact list; the getter permutes them with cidx and must not do so with the index of a
+     * list written after the launch */
+    std::vector<unsigned long long> list_gen;
+    std::vector<int> pt4_rows;      /* per pair: image rows the 4-byte twin of the list was encoded against (pt4_decode needs the same) */
     int pt_cap = 0;
     int *dN = nullptr;
     std::vector<int> hN;            /* 0 = not set */
@@ -153,6 +158,7 @@ struct dvo_ctx {
      * the buffers were re-allocated) has nothing valid to report */
     int sched_gen = 0;
     std::vector<int> pair_gen;      /* per pair: sched_gen of the enqueue that last aligned it (0 = never) */
+    std::vector<unsigned long long> final_list_gen;   /* per pair: list_gen of the finest level's list the last enqueue aligned */
     std::string err;
 };
 
@@ -219,6 +225,9 @@ int check_ready(dvo_ctx *c, int pair, int level);
 int build_schedule(dvo_ctx *c, int n_levels, const int *iters, int flags, dvo::Schedule &sc);
 int ensure_outputs(dvo_ctx *c, const dvo::Schedule &sc);
 void stamp_outputs(dvo_ctx *c, const dvo::Schedule &sc, int first, int n);
+/* the reference lists of pairs [first, first + n) of a level were (re)written: bumps points_gen and the pairs' list stamps;
+ * rows > 0: the rows of the image their 4-byte twins were encoded against (0: no valid 4-byte twin) */
+void ref_list_written(dvo_ctx *c, int level, int first, int n, int rows);
 void tiled_forget(dvo_ctx *c);
 void photo_forget(dvo_ctx *c);           /* dvo_capi_photo.cpp */          /* dvo_capi_tiled.cpp: drop the RCCL attachment of a context */
 

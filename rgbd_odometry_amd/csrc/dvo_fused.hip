@@ -899,6 +899,14 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
                 accumulate_points2<BLOCK, true, TEX_G16>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
                 accumulate_points2<BLOCK, false, TEX_G16>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);       /* beyond the LDS budget */
             }
+            {   /* A lane without a visible point keeps its coordinates (round2_issue): its gradient, weight and residual are exact
+                 * zeros, so it adds exact zeros -- unless one of its coordinate products overflowed (a point a hair off the camera
+                 * plane, an absurd pose): 0 * inf = NaN would then sit in the lane's sums.  NaN and inf are sticky in a sum, so one
+                 * test per iteration catches it: such a wave redoes its share with the literal scalar code, which skips invisible
+                 * points like the reference does (:371).  (seven additions and a compare per iteration, not per round.) */
+                const double chk = ((a.g[0] + a.g[1]) + (a.g[2] + a.g[3])) + ((a.g[4] + a.g[5]) + a.e2);
+                any_odd |= (__builtin_amdgcn_ballot_w64(!__builtin_isfinite(chk)) != 0ull);
+            }
             if (any_odd || sc.force_exact) {      /* wave-uniform; a point with a degenerate z: this wave's share again, literal divisions */
                 acc7_zero(a);
                 const float2 *pal_lds = reinterpret_cast<const float2 *>(lds_dyn);

@@ -181,6 +181,65 @@ def test_degenerate_depth_takes_the_exact_fallback(oracle):
                 assert _same(ref["final_eps"], got["final_eps"]) and _same(ref["final_reproj"], got["final_reproj"])
 
 
+def test_overflowing_invisible_point_takes_the_exact_fallback(oracle):
+    """a point whose z is tiny but INSIDE the range of the fast reciprocal (1e-37) gets coordinates so large that
+    s*fx*x/z overflows: the point is not visible (u = inf), but in the packed loop -- which keeps the coordinates of invisible
+    lanes -- 0 * inf = NaN would reach the lane's sums.  The per-iteration finiteness test sends such a wave through the
+    literal scalar code, which skips the point like the reference (:371): same bits as the oracle, finite energies."""
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    sc = SynthScene(320, 240, 3, 21)
+    lv = oracle_lib.scene_levels(sc, oracle)
+    with DvoContext(1) as ctx:
+        ctx.set_intrinsics(*sc.intrinsics)
+        lists = _load(ctx, sc)
+        level = 0
+        xyz = np.asarray(lists[level]).reshape(-1, 3)
+        for idx in (1, len(xyz) // 3):
+            t0 = xyz[idx].astype(np.float64)
+            t0[0] = float(np.float32(t0[0]) - np.float32(0.25))        # d0 = 0.25 (float-exactly), d1 = d2 = 0
+            R0 = np.eye(3)
+            R0[0, 2] = 1e-36                                            # p2 = cR(0,2) * d0 = 2.5e-37: tiny, yet a normal float
+            L = lv[level]
+            ref = oracle.run_iterations(level, 5, L["xyz"], L["dt"], L["gx"], L["gy"], L["rows"], L["cols"], sc.intrinsics, R0, t0)
+            got = ctx.run_iterations(level, 5, R0, t0)
+            assert np.all(np.isfinite(ref["energy"])) and np.all(np.isfinite(got["energy"]))
+            assert ctx.level_exact_fallback(0, level)
+            assert _same(ref["energy"], got["energy"]), (idx, ref["energy"], got["energy"])
+            assert ref["best_idx"] == got["best_idx"] and ref["visible_ratio"] == got["visible_ratio"]
+            assert _same(ref["final_eps"], got["final_eps"]) and _same(ref["final_reproj"], got["final_reproj"])
+
+
+def test_final_outputs_refused_after_the_reference_list_was_replaced(oracle):
+    """the packed kernel stores finalEpsilons / finalReprojections in the order of its compact point list and the
+    getter permutes them with that list's index.  Once the pair's reference list has been rewritten (a key-frame switch, a new
+    dvo_set_ref_level*) that index describes other points: the getter must refuse, not hand out scrambled values; other pairs
+    and a fresh alignment are unaffected."""
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    from rgbd_odometry_amd.capi import DVO_FLAG_FINAL_OUTPUTS, DvoError, DVO_ERR_STATE
+    a, b = SynthScene(320, 240, 3, 31), SynthScene(320, 240, 3, 32)
+    iters = [5, 5, 5]
+    with DvoContext(2) as ctx:
+        ctx.set_intrinsics(*a.intrinsics)
+        _load(ctx, a, pair=0)
+        _load(ctx, b, pair=1)
+        ref_a = _check(ctx, oracle, a, oracle_lib.scene_levels(a, oracle), iters, pair=0)
+        n0 = len(ref_a["levels"][0]["final_eps"])
+        ctx.align_batch(iters, np.tile(np.eye(3), (2, 1, 1)), np.zeros((2, 3)), flags=DVO_FLAG_FINAL_OUTPUTS)
+        feps1, _ = ctx.final_outputs(1, 1 << 17)
+        # pair 0 gets another reference list (scene b's) at the finest level AFTER the alignment
+        L = b.levels[0]
+        ctx.set_ref_level_from_images(0, L.ref_edge, L.ref_depth, L.rows, L.cols, pair=0)
+        with pytest.raises(DvoError) as ei:
+            ctx.final_outputs(0, n0)
+        assert ei.value.code == DVO_ERR_STATE and "replaced" in str(ei.value)
+        feps1b, _ = ctx.final_outputs(1, 1 << 17)               # the other pair's outputs are still there
+        assert np.array_equal(feps1, feps1b)
+        # a fresh alignment of pair 0 (ref of b against now of a: nothing to compare with, but it must come back whole)
+        ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)), first_pair=0, n_pairs=1, flags=DVO_FLAG_FINAL_OUTPUTS)
+        fe, fr = ctx.final_outputs(0, 1 << 17)
+        assert len(fe) == ctx._N[(0, 0)] and np.all(np.isfinite(fe)) and np.all(fr[:, 2] > 0.99)
+
+
 def test_config4_batch_of_distinct_640x480_pairs(oracle):
     """BASELINE configs[3] at its per-GPU share: 32 DISTINCT 640x480 pairs in one launch (compact lists, packed kernel),
     every pair checked against its own oracle run"""
