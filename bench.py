@@ -50,7 +50,8 @@ def keep_host_memory_mapped():
     except Exception:
         pass
 
-HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak ~6290
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_COPY_GBPS = 6290.0      # measured float4 copy (same guide): what a streaming kernel reaches
 
 #: the sources the fused alignment kernels are built from: their hash ties profiles/pmc_traffic.json to a kernel build
 KERNEL_SOURCES = ["dvo_fused.hip", "dvo_point_pk.h", "dvo_palette.h", "dvo_kernels.hip", "dvo_kernel_common.h", "dvo_device_math.h"]
@@ -387,7 +388,8 @@ def main_batch(args):
                     "ranks from the integer squared distances; no re-encoding pass exists, 16-byte texels are never written)")
     out = {
         "metric": "frame-pair aligns/sec (%dx%d, %d-lvl pyr)" % (args.width, args.height, args.levels),
-        "value": value, "unit": "aligns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "aligns/s", "n_gpus": world, "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if total_pairs > 0 else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
@@ -426,19 +428,23 @@ def main_batch(args):
         out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
         out["roofline"]["traffic_source"] = rec.get("source")
         side = rec["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
-        out["roofline"]["hbm_side"] = {"GBps": side, "frac_of_peak": side / HBM_PEAK_GBPS,
+        out["roofline"]["hbm_side"] = {"GBps": side, "frac_of_peak": side / HBM_PEAK_GBPS, "frac_of_measured_copy_peak": side / HBM_COPY_GBPS,
                                        "traffic_over_algorithmic": rec["hbm_bytes_per_launch"] / bytes_per_launch,
-                                       "note": "PMC FETCH_SIZE + WRITE_SIZE per launch / live kernel time: the bandwidth the launch really drew"}
+                                       "read_bytes": rec.get("fetch_bytes"), "write_bytes": rec.get("write_bytes"),
+                                       "fetch_size_as_reported_bytes": rec.get("fetch_size_as_reported_bytes"),
+                                       "note": "what the launch really drew from HBM / the Infinity Cache: TCC_EA0_RDREQ x 128 B (every L2 -> fabric "
+                                               "read request is a whole 128-byte line on gfx950, gathers included: profiles/r04_line_fetch; FETCH_SIZE "
+                                               "tallies them at 64 B) + WRITE_SIZE, per launch / live kernel time"}
         if rec.get("l2_read_requests"):
-            # the ceiling this kernel actually sits at: L2 -> fabric read requests
             rate = rec["l2_read_requests"] / (kernel_ms * 1e-3) / 1e9
             out["roofline"]["request_rate"] = {
-                "achieved_G_req_per_s": rate, "calibrated_ceiling_G_req_per_s": [44.0, 50.0],
+                "achieved_G_lines_per_s": rate, "calibrated_ceiling_G_lines_per_s": [44.0, 50.0],
                 "frac_of_ceiling": rate / 47.0,
                 "requests_per_alignment": rec["l2_read_requests"] / args.batch,
                 "l2_hit_rate": (rec.get("l2_hits", 0) / rec["l2_requests"]) if rec.get("l2_requests") else None,
-                "note": "TCC_EA0_RDREQ per launch (PMC profile) / live kernel time; ceiling measured by "
-                        "tools/exhaustive/fetch_calib.hip (profiles/r01_fetch_size_calibration), same for 64- and 128-byte requests",
+                "note": "TCC_EA0_RDREQ per launch (PMC profile) / live kernel time.  The ceiling (tools/exhaustive/fetch_calib.hip, "
+                        "profiles/r01_fetch_size_calibration: 44-50 G requests/s for streams and sparse gathers alike) is the HBM bandwidth "
+                        "itself: 128 B per request = 5.6-6.4 TB/s",
             }
     else:
         out["roofline"]["traffic_reason"] = reason
@@ -601,7 +607,7 @@ def main_tiled(args):
     achieved = bytes_launch / (acc_ms * 1e-3) / 1e9
     out = {
         "metric": "frame-pair aligns/sec (%dx%d, %d-lvl pyr)" % (args.width, args.height, args.levels),
-        "value": value, "unit": "aligns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "aligns/s", "n_gpus": world, "rccl_ranks": comm.count(), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
@@ -648,8 +654,39 @@ def main_tiled(args):
         dist.destroy_process_group()
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: THIS process -- which has made no GPU call and never will
+    -- starts `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a child process, relays its output
+    (rank 0's JSON line) and its return code.  Under a launcher (WORLD_SIZE set) nothing is started: the process IS a rank, and
+    WORLD_SIZE must then agree with --gpus.  Returns only when this process should run a rank itself."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but the launcher set WORLD_SIZE=%s: start as many ranks as GPUs are asked for "
+                             "(python -m torch.distributed.run --nproc-per-node %d ... bench.py --gpus %d)\n" % (args.gpus, world_env, args.gpus, args.gpus))
+            sys.exit(2)
+        return
+    if args.gpus <= 1:
+        return
+    n_dev = torch.cuda.device_count()           # counts devices without initialising the GPU (no HIP context in this process)
+    if n_dev < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing to print a %d-GPU line from fewer GPUs\n" % (args.gpus, n_dev, args.gpus))
+        sys.exit(3)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this driver
+    proc = subprocess.run(cmd, env=env)                      # a child process, never exec: stdout / stderr are inherited
+    sys.exit(proc.returncode)
+
+
 def main():
     args = parse_args()
+    launch_ranks(args)
     keep_host_memory_mapped()
     if args.mode == "tiled":
         main_tiled(args)

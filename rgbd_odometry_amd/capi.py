@@ -107,6 +107,15 @@ class RcclComm:
         self.comm = self.comm.value
         self.rank, self.world = rank, world
 
+    def count(self) -> int:
+        """ncclCommCount: the number of ranks RCCL itself says this communicator has"""
+        n = C.c_int(0)
+        self.lib.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        rc = self.lib.ncclCommCount(C.c_void_p(self.comm), C.byref(n))
+        if rc != 0:
+            raise RuntimeError("ncclCommCount failed: %d" % rc)
+        return n.value
+
     def close(self):
         if self.comm:
             self.lib.ncclCommDestroy(C.c_void_p(self.comm))

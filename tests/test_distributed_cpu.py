@@ -160,3 +160,20 @@ def test_batch_mode_sharding_covers_all_pairs():
         assert (owners[f:f + c] == -1).all()
         owners[f:f + c] = r
     assert (owners >= 0).all()
+
+
+def test_bench_gpus_flag_is_checked_before_anything_runs():
+    """`bench.py --gpus N` must never print an N-GPU line from fewer GPUs: without a launcher it refuses when
+    fewer than N devices are visible; under a launcher WORLD_SIZE has to agree with --gpus.  Neither path touches a GPU."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box could really run two ranks: covered by tests/test_gpu_tiled_ranks.py")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 3 and "device(s) visible" in r.stderr and "{" not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr and "{" not in r.stdout

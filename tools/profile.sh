@@ -26,5 +26,5 @@ python3 tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # keep what profiles/ keeps (summary, kernel stats, the profiled bench line); the raw per-dispatch CSVs are tens of megabytes
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/trace_kernel_stats.csv 2>/dev/null
-tail -1 $OUT/trace.log > $OUT/bench_line_profiled.json
+grep '^{' $OUT/trace.log | tail -1 > $OUT/bench_line_profiled.json      # the bench's JSON line (rocprofv3 writes its own log lines after it)
 [ -z "${KEEP_RAW:-}" ] && rm -rf $OUT/trace $OUT/pmc[0-9]*

@@ -5,8 +5,10 @@ Run on the GPU box (python3 tools/update_pmc_traffic.py [tag]).  Three separate,
 WRITE_SIZE, TCC_EA0_RDREQ + TCC hit/req) over `bench.py --steps 3`, as MI355X_MICROARCH.md prescribes (counters in
 their own runs, --kernel-trace only).  The record carries the hash of the kernel sources (bench.kernel_source_hash), so
 bench.py reports `traffic: null` instead of a stale number once the kernel changes.
-FETCH_SIZE is used as reported: for this kernel's sparse 16-byte gathers it was calibrated exact
-(profiles/r01_fetch_size_calibration); the guide's x2 correction applies to wide coalesced streaming reads only.
+Read bytes = TCC_EA0_RDREQ x 128: on gfx950 EVERY L2 -> fabric read request is a whole 128-byte line, for sparse gathers as
+for streams (round 4, tools/exhaustive/line_fetch.hip, profiles/r04_line_fetch: the other half of a line fetched for one
+4-byte load is an L2 hit), while FETCH_SIZE tallies every request at 64 bytes.  FETCH_SIZE is kept in the record as reported
+(rounds 1-3 took it at face value: half the real read traffic).
 """
 import csv
 import glob
@@ -17,7 +19,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 extra = sys.argv[2:]          # extra bench.py arguments, e.g. --batch 1024 (the record key follows them)
 out_dir = os.path.join(ROOT, "gpurun_out", "pmc_traffic_" + tag)
 os.makedirs(out_dir, exist_ok=True)
@@ -38,14 +40,16 @@ for name, cnt in groups.items():
 avg = {k: sum(v) / len(v) for k, v in vals.items()}
 print(avg)
 import bench
-fetch, write = avg["FETCH_SIZE"] * 1024.0, avg["WRITE_SIZE"] * 1024.0      # rocprofv3 reports KiB
+fetch_reported, write = avg["FETCH_SIZE"] * 1024.0, avg["WRITE_SIZE"] * 1024.0      # rocprofv3 reports KiB
+fetch = avg["TCC_EA0_RDREQ_sum"] * 128.0       # whole lines (see the module docstring)
 rec = {
     "hbm_bytes_per_launch": int(fetch + write), "fetch_bytes": int(fetch), "write_bytes": int(write),
+    "fetch_size_as_reported_bytes": int(fetch_reported),
     "l2_read_requests": int(avg["TCC_EA0_RDREQ_sum"]), "l2_requests": int(avg.get("TCC_REQ_sum", 0)), "l2_hits": int(avg.get("TCC_HIT_sum", 0)),
     "kernel_source_sha256": bench.kernel_source_hash(),
     "source": ("tools/update_pmc_traffic.py %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_EA0_RDREQ, separate passes over bench.py "
-               "--steps 3 %s; FETCH_SIZE calibrated for sparse 16-byte gathers in profiles/r01_fetch_size_calibration: exact, no 2x "
-               "correction)") % (tag, " ".join(extra)),
+               "--steps 3 %s; read bytes = TCC_EA0_RDREQ x 128: every L2 -> fabric read is a whole line, profiles/r04_line_fetch; "
+               "FETCH_SIZE tallies them at 64 bytes)") % (tag, " ".join(extra)),
 }
 path = os.path.join(ROOT, "gpurun_out", "pmc_traffic.json")
 allrec = {}
