@@ -692,6 +692,9 @@ def main():
         main_tiled(args)
     else:
         main_batch(args)
+    if os.environ.get("DVO_DUMP_MAPS"):       # diagnostics (tools/experiments/r04_exit_segv.sh): which library owns an address of a crash at exit
+        with open("/proc/self/maps") as f:
+            sys.stderr.write("".join(l for l in f if " r-xp " in l))
 
 
 if __name__ == "__main__":

@@ -1014,12 +1014,31 @@ static hipError_t launch_fused2_b(const LevelSet &lv, const Schedule &sc, const 
         if ((e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)) != hipSuccess) return e;
         const int grid = (sc.team > DVO_TEAM_MAX) ? sc.team : 8 * ((n_pairs + 7) / 8) * sc.team;
         /* The members of a team wait for each other inside the kernel, so ALL workgroups of the launch must be resident at
-         * once.  A cooperative launch makes the runtime guarantee exactly that -- or refuse the launch (the host then runs the
-         * batch without teams) -- whatever else the process has on the GPU: another context, another stream, a kernel of
-         * the caller's holding LDS.  (DVO_TEAM_PLAIN_LAUNCH=1: the plain launch of round 2, for A/B measurements; a team
-         * that is not co-resident then ends in the bounded spin's error flag.) */
-        static const bool plain = std::getenv("DVO_TEAM_PLAIN_LAUNCH") != nullptr;
-        if (plain) {
+         * once.  The engine checks that itself -- the grid against what the occupancy query says the device can hold of THIS
+         * kernel with THIS much LDS, which is all hipLaunchCooperativeKernel checks (MI355X_MICROARCH.md, residency and
+         * cooperative launch: plain and cooperative launches have identical residency) -- and refuses the launch otherwise
+         * (the host then runs the batch without teams).  A member that still finds itself alone (another process or stream
+         * holding compute units) ends in the bounded spin's error flag, which every output getter reports.
+         * Round 3 made the launch itself cooperative; round 4 went back to a plain launch behind the same check because
+         * (1) ROCm 7.2 kills any process that made ONE cooperative launch inside the HIP runtime's own exit handler when it runs
+         * under rocprofv3 (reproduced with examples/solve_dvo_demo.cpp against the system runtime, no engine resource alive:
+         * tools/experiments/r04_exit_segv*.sh), and (2) it cost 0.03 ms of every 0.3 ms small-batch
+         * step.  DVO_TEAM_COOP_LAUNCH=1 brings the cooperative launch back for A/B measurements. */
+        {   /* the answer only depends on (device, dynamic LDS): asked once per thread and shape, not per launch */
+            struct Seen { int dev = -1; size_t dyn = 0; long long limit = 0; };
+            thread_local Seen seen;
+            int dev = 0;
+            if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+            if (seen.dev != dev || seen.dyn != dyn) {
+                int per_cu = 0, n_cu = 0;
+                if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, BLOCK, dyn)) != hipSuccess) return e;
+                if ((e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+                seen.dev = dev; seen.dyn = dyn; seen.limit = (long long)per_cu * n_cu;
+            }
+            if ((long long)grid > seen.limit) return hipErrorCooperativeLaunchTooLarge;
+        }
+        static const bool coop = std::getenv("DVO_TEAM_COOP_LAUNCH") != nullptr;
+        if (!coop) {
             hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), dyn, s, lv, sc, K, prm, out, first_pair);
         } else {
             LevelSet a0 = lv; Schedule a1 = sc; Intrinsics a2 = K; DevParams a3 = prm; Outputs a4 = out; int a5 = first_pair;

@@ -198,7 +198,7 @@ def test_overflowing_invisible_point_takes_the_exact_fallback(oracle):
             t0 = xyz[idx].astype(np.float64)
             t0[0] = float(np.float32(t0[0]) - np.float32(0.25))        # d0 = 0.25 (float-exactly), d1 = d2 = 0
             R0 = np.eye(3)
-            R0[0, 2] = 1e-36                                            # p2 = cR(0,2) * d0 = 2.5e-37: tiny, yet a normal float
+            R0[0, 2] = 2e-37                                            # p2 = cR(0,2) * d0 = 5e-38: tiny, yet a normal float; x/z = 5e36, s*fx*x/z = inf
             L = lv[level]
             ref = oracle.run_iterations(level, 5, L["xyz"], L["dt"], L["gx"], L["gy"], L["rows"], L["cols"], sc.intrinsics, R0, t0)
             got = ctx.run_iterations(level, 5, R0, t0)

@@ -13,7 +13,7 @@ run python bench.py $Q --batch 4096 --steps 20
 run python bench.py $Q --batch 32 --steps 20
 run python bench.py $Q --batch 64 --steps 20
 run python bench.py $Q --batch 128 --steps 20
-DVO_TEAM_PLAIN_LAUNCH=1 run python bench.py $Q --batch 32 --steps 20
+DVO_TEAM_COOP_LAUNCH=1 run python bench.py $Q --batch 32 --steps 20
 run python bench.py $Q --batch 1024 --steps 20 --float-now-levels
 run python bench.py $Q --batch 1024 --steps 20 --float-now-levels --prepare
 run python bench.py --mode tiled --steps 50 --cpu-seconds 0
