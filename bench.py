@@ -264,6 +264,69 @@ def frames_leg(args, iters):
     return out
 
 
+def float_boundary_leg(args, iters, flags, stream, per_scene_bytes):
+    """extra leg, never `value`: 256 pairs whose now levels arrive as the reference keeps them -- DT, gradX, gradY float images in
+    host memory (SolveDVO.cpp:1788-1795 -> dvo_set_now_level)"""
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    B, D = 256, min(8, args.distinct)
+    scenes = [SynthScene(args.width, args.height, args.levels, 1000 + i) for i in range(D)]
+    ctx = DvoContext(B)
+    try:
+        ctx.set_intrinsics(*scenes[0].intrinsics)
+        for p in range(B):
+            for l, L in enumerate(scenes[p % D].levels):
+                if p < D:
+                    ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols, pair=p)
+        ctx.replicate_pairs(D)
+        ctx.synchronize()
+
+        def install():
+            for p in range(B):
+                for l, L in enumerate(scenes[p % D].levels):
+                    ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols, pair=p)
+            ctx.synchronize()
+        install()
+        t0 = time.perf_counter()
+        install()
+        install_us = 1e6 * (time.perf_counter() - t0) / B
+        ctx.set_stream(stream.cuda_stream)
+
+        def rate(n):
+            for _ in range(2):
+                ctx.enqueue(iters, flags=flags); ctx.get_poses()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for a, b in ev:
+                a.record(stream); ctx.enqueue(iters, flags=flags); b.record(stream); ctx.get_poses()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            k = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+            by = sum(per_scene_bytes[p % len(per_scene_bytes)] for p in range(B))
+            return {"aligns_per_s": B * n / el, "kernel_ms": k, "roofline_frac": by / (k * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "texel_modes": [ctx.level_texel_mode(0, l) for l in range(args.levels)]}
+        r16 = rate(8)                                  # 2 + 8 alignments: below DVO_COMPACT_NOW_AFTER, still on 16-byte texels
+        install()                                      # fresh now levels (use count 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.now_prepare()
+        ctx.synchronize()
+        build_us = 1e6 * (time.perf_counter() - t0) / B
+        r4 = rate(8)
+        return {"pairs": B, "install_us_per_pair_pcie_inclusive": install_us, "on_16_byte_texels": r16,
+                "compact_build_us_per_pair": build_us, "on_compact_form": r4,
+                "break_even_alignments_per_now_level": (build_us * 1e-6) / max(1e-12, (1.0 / r16["aligns_per_s"] - 1.0 / r4["aligns_per_s"])),
+                "note": "never `value`.  Three float images per level from pageable host memory (12 B/pixel over PCIe) dominate this boundary: "
+                        "installing a pair costs a hundred alignments.  The alignment starts on the 16-byte texels the installation "
+                        "packs; the batched compact build (verified bit for bit against those texels) pays for itself after "
+                        "break_even_alignments_per_now_level alignments of the SAME now level at this batch size, which is when the "
+                        "engine builds it on its own (DVO_COMPACT_NOW_AFTER; dvo_now_prepare builds it at once) -- the reference aligns "
+                        "a now level once or twice (SolveDVO.cpp:2097-2104, :2220-2227).  Callers after throughput hand over edge "
+                        "maps or camera frames instead (dvo_set_now_level_from_edges, dvo_frames_*: `frames_in`)."}
+    finally:
+        ctx.close()
+
+
 def dist_setup():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -514,6 +577,14 @@ def main_batch(args):
         if ctx is not None:
             ctx.close()
             ctx = None
+        # the section-8(b) boundary as the reference would use it: the now levels handed over as three float images per level
+        # (dvo_set_now_level).  What it costs to INSTALL a pair that way (PCIe-inclusive), the alignment rate on the 16-byte texels
+        # such a level starts with, the cost of the batched compact build (dvo_now_prepare / automatic after DVO_COMPACT_NOW_AFTER
+        # alignments of the same now level) and the rate on its result
+        try:
+            out["float_now_levels"] = float_boundary_leg(args, iters, flags, stream, per_scene_bytes)
+        except Exception as e:
+            out["float_now_levels"] = {"error": repr(e)}
     if frames_in is not None:
         out["frames_in"] = frames_in
     print(json.dumps(out), flush=True)
@@ -576,26 +647,31 @@ def main_tiled(args):
         allp = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allp, mine)
         same = all(bool(torch.equal(allp[0], a)) for a in allp)
+    graph_replayed = ctx.tiled_graph_replayed()
     # per-level reports of the LAST timed alignment, read before anything else touches the context's outputs
     reports = {l: ctx.level_report(0, l, iters[l]) for l in range(args.levels) if iters[l] > 0}
     finals = None
     if flags:
         finals = ctx.final_outputs(0, n_pts[[l for l in range(args.levels) if iters[l] > 0][0]])
-    # the dominant kernel: accumulate_state_kernel over this rank's shard of the finest level, timed live with HIP events
+    # the dominant kernel: tiled_step_kernel over this rank's shard of the finest level.  The schedule is one replayed graph, so the
+    # launch is timed through the product path itself: alignments with 10 and with 60 iterations at the finest level only -- the
+    # slope is one iteration there (the launch, its boundary and the collective)
     first, count = shard_range(n_pts[0], rank, world)
-    acc = torch.zeros(32, dtype=torch.float64, device="cuda")
-    ctx.iter_begin(0, 1, R, t)
-    n_acc = 50
-    with torch.cuda.stream(stream):
-        ctx.iter_accumulate(0, first, count, acc.data_ptr())
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(n_acc):
-            ctx.iter_accumulate(0, first, count, acc.data_ptr())
-        e1.record(stream)
-    torch.cuda.synchronize()
-    ctx.iter_end(0)
-    acc_ms = e0.elapsed_time(e1) / n_acc
+
+    def level0_ms(n_it, reps=5):
+        it = [n_it] + [0] * (args.levels - 1)
+        ctx.align_pyramid_tiled(it, I, z, flags=0)
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.align_pyramid_tiled(it, I, z, flags=0)
+        torch.cuda.synchronize(); barrier()
+        return 1e3 * (time.perf_counter() - t0) / reps
+    acc_ms = max(1e-6, (level0_ms(60) - level0_ms(10)) / 50.0)
+    if dist is not None:
+        tt = torch.tensor([acc_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        acc_ms = float(tt.item())
     L0 = sc.levels[0]
     bytes_launch = 12 * count + 12 * L0.rows * L0.cols // max(1, iters[0])
     bytes_align = ctx.algorithmic_bytes(iters, flags=flags)
@@ -616,16 +692,17 @@ def main_tiled(args):
                         "(dvo_align_pyramid_tiled); identity start" % (args.width, args.height, args.levels, args.iters, world),
             "mode": "tiled", "points_per_level": n_pts, "iters_per_level": iters, "final_outputs": not args.no_final_outputs,
             "us_per_iteration": 1e6 * elapsed / args.steps / sum(iters), "timed_region_s": elapsed,
-            "all_ranks_bit_identical": same,
+            "all_ranks_bit_identical": same, "graph_replayed": graph_replayed,
             "algorithmic_bytes_per_alignment": bytes_align,
             "alignment_GBps": bytes_align * value / 1e9,
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-            "kernel": "accumulate_state_kernel + reduce_partials_kernel (dvo_kernels.hip), this rank's shard of level 0 (%d of %d points)" % (count, n_pts[0]),
+            "kernel": "tiled_step_kernel (dvo_kernels.hip: update of the previous iteration + this rank's shard of level 0, %d of %d points, + the sums of the launch) and its ncclAllReduce" % (count, n_pts[0]),
             "kernel_ms": acc_ms, "algorithmic_bytes_per_launch": bytes_launch,
             "definition": "12 B x points of the shard + the level's 12 B/pixel images amortised over its iterations, per accumulate "
-                          "launch; the mode is latency-bound (two dependent launches + one 256-byte all-reduce per iteration)",
+                          "launch; kernel_ms = one iteration at level 0 measured through the product path (slope of the alignment time over "
+                          "the number of level-0 iterations): the launch, its boundary and the 256-byte all-reduce",
             "traffic_reason": "no PMC record for the tiled mode",
         },
     }

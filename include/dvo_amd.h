@@ -263,6 +263,10 @@ int  dvo_tiled_detach(dvo_ctx *ctx);
 int  dvo_align_pyramid_tiled(dvo_ctx *ctx, int pair, int n_levels, const int *iters, int flags, double *R, double *t);
 /* the contiguous index range of `level`'s reference list this rank works on */
 int  dvo_tiled_shard(dvo_ctx *ctx, int pair, int level, int *first, int *count);
+/* inspection: *graph_replayed = 1 if the last dvo_align_pyramid_tiled replayed its captured graph (one kernel + one ncclAllReduce
+ * per iteration, no host work in between), 0 if the schedule was submitted launch by launch (the runtime refused to capture the
+ * collective, DVO_TILED_NO_GRAPH=1, or the legacy null stream) */
+int  dvo_tiled_graph_replayed(dvo_ctx *ctx, int *graph_replayed);
 
 /* ---- inspection (used by the parity tests) ---------------------------------
  * One evaluation of computeJacobianOfNowFrame + getReprojectedEpsilons at the

@@ -753,6 +753,8 @@ int dvo_destroy(dvo_ctx *c) {
     if (c->d_umap_xy) (void)hipFree(c->d_umap_xy);
     if (c->d_umap_frac) (void)hipFree(c->d_umap_frac);
     if (c->wide_exec) (void)hipGraphExecDestroy(c->wide_exec);
+    if (c->tiled_exec) (void)hipGraphExecDestroy(c->tiled_exec);
+    if (c->d_step_state) { (void)hipFree(c->d_step_state); (void)hipFree(c->d_step_acc); (void)hipFree(c->d_step_ticket); }
     if (c->h_pose) (void)hipHostFree(c->h_pose);
     if (c->h_poses) (void)hipHostFree(c->h_poses);
     for (int l = 0; l < DVO_LEVELS; l++) {
@@ -1351,33 +1353,74 @@ int dvo_iter_end(dvo_ctx *c, int pair, int level, double *R, double *t, float *e
 
 /* The level schedule (SolveDVO.cpp:2097-2104) with every iteration spread over all CUs: the single-GPU
  * form of the host-driven loop, enqueued back to back from C (no collective, one synchronisation). */
-int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters, int flags, double *R, double *t) {
-    DVO_ENTER(c);
-    if (!pair_ok(c, pair) || !R || !t) return fail(c, DVO_ERR_INVALID, "bad arguments");
-    if (flags & ~DVO_FLAG_FINAL_OUTPUTS) return fail(c, DVO_ERR_INVALID, "dvo_align_pyramid_wide takes DVO_FLAG_FINAL_OUTPUTS only");
-    Schedule sc;
-    int rc = build_schedule(c, n_levels, iters, flags, sc);
-    if (rc) return rc;
-    for (int l = 0; l < n_levels; l++)
-        if (sc.iters[l] > 0 && ((rc = check_ready(c, pair, l)) || (rc = ensure_tex16(c, l, pair, 1)))) return rc;
-    if ((rc = ensure_outputs(c, sc))) return rc;
-    if (!c->d_states) {
-        HIPCHK(c, hipMalloc((void **)&c->d_states, pose_state_bytes() * c->n_pairs));
-        c->iter_max.assign(c->n_pairs, 0);
-    }
-    if (!c->h_pose) HIPCHK(c, hipHostMalloc((void **)&c->h_pose, sizeof(double) * 12, hipHostMallocDefault));
-    double *h = c->h_pose;
-    std::memcpy(h, R, sizeof(double) * 9);
-    std::memcpy(h + 9, t, sizeof(double) * 3);
-    double *d_pose = c->d_poses + (size_t)12 * pair;
-    void *state = c->d_states + pose_state_bytes() * pair;
+}  /* extern "C" */
+
+namespace dvo_host {
+
+int ensure_step_buffers(dvo_ctx *c) {
+    if (c->d_step_state) return DVO_OK;
+    HIPCHK(c, hipMalloc((void **)&c->d_step_state, 2 * pose_state_bytes()));
+    HIPCHK(c, hipMalloc((void **)&c->d_step_acc, sizeof(double) * 2 * DVO_NACC_PAD));
+    HIPCHK(c, hipMalloc((void **)&c->d_step_ticket, sizeof(unsigned)));
+    HIPCHK(c, hipMemsetAsync(c->d_step_acc, 0, sizeof(double) * 2 * DVO_NACC_PAD, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_step_ticket, 0, sizeof(unsigned), c->stream));
+    HIPCHK(c, stream_wait(c->stream));
+    return DVO_OK;
+}
+
+static void shard_of(int n, int rank, int world, int &first, int &count) {      /* distributed.py::shard_range, dvo_tiled_shard */
+    const int base = n / world, rem = n % world;
+    count = base + (rank < rem ? 1 : 0);
+    first = rank * base + (rank < rem ? rank : rem);
+}
+
+hipError_t enqueue_step_schedule(dvo_ctx *c, const Schedule &sc, int pair, int flags, double *d_pose, int rank, int world,
+                                 const std::function<hipError_t(double *)> &all_reduce) {
+    hipError_t first_err = hipSuccess;
+    auto rec = [&first_err](hipError_t e) { if (first_err == hipSuccess && e != hipSuccess) first_err = e; };
+    char *st[2] = {c->d_step_state, c->d_step_state + pose_state_bytes()};
+    double *acc[2] = {c->d_step_acc, c->d_step_acc + DVO_NACC_PAD};
     double *partials = c->d_scratch;
-    /* everything the enqueued sequence depends on; an unchanged signature replays the instantiated graph */
+    int cur = 0, k = 0;                                                 /* state to read next; launches so far (the sums alternate) */
+    for (int l = sc.n_levels - 1; l >= 0; --l) {                        /* :2097 */
+        if (sc.iters[l] <= 0) continue;                                 /* :2099 */
+        const int N = c->lv[l].hN[pair];
+        int first = 0, count = 0;
+        shard_of(N, rank, world, first, count);
+        float *energy = c->d_energy + (size_t)pair * sc.e_stride + sc.e_off[l];
+        const LevelSlab sl = slab_of(c, l);
+        rec(launch_iter_begin(st[cur], d_pose, energy, sc.iters[l], c->stream));
+        const int nb = tiled_step_blocks(count, c->n_cu);
+        /* DVO_FLAG_NORMAL_MATRIX: the launches also form H = sum w J J^T (21 more double sums per point: + 40 % on the launch),
+         * it rides in the same 32 doubles through the all-reduce and is kept per iterate (dvo_get_level_normal_matrix); without
+         * the flag those 21 slots are zeros -- the reference's update never reads them (SolveDVO.cpp:777) */
+        double *H = (flags & DVO_FLAG_NORMAL_MATRIX) ? c->d_H + ((size_t)pair * sc.e_stride + sc.e_off[l]) * 21 : nullptr;
+        for (int itr = 0; itr < sc.iters[l]; itr++, k++) {
+            const int apply = itr > 0;
+            rec(launch_tiled_step(sl, pair, l, c->K, c->dprm, st[cur], st[cur ^ 1], acc[(k + 1) & 1], itr, apply, N, first, count, partials,
+                                  c->d_step_ticket, acc[k & 1], energy, nb, H ? H + (size_t)(itr > 0 ? itr - 1 : 0) * 21 : nullptr, c->stream));
+            if (apply) cur ^= 1;
+            if (all_reduce) rec(all_reduce(acc[k & 1]));
+        }
+        rec(launch_tiled_finish(st[cur], st[cur ^ 1], c->dprm, acc[(k + 1) & 1], sc.iters[l] - 1, N, energy, d_pose,
+                                c->d_best + pair * DVO_LEVELS + l, c->d_ratio + pair * DVO_LEVELS + l,
+                                H ? H + (size_t)(sc.iters[l] - 1) * 21 : nullptr, c->stream));
+        cur ^= 1;
+        /* finalEpsilons / finalReprojections (:703-704, :1002-1003): this rank's share, at the points' own indices */
+        if ((flags & DVO_FLAG_FINAL_OUTPUTS) && l == sc.last_level)
+            rec(launch_final_outputs_state(sl, pair, l, c->K, st[cur], first, count, c->d_final_eps + (size_t)pair * c->final_cap,
+                                           c->d_final_reproj + (size_t)pair * c->final_cap * 3, c->d_final_N + pair, c->stream));
+    }
+    return first_err;
+}
+
+unsigned long long step_schedule_signature(dvo_ctx *c, const Schedule &sc, int pair, int n_levels, int flags, int rank, int world) {
     unsigned long long sig = 1469598103934665603ull;
     auto mix = [&sig](unsigned long long v) { sig = (sig ^ v) * 1099511628211ull; };
     mix((unsigned long long)pair); mix((unsigned long long)n_levels); mix((unsigned long long)(size_t)c->stream);
     mix((unsigned long long)flags); mix((unsigned long long)(size_t)c->d_final_eps); mix((unsigned long long)c->final_cap);
-    mix((unsigned long long)(size_t)c->d_energy); mix((unsigned long long)sc.e_stride);
+    mix((unsigned long long)(size_t)c->d_energy); mix((unsigned long long)sc.e_stride); mix((unsigned long long)rank); mix((unsigned long long)world);
+    mix((unsigned long long)(size_t)c->d_H);
     for (int l = 0; l < n_levels; l++) {
         const LevelSlab sl = slab_of(c, l);
         mix((unsigned long long)sc.iters[l]); mix((unsigned long long)c->lv[l].hN[pair]);
@@ -1385,6 +1428,34 @@ int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters,
         mix((unsigned long long)sl.pt_cap); mix((unsigned long long)sl.rows); mix((unsigned long long)sl.cols);
     }
     { unsigned long long kb[3] = {0, 0, 0}; std::memcpy(kb, &c->K, sizeof(c->K) < sizeof(kb) ? sizeof(c->K) : sizeof(kb)); mix(kb[0]); mix(kb[1]); mix(kb[2]); }
+    { unsigned long long pb[16] = {0}; std::memcpy(pb, &c->dprm, sizeof(c->dprm) < sizeof(pb) ? sizeof(c->dprm) : sizeof(pb)); for (unsigned long long v : pb) mix(v); }
+    return sig;
+}
+
+}  // namespace dvo_host
+
+extern "C" {
+
+int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters, int flags, double *R, double *t) {
+    DVO_ENTER(c);
+    if (!pair_ok(c, pair) || !R || !t) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    if (flags & ~(DVO_FLAG_FINAL_OUTPUTS | DVO_FLAG_NORMAL_MATRIX)) return fail(c, DVO_ERR_INVALID, "dvo_align_pyramid_wide takes DVO_FLAG_FINAL_OUTPUTS and DVO_FLAG_NORMAL_MATRIX only");
+    Schedule sc;
+    int rc = build_schedule(c, n_levels, iters, flags, sc);
+    if (rc) return rc;
+    for (int l = 0; l < n_levels; l++)
+        if (sc.iters[l] > 0 && ((rc = check_ready(c, pair, l)) || (rc = ensure_tex16(c, l, pair, 1)))) return rc;
+    if ((rc = ensure_outputs(c, sc))) return rc;
+    if ((rc = ensure_step_buffers(c))) return rc;
+    if (!c->h_pose) HIPCHK(c, hipHostMalloc((void **)&c->h_pose, sizeof(double) * 12, hipHostMallocDefault));
+    double *h = c->h_pose;
+    std::memcpy(h, R, sizeof(double) * 9);
+    std::memcpy(h + 9, t, sizeof(double) * 3);
+    double *d_pose = c->d_poses + (size_t)12 * pair;
+    /* everything the enqueued sequence depends on; an unchanged signature replays the instantiated graph.  One launch per iteration
+     * (round 4: the update of an iteration rides at the head of the next one's accumulate launch, the partial sums are added by the
+     * workgroup that arrives last -- dvo_kernels.hip: tiled_step_kernel); rounds 1-3 used two. */
+    const unsigned long long sig = step_schedule_signature(c, sc, pair, n_levels, flags, 0, 1);
     static const bool env_no_graph = std::getenv("DVO_WIDE_NO_GRAPH") != nullptr;  /* A/B switch for measurements */
     const bool no_graph = env_no_graph || c->stream == nullptr;                    /* the legacy null stream cannot be captured */
     if (no_graph || !c->wide_exec || sig != c->wide_sig) {
@@ -1393,19 +1464,7 @@ int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters,
         hipError_t first_err = hipSuccess;
         auto rec = [&first_err](hipError_t e) { if (first_err == hipSuccess && e != hipSuccess) first_err = e; };
         rec(hipMemcpyAsync(d_pose, h, sizeof(double) * 12, hipMemcpyHostToDevice, c->stream));
-        for (int l = n_levels - 1; l >= 0; --l) {                       /* :2097 */
-            if (sc.iters[l] <= 0) continue;                             /* :2099 */
-            const int N = c->lv[l].hN[pair];
-            float *energy = c->d_energy + (size_t)pair * sc.e_stride + sc.e_off[l];
-            rec(launch_iter_begin(state, d_pose, energy, sc.iters[l], c->stream));
-            const int nb = accumulate_blocks_for(N);
-            for (int itr = 0; itr < sc.iters[l]; itr++)
-                rec(launch_iter_step_fused(slab_of(c, l), pair, l, c->K, state, c->dprm, itr, N, partials, nb, energy, c->stream));
-            if ((flags & DVO_FLAG_FINAL_OUTPUTS) && l == sc.last_level)       /* :703-704, :1002-1003 */
-                rec(launch_final_outputs_state(slab_of(c, l), pair, l, c->K, state, 0, N, c->d_final_eps + (size_t)pair * c->final_cap,
-                                               c->d_final_reproj + (size_t)pair * c->final_cap * 3, c->d_final_N + pair, c->stream));
-            rec(launch_iter_end(state, d_pose, c->d_best + pair * DVO_LEVELS + l, c->d_ratio + pair * DVO_LEVELS + l, c->stream));
-        }
+        rec(enqueue_step_schedule(c, sc, pair, flags, d_pose, 0, 1, nullptr));
         rec(hipMemcpyAsync(h, d_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, c->stream));
         if (!no_graph) {
             hipGraph_t graph = nullptr;

@@ -3,8 +3,10 @@
  * sharded over the GPUs of a node, the per-iteration all-reduce of the 32 accumulator doubles done by RCCL over xGMI, the
  * whole level schedule of SolveDVO::loop (reference src/SolveDVO.cpp:2097-2104) enqueued from C on the context stream:
  *
- *     per iteration:  accumulate(own point range) -> reduce partials -> ncclAllReduce(32, ncclDouble, ncclSum)
- *                     -> the reference's 6-DoF update (:724-920), executed identically on every rank
+ *     per iteration:  ONE kernel -- the previous iteration's 6-DoF update (:724-920) at its head, executed identically by every
+ *                     workgroup of every rank; this rank's point range at the new pose; the 32 sums written by the workgroup that
+ *                     arrives last (dvo_kernels.hip: tiled_step_kernel) -- then ncclAllReduce(32, ncclDouble, ncclSum);
+ *                     the whole schedule captured into one graph (rounds 1-3: accumulate, reduce, all-reduce, update per iteration)
  *
  * No Python in the loop (rgbd_odometry_amd/distributed.py::TiledAligner is the torch.distributed twin used by the CPU/gloo
  * tests).  RCCL is NOT a link-time dependency of libdvo_amd.so: the communicator is created by the caller (a C++ ROS node
@@ -35,7 +37,7 @@ struct Tiled {
     nccl_allreduce_fn all_reduce = nullptr;
     nccl_errstr_fn errstr = nullptr;
     void *lib = nullptr;            /* dlopen handle we own (or nullptr) */
-    double *d_acc = nullptr;        /* 32 doubles on the device: the all-reduce buffer */
+    bool no_graph = false;          /* the runtime refused to capture the schedule with this communicator: direct submission */
 };
 
 /* one record per context, kept outside struct dvo_ctx (only this file knows RCCL) */
@@ -69,7 +71,6 @@ void tiled_forget(dvo_ctx *c) {           /* called by dvo_destroy */
             if (r[i]->ctx == c) { gone = r[i]; r.erase(r.begin() + i); break; }
     }
     if (!gone) return;
-    if (gone->t.d_acc) (void)hipFree(gone->t.d_acc);
     if (gone->t.lib) dlclose(gone->t.lib);
     delete gone;
 }
@@ -101,7 +102,6 @@ int dvo_tiled_attach(dvo_ctx *c, void *nccl_comm, int rank, int world, const cha
     }
     t.all_reduce = (nccl_allreduce_fn)sym;
     t.errstr = (nccl_errstr_fn)(t.lib ? dlsym(t.lib, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
-    HIPCHK(c, hipMalloc((void **)&t.d_acc, sizeof(double) * DVO_NACC_PAD));
     {
         std::lock_guard<std::mutex> lock(registry_mutex());
         registry().push_back(new Entry{c, t});
@@ -112,6 +112,7 @@ int dvo_tiled_attach(dvo_ctx *c, void *nccl_comm, int rank, int world, const cha
 int dvo_tiled_detach(dvo_ctx *c) {
     DVO_ENTER(c);
     if (c->stream) (void)stream_wait(c->stream);
+    if (c->tiled_exec) { (void)hipGraphExecDestroy(c->tiled_exec); c->tiled_exec = nullptr; }      /* it refers to the communicator */
     tiled_forget(c);
     return DVO_OK;
 }
@@ -126,10 +127,17 @@ int dvo_tiled_shard(dvo_ctx *c, int pair, int level, int *first, int *count) {
     return DVO_OK;
 }
 
+int dvo_tiled_graph_replayed(dvo_ctx *c, int *graph_replayed) {
+    DVO_ENTER(c);
+    if (!graph_replayed) return fail(c, DVO_ERR_INVALID, "graph_replayed is NULL");
+    *graph_replayed = c->tiled_graph_used ? 1 : 0;
+    return DVO_OK;
+}
+
 int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters, int flags, double *R, double *t) {
     DVO_ENTER(c);
     if (!pair_ok(c, pair) || !R || !t) return fail(c, DVO_ERR_INVALID, "bad arguments");
-    if (flags & ~DVO_FLAG_FINAL_OUTPUTS) return fail(c, DVO_ERR_INVALID, "dvo_align_pyramid_tiled takes DVO_FLAG_FINAL_OUTPUTS only");
+    if (flags & ~(DVO_FLAG_FINAL_OUTPUTS | DVO_FLAG_NORMAL_MATRIX)) return fail(c, DVO_ERR_INVALID, "dvo_align_pyramid_tiled takes DVO_FLAG_FINAL_OUTPUTS and DVO_FLAG_NORMAL_MATRIX only");
     Tiled *T = find(c);
     if (!T) return fail(c, DVO_ERR_STATE, "no communicator attached (dvo_tiled_attach)");
     Schedule sc;
@@ -138,42 +146,61 @@ int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters
     for (int l = 0; l < n_levels; l++)
         if (sc.iters[l] > 0 && ((rc = dvo_host::check_ready(c, pair, l)) || (rc = dvo_host::ensure_tex16(c, l, pair, 1)))) return rc;
     if ((rc = dvo_host::ensure_outputs(c, sc))) return rc;
-    if (!c->d_states) {
-        HIPCHK(c, hipMalloc((void **)&c->d_states, pose_state_bytes() * c->n_pairs));
-        c->iter_max.assign(c->n_pairs, 0);
-    }
+    if ((rc = dvo_host::ensure_step_buffers(c))) return rc;
     if (!c->h_pose) HIPCHK(c, hipHostMalloc((void **)&c->h_pose, sizeof(double) * 12, hipHostMallocDefault));
     double *h = c->h_pose;
     std::memcpy(h, R, sizeof(double) * 9);
     std::memcpy(h + 9, t, sizeof(double) * 3);
     double *d_pose = c->d_poses + (size_t)12 * pair;
-    void *state = c->d_states + pose_state_bytes() * pair;
-    double *partials = c->d_scratch;
-    HIPCHK(c, hipMemcpyAsync(d_pose, h, sizeof(double) * 12, hipMemcpyHostToDevice, c->stream));
-    for (int l = n_levels - 1; l >= 0; --l) {                       /* :2097 */
-        if (sc.iters[l] <= 0) continue;                             /* :2099 */
-        const int N = c->lv[l].hN[pair];
-        int first = 0, count = 0;
-        shard(N, T->rank, T->world, first, count);
-        float *energy = c->d_energy + (size_t)pair * sc.e_stride + sc.e_off[l];
-        HIPCHK(c, launch_iter_begin(state, d_pose, energy, sc.iters[l], c->stream));
-        const int nb = accumulate_blocks_for(count);
-        const LevelSlab sl = dvo_host::slab_of(c, l);
-        for (int itr = 0; itr < sc.iters[l]; itr++) {
-            HIPCHK(c, launch_iter_accumulate(sl, pair, l, c->K, state, first, count, partials, nb, T->d_acc, c->stream));
-            const int nrc = T->all_reduce(T->d_acc, T->d_acc, DVO_NACC_PAD, kNcclDouble, kNcclSum, T->comm, c->stream);
-            if (nrc != 0)
-                return fail(c, DVO_ERR_HIP, std::string("ncclAllReduce: ") + (T->errstr ? T->errstr(nrc) : "error " + std::to_string(nrc)));
-            HIPCHK(c, launch_iter_update(state, c->dprm, itr, N, T->d_acc, energy, c->stream));
+    /* Per iteration ONE kernel and ONE collective (round 4; rounds 1-3: accumulate, reduce, all-reduce, update): the update of an
+     * iteration is applied at the head of the next iteration's launch by every workgroup of every rank from the same all-reduced
+     * bits (dvo_kernels.hip: tiled_step_kernel), the 32 sums of a launch are written by its last workgroup.  The whole schedule,
+     * ncclAllReduce calls included, is captured once into a graph and replayed (RCCL collectives are capturable); a capture the
+     * runtime refuses falls back to direct submission (DVO_TILED_NO_GRAPH=1 forces that for A/B measurements). */
+    int nccl_rc = 0;
+    auto all_reduce = [&](double *buf) -> hipError_t {
+        const int nrc = T->all_reduce(buf, buf, DVO_NACC_PAD, kNcclDouble, kNcclSum, T->comm, c->stream);
+        if (nrc != 0 && nccl_rc == 0) nccl_rc = nrc;
+        return nrc == 0 ? hipSuccess : hipErrorUnknown;
+    };
+    auto submit = [&]() -> hipError_t {
+        hipError_t e = hipMemcpyAsync(d_pose, h, sizeof(double) * 12, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = dvo_host::enqueue_step_schedule(c, sc, pair, flags, d_pose, T->rank, T->world, all_reduce);
+        if (e == hipSuccess) e = hipMemcpyAsync(h, d_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, c->stream);
+        return e;
+    };
+    auto nccl_fail = [&]() { return fail(c, DVO_ERR_HIP, std::string("ncclAllReduce: ") + (T->errstr ? T->errstr(nccl_rc) : "error " + std::to_string(nccl_rc))); };
+    static const bool env_no_graph = std::getenv("DVO_TILED_NO_GRAPH") != nullptr;
+    const unsigned long long sig = dvo_host::step_schedule_signature(c, sc, pair, n_levels, flags, T->rank, T->world) ^ (unsigned long long)(size_t)T->comm;
+    bool direct = env_no_graph || c->stream == nullptr || T->no_graph;
+    if (!direct && (!c->tiled_exec || sig != c->tiled_sig)) {
+        if (c->tiled_exec) { (void)hipGraphExecDestroy(c->tiled_exec); c->tiled_exec = nullptr; }
+        hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            e = submit();
+            hipGraph_t graph = nullptr;
+            const hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
+            if (e == hipSuccess) e = e2;
+            if (e == hipSuccess) e = hipGraphInstantiate(&c->tiled_exec, graph, nullptr, nullptr, 0);
+            if (graph) (void)hipGraphDestroy(graph);
         }
-        /* finalEpsilons / finalReprojections (:703-704, :1002-1003): this rank's shard, at the points' own indices; the caller
-         * concatenates the shards (dvo_tiled_shard gives the ranges) */
-        if ((flags & DVO_FLAG_FINAL_OUTPUTS) && l == sc.last_level)
-            HIPCHK(c, launch_final_outputs_state(sl, pair, l, c->K, state, first, count, c->d_final_eps + (size_t)pair * c->final_cap,
-                                                 c->d_final_reproj + (size_t)pair * c->final_cap * 3, c->d_final_N + pair, c->stream));
-        HIPCHK(c, launch_iter_end(state, d_pose, c->d_best + pair * DVO_LEVELS + l, c->d_ratio + pair * DVO_LEVELS + l, c->stream));
+        if (e != hipSuccess) {          /* this RCCL / runtime pair does not capture the collective: submit directly from now on */
+            (void)hipGetLastError();
+            if (c->tiled_exec) { (void)hipGraphExecDestroy(c->tiled_exec); c->tiled_exec = nullptr; }
+            T->no_graph = true;
+            direct = true;
+            nccl_rc = 0;
+        } else {
+            c->tiled_sig = sig;
+        }
     }
-    HIPCHK(c, hipMemcpyAsync(h, d_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, c->stream));
+    if (direct) {
+        const hipError_t e = submit();
+        if (nccl_rc != 0) return nccl_fail();
+        HIPCHK(c, e);
+    } else {
+        HIPCHK(c, hipGraphLaunch(c->tiled_exec, c->stream));
+    }
     HIPCHK(c, stream_wait(c->stream));
     std::memcpy(R, h, sizeof(double) * 9);
     std::memcpy(t, h + 9, sizeof(double) * 3);
@@ -181,6 +208,7 @@ int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters
     c->sched = sc;
     c->have_sched = true;
     c->team_used = false;
+    c->tiled_graph_used = !direct;
     return DVO_OK;
 }
 

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -119,6 +120,14 @@ struct dvo_ctx {
     double *h_poses = nullptr;      /* pinned: dvo_get_poses / dvo_set_poses staging, 12 doubles per pair */
     unsigned long long *d_dbg = nullptr;
     char *d_states = nullptr;       /* n_pairs x pose_state_bytes(): host-driven iteration state */
+    /* one-launch-per-iteration schedule (dvo_align_pyramid_wide / _tiled, round 4): two optimiser states (double-buffered), two
+     * rows of 32 reduced sums (alternating), the arrival ticket of the partial rows */
+    char *d_step_state = nullptr;
+    double *d_step_acc = nullptr;
+    unsigned *d_step_ticket = nullptr;
+    hipGraphExec_t tiled_exec = nullptr;     /* the tiled schedule (incl. its ncclAllReduce calls) as a replayable graph */
+    unsigned long long tiled_sig = 0;
+    bool tiled_graph_used = false;           /* inspection: the last dvo_align_pyramid_tiled replayed its graph */
     float *d_iter_energy = nullptr; /* n_pairs x iter_energy_cap */
     int iter_energy_cap = 0;
     std::vector<int> iter_max;      /* per pair: max_iters of the running dvo_iter_begin (0 = none) */
@@ -225,6 +234,13 @@ int check_ready(dvo_ctx *c, int pair, int level);
 int build_schedule(dvo_ctx *c, int n_levels, const int *iters, int flags, dvo::Schedule &sc);
 int ensure_outputs(dvo_ctx *c, const dvo::Schedule &sc);
 void stamp_outputs(dvo_ctx *c, const dvo::Schedule &sc, int first, int n);
+/* enqueues the level schedule of one pair as ONE launch per iteration on c->stream (dvo_kernels.hip: tiled_step_kernel): this
+ * rank's contiguous share of every level's points (rank / world: dvo_tiled_shard's decomposition), `all_reduce` (may be empty:
+ * one GPU) called on the 32 sums between two launches.  Pose in / out through d_pose (12 doubles on the device). */
+hipError_t enqueue_step_schedule(dvo_ctx *c, const dvo::Schedule &sc, int pair, int flags, double *d_pose, int rank, int world,
+                                 const std::function<hipError_t(double *)> &all_reduce);
+int ensure_step_buffers(dvo_ctx *c);
+unsigned long long step_schedule_signature(dvo_ctx *c, const dvo::Schedule &sc, int pair, int n_levels, int flags, int rank, int world);
 /* the reference lists of pairs [first, first + n) of a level were (re)written: bumps points_gen and the pairs' list stamps;
  * rows > 0: the rows of the image their 4-byte twins were encoded against (0: no valid 4-byte twin) */
 void ref_list_written(dvo_ctx *c, int level, int first, int n, int rows);

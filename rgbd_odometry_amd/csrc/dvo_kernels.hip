@@ -722,6 +722,180 @@ iter_reduce_update_kernel(PoseState *st, DevParams prm, int itr, int n_total,
     }
 }
 
+/* ---- one launch per iteration of the tiled / wide schedule (round 4) ---------------------------------------------------
+ * Rounds 1-3 ran an iteration as accumulate -> reduce partials -> [all-reduce] -> update: three dependent launches, each ~1.5 us
+ * of boundary on top of its work (MI355X_MICROARCH.md, price list: boundary).  tiled_step_kernel is the whole iteration but the
+ * collective:
+ *   head   EVERY workgroup applies the pending update of the previous iteration -- the reduced (all-reduced) sums `acc_in` and
+ *          the state st_in are the same bits for every workgroup (and, in a tiled run, for every rank), the update is a pure
+ *          function of them, so every workgroup derives the same float pose; workgroup 0 also writes the new state to st_out
+ *          (double-buffered: no workgroup of this launch reads what it writes) and the energy of the iterate (:690);
+ *   body   the workgroup's share of this rank's point range at that pose: 29 sums (:714-720, :777);
+ *   tail   the 32 doubles of every workgroup go to `partials` with write-through (sc1) stores, a ticket counts the arrivals, and
+ *          the workgroup whose ticket comes last adds all rows in a fixed order (that of reduce_partials_kernel) and writes
+ *          `acc_out`: the buffer the all-reduce works on, or directly the next launch's acc_in on one GPU.
+ * Hand-off form: MI355X_MICROARCH.md, Workgroup dispatch ..., hand-offs measured with sc1 loads, first row -- one lane of each
+ * storing workgroup adds to one unsharded counter after that workgroup's stores have drained (every storing wave's vmcnt(0),
+ * then the workgroup barrier), the last arriver is told by the value its add returned, its other waves load after a barrier it
+ * then joins; hipMalloc memory, one workgroup per CU (the host launches at most that many), all stores and loads of the handed-
+ * off rows 8-byte sc1.  */
+DVO_DEV void store_sc1_f64(double *p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
+/* a relaxed agent-scope atomic load IS global_load_dwordx2 sc1 (MI355X_MICROARCH.md, the HIP construct table), with the wait
+ * counters left to the compiler: the sixteen loads of a lane below are all in flight before the first is consumed (an inline-asm
+ * load would have to wait for itself: 16 dependent memory latencies in the last workgroup of every launch) */
+DVO_DEV double load_sc1_f64(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#ifndef DVO_STEP_U
+#define DVO_STEP_U 2          /* points in flight per lane */
+#endif
+#ifndef DVO_STEP_THREADS
+#define DVO_STEP_THREADS 512
+#endif
+static_assert(sizeof(PoseState) % 8 == 0, "the state is copied 8 bytes per lane");
+template <bool WITH_H>
+__global__ void __launch_bounds__(DVO_STEP_THREADS)
+tiled_step_kernel(LevelSlab L, int pair, int level, Intrinsics K, DevParams prm, const PoseState *st_in, PoseState *st_out,
+                  const double *__restrict__ acc_in, int itr, int apply_prev, int n_total, int first, int n,
+                  double *partials, unsigned *ticket, double *acc_out, float *energy, double *H_prev) {
+    __shared__ double red[DVO_STEP_THREADS / 64][DVO_NACC_PAD];
+    __shared__ double tot[DVO_NACC_PAD];
+    __shared__ double part[16][DVO_NACC_PAD + 1];
+    __shared__ PoseState s;
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
+    {   /* the state, 8 bytes per lane (sizeof(PoseState) is a multiple of 8) */
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(st_in);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(&s);
+        for (int i = tid; i < (int)(sizeof(PoseState) / 8); i += DVO_STEP_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int was_stopped = s.stop;                                         /* before lane 0 touches the state */
+    __syncthreads();
+    if (tid == 0 && apply_prev && !was_stopped) {                          /* after :877 nothing runs */
+        double g[6];
+        for (int k = 0; k < 6; k++) g[k] = acc_in[21 + k];
+        const float e = pose_update(s, prm, itr - 1, n_total, g, acc_in[27], (int)acc_in[28]);
+        if (blockIdx.x == 0) energy[itr - 1] = e;                           /* :690 */
+    }
+    /* DVO_FLAG_NORMAL_MATRIX: H = sum w J J^T of the previous iterate (reduced over all ranks), kept per iterate like the batch kernels do */
+    if (WITH_H && H_prev && apply_prev && blockIdx.x == 0 && tid < 21 && !was_stopped) H_prev[tid] = acc_in[tid];
+    __syncthreads();
+    if (blockIdx.x == 0 && apply_prev) {
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&s);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(st_out);
+        for (int i = tid; i < (int)(sizeof(PoseState) / 8); i += DVO_STEP_THREADS) dst[i] = src[i];
+    }
+    Acc a;
+    acc_zero(a);
+    if (!s.stop) {                                                          /* wave-uniform (LDS) */
+        const float4 *__restrict__ tex = L.tex + (size_t)pair * L.tex_stride;
+        const float *__restrict__ pts = L.pts + (size_t)pair * L.pt_cap * 3;
+        IterConst c;
+        level_consts(c, K, level, L.rows, L.cols);
+#pragma unroll
+        for (int k = 0; k < 9; k++) c.r[k] = uniform_f(s.Rf[k]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) c.t[k] = uniform_f(s.tf[k]);
+        const int per = (n + gridDim.x - 1) / gridDim.x;
+        const int b0 = first + blockIdx.x * per;
+        int b1 = b0 + per;
+        if (b1 > first + n) b1 = first + n;
+        PointSrc psrc;
+        psrc.g = pts; psrc.gc = nullptr; psrc.l = nullptr; psrc.n_lds = 0; psrc.cap = 0;
+        if (b0 < b1) accumulate_points<DVO_STEP_U, WITH_H, SRC_GLOBAL_XYZ, 2>(c, tex, psrc, b0, b1, tid, DVO_STEP_THREADS, a);
+    }
+    block_reduce<DVO_STEP_THREADS, WITH_H>(a, red, tot);
+    /* tail: this workgroup's row, then the ticket */
+    if (tid < DVO_NACC_PAD) store_sc1_f64(partials + (size_t)blockIdx.x * DVO_NACC_PAD + tid, (tid < DVO_NACC) ? tot[tid] : 0.0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        /* every storing wave: its stores have left */
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    {   /* the last arriver: all rows in the fixed two-level order of reduce_partials_kernel (16 interleaved chains, then in order) */
+        const int k = tid & 31, ch = tid >> 5;                              /* 512 threads: 16 chains x 32 values */
+        double sum = 0.0;
+        const int nb = (int)gridDim.x;
+        for (int b0 = ch; b0 < nb && ch < 16; b0 += 16 * 16) {                          /* up to 16 rows of this chain at a time, all loads issued first */
+            double v[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int b = b0 + 16 * q;
+                v[q] = (b < nb) ? load_sc1_f64(partials + (size_t)b * DVO_NACC_PAD + k) : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) sum += v[q];                       /* fixed order: rows ch, ch + 16, ch + 32, ... */
+        }
+        if (ch < 16) part[ch][k] = sum;
+        __syncthreads();
+        if (tid < DVO_NACC_PAD) {
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) t += part[j][tid];
+            acc_out[tid] = t;
+        }
+        if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* for the next launch (visible at the kernel boundary) */
+    }
+}
+/* after the last iteration of a level: the pending update, then what iter_end_kernel does */
+__global__ void __launch_bounds__(64)
+tiled_finish_kernel(const PoseState *st_in, PoseState *st_out, DevParams prm, const double *__restrict__ acc_in, int itr_last,
+                    int n_total, float *energy, double *Rt12, int *best_idx, float *ratio, double *H_last) {
+    __shared__ PoseState s;
+    {
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(st_in);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(&s);
+        for (int i = threadIdx.x; i < (int)(sizeof(PoseState) / 8); i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (H_last && threadIdx.x < 21 && !s.stop) H_last[threadIdx.x] = acc_in[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (!s.stop) {
+            double g[6];
+            for (int k = 0; k < 6; k++) g[k] = acc_in[21 + k];
+            energy[itr_last] = pose_update(s, prm, itr_last, n_total, g, acc_in[27], (int)acc_in[28]);
+        }
+        pose_state_finish(s);                                               /* :997-1001 */
+        for (int k = 0; k < 9; k++) Rt12[k] = s.R[k];
+        for (int k = 0; k < 3; k++) Rt12[9 + k] = s.t[k];
+        *best_idx = s.bestItr;
+        *ratio = s.bestRatio;
+    }
+    __syncthreads();
+    {
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&s);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(st_out);
+        for (int i = threadIdx.x; i < (int)(sizeof(PoseState) / 8); i += 64) dst[i] = src[i];
+    }
+}
+int tiled_step_blocks(int n_points, int n_cu) {
+    int b = (n_points + DVO_STEP_THREADS - 1) / DVO_STEP_THREADS;
+    if (b < 1) b = 1;
+    if (b > n_cu) b = n_cu;             /* one workgroup per CU: the hand-off form of the tail is measured for that */
+    if (b > 1024) b = 1024;             /* rows of the partials buffer */
+    return b;
+}
+hipError_t launch_tiled_step(const LevelSlab &L, int pair, int level, const Intrinsics &K, const DevParams &prm, const void *st_in,
+                             void *st_out, const double *acc_in, int itr, int apply_prev, int n_total, int first_point, int n_points,
+                             double *partials, unsigned *ticket, double *acc_out, float *energy, int nblocks, double *H_prev, hipStream_t s) {
+    if (H_prev)
+        hipLaunchKernelGGL(tiled_step_kernel<true>, dim3(nblocks), dim3(DVO_STEP_THREADS), 0, s, L, pair, level, K, prm, (const PoseState *)st_in,
+                           (PoseState *)st_out, acc_in, itr, apply_prev, n_total, first_point, n_points, partials, ticket, acc_out, energy, H_prev);
+    else
+        hipLaunchKernelGGL(tiled_step_kernel<false>, dim3(nblocks), dim3(DVO_STEP_THREADS), 0, s, L, pair, level, K, prm, (const PoseState *)st_in,
+                           (PoseState *)st_out, acc_in, itr, apply_prev, n_total, first_point, n_points, partials, ticket, acc_out, energy, H_prev);
+    return hipGetLastError();
+}
+hipError_t launch_tiled_finish(const void *st_in, void *st_out, const DevParams &prm, const double *acc_in, int itr_last, int n_total,
+                               float *energy, double *Rt12, int *best_idx, float *ratio, double *H_last, hipStream_t s) {
+    hipLaunchKernelGGL(tiled_finish_kernel, dim3(1), dim3(64), 0, s, (const PoseState *)st_in, (PoseState *)st_out, prm, acc_in, itr_last,
+                       n_total, energy, Rt12, best_idx, ratio, H_last);
+    return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(64)
 iter_end_kernel(PoseState *st, double *Rt12, int *best_idx, float *ratio) {
     if (threadIdx.x == 0) {

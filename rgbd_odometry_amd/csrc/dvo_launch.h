@@ -133,6 +133,15 @@ hipError_t launch_iter_step_fused(const LevelSlab &L, int pair, int level, const
                                   const DevParams &prm, int itr, int n_points, double *partials, int nblocks,
                                   float *energy, hipStream_t s);
 hipError_t launch_iter_end(void *state, double *Rt12, int *best_idx, float *ratio, hipStream_t s);
+/* one launch per iteration (round 4, dvo_kernels.hip: tiled_step_kernel): pending update of iteration itr - 1 (apply_prev) from the
+ * reduced sums acc_in and the state st_in -> st_out, this rank's point range at the new pose, the 32 sums of the launch in acc_out */
+int tiled_step_blocks(int n_points, int n_cu);
+hipError_t launch_tiled_step(const LevelSlab &L, int pair, int level, const Intrinsics &K, const DevParams &prm, const void *st_in,
+                             void *st_out, const double *acc_in, int itr, int apply_prev, int n_total, int first_point, int n_points,
+                             double *partials, unsigned *ticket, double *acc_out, float *energy, int nblocks,
+                             double *H_prev /* NULL: the 21 H sums are not formed; else: where H of iterate itr - 1 goes (21 doubles) */, hipStream_t s);
+hipError_t launch_tiled_finish(const void *st_in, void *st_out, const DevParams &prm, const double *acc_in, int itr_last, int n_total,
+                               float *energy, double *Rt12, int *best_idx, float *ratio, double *H_last, hipStream_t s);
 /* finalEpsilons / finalReprojections of points [first, first+n) at the best iterate kept in `state` (host-driven / tiled paths) */
 hipError_t launch_final_outputs_state(const LevelSlab &L, int pair, int level, const Intrinsics &K, const void *state,
                                       int first_point, int n_points, float *final_eps, float *final_reproj, int *final_N,

@@ -88,6 +88,44 @@ def test_accumulators(scene320, ctx320, oracle):
             np.testing.assert_allclose(acc[:21], tr["H"], rtol=1e-12, atol=1e-12 * np.abs(tr["H"]).max())
 
 
+def test_wide_schedule_one_launch_per_iteration_with_and_without_normal_matrix(scene320, oracle):
+    """dvo_align_pyramid_wide (the single-GPU form of the tiled schedule, same tiled_step_kernel: the update of an iteration at
+    the head of the next launch, the sums added by the last workgroup): energies / best index / ratio / final outputs bit-equal to
+    the oracle, skipped levels included; with DVO_FLAG_NORMAL_MATRIX the same launches also form H per iterate"""
+    from rgbd_odometry_amd import DvoContext
+    from rgbd_odometry_amd.capi import DVO_FLAG_NORMAL_MATRIX, DVO_FLAG_FINAL_OUTPUTS
+    sc, lv = scene320
+    iters = [6, 0, 5, 4]
+    with DvoContext(1) as ctx:
+        ctx.set_intrinsics(*sc.intrinsics)
+        for l, L in enumerate(lv):
+            ctx.set_ref_level(l, L["xyz"])
+            ctx.set_now_level(l, L["dt"], L["gx"], L["gy"], L["rows"], L["cols"])
+        ref = oracle.align_pyramid(iters, lv, sc.intrinsics, np.eye(3), np.zeros(3))
+        for flags in (DVO_FLAG_FINAL_OUTPUTS, DVO_FLAG_FINAL_OUTPUTS | DVO_FLAG_NORMAL_MATRIX):
+            for rep in range(2):                        # the second call replays the captured graph
+                R, t = ctx.align_pyramid_wide(iters, np.eye(3), np.zeros(3), flags=flags)
+                for l, rep_l in ref["levels"].items():
+                    e, b, ratio = ctx.level_report(0, l, iters[l])
+                    assert np.array_equal(e, rep_l["energy"]) and b == rep_l["best_idx"] and ratio == rep_l["visible_ratio"], (flags, l)
+                assert rot_angle(ref["R"], R) <= 1e-5 and np.linalg.norm(ref["t"] - t) <= 1e-4
+                last = ref["levels"][ref["last_level"]]
+                fe, fr = ctx.final_outputs(0, len(last["final_eps"]))
+                assert np.array_equal(fe, last["final_eps"]) and np.array_equal(fr, last["final_reproj"], equal_nan=True)
+        Rc, tc = np.eye(3), np.zeros(3)
+        for l in (3, 2, 0):
+            L = lv[l]
+            r = oracle.run_iterations(l, iters[l], L["xyz"], L["dt"], L["gx"], L["gy"], L["rows"], L["cols"], sc.intrinsics, Rc, tc, trace=True)
+            for itr, tr in enumerate(r["trace"]):
+                H = ctx.level_normal_matrix(0, l, itr)
+                want = np.zeros((6, 6)); k = 0
+                for i in range(6):
+                    for j in range(i, 6):
+                        want[i, j] = want[j, i] = tr["H"][k]; k += 1
+                np.testing.assert_allclose(H, want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+            Rc, tc = r["R"], r["t"]
+
+
 def test_normal_matrix_of_every_iterate(scene320, oracle):
     """DVO_FLAG_NORMAL_MATRIX: the fused launch also keeps H = sum w J^T J (the 21 of the "21+6" accumulators) per
     iterate, in double; poses and energies are those of the plain launch"""
