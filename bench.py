@@ -70,9 +70,12 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", choices=["batch", "tiled"], default="batch")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 100 in batch mode, 200 in tiled mode: a timed region of about a second)")
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 40 in batch mode = 2.1 s, 200 in tiled mode)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16384, help="frame pairs per GPU per step (weak scaling: fixed per GPU; 16384 resident pairs = 159 GB of HBM)")
+    ap.add_argument("--batch", type=int, default=40000,
+                    help="frame pairs per GPU per step (weak scaling: fixed per GPU).  40000 resident 640x480x4 pairs = 140 GB of HBM (3.5 MB each: "
+                         "compact now form, point lists, outputs; their 16-byte texels are address space only, dvo_capi.cpp: ensure_texels); "
+                         "one step = 54 ms, so the driver's --steps 20 times 1.07 s")
     ap.add_argument("--total-pairs", type=int, default=0,
                     help="strong scaling: this many pairs IN TOTAL per step, split over the GPUs by shard_range "
                          "(BASELINE configs[3]: --total-pairs 256); overrides --batch")
@@ -102,7 +105,7 @@ def parse_args():
     a.width = a.width or (4096 if tiled else 640)
     a.height = a.height or (3072 if tiled else 480)
     a.levels = a.levels or (5 if tiled else 4)
-    a.steps = a.steps or (200 if tiled else 100)
+    a.steps = a.steps or (200 if tiled else 40)
     return a
 
 
@@ -273,10 +276,10 @@ def float_boundary_leg(args, iters, flags, stream, per_scene_bytes):
     ctx = DvoContext(B)
     try:
         ctx.set_intrinsics(*scenes[0].intrinsics)
-        for p in range(B):
-            for l, L in enumerate(scenes[p % D].levels):
-                if p < D:
-                    ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols, pair=p)
+        for p in range(D):
+            for l, L in enumerate(scenes[p].levels):
+                ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols, pair=p)
+                ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols, pair=p)
         ctx.replicate_pairs(D)
         ctx.synchronize()
 

@@ -122,14 +122,85 @@ int ensure_points(dvo_ctx *c, int level, int N) {
     return DVO_OK;
 }
 
+/* ---- the 16-byte texel slab: dense (hipMalloc) or sparse (virtual range, chunks mapped on demand) --------------------------- */
+static bool tex_sparse_wanted(size_t bytes) {
+    static const int pol = [] { const char *e = std::getenv("DVO_TEX_SLAB"); return e ? (!std::strcmp(e, "sparse") ? 1 : (!std::strcmp(e, "dense") ? 2 : 0)) : 0; }();
+    return pol == 1 || (pol == 0 && bytes >= ((size_t)2 << 30));      /* default: from 2 GiB per level on */
+}
+void free_texels(dvo_ctx *c, Level &L) {
+    if (!L.tex) return;
+    if (L.tex_sparse) {
+        for (size_t i = 0; i < L.tex_mapped.size(); i++)
+            if (L.tex_mapped[i]) {
+                (void)hipMemUnmap(reinterpret_cast<char *>(L.tex) + i * L.tex_chunk, L.tex_chunk);
+                (void)hipMemRelease(L.tex_handles[i]);
+            }
+        (void)hipMemAddressFree(L.tex, L.tex_va_bytes);
+    } else {
+        (void)hipFree(L.tex);
+    }
+    L.tex = nullptr; L.tex_sparse = false; L.tex_mapped.clear(); L.tex_handles.clear(); L.tex_va_bytes = 0;
+    (void)c;
+}
+int map_texels(dvo_ctx *c, int level, int first, int count) {
+    Level &L = c->lv[level];
+    if (!L.tex_sparse || count <= 0) return DVO_OK;
+    const size_t pair_bytes = sizeof(float4) * L.tex_stride;
+    const size_t lo = (size_t)first * pair_bytes / L.tex_chunk, hi = ((size_t)(first + count) * pair_bytes - 1) / L.tex_chunk;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = c->device;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    for (size_t i = lo; i <= hi; i++) {
+        if (L.tex_mapped[i]) continue;
+        char *addr = reinterpret_cast<char *>(L.tex) + i * L.tex_chunk;
+        hipMemGenericAllocationHandle_t h;
+        hipError_t e = hipMemCreate(&h, L.tex_chunk, &prop, 0);
+        if (e == hipSuccess) {
+            e = hipMemMap(addr, L.tex_chunk, 0, h, 0);
+            if (e == hipSuccess) e = hipMemSetAccess(addr, L.tex_chunk, &acc, 1);
+            if (e != hipSuccess) { (void)hipMemUnmap(addr, L.tex_chunk); (void)hipMemRelease(h); }
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(c, DVO_ERR_NOMEM, "cannot back the 16-byte texels of pairs " + std::to_string(first) + ".." + std::to_string(first + count - 1) +
+                                              " of level " + std::to_string(level) + " with memory: " + hipGetErrorString(e));
+        }
+        L.tex_handles[i] = h; L.tex_mapped[i] = 1;
+        HIPCHK(c, hipMemsetAsync(addr, 0, L.tex_chunk, c->stream));      /* tile padding is never read, but keep it defined */
+    }
+    return DVO_OK;
+}
+int sparse_map_compact_failures(dvo_ctx *c, int level, int first, int count, hipStream_t stream, int *n_failed) {
+    Level &L = c->lv[level];
+    std::vector<int> pn((size_t)count);
+    HIPCHK(c, hipMemcpyAsync(pn.data(), L.d_pal_n + first, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost, stream));
+    HIPCHK(c, stream_wait(stream));
+    int n = 0;
+    for (int i = 0; i < count; ) {
+        if (pn[i] > 0) { i++; continue; }
+        int j = i;
+        while (j < count && pn[j] <= 0) j++;
+        const int rc = map_texels(c, level, first + i, j - i);
+        if (rc) return rc;
+        n += j - i;
+        i = j;
+    }
+    if (n && stream != c->stream) HIPCHK(c, stream_wait(c->stream));      /* the zero fill of fresh chunks runs on the context stream */
+    *n_failed = n;
+    return DVO_OK;
+}
+
 int ensure_texels(dvo_ctx *c, int level, int rows, int cols) {
     Level &L = c->lv[level];
     if (L.have_now.empty()) L.have_now.assign(c->n_pairs, 0);
     if (L.tex && L.rows == rows && L.cols == cols) return DVO_OK;
     if (L.tex) {
         HIPCHK(c, stream_wait(c->stream));
-        HIPCHK(c, hipFree(L.tex));
-        L.tex = nullptr;
+        free_texels(c, L);
         std::fill(L.have_now.begin(), L.have_now.end(), 0);
         if (L.p4) { (void)hipFree(L.p4); (void)hipFree(L.pal); (void)hipFree(L.d_pal_n); L.p4 = nullptr; L.pal = nullptr; L.d_pal_n = nullptr; }
         L.pal_built.clear(); L.now_uses.clear(); L.tex16_stale.clear();
@@ -137,9 +208,30 @@ int ensure_texels(dvo_ctx *c, int level, int rows, int cols) {
 
     L.rows = rows; L.cols = cols;
     L.tex_stride = texel_count(rows, cols);
-    HIPCHK(c, hipMalloc((void **)&L.tex, sizeof(float4) * L.tex_stride * c->n_pairs));
+    const size_t bytes = sizeof(float4) * L.tex_stride * c->n_pairs;
+    if (tex_sparse_wanted(bytes)) {
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = c->device;
+        size_t gran = 0;
+        void *va = nullptr;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) == hipSuccess && gran > 0) {
+            const size_t chunk = ((((size_t)16 << 20) + gran - 1) / gran) * gran;         /* ~16 MiB: a few 640x480 pairs per mapping */
+            const size_t va_bytes = (bytes + chunk - 1) / chunk * chunk;
+            if (hipMemAddressReserve(&va, va_bytes, chunk, nullptr, 0) == hipSuccess && va) {
+                L.tex = reinterpret_cast<float4 *>(va);
+                L.tex_sparse = true; L.tex_chunk = chunk; L.tex_va_bytes = va_bytes;
+                L.tex_handles.assign(va_bytes / chunk, hipMemGenericAllocationHandle_t{});
+                L.tex_mapped.assign(va_bytes / chunk, 0);
+                return DVO_OK;
+            }
+        }
+        (void)hipGetLastError();                /* no virtual memory management on this runtime: the dense slab */
+    }
+    HIPCHK(c, hipMalloc((void **)&L.tex, bytes));
     if (L.tex_stride != (size_t)rows * cols)      /* tile padding is never read, but keep it defined */
-        HIPCHK(c, hipMemsetAsync(L.tex, 0, sizeof(float4) * L.tex_stride * c->n_pairs, c->stream));
+        HIPCHK(c, hipMemsetAsync(L.tex, 0, bytes, c->stream));
     return DVO_OK;
 }
 
@@ -191,6 +283,7 @@ int ensure_tex16(dvo_ctx *c, int level, int first_pair, int count) {
         if (!L.tex16_stale[p]) { p++; continue; }
         int q = p;
         while (q < first_pair + count && L.tex16_stale[q]) q++;
+        { const int mrc = map_texels(c, level, p, q - p); if (mrc) return mrc; }
         HIPCHK(c, launch_p4_decode_texels(L.p4, L.p4_stride, L.pal, L.d_pal_n, L.tex, L.tex_stride, L.rows, L.cols, p, q - p, c->stream));
         for (int i = p; i < q; i++) L.tex16_stale[i] = 0;
         p = q;
@@ -731,7 +824,7 @@ int dvo_destroy(dvo_ctx *c) {
     keep_warm_stop(c);
     if (c->stream) (void)stream_wait(c->stream);
     for (int l = 0; l < DVO_LEVELS; l++) {
-        if (c->lv[l].tex) (void)hipFree(c->lv[l].tex);
+        free_texels(c, c->lv[l]);
         if (c->lv[l].pts) (void)hipFree(c->lv[l].pts);
         if (c->lv[l].cpts) (void)hipFree(c->lv[l].cpts);
         if (c->lv[l].cidx) (void)hipFree(c->lv[l].cidx);
@@ -919,6 +1012,7 @@ static int set_now_common(dvo_ctx *c, int pair, int level, const float *dt, cons
         HIPCHK(c, hipMemcpyAsync(c->staging + 2 * npx, gy, npx * 4, hipMemcpyHostToDevice, c->stream));
         s_dt = c->staging; s_gx = c->staging + npx; s_gy = c->staging + 2 * npx;
     }
+    if ((rc = map_texels(c, level, pair, 1))) return rc;
     HIPCHK(c, launch_pack_texels(s_dt, s_gx, s_gy, L.tex + (size_t)pair * L.tex_stride, rows, cols, c->stream));
     if ((rc = now_written(c, level, pair, 1))) return rc;
     if (direct) {
@@ -984,8 +1078,19 @@ int dvo_set_now_level_from_edges(dvo_ctx *c, int pair, int level, const unsigned
     Level &L = c->lv[level];
     const bool compact = native_compact_wanted(c);
     if (compact && (rc = ensure_compact_slabs(c, level))) return rc;
-    HIPCHK(c, launch_edges_to_now(d_edge, 0, ImgBatch{rows, cols, 1}, work, L.tex + (size_t)pair * L.tex_stride, L.tex_stride,
+    /* a sparse texel slab: the stage runs without texel output first; the (rare) image the compact form cannot hold gets its
+     * texels mapped and written by a second run of the last pass */
+    const bool defer = compact && L.tex_sparse;
+    if (L.tex_sparse && !compact && (rc = map_texels(c, level, pair, 1))) return rc;
+    HIPCHK(c, launch_edges_to_now(d_edge, 0, ImgBatch{rows, cols, 1}, work, defer ? nullptr : L.tex + (size_t)pair * L.tex_stride, L.tex_stride,
                                   compact ? L.p4 : nullptr, L.p4_stride, L.pal, L.d_pal_n, pair, c->stream));
+    if (defer) {
+        int n_failed = 0;
+        if ((rc = sparse_map_compact_failures(c, level, pair, 1, c->stream, &n_failed))) return rc;
+        if (n_failed)
+            HIPCHK(c, launch_edges_to_now(d_edge, 0, ImgBatch{rows, cols, 1}, work, L.tex + (size_t)pair * L.tex_stride, L.tex_stride,
+                                          L.p4, L.p4_stride, L.pal, L.d_pal_n, pair, c->stream, true));
+    }
     if ((rc = compact ? now_written_compact(c, level, pair, 1) : now_written(c, level, pair, 1))) return rc;
     HIPCHK(c, stream_wait(c->stream));
     return DVO_OK;
@@ -1045,6 +1150,11 @@ int dvo_replicate_pairs(dvo_ctx *c, int n_src, int dst_first, int dst_count) {
             const bool stale = !L.tex16_stale.empty() && L.tex16_stale[p];
             any_tex16 = any_tex16 || !stale;
             any_compact = any_compact || (!L.pal_built.empty() && L.pal_built[p]);
+        }
+        if (any_tex16 && L.tex) {                    /* 16-byte texels travel: the destinations (and sources) need memory behind them */
+            int mrc = map_texels(c, l, 0, n_src);
+            if (!mrc) mrc = map_texels(c, l, dst_first, dst_count);
+            if (mrc) return mrc;
         }
         HIPCHK(c, launch_replicate_level(any_tex16 ? L.tex : nullptr, L.tex_stride, L.pts, L.cpts, L.cidx, L.cpt4, L.chdr, L.d_pt4_ok, L.pt_cap, L.dN, n_src, dst_first, dst_count, c->stream));
         for (int p = dst_first; p < dst_first + dst_count; p++) {

@@ -631,18 +631,30 @@ static int frames_as_now_level(dvo_ctx *c, int l, int first_slot, int first_pair
     if (compact && (rc = ensure_compact_slabs(c, l))) return rc;
     Level &L = c->lv[l];
     unsigned *p4 = compact ? L.p4 : nullptr;
+    /* sparse texel slab (dvo_ctx.h): the stage runs without texel output; the images the compact form cannot hold get their
+     * texels mapped and written by a second run of the last pass -- per chunk, while the chunk's scratch still holds them */
+    const bool defer = compact && L.tex_sparse;
+    if (L.tex_sparse && !compact && (rc = map_texels(c, l, first_pair, count))) return rc;
+    auto run = [&](const unsigned char *edge, int nc, int *wk, int pair0) -> int {
+        HIPCHK(c, launch_edges_to_now(edge, F.npx, ImgBatch{F.rows, F.cols, nc}, wk, defer ? nullptr : L.tex + (size_t)pair0 * L.tex_stride,
+                                      L.tex_stride, p4, L.p4_stride, L.pal, L.d_pal_n, pair0, stream));
+        if (defer) {
+            int n_failed = 0, rc2;
+            if ((rc2 = sparse_map_compact_failures(c, l, pair0, nc, stream, &n_failed))) return rc2;
+            if (n_failed)
+                HIPCHK(c, launch_edges_to_now(edge, F.npx, ImgBatch{F.rows, F.cols, nc}, wk, L.tex + (size_t)pair0 * L.tex_stride, L.tex_stride,
+                                              p4, L.p4_stride, L.pal, L.d_pal_n, pair0, stream, true));
+        }
+        return DVO_OK;
+    };
     if (work) {
-        HIPCHK(c, launch_edges_to_now(F.edge + (size_t)first_slot * F.npx, F.npx, ImgBatch{F.rows, F.cols, count}, work,
-                                      L.tex + (size_t)first_pair * L.tex_stride, L.tex_stride, p4, L.p4_stride, L.pal, L.d_pal_n,
-                                      first_pair, stream));
+        if ((rc = run(F.edge + (size_t)first_slot * F.npx, count, work, first_pair))) return rc;
     } else {
         const int chunk = chunk_for(sizeof(int) * edt_work_ints(F.rows, F.cols, 1), count);
         if ((rc = ensure_work(c, sizeof(int) * edt_work_ints(F.rows, F.cols, chunk)))) return rc;
         for (int b = 0; b < count; b += chunk) {
             const int nc = std::min(chunk, count - b);
-            HIPCHK(c, launch_edges_to_now(F.edge + (size_t)(first_slot + b) * F.npx, F.npx, ImgBatch{F.rows, F.cols, nc}, c->work,
-                                          L.tex + (size_t)(first_pair + b) * L.tex_stride, L.tex_stride, p4, L.p4_stride, L.pal,
-                                          L.d_pal_n, first_pair + b, stream));
+            if ((rc = run(F.edge + (size_t)(first_slot + b) * F.npx, nc, c->work, first_pair + b))) return rc;
         }
     }
     return compact ? now_written_compact(c, l, first_pair, count) : now_written(c, l, first_pair, count);
@@ -671,15 +683,33 @@ static int frames_as_now_all(dvo_ctx *c, int n_levels, int first_slot, int first
         const int nc = std::min(chunk, count - b);
         const unsigned char *edge[DVO_LEVELS]; size_t estride[DVO_LEVELS], tstride[DVO_LEVELS], pstride[DVO_LEVELS];
         float4 *tex[DVO_LEVELS]; unsigned *p4[DVO_LEVELS]; float2 *pal[DVO_LEVELS]; int *pal_n[DVO_LEVELS];
+        bool defer = false;
         for (int l = 0; l < n_levels; l++) {
             const FrameLevel &F = c->fs.lv[l];
             Level &L = c->lv[l];
             edge[l] = F.edge + (size_t)(first_slot + b) * F.npx; estride[l] = F.npx;
-            tex[l] = L.tex + (size_t)(first_pair + b) * L.tex_stride; tstride[l] = L.tex_stride;
+            if (L.tex_sparse && !compact && (rc = map_texels(c, l, first_pair + b, nc))) return rc;
+            const bool dl = compact && L.tex_sparse;                 /* sparse texel slab: no texel output in the first run */
+            defer = defer || dl;
+            tex[l] = dl ? nullptr : L.tex + (size_t)(first_pair + b) * L.tex_stride; tstride[l] = L.tex_stride;
             p4[l] = compact ? L.p4 : nullptr; pstride[l] = L.p4_stride; pal[l] = L.pal; pal_n[l] = L.d_pal_n;
         }
         HIPCHK(c, launch_edges_to_now_levels(n_levels, rows, cols, edge, estride, nc, c->work, tex, tstride, p4, pstride, pal, pal_n,
                                              first_pair + b, stream));
+        if (defer) {
+            int failed_any = 0;
+            for (int l = 0; l < n_levels; l++) {
+                Level &L = c->lv[l];
+                if (!L.tex_sparse) continue;
+                int n_failed = 0;
+                if ((rc = sparse_map_compact_failures(c, l, first_pair + b, nc, stream, &n_failed))) return rc;
+                failed_any += n_failed;
+                tex[l] = L.tex + (size_t)(first_pair + b) * L.tex_stride;      /* only the pairs just mapped are written (pal_n < 0) */
+            }
+            if (failed_any)
+                HIPCHK(c, launch_edges_to_now_levels(n_levels, rows, cols, edge, estride, nc, c->work, tex, tstride, p4, pstride, pal, pal_n,
+                                                     first_pair + b, stream, true));
+        }
     }
     for (int l = 0; l < n_levels; l++)
         if ((rc = compact ? now_written_compact(c, l, first_pair, count) : now_written(c, l, first_pair, count))) return rc;

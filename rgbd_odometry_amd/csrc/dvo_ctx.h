@@ -24,6 +24,14 @@ struct Level {
     int rows = 0, cols = 0;
     float4 *tex = nullptr;
     size_t tex_stride = 0;
+    /* SPARSE texel slab (round 4): the 16-byte texels of all pairs are one virtual address range (hipMemAddressReserve) of which
+     * only the chunks that some pair's texels were ever asked for are backed by memory (map_texels).  The engine's own now levels
+     * exist in the compact form only, so a large resident batch never maps any: 6.5 of the 9.7 MB a 640x480x4 pair used to hold.
+     * Kernels keep addressing base + pair * stride.  Dense (one hipMalloc, everything backed) for small slabs. */
+    bool tex_sparse = false;
+    size_t tex_chunk = 0, tex_va_bytes = 0;
+    std::vector<hipMemGenericAllocationHandle_t> tex_handles;   /* per chunk; tex_mapped says which are live */
+    std::vector<char> tex_mapped;
     float *pts = nullptr;
     uint2 *cpts = nullptr;          /* compact twin of pts (8 B / point), same capacity; valid where compact_ok */
     unsigned *cidx = nullptr;       /* per compact point: its index in the 3 x N list (the compact twin is in block order) */
@@ -234,6 +242,12 @@ int check_ready(dvo_ctx *c, int pair, int level);
 int build_schedule(dvo_ctx *c, int n_levels, const int *iters, int flags, dvo::Schedule &sc);
 int ensure_outputs(dvo_ctx *c, const dvo::Schedule &sc);
 void stamp_outputs(dvo_ctx *c, const dvo::Schedule &sc, int first, int n);
+/* backs the texels of pairs [first, first + count) of a level with memory (no-op for a dense slab) */
+int map_texels(dvo_ctx *c, int level, int first, int count);
+void free_texels(dvo_ctx *c, Level &L);
+/* sparse slabs, after a distance-transform launch over pairs [first, first + count) that ran WITHOUT texel output: waits for it,
+ * reads the palette sizes back and maps the texels of the images the compact form could not hold; *n_failed = how many */
+int sparse_map_compact_failures(dvo_ctx *c, int level, int first, int count, hipStream_t stream, int *n_failed);
 /* enqueues the level schedule of one pair as ONE launch per iteration on c->stream (dvo_kernels.hip: tiled_step_kernel): this
  * rank's contiguous share of every level's points (rank / world: dvo_tiled_shard's decomposition), `all_reduce` (may be empty:
  * one GPU) called on the 32 sums between two launches.  Pose in / out through d_pose (12 doubles on the device). */

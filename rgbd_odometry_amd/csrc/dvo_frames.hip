@@ -1345,6 +1345,9 @@ DVO_DEV void dt_normalize_gradient_pack_body(const int bx, const int gx, const i
         if (pal_n[pair] > 0 && !step) return;
         if (step && bx == 0 && threadIdx.x == 0) pal_n[pair] = -(int)PAL_STEP;   /* the other workgroups read the flag, not this */
     }
+    /* sparse texel slabs (round 4): the host has not mapped texel memory for these pairs yet -- this pass only settles pal_n;
+     * the host reads the palette sizes back, maps the texels of the (rare) images that need them and runs this pass again */
+    if (!out) return;
     d2 += (size_t)by * edt_g_count(rows, cols, R);      /* row blocks of R rows, like g */
     partial += (size_t)by * n_partial;
     out += (size_t)by * tex_stride;
@@ -1526,7 +1529,7 @@ static hipError_t edt_rows_pk_launch(const unsigned short *g, ImgBatch gb, unsig
  * written (16-byte texels only for the images it cannot hold); with p4 == NULL the 16-byte texels of every image. */
 hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, ImgBatch gb, int *work,
                                float4 *tex_out, size_t tex_stride, unsigned *p4, size_t p4_stride, float2 *pal, int *pal_n,
-                               int first_pair, hipStream_t s) {
+                               int first_pair, hipStream_t s, bool only_texels) {
     const int R = edt_rows_per_block(gb.cols);
     const unsigned nblk = edt_row_blocks(gb.rows, gb.cols);
     const int bm_words = edt_bitmap_words(gb.rows, gb.cols);
@@ -1538,7 +1541,7 @@ hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, Im
     unsigned *bitmap = reinterpret_cast<unsigned *>(partial + (size_t)nblk * gb.count);
     int *flags = reinterpret_cast<int *>(bitmap + (size_t)bm_words * gb.count);
     hipError_t e;
-    {
+    if (!only_texels) {
         const size_t lds_wave = (size_t)((gb.rows + 511) / 512) * 64 * sizeof(uint4);      /* 2 bytes per (padded) row */
         if (R <= 8 && lds_wave * 8 <= 48 * 1024) {            /* eight adjacent columns complete a 128-byte line of 8-row blocks */
             hipLaunchKernelGGL(edt_columns8_kernel<8>, dim3((gb.cols + 7) / 8, gb.count), dim3(512), lds_wave * 8, s, edge, edge_stride,
@@ -1553,7 +1556,8 @@ hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, Im
                                bm_words, flags);
         }
     }
-    switch (R) {
+    if (only_texels) e = hipSuccess;
+    else switch (R) {
     case 16: e = edt_rows_pk_launch<16>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
     case 8: e = edt_rows_pk_launch<8>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
     case 4: e = edt_rows_pk_launch<4>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
@@ -1564,7 +1568,7 @@ hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, Im
         break;
     }
     if (e != hipSuccess) return e;
-    if (p4) {
+    if (p4 && !only_texels) {
         const int ptiles_y = (p4_tiles_per_col(gb.rows) + PK_LR - 1) / PK_LR, ptiles_x = (((gb.cols + 3) >> 2) + PK_LC - 1) / PK_LC;
         /* tiles per workgroup: whole tile columns for large batches (the rank table is built once per workgroup), single tiles
          * when the launch would not fill the GPU otherwise (one camera stream) */
@@ -1623,7 +1627,7 @@ static hipError_t edt_rows_pk_levels_launch(const EdtLevels &t, unsigned g, int 
 }
 hipError_t launch_edges_to_now_levels(int n, const int *rows, const int *cols, const unsigned char *const *edge, const size_t *edge_stride, int count,
                                       int *work, float4 *const *tex_out, const size_t *tex_stride, unsigned *const *p4, const size_t *p4_stride,
-                                      float2 *const *pal, int *const *pal_n, int first_pair, hipStream_t s) {
+                                      float2 *const *pal, int *const *pal_n, int first_pair, hipStream_t s, bool only_texels) {
     EdtLevelShape sh;
     if (!edt_levels_shape(n, rows, cols, sh)) return hipErrorInvalidValue;
     EdtLevels t;
@@ -1652,19 +1656,22 @@ hipError_t launch_edges_to_now_levels(int n, const int *rows, const int *cols, c
         t.ntiles_y[l] = (rows[l] + NP_TY - 1) / NP_TY;
     }
     auto prefix = [&](auto blocks_of) { t.first[0] = 0; for (int l = 0; l < n; l++) t.first[l + 1] = t.first[l] + blocks_of(l); return t.first[n]; };
-    hipError_t e;
-    unsigned g = prefix([&](int l) { return (unsigned)((cols[l] + sh.waves - 1) / sh.waves); });
-    if (sh.waves == 8) hipLaunchKernelGGL(edt_columns8_levels_kernel<8>, dim3(g, count), dim3(512), sh.lds_cols, s, t);
-    else hipLaunchKernelGGL(edt_columns8_levels_kernel<4>, dim3(g, count), dim3(256), sh.lds_cols, s, t);
-    g = prefix([&](int l) { return (unsigned)t.n_partial[l]; });
-    switch (sh.R) {
-    case 16: e = edt_rows_pk_levels_launch<16>(t, g, count, sh.lds_rows, s); break;
-    case 8: e = edt_rows_pk_levels_launch<8>(t, g, count, sh.lds_rows, s); break;
-    case 4: e = edt_rows_pk_levels_launch<4>(t, g, count, sh.lds_rows, s); break;
-    default: e = edt_rows_pk_levels_launch<2>(t, g, count, sh.lds_rows, s); break;
+    hipError_t e = hipSuccess;
+    unsigned g = 0;
+    if (!only_texels) {
+        g = prefix([&](int l) { return (unsigned)((cols[l] + sh.waves - 1) / sh.waves); });
+        if (sh.waves == 8) hipLaunchKernelGGL(edt_columns8_levels_kernel<8>, dim3(g, count), dim3(512), sh.lds_cols, s, t);
+        else hipLaunchKernelGGL(edt_columns8_levels_kernel<4>, dim3(g, count), dim3(256), sh.lds_cols, s, t);
+        g = prefix([&](int l) { return (unsigned)t.n_partial[l]; });
+        switch (sh.R) {
+        case 16: e = edt_rows_pk_levels_launch<16>(t, g, count, sh.lds_rows, s); break;
+        case 8: e = edt_rows_pk_levels_launch<8>(t, g, count, sh.lds_rows, s); break;
+        case 4: e = edt_rows_pk_levels_launch<4>(t, g, count, sh.lds_rows, s); break;
+        default: e = edt_rows_pk_levels_launch<2>(t, g, count, sh.lds_rows, s); break;
+        }
     }
     if (e != hipSuccess) return e;
-    if (with_p4) {
+    if (with_p4 && !only_texels) {
         g = prefix([&](int l) {
             const int ptx = (((cols[l] + 3) >> 2) + PK_LC - 1) / PK_LC, n_strips = (t.ptiles_y[l] + t.strip[l] - 1) / t.strip[l];
             return (unsigned)(n_strips * ptx);

@@ -192,7 +192,8 @@ bool edt_levels_ok(int n, const int *rows, const int *cols);
 size_t edt_levels_work_ints(int n, const int *rows, const int *cols, int count);
 hipError_t launch_edges_to_now_levels(int n, const int *rows, const int *cols, const unsigned char *const *edge, const size_t *edge_stride, int count,
                                       int *work, float4 *const *tex_out, const size_t *tex_stride, unsigned *const *p4, const size_t *p4_stride,
-                                      float2 *const *pal, int *const *pal_n, int first_pair, hipStream_t s);
+                                      float2 *const *pal, int *const *pal_n, int first_pair, hipStream_t s,
+                                      bool only_texels = false /* only the pass that writes 16-byte texels (for images without a compact form); work as left by a full run */);
 /* caller-supplied float images -> compact form (see dvo_frames.hip); work: float_level_work_ints() ints */
 size_t float_level_work_ints(int rows, int cols);
 hipError_t launch_float_level_to_compact(const float *dt, const float *gx, const float *gy, int rows, int cols, int *work,
@@ -200,7 +201,7 @@ hipError_t launch_float_level_to_compact(const float *dt, const float *gx, const
 size_t edt_work_ints(int rows, int cols, int count);
 hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, ImgBatch g, int *work,
                                float4 *tex_out, size_t tex_stride, unsigned *p4, size_t p4_stride, float2 *pal, int *pal_n,
-                               int first_pair, hipStream_t s);
+                               int first_pair, hipStream_t s, bool only_texels = false);
 /* 16-byte texels of pairs [first_pair, first_pair + count) decoded from their compact form (pairs without one are skipped) */
 hipError_t launch_p4_decode_texels(const unsigned *p4, size_t p4_stride, const float2 *pal, const int *pal_n, float4 *tex,
                                    size_t tex_stride, int rows, int cols, int first_pair, int count, hipStream_t s);
