@@ -1332,10 +1332,13 @@ DVO_DEV void edt_rank_pack_body(const int bx, const int gx, const int by, const 
  * (one double sqrt per pixel); the lanes are then mapped so that 8 consecutive lanes write one whole 128-byte texel tile. */
 constexpr int NP_TY = 64, NP_TX = 16;
 static_assert(DVO_TILE_Y_LOG2 == 2 && DVO_TILE_X_LOG2 == 1, "the store mapping below assumes 4 x 2 texel tiles");
+/* bx / gx: this workgroup's index among the gx workgroups of its image (and level); it takes tiles bx, bx + gx, ... of the
+ * n_tiles the image has.  With a compact form in play the launch gives every image a handful of workgroups only (round 4): all
+ * but a rare image leave at the first test, and a grid of one workgroup per tile spent 63 us per 256 frames on leaving. */
 DVO_DEV void dt_normalize_gradient_pack_body(const int bx, const int gx, const int by, const unsigned *__restrict__ d2, int rows, int cols, int R, int tiles_y,
                                   const int *__restrict__ partial, int n_partial,
                                   float4 *__restrict__ out, size_t tex_stride,
-                                  int *__restrict__ pal_n /* NULL: every image */, const int *__restrict__ flags, int first_pair) {
+                                  int *__restrict__ pal_n /* NULL: every image */, const int *__restrict__ flags, int first_pair, int n_tiles) {
     constexpr int SH = NP_TY + 2, SW = NP_TX + 2;
     __shared__ float sn[SW * SH];                            /* [x][y], halo 1 */
     __shared__ int s_max;
@@ -1357,7 +1360,8 @@ DVO_DEV void dt_normalize_gradient_pack_body(const int bx, const int gx, const i
     if (threadIdx.x == 0) s_max = m;
     __syncthreads();
     const EdtScale sc = edt_scale((unsigned)s_max, rows, cols);
-    const int y0 = (bx % tiles_y) * NP_TY, x0 = (bx / tiles_y) * NP_TX;
+    for (int tile = bx; tile < n_tiles; tile += gx) {
+    const int y0 = (tile % tiles_y) * NP_TY, x0 = (tile / tiles_y) * NP_TX;
     for (int idx = threadIdx.x; idx < SW * SH; idx += 256) {
         const int lx = idx / SH, ly = idx - lx * SH;
         int yy = y0 + ly - 1, xx = x0 + lx - 1;
@@ -1382,6 +1386,8 @@ DVO_DEV void dt_normalize_gradient_pack_body(const int bx, const int gx, const i
             const float v = c[0];
             out[texel_index(yy, xx, tpc)] = make_float4(v, 0.5f * c[SH] - 0.5f * c[-SH], 0.5f * c[1] - 0.5f * c[-1], weight_of(v));
         }
+    }
+    __syncthreads();                                         /* the tile's values are consumed: the next tile may overwrite them */
     }
 }
 
@@ -1410,8 +1416,8 @@ edt_rank_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int R,
 __global__ void __launch_bounds__(256)
 dt_normalize_gradient_pack_kernel(const unsigned *__restrict__ d2, int rows, int cols, int R, int tiles_y,
                                   const int *__restrict__ partial, int n_partial, float4 *__restrict__ out, size_t tex_stride,
-                                  int *__restrict__ pal_n, const int *__restrict__ flags, int first_pair) {
-    dt_normalize_gradient_pack_body(blockIdx.x, gridDim.x, blockIdx.y, d2, rows, cols, R, tiles_y, partial, n_partial, out, tex_stride, pal_n, flags, first_pair);
+                                  int *__restrict__ pal_n, const int *__restrict__ flags, int first_pair, int n_tiles) {
+    dt_normalize_gradient_pack_body(blockIdx.x, gridDim.x, blockIdx.y, d2, rows, cols, R, tiles_y, partial, n_partial, out, tex_stride, pal_n, flags, first_pair, n_tiles);
 }
 
 /* ... and all pyramid levels per launch (see CannyLevels): the level table of the distance-transform stage.  One R (rows per
@@ -1448,7 +1454,7 @@ __global__ void __launch_bounds__(256) dt_normalize_gradient_pack_levels_kernel(
     const int l = level_of_block(t.first, t.n, blockIdx.x);
     dt_normalize_gradient_pack_body((int)(blockIdx.x - t.first[l]), (int)(t.first[l + 1] - t.first[l]), blockIdx.y, t.d2[l], t.rows[l], t.cols[l], t.R,
                                     t.ntiles_y[l], t.partial[l], t.n_partial[l], t.tex[l], t.tex_stride[l], with_p4 ? t.pal_n[l] : nullptr, t.flags[l],
-                                    t.first_pair);
+                                    t.first_pair, t.ntiles_y[l] * ((t.cols[l] + NP_TX - 1) / NP_TX));
 }
 
 /* compact form -> 16-byte texels {DT, gx, gy, w} of the images that have one (pal_n > 0), decoded exactly as the fused kernel
@@ -1582,8 +1588,10 @@ hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, Im
                                gb.cols, R, ptiles_y, (int)strip, partial, (int)nblk, bitmap, bm_words, flags, p4, p4_stride, pal, pal_n, first_pair, nullptr);
     }
     const int tiles_y = (gb.rows + NP_TY - 1) / NP_TY, tiles_x = (gb.cols + NP_TX - 1) / NP_TX;
-    hipLaunchKernelGGL(dt_normalize_gradient_pack_kernel, dim3(tiles_y * tiles_x, gb.count), dim3(256), 0, s, d2, gb.rows, gb.cols, R,
-                       tiles_y, partial, (int)nblk, tex_out, tex_stride, p4 ? pal_n : nullptr, flags, first_pair);
+    /* with a compact form nearly every image leaves at once: a few workgroups per image then, one per tile otherwise */
+    const int pack_wgs = p4 ? std::min(tiles_y * tiles_x, 8) : tiles_y * tiles_x;
+    hipLaunchKernelGGL(dt_normalize_gradient_pack_kernel, dim3(pack_wgs, gb.count), dim3(256), 0, s, d2, gb.rows, gb.cols, R,
+                       tiles_y, partial, (int)nblk, tex_out, tex_stride, p4 ? pal_n : nullptr, flags, first_pair, tiles_y * tiles_x);
     return hipGetLastError();
 }
 
@@ -1679,7 +1687,7 @@ hipError_t launch_edges_to_now_levels(int n, const int *rows, const int *cols, c
         hipLaunchKernelGGL(edt_rank_pack_levels_kernel<PK_SMALL_WORDS>, dim3(g, count), dim3(256), 0, s, t);
         if (max_bm > PK_SMALL_WORDS) hipLaunchKernelGGL(edt_rank_pack_levels_kernel<DVO_EDT_BITMAP_BITS / 32>, dim3(g, count), dim3(256), 0, s, t);
     }
-    g = prefix([&](int l) { return (unsigned)(t.ntiles_y[l] * ((cols[l] + NP_TX - 1) / NP_TX)); });
+    g = prefix([&](int l) { const unsigned nt = (unsigned)(t.ntiles_y[l] * ((cols[l] + NP_TX - 1) / NP_TX)); return with_p4 ? std::min(nt, 8u) : nt; });
     hipLaunchKernelGGL(dt_normalize_gradient_pack_levels_kernel, dim3(g, count), dim3(256), 0, s, t, with_p4 ? 1 : 0);
     return hipGetLastError();
 }
