@@ -556,6 +556,9 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         sc.force_exact = (c->prm.engine_variant == 3) ? 1 : 0;
         static const bool no_pt4_env = [] { const char *e = std::getenv("DVO_POINTS4"); return e && std::strcmp(e, "off") == 0; }();
         sc.no_pt4 = no_pt4_env ? 1 : 0;
+        /* 4-byte points from this many times the LDS capacity (in 8-byte points) on; DVO_POINTS4_FACTOR for A/B measurements */
+        static const int pt4_factor_env = [] { const char *e = std::getenv("DVO_POINTS4_FACTOR"); return e ? std::atoi(e) : 3; }();
+        sc.pt4_factor = pt4_factor_env;
         /* pt4_decode rebuilds a point's pixel from its 16 x 16 block index with the number of block rows of the image the list was
          * ENCODED against; the kernel only knows the now level's rows.  Reference and now levels of different heights (nothing
          * forbids them) therefore read the 8-byte form, which carries absolute coordinates */

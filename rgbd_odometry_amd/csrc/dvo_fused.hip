@@ -788,7 +788,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
          * the kernel is as close to its instruction-issue ceiling as to the request ceiling.  Measured A/B (DVO_POINTS4=off):
          * 640x480 level 0 (14.8 k points, 8.2 k fit as 8-byte points) 723 k vs 731 k aligns/s -- a wash, so not taken;
          * 1920x1080 (130 k / 67 k points against 19 k that fit) 77.5 k vs 75.0 k.  Taken from three times the LDS capacity. */
-        const bool pt4 = !TEAM && mode == TEX_P4 && !sc.no_pt4 && N >= 3 * (((lds_words - pal_words) >> 1) & ~1) && L.pt4_ok &&
+        const bool pt4 = !TEAM && mode == TEX_P4 && !sc.no_pt4 && N >= sc.pt4_factor * (((lds_words - pal_words) >> 1) & ~1) && L.pt4_ok &&
                          __builtin_amdgcn_readfirstlane(L.pt4_ok[dpair]) != 0;
         float *const lds_pts = lds_dyn + pal_words;
         const int cap = (mode == TEX_L16) ? n_pad

@@ -64,6 +64,7 @@ struct Schedule {
     int force_exact;         /* tests: every wave takes the literal-division fallback of the packed kernel (accumulate_points_exact) */
     int compact;             /* every pair/level of this launch has a compact point list: read 8 B / point instead of 12 */
     int no_pt4;              /* diagnostics: never read the 4-byte form of a reference list (DVO_POINTS4=off) */
+    int pt4_factor;          /* 4-byte points for lists of at least this many times what the LDS holds as 8-byte points (default 3) */
     int final_blk;           /* host bookkeeping: the final outputs of this launch are stored in the compact lists' (block) order */
 };
 
