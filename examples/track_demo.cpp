@@ -5,6 +5,7 @@
  * reference and writes one "qx qy qz qw tx ty tz" line per frame (printPose, :1341-1354).
  *
  *   track_demo <dir> <start> <end> <skip> <n_levels> <fx> <fy> <cx> <cy> <iters_per_level> <poses.txt>
+ *              [<laplacian_b_thresh> <visible_ratio_thresh> <min_points>]     the reference's adaptive key-frame exits (:2129-2152)
  */
 #include <chrono>
 #include <cstdio>
@@ -14,8 +15,8 @@
 #include "dvo_amd.hpp"
 
 int main(int argc, char **argv) {
-    if (argc != 12) {
-        std::fprintf(stderr, "usage: %s dir start end skip n_levels fx fy cx cy iters poses.txt\n", argv[0]);
+    if (argc != 12 && argc != 15) {
+        std::fprintf(stderr, "usage: %s dir start end skip n_levels fx fy cx cy iters poses.txt [laplacian_b_thresh visible_ratio_thresh min_points]\n", argv[0]);
         return 2;
     }
     const char *dir = argv[1];
@@ -26,6 +27,12 @@ int main(int argc, char **argv) {
         dvo.setCameraMatrix((float)std::atof(argv[6]), (float)std::atof(argv[7]), (float)std::atof(argv[8]), (float)std::atof(argv[9]));
         dvo.iterationsConfig.assign(nl, iters);
         dvo.syncAfterNowFrame = std::getenv("TRACK_DEMO_SYNC") != nullptr;
+        if (argc == 15) {
+            dvo.adaptiveKeyFrames = true;
+            dvo.laplacianThreshExitCond = (float)std::atof(argv[12]);
+            dvo.ratio_of_visible_pts_thresh = (float)std::atof(argv[13]);
+            dvo.minReprojectedPoints = std::atoi(argv[14]);
+        }
         std::ofstream poses(argv[11]);
         char name[1024];
         double load_ms = 0, track_ms = 0;
@@ -48,6 +55,7 @@ int main(int argc, char **argv) {
             const dvo_amd::Pose p = dvo.processFrame();
             dvo_amd::SolveDVO::printPose(p, poses);
             const double dt = ms(t1, now());
+            if (dvo.adaptiveKeyFrames && std::getenv("TRACK_DEMO_VERBOSE")) std::printf("frame %ld: b_cap %.9g visible %.9g points %d\n", n, dvo.lastLaplacianB, dvo.lastVisibleRatio, dvo.lastNumPoints);
             if (std::getenv("TRACK_DEMO_VERBOSE")) std::printf("frame %ld: %.3f ms (now-frame %.3f, first alignment %.3f)  t = %.4f %.4f %.4f\n", n, dt, dvo.lastNowFrameMs, dvo.lastAlignMs, p.px, p.py, p.pz);
             track_ms += dt;
             tracked++;

@@ -310,8 +310,15 @@ public:
 
     /* the level loop of SolveDVO::loop (:2097-2104): for f = size-1 .. 0: if cfg[f] > 0: runIterations(f, ...) --
      * fused into one kernel launch. */
-    void alignPyramid(double *cR, double *cT) {
-        chk(dvo_align_pyramid(ctx_, (int)iterationsConfig.size(), iterationsConfig.data(), 0, cR, cT));
+    void alignPyramid(double *cR, double *cT, int flags = 0) {
+        chk(dvo_align_pyramid(ctx_, (int)iterationsConfig.size(), iterationsConfig.data(), flags, cR, cT));
+    }
+    /* processResidueHistogram (:1398-1481) without its display: the MLE of the Laplacian scale of the residues = their mean,
+     * accumulated in float in the list's order as the reference does (:1455-1462) */
+    static float processResidueHistogram(const std::vector<float> &residi) {
+        float b_cap = 0;
+        for (size_t i = 0; i < residi.size(); i++) b_cap += residi[i];
+        return residi.empty() ? 0.0f : b_cap / (float)residi.size();
     }
     void levelReport(int level, std::vector<float> &energy, int &bestEnergyIndex, float &visibleRatio) {
         energy.assign(iterationsConfig.at(level), 0.0f);
@@ -415,12 +422,32 @@ public:
         setRcvdFrameAsNowFrame();
         if (syncAfterNowFrame) chk(dvo_synchronize(ctx_));                          /* diagnostics: separates the two stages' times */
         const auto t1 = std::chrono::steady_clock::now();
-        alignPyramid(cR_64, cT_64);                                                /* :2097-2104 (warm start from the last estimate) */
+        alignPyramid(cR_64, cT_64, adaptiveKeyFrames ? DVO_FLAG_FINAL_OUTPUTS : 0);  /* :2097-2104 (warm start from the last estimate) */
         const auto t2 = std::chrono::steady_clock::now();
         lastNowFrameMs = std::chrono::duration<double, std::milli>(t1 - t0).count();
         lastAlignMs = std::chrono::duration<double, std::milli>(t2 - t1).count();   /* jdur of :2092-2109 */
         bool signalGetNewRefImage = false;
         int reasonForChange = 0;
+        if (adaptiveKeyFrames) {
+            /* the three exits the reference has commented out (:2129-2152), evaluated on the last level that ran -- its best iterate's
+             * visible ratio, finalEpsilons and point count, as the loop leaves them (:2102).  As written there the statement that
+             * follows them (`signalGetNewRefImage = false`, :2154) would void all three; here they are OR-ed with the live rule. */
+            int last = -1;
+            for (int f = 0; f < (int)iterationsConfig.size() && last < 0; f++) if (iterationsConfig[f] > 0) last = f;
+            need(last >= 0, "processFrame: no level has iterations");
+            std::vector<float> energy; int best = -1; float visibleRatio = 1.0f;
+            levelReport(last, energy, best, visibleRatio);
+            int n = 0;
+            epsilonVec_.assign(ref_points_.at(last).size() / 3, 0.0f);              /* one residue per reference point of that level */
+            chk(dvo_get_final_outputs(ctx_, 0, epsilonVec_.data(), nullptr, (int)epsilonVec_.size(), &n));
+            epsilonVec_.resize((size_t)n);
+            lastLaplacianB = processResidueHistogram(epsilonVec_);                  /* b_cap :2116-2120 */
+            lastVisibleRatio = visibleRatio;
+            lastNumPoints = n;
+            if (lastLaplacianB > laplacianThreshExitCond) { signalGetNewRefImage = true; reasonForChange = 2; }      /* :2131-2136 */
+            if (visibleRatio < ratio_of_visible_pts_thresh) { signalGetNewRefImage = true; reasonForChange = 3; }    /* :2139-2144 */
+            if (n < minReprojectedPoints) { signalGetNewRefImage = true; reasonForChange = 4; }                      /* :2146-2151 */
+        }
         if ((nFrame - lastRefFrame) == keyFrameEvery) { signalGetNewRefImage = true; reasonForChange = 5; }   /* :2155-2160 */
         if (signalGetNewRefImage && lastRefFrame != nFrame - 1) {                  /* :2198 */
             lastRefFrame = nFrame - 1;
@@ -446,6 +473,12 @@ public:
     double cR_64[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, cT_64[3] = {0, 0, 0};          /* key-frame relative estimate (column-major) */
     long nFrame = 0, lastRefFrame = 0;
     int keyFrameEvery = 5;                                                         /* (nFrame - lastRefFrame) == 5  :2156 */
+    /* the reference's adaptive key-frame signals (:2129-2152, commented out there; constants :22-23): off by default */
+    bool adaptiveKeyFrames = false;
+    float ratio_of_visible_pts_thresh = 0.8f, laplacianThreshExitCond = 3.0f;
+    int minReprojectedPoints = 50;
+    float lastLaplacianB = 0.0f, lastVisibleRatio = 1.0f;                          /* what the last frame's first alignment produced */
+    int lastNumPoints = 0;
 
     /* casualTestFunction (:2377-2442), the reference's only two-frame regression of the hot path: frame `refFile` as the
      * reference frame, `nowFile` as the now frame (TUM_RGBD/fr1_rpy/framemono_0080.xml and _0085.xml there, not shipped),
@@ -476,6 +509,7 @@ public:
     dvo_ctx *handle() { return ctx_; }
 
 private:
+    std::vector<float> epsilonVec_;                                                /* keeps its capacity from frame to frame */
     void chk(int rc) { if (rc != DVO_OK) throw std::runtime_error(dvo_last_error(ctx_)); }
     static void need(bool ok, const char *what) { if (!ok) throw std::runtime_error(what); }
 public:

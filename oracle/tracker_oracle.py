@@ -10,6 +10,8 @@ TEST INFRASTRUCTURE, NOT PRODUCT CODE (same rule as oracle/dvo_oracle.h).  numpy
   src/GOP.cpp:138-196          global_T = key_T + key_R*cT, global_R = key_R*cR; updateMostRecentToKeyFrame
   src/GOP.cpp:103-115          Eigen::Quaternion(Matrix3) for the pose message
   src/SolveDVO.cpp:1341-1354   "qx qy qz qw tx ty tz" (default ostream precision: 6 significant digits)
+  src/SolveDVO.cpp:2129-2152   the adaptive key-frame exits (Laplacian scale of the residues :1398-1481, visible ratio, < 50
+                               points; constants :22-23) -- commented out in the reference, optional here
 
 PARITY UNPINNED (no reference vectors exist for any of this; Eigen is not in the image).  The alignment itself is
 delegated to a callable so that the policy can be checked with a stub and, with the C oracle, end to end.
@@ -76,9 +78,19 @@ def pose_line(R, t):
     return " ".join("%g" % v for v in (q[0], q[1], q[2], q[3], t[0], t[1], t[2]))
 
 
-def track(n_frames, align, key_frame_every=5):
-    """align(ref_index, now_index, R0, t0) -> (R, t): the level schedule of :2097-2104 between two frames.
-    Returns (gop, lines) with one pose line per frame after the first."""
+def laplacian_b(residues):
+    """processResidueHistogram (:1455-1462): mean of the residues, accumulated in float32 in the list's order"""
+    r = np.asarray(residues, dtype=np.float32)
+    if r.size == 0:
+        return np.float32(0)
+    return np.float32(np.cumsum(r, dtype=np.float32)[-1] / np.float32(r.size))
+
+
+def track(n_frames, align, key_frame_every=5, adaptive=None):
+    """align(ref_index, now_index, R0, t0) -> (R, t) or (R, t, info): the level schedule of :2097-2104 between two frames;
+    info = dict(final_eps=..., visible_ratio=..., n=...) of the last level that ran (needed when `adaptive` is given).
+    adaptive: None, or dict(laplacian_b=3.0, visible_ratio=0.8, min_points=50): the three exits of :2129-2152 (commented out in the
+    reference), OR-ed with the live every-5-frames rule.  Returns (gop, lines) with one pose line per frame after the first."""
     gop = GOP()
     cR, cT = np.eye(3), np.zeros(3)
     last_ref = 0
@@ -86,13 +98,25 @@ def track(n_frames, align, key_frame_every=5):
     gop.push_key(0, 1, cR, cT)                                   # :2014
     lines = []
     for n in range(1, n_frames):
-        cR, cT = align(ref, n, cR, cT)                           # :2097-2104 (warm start)
-        signal = (n - last_ref) == key_frame_every               # :2155-2160
+        out = align(ref, n, cR, cT)                              # :2097-2104 (warm start)
+        cR, cT = out[0], out[1]
+        signal, reason = False, 0
+        if adaptive is not None:
+            info = out[2]
+            if laplacian_b(info["final_eps"]) > np.float32(adaptive["laplacian_b"]):      # :2131
+                signal, reason = True, 2
+            if np.float32(info["visible_ratio"]) < np.float32(adaptive["visible_ratio"]):  # :2139
+                signal, reason = True, 3
+            if info["n"] < adaptive["min_points"]:                                          # :2146
+                signal, reason = True, 4
+        if (n - last_ref) == key_frame_every:                    # :2155-2160
+            signal, reason = True, 5
         if signal and last_ref != n - 1:                         # :2198
             last_ref = n - 1
             ref = n - 1                                          # setPrevFrameAsRefFrame + preProcessRefFrame
-            gop.update_most_recent_to_key(5)                     # :2207
-            cR, cT = align(ref, n, np.eye(3), np.zeros(3))       # :2210-2227
+            gop.update_most_recent_to_key(reason)                # :2207
+            out = align(ref, n, np.eye(3), np.zeros(3))          # :2210-2227
+            cR, cT = out[0], out[1]
         gop.push_ordinary(n, cR, cT)                             # :2232 / :2239
         lines.append(pose_line(gop.elems[-1]["R"], gop.elems[-1]["t"]))
     return gop, lines

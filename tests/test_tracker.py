@@ -60,6 +60,30 @@ def test_key_frame_policy_with_stub_aligner():
     assert len(lines) == 12 and lines[0].split() == ["0", "0", "0", "1", "1", "0", "0"]
 
 
+def test_adaptive_key_frame_exits_with_stub_aligner():
+    """the three exits the reference has commented out (:2129-2152): a Laplacian scale above its threshold (reason 2), too few
+    visible points (3), too few points (4); OR-ed with the every-5-frames rule (5); never a switch when n-1 is the reference already"""
+    seen = {}
+
+    def align(ref, now, R0, t0):
+        info = dict(final_eps=np.full(100, 1.0, np.float32), visible_ratio=0.95, n=100)
+        if now == 3 and ref == 0:
+            info["final_eps"] = np.full(100, 4.0, np.float32)         # b_cap = 4 > 3
+        if now == 6 and ref != 5:
+            info["visible_ratio"] = 0.5
+        if now == 9 and ref != 8:
+            info["n"] = 10
+        seen[(ref, now)] = True
+        return np.eye(3), np.array([float(now - ref), 0.0, 0.0]), info
+
+    gop, lines = T.track(12, align, adaptive=dict(laplacian_b=3.0, visible_ratio=0.8, min_points=50))
+    keys = [(e["frame"], e["reason"]) for e in gop.elems if e["key"]]
+    assert keys == [(0, 1), (2, 2), (5, 3), (8, 4)], keys
+    assert (2, 3) in seen and (5, 6) in seen and (8, 9) in seen            # re-runs against the new reference
+    assert np.allclose([e["t"][0] for e in gop.elems], np.arange(12))
+    assert T.laplacian_b(np.array([1, 2, 3], np.float32)) == np.float32(2.0) and T.laplacian_b([]) == 0
+
+
 def _sequence(n, rows, cols, levels, first_shift, oracle):
     frames = []
     for i in range(n):
@@ -113,3 +137,47 @@ def test_cpp_file_replay_matches_oracle_chain(tmp_path, oracle):
     W = np.array([[float(x) for x in ln.split()] for ln in want])
     assert np.abs(G - W).max() <= 2e-5                       # 6 significant digits in the file; poses agree to ~1e-15
     assert np.abs(W[-1, 4:]).max() > 1e-3                    # the sequence really moves
+
+
+@pytest.mark.gpu
+def test_cpp_file_replay_with_adaptive_key_frames(tmp_path, oracle):
+    """the same replay with the reference's adaptive exits switched on (SolveDVO.cpp:2129-2152; dvo_amd::SolveDVO::adaptiveKeyFrames):
+    the Laplacian scale of finalEpsilons -- a float sum in the list's order, bit-equal between the engine and the oracle -- against a
+    threshold placed between the values the sequence produces, so that exits of reason 2 really happen; key frames and poses must
+    match the oracle chain"""
+    n, rows, cols, nl, it = 12, 240, 320, 3, 8
+    K = tuple(np.float32(k) for k in (262.5, 262.5, 159.75, 119.75))
+    frames = _sequence(n, rows, cols, nl, 0, oracle)
+    for i, pyr in enumerate(frames):
+        frame_io.write_frame_xml(str(tmp_path / ("framemono_%04d.xml" % i)), pyr)
+    cache, b_seen = {}, []
+
+    def level_inputs(ref, now):
+        if ("r", ref) not in cache:
+            cache[("r", ref)] = [oracle.ref_level_from_grey(l, g, d, K) for l, (g, d) in enumerate(frames[ref])]
+        if ("n", now) not in cache:
+            cache[("n", now)] = [oracle.now_level_from_grey(g) for g, _ in frames[now]]
+        return [dict(xyz=r[0], uv=r[1], dt=m[0], gx=m[1], gy=m[2], rows=g.shape[0], cols=g.shape[1])
+                for r, m, (g, _) in zip(cache[("r", ref)], cache[("n", now)], frames[now])]
+
+    def align(ref, now, R0, t0):
+        r = oracle.align_pyramid([it] * nl, level_inputs(ref, now), K, R0, t0)
+        last = r["levels"][r["last_level"]]
+        info = dict(final_eps=last["final_eps"], visible_ratio=last["visible_ratio"], n=len(last["final_eps"]))
+        b_seen.append(float(T.laplacian_b(info["final_eps"])))
+        return np.array(r["R"]), np.array(r["t"]), info
+
+    T.track(n, align, adaptive=dict(laplacian_b=1e9, visible_ratio=0.0, min_points=0))      # first pass: the values this sequence has
+    b_thresh = float(np.float32(np.sort(b_seen)[len(b_seen) * 2 // 3]))                     # a third of the frames exceed it
+    gop, want = T.track(n, align, adaptive=dict(laplacian_b=b_thresh, visible_ratio=0.3, min_points=50))
+    keys = " ".join("%d(reason %d)" % (e["frame"], e["reason"]) for e in gop.elems if e["key"])
+    assert "reason 2" in keys, (keys, b_thresh, b_seen)
+    out = tmp_path / "estPoses.txt"
+    run = subprocess.run([DEMO, str(tmp_path), "0", str(n - 1), "1", str(nl)] + [repr(float(k)) for k in K] +
+                         [str(it), str(out), repr(b_thresh), "0.3", "50"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr
+    assert "keyframes: " + keys in run.stdout, (run.stdout, keys)
+    got = out.read_text().strip().splitlines()
+    G = np.array([[float(x) for x in ln.split()] for ln in got])
+    W = np.array([[float(x) for x in ln.split()] for ln in want])
+    assert G.shape == W.shape and np.abs(G - W).max() <= 2e-5
