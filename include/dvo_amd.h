@@ -237,8 +237,10 @@ int  dvo_iter_end(dvo_ctx *ctx, int pair, int level, double *R, double *t, float
 
 /* The same loop for ONE GPU, enqueued from C: the level schedule of SolveDVO::loop with every iteration
  * spread over all CUs (frames whose point lists are too long for one workgroup).  Synchronous; per-level
- * energies / best index / ratio afterwards through dvo_get_level_report.  flags: 0 or DVO_FLAG_FINAL_OUTPUTS
- * (finalEpsilons / finalReprojections of the last level, SolveDVO.cpp:703-704, :1002-1003 -> dvo_get_final_outputs). */
+ * energies / best index / ratio afterwards through dvo_get_level_report.  flags: DVO_FLAG_FINAL_OUTPUTS
+ * (finalEpsilons / finalReprojections of the last level, SolveDVO.cpp:703-704, :1002-1003 -> dvo_get_final_outputs) and / or
+ * DVO_FLAG_NORMAL_MATRIX (H = sum w J J^T of every iterate -> dvo_get_level_normal_matrix; + 40 % on every launch).
+ * One launch per iteration (the update of an iteration rides at the head of the next launch), replayed as a graph. */
 int  dvo_align_pyramid_wide(dvo_ctx *ctx, int pair, int n_levels, const int *iters, int flags, double *R, double *t);
 
 /* ---- tiled mode from C: one large frame sharded over the GPUs of a node (BASELINE configs[4]) ----------
@@ -254,7 +256,10 @@ int  dvo_align_pyramid_wide(dvo_ctx *ctx, int pair, int n_levels, const int *ite
  * or does not finish fast enough (break-even: DESIGN.md section 5). */
 int  dvo_tiled_attach(dvo_ctx *ctx, void *nccl_comm, int rank, int world, const char *rccl_library);
 int  dvo_tiled_detach(dvo_ctx *ctx);
-/* flags: 0 or DVO_FLAG_FINAL_OUTPUTS.  With it every rank computes finalEpsilons / finalReprojections (SolveDVO.cpp:703-704,
+/* flags: DVO_FLAG_FINAL_OUTPUTS and / or DVO_FLAG_NORMAL_MATRIX (H = sum w J J^T travels in the same 32 all-reduced doubles and is
+ * kept per iterate: dvo_get_level_normal_matrix; without it the 21 slots are zeros).  One kernel + one ncclAllReduce per
+ * iteration, the whole schedule captured once and replayed as a graph (dvo_tiled_graph_replayed).
+ * With DVO_FLAG_FINAL_OUTPUTS every rank computes finalEpsilons / finalReprojections (SolveDVO.cpp:703-704,
  * :1002-1003) of ITS shard of the last level's list, at the points' own indices: dvo_get_final_outputs then returns arrays in
  * which only [first, first + count) of dvo_tiled_shard is filled in on this rank -- the caller concatenates the shards
  * (SURVEY.md 8e).  Thread safety: contexts of different GPUs may be driven from different host threads of one process
