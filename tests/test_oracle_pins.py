@@ -153,3 +153,166 @@ def test_per_point_path_against_the_matrix_form(oracle):
 def oracle_lib_levels(sc, oracle):
     import oracle_lib
     return oracle_lib.scene_levels(sc, oracle)
+
+
+# ---- SolveDVO::runIterations (SolveDVO.cpp:619-1005) restated a second time, from scipy's Lie-group and polar routines ----
+def _np_eval_points(level, P32, dt, gx, gy, rows, cols, K, R, t):
+    """computeJacobianOfNowFrame + getReprojectedEpsilons (:302-460) in numpy float32, array at a time as the reference's Eigen
+    expressions are (repmat / cR^T * (.) / row-wise inverse / scaleMatrix * K * (.)), the per-point part as G * A1 * A2."""
+    f = np.float32
+    fx, fy, cx, cy = (f(k) for k in K)
+    Rt = R.astype(f).T
+    Pt = (Rt @ (P32.T - t.astype(f)[:, None])).astype(f)                       # :330
+    inv = (f(1) / Pt[2]).astype(f)                                             # :338 array().inverse()
+    Pt = (Pt * inv).astype(f)                                                  # :339-341
+    s = f(2.0 ** (-level))
+    Km = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], f)
+    rep = ((np.diag([s, s, f(1)]).astype(f) @ Km).astype(f) @ Pt).astype(f)    # :344 (scaleMatrix * K first, as Eigen evaluates it)
+    u, v = rep[0], rep[1]
+    vis = (u >= 0) & (u < cols) & (v >= 0) & (v < rows)                        # :371 with the half-open fix the oracle documents
+    xx = np.where(vis, u, 0).astype(np.int64)
+    yy = np.where(vis, v, 0).astype(np.int64)
+    X, Y, Z = Pt
+    G = np.stack([gx[yy, xx], gy[yy, xx]], 1).astype(f)                        # N x 2
+    A1 = np.zeros((len(X), 2, 3), f)
+    A1[:, 0, 0] = s * fx / Z
+    A1[:, 0, 2] = -s * fx * X / (Z * Z)
+    A1[:, 1, 1] = s * fy / Z
+    A1[:, 1, 2] = -s * fy * Y / (Z * Z)
+    tmp = (Rt @ Pt).astype(f).T                                                # :399
+    A2 = np.zeros((len(X), 3, 6), f)
+    A2[:, :, :3] = -Rt
+    A2[:, 0, 4], A2[:, 0, 5] = -tmp[:, 2], tmp[:, 1]                           # to_se_3 (:1104-1114)
+    A2[:, 1, 3], A2[:, 1, 5] = tmp[:, 2], -tmp[:, 0]
+    A2[:, 2, 3], A2[:, 2, 4] = -tmp[:, 1], tmp[:, 0]
+    J = np.einsum("na,nab,nbc->nc", G, A1, A2).astype(f)
+    J[~vis] = 0                                                                # :375 continue leaves the zero row
+    eps = np.where(vis, dt[yy, xx], f(0)).astype(f)                            # :446
+    w = np.where(vis, (6.0 / (6.0 + (eps * eps).astype(f).astype(np.float64) / .25)).astype(f), f(0))   # :1047-1053
+    return J, eps, w, vis
+
+
+def _np_update(itr, R, t, d, g, trust, stop):
+    """:724-919 after the per-point phase: pre-conditioner, normalised-log regulariser, step schedule, momentum, trust region,
+    termination, right-multiplied exponential update, polar re-orthonormalisation.  Returns (R, t, d, psi, broke)."""
+    PVec = np.array([1.0, 1.0, 1.0, .5, .5, .5])
+    rv = Rotation.from_matrix(R).as_rotvec()
+    cPsi = np.concatenate([np.linalg.solve(_V(rv), t), rv])                    # Sophus::SE3d::log: (upsilon, omega)
+    if np.linalg.norm(cPsi) > 0:
+        cPsi = cPsi / np.linalg.norm(cPsi)
+    step = 9.0 * 1.0E-2 / ((itr - 4.0) if itr > 5 else 1.0)
+    g = g + 0.05 * cPsi
+    d = 0.5 * g + 0.5 * d
+    psi = -step * PVec * d
+    n = np.linalg.norm(psi)
+    if n > trust:
+        psi = psi / n * trust
+    elif n < stop:
+        return R, t, d, np.zeros(6), True
+    xR = Rotation.from_rotvec(psi[3:]).as_matrix()
+    xT = _V(psi[3:]) @ psi[:3]
+    t = t + R @ xT
+    R = polar(R @ xR)[0]
+    return R, t, d, psi, False
+
+
+def _level_arrays(L):
+    rows, cols = L["rows"], L["cols"]
+    return tuple(np.asarray(L[k], np.float32).reshape(cols, rows).T for k in ("dt", "gx", "gy"))
+
+
+def test_update_policy_against_numpy_restatement_step_by_step(oracle):
+    """Every iteration of the oracle's trace: from the pose before the iteration and the oracle's own gradient sum, the scipy
+    restatement of :724-919 must produce the same increment and the same next pose (to double rounding)."""
+    from rgbd_odometry_amd import SynthScene
+    sc = SynthScene(320, 240, 3, 5)
+    prm = oracle.default_params()
+    levels = oracle_lib_levels(sc, oracle)
+    for level, iters in ((2, 40), (0, 25)):
+        L = levels[level]
+        R0, t0 = oracle.se3_exp(np.array([0.01, -0.02, 0.015, 0.004, -0.003, 0.005]))
+        out = oracle.run_iterations(level, iters, L["xyz"], L["dt"], L["gx"], L["gy"], L["rows"], L["cols"], sc.intrinsics,
+                                    R0, t0, trace=True)
+        R, t, d = np.asarray(R0, float), np.asarray(t0, float), np.zeros(6)
+        clamped = free = 0
+        for itr, tr in enumerate(out["trace"]):
+            R, t, d, psi, broke = _np_update(itr, R, t, d, tr["g"], float(prm.trust_radius), float(prm.psi_norm_stop))
+            assert broke == bool(tr["broke"])
+            if broke:
+                break
+            assert np.abs(psi - tr["psi"]).max() <= 1e-12 * max(1.0, np.abs(psi).max()), (level, itr)
+            assert np.abs(R - tr["R"]).max() <= 1e-12 and np.abs(t - tr["t"]).max() <= 1e-12, (level, itr)
+            R, t = tr["R"].copy(), tr["t"].copy()                              # restart from the oracle's pose: no drift
+            clamped += np.linalg.norm(psi) >= float(prm.trust_radius) * (1 - 1e-12)
+        assert clamped > 0, level                                              # real gradients: the trust region decides the length
+
+
+def test_update_policy_below_the_trust_radius_and_at_termination(oracle):
+    """Gradients of the bench scenes always hit the trust-region clamp; here synthetic gradient sums small enough to pass it
+    unclamped (step schedule, pre-conditioner and momentum then set the increment) and to reach the termination test (:872)."""
+    prm = oracle.default_params()
+    rng = np.random.default_rng(11)
+    for trial in range(6):
+        R0, t0 = oracle.se3_exp(rng.standard_normal(6) * 0.05)
+        st = oracle.state_begin(R0, t0)
+        R, t, d = np.asarray(R0, float), np.asarray(t0, float), np.zeros(6)
+        free = stops = 0
+        for itr in range(30):
+            g = rng.standard_normal(6) * 10.0 ** rng.uniform(-3, -1)
+            if itr >= 12:                                                      # cancel the regulariser: the momentum term halves to a stop
+                rv = Rotation.from_matrix(R).as_rotvec()
+                cPsi = np.concatenate([np.linalg.solve(_V(rv), t), rv])
+                g = -0.05 * cPsi / np.linalg.norm(cPsi)
+            _, broke, psi_o = oracle.state_update(st, itr, 100, g, 1.0 + itr, 90)
+            R, t, d, psi, broke_n = _np_update(itr, R, t, d, g, float(prm.trust_radius), float(prm.psi_norm_stop))
+            assert broke == broke_n, (trial, itr)
+            if broke:
+                stops += 1
+                break
+            Ro, to = oracle.state_pose(st)
+            assert np.abs(psi - psi_o).max() <= 1e-15 + 1e-12 * np.abs(psi).max(), (trial, itr)
+            assert np.abs(R - Ro).max() <= 1e-12 and np.abs(t - to).max() <= 1e-12, (trial, itr)
+            free += np.linalg.norm(psi) < float(prm.trust_radius) * (1 - 1e-12)
+            R, t = Ro, to
+        assert free > 10 and stops == 1, (trial, free, stops)
+
+
+def test_run_iterations_against_numpy_restatement_end_to_end(oracle):
+    """The whole loop restated (per-point phase in numpy float32 matrices, J^T W eps in double as :714-777 casts it, best-iterate
+    bookkeeping of :696-704 / :997-1005).  float32 rounding differs between the two derivations, a point near a pixel corner may
+    read the neighbouring texel, so energies agree to 1e-3 relative and poses to 1e-5 -- not bit for bit."""
+    from rgbd_odometry_amd import SynthScene
+    sc = SynthScene(320, 240, 3, 23)
+    prm = oracle.default_params()
+    levels = oracle_lib_levels(sc, oracle)
+    for level, iters in ((2, 30), (1, 20)):
+        L = levels[level]
+        rows, cols = L["rows"], L["cols"]
+        dt, gx, gy = _level_arrays(L)
+        P32 = np.asarray(L["xyz"], np.float32).reshape(-1, 3)
+        R0, t0 = oracle.se3_exp(np.array([-0.012, 0.01, 0.02, -0.003, 0.004, 0.002]))
+        want = oracle.run_iterations(level, iters, L["xyz"], L["dt"], L["gx"], L["gy"], rows, cols, sc.intrinsics, R0, t0)
+        R, t, d = np.asarray(R0, float), np.asarray(t0, float), np.zeros(6)
+        best = dict(E=np.float32(1.0E10), R=np.eye(3), t=np.zeros(3), itr=-1, ratio=np.float32(1))
+        energy = np.zeros(iters, np.float32)
+        for itr in range(iters):
+            J, eps, w, vis = _np_eval_points(level, P32, dt, gx, gy, rows, cols, sc.intrinsics,
+                                             R.astype(np.float32), t.astype(np.float32))
+            E = np.float32(np.linalg.norm(eps.astype(np.float64)))             # :689 / :1312
+            energy[itr] = E
+            if E <= best["E"]:                                                 # :696
+                best = dict(E=E, R=R.copy(), t=t.copy(), itr=itr, ratio=np.float32(vis.sum()) / np.float32(len(vis)), eps=eps)
+            JTW = (J * w[:, None]).astype(np.float32)                          # :714-716 in float
+            g = JTW.astype(np.float64).T @ eps.astype(np.float64)              # :719-720, :777
+            R, t, d, psi, broke = _np_update(itr, R, t, d, g, float(prm.trust_radius), float(prm.psi_norm_stop))
+            if broke:
+                break
+        Rf = polar(best["R"])[0]                                               # :997-999
+        n = want["iters_run"]
+        assert n == itr + 1
+        assert np.abs(energy[:n] - want["energy"][:n]).max() <= 1e-3 * want["energy"][:n].max(), (level, energy[:n], want["energy"][:n])
+        assert abs(best["itr"] - want["best_idx"]) <= 1 or abs(energy[best["itr"]] - energy[want["best_idx"]]) <= 1e-3 * energy.max()
+        if best["itr"] == want["best_idx"]:
+            assert np.abs(Rf - want["R"]).max() <= 1e-5 and np.abs(best["t"] - want["t"]).max() <= 1e-5
+            assert abs(float(best["ratio"]) - want["visible_ratio"]) <= 2e-3
+            assert np.mean(best["eps"] != want["final_eps"]) <= 0.01
