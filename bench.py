@@ -100,6 +100,7 @@ def parse_args():
     ap.add_argument("--prepare", action="store_true", help="with --float-now-levels: dvo_now_prepare at set-up (round 2's headline)")
     ap.add_argument("--no-extra-legs", "--no-frames-leg", dest="no_extra_legs", action="store_true",
                     help="skip the extra (never `value`) measurements: 16-byte texels, camera frames in host memory -> poses out, ...")
+    ap.add_argument("--assume-free-gb", type=float, default=0.0, help="testing: pretend this much HBM is free when sizing the resident batch")
     a = ap.parse_args()
     tiled = a.mode == "tiled"
     a.width = a.width or (4096 if tiled else 640)
@@ -387,6 +388,17 @@ def main_batch(args):
             frames_in = frames_leg(args, iters)
         except Exception as e:                       # the extra legs must never cost the headline line
             frames_in = {"error": repr(e)}
+    # a box with less free HBM than the resident batch needs (another tenant, a partitioned GPU): shrink the batch to what fits
+    # instead of dying in an allocation -- the line then says so (config.batch_reduced_from)
+    batch_asked = args.batch
+    sum_px = sum((args.width >> l) * (args.height >> l) for l in range(args.levels))
+    per_pair = 9.0 * sum_px + 0.3e6                  # compact now form + palettes + point lists + outputs (3.5 MB at 640x480x4)
+    free_b, _total_b = torch.cuda.mem_get_info()
+    if args.assume_free_gb > 0:
+        free_b = args.assume_free_gb * 1e9
+    fits = int((free_b - 12e9) / per_pair)
+    if not total_pairs and fits < args.batch:
+        args.batch = max(256, fits // 256 * 256)
     ctx = DvoContext(args.batch, block_threads=args.block, debug_alias_mod=args.debug_alias,
                      points_in_flight=args.inflight, lds_point_bytes=args.lds_point_bytes,
                      engine_variant=args.variant, team_size=args.team)
@@ -463,7 +475,8 @@ def main_batch(args):
                         "frame pairs per GPU (%d distinct synthetic scenes), identity start, "
                         "sub-gradient policy of SolveDVO::runIterations" %
                         (args.width, args.height, args.levels, args.iters, args.batch, D),
-            "pairs_per_gpu": args.batch, "iters_per_level": iters,
+            "pairs_per_gpu": args.batch, **({"batch_reduced_from": batch_asked} if args.batch != batch_asked and not total_pairs else {}),
+            "iters_per_level": iters,
             **({"total_pairs": total_pairs} if total_pairs > 0 else {}),
             "final_outputs": not args.no_final_outputs,
             "now_levels": now_desc,

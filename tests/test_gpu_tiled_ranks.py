@@ -68,3 +68,16 @@ def test_tiled_bench_two_ranks_bit_identical():
     d2 = _run(2, ["--width", "640", "--height", "480", "--levels", "4", "--cpu-seconds", "0"])
     assert d2["n_gpus"] == 2 and d2["rccl_ranks"] == 2 and d2["config"]["all_ranks_bit_identical"]
     assert d2["config"]["points_per_level"] == d1["config"]["points_per_level"]
+
+
+def test_bench_shrinks_the_default_batch_to_the_free_memory():
+    """a box with less free HBM than 40 000 resident pairs need: the default run must still produce its line, on a smaller batch,
+    and say so"""
+    r = _bench(1, ["--cpu-seconds", "0", "--no-extra-legs", "--assume-free-gb", "14"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["batch_reduced_from"] == 40000 and d["config"]["pairs_per_gpu"] == 256 * int((14e9 - 12e9) / (9.0 * 408000 + 0.3e6) / 256)
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0.2
+    r = _bench(1, ["--batch", "512", "--cpu-seconds", "0", "--no-extra-legs"])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "batch_reduced_from" not in d["config"] and d["config"]["pairs_per_gpu"] == 512
