@@ -3,7 +3,8 @@ through every single-pair path -- the C-driven all-CU path (dvo_align_pyramid_wi
 the RCCL all-reduce forced at world size 1 (TiledAligner), and the C-driven tiled entry point with a raw RCCL communicator
 (dvo_tiled_attach / dvo_align_pyramid_tiled) -- each against the CPU oracle: energies, best index and visible ratio
 bit-equal, pose within 1e-5 rad / 1e-4 m.  (More than one GPU is not available to the tests; the multi-rank logic is
-covered by the gloo world-size-2 tests in test_distributed_cpu.py.)"""
+covered by the gloo world-size-2 tests in test_distributed_cpu.py and, on the GPU, by host threads as ranks over a loopback
+all-reduce in test_gpu_tiled_ranks.py.)"""
 import numpy as np
 import pytest
 

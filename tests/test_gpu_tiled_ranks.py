@@ -81,3 +81,100 @@ def test_bench_shrinks_the_default_batch_to_the_free_memory():
     r = _bench(1, ["--batch", "512", "--cpu-seconds", "0", "--no-extra-legs"])
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert "batch_reduced_from" not in d["config"] and d["config"]["pairs_per_gpu"] == 512
+
+
+# ---- rank > 0 of the C tiled path on ONE GPU: host threads as ranks, a loopback stand-in for ncclAllReduce ---------------------
+LOOPBACK_DIR = os.path.join(ROOT, "tests", "loopback_collective")
+LOOPBACK_SO = os.path.join(LOOPBACK_DIR, "libloopback_rccl.so")
+
+
+def _loopback_library():
+    src = os.path.join(LOOPBACK_DIR, "loopback_rccl.hip")
+    if not os.path.exists(LOOPBACK_SO) or os.path.getmtime(LOOPBACK_SO) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-shared", "-o", LOOPBACK_SO, src])
+    import ctypes as C
+    lib = C.CDLL(LOOPBACK_SO)
+    lib.loopback_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.loopback_destroy.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.loopback_calls.argtypes = [C.c_void_p]
+    lib.loopback_calls.restype = C.c_long
+    return lib
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_c_tiled_path_with_several_ranks_on_one_gpu(world, oracle):
+    """dvo_align_pyramid_tiled has only ever met world size 1 on hardware (RCCL refuses two ranks on one device, the boxes have one).
+    Here `world` host threads each drive their own context as rank r of `world`, with tests/loopback_collective standing in for
+    ncclAllReduce (resolved from the library dvo_tiled_attach is given, like librccl.so.1): every rank works on ITS index range of
+    every level, the sums meet in the all-reduce, every rank takes the update.  All ranks must end with identical bits; energies /
+    best index / visible ratio bit-equal to the oracle's; the final outputs of the ranks' shards, concatenated, are the oracle's."""
+    import ctypes as C
+    import threading
+    import numpy as np
+    import oracle_lib
+    from oracle_lib import rot_angle
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    from rgbd_odometry_amd.capi import DVO_FLAG_FINAL_OUTPUTS
+    lib = _loopback_library()
+    sc = SynthScene(640, 480, 4, 9)
+    lv = oracle_lib.scene_levels(sc, oracle)
+    iters = [6, 0, 5, 7]
+    R0, t0 = oracle.se3_exp(np.array([0.004, -0.003, 0.002, 0.001, -0.002, 0.0015]))
+    ref = oracle.align_pyramid(iters, lv, sc.intrinsics, R0, t0)
+    comms = (C.c_void_p * world)()
+    assert lib.loopback_create(world, comms) == 0
+    ctxs = []
+    try:
+        for r in range(world):
+            ctx = DvoContext(1)
+            ctx.set_intrinsics(*sc.intrinsics)
+            for l, L in enumerate(sc.levels):
+                ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols)
+                ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols)
+            ctx.tiled_attach(comms[r], r, world, LOOPBACK_SO)
+            ctxs.append(ctx)
+        out, err = [None] * world, [None] * world
+
+        def run(r):
+            try:
+                out[r] = ctxs[r].align_pyramid_tiled(iters, R0, t0, flags=DVO_FLAG_FINAL_OUTPUTS)
+            except Exception as e:          # a failing rank must not leave the others at the barrier for ever: the library times out
+                err[r] = e
+        for rep in range(2):                # the second alignment starts from scratch on the same attachment
+            th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join(120)
+            assert not any(x.is_alive() for x in th) and err == [None] * world, err
+            for r in range(1, world):
+                assert np.array_equal(out[r][0], out[0][0]) and np.array_equal(out[r][1], out[0][1]), r
+            assert rot_angle(ref["R"], out[0][0]) <= 1e-5 and np.linalg.norm(ref["t"] - out[0][1]) <= 1e-4
+            n_it = sum(iters)
+            for r in range(world):
+                assert lib.loopback_calls(comms[r]) == (rep + 1) * n_it, (r, lib.loopback_calls(comms[r]))   # one all-reduce per iteration
+                assert not ctxs[r].tiled_graph_replayed()                    # the loopback refuses a capturing stream: direct submission
+                for l, rp in ref["levels"].items():
+                    e, b, ratio = ctxs[r].level_report(0, l, iters[l])
+                    assert np.array_equal(e, rp["energy"]) and b == rp["best_idx"] and ratio == rp["visible_ratio"], (r, l)
+        # shards: contiguous, disjoint, covering; final outputs of the last level rank by rank
+        last = ref["last_level"]
+        N = len(lv[last]["xyz"])
+        eps_all = np.full(N, np.nan, np.float32)
+        rep_all = np.full((N, 3), np.nan, np.float32)
+        nxt = 0
+        for r in range(world):
+            first, count = ctxs[r].tiled_shard(last)
+            assert first == nxt and count in (N // world, N // world + 1)
+            nxt = first + count
+            eps, reproj = ctxs[r].final_outputs(0, N)
+            assert len(eps) == N
+            eps_all[first:first + count] = eps[first:first + count]
+            rep_all[first:first + count] = reproj[first:first + count]
+        assert nxt == N
+        want = ref["levels"][last]
+        assert np.array_equal(eps_all, want["final_eps"]) and np.array_equal(rep_all, want["final_reproj"])
+    finally:
+        for ctx in ctxs:
+            ctx.close()
+        lib.loopback_destroy(comms, world)
