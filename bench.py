@@ -100,6 +100,10 @@ def parse_args():
     ap.add_argument("--prepare", action="store_true", help="with --float-now-levels: dvo_now_prepare at set-up (round 2's headline)")
     ap.add_argument("--no-extra-legs", "--no-frames-leg", dest="no_extra_legs", action="store_true",
                     help="skip the extra (never `value`) measurements: 16-byte texels, camera frames in host memory -> poses out, ...")
+    ap.add_argument("--ranks-share-gpu", action="store_true",
+                    help="testing only (batch mode): the N ranks of --gpus N all use device 0 and meet over gloo, so that the N > 1 code path "
+                         "-- launcher, barriers, MAX over ranks, rank-0 line -- runs on a one-GPU box; the line says so (config.ranks_share_one_gpu) "
+                         "and is NOT a scaling measurement")
     ap.add_argument("--assume-free-gb", type=float, default=0.0, help="testing: pretend this much HBM is free when sizing the resident batch")
     a = ap.parse_args()
     tiled = a.mode == "tiled"
@@ -331,17 +335,22 @@ def float_boundary_leg(args, iters, flags, stream, per_scene_bytes):
         ctx.close()
 
 
-def dist_setup():
+def dist_setup(share_gpu=False):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the engine has no CPU fallback")
+    if share_gpu:
+        local_rank = 0                      # --ranks-share-gpu (testing): every rank on device 0, RCCL would refuse that -> gloo
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     return rank, local_rank, world, dist
 
 
@@ -366,7 +375,7 @@ def traffic_record(args, key, default_knobs):
 
 
 def main_batch(args):
-    rank, local_rank, world, dist = dist_setup()
+    rank, local_rank, world, dist = dist_setup(args.ranks_share_gpu)
     from rgbd_odometry_amd import DvoContext
     from rgbd_odometry_amd.capi import DVO_FLAG_FINAL_OUTPUTS, DVO_FLAG_IDENTITY_START, DVO_FLAG_NORMAL_MATRIX
     from rgbd_odometry_amd.distributed import shard_range, whole_job_throughput
@@ -396,7 +405,7 @@ def main_batch(args):
     free_b, _total_b = torch.cuda.mem_get_info()
     if args.assume_free_gb > 0:
         free_b = args.assume_free_gb * 1e9
-    fits = int((free_b - 12e9) / per_pair)
+    fits = int((free_b / (world if args.ranks_share_gpu else 1) - 12e9) / per_pair)
     if not total_pairs and fits < args.batch:
         args.batch = max(256, fits // 256 * 256)
     ctx = DvoContext(args.batch, block_threads=args.block, debug_alias_mod=args.debug_alias,
@@ -430,7 +439,7 @@ def main_batch(args):
     torch.cuda.synchronize()
     barrier()
     elapsed_local = time.perf_counter() - t0
-    value, elapsed = whole_job_throughput(args.batch, args.steps, elapsed_local, device="cuda")   # MAX over ranks
+    value, elapsed = whole_job_throughput(args.batch, args.steps, elapsed_local, device="cpu" if args.ranks_share_gpu else "cuda")   # MAX over ranks
     if total_pairs > 0:
         value = total_pairs * args.steps / elapsed            # the blocks differ by at most one pair: count the real total
 
@@ -475,6 +484,7 @@ def main_batch(args):
                         "frame pairs per GPU (%d distinct synthetic scenes), identity start, "
                         "sub-gradient policy of SolveDVO::runIterations" %
                         (args.width, args.height, args.levels, args.iters, args.batch, D),
+            **({"ranks_share_one_gpu": True} if args.ranks_share_gpu else {}),
             "pairs_per_gpu": args.batch, **({"batch_reduced_from": batch_asked} if args.batch != batch_asked and not total_pairs else {}),
             "iters_per_level": iters,
             **({"total_pairs": total_pairs} if total_pairs > 0 else {}),
@@ -762,7 +772,10 @@ def launch_ranks(args):
     if args.gpus <= 1:
         return
     n_dev = torch.cuda.device_count()           # counts devices without initialising the GPU (no HIP context in this process)
-    if n_dev < args.gpus:
+    if args.ranks_share_gpu and args.mode != "batch":
+        sys.stderr.write("bench.py: --ranks-share-gpu is a batch-mode test switch (the tiled path's ranks need RCCL: tests/test_gpu_tiled_ranks.py runs them over a loopback)\n")
+        sys.exit(2)
+    if n_dev < (1 if args.ranks_share_gpu else args.gpus):
         sys.stderr.write("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing to print a %d-GPU line from fewer GPUs\n" % (args.gpus, n_dev, args.gpus))
         sys.exit(3)
     import socket

@@ -178,3 +178,22 @@ def test_c_tiled_path_with_several_ranks_on_one_gpu(world, oracle):
         for ctx in ctxs:
             ctx.close()
         lib.loopback_destroy(comms, world)
+
+
+def test_batch_bench_with_two_and_three_ranks_sharing_the_gpu():
+    """The N > 1 path of the batch bench -- bench.py starting its own ranks under torch.distributed.run, per-rank scene seeds,
+    barriers, MAX over ranks, the rank-0 line -- has never run on hardware (one-GPU boxes).  --ranks-share-gpu puts all ranks on
+    device 0 over gloo: not a scaling measurement (the line says so), but every line of that path executes."""
+    for world, extra in ((2, ["--batch", "256"]), (3, ["--total-pairs", "200"])):
+        r = _bench(world, extra + ["--ranks-share-gpu", "--cpu-seconds", "0", "--no-extra-legs"])
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1                                     # rank 0 only
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["config"]["ranks_share_one_gpu"] is True
+        assert d["scaling"] == ("weak" if world == 2 else "strong")
+        units = 256 * world if world == 2 else 200
+        assert abs(d["value"] - units * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) <= 1e-6 * d["value"]
+        assert "cpu_baseline" not in d or d["cpu_baseline"] is None or world == 1
+    r = _bench(2, ["--mode", "tiled", "--ranks-share-gpu"])
+    assert r.returncode == 2 and "loopback" in r.stderr
