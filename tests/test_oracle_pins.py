@@ -316,3 +316,71 @@ def test_run_iterations_against_numpy_restatement_end_to_end(oracle):
             assert np.abs(Rf - want["R"]).max() <= 1e-5 and np.abs(best["t"] - want["t"]).max() <= 1e-5
             assert abs(float(best["ratio"]) - want["visible_ratio"]) <= 2e-3
             assert np.mean(best["eps"] != want["final_eps"]) <= 0.01
+
+
+# ---- how much hangs on the oracle's definition of the energy ---------------------------------------------
+def _float_norms(eps):
+    """epsilon.norm() (:1312) as float32 accumulations in the orders a -ffast-math -mavx build of Eigen may use: plain sequential;
+    8-lane strided partial sums (one AVX packet accumulator) and 16-lane (two packet accumulators, Eigen's linear vectorised
+    reduction) followed by a horizontal add and the scalar tail; pairwise.  Each narrowed like the reference's float result."""
+    f = np.float32
+    sq = (eps * eps).astype(f)
+    out = {}
+    s = f(0)
+    for v in sq:
+        s = f(s + v)
+    out["sequential"] = f(np.sqrt(s))
+    for lanes in (8, 16):
+        n = len(sq) // lanes * lanes
+        acc = np.zeros(lanes, f)
+        for row in sq[:n].reshape(-1, lanes):
+            acc = (acc + row).astype(f)
+        while len(acc) > 1:                                     # horizontal add, halves
+            acc = (acc[:len(acc) // 2] + acc[len(acc) // 2:]).astype(f)
+        s = acc[0]
+        for v in sq[n:]:
+            s = f(s + v)
+        out["avx%d" % lanes] = f(np.sqrt(s))
+    a = sq.copy()
+    while len(a) > 1:
+        if len(a) & 1:
+            a = np.append(a, f(0))
+        a = (a[0::2] + a[1::2]).astype(f)
+    out["pairwise"] = f(np.sqrt(a[0]))
+    return out
+
+
+def test_energy_definition_sensitivity(oracle):
+    """The reference's energy is a float32 norm in an unspecified (vectorised, -ffast-math) order; the oracle DEFINES
+    (float)sqrt(sum of (double)eps^2).  Here the per-iteration energies of oracle runs are recomputed as float32 sums in four
+    plausible orders: they differ from the oracle's by a few float ulps, and what matters -- the best-iterate choice of :696
+    (`<=` on these values) -- is counted.  The assertion is the bound; the count is printed (pytest -s) and quoted in DESIGN.md."""
+    from rgbd_odometry_amd import SynthScene
+    runs = flips = 0
+    worst = {}
+    for seed in (5, 17, 23, 31):
+        sc = SynthScene(320, 240, 3, seed)
+        levels = oracle_lib_levels(sc, oracle)
+        R, t = np.eye(3), np.zeros(3)
+        for level, iters in ((2, 12), (1, 12), (0, 12), (0, 50)):      # the last run starts converged: the energies plateau, ties are near
+            L = levels[level]
+            out = oracle.run_iterations(level, iters, L["xyz"], L["dt"], L["gx"], L["gy"], L["rows"], L["cols"], sc.intrinsics, R, t, trace=True)
+            poses = [(np.asarray(R, float), np.asarray(t, float))] + [(tr["R"], tr["t"]) for tr in out["trace"][:-1]]
+            alt = {k: [] for k in ("sequential", "avx8", "avx16", "pairwise")}
+            for itr, (Rk, tk) in enumerate(poses):
+                ev = oracle.eval_points(level, L["xyz"], L["dt"], L["gx"], L["gy"], L["rows"], L["cols"], sc.intrinsics,
+                                        np.asarray(Rk, np.float32).astype(float), np.asarray(tk, np.float32).astype(float))
+                assert np.float32(np.sqrt(np.sum(ev["eps"].astype(np.float64) ** 2))) == out["energy"][itr]      # the oracle's definition
+                for k, v in _float_norms(ev["eps"]).items():
+                    alt[k].append(v)
+                    worst[k] = max(worst.get(k, 0.0), abs(float(v) - float(out["energy"][itr])) / float(out["energy"][itr]))
+            for k, e in alt.items():
+                e = np.asarray(e, np.float32)
+                best = max(i for i in range(len(e)) if e[i] <= e[:i + 1].min())     # :696 with `<=`: the LAST minimum so far
+                runs += 1
+                flips += int(best != out["best_idx"])
+            R, t = out["R"], out["t"]
+    print("energy definition: %d (run, order) cases, %d with another best iterate; worst relative energy difference per order: %s" % (
+        runs, flips, ", ".join("%s %.1e" % kv for kv in sorted(worst.items()))))
+    assert worst["sequential"] <= 3e-5 and max(worst[k] for k in ("avx8", "avx16", "pairwise")) <= 2e-6     # float32 sums of ~10^3..10^4 terms
+    assert flips <= runs // 4       # the choice is rarely affected; when it is, two iterates have energies within those differences
