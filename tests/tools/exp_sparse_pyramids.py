@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The C++ file replay's exact call sequence from Python: per frame a busy host gap, dvo_frames_upload_pyramids (mono8 + mono16
 levels, synchronous), dvo_frames_as_now, dvo_align_pyramid-style align (set poses, enqueue, get poses).  Same library, same
-HIP runtime (DVO_NO_TORCH=1).  usage: DVO_NO_TORCH=1 exp_sparse_pyramids.py [frames] [gap_ms]"""
+HIP runtime (DVO_NO_TORCH=1).  Under tests/: the oracle generates the pyramids.  usage: DVO_NO_TORCH=1 tests/tools/exp_sparse_pyramids.py [frames] [gap_ms]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

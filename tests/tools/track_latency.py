@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Single-stream tracking latency of the C++ replay (examples/track_demo.cpp): writes a short synthetic sequence
-as OpenCV-XML frame files and replays it.  usage: track_latency.py [width height levels iters n_frames]"""
+as OpenCV-XML frame files and replays it.  Lives under tests/ because it uses the oracle (test infrastructure) as the generator of
+the node's pyramid format.  usage: tests/tools/track_latency.py [width height levels iters n_frames]"""
 import os, subprocess, sys, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import frame_io, oracle_lib

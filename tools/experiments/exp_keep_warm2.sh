@@ -1,6 +1,6 @@
 #!/bin/bash
 O=gpurun_out/r03_single_stream; mkdir -p $O
-run() { echo "== $1 ($2)"; env $2 VERBOSE=1 python tools/track_latency.py 640 480 4 10 16 2>&1 | grep "frame \|per frame" | awk 'NR<=2 || NR>=15' | cut -c1-120; }
+run() { echo "== $1 ($2)"; env $2 VERBOSE=1 python tests/tools/track_latency.py 640 480 4 10 16 2>&1 | grep "frame \|per frame" | awk 'NR<=2 || NR>=15' | cut -c1-120; }
 {
 run "first process of the box" "X=1"
 run "second process" "X=1"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel traces of the C++ replay as consecutive processes: in a slow process, are the KERNELS slow or the gaps between them?
 R=$PWD; O=$R/gpurun_out/r03_single_stream; mkdir -p $O
-FRAMES_DIR=/tmp/frames ONLY_GENERATE=1 python tools/track_latency.py 640 480 4 10 16 > /dev/null
+FRAMES_DIR=/tmp/frames ONLY_GENERATE=1 python tests/tools/track_latency.py 640 480 4 10 16 > /dev/null
 DEMO="$R/rgbd_odometry_amd/lib/track_demo /tmp/frames 0 15 1 4 525.0 525.0 319.5 239.5 10 /tmp/poses.txt"
 cd /tmp && export TMPDIR=/tmp
 for i in 1 2 3 4 5; do

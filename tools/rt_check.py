@@ -2,7 +2,7 @@ import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, 'tests')
 import torch
 print("torch", torch.__version__, torch.cuda.is_available(), torch.cuda.get_device_name(0))
-import numpy as np, oracle_lib
+import numpy as np
 from rgbd_odometry_amd import DvoContext, SynthScene
 x = torch.ones(4, device='cuda') * 2
 print(x.sum().item())
