@@ -22,7 +22,7 @@ def test_pmc_traffic_record_matches_the_kernel_sources():
     default_key = "640x480x4x10_b40000"                        # the default line's workload (bench.py --batch default)
     assert default_key in rec
     stale = [k for k, v in rec.items() if v.get("kernel_source_sha256") != h]
-    assert default_key not in stale, ("profiles/pmc_traffic.json was measured on other kernel sources (%s, now %s): run "
+    assert not stale, ("profiles/pmc_traffic.json was measured on other kernel sources (%s, now %s): run "
                                       "tools/r04_record.sh traffic bench on the GPU box and copy gpurun_out/pmc_traffic.json" % (rec[default_key].get("kernel_source_sha256"), h))
     for k, v in rec.items():
         assert abs(v["hbm_bytes_per_launch"] - (v["fetch_bytes"] + v["write_bytes"])) <= 2, k
