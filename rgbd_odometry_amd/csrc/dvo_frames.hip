@@ -1257,8 +1257,11 @@ DVO_DEV void edt_rank_pack_body(const int bx, const int gx, const int by, const 
     const int tpc = p4_tiles_per_col(rows);
     const int n_tcols = (cols + 3) >> 2;
     const int n_strips = (tiles_y + strip - 1) / strip;
-    const int sy = bx % n_strips, tcx = bx / n_strips;
-    const int tc0 = tcx * PK_LC, x0 = tc0 * 4 - 1;
+    /* a workgroup takes the strips bx, bx + gx, ...: the small-bitmap launch has one workgroup per strip; the large-bitmap launch,
+     * which nearly every image leaves at the test above, only a handful per image (its 54 KB of LDS made a full grid cost 17-25 us per
+     * 256 frames just to leave) */
+    const int n_work = n_strips * ((n_tcols + PK_LC - 1) / PK_LC);
+    int sy = 0, tc0 = 0, x0 = 0;
     bool bad_step = false;
     /* A thread's share of a tile's pixels + one-pixel halo: 12 interior pixels and one of the halo.  d2 lies in row blocks of R
      * rows ([block][column][R]), so the 64 x 48 interior is walked in groups of 8 rows x 32 columns -- eight consecutive lanes
@@ -1286,6 +1289,8 @@ DVO_DEV void edt_rank_pack_body(const int bx, const int gx, const int by, const 
         }
         v[PK_NV - 1] = hlx >= 0 ? fetch_at(y0, hlx, hly) : PK_NONE;
     };
+    for (int b = bx; b < n_work; b += gx) {
+    sy = b % n_strips; tc0 = (b / n_strips) * PK_LC; x0 = tc0 * 4 - 1;
     const int t_first = sy * strip, t_end = (tiles_y < (sy + 1) * strip) ? tiles_y : (sy + 1) * strip;
     unsigned cur[PK_NV];
     if (t_first < t_end) fetch_tile(t_first, cur);
@@ -1321,6 +1326,7 @@ DVO_DEV void edt_rank_pack_body(const int bx, const int gx, const int by, const 
             p4[32u + ((size_t)tc * tpc + ty) * 32u + wd] = word;
         }
         __syncthreads();
+    }
     }
     if (__syncthreads_or(bad_step ? 1 : 0) && tid == 0) atomicOr(flags + by, (int)EDT_FLAG_STEP);
     if (first_wg && tid == 0) pal_n[pair] = n_pal;               /* EDT_FLAG_STEP overrides it in the fallback launch */
@@ -1584,7 +1590,7 @@ hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, Im
         hipLaunchKernelGGL(edt_rank_pack_kernel<PK_SMALL_WORDS>, dim3(n_strips * ptiles_x, gb.count), dim3(256), 0, s, d2, gb.rows, gb.cols, R, ptiles_y,
                            (int)strip, partial, (int)nblk, bitmap, bm_words, flags, p4, p4_stride, pal, pal_n, first_pair, nullptr);
         if (bm_words > PK_SMALL_WORDS)            /* squared distances of 65536 and more are possible at this size: the full-bitmap twin */
-            hipLaunchKernelGGL(edt_rank_pack_kernel<DVO_EDT_BITMAP_BITS / 32>, dim3(n_strips * ptiles_x, gb.count), dim3(256), 0, s, d2, gb.rows,
+            hipLaunchKernelGGL(edt_rank_pack_kernel<DVO_EDT_BITMAP_BITS / 32>, dim3(std::min(n_strips * ptiles_x, 8), gb.count), dim3(256), 0, s, d2, gb.rows,
                                gb.cols, R, ptiles_y, (int)strip, partial, (int)nblk, bitmap, bm_words, flags, p4, p4_stride, pal, pal_n, first_pair, nullptr);
     }
     const int tiles_y = (gb.rows + NP_TY - 1) / NP_TY, tiles_x = (gb.cols + NP_TX - 1) / NP_TX;
@@ -1685,7 +1691,13 @@ hipError_t launch_edges_to_now_levels(int n, const int *rows, const int *cols, c
             return (unsigned)(n_strips * ptx);
         });
         hipLaunchKernelGGL(edt_rank_pack_levels_kernel<PK_SMALL_WORDS>, dim3(g, count), dim3(256), 0, s, t);
-        if (max_bm > PK_SMALL_WORDS) hipLaunchKernelGGL(edt_rank_pack_levels_kernel<DVO_EDT_BITMAP_BITS / 32>, dim3(g, count), dim3(256), 0, s, t);
+        if (max_bm > PK_SMALL_WORDS) {          /* images with a squared distance >= 65536: rare, a few workgroups per image and level loop over the strips */
+            g = prefix([&](int l) {
+                const int ptx = (((cols[l] + 3) >> 2) + PK_LC - 1) / PK_LC, n_strips = (t.ptiles_y[l] + t.strip[l] - 1) / t.strip[l];
+                return std::min((unsigned)(n_strips * ptx), 8u);
+            });
+            hipLaunchKernelGGL(edt_rank_pack_levels_kernel<DVO_EDT_BITMAP_BITS / 32>, dim3(g, count), dim3(256), 0, s, t);
+        }
     }
     g = prefix([&](int l) { const unsigned nt = (unsigned)(t.ntiles_y[l] * ((cols[l] + NP_TX - 1) / NP_TX)); return with_p4 ? std::min(nt, 8u) : nt; });
     hipLaunchKernelGGL(dt_normalize_gradient_pack_levels_kernel, dim3(g, count), dim3(256), 0, s, t, with_p4 ? 1 : 0);
