@@ -12,7 +12,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "build", "libdvo_oracle.so")
+ORACLE_SO = os.environ.get("DVO_ORACLE_SO") or os.path.join(ORACLE_DIR, "build", "libdvo_oracle.so")      # DVO_ORACLE_SO: a sanitizer build of the oracle (CPU suite only)
 
 
 class OracleParams(C.Structure):
