@@ -804,26 +804,53 @@ DVO_DEV unsigned edt_nonzero_bytes(unsigned v) {           /* bit k = (byte k of
     const unsigned t = ((((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v) & 0x80808080u) >> 7;
     return (t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xfu;
 }
+/* per 8-bit edge mask of a lane: the distance of each of its eight rows to the nearest set bit of the mask, 16 bits each (rows j,
+ * j + 1 share a dword), 0xffff = no edge among the eight rows */
+struct EdtColLut { unsigned v[256][4]; };
+constexpr EdtColLut edt_col_lut_make() {
+    EdtColLut t{};
+    for (int m = 0; m < 256; m++)
+        for (int r = 0; r < 8; r++) {
+            unsigned best = 0xffffu;
+            for (int k = 0; k < 8; k++) if ((m >> k) & 1) { const unsigned a = (unsigned)(r > k ? r - k : k - r); best = a < best ? a : best; }
+            t.v[m][r >> 1] |= best << ((r & 1) * 16);
+        }
+    return t;
+}
+__device__ const EdtColLut EDT_COL_LUT = edt_col_lut_make();
+typedef unsigned short edt_col_us2 __attribute__((ext_vector_type(2)));
+DVO_DEV edt_col_us2 edt_col_pair(unsigned v) { return __builtin_bit_cast(edt_col_us2, v); }
+DVO_DEV unsigned edt_col_word(edt_col_us2 v) { return __builtin_bit_cast(unsigned, v); }
 template <int WAVES>
 DVO_DEV void edt_columns8_body(const int bx, const int gx, const int by, const unsigned char *__restrict__ edge, size_t edge_stride, int rows, int cols, int R, unsigned short *__restrict__ g,
                     unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags) {
-    extern __shared__ uint4 s_da8[];                    /* [WAVES][nchunk * 64]: the eight upward distances of a lane */
+    /* Round 4: ONE pass per 512-row chunk.  The distance of a lane's row j to the nearest edge of its column is the minimum of
+     * three: the nearest edge among the lane's own eight rows (a 256-entry table in LDS: per mask, eight 16-bit distances, 0xffff
+     * = none), the nearest edge above the lane's rows (d_up + 1 + j) and the nearest below them (d_dn + 8 - j) -- the last two as
+     * packed 16-bit additions / minima, two rows per instruction, already in the layout of the store.  (Rounds 1-3 walked the
+     * eight rows twice with a running counter, up and down, parking the upward pass in LDS: 312 vector instructions per wave and
+     * chunk, the kernel was bound by their issue.)  Columns taller than 512 rows first collect, per chunk, the distance from the
+     * chunk's borders to the nearest edge outside it (two sweeps of ballots, wave-uniform). */
+    extern __shared__ uint4 s_da8[];                    /* per wave: 2 * nchunk ints (the launch sizes it generously) */
+    __shared__ uint4 s_lut[256];
+    __shared__ uint4 s_tile[WAVES == 8 ? 4 * 64 * 9 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     {
         unsigned *bm = bitmap + (size_t)by * bm_words;
         for (int i = bx * (WAVES * 64) + threadIdx.x; i < bm_words; i += gx * (WAVES * 64)) bm[i] = 0u;
         if (bx == 0 && threadIdx.x == 0) flags[by] = 0;
     }
-    const int xx = bx * WAVES + wave;
-    if (xx >= cols) return;
-    const unsigned char *col = edge + (size_t)by * edge_stride + (size_t)xx * rows;
+    for (int m = threadIdx.x; m < 256; m += WAVES * 64)
+        s_lut[m] = make_uint4(EDT_COL_LUT.v[m][0], EDT_COL_LUT.v[m][1], EDT_COL_LUT.v[m][2], EDT_COL_LUT.v[m][3]);
+    __syncthreads();
     g += (size_t)by * edt_g_count(rows, cols, R);
     const int rows_pad = ((rows + R - 1) / R) * R;
     const int nchunk = (rows + 511) / 512;
-    uint4 *da_col = s_da8 + (size_t)wave * nchunk * 64;
+    int *carries = reinterpret_cast<int *>(s_da8) + (size_t)wave * 2 * nchunk;
     const int INF = DVO_EDT_INF(rows, cols);
-    const bool vec = ((rows & 7) == 0) && ((reinterpret_cast<size_t>(col) & 7) == 0);
-    auto load_mask = [&](int y0) -> unsigned {             /* bit j = edge at row y0 + j */
+    const unsigned inf2 = (unsigned)INF | ((unsigned)INF << 16);
+    const unsigned char *img = edge + (size_t)by * edge_stride;
+    auto load_mask = [&](const unsigned char *col, bool vec, int y0) -> unsigned {             /* bit j = edge at row y0 + j */
         if (y0 >= rows) return 0u;
         if (vec) {
             const uint2 v = *reinterpret_cast<const uint2 *>(col + y0);
@@ -833,58 +860,131 @@ DVO_DEV void edt_columns8_body(const int bx, const int gx, const int by, const u
         for (int j = 0; j < 8; j++) if (y0 + j < rows && col[y0 + j] != 0) m |= 1u << j;
         return m;
     };
-    int carry = INF;                                    /* distance from the row above this chunk to the nearest edge above it */
-    for (int c = 0; c < nchunk; c++) {
+    /* the eight rows of this lane in chunk c of column xx from their mask: three candidates per row, packed minima, one store */
+    auto emit = [&](int xx, int c, unsigned m8, uint4 *to_lds) {
         const int y0 = c * 512 + lane * 8;
-        const unsigned m8 = load_mask(y0);
         const unsigned long long bal = __ballot(m8 != 0u);
         const unsigned long long lower = bal & ((1ull << lane) - 1ull);                          /* lanes above these rows */
-        const int lpu = lower ? 63 - __clzll((long long)lower) : lane;
-        const unsigned mlu = (unsigned)__shfl((int)m8, lpu);   /* every lane takes part: no cross-lane read under a branch */
-        int d;                                              /* distance from row y0 - 1 to the nearest edge at or above it */
-        if (lower) d = (lane * 8 - 1) - (lpu * 8 + (31 - __clz((int)mlu)));
-        else d = (carry >= INF) ? INF : carry + lane * 8;
-        unsigned short da[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) { d = ((m8 >> j) & 1u) ? 0 : d + 1; da[j] = (unsigned short)(d > INF ? INF : d); }
-        uint4 o;
-        o.x = da[0] | ((unsigned)da[1] << 16); o.y = da[2] | ((unsigned)da[3] << 16);
-        o.z = da[4] | ((unsigned)da[5] << 16); o.w = da[6] | ((unsigned)da[7] << 16);
-        da_col[c * 64 + lane] = o;
-        carry = __shfl((int)da[7], 63);                     /* the chunk's last row */
-    }
-    carry = INF;                                        /* distance from the row below this chunk to the nearest edge below it */
-    for (int c = nchunk - 1; c >= 0; c--) {
-        const int y0 = c * 512 + lane * 8;
-        const unsigned m8 = load_mask(y0);
-        const unsigned long long bal = __ballot(m8 != 0u);
         const unsigned long long upper = (lane == 63) ? 0ull : (bal & (~0ull << (lane + 1)));  /* lanes below these rows */
+        const int lpu = lower ? 63 - __clzll((long long)lower) : lane;
         const int lpd = upper ? __ffsll((long long)upper) - 1 : lane;
+        const unsigned mlu = (unsigned)__shfl((int)m8, lpu);   /* every lane takes part: no cross-lane read under a branch */
         const unsigned mld = (unsigned)__shfl((int)m8, lpd);
-        int d;                                              /* distance from row y0 + 8 to the nearest edge at or below it */
-        if (upper) d = (lpd * 8 + (__ffs((int)mld) - 1)) - (lane * 8 + 8);
-        else d = (carry >= INF) ? INF : carry + (63 - lane) * 8;
-        const uint4 up = da_col[c * 64 + lane];
-        const unsigned upw[4] = {up.x, up.y, up.z, up.w};
-        unsigned short v[8];
-#pragma unroll
-        for (int j = 7; j >= 0; j--) {
-            d = ((m8 >> j) & 1u) ? 0 : d + 1;
-            const int da = (int)((upw[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
-            int m = da < d ? da : d;
-            m = m > INF ? INF : m;
-            v[j] = (unsigned short)((y0 + j < rows) ? m : 0);
+        const int cu = nchunk > 1 ? carries[c] : INF, cd = nchunk > 1 ? carries[nchunk + c] : INF;
+        int d_up, d_dn;                                     /* from row y0 - 1 upwards / from row y0 + 8 downwards to the nearest edge */
+        if (lower) d_up = (lane * 8 - 1) - (lpu * 8 + (31 - __clz((int)mlu)));
+        else d_up = (cu + lane * 8 > INF) ? INF : cu + lane * 8;
+        if (upper) d_dn = (lpd * 8 + (__ffs((int)mld) - 1)) - (lane * 8 + 8);
+        else d_dn = (cd - 1 + (63 - lane) * 8 > INF) ? INF : cd - 1 + (63 - lane) * 8;
+        const uint4 in = s_lut[m8];
+        const edt_col_us2 up2 = edt_col_pair((unsigned)d_up | ((unsigned)d_up << 16)), dn2 = edt_col_pair((unsigned)d_dn | ((unsigned)d_dn << 16));
+        const edt_col_us2 lim = edt_col_pair(inf2);
+        auto rows2 = [&](unsigned inside, unsigned up_off, unsigned dn_off) -> unsigned {
+            const edt_col_us2 a = up2 + edt_col_pair(up_off), b = dn2 + edt_col_pair(dn_off);
+            return edt_col_word(__builtin_elementwise_min(__builtin_elementwise_min(edt_col_pair(inside), a), __builtin_elementwise_min(b, lim)));
+        };
+        uint4 o;                                            /* rows j, j + 1 of a dword: d_up + 1 + j, d_dn + 8 - j */
+        o.x = rows2(in.x, 0x00020001u, 0x00070008u);
+        o.y = rows2(in.y, 0x00040003u, 0x00050006u);
+        o.z = rows2(in.z, 0x00060005u, 0x00030004u);
+        o.w = rows2(in.w, 0x00080007u, 0x00010002u);
+        if (y0 + 8 > rows) {                                /* rows past the image hold 0 */
+            const int n = rows - y0;                        /* rows of this lane inside the image: <= 7 here, possibly <= 0 */
+            auto keep = [&](unsigned w, int j) -> unsigned { return (j + 1 < n) ? w : ((j < n) ? (w & 0xffffu) : 0u); };
+            o.x = keep(o.x, 0); o.y = keep(o.y, 2); o.z = keep(o.z, 4); o.w = keep(o.w, 6);
         }
-        carry = __shfl(d, 0);                               /* the chunk's first row (d after j = 0) */
+        if (to_lds) { *to_lds = o; return; }                /* the workgroup stores whole 128-byte lines afterwards */
         if (y0 < rows_pad) {
             if ((R & 7) == 0) {                             /* the eight rows are contiguous inside their block */
-                uint4 o;
-                o.x = v[0] | ((unsigned)v[1] << 16); o.y = v[2] | ((unsigned)v[3] << 16);
-                o.z = v[4] | ((unsigned)v[5] << 16); o.w = v[6] | ((unsigned)v[7] << 16);
                 *reinterpret_cast<uint4 *>(g + edt_g_index(xx, y0, cols, R)) = o;
             } else {
-                for (int j = 0; j < 8; j++) if (y0 + j < rows_pad) g[edt_g_index(xx, y0 + j, cols, R)] = v[j];
+                const unsigned ow[4] = {o.x, o.y, o.z, o.w};
+                for (int j = 0; j < 8; j++) if (y0 + j < rows_pad) g[edt_g_index(xx, y0 + j, cols, R)] = (unsigned short)((ow[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
             }
+        }
+    };
+    /* A workgroup takes the column groups bx, bx + gx, ... (the table and the launch are paid once for several columns), FOUR at a
+     * time when a column is one chunk: the four loads are in flight together -- a wave's work per column is a memory latency
+     * followed by ~100 instructions, so columns in flight, not instructions, set the pace. */
+    constexpr int KF = 4;
+    const int stride = gx * WAVES;
+    if (WAVES == 8 && nchunk == 1 && R == 8) {
+        /* The throughput shape (every level of a 640x480 pyramid): the workgroup's eight waves are eight ADJACENT columns, and a
+         * 128-byte line of g is one 8-row block of exactly those eight columns.  Each wave parks its column's blocks in an LDS tile,
+         * then the waves write the tile out line by line (eight lanes = one line): whole-line stores instead of sixty 16-byte pieces
+         * of sixty different lines per wave. */
+        uint4 *tile = s_tile;                               /* [KF][64 blocks][8 columns + 1 pad] */
+        const int ngroups = (cols + 7) >> 3;
+        for (int grp0 = bx; grp0 < ngroups; grp0 += KF * gx) {        /* workgroup-uniform: barriers inside */
+            unsigned m8[KF];
+#pragma unroll
+            for (int k = 0; k < KF; k++) {
+                const int xx = (grp0 + k * gx) * 8 + wave;
+                const int xc = xx < cols ? xx : 0;
+                const unsigned char *col = img + (size_t)xc * rows;
+                m8[k] = load_mask(col, ((rows & 7) == 0) && ((reinterpret_cast<size_t>(col) & 7) == 0), lane * 8);
+            }
+#pragma unroll
+            for (int k = 0; k < KF; k++) {
+                const int xx = (grp0 + k * gx) * 8 + wave;
+                if (grp0 + k * gx < ngroups) emit(xx, 0, (xx < cols) ? m8[k] : 0u, tile + ((size_t)k * 64 + lane) * 9 + wave);      /* workgroup-uniform */
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < KF; k++) {
+                const int b = wave * 8 + (lane >> 3), cix = lane & 7;
+                const int xx = (grp0 + k * gx) * 8 + cix;
+                if (grp0 + k * gx < ngroups && xx < cols && b * 8 < rows_pad)
+                    *reinterpret_cast<uint4 *>(g + edt_g_index(xx, b * 8, cols, 8)) = tile[((size_t)k * 64 + b) * 9 + cix];
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    for (int xx0 = bx * WAVES + wave; xx0 < cols; xx0 += KF * stride) {
+        if (nchunk == 1) {
+            unsigned m8[KF];
+#pragma unroll
+            for (int k = 0; k < KF; k++) {
+                const int xx = xx0 + k * stride;
+                const int xc = xx < cols ? xx : xx0;        /* a column past the image: the first one again (not emitted) */
+                const unsigned char *col = img + (size_t)xc * rows;
+                m8[k] = load_mask(col, ((rows & 7) == 0) && ((reinterpret_cast<size_t>(col) & 7) == 0), lane * 8);
+            }
+#pragma unroll
+            for (int k = 0; k < KF; k++) {
+                const int xx = xx0 + k * stride;
+                if (xx < cols) emit(xx, 0, m8[k], nullptr);          /* wave-uniform */
+            }
+            continue;
+        }
+        for (int k = 0; k < KF; k++) {
+            const int xx = xx0 + k * stride;
+            if (xx >= cols) break;
+            const unsigned char *col = img + (size_t)xx * rows;
+            const bool vec = ((rows & 7) == 0) && ((reinterpret_cast<size_t>(col) & 7) == 0);
+            int cu = INF;                                   /* distance from the row above chunk c to the nearest edge at or above it */
+            for (int c = 0; c < nchunk; c++) {
+                if (lane == 0) carries[c] = cu;
+                const unsigned m = load_mask(col, vec, c * 512 + lane * 8);
+                const unsigned long long bal = __ballot(m != 0u);
+                const int L = bal ? 63 - __clzll((long long)bal) : 0;
+                const unsigned mL = (unsigned)__shfl((int)m, L);
+                if (bal) cu = 511 - (L * 8 + (31 - __clz((int)mL)));
+                else cu = (cu + 512 > INF) ? INF : cu + 512;
+            }
+            int cd = INF;                                   /* distance from the LAST row of chunk c to the nearest edge below the chunk */
+            for (int c = nchunk - 1; c >= 0; c--) {
+                if (lane == 0) carries[nchunk + c] = cd;
+                const unsigned m = load_mask(col, vec, c * 512 + lane * 8);
+                const unsigned long long bal = __ballot(m != 0u);
+                const int L = bal ? __ffsll((long long)bal) - 1 : 0;
+                const unsigned mL = (unsigned)__shfl((int)m, L);
+                if (bal) cd = L * 8 + (__ffs((int)mL) - 1) + 1;          /* from the last row of chunk c - 1 */
+                else cd = (cd + 512 > INF) ? INF : cd + 512;
+            }
+            /* the wave reads back what its lane 0 wrote: LDS operations of one wave complete in order */
+            for (int c = 0; c < nchunk; c++) emit(xx, c, load_mask(col, vec, c * 512 + lane * 8), nullptr);
         }
     }
 }
@@ -1556,7 +1656,8 @@ hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, Im
     if (!only_texels) {
         const size_t lds_wave = (size_t)((gb.rows + 511) / 512) * 64 * sizeof(uint4);      /* 2 bytes per (padded) row */
         if (R <= 8 && lds_wave * 8 <= 48 * 1024) {            /* eight adjacent columns complete a 128-byte line of 8-row blocks */
-            hipLaunchKernelGGL(edt_columns8_kernel<8>, dim3((gb.cols + 7) / 8, gb.count), dim3(512), lds_wave * 8, s, edge, edge_stride,
+            const int cg = gb.count >= 64 ? 4 : (gb.count >= 16 ? 2 : 1);      /* column groups per workgroup */
+            hipLaunchKernelGGL(edt_columns8_kernel<8>, dim3(((gb.cols + 7) / 8 + cg - 1) / cg, gb.count), dim3(512), lds_wave * 8, s, edge, edge_stride,
                                gb.rows, gb.cols, R, g, bitmap, bm_words, flags);
         } else if (lds_wave * 4 <= 48 * 1024) {
             hipLaunchKernelGGL(edt_columns8_kernel<4>, dim3((gb.cols + 3) / 4, gb.count), dim3(256), lds_wave * 4, s, edge, edge_stride,
@@ -1673,7 +1774,9 @@ hipError_t launch_edges_to_now_levels(int n, const int *rows, const int *cols, c
     hipError_t e = hipSuccess;
     unsigned g = 0;
     if (!only_texels) {
-        g = prefix([&](int l) { return (unsigned)((cols[l] + sh.waves - 1) / sh.waves); });
+        /* column groups per workgroup: several for large batches (the workgroup's table and launch are paid once) */
+        const int cg = count >= 64 ? 4 : (count >= 16 ? 2 : 1);
+        g = prefix([&](int l) { const int ng = (cols[l] + sh.waves - 1) / sh.waves; return (unsigned)((ng + cg - 1) / cg); });
         if (sh.waves == 8) hipLaunchKernelGGL(edt_columns8_levels_kernel<8>, dim3(g, count), dim3(512), sh.lds_cols, s, t);
         else hipLaunchKernelGGL(edt_columns8_levels_kernel<4>, dim3(g, count), dim3(256), sh.lds_cols, s, t);
         g = prefix([&](int l) { return (unsigned)t.n_partial[l]; });
