@@ -831,7 +831,7 @@ DVO_DEV void edt_columns8_body(const int bx, const int gx, const int by, const u
      * eight rows twice with a running counter, up and down, parking the upward pass in LDS: 312 vector instructions per wave and
      * chunk, the kernel was bound by their issue.)  Columns taller than 512 rows first collect, per chunk, the distance from the
      * chunk's borders to the nearest edge outside it (two sweeps of ballots, wave-uniform). */
-    extern __shared__ uint4 s_da8[];                    /* per wave: 2 * nchunk ints (the launch sizes it generously) */
+    extern __shared__ uint4 s_da8[];                    /* per wave: 2 * nchunk ints, rounded up to 16 bytes (the launchers size it) */
     __shared__ uint4 s_lut[256];
     __shared__ uint4 s_tile[WAVES == 8 ? 4 * 64 * 9 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -846,7 +846,7 @@ DVO_DEV void edt_columns8_body(const int bx, const int gx, const int by, const u
     g += (size_t)by * edt_g_count(rows, cols, R);
     const int rows_pad = ((rows + R - 1) / R) * R;
     const int nchunk = (rows + 511) / 512;
-    int *carries = reinterpret_cast<int *>(s_da8) + (size_t)wave * 2 * nchunk;
+    int *carries = reinterpret_cast<int *>(s_da8) + (size_t)wave * (((size_t)2 * nchunk + 3) & ~(size_t)3);
     const int INF = DVO_EDT_INF(rows, cols);
     const unsigned inf2 = (unsigned)INF | ((unsigned)INF << 16);
     const unsigned char *img = edge + (size_t)by * edge_stride;
@@ -1654,7 +1654,7 @@ hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, Im
     int *flags = reinterpret_cast<int *>(bitmap + (size_t)bm_words * gb.count);
     hipError_t e;
     if (!only_texels) {
-        const size_t lds_wave = (size_t)((gb.rows + 511) / 512) * 64 * sizeof(uint4);      /* 2 bytes per (padded) row */
+        const size_t lds_wave = (((size_t)((gb.rows + 511) / 512) * 2 * sizeof(int)) + 15) & ~(size_t)15;      /* per wave: two border distances per 512-row chunk */
         if (R <= 8 && lds_wave * 8 <= 48 * 1024) {            /* eight adjacent columns complete a 128-byte line of 8-row blocks */
             const int cg = gb.count >= 64 ? 4 : (gb.count >= 16 ? 2 : 1);      /* column groups per workgroup */
             hipLaunchKernelGGL(edt_columns8_kernel<8>, dim3(((gb.cols + 7) / 8 + cg - 1) / cg, gb.count), dim3(512), lds_wave * 8, s, edge, edge_stride,
@@ -1711,7 +1711,7 @@ static bool edt_levels_shape(int n, const int *rows, const int *cols, EdtLevelSh
     for (int l = 0; l < n; l++) { if (rows[l] < 2 || cols[l] < 2) return false; r0 = rows[l] > r0 ? rows[l] : r0; c0 = cols[l] > c0 ? cols[l] : c0; }
     sh.R = edt_rows_per_block(c0);
     if (sh.R < 2) return false;
-    const size_t lds_wave = (size_t)((r0 + 511) / 512) * 64 * sizeof(uint4);
+    const size_t lds_wave = (((size_t)((r0 + 511) / 512) * 2 * sizeof(int)) + 15) & ~(size_t)15;       /* per wave: two border distances per 512-row chunk */
     sh.waves = (sh.R <= 8 && lds_wave * 8 <= 48 * 1024) ? 8 : ((lds_wave * 4 <= 48 * 1024) ? 4 : 0);
     if (!sh.waves) return false;
     sh.lds_cols = lds_wave * sh.waves;

@@ -330,6 +330,8 @@ def _sparse_edge_maps():
     yield "dense_random", e
     e = blank(1030, 40); e[515, 20] = 255                                 # three 512-row chunks in the column pass
     yield "tall_three_chunks", e
+    e = blank(3000, 48); e[[7, 1499, 2990], [3, 40, 20]] = 255            # six 512-row chunks, edges in the first, third and last: the
+    yield "tall_six_chunks", e                                            # chunk borders' distances travel over empty chunks both ways
 
 
 @pytest.mark.parametrize("name,edge", list(_sparse_edge_maps()))
