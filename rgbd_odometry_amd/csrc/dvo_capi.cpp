@@ -142,8 +142,11 @@ void free_texels(dvo_ctx *c, Level &L) {
     L.tex = nullptr; L.tex_sparse = false; L.tex_mapped.clear(); L.tex_handles.clear(); L.tex_va_bytes = 0;
     (void)c;
 }
-int map_texels(dvo_ctx *c, int level, int first, int count) {
+/* `stream`: the stream whose work will write the texels next (the zero fill of a fresh chunk must be ordered before that work;
+ * the frame path writes on its own lane streams); nullptr = the context stream */
+int map_texels(dvo_ctx *c, int level, int first, int count, hipStream_t stream) {
     Level &L = c->lv[level];
+    if (!stream) stream = c->stream;
     if (!L.tex_sparse || count <= 0) return DVO_OK;
     const size_t pair_bytes = sizeof(float4) * L.tex_stride;
     const size_t lo = (size_t)first * pair_bytes / L.tex_chunk, hi = ((size_t)(first + count) * pair_bytes - 1) / L.tex_chunk;
@@ -170,7 +173,7 @@ int map_texels(dvo_ctx *c, int level, int first, int count) {
                                               " of level " + std::to_string(level) + " with memory: " + hipGetErrorString(e));
         }
         L.tex_handles[i] = h; L.tex_mapped[i] = 1;
-        HIPCHK(c, hipMemsetAsync(addr, 0, L.tex_chunk, c->stream));      /* tile padding is never read, but keep it defined */
+        HIPCHK(c, hipMemsetAsync(addr, 0, L.tex_chunk, stream));      /* tile padding is never read, but keep it defined */
     }
     return DVO_OK;
 }
@@ -179,18 +182,39 @@ int sparse_map_compact_failures(dvo_ctx *c, int level, int first, int count, hip
     std::vector<int> pn((size_t)count);
     HIPCHK(c, hipMemcpyAsync(pn.data(), L.d_pal_n + first, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost, stream));
     HIPCHK(c, stream_wait(stream));
+    if (L.p4_known.empty()) { L.p4_known.assign(c->n_pairs, Level::P4_UNKNOWN); L.p4_fresh.assign(c->n_pairs, 0); }
+    for (int i = 0; i < count; i++) { L.p4_known[first + i] = pn[i] > 0 ? Level::P4_OK : Level::P4_REFUSED; L.p4_fresh[first + i] = 1; }
     int n = 0;
     for (int i = 0; i < count; ) {
         if (pn[i] > 0) { i++; continue; }
         int j = i;
         while (j < count && pn[j] <= 0) j++;
-        const int rc = map_texels(c, level, first + i, j - i);
+        const int rc = map_texels(c, level, first + i, j - i, stream);
         if (rc) return rc;
         n += j - i;
         i = j;
     }
-    if (n && stream != c->stream) HIPCHK(c, stream_wait(c->stream));      /* the zero fill of fresh chunks runs on the context stream */
     *n_failed = n;
+    return DVO_OK;
+}
+/* pal_n of the pairs whose compact form the host has not looked at yet (one copy + one wait per run of such pairs) */
+int refresh_p4_known(dvo_ctx *c, int level, int first, int count) {
+    Level &L = c->lv[level];
+    if (!L.d_pal_n || L.pal_built.empty()) return DVO_OK;
+    if (L.p4_known.empty()) { L.p4_known.assign(c->n_pairs, Level::P4_UNKNOWN); L.p4_fresh.assign(c->n_pairs, 0); }
+    for (int p = first; p < first + count; ) {
+        if (!L.pal_built[p] || L.p4_known[p] != Level::P4_UNKNOWN) { p++; continue; }
+        int q = p;
+        while (q < first + count && L.pal_built[q] && L.p4_known[q] == Level::P4_UNKNOWN) q++;
+        std::vector<int> pn((size_t)(q - p));
+        HIPCHK(c, hipMemcpyAsync(pn.data(), L.d_pal_n + p, sizeof(int) * (size_t)(q - p), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, stream_wait(c->stream));
+        for (int i = p; i < q; i++) {
+            L.p4_known[i] = pn[i - p] > 0 ? Level::P4_OK : Level::P4_REFUSED;
+            if (pn[i - p] <= 0 && !L.tex16_stale.empty()) L.tex16_stale[i] = 0;      /* the refused image's texels were written with it */
+        }
+        p = q;
+    }
     return DVO_OK;
 }
 
@@ -203,7 +227,7 @@ int ensure_texels(dvo_ctx *c, int level, int rows, int cols) {
         free_texels(c, L);
         std::fill(L.have_now.begin(), L.have_now.end(), 0);
         if (L.p4) { (void)hipFree(L.p4); (void)hipFree(L.pal); (void)hipFree(L.d_pal_n); L.p4 = nullptr; L.pal = nullptr; L.d_pal_n = nullptr; }
-        L.pal_built.clear(); L.now_uses.clear(); L.tex16_stale.clear();
+        L.pal_built.clear(); L.now_uses.clear(); L.tex16_stale.clear(); L.p4_known.clear(); L.p4_fresh.clear();
     }
 
     L.rows = rows; L.cols = cols;
@@ -239,6 +263,7 @@ static void level_flags(dvo_ctx *c, Level &L) {
     if (L.pal_built.empty()) { L.pal_built.assign(c->n_pairs, 0); L.now_uses.assign(c->n_pairs, 0); }
     if (L.tex16_stale.empty()) L.tex16_stale.assign(c->n_pairs, 0);
     if (L.have_now.empty()) L.have_now.assign(c->n_pairs, 0);
+    if (L.p4_known.empty()) { L.p4_known.assign(c->n_pairs, Level::P4_UNKNOWN); L.p4_fresh.assign(c->n_pairs, 0); }
 }
 
 bool native_compact_wanted(const dvo_ctx *c) { return c->prm.engine_variant != 4 && compact_now_policy() != 2; }
@@ -272,7 +297,12 @@ int ensure_compact_slabs(dvo_ctx *c, int level) {
 int now_written_compact(dvo_ctx *c, int level, int first_pair, int count) {
     Level &L = c->lv[level];
     level_flags(c, L);
-    for (int p = first_pair; p < first_pair + count; p++) { L.have_now[p] = 1; L.now_uses[p] = 0; L.pal_built[p] = 1; L.tex16_stale[p] = 1; }
+    for (int p = first_pair; p < first_pair + count; p++) {
+        L.have_now[p] = 1; L.now_uses[p] = 0; L.pal_built[p] = 1;
+        if (L.p4_fresh[p]) L.p4_fresh[p] = 0;               /* pal_n of THIS write was read back (sparse slab): known */
+        else L.p4_known[p] = Level::P4_UNKNOWN;
+        L.tex16_stale[p] = (L.p4_known[p] == Level::P4_REFUSED) ? 0 : 1;      /* a refused image got its texels from the same launch */
+    }
     return DVO_OK;
 }
 
@@ -294,7 +324,7 @@ int ensure_tex16(dvo_ctx *c, int level, int first_pair, int count) {
 int now_written(dvo_ctx *c, int level, int first_pair, int count) {
     Level &L = c->lv[level];
     level_flags(c, L);
-    for (int p = first_pair; p < first_pair + count; p++) L.tex16_stale[p] = 0;
+    for (int p = first_pair; p < first_pair + count; p++) { L.tex16_stale[p] = 0; L.p4_known[p] = Level::P4_UNKNOWN; L.p4_fresh[p] = 0; }
     for (int p = first_pair; p < first_pair + count; ) {
         L.have_now[p] = 1; L.now_uses[p] = 0;
         if (!L.pal_built[p]) { p++; continue; }
@@ -330,7 +360,7 @@ int build_compact_now(dvo_ctx *c, int level, int first_pair, int count, bool onl
             }
             HIPCHK(c, launch_palette_build(L.tex, L.tex_stride, L.rows, L.cols, L.p4, L.p4_stride, L.pal, L.d_pal_n, b, nb, c->pal_work, c->stream));
         }
-        for (int i = p; i < q; i++) L.pal_built[i] = 1;
+        for (int i = p; i < q; i++) { L.pal_built[i] = 1; L.p4_known[i] = Level::P4_UNKNOWN; }      /* the builder may have refused (pal_n < 0) */
         p = q;
     }
     return DVO_OK;
@@ -497,6 +527,18 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
             if ((rc = build_compact_now(c, l, first_pair, n_pairs, compact_now_policy() != 1))) return rc;
             Level &L = c->lv[l];
             for (int p = first_pair; p < first_pair + n_pairs; p++) { L.now_uses[p]++; all_p4 = all_p4 && L.pal_built[p]; }
+        }
+        /* the 256-thread shape is chosen for launches that read the compact form: ask the device which pairs really have one
+         * where that decides the shape (round 5, ADVICE r3/r4: pal_built is also set for images the form could not hold) */
+        const bool shape_depends = all_p4 && c->prm.block_threads != 256 && c->prm.block_threads != 512 && c->prm.block_threads != 1024 &&
+                                   (2 * n_pairs >= 3 * c->n_cu || n_pairs > c->n_cu);
+        for (int l = 0; l < n_levels && shape_depends && all_p4; l++) {
+            if (sc.iters[l] <= 0) continue;
+            if ((rc = refresh_p4_known(c, l, first_pair, n_pairs))) return rc;
+            const Level &L = c->lv[l];
+            int refused = 0;
+            for (int p = first_pair; p < first_pair + n_pairs; p++) refused += (L.p4_known[p] == Level::P4_REFUSED);
+            if (20 * refused > n_pairs) all_p4 = false;       /* more than 5 % of a level on 16-byte texels: the request-bound shape */
         }
         for (int l = 0; l < DVO_LEVELS; l++) ls.l[l] = slab_of(c, l);       /* the build may have allocated */
     }
@@ -1147,19 +1189,43 @@ int dvo_replicate_pairs(dvo_ctx *c, int n_src, int dst_first, int dst_count) {
             int rc = check_ready(c, p, l);
             if (rc) return rc;
         }
-        /* the now level travels in the form(s) its sources have: 16-byte texels, the compact form, or both */
+        /* the now level travels in the form(s) its sources have: 16-byte texels, the compact form, or both.  A source whose image
+         * the compact form could not hold HAS 16-byte texels (refresh_p4_known clears its stale mark) */
+        { const int prc = refresh_p4_known(c, l, 0, n_src); if (prc) return prc; }
         bool any_tex16 = false, any_compact = false;
         for (int p = 0; p < n_src; p++) {
             const bool stale = !L.tex16_stale.empty() && L.tex16_stale[p];
             any_tex16 = any_tex16 || !stale;
             any_compact = any_compact || (!L.pal_built.empty() && L.pal_built[p]);
         }
-        if (any_tex16 && L.tex) {                    /* 16-byte texels travel: the destinations (and sources) need memory behind them */
-            int mrc = map_texels(c, l, 0, n_src);
-            if (!mrc) mrc = map_texels(c, l, dst_first, dst_count);
-            if (mrc) return mrc;
+        unsigned char *d_has_tex = nullptr;
+        if (any_tex16 && L.tex) {
+            /* 16-byte texels travel with the sources that have them: those destinations (and sources) need memory behind theirs */
+            std::vector<unsigned char> has((size_t)n_src);
+            bool all = true;
+            for (int p = 0; p < n_src; p++) { has[p] = !(!L.tex16_stale.empty() && L.tex16_stale[p]); all = all && has[p]; }
+            for (int p = 0; p < n_src; p++)
+                if (has[p]) { const int mrc = map_texels(c, l, p, 1); if (mrc) return mrc; }
+            for (int p = dst_first; p < dst_first + dst_count; ) {
+                if (!has[(p - dst_first) % n_src]) { p++; continue; }
+                int q = p;
+                while (q < dst_first + dst_count && has[(q - dst_first) % n_src]) q++;
+                const int mrc = map_texels(c, l, p, q - p);
+                if (mrc) return mrc;
+                p = q;
+            }
+            if (!all) {
+                HIPCHK(c, hipMalloc((void **)&d_has_tex, (size_t)n_src));
+                HIPCHK(c, hipMemcpyAsync(d_has_tex, has.data(), (size_t)n_src, hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, stream_wait(c->stream));          /* `has` leaves scope */
+            }
         }
-        HIPCHK(c, launch_replicate_level(any_tex16 ? L.tex : nullptr, L.tex_stride, L.pts, L.cpts, L.cidx, L.cpt4, L.chdr, L.d_pt4_ok, L.pt_cap, L.dN, n_src, dst_first, dst_count, c->stream));
+        {
+            const hipError_t le = launch_replicate_level(any_tex16 ? L.tex : nullptr, d_has_tex, L.tex_stride, L.pts, L.cpts, L.cidx, L.cpt4, L.chdr, L.d_pt4_ok,
+                                                         L.pt_cap, L.dN, n_src, dst_first, dst_count, c->stream);
+            if (d_has_tex) { (void)hipStreamSynchronize(c->stream); (void)hipFree(d_has_tex); }
+            HIPCHK(c, le);
+        }
         for (int p = dst_first; p < dst_first + dst_count; p++) {
             const int src = (p - dst_first) % n_src;
             if (src == p) continue;                                 /* a source inside the destination range keeps its own list */
@@ -1180,6 +1246,7 @@ int dvo_replicate_pairs(dvo_ctx *c, int n_src, int dst_first, int dst_count) {
                     if (p == src) continue;
                     L.pal_built[p] = L.pal_built[src];
                     L.tex16_stale[p] = L.tex16_stale[src];
+                    L.p4_known[p] = L.p4_known[src];
                 }
             }
         }
@@ -1413,7 +1480,7 @@ int dvo_iter_begin(dvo_ctx *c, int pair, int level, int max_iters, const double 
     std::memcpy(h + 9, t, sizeof(double) * 3);
     double *d_pose = c->d_poses + (size_t)12 * pair;
     HIPCHK(c, hipMemcpyAsync(d_pose, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, launch_iter_begin(c->d_states + pose_state_bytes() * pair, d_pose,
+    HIPCHK(c, launch_iter_begin(c->d_states + pose_state_bytes() * pair, c->dprm, d_pose,
                                 c->d_iter_energy + (size_t)c->iter_energy_cap * pair, max_iters, c->stream));
     HIPCHK(c, stream_wait(c->stream));     /* h is a stack buffer */
     c->iter_max[pair] = max_iters;
@@ -1502,7 +1569,7 @@ hipError_t enqueue_step_schedule(dvo_ctx *c, const Schedule &sc, int pair, int f
         shard_of(N, rank, world, first, count);
         float *energy = c->d_energy + (size_t)pair * sc.e_stride + sc.e_off[l];
         const LevelSlab sl = slab_of(c, l);
-        rec(launch_iter_begin(st[cur], d_pose, energy, sc.iters[l], c->stream));
+        rec(launch_iter_begin(st[cur], c->dprm, d_pose, energy, sc.iters[l], c->stream));
         const int nb = tiled_step_blocks(count, c->n_cu);
         /* DVO_FLAG_NORMAL_MATRIX: the launches also form H = sum w J J^T (21 more double sums per point: + 40 % on the launch),
          * it rides in the same 32 doubles through the all-reduce and is kept per iterate (dvo_get_level_normal_matrix); without

@@ -634,7 +634,7 @@ static int frames_as_now_level(dvo_ctx *c, int l, int first_slot, int first_pair
     /* sparse texel slab (dvo_ctx.h): the stage runs without texel output; the images the compact form cannot hold get their
      * texels mapped and written by a second run of the last pass -- per chunk, while the chunk's scratch still holds them */
     const bool defer = compact && L.tex_sparse;
-    if (L.tex_sparse && !compact && (rc = map_texels(c, l, first_pair, count))) return rc;
+    if (L.tex_sparse && !compact && (rc = map_texels(c, l, first_pair, count, stream))) return rc;
     auto run = [&](const unsigned char *edge, int nc, int *wk, int pair0) -> int {
         HIPCHK(c, launch_edges_to_now(edge, F.npx, ImgBatch{F.rows, F.cols, nc}, wk, defer ? nullptr : L.tex + (size_t)pair0 * L.tex_stride,
                                       L.tex_stride, p4, L.p4_stride, L.pal, L.d_pal_n, pair0, stream));
@@ -698,7 +698,7 @@ static int frames_as_now_all(dvo_ctx *c, int n_levels, int first_slot, int first
             const FrameLevel &F = c->fs.lv[l];
             Level &L = c->lv[l];
             edge[l] = F.edge + (size_t)(first_slot + b) * F.npx; estride[l] = F.npx;
-            if (L.tex_sparse && !compact && (rc = map_texels(c, l, first_pair + b, nc))) return rc;
+            if (L.tex_sparse && !compact && (rc = map_texels(c, l, first_pair + b, nc, ls))) return rc;
             const bool dl = compact && L.tex_sparse;                 /* sparse texel slab: no texel output in the first run */
             defer = defer || dl;
             tex[l] = dl ? nullptr : L.tex + (size_t)(first_pair + b) * L.tex_stride; tstride[l] = L.tex_stride;

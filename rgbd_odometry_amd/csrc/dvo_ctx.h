@@ -59,6 +59,15 @@ struct Level {
      * 16-byte texels have not been decoded from it yet.  (A pair whose image the compact form could not hold got its texels
      * from the same launch; the decode launch skips it on the device: pal_n <= 0.) */
     std::vector<char> tex16_stale;
+    /* per pair: what the HOST knows about the compact form of the current now level -- the device's pal_n says whether the builder
+     * (the distance-transform stage, or the generic one) could make it, and the host only learns that where it reads pal_n back:
+     * at once on a sparse texel slab (the refused images need memory mapped), otherwise on demand (refresh_p4_known: before a
+     * replication and before a launch-shape decision that depends on it).  A REFUSED pair's 16-byte texels are its real form:
+     * they are current (tex16_stale = 0) and travel with it (round 5, ADVICE r4: a replicated refused source left its
+     * destinations without texels -- on a sparse slab without memory behind them). */
+    enum : char { P4_UNKNOWN = 0, P4_OK = 1, P4_REFUSED = 2 };
+    std::vector<char> p4_known;
+    std::vector<char> p4_fresh;     /* set where sparse_map_compact_failures has just read pal_n; consumed by now_written_compact */
 };
 
 /* frame store (rows f1/f2): per level one slab per plane for all slots, slot s at base + s*npx */
@@ -243,11 +252,12 @@ int build_schedule(dvo_ctx *c, int n_levels, const int *iters, int flags, dvo::S
 int ensure_outputs(dvo_ctx *c, const dvo::Schedule &sc);
 void stamp_outputs(dvo_ctx *c, const dvo::Schedule &sc, int first, int n);
 /* backs the texels of pairs [first, first + count) of a level with memory (no-op for a dense slab) */
-int map_texels(dvo_ctx *c, int level, int first, int count);
+int map_texels(dvo_ctx *c, int level, int first, int count, hipStream_t stream = nullptr);
 void free_texels(dvo_ctx *c, Level &L);
 /* sparse slabs, after a distance-transform launch over pairs [first, first + count) that ran WITHOUT texel output: waits for it,
  * reads the palette sizes back and maps the texels of the images the compact form could not hold; *n_failed = how many */
 int sparse_map_compact_failures(dvo_ctx *c, int level, int first, int count, hipStream_t stream, int *n_failed);
+int refresh_p4_known(dvo_ctx *c, int level, int first, int count);      /* reads pal_n back where the host does not know it yet */
 /* enqueues the level schedule of one pair as ONE launch per iteration on c->stream (dvo_kernels.hip: tiled_step_kernel): this
  * rank's contiguous share of every level's points (rank / world: dvo_tiled_shard's decomposition), `all_reduce` (may be empty:
  * one GPU) called on the 32 sums between two launches.  Pose in / out through d_pose (12 doubles on the device). */

@@ -294,30 +294,57 @@ DVO_DEV double d_sqrt(double x) {            /* x >= 0, normal range */
     g = fma(g, r, g); h = fma(h, r, h);
     return fma(fma(-g, g, x), h, g);
 }
+/* Double constants of the update's polynomials.  Left to itself the compiler hoists every literal of the update into vector
+ * registers for the whole kernel (two dozen register pairs pinned across the point loops, the surplus spilled to scratch and
+ * re-loaded inside the serial chain).  DVO_K(c) materialises c where it is used, in a scalar register pair (two s_mov_b32 that
+ * the optimiser may not move); make EXP=vconst EXPDEFS=-DDVO_CONST_VGPR=1 builds the plain-literal form for the A/B (DESIGN.md
+ * section 6).  With it no fused kernel of the 256- or 512-thread shapes touches scratch any more. */
+#ifndef DVO_CONST_VGPR
+template <unsigned long long BITS> DVO_DEV double kconst_sgpr() {
+    unsigned lo, hi;
+    asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "i"((unsigned)BITS), "i"((unsigned)(BITS >> 32)));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+#define DVO_K(c) kconst_sgpr<__builtin_bit_cast(unsigned long long, (double)(c))>()
+#else
+#define DVO_K(c) (c)
+#endif
+/* 1/sqrt(x), x > 0 in the normal range: hardware seed + two Newton steps y <- y + y (1 - x y^2) / 2 (<= ~1 ulp).  Nine
+ * instructions where d_rcp(d_sqrt(x)) takes fifteen: the update is one lane's serial instruction stream (round 5). */
+DVO_DEV double d_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-(x * y), y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-(x * y), y, 1.0);
+    return fma(0.5 * y, e, y);
+}
+/* 1/sqrt(n2) for the squared norm of a quaternion that is unit up to rounding (|n2 - 1| ~ 1e-15: a product of two unit
+ * quaternions, or {cos, sin * axis}): first order, error 3/8 (n2 - 1)^2 < 1e-30.  Two instructions instead of fifteen. */
+DVO_DEV double unit_rnorm(double n2) { return fma(-0.5, n2 - 1.0, 1.0); }
 /* sin and cos of |x| <= ~2*pi : quadrant reduction with a two-part pi/2, then
  * Taylor series on [-pi/4, pi/4] (terms below 1e-19). */
 DVO_DEV void d_sincos(double x, double &s, double &c) {
-    const double k = rint(x * 0.63661977236758134308);          /* 2/pi */
-    double r = fma(-k, 1.57079632679489655800e+00, x);          /* pi/2 hi */
-    r = fma(-k, 6.12323399573676603587e-17, r);                 /* pi/2 lo */
+    const double k = rint(x * DVO_K(0.63661977236758134308));          /* 2/pi */
+    double r = fma(-k, DVO_K(1.57079632679489655800e+00), x);          /* pi/2 hi */
+    r = fma(-k, DVO_K(6.12323399573676603587e-17), r);                 /* pi/2 lo */
     const double z = r * r;
-    double ps = 1.0 / 355687428096000.0;                        /* 1/17! */
-    ps = fma(ps, z, -1.0 / 1307674368000.0);                    /* 1/15! */
-    ps = fma(ps, z, 1.0 / 6227020800.0);                        /* 1/13! */
-    ps = fma(ps, z, -1.0 / 39916800.0);                         /* 1/11! */
-    ps = fma(ps, z, 1.0 / 362880.0);                            /* 1/9!  */
-    ps = fma(ps, z, -1.0 / 5040.0);                             /* 1/7!  */
-    ps = fma(ps, z, 1.0 / 120.0);                               /* 1/5!  */
-    ps = fma(ps, z, -1.0 / 6.0);                                /* 1/3!  */
+    double ps = DVO_K(1.0 / 355687428096000.0);                        /* 1/17! */
+    ps = fma(ps, z, DVO_K(-1.0 / 1307674368000.0));                    /* 1/15! */
+    ps = fma(ps, z, DVO_K(1.0 / 6227020800.0));                        /* 1/13! */
+    ps = fma(ps, z, DVO_K(-1.0 / 39916800.0));                         /* 1/11! */
+    ps = fma(ps, z, DVO_K(1.0 / 362880.0));                            /* 1/9!  */
+    ps = fma(ps, z, DVO_K(-1.0 / 5040.0));                             /* 1/7!  */
+    ps = fma(ps, z, DVO_K(1.0 / 120.0));                               /* 1/5!  */
+    ps = fma(ps, z, DVO_K(-1.0 / 6.0));                                /* 1/3!  */
     const double sr = fma(ps * z, r, r);
-    double pc = -1.0 / 6402373705728000.0;                      /* 1/18! */
-    pc = fma(pc, z, 1.0 / 20922789888000.0);                    /* 1/16! */
-    pc = fma(pc, z, -1.0 / 87178291200.0);                      /* 1/14! */
-    pc = fma(pc, z, 1.0 / 479001600.0);                         /* 1/12! */
-    pc = fma(pc, z, -1.0 / 3628800.0);                          /* 1/10! */
-    pc = fma(pc, z, 1.0 / 40320.0);                             /* 1/8!  */
-    pc = fma(pc, z, -1.0 / 720.0);                              /* 1/6!  */
-    pc = fma(pc, z, 1.0 / 24.0);                                /* 1/4!  */
+    double pc = DVO_K(-1.0 / 6402373705728000.0);                      /* 1/18! */
+    pc = fma(pc, z, DVO_K(1.0 / 20922789888000.0));                    /* 1/16! */
+    pc = fma(pc, z, DVO_K(-1.0 / 87178291200.0));                      /* 1/14! */
+    pc = fma(pc, z, DVO_K(1.0 / 479001600.0));                         /* 1/12! */
+    pc = fma(pc, z, DVO_K(-1.0 / 3628800.0));                          /* 1/10! */
+    pc = fma(pc, z, DVO_K(1.0 / 40320.0));                             /* 1/8!  */
+    pc = fma(pc, z, DVO_K(-1.0 / 720.0));                              /* 1/6!  */
+    pc = fma(pc, z, DVO_K(1.0 / 24.0));                                /* 1/4!  */
     pc = fma(pc, z, -0.5);
     const double cr = fma(pc, z, 1.0);
     const int q = ((int)k) & 3;
@@ -330,20 +357,20 @@ DVO_DEV void d_sincos(double x, double &s, double &c) {
  * atan(y) = 2 atan(y / (1 + sqrt(1+y^2))) bring |y| <= tan(pi/16); 12-term series. */
 DVO_DEV double d_atan_series(double y) {        /* |y| <= 0.25: |y|^31/31 < 1e-20 */
     const double z = y * y;
-    double p = 1.0 / 29.0;
-    p = fma(p, z, -1.0 / 27.0);
-    p = fma(p, z, 1.0 / 25.0);
-    p = fma(p, z, -1.0 / 23.0);
-    p = fma(p, z, 1.0 / 21.0);
-    p = fma(p, z, -1.0 / 19.0);
-    p = fma(p, z, 1.0 / 17.0);
-    p = fma(p, z, -1.0 / 15.0);
-    p = fma(p, z, 1.0 / 13.0);
-    p = fma(p, z, -1.0 / 11.0);
-    p = fma(p, z, 1.0 / 9.0);
-    p = fma(p, z, -1.0 / 7.0);
-    p = fma(p, z, 1.0 / 5.0);
-    p = fma(p, z, -1.0 / 3.0);
+    double p = DVO_K(1.0 / 29.0);
+    p = fma(p, z, DVO_K(-1.0 / 27.0));
+    p = fma(p, z, DVO_K(1.0 / 25.0));
+    p = fma(p, z, DVO_K(-1.0 / 23.0));
+    p = fma(p, z, DVO_K(1.0 / 21.0));
+    p = fma(p, z, DVO_K(-1.0 / 19.0));
+    p = fma(p, z, DVO_K(1.0 / 17.0));
+    p = fma(p, z, DVO_K(-1.0 / 15.0));
+    p = fma(p, z, DVO_K(1.0 / 13.0));
+    p = fma(p, z, DVO_K(-1.0 / 11.0));
+    p = fma(p, z, DVO_K(1.0 / 9.0));
+    p = fma(p, z, DVO_K(-1.0 / 7.0));
+    p = fma(p, z, DVO_K(1.0 / 5.0));
+    p = fma(p, z, DVO_K(-1.0 / 3.0));
     return fma(p * z, y, y);
 }
 DVO_DEV double d_atan(double x) {
@@ -354,19 +381,19 @@ DVO_DEV double d_atan(double x) {
     y = d_div(y, 1.0 + d_sqrt(fma(y, y, 1.0)));
     y = d_div(y, 1.0 + d_sqrt(fma(y, y, 1.0)));
     const double z = y * y;
-    double p = -1.0 / 23.0;
-    p = fma(p, z, 1.0 / 21.0);
-    p = fma(p, z, -1.0 / 19.0);
-    p = fma(p, z, 1.0 / 17.0);
-    p = fma(p, z, -1.0 / 15.0);
-    p = fma(p, z, 1.0 / 13.0);
-    p = fma(p, z, -1.0 / 11.0);
-    p = fma(p, z, 1.0 / 9.0);
-    p = fma(p, z, -1.0 / 7.0);
-    p = fma(p, z, 1.0 / 5.0);
-    p = fma(p, z, -1.0 / 3.0);
+    double p = DVO_K(-1.0 / 23.0);
+    p = fma(p, z, DVO_K(1.0 / 21.0));
+    p = fma(p, z, DVO_K(-1.0 / 19.0));
+    p = fma(p, z, DVO_K(1.0 / 17.0));
+    p = fma(p, z, DVO_K(-1.0 / 15.0));
+    p = fma(p, z, DVO_K(1.0 / 13.0));
+    p = fma(p, z, DVO_K(-1.0 / 11.0));
+    p = fma(p, z, DVO_K(1.0 / 9.0));
+    p = fma(p, z, DVO_K(-1.0 / 7.0));
+    p = fma(p, z, DVO_K(1.0 / 5.0));
+    p = fma(p, z, DVO_K(-1.0 / 3.0));
     double a = 4.0 * fma(p * z, y, y);
-    if (inv) a = 1.57079632679489655800e+00 - a + 6.12323399573676603587e-17;
+    if (inv) a = DVO_K(1.57079632679489655800e+00) - a + DVO_K(6.12323399573676603587e-17);
     return (x < 0.0) ? -a : a;
 }
 
@@ -389,9 +416,9 @@ DVO_DEV void m3_vec(const double *A, const double *x, double *y) {
 /* y = (I + a*hat(w) + b*hat(w)^2) x   without forming the matrices:
  * hat(w) x = w cross x ;  hat(w)^2 x = w (w.x) - (w.w) x */
 DVO_DEV void apply_I_aW_bW2(const double *w, double a, double b, const double *x, double *y) {
-    const double c0 = w[1] * x[2] - w[2] * x[1];
-    const double c1 = w[2] * x[0] - w[0] * x[2];
-    const double c2 = w[0] * x[1] - w[1] * x[0];
+    const double c0 = fma(w[1], x[2], -(w[2] * x[1]));
+    const double c1 = fma(w[2], x[0], -(w[0] * x[2]));
+    const double c2 = fma(w[0], x[1], -(w[1] * x[0]));
     const double wx = fma(w[2], x[2], fma(w[1], x[1], w[0] * x[0]));
     const double ww = fma(w[2], w[2], fma(w[1], w[1], w[0] * w[0]));
     y[0] = fma(b, fma(w[0], wx, -ww * x[0]), fma(a, c0, x[0]));
@@ -403,6 +430,48 @@ DVO_DEV double norm6(const double *v) {
 #pragma unroll
     for (int k = 1; k < 6; k++) s = fma(v[k], v[k], s);
     return d_sqrt(s);
+}
+
+/* ---- constants of the update, as a block in LDS (round 5) ------------------------------------------------------------------
+ * The update is ONE wave's serial instruction stream, and a wave alone issues one instruction every 4-5 cycles whatever it is.
+ * A polynomial coefficient written as a literal costs such a stream up to six issue slots (two s_mov_b32, two v_mov_b32 and the
+ * v_fmac that wants its addend in a vector register) -- or, hoisted by the compiler, a register pair pinned for the whole kernel
+ * (the scratch traffic of rounds 2-4's fused kernels was exactly that).  Kept in LDS, two coefficients arrive per ds_read_b128
+ * in registers that the v_fmac may overwrite: 1.5 slots per Horner step.  The parameters of dvo_params the update reads are in
+ * the same block, so that the kernels need not hold DevParams in scalar registers (they were spilled to vector-register lanes and
+ * read back with v_readlane all over the serial chain).  Built once per kernel by upd_const_build(); kernels without LDS state
+ * (single-lane helpers) build it on the stack, where it folds back into literals. */
+struct __attribute__((aligned(16))) UpdConst {
+    double omb, beta;            /* 1 - beta, beta (:799) */
+    double ab, lambda;           /* step_a * step_b (:773), reg_lambda (:742) */
+    double pk[6];                /* pre-conditioner diagonal (:724-730) */
+    double tr, tr2;              /* trust radius (:25, widened like the reference does at :835) and its square */
+    double stop2, eps2;          /* psi_norm_stop^2 (:24, :872); DVO_SOPHUS_EPS^2 */
+    double ke[12];               /* se3_exp_q, theta < 0.01: sin(x)/x {3}, cos(x) {3}, (th - sin th)/th^3 {4}, threshold, spare */
+    double kl[12];               /* se3_log_q, theta < 0.1: atan(y)/y {6}, c {5}, threshold */
+    int decay_after, decay_offset, l2_reg, pad_;
+};
+DVO_DEV void upd_const_build(UpdConst &u, const DevParams &prm) {
+    u.omb = 1.0 - prm.beta; u.beta = prm.beta;
+    u.ab = prm.step_a * prm.step_b; u.lambda = prm.reg_lambda;
+#pragma unroll
+    for (int k = 0; k < 6; k++) u.pk[k] = (k < 3) ? 1.0 : prm.precond_rot;
+    u.tr = prm.trust_radius; u.tr2 = prm.trust_radius * prm.trust_radius;
+    u.stop2 = prm.psi_norm_stop * prm.psi_norm_stop; u.eps2 = 1e-10 * 1e-10;
+    /* sin(x)/x = 1 - z/6 + z^2/120 - z^3/5040, z = x^2 <= 2.5e-5 (z^4/9! < 1e-24) */
+    u.ke[0] = -1.0 / 5040.0; u.ke[1] = 1.0 / 120.0; u.ke[2] = -1.0 / 6.0;
+    /* cos(x) = 1 - z/2 + z^2/24 - z^3/720 + z^4/40320 */
+    u.ke[3] = 1.0 / 40320.0; u.ke[4] = -1.0 / 720.0; u.ke[5] = 1.0 / 24.0;
+    /* (th - sin th)/th^3 = 1/6 - th^2/120 + th^4/5040 - th^6/362880 (th^8/11! < 3e-24) */
+    u.ke[6] = -1.0 / 362880.0; u.ke[7] = 1.0 / 5040.0; u.ke[8] = -1.0 / 120.0; u.ke[9] = 1.0 / 6.0;
+    u.ke[10] = 1e-4; u.ke[11] = 0.0;
+    /* atan(y)/y = 1 - y^2/3 + ... + y^12/13, y^2 < 2.5e-3 (y^14/15 < 1e-19) */
+    u.kl[0] = 1.0 / 13.0; u.kl[1] = -1.0 / 11.0; u.kl[2] = 1.0 / 9.0; u.kl[3] = -1.0 / 7.0; u.kl[4] = 1.0 / 5.0; u.kl[5] = -1.0 / 3.0;
+    /* c = (1 - (th/2) cot(th/2)) / th^2 = 1/12 + th^2/720 + th^4/30240 + th^6/1209600 + th^8/47900160 */
+    u.kl[6] = 1.0 / 47900160.0; u.kl[7] = 1.0 / 1209600.0; u.kl[8] = 1.0 / 30240.0; u.kl[9] = 1.0 / 720.0; u.kl[10] = 1.0 / 12.0;
+    u.kl[11] = 2.5e-3;
+    u.decay_after = prm.step_decay_after; u.decay_offset = prm.step_decay_offset;
+    u.l2_reg = prm.enable_l2_reg; u.pad_ = 0;
 }
 
 #define DVO_SOPHUS_EPS 1e-10
@@ -463,53 +532,103 @@ DVO_DEV void quat_to_matrix(const double *q, double *R) {
  * re-orthogonalisation of :919 -- for unit quaternions the orthogonal polar
  * factor of the product matrix is the matrix of the normalised product. */
 DVO_DEV void quat_mul_normalize(const double *a, const double *b, double *o) {
-    const double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
-    const double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
-    const double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
-    const double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
-    const double rn = d_rcp(d_sqrt(fma(z, z, fma(y, y, fma(x, x, w * w)))));
+    /* one multiply and three fused multiply-adds per component (round 5: the update is one wave's serial instruction stream;
+     * written out with -ffp-contract=off these were 28 instructions) */
+    const double w = fma(-a[3], b[3], fma(-a[2], b[2], fma(-a[1], b[1], a[0] * b[0])));
+    const double x = fma(-a[3], b[2], fma(a[2], b[3], fma(a[1], b[0], a[0] * b[1])));
+    const double y = fma(a[3], b[1], fma(a[2], b[0], fma(-a[1], b[3], a[0] * b[2])));
+    const double z = fma(a[3], b[0], fma(-a[2], b[1], fma(a[1], b[2], a[0] * b[3])));
+    const double n2 = fma(z, z, fma(y, y, fma(x, x, w * w)));
+    /* both factors are unit quaternions up to rounding, so |n2 - 1| ~ 1e-15; anything else (a caller that bypassed
+     * pose_state_load) takes the full form */
+    const double rn = (fabs(n2 - 1.0) < DVO_K(1e-8)) ? unit_rnorm(n2) : d_rsqrt(n2);
     o[0] = w * rn; o[1] = x * rn; o[2] = y * rn; o[3] = z * rn;
 }
 
 /* SE(3) logarithm of (unit quaternion q, translation t); tangent order
  * [upsilon(3), omega(3)] like Sophus::SE3d::log (atan form of SO3::logAndTheta).
  * tan(theta/2) = |q.vec| / q.w for a unit quaternion, so no sin/cos is needed. */
-DVO_DEV void se3_log_q(const double *q, const double *t, double *psi) {
+DVO_DEV void se3_log_q(const UpdConst &u, const double *q, const double *t, double *psi) {
     const double squared_n = fma(q[3], q[3], fma(q[2], q[2], q[1] * q[1]));
-    const double n = d_sqrt(squared_n);
     const double w = q[0];
-    double k2;                               /* 2*atan(n/w)/n */
-    if (n < DVO_SOPHUS_EPS) {
+    double k2, c;                            /* k2 = 2*atan(n/w)/n ;  c = (1 - theta/(2 tan(theta/2))) / theta^2 */
+    if (w > 0.5 && squared_n < u.kl[11] * (w * w)) {
+        /* the usual case (round 5): a rotation below ~0.1 rad (down to none: Sophus' own small-angle forms, 2/w - 2 n^2/w^3 and
+         * c = 1/12, are the same doubles as these series below n = 1e-10).  With y = n/w = tan(theta/2), y^2 < 2.5e-3:
+         * atan(y)/n = P(y^2)/w with P the arctangent series (through y^12/13), so neither n = sqrt(n^2) nor 1/n is needed;
+         * theta^2 = k2^2 n^2, and c from its own series (th^2 < 0.01: the term after th^8 is 1e-13 of c, and c multiplies a term
+         * th^2 times smaller than psi) -- which also avoids the cancellation of the closed form.  ~40 instructions where the
+         * general form below takes ~130. */
         const double rw = d_rcp(w);
-        k2 = 2.0 * rw - 2.0 * squared_n * (rw * rw * rw);
-    } else if (fabs(w) < DVO_SOPHUS_EPS) {
-        k2 = (w > 0.0) ? d_div(M_PI, n) : -d_div(M_PI, n);
+        const double y2 = squared_n * (rw * rw);
+        double P = u.kl[0];
+        P = fma(P, y2, u.kl[1]);
+        P = fma(P, y2, u.kl[2]);
+        P = fma(P, y2, u.kl[3]);
+        P = fma(P, y2, u.kl[4]);
+        P = fma(P, y2, u.kl[5]);
+        P = fma(P, y2, 1.0);
+        k2 = (2.0 * rw) * P;
+        const double th2 = (k2 * k2) * squared_n;
+        c = u.kl[6];
+        c = fma(c, th2, u.kl[7]);
+        c = fma(c, th2, u.kl[8]);
+        c = fma(c, th2, u.kl[9]);
+        c = fma(c, th2, u.kl[10]);
     } else {
-        k2 = 2.0 * d_atan(n * d_rcp(w)) * d_rcp(n);
+        const double n = d_sqrt(squared_n);
+        if (n < DVO_K(DVO_SOPHUS_EPS)) {
+            const double rw = d_rcp(w);
+            k2 = 2.0 * rw - 2.0 * squared_n * (rw * rw * rw);
+        } else if (fabs(w) < DVO_K(DVO_SOPHUS_EPS)) {
+            k2 = (w > 0.0) ? d_div(DVO_K(M_PI), n) : -d_div(DVO_K(M_PI), n);
+        } else {
+            k2 = 2.0 * d_atan(n * d_rcp(w)) * d_rcp(n);
+        }
+        const double theta = k2 * n;
+        if (fabs(theta) < DVO_K(DVO_SOPHUS_EPS)) c = DVO_K(1. / 12.);
+        else c = (1.0 - 0.5 * theta * w * d_rcp(n)) * d_rcp(theta * theta);
     }
-    const double theta = k2 * n;
     const double om[3] = {k2 * q[1], k2 * q[2], k2 * q[3]};
-    double c;                                /* (1 - theta/(2 tan(theta/2))) / theta^2 */
-    if (fabs(theta) < DVO_SOPHUS_EPS) c = 1. / 12.;
-    else c = (1.0 - 0.5 * theta * w * d_rcp(n)) * d_rcp(theta * theta);
     apply_I_aW_bW2(om, -0.5, c, t, psi);     /* V^-1 t = (I - W/2 + c W^2) t */
     psi[3] = om[0]; psi[4] = om[1]; psi[5] = om[2];
 }
 
 /* SE(3) exponential, Sophus::SE3d::exp: unit quaternion from the half angle and
  * t = V upsilon with V = I + (1-cos)/th^2 W + (th-sin)/th^3 W^2. */
-DVO_DEV void se3_exp_q(const double *psi, double *q, double *t) {
+DVO_DEV void se3_exp_q(const UpdConst &u, const double *psi, double *q, double *t) {
     const double *om = psi + 3;
     const double theta_sq = fma(om[2], om[2], fma(om[1], om[1], om[0] * om[0]));
-    const double theta = d_sqrt(theta_sq);
     double imag, real, a, b;
-    const bool small_angle = theta < DVO_SOPHUS_EPS;
+    const bool small_angle = theta_sq < u.eps2;
     if (small_angle) {
         const double theta_po4 = theta_sq * theta_sq;
-        imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
-        real = 1.0 - 0.5 * theta_sq + (1.0 / 384.0) * theta_po4;
+        imag = 0.5 - DVO_K(1.0 / 48.0) * theta_sq + DVO_K(1.0 / 3840.0) * theta_po4;
+        real = 1.0 - 0.5 * theta_sq + DVO_K(1.0 / 384.0) * theta_po4;
         a = 0.0; b = 0.0;
+    } else if (theta_sq < u.ke[10]) {
+        /* the usual case (round 5): the step is clamped to the trust radius (0.003 by default, :25), so theta < 0.01.  The
+         * coefficients are short series in theta^2 (the terms left out are below 1e-17 relative): no square root, no reciprocal,
+         * no argument reduction -- and none of the closed forms' cancellation ((theta - sin theta)/theta^3 loses ten digits at
+         * theta = 0.003).  ~20 instructions where the general form below takes ~90. */
+        const double z = 0.25 * theta_sq;              /* (theta/2)^2 <= 2.5e-5 */
+        double p = u.ke[0];                            /* sin(x)/x, x = theta/2 */
+        p = fma(p, z, u.ke[1]);
+        p = fma(p, z, u.ke[2]);
+        p = fma(p, z, 1.0);
+        imag = 0.5 * p;                                /* sin(theta/2)/theta */
+        double c = u.ke[3];                            /* cos(x) */
+        c = fma(c, z, u.ke[4]);
+        c = fma(c, z, u.ke[5]);
+        c = fma(c, z, -0.5);
+        real = fma(c, z, 1.0);
+        a = (2.0 * imag) * imag;                       /* (1 - cos th)/th^2 = 2 sin^2(th/2)/th^2 */
+        b = u.ke[6];                                   /* (th - sin th)/th^3 */
+        b = fma(b, theta_sq, u.ke[7]);
+        b = fma(b, theta_sq, u.ke[8]);
+        b = fma(b, theta_sq, u.ke[9]);
     } else {
+        const double theta = d_sqrt(theta_sq);
         double sh, ch;
         d_sincos(0.5 * theta, sh, ch);
         const double rth = d_rcp(theta);
@@ -520,7 +639,8 @@ DVO_DEV void se3_exp_q(const double *psi, double *q, double *t) {
         b = (theta - 2.0 * sh * ch) * (rth2 * rth);       /* (th-sin th)/th^3 */
     }
     double qw = real, qx = imag * om[0], qy = imag * om[1], qz = imag * om[2];
-    const double rn = d_rcp(d_sqrt(fma(qz, qz, fma(qy, qy, fma(qx, qx, qw * qw)))));
+    /* {cos, sin * axis}: unit up to rounding by construction in all three branches (Sophus normalises here) */
+    const double rn = unit_rnorm(fma(qz, qz, fma(qy, qy, fma(qx, qx, qw * qw))));
     q[0] = qw * rn; q[1] = qx * rn; q[2] = qy * rn; q[3] = qz * rn;
     if (small_angle) {                                    /* Sophus: V = so3.matrix() */
         double R[9];
@@ -533,13 +653,19 @@ DVO_DEV void se3_exp_q(const double *psi, double *q, double *t) {
 
 /* matrix forms (C ABI helpers and tests) */
 DVO_DEV void se3_log(const double *R, const double *t, double *psi) {
+    DevParams none = {};
+    UpdConst u;
+    upd_const_build(u, none);              /* on the stack: folds into literals */
     double q[4];
     quat_of_matrix(R, q);
-    se3_log_q(q, t, psi);
+    se3_log_q(u, q, t, psi);
 }
 DVO_DEV void se3_exp(const double *psi, double *R, double *t) {
+    DevParams none = {};
+    UpdConst u;
+    upd_const_build(u, none);
     double q[4];
-    se3_exp_q(psi, q, t);
+    se3_exp_q(u, psi, q, t);
     quat_to_matrix(q, R);
 }
 
@@ -586,22 +712,33 @@ DVO_DEV void rotationize(double *X) {
     }
 }
 
-/* Optimiser state of one runIterations call (lives in LDS, touched by one lane).
- * The rotation cR is carried as a unit quaternion q; R is its matrix (what the
- * reference holds in cR after rotationize, :919). */
-struct PoseState {
-    double q[4], t[3];           /* cR (as quaternion), cT */
-    double R[9];                 /* matrix of q */
+/* Optimiser state of one runIterations call (lives in LDS, or in HBM between the launches of the tiled schedule).
+ * The rotation cR is carried as a unit quaternion q; R is its matrix (what the reference holds in cR after rotationize, :919).
+ *
+ * Round 5: the pose iterate {q, t, float casts} exists TWICE (p[0], p[1]).  The update of iteration itr reads `cur` and writes
+ * `nxt`; the kernels that run the update on one wave and the best-iterate bookkeeping (:689-705) on another AT THE SAME TIME
+ * (dvo_fused.hip) pass p[itr & 1] and p[(itr + 1) & 1], so the bookkeeping copies the current iterate while the next one is
+ * being written; everybody else passes p[0] for both (the update reads all it needs before its first store). */
+struct PoseCur {
+    double q[4];                 /* cR (as quaternion) */
+    double t[3], pad_;           /* cT */
+    float Rf[9], tf[3];          /* cR_32, cT_32 (:673-674) for the next evaluation */
+};
+struct __attribute__((aligned(16))) PoseState {
+    PoseCur p[2];
+    double R[9], pad0_;          /* matrix of the current q */
     double d[6];                 /* descentDirection (:654) */
-    double bq[4], bt[3];         /* best iterate (:646-647) */
+    double creg[6], creg_scale, pad1_;  /* regulariser of the CURRENT pose, precomputed (fused kernels): log(pose) and lambda/|log| */
+    double bq[4], bt[3], pad2_;  /* best iterate (:646-647) */
+    float bRf[9], btf[3];        /* cR_32, cT_32 of the best iterate (for finalEpsilons/Reprojections) */
     float bestE, bestRatio;      /* :644-645 */
     int bestItr;                 /* :648 */
     int stop;
-    float Rf[9], tf[3];          /* cR_32, cT_32 (:673-674) for the next evaluation */
-    float bRf[9], btf[3];        /* cR_32, cT_32 of the best iterate (for finalEpsilons/Reprojections) */
-    double creg[6], creg_scale;  /* regulariser of the CURRENT pose, precomputed (fused kernel): log(pose) and lambda/|log| */
-    int exact_ran, pad_;         /* packed kernel, inspection: a wave took the literal-division fallback during this level */
+    int exact_ran, pad3_[3];     /* packed kernel, inspection: a wave took the literal-division fallback during this level */
+    UpdConst u;                  /* the update's constants: built once per kernel (or once per level by iter_begin_kernel for the state
+                                    that travels through HBM between the launches of the tiled schedule) */
 };
+static_assert(sizeof(PoseCur) % 16 == 0 && sizeof(PoseState) % 16 == 0, "16-byte LDS accesses");
 
 /* state from a caller-supplied pose (kernel entry) */
 DVO_DEV void pose_state_load(PoseState &s, const double *R, const double *t) {
@@ -610,12 +747,12 @@ DVO_DEV void pose_state_load(PoseState &s, const double *R, const double *t) {
     for (int k = 0; k < 9; k++) { Rl[k] = R[k]; s.R[k] = R[k]; }
     quat_of_matrix(Rl, q);
 #pragma unroll
-    for (int k = 0; k < 4; k++) s.q[k] = q[k];
+    for (int k = 0; k < 4; k++) s.p[0].q[k] = q[k];
 #pragma unroll
-    for (int k = 0; k < 3; k++) s.t[k] = t[k];
+    for (int k = 0; k < 3; k++) s.p[0].t[k] = t[k];
 }
 
-/* start of one runIterations call (:642-657) */
+/* start of one runIterations call (:642-657); the current iterate is p[0] */
 DVO_DEV void pose_state_begin(PoseState &s) {
 #pragma unroll
     for (int k = 0; k < 6; k++) s.d[k] = 0.0;
@@ -626,156 +763,198 @@ DVO_DEV void pose_state_begin(PoseState &s) {
     s.bestItr = -1;
     s.stop = 0;
 #pragma unroll
-    for (int k = 0; k < 9; k++) s.Rf[k] = (float)s.R[k];
+    for (int k = 0; k < 9; k++) s.p[0].Rf[k] = (float)s.R[k];
 #pragma unroll
-    for (int k = 0; k < 3; k++) s.tf[k] = (float)s.t[k];
+    for (int k = 0; k < 3; k++) s.p[0].tf[k] = (float)s.p[0].t[k];
 }
 
-/* end of one runIterations call (:997-1001): pose <- best iterate */
+/* end of one runIterations call (:997-1001): pose <- best iterate (into p[0]) */
 DVO_DEV void pose_state_finish(PoseState &s) {
     double q[4], R[9];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { q[k] = s.bq[k]; s.q[k] = q[k]; }
+    for (int k = 0; k < 4; k++) { q[k] = s.bq[k]; s.p[0].q[k] = q[k]; }
     quat_to_matrix(q, R);
 #pragma unroll
     for (int k = 0; k < 9; k++) s.R[k] = R[k];
 #pragma unroll
-    for (int k = 0; k < 3; k++) s.t[k] = s.bt[k];
+    for (int k = 0; k < 3; k++) s.p[0].t[k] = s.bt[k];
 }
 
-/* Phase fence for the single-lane update: the update is written as short phases
- * that hand their results over through LDS (PoseState) or a few registers, and
- * this fence stops the compiler from hoisting the next phase's loads / keeping
- * the previous phase's values alive across it. */
+/* Phase fence for the update: it is written as short phases that hand their results over through LDS (PoseState) or a few
+ * registers, and this fence stops the compiler from hoisting the next phase's loads / keeping the previous phase's values
+ * alive across it. */
 #define DVO_PHASE_FENCE()                       \
     do {                                        \
         asm volatile("" ::: "memory");          \
         __builtin_amdgcn_sched_barrier(0);      \
     } while (0)
 
-/* Everything runIterations does after the per-point phase of iteration `itr`
- * (:689-920).  g = J^T W eps (:777), sum_eps2 = sum eps^2, n_vis visible points.
- * Returns the energy; sets s.stop on early termination. */
 /* the L2 regulariser's share that depends on the pose only (:734-743): cpsi = log(pose), returns lambda/|cpsi| (0 if the
  * pose is the identity: nothing is added then).  reg_lambda > 0, so "scale == 0" <=> "n == 0". */
-DVO_DEV double pose_regulariser_terms(const PoseState &s, const DevParams &prm, double *cpsi) {
+DVO_DEV double pose_regulariser_terms(const PoseCur &cur, const UpdConst &u, double *cpsi) {
     double q[4], t[3];
 #pragma unroll
-    for (int k = 0; k < 4; k++) q[k] = s.q[k];
+    for (int k = 0; k < 4; k++) q[k] = cur.q[k];
 #pragma unroll
-    for (int k = 0; k < 3; k++) t[k] = s.t[k];
-    se3_log_q(q, t, cpsi);
-    const double n = norm6(cpsi);
-    return (n > 0.0) ? prm.reg_lambda * d_rcp(n) : 0.0;
+    for (int k = 0; k < 3; k++) t[k] = cur.t[k];
+    se3_log_q(u, q, t, cpsi);
+    double n2 = cpsi[0] * cpsi[0];
+#pragma unroll
+    for (int k = 1; k < 6; k++) n2 = fma(cpsi[k], cpsi[k], n2);
+    return (n2 > 0.0) ? u.lambda * d_rsqrt(n2) : 0.0;
 }
-/* fused kernel: lane 0 runs this right after the barrier that releases the other waves into the next iteration */
-DVO_DEV void pose_regulariser_precompute(PoseState &s, const DevParams &prm) {
-    if (!prm.enable_l2_reg) return;
+/* fused kernels: one lane runs this right after the barrier that releases the other waves into the next iteration */
+DVO_DEV void pose_regulariser_precompute(PoseState &s, const PoseCur &cur, const UpdConst &u) {
+    if (!u.l2_reg) return;
     double cpsi[6];
-    const double sc = pose_regulariser_terms(s, prm, cpsi);
+    const double sc = pose_regulariser_terms(cur, u, cpsi);
 #pragma unroll
     for (int k = 0; k < 6; k++) s.creg[k] = cpsi[k];
     s.creg_scale = sc;
 }
 
-template <bool PRE_REG>
-#ifndef DVO_NOINLINE_UPDATE
-DVO_DEV
-#else
-/* experiment (make NOINLINE_UPDATE=1): out of line the fused kernel fits 128 VGPRs (4 waves per SIMD)
- * but the update itself takes 1.6-2x longer; measured slower at 512 threads, faster only at 1024. */
-__device__ __noinline__
-#endif
-float pose_update_t(PoseState &s, const DevParams &prm, int itr, int N,
-                            const double *g_in, double sum_eps2, int n_vis) {
-    /* ---- phase 1: energy and best-iterate bookkeeping (:689-705) ------------
-     * energy narrows to float, so it needs the correctly rounded double sqrt to
-     * match the oracle's (float)sqrt(double) bit for bit. */
+/* ---- everything runIterations does after the per-point phase of iteration `itr` (:689-920), in three pieces -------------
+ *   pose_bookkeep   energy + best-iterate bookkeeping (:689-705)              needs sum eps^2, the visible count, `cur`
+ *   pose_direction  regulariser, heavy ball, step (:724-821) -> psi           needs g = J^T W eps (:777)
+ *   pose_apply      trust region, termination, exponential map, compose (:832-919, :673-674): cur -> nxt
+ * The pieces are independent but for `cur`, which the first only reads and the last only reads before it writes `nxt`. */
+
+/* energy narrows to float, so it needs the correctly rounded double sqrt to match the oracle's (float)sqrt(double) bit for bit */
+DVO_DEV float pose_bookkeep(PoseState &s, const PoseCur &cur, int itr, int N, double sum_eps2, int n_vis) {
     const float energy = (float)sqrt(sum_eps2);                           /* :689, :1312 */
     if (energy <= s.bestE) {                                              /* :696 */
         s.bestE = energy;
         s.bestRatio = (float)n_vis / (float)N;                            /* :457 */
 #pragma unroll
-        for (int k = 0; k < 4; k++) s.bq[k] = s.q[k];
+        for (int k = 0; k < 4; k++) s.bq[k] = cur.q[k];
 #pragma unroll
-        for (int k = 0; k < 3; k++) { s.bt[k] = s.t[k]; s.btf[k] = s.tf[k]; }
+        for (int k = 0; k < 3; k++) { s.bt[k] = cur.t[k]; s.btf[k] = cur.tf[k]; }
 #pragma unroll
-        for (int k = 0; k < 9; k++) s.bRf[k] = s.Rf[k];
+        for (int k = 0; k < 9; k++) s.bRf[k] = cur.Rf[k];
         s.bestItr = itr;
-    }
-    DVO_PHASE_FENCE();
-    /* ---- phase 2: regulariser, heavy ball, step, trust region (:724-878) ---- */
-    double psi[6];
-    {
-        double g[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) g[k] = g_in[k];
-        if (prm.enable_l2_reg) {                                          /* :734-743, :796 */
-            if (PRE_REG) {                                                /* log(pose) was taken while the other waves worked */
-                const double lam_n = s.creg_scale;
-                if (lam_n != 0.0) {
-#pragma unroll
-                    for (int k = 0; k < 6; k++) g[k] = fma(lam_n, s.creg[k], g[k]);
-                }
-            } else {
-                double cpsi[6];
-                const double lam_n = pose_regulariser_terms(s, prm, cpsi);
-                if (lam_n != 0.0) {
-#pragma unroll
-                    for (int k = 0; k < 6; k++) g[k] = fma(lam_n, cpsi[k], g[k]);
-                }
-            }
-        }
-        const double step = prm.step_a * prm.step_b *
-                            ((itr > prm.step_decay_after) ? d_rcp((double)(itr - prm.step_decay_offset)) : 1.0);  /* :773 */
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const double dk = (1.0 - prm.beta) * g[k] + prm.beta * s.d[k];    /* :799 */
-            s.d[k] = dk;
-            const double pk = (k < 3) ? 1.0 : prm.precond_rot;                /* :729 */
-            psi[k] = ((-step) * pk) * dk;                                     /* :821 */
-        }
-        double nrm = norm6(psi);                                              /* :832 */
-        if (nrm > prm.trust_radius) {                                         /* :835 */
-            const double sc = prm.trust_radius * d_rcp(nrm);                  /* :837 */
-#pragma unroll
-            for (int k = 0; k < 6; k++) psi[k] *= sc;
-            nrm = prm.trust_radius;  /* |psi| after the projection; only compared with 1e-7 below */
-        }
-        if (nrm < prm.psi_norm_stop) {                                        /* :872 */
-            s.stop = 1;
-            return energy;
-        }
-    }
-    DVO_PHASE_FENCE();
-    /* ---- phase 3: exponential map (:905-907) --------------------------------- */
-    double qx[4], xT[3];
-    se3_exp_q(psi, qx, xT);
-    DVO_PHASE_FENCE();
-    /* ---- phase 4: compose, publish (:916-919, :673-674) ------------------------ */
-    {
-        double R[9], dT[3], q[4];
-#pragma unroll
-        for (int k = 0; k < 9; k++) R[k] = s.R[k];
-        m3_vec(R, xT, dT);                                                    /* cR*xTrans */
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const double tk = s.t[k] + dT[k];                                 /* :916 */
-            s.t[k] = tk; s.tf[k] = (float)tk;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) q[k] = s.q[k];
-        quat_mul_normalize(q, qx, q);                                         /* :917 + :919 */
-        quat_to_matrix(q, R);
-#pragma unroll
-        for (int k = 0; k < 4; k++) s.q[k] = q[k];
-#pragma unroll
-        for (int k = 0; k < 9; k++) { s.R[k] = R[k]; s.Rf[k] = (float)R[k]; }
     }
     return energy;
 }
-DVO_DEV float pose_update(PoseState &s, const DevParams &prm, int itr, int N, const double *g_in, double sum_eps2, int n_vis) {
-    return pose_update_t<false>(s, prm, itr, N, g_in, sum_eps2, n_vis);
+
+/* -stepLength of iteration itr (:773): a function of the iteration index only */
+DVO_DEV double pose_neg_step(const UpdConst &u, int itr) {
+    const double step = u.ab * ((itr > u.decay_after) ? d_rcp((double)(itr - u.decay_offset)) : 1.0);
+    return -step;
+}
+
+/* one lane, all six components (the host-driven / tiled kernels and the one-point-per-lane kernel) */
+template <bool PRE_REG>
+DVO_DEV void pose_direction(PoseState &s, const PoseCur &cur, const UpdConst &u, int itr, const double *g_in, double *psi) {
+    double g[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) g[k] = g_in[k];
+    if (u.l2_reg) {                                                   /* :734-743, :796 */
+        if (PRE_REG) {                                                /* log(pose) was taken while the other waves worked */
+            const double lam_n = s.creg_scale;
+            if (lam_n != 0.0) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) g[k] = fma(lam_n, s.creg[k], g[k]);
+            }
+        } else {
+            double cpsi[6];
+            const double lam_n = pose_regulariser_terms(cur, u, cpsi);
+            if (lam_n != 0.0) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) g[k] = fma(lam_n, cpsi[k], g[k]);
+            }
+        }
+    }
+    const double ns = pose_neg_step(u, itr);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const double dk = u.omb * g[k] + u.beta * s.d[k];                 /* :799 */
+        s.d[k] = dk;
+        psi[k] = (ns * u.pk[k]) * dk;                                     /* :821 */
+    }
+}
+
+/* a double of lane `lane` -> every lane (two v_readlane_b32: the value lands in scalar registers) */
+DVO_DEV double readlane_f64(double x, int lane) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+/* The same, executed by a WHOLE WAVE whose lane k < 6 holds g_k (the packed kernel hands the reduced sums over in registers):
+ * component k is worked on by lane k -- one instruction where the single-lane form has six, one LDS access for creg / d / the
+ * pre-conditioner where it has six each -- and the six results are then broadcast through scalar registers.  Needs the
+ * regulariser precomputed (creg finite; creg_scale == 0 adds an exact zero).  neg_step = pose_neg_step(u, itr), which the
+ * caller can take before the sums exist. */
+DVO_DEV void pose_direction_lanes(PoseState &s, const UpdConst &u, double neg_step, double g_lane, int lane, double *psi) {
+    const int k = (lane < 6) ? lane : 5;
+    double g = g_lane;
+    if (u.l2_reg) g = fma(s.creg_scale, s.creg[k], g);                    /* :734-743, :796 */
+    const double dk = u.omb * g + u.beta * s.d[k];                        /* :799 */
+    if (lane < 6) s.d[k] = dk;
+    const double pl = (neg_step * u.pk[k]) * dk;                          /* :821 */
+#pragma unroll
+    for (int q = 0; q < 6; q++) psi[q] = readlane_f64(pl, q);
+}
+
+/* Trust region, termination test, exponential map, composition (:832-919).  Reads cur (and s.R), writes nxt (and s.R); sets
+ * s.stop instead when the step is below the termination threshold (:872).  The norm is only ever compared, so it is compared
+ * squared; the clamp's 1/|psi| is one reciprocal square root. */
+DVO_DEV void pose_apply(PoseState &s, const PoseCur &cur, PoseCur &nxt, const UpdConst &u, double *psi) {
+    double n2 = psi[0] * psi[0];
+#pragma unroll
+    for (int k = 1; k < 6; k++) n2 = fma(psi[k], psi[k], n2);                 /* :832 */
+    const double tr2 = u.tr2;
+    if (n2 > tr2) {                                                           /* :835 */
+        const double sc = u.tr * d_rsqrt(n2);                                 /* :837 */
+#pragma unroll
+        for (int k = 0; k < 6; k++) psi[k] *= sc;
+        n2 = tr2;                       /* |psi|^2 after the projection; only compared with the threshold below (Q5) */
+    }
+    if (n2 < u.stop2) {                                                       /* :872 */
+        s.stop = 1;
+        return;
+    }
+    double qx[4], xT[3];
+    se3_exp_q(u, psi, qx, xT);                                                /* :905-907 */
+    DVO_PHASE_FENCE();
+    {   /* cT += cR*xTrans (:916), with the OLD cR */
+        double R[9], dT[3];
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = s.R[k];
+        m3_vec(R, xT, dT);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double tk = cur.t[k] + dT[k];
+            nxt.t[k] = tk; nxt.tf[k] = (float)tk;
+        }
+    }
+    DVO_PHASE_FENCE();
+    {   /* cR *= xRot; rotationize (:917, :919); casts (:673) */
+        double q[4], R[9];
+#pragma unroll
+        for (int k = 0; k < 4; k++) q[k] = cur.q[k];
+        quat_mul_normalize(q, qx, q);
+        quat_to_matrix(q, R);
+#pragma unroll
+        for (int k = 0; k < 4; k++) nxt.q[k] = q[k];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { s.R[k] = R[k]; nxt.Rf[k] = (float)R[k]; }
+    }
+}
+
+/* the three pieces in a row on one lane, in place (p[0] is both the iterate read and the iterate written) */
+template <bool PRE_REG>
+DVO_DEV float pose_update_t(PoseState &s, const UpdConst &u, int itr, int N,
+                            const double *g_in, double sum_eps2, int n_vis) {
+    const float energy = pose_bookkeep(s, s.p[0], itr, N, sum_eps2, n_vis);
+    DVO_PHASE_FENCE();
+    double psi[6];
+    pose_direction<PRE_REG>(s, s.p[0], u, itr, g_in, psi);
+    DVO_PHASE_FENCE();
+    pose_apply(s, s.p[0], s.p[0], u, psi);
+    return energy;
+}
+DVO_DEV float pose_update(PoseState &s, const UpdConst &u, int itr, int N, const double *g_in, double sum_eps2, int n_vis) {
+    return pose_update_t<false>(s, u, itr, N, g_in, sum_eps2, n_vis);
 }
 
 }  // namespace dvo

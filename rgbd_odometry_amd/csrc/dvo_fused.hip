@@ -561,10 +561,11 @@ DVO_DEV void final_outputs2(const IterConst &c, const TexSrc &ts, const LdsPoint
     }
 }
 
-/* fixed-shape reduction of the 7 double sums + the visible count over the workgroup: tot[0..5] g, [6] sum eps^2,
- * [7] visible points (valid after the trailing barrier) */
-template <int BLOCK>
-DVO_DEV void block_reduce7(const Acc7 &a, double (*red)[8], double *tot) {
+/* Fixed-shape reduction of the 7 double sums + the visible count, first half: every wave leaves its eight totals in
+ * red[wave][0..5] g, [6] sum eps^2, [7] visible points.  After the workgroup barrier lane k < 8 of the waves that go on (wave 0:
+ * the update; wave 1: the bookkeeping) adds the waves' rows in wave order into a register (block_sum8) -- round 5: no second
+ * pass through LDS, no second barrier. */
+DVO_DEV void wave_sums7(const Acc7 &a, double (*red)[8]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double d[8];
 #pragma unroll
@@ -582,14 +583,16 @@ DVO_DEV void block_reduce7(const Acc7 &a, double (*red)[8], double *tot) {
     if ((lane & 7) == 0 && idx < 7) red[wave][idx] = d[0];
     if (lane == 1) red[wave][7] = (double)a.nvis;
 #endif
-    __syncthreads();
-    if (threadIdx.x < 8) {
-        double s = 0.0;
+}
+template <int BLOCK>
+DVO_DEV double block_sum8(const double (*red)[8], int k /* 0..7 */) {
+    double v[BLOCK / 64];
 #pragma unroll
-        for (int w = 0; w < BLOCK / 64; w++) s += red[w][threadIdx.x];
-        tot[threadIdx.x] = s;
-    }
-    __syncthreads();
+    for (int w = 0; w < BLOCK / 64; w++) v[w] = red[w][k];      /* all reads in flight before the first addition */
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; w++) s += v[w];
+    return s;
 }
 
 /* ---- teams: G workgroups share ONE frame pair (small batches) ------------------------------------------------------
@@ -610,64 +613,79 @@ DVO_DEV void block_reduce7(const Acc7 &a, double (*red)[8], double *tot) {
  * per location across the XCDs' L2s).  Agent-scope release / acquire FENCES are what must be avoided here: on gfx950 they
  * are buffer_wbl2 / buffer_inv of the whole L2, per poll (measured: batch 32 ran 2x slower than without teams, and the
  * other workgroups' texels were thrown out of the L2).  The wave polls all G*8 records at once (lane m*8+k reads record k
- * of member m) until every tag matches, parks the values in LDS, and lane 0 adds them in member order. */
+ * of member m) until every tag matches (team_exchange below). */
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 /* record = {value lo32, tag, value hi32, tag}: each 8-byte half carries the tag, so the record is consistent even if the
  * 16-byte store were performed as two 8-byte pieces */
 DVO_DEV void team_store_rec(v4u *p, v4u r) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(r) : "memory"); }
-DVO_DEV v4u team_load_rec(const v4u *p) {
-    v4u r;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
-    return r;
+/* One poll round: the loads of all the lane's records issued together, then ONE wait -- inside one asm statement, so that the
+ * compiler never sees (and never copies) a register whose load is still in flight.  Teams of up to 8 members need one record per
+ * lane; larger ones poll four (addresses of records beyond the team's are clamped by the caller). */
+DVO_DEV void team_poll1(v4u &r0, const v4u *p0) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r0) : "v"(p0) : "memory");
 }
-DVO_DEV void team_exchange(double *tot, v4u *buf /* this pair's [2][DVO_TEAM_MAX][8] records */, double (*stage)[8] /* LDS [DVO_TEAM_MAX][8] */,
-                           int member, int G, unsigned epoch, int *err, bool publish = true) {
+DVO_DEV void team_poll4(v4u (&r)[4], const v4u *p0, const v4u *p1, const v4u *p2, const v4u *p3) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+}
+DVO_DEV double team_rec_value(const v4u &r) { return __longlong_as_double((long long)(((unsigned long long)r.z << 32) | r.x)); }
+/* One exchange, executed by wave 0 of every member (round 5: everything in registers, lane-parallel).  In: lane k < 8 holds this
+ * member's sum k.  Out: EVERY lane L holds the team total of sum L & 7.  Lane m*8 + k polls record k of member m (lanes L + 64 q
+ * for teams of more than 8), all loads of a round in flight together; once every tag matches, a lane adds its up to four records
+ * in order and three lane-permute steps (8, 16, 32) add the members that share L & 7 -- the same fixed order on every member, so
+ * identical bits on all of them.  (Rounds 2-4 parked the G x 8 values in LDS and lane 0 added them one by one: 8 x G dependent
+ * additions and as many LDS reads in the serial chain of every iteration.) */
+DVO_DEV double team_exchange(double mine, v4u *buf /* this pair's [2][DVO_TEAM_MAX][8] records */,
+                             int member, int G, unsigned epoch, int *err, bool publish = true) {
     const int lane = threadIdx.x & 63;
     v4u *base = buf + (size_t)(epoch & 1u) * DVO_TEAM_MAX * 8;
     const unsigned tag = epoch + 1u;
     if (lane < 8 && publish) {
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(tot[lane]);
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
         v4u rec;
         rec.x = (unsigned)bits; rec.y = tag; rec.z = (unsigned)(bits >> 32); rec.w = tag;
         team_store_rec(base + member * 8 + lane, rec);
     }
     const int n_rec = G * 8;                       /* <= 256: lane L polls records L, L + 64, L + 128, L + 192 */
+    const bool big = n_rec > 64;                   /* wave-uniform */
     v4u r[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) r[q] = v4u{0u, 0u, 0u, 0u};
     int spins = 0;
-    /* a member of this launch already gave up (not co-resident): the results are void and reported as such by every output
-     * getter -- do not spin seconds again at each of the remaining exchanges */
-    const bool dead = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    for (; !dead;) {
-        bool ok = true;
+    for (;;) {
+        bool ok;
+        if (!big) {
+            team_poll1(r[0], base + ((lane < n_rec) ? lane : 0));
+            ok = (lane >= n_rec) || ((r[0].y == tag) && (r[0].w == tag));
+        } else {
+            team_poll4(r, base + lane, base + ((lane + 64 < n_rec) ? lane + 64 : 0), base + ((lane + 128 < n_rec) ? lane + 128 : 0),
+                       base + ((lane + 192 < n_rec) ? lane + 192 : 0));
+            ok = true;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (lane + 64 * q < n_rec) {
-                r[q] = team_load_rec(base + lane + 64 * q);
-                ok = ok && (r[q].y == tag) && (r[q].w == tag);
-            }
+            for (int q = 0; q < 4; q++) ok = ok && ((lane + 64 * q >= n_rec) || ((r[q].y == tag) && (r[q].w == tag)));
         }
         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-        if (++spins > (1 << 21)) { if (lane == 0) *err = 1; break; }       /* seconds: a member is not resident -- report, do not hang */
+        /* A member of this launch already gave up (not co-resident): the results are void and reported as such by every output
+         * getter -- do not spin seconds again at each of the remaining exchanges.  Looked at only after 64 fruitless polls (~50
+         * us): rounds 2-4 loaded the flag first and WAITED for it before publishing, one memory round trip in the serial chain
+         * of every iteration. */
+        ++spins;
+        if ((spins & 63) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        if (spins > (1 << 21)) { if (lane == 0) *err = 1; break; }       /* seconds: a member is not resident -- report, do not hang */
         __builtin_amdgcn_s_sleep(1);
     }
+    double v;
+    if (!big) {
+        v = (lane < n_rec) ? team_rec_value(r[0]) : 0.0;
+    } else {
+        v = 0.0;
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-        if (lane + 64 * q < n_rec)
-            stage[(lane >> 3) + 8 * q][lane & 7] = __longlong_as_double((long long)(((unsigned long long)r[q].z << 32) | r[q].x));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      /* same wave: the LDS writes are done */
-    if (lane == 0) {
-        double s[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) s[k] = 0.0;
-        for (int m = 0; m < G; m++) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) s[k] += stage[m][k];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) tot[k] = s[k];
+        for (int q = 0; q < 4; q++) v += (lane + 64 * q < n_rec) ? team_rec_value(r[q]) : 0.0;
     }
+    v += dpp_xor_row<8>(v);
+    v = xor16_sum(v);
+    return xor32_sum(v);
 }
 
 /* DVO_STAMPS: diagnostic build only (make STAMPS=1 -> libdvo_amd_stamps.so): lane 0 of wave 0 accumulates s_memtime
@@ -683,9 +701,13 @@ DVO_DEV unsigned long long stamp_now2() {
 }
 #define DVO_STAMP(var) const unsigned long long var = stamp_now2()
 #define DVO_STAMP_ADD(slot, a, b) do { if (tid == 0 && out.dbg) out.dbg[(size_t)pair * 64 + l * 8 + (slot)] += (b) - (a); } while (0)
+#define DVO_STAMP_T2_DECL() unsigned long long t2 = 0
+#define DVO_STAMP_T2() do { t2 = stamp_now2(); } while (0)
 #else
 #define DVO_STAMP(var) do {} while (0)
 #define DVO_STAMP_ADD(slot, a, b) do {} while (0)
+#define DVO_STAMP_T2_DECL() do {} while (0)
+#define DVO_STAMP_T2() do {} while (0)
 #endif
 
 template <int BLOCK, bool TEAM>
@@ -717,13 +739,14 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
     unsigned epoch = 0;                          /* exchanges done so far (team mode) */
     /* static LDS as ONE block of known size, so that the dynamic part -- which starts with the palette of the compact now
      * form -- begins at a compile-time LDS address (kStatic; verified below): palette look-ups then need no address add */
+    static_assert(BLOCK >= 128, "wave 0 runs the update, wave 1 the bookkeeping");
     constexpr unsigned kPose = (unsigned)((sizeof(PoseState) + 15) & ~15u);
-    constexpr unsigned kStatic = kPose + (BLOCK / 64) * 64 + 64 + (TEAM ? DVO_TEAM_MAX : 1) * 64;
+    constexpr unsigned kStatic = kPose + (BLOCK / 64) * 64 + 64;
     __shared__ __attribute__((aligned(16))) char s_static[kStatic];
     PoseState &st = *reinterpret_cast<PoseState *>(s_static);
     double (*const red)[8] = reinterpret_cast<double (*)[8]>(s_static + kPose);
-    double *const tot = reinterpret_cast<double *>(s_static + kPose + (BLOCK / 64) * 64);
-    double (*const team_stage)[8] = reinterpret_cast<double (*)[8]>(s_static + kPose + (BLOCK / 64) * 64 + 64);
+    double *const tot = reinterpret_cast<double *>(s_static + kPose + (BLOCK / 64) * 64);      /* team mode: [6], [7] = the team's sum eps^2, visible count */
+    UpdConst &uc = st.u;                                         /* the update's constants (dvo_device_math.h) */
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];   /* sc.lds_bytes: per level [palette |] points [| the now level, when it fits] */
     const bool pal_base_ok = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds_dyn == kStatic;
 
@@ -739,6 +762,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
 #pragma unroll
         for (int k = 0; k < 3; k++) t0[k] = ident ? 0.0 : p[9 + k];
         pose_state_load(st, R0, t0);
+        upd_const_build(uc, prm);
     }
     __syncthreads();
 
@@ -765,7 +789,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
 
         if (member == 0)
             for (int i = tid; i < iters; i += BLOCK) energy[i] = 0.0f;      /* :634 */
-        if (tid == 0) { pose_state_begin(st); pose_regulariser_precompute(st, prm); }   /* :642-657 */
+        if (tid == 0) { pose_state_begin(st); pose_regulariser_precompute(st, st.p[0], uc); }   /* :642-657 */
 
         /* ---- what lives in LDS for this level (wave-uniform decisions) --------------------------------------------
          * Always the compact point list (the reference deep-copies the 3xN list every iteration, :670; here HBM sees it once
@@ -874,10 +898,14 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
                 else __builtin_amdgcn_s_setprio(0);
             }
 #endif
+            /* the iterate this iteration evaluates, and the one its update writes (PoseState: the bookkeeping of this iterate
+             * runs beside the update) */
+            const PoseCur &pc = st.p[itr & 1];
+            PoseCur &pn = st.p[(itr + 1) & 1];
 #pragma unroll
-            for (int k = 0; k < 9; k++) c.r[k] = uniform_f(st.Rf[k]);        /* :673 */
+            for (int k = 0; k < 9; k++) c.r[k] = uniform_f(pc.Rf[k]);        /* :673 */
 #pragma unroll
-            for (int k = 0; k < 3; k++) c.t[k] = uniform_f(st.tf[k]);        /* :674 */
+            for (int k = 0; k < 3; k++) c.t[k] = uniform_f(pc.tf[k]);        /* :674 */
 
             DVO_STAMP(t0);
             Acc7 a;
@@ -923,19 +951,42 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
                 if ((tid & 63) == 0) st.exact_ran = 1;          /* inspection: dvo_get_level_texel_mode reports it (tests) */
             }
             DVO_STAMP(t1);
-            block_reduce7<BLOCK>(a, red, tot);
-            DVO_STAMP(t2);
-            if (TEAM && tid < 64) {    /* wave 0: the sums of the other members; identical bits on every member */
-                v4u *tb = reinterpret_cast<v4u *>(out.team_buf);
-                if (super_team) {
-                    team_exchange(tot, tb + (size_t)xcd * 2 * DVO_TEAM_MAX * 8, team_stage, local, G >> 3, epoch, out.team_err);
-                    team_exchange(tot, tb + (size_t)8 * 2 * DVO_TEAM_MAX * 8, team_stage, xcd, 8, epoch, out.team_err, local == 0);
-                } else {
-                    team_exchange(tot, tb + (size_t)pair_local * 2 * DVO_TEAM_MAX * 8, team_stage, member, G, epoch, out.team_err);
+            DVO_STAMP_T2_DECL();
+            /* ---- the serial part of the iteration (round 5) -----------------------------------------------------------------
+             * Every wave leaves its eight totals in LDS; after ONE barrier wave 0 adds them (lane k: sum k) and runs the update
+             * from those registers -- in team mode after exchanging them with the other members, also in registers -- while wave
+             * 1 does the energy and the best-iterate bookkeeping (:689-705) of the SAME iterate: the two read the iterate `pc`,
+             * the update writes `pn`.  (Rounds 1-4: a second pass through LDS and a second barrier for the totals, then one
+             * lane doing bookkeeping, update and all LDS traffic in a row.) */
+            wave_sums7(a, red);
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+            double neg_step = 0.0;
+            if (wave == 0) neg_step = pose_neg_step(uc, itr);        /* :773: needs the iteration index only -- taken while the other waves arrive */
+            __syncthreads();
+            double sl = 0.0;
+            if (wave == 0) {
+                sl = block_sum8<BLOCK>(red, lane & 7);
+                DVO_STAMP_T2();
+                if (TEAM) {    /* the sums of the other members; identical bits on every member */
+                    v4u *tb = reinterpret_cast<v4u *>(out.team_buf);
+                    if (super_team) {
+                        sl = team_exchange(sl, tb + (size_t)xcd * 2 * DVO_TEAM_MAX * 8, local, G >> 3, epoch, out.team_err);
+                        sl = team_exchange(sl, tb + (size_t)8 * 2 * DVO_TEAM_MAX * 8, xcd, 8, epoch, out.team_err, local == 0);
+                    } else {
+                        sl = team_exchange(sl, tb + (size_t)pair_local * 2 * DVO_TEAM_MAX * 8, member, G, epoch, out.team_err);
+                    }
+                    if (lane == 6 || lane == 7) tot[lane] = sl;            /* for the bookkeeping wave */
                 }
             }
-            if (tid == 0) {
-                const float e = pose_update_t<true>(st, prm, itr, Nall, &tot[0], tot[6], (int)tot[7]);
+            if (TEAM) __syncthreads();
+            if (wave == 0) {
+                double psi[6];
+                pose_direction_lanes(st, uc, neg_step, sl, lane, psi);
+                if (lane == 0) pose_apply(st, pc, pn, uc, psi);
+            } else if (wave == 1 && lane == 0) {
+                const double e2 = TEAM ? tot[6] : block_sum8<BLOCK>(red, 6);
+                const double nv = TEAM ? tot[7] : block_sum8<BLOCK>(red, 7);
+                const float e = pose_bookkeep(st, pc, itr, Nall, e2, (int)nv);
                 if (member == 0) energy[itr] = e;                            /* :690 */
             }
             epoch++;
@@ -947,7 +998,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             if (st.stop) break;                                              /* :877 */
             /* log(new pose) for the next iteration's regulariser: lane 0 takes it now, while the other waves are
              * already in their point phase */
-            if (tid == 0 && itr + 1 < iters) pose_regulariser_precompute(st, prm);
+            if (tid == 0 && itr + 1 < iters) pose_regulariser_precompute(st, pn, uc);
         }
 
         /* finalEpsilons / finalReprojections = those of the best iterate (:703-704, :1002-1003); recomputed once from
@@ -1000,7 +1051,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
 #pragma unroll
         for (int k = 0; k < 9; k++) p[k] = st.R[k];
 #pragma unroll
-        for (int k = 0; k < 3; k++) p[9 + k] = st.t[k];
+        for (int k = 0; k < 3; k++) p[9 + k] = st.p[0].t[k];
     }
 }
 
@@ -1057,8 +1108,8 @@ static hipError_t launch_fused2_b(const LevelSet &lv, const Schedule &sc, const 
 }
 
 /* static LDS of align_fused2_kernel<BLOCK> (the host sizes the dynamic part against the CU's 160 KiB) */
-size_t fused2_static_lds(int block_threads) {      /* 256 threads never run in team mode: one exchange row instead of DVO_TEAM_MAX */
-    return ((sizeof(PoseState) + 15) & ~(size_t)15) + (size_t)(block_threads / 64) * 64 + 64 + (block_threads == 256 ? 1 : DVO_TEAM_MAX) * 64 + 16;
+size_t fused2_static_lds(int block_threads) {
+    return ((sizeof(PoseState) + 15) & ~(size_t)15) + (size_t)(block_threads / 64) * 64 + 64 + 16;
 }
 
 hipError_t launch_align_fused2(int block_threads, const LevelSet &lv, const Schedule &sc, const Intrinsics &K,

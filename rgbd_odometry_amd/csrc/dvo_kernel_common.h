@@ -113,7 +113,7 @@ DVO_DEV void wave_reduce_scatter(T (&v)[NV]) {
 /* The same reduce-scatter for exactly 8 doubles with the NEAR lane exchanges done by DPP (data-parallel-primitive operand
  * modifiers: a register move with a lane permutation, a few cycles) instead of ds_bpermute (a round trip through the LDS
  * crossbar, ~100 cycles each, twenty of them in a row in wave_reduce_scatter<double, 8>): bits 1, 2, 4 scatter the 8 values
- * (4 + 2 + 1 doubles exchanged), bit 8 folds by DPP too, only bits 16 and 32 go through the crossbar (one double each).
+ * (4 + 2 + 1 doubles exchanged), bit 8 folds by DPP too, bits 16 and 32 by lane-permute swaps (xor16_sum, xor32_sum).
  * On return lane L holds, in v[0], the wave total of value index  4*(L&1) + 2*((L>>1)&1) + ((L>>2)&1).  Fixed shape:
  * deterministic. */
 #define DVO_DPP_QUAD_XOR1 0xB1      /* quad_perm [1,0,3,2] */
@@ -140,6 +140,25 @@ DVO_DEV double dpp_xor_row(double x) {
     hi = __builtin_amdgcn_update_dpp(hi, (int)(b >> 32), DVO_DPP_ROW_SHR(N), 0xF, HIGH, false);
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
+/* x[L] + x[L ^ 16] and x[L] + x[L ^ 32] in every lane, through gfx950's v_permlane16_swap / v_permlane32_swap (register moves
+ * between the rows of 16 lanes / the halves of the wave) instead of ds_bpermute (round 5: the two crossbar round trips per
+ * double were ~200 cycles of every wave's reduction).  swap(a, a) leaves the even rows' (low half's) values in both rows of a
+ * pair in the first result and the odd rows' (high half's) in the second: their sum is the pairwise sum, the same bits in both
+ * partners. */
+DVO_DEV double xor16_sum(double x) {
+    const long long b = __double_as_longlong(x);
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])) +
+           __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+}
+DVO_DEV double xor32_sum(double x) {
+    const long long b = __double_as_longlong(x);
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])) +
+           __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+}
 DVO_DEV void wave_reduce_scatter8_dpp(double (&v)[8]) {
     const int lane = threadIdx.x & 63;
     {   /* bit 1: 8 -> 4 values */
@@ -164,8 +183,8 @@ DVO_DEV void wave_reduce_scatter8_dpp(double (&v)[8]) {
         v[0] = keep + dpp_xor_row<4>(send);
     }
     v[0] += dpp_xor_row<8>(v[0]);
-    v[0] += __shfl_xor(v[0], 16, 64);
-    v[0] += __shfl_xor(v[0], 32, 64);
+    v[0] = xor16_sum(v[0]);
+    v[0] = xor32_sum(v[0]);
 }
 /* value index held by lane L after wave_reduce_scatter8_dpp */
 DVO_DEV int reduce_scatter8_dpp_index(int lane) { return 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1); }

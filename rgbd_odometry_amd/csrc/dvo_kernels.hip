@@ -183,13 +183,15 @@ hipError_t launch_pack_texels(const float *dt, const float *gx, const float *gy,
 /* slot p in [dst_first, dst_first+dst_count) <- copy of slot (p - dst_first) % n_src : one launch per level
  * instead of a pack + copies per pair (bench / throughput set-up, warm replicas) */
 __global__ void __launch_bounds__(256)
-replicate_level_kernel(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, unsigned *cidx, unsigned *cpt4, unsigned *chdr, int *pt4_ok,
-                       int pt_cap, int *N, int n_src, int dst_first, int dst_count) {
+replicate_level_kernel(float4 *tex, const unsigned char *__restrict__ src_has_tex, size_t tex_stride, float *pts, uint2 *cpts, unsigned *cidx,
+                       unsigned *cpt4, unsigned *chdr, int *pt4_ok, int pt_cap, int *N, int n_src, int dst_first, int dst_count) {
     const int p = dst_first + blockIdx.y;
     const int src = blockIdx.y % n_src;
     if (p == src) return;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    if (tex) {                                       /* NULL: no source holds 16-byte texels (compact form only) */
+    /* tex NULL: no source holds 16-byte texels (compact form only); otherwise per source (on a sparse slab only the destinations
+     * of sources WITH texels have memory behind theirs) */
+    if (tex && (!src_has_tex || src_has_tex[src])) {
         const float4 *st = tex + (size_t)src * tex_stride;
         float4 *dt = tex + (size_t)p * tex_stride;
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tex_stride; i += stride) dt[i] = st[i];
@@ -217,10 +219,10 @@ replicate_level_kernel(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, 
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) N[p] = n;
 }
-hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, unsigned *cidx, unsigned *cpt4, unsigned *chdr,
-                                  int *pt4_ok, int pt_cap, int *N, int n_src, int dst_first, int dst_count, hipStream_t s) {
+hipError_t launch_replicate_level(float4 *tex, const unsigned char *src_has_tex, size_t tex_stride, float *pts, uint2 *cpts, unsigned *cidx, unsigned *cpt4,
+                                  unsigned *chdr, int *pt4_ok, int pt_cap, int *N, int n_src, int dst_first, int dst_count, hipStream_t s) {
     if (dst_count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(replicate_level_kernel, dim3(64, dst_count), dim3(256), 0, s, tex, tex_stride, pts, cpts, cidx, cpt4, chdr, pt4_ok,
+    hipLaunchKernelGGL(replicate_level_kernel, dim3(64, dst_count), dim3(256), 0, s, tex, src_has_tex, tex_stride, pts, cpts, cidx, cpt4, chdr, pt4_ok,
                        pt_cap, N, n_src, dst_first, dst_count);
     return hipGetLastError();
 }
@@ -345,6 +347,7 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
 #pragma unroll
         for (int k = 0; k < 3; k++) t0[k] = ident ? 0.0 : p[9 + k];
         pose_state_load(st, R0, t0);
+        upd_const_build(st.u, prm);
     }
     __syncthreads();
 
@@ -362,7 +365,7 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
         level_consts(c, K, l, L.rows, L.cols);
 
         for (int i = tid; i < iters; i += BLOCK) energy[i] = 0.0f;          /* :634 */
-        if (tid == 0) { pose_state_begin(st); pose_regulariser_precompute(st, prm); }   /* :642-657 */
+        if (tid == 0) { pose_state_begin(st); pose_regulariser_precompute(st, st.p[0], st.u); }   /* :642-657 */
         /* The reference re-reads (in fact deep-copies, :670) the 3xN point list every
          * iteration; here the level's points are staged into LDS once and stay there
          * for all its iterations, so HBM sees them once per level. */
@@ -398,9 +401,9 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
 
         for (int itr = 0; itr < iters; ++itr) {                              /* :658 */
 #pragma unroll
-            for (int k = 0; k < 9; k++) c.r[k] = uniform_f(st.Rf[k]);        /* :673 */
+            for (int k = 0; k < 9; k++) c.r[k] = uniform_f(st.p[0].Rf[k]);        /* :673 */
 #pragma unroll
-            for (int k = 0; k < 3; k++) c.t[k] = uniform_f(st.tf[k]);        /* :674 */
+            for (int k = 0; k < 3; k++) c.t[k] = uniform_f(st.p[0].tf[k]);        /* :674 */
 
             DVO_STAMP(t0);
 #ifdef DVO_YOUNG_WAVE_PRIO
@@ -425,7 +428,7 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
                 out.H[((size_t)pair * sc.e_stride + sc.e_off[l] + itr) * 21 + tid] = tot[tid];
             DVO_STAMP(t2);
             if (tid == 0) {
-                const float e = pose_update_t<true>(st, prm, itr, N, &tot[21], tot[27], (int)tot[28]);
+                const float e = pose_update_t<true>(st, st.u, itr, N, &tot[21], tot[27], (int)tot[28]);
                 energy[itr] = e;                                             /* :690 */
             }
             DVO_STAMP(t3);
@@ -436,7 +439,7 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
             if (st.stop) break;                                              /* :877 */
             /* log(new pose) for the next iteration's regulariser: only the pose is needed, so lane 0 takes it now,
              * while the other waves are already in their point phase */
-            if (tid == 0 && itr + 1 < iters) pose_regulariser_precompute(st, prm);
+            if (tid == 0 && itr + 1 < iters) pose_regulariser_precompute(st, st.p[0], st.u);
         }
 
         /* finalEpsilons / finalReprojections = those of the best iterate (:703-704,
@@ -477,7 +480,7 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
 #pragma unroll
         for (int k = 0; k < 9; k++) p[k] = st.R[k];
 #pragma unroll
-        for (int k = 0; k < 3; k++) p[9 + k] = st.t[k];
+        for (int k = 0; k < 3; k++) p[9 + k] = st.p[0].t[k];
     }
 }
 
@@ -648,7 +651,8 @@ hipError_t launch_accumulate(const LevelSlab &L, int pair, int level, const Intr
 /* the optimiser state lives in HBM, one PoseState per pair                    */
 /* ------------------------------------------------------------------------- */
 __global__ void __launch_bounds__(64)
-iter_begin_kernel(PoseState *st, const double *Rt12, float *energy, int max_iters) {
+iter_begin_kernel(PoseState *st, DevParams prm, const double *Rt12, float *energy, int max_iters) {
+    if (threadIdx.x == 1) upd_const_build(st->u, prm);
     if (threadIdx.x == 0) {
         double R[9], t[3];
         for (int k = 0; k < 9; k++) R[k] = Rt12[k];
@@ -670,9 +674,9 @@ accumulate_state_kernel(LevelSlab L, int pair, int level, Intrinsics K, const Po
     IterConst c;
     level_consts(c, K, level, L.rows, L.cols);
 #pragma unroll
-    for (int k = 0; k < 9; k++) c.r[k] = uniform_f(st->Rf[k]);
+    for (int k = 0; k < 9; k++) c.r[k] = uniform_f(st->p[0].Rf[k]);
 #pragma unroll
-    for (int k = 0; k < 3; k++) c.t[k] = uniform_f(st->tf[k]);
+    for (int k = 0; k < 3; k++) c.t[k] = uniform_f(st->p[0].tf[k]);
     Acc a;
     acc_zero(a);
     const int per = (n + gridDim.x - 1) / gridDim.x;
@@ -693,7 +697,7 @@ iter_update_kernel(PoseState *st, DevParams prm, int itr, int n_total, const dou
     if (threadIdx.x == 0 && !st->stop) {                                    /* after :877 nothing runs */
         double g[6];
         for (int k = 0; k < 6; k++) g[k] = acc[21 + k];
-        energy[itr] = pose_update(*st, prm, itr, n_total, g, acc[27], (int)acc[28]);
+        energy[itr] = pose_update(*st, st->u, itr, n_total, g, acc[27], (int)acc[28]);
     }
 }
 
@@ -718,7 +722,7 @@ iter_reduce_update_kernel(PoseState *st, DevParams prm, int itr, int n_total,
     if (threadIdx.x == 0 && !st->stop) {
         double g[6];
         for (int q = 0; q < 6; q++) g[q] = acc[21 + q];
-        energy[itr] = pose_update(*st, prm, itr, n_total, g, acc[27], (int)acc[28]);
+        energy[itr] = pose_update(*st, st->u, itr, n_total, g, acc[27], (int)acc[28]);
     }
 }
 
@@ -774,7 +778,7 @@ tiled_step_kernel(LevelSlab L, int pair, int level, Intrinsics K, DevParams prm,
     if (tid == 0 && apply_prev && !was_stopped) {                          /* after :877 nothing runs */
         double g[6];
         for (int k = 0; k < 6; k++) g[k] = acc_in[21 + k];
-        const float e = pose_update(s, prm, itr - 1, n_total, g, acc_in[27], (int)acc_in[28]);
+        const float e = pose_update(s, s.u, itr - 1, n_total, g, acc_in[27], (int)acc_in[28]);
         if (blockIdx.x == 0) energy[itr - 1] = e;                           /* :690 */
     }
     /* DVO_FLAG_NORMAL_MATRIX: H = sum w J J^T of the previous iterate (reduced over all ranks), kept per iterate like the batch kernels do */
@@ -793,9 +797,9 @@ tiled_step_kernel(LevelSlab L, int pair, int level, Intrinsics K, DevParams prm,
         IterConst c;
         level_consts(c, K, level, L.rows, L.cols);
 #pragma unroll
-        for (int k = 0; k < 9; k++) c.r[k] = uniform_f(s.Rf[k]);
+        for (int k = 0; k < 9; k++) c.r[k] = uniform_f(s.p[0].Rf[k]);
 #pragma unroll
-        for (int k = 0; k < 3; k++) c.t[k] = uniform_f(s.tf[k]);
+        for (int k = 0; k < 3; k++) c.t[k] = uniform_f(s.p[0].tf[k]);
         const int per = (n + gridDim.x - 1) / gridDim.x;
         const int b0 = first + blockIdx.x * per;
         int b1 = b0 + per;
@@ -857,11 +861,11 @@ tiled_finish_kernel(const PoseState *st_in, PoseState *st_out, DevParams prm, co
         if (!s.stop) {
             double g[6];
             for (int k = 0; k < 6; k++) g[k] = acc_in[21 + k];
-            energy[itr_last] = pose_update(s, prm, itr_last, n_total, g, acc_in[27], (int)acc_in[28]);
+            energy[itr_last] = pose_update(s, s.u, itr_last, n_total, g, acc_in[27], (int)acc_in[28]);
         }
         pose_state_finish(s);                                               /* :997-1001 */
         for (int k = 0; k < 9; k++) Rt12[k] = s.R[k];
-        for (int k = 0; k < 3; k++) Rt12[9 + k] = s.t[k];
+        for (int k = 0; k < 3; k++) Rt12[9 + k] = s.p[0].t[k];
         *best_idx = s.bestItr;
         *ratio = s.bestRatio;
     }
@@ -902,7 +906,7 @@ iter_end_kernel(PoseState *st, double *Rt12, int *best_idx, float *ratio) {
     if (threadIdx.x == 0) {
         pose_state_finish(*st);                                             /* :997-1001 */
         for (int k = 0; k < 9; k++) Rt12[k] = st->R[k];
-        for (int k = 0; k < 3; k++) Rt12[9 + k] = st->t[k];
+        for (int k = 0; k < 3; k++) Rt12[9 + k] = st->p[0].t[k];
         *best_idx = st->bestItr;
         *ratio = st->bestRatio;
     }
@@ -944,8 +948,8 @@ hipError_t launch_final_outputs_state(const LevelSlab &L, int pair, int level, c
     return hipGetLastError();
 }
 
-hipError_t launch_iter_begin(void *state, const double *Rt12, float *energy, int max_iters, hipStream_t s) {
-    hipLaunchKernelGGL(iter_begin_kernel, dim3(1), dim3(64), 0, s, (PoseState *)state, Rt12, energy, max_iters);
+hipError_t launch_iter_begin(void *state, const DevParams &prm, const double *Rt12, float *energy, int max_iters, hipStream_t s) {
+    hipLaunchKernelGGL(iter_begin_kernel, dim3(1), dim3(64), 0, s, (PoseState *)state, prm, Rt12, energy, max_iters);
     return hipGetLastError();
 }
 hipError_t launch_iter_accumulate(const LevelSlab &L, int pair, int level, const Intrinsics &K, const void *state,

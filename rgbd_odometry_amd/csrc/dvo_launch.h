@@ -95,8 +95,9 @@ size_t palette_work_ints(int count);        /* scratch of one launch_palette_bui
 hipError_t launch_palette_build(const float4 *tex, size_t tex_stride, int rows, int cols, unsigned *p4, size_t p4_stride,
                                 float2 *pal, int *pal_n, int first_pair, int count, unsigned *work, hipStream_t s);
 bool fused_uses_compact(int points_in_flight, int interp);
-hipError_t launch_replicate_level(float4 *tex, size_t tex_stride, float *pts, uint2 *cpts, unsigned *cidx, unsigned *cpt4, unsigned *chdr,
-                                  int *pt4_ok, int pt_cap, int *N, int n_src, int dst_first, int dst_count, hipStream_t s);
+hipError_t launch_replicate_level(float4 *tex, const unsigned char *src_has_tex /* device, n_src flags, or NULL = all */, size_t tex_stride, float *pts,
+                                  uint2 *cpts, unsigned *cidx, unsigned *cpt4, unsigned *chdr, int *pt4_ok, int pt_cap, int *N, int n_src, int dst_first,
+                                  int dst_count, hipStream_t s);
 /* 4-byte twins of the compact lists of pairs [first_pair, first_pair + count): encode, decode with pt4_decode, compare with the
  * 8-byte form; pt4_ok[pair] = 1 only if every point survives */
 hipError_t launch_points4_build(const uint2 *cpts, const int *N, int pt_cap, int rows, unsigned *cpt4, unsigned *chdr, int *pt4_ok,
@@ -124,7 +125,7 @@ hipError_t launch_accumulate(const LevelSlab &L, int pair, int level, const Intr
 int accumulate_blocks_for(int n_points);
 /* host-driven iteration: optimiser state (opaque, pose_state_bytes() each) in HBM */
 size_t pose_state_bytes();
-hipError_t launch_iter_begin(void *state, const double *Rt12, float *energy, int max_iters, hipStream_t s);
+hipError_t launch_iter_begin(void *state, const DevParams &prm, const double *Rt12, float *energy, int max_iters, hipStream_t s);
 hipError_t launch_iter_accumulate(const LevelSlab &L, int pair, int level, const Intrinsics &K, const void *state,
                                   int first_point, int n_points, double *partials, int nblocks, double *acc,
                                   hipStream_t s);

@@ -1,7 +1,7 @@
 """Phase anatomy of the packed fused kernel from the stamps build (make STAMPS=1; DVO_LIB_VARIANT=_stamps).
 usage: exp_stamps2.py [B] [block] [engine_variant] [alias]"""
 import os, sys
-os.environ["DVO_LIB_VARIANT"] = "_stamps"
+os.environ["DVO_LIB_VARIANT"] = os.environ.get("DVO_STAMPS_VARIANT", "_stamps")   # e.g. _stamps_r4base for an A/B
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
 import numpy as np, torch
 from rgbd_odometry_amd import DvoContext, SynthScene
