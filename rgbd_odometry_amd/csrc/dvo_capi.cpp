@@ -634,6 +634,10 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
      * resident at once (one 512-thread workgroup per CU).  dvo_params.team_size: 0 = auto, 1 = off, k = force k. */
     sc.team = 1;
     sc.n_pairs_launch = n_pairs;
+    {   /* A/B switch: DVO_TEAM_PLAIN_STORES=off keeps every team record on the sc1 (cross-XCD) form */
+        static const bool no_plain = [] { const char *e = std::getenv("DVO_TEAM_PLAIN_STORES"); return e && std::strcmp(e, "off") == 0; }();
+        sc.team_no_plain = no_plain ? 1 : 0;
+    }
     c->team_used = false;
     if (sc.compact && c->prm.engine_variant != 1 && !(sc.flags & DVO_FLAG_NORMAL_MATRIX) && block == 512 && c->prm.team_size != 1) {
         const int slots8 = 8 * ((n_pairs + 7) / 8);

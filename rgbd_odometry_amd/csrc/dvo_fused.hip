@@ -618,6 +618,17 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 /* record = {value lo32, tag, value hi32, tag}: each 8-byte half carries the tag, so the record is consistent even if the
  * 16-byte store were performed as two 8-byte pieces */
 DVO_DEV void team_store_rec(v4u *p, v4u r) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(r) : "memory"); }
+/* A record for members that are KNOWN to sit on this workgroup's XCD (same HW_REG_XCC_ID, checked once per launch by a hand-shake
+ * over the sc1 form: align_fused2_kernel).  A plain store leaves the line in that XCD's L2, which all its CUs share, and the
+ * pollers' sc1 loads (which bypass only their L1) are served from there: 820 instead of 1260 cycles per hop between two
+ * workgroups of one XCD -- and NEVER visible to a poller on another XCD (tools/exhaustive/xcd_handoff.hip, profiles/r05_xcd_handoff/:
+ * every cross-XCD hop timed out), which is why the placement is verified, not assumed. */
+DVO_DEV void team_store_rec_same_xcd(v4u *p, v4u r) { asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(p), "v"(r) : "memory"); }
+DVO_DEV unsigned hw_xcc_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 0xfu;
+}
 /* One poll round: the loads of all the lane's records issued together, then ONE wait -- inside one asm statement, so that the
  * compiler never sees (and never copies) a register whose load is still in flight.  Teams of up to 8 members need one record per
  * lane; larger ones poll four (addresses of records beyond the team's are clamped by the caller). */
@@ -637,7 +648,7 @@ DVO_DEV double team_rec_value(const v4u &r) { return __longlong_as_double((long 
  * identical bits on all of them.  (Rounds 2-4 parked the G x 8 values in LDS and lane 0 added them one by one: 8 x G dependent
  * additions and as many LDS reads in the serial chain of every iteration.) */
 DVO_DEV double team_exchange(double mine, v4u *buf /* this pair's [2][DVO_TEAM_MAX][8] records */,
-                             int member, int G, unsigned epoch, int *err, bool publish = true) {
+                             int member, int G, unsigned epoch, int *err, bool publish = true, bool same_xcd = false) {
     const int lane = threadIdx.x & 63;
     v4u *base = buf + (size_t)(epoch & 1u) * DVO_TEAM_MAX * 8;
     const unsigned tag = epoch + 1u;
@@ -645,7 +656,8 @@ DVO_DEV double team_exchange(double mine, v4u *buf /* this pair's [2][DVO_TEAM_M
         const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
         v4u rec;
         rec.x = (unsigned)bits; rec.y = tag; rec.z = (unsigned)(bits >> 32); rec.w = tag;
-        team_store_rec(base + member * 8 + lane, rec);
+        if (same_xcd) team_store_rec_same_xcd(base + member * 8 + lane, rec);      /* wave-uniform */
+        else team_store_rec(base + member * 8 + lane, rec);
     }
     const int n_rec = G * 8;                       /* <= 256: lane L polls records L, L + 64, L + 128, L + 192 */
     const bool big = n_rec > 64;                   /* wave-uniform */
@@ -737,6 +749,26 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
     const int pair = __builtin_amdgcn_readfirstlane(first_pair + pair_local);
     const int tid = threadIdx.x;
     unsigned epoch = 0;                          /* exchanges done so far (team mode) */
+    /* Team mode, once per launch: do the members that exchange records directly (a team of up to 32, or the members of one XCD
+     * of a team over all XCDs) really share an XCD?  The placement (workgroup b on XCD b % 8) is an observation, not a contract:
+     * every member publishes its HW_REG_XCC_ID and its square through the sc1 exchange; sum x = G x and sum x^2 = G x^2 hold for
+     * one member only if they hold for all (zero variance), so the answer is the same on every member -- and from then on the
+     * records of that stage travel as plain stores through the shared L2 (team_store_rec_same_xcd). */
+    bool team_same_xcd = false;
+    if (TEAM) {
+        if (tid < 64) {
+            const double x = (double)hw_xcc_id();
+            const int k = tid & 7;
+            const double mine = (k == 0) ? x : ((k == 1) ? x * x : 0.0);
+            v4u *tb = reinterpret_cast<v4u *>(out.team_buf);
+            const int Gs = super_team ? (G >> 3) : G;
+            const double tot = team_exchange(mine, tb + (size_t)(super_team ? xcd : pair_local) * 2 * DVO_TEAM_MAX * 8, super_team ? local : member, Gs, epoch,
+                                             out.team_err);
+            const double sx = readlane_f64(tot, 0), sxx = readlane_f64(tot, 1);
+            team_same_xcd = !sc.team_no_plain && sx == (double)Gs * x && sxx == (double)Gs * (x * x);
+        }
+        epoch = 1;
+    }
     /* static LDS as ONE block of known size, so that the dynamic part -- which starts with the palette of the compact now
      * form -- begins at a compile-time LDS address (kStatic; verified below): palette look-ups then need no address add */
     static_assert(BLOCK >= 128, "wave 0 runs the update, wave 1 the bookkeeping");
@@ -970,10 +1002,10 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
                 if (TEAM) {    /* the sums of the other members; identical bits on every member */
                     v4u *tb = reinterpret_cast<v4u *>(out.team_buf);
                     if (super_team) {
-                        sl = team_exchange(sl, tb + (size_t)xcd * 2 * DVO_TEAM_MAX * 8, local, G >> 3, epoch, out.team_err);
+                        sl = team_exchange(sl, tb + (size_t)xcd * 2 * DVO_TEAM_MAX * 8, local, G >> 3, epoch, out.team_err, true, team_same_xcd);
                         sl = team_exchange(sl, tb + (size_t)8 * 2 * DVO_TEAM_MAX * 8, xcd, 8, epoch, out.team_err, local == 0);
                     } else {
-                        sl = team_exchange(sl, tb + (size_t)pair_local * 2 * DVO_TEAM_MAX * 8, member, G, epoch, out.team_err);
+                        sl = team_exchange(sl, tb + (size_t)pair_local * 2 * DVO_TEAM_MAX * 8, member, G, epoch, out.team_err, true, team_same_xcd);
                     }
                     if (lane == 6 || lane == 7) tot[lane] = sl;            /* for the bookkeeping wave */
                 }

@@ -66,6 +66,7 @@ struct Schedule {
     int no_pt4;              /* diagnostics: never read the 4-byte form of a reference list (DVO_POINTS4=off) */
     int pt4_factor;          /* 4-byte points for lists of at least this many times what the LDS holds as 8-byte points (default 3) */
     int final_blk;           /* host bookkeeping: the final outputs of this launch are stored in the compact lists' (block) order */
+    int team_no_plain;       /* diagnostics (DVO_TEAM_PLAIN_STORES=off): team records always travel as sc1 stores, even inside one XCD */
 };
 
 struct Intrinsics { float fx, fy, cx, cy; int interp; /* dvo_params.interpolate_dt, travels with the camera model to every kernel */ };

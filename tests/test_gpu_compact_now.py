@@ -222,6 +222,49 @@ def test_native_compact_refusals_fall_back_to_16_byte_texels(oracle):
             ctx.set_now_level_from_edges(0, np.zeros(rows * cols, np.uint8), rows, cols)
 
 
+def test_replicating_a_refused_source_carries_its_texels(oracle):
+    """a source whose image the compact form could not hold (pal_n <= 0) has 16-byte texels as its REAL form; replicating
+    it must copy them (and, on a sparse texel slab, map memory behind the destinations') -- beside a second source that has the
+    compact form only.  Both kinds of destination then give their source's oracle results.  (tests/test_gpu_capacity.py runs this
+    file again with DVO_TEX_SLAB=sparse.)"""
+    from rgbd_odometry_amd import DvoContext
+    rows, cols = 40, 700
+    far = np.zeros(rows * cols, np.uint8)                       # refused: pixels 512 or more from every edge (-7)
+    far[5 + 3 * rows] = 255
+    far[7 + 20 * rows] = 255
+    rng = np.random.default_rng(11)
+    dense = (rng.random(rows * cols) < 0.05).astype(np.uint8) * 255      # holds a compact form
+    ref_edge = (rng.random(rows * cols) < 0.3).astype(np.int32) * 255
+    depth = rng.uniform(400, 3000, rows * cols).astype(np.float32)
+    K = (600.0, 600.0, 350.0, 20.0)
+    B = 6
+    with DvoContext(B, team_size=1) as ctx:
+        ctx.set_intrinsics(*K)
+        xyz = None
+        for p, e in enumerate((far, dense)):
+            xyz, _ = ctx.set_ref_level_from_images(0, ref_edge, depth, rows, cols, pair=p)
+            ctx.set_now_level_from_edges(0, e, rows, cols, pair=p)
+        assert ctx.now_compact_info(0, 0) == -7 and ctx.now_compact_info(1, 0) > 0
+        ctx.replicate_pairs(2)
+        assert [ctx.now_compact_info(p, 0) for p in range(B)] == [ctx.now_compact_info(p % 2, 0) for p in range(B)]
+        refs = []
+        for e in (far, dense):
+            dt, gx, gy = oracle.now_level_from_edges(e, rows, cols)
+            refs.append((dt, gx, gy, oracle.run_iterations(0, 6, xyz, dt, gx, gy, rows, cols, K, np.eye(3), np.zeros(3))))
+        for p in range(B):
+            dt, gx, gy, ref = refs[p % 2]
+            d2, g2, h2 = ctx.get_now_level(0, pair=p)
+            assert _same(d2, dt) and _same(g2, gx) and _same(h2, gy), p
+        ctx.enqueue([6], flags=3)                               # identity start + final outputs: all pairs in one launch
+        ctx.synchronize()
+        for p in range(B):
+            e, b, ratio = ctx.level_report(p, 0, 6)
+            ref = refs[p % 2][3]
+            assert _same(e, ref["energy"]) and b == ref["best_idx"], p
+            mode = ctx.level_texel_mode(p, 0) & 3
+            assert (mode == 2) if p % 2 else (mode in (0, 1)), (p, mode)      # the compact form / the 16-byte texels
+
+
 def test_compact_now_is_built_for_a_level_that_keeps_being_aligned(oracle):
     """policy (DVO_COMPACT_NOW_AFTER = 16 in dvo_amd.h): a now level keeps the 16-byte form for its first 16 alignments, the
     17th builds the compact form; writing the level again makes it stale (and the results follow the new image)"""
