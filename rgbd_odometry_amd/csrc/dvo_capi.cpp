@@ -515,7 +515,9 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         for (int p = first_pair; p < first_pair + n_pairs && sc.compact; p++)
             if (c->lv[l].compact_ok.empty() || !c->lv[l].compact_ok[sc.alias_mod > 0 ? p % sc.alias_mod : p]) sc.compact = 0;
     }
-    const bool packed = sc.compact && c->prm.engine_variant != 1 && !(sc.flags & DVO_FLAG_NORMAL_MATRIX);
+    /* round 5: DVO_FLAG_NORMAL_MATRIX rides on the packed kernel too (its 512-thread shape, no teams: align_fused2_kernel<512, false, true>) */
+    const bool with_h = (sc.flags & DVO_FLAG_NORMAL_MATRIX) != 0;
+    const bool packed = sc.compact && c->prm.engine_variant != 1;
     sc.no_p4 = (c->prm.engine_variant == 4 || !packed || compact_now_policy() == 2) ? 1 : 0;
     /* compact form of the now levels (dvo_palette.h): built for a level that has been aligned DVO_COMPACT_NOW_AFTER times (or
      * up front by dvo_now_prepare) -- the build costs about 4.4 alignments and saves 0.28 of one per use: a now level aligned
@@ -549,7 +551,8 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
          * LDS budget for that, and refuse the combination it has no instantiation for instead of returning unwritten memory */
         if (c->prm.interpolate_dt)
             return fail(c, DVO_ERR_INVALID, "DVO_FLAG_NORMAL_MATRIX is not available together with dvo_params.interpolate_dt");
-        block = 512;
+        /* the packed kernel carries H on both of its one-workgroup-per-pair shapes (round 5); 1024 threads have no such instantiation */
+        if (!packed || block == 1024) block = packed ? 0 : 512;
     }
     const bool block_auto = (block != 256 && block != 512 && block != 1024);
     if (block_auto) {
@@ -586,7 +589,7 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         /* the packed kernel needs its 256-register budget: 1024 threads would halve it (measured, 1920x1080x5, 256 pairs:
          * 512 threads 45.2 k aligns/s, 1024 threads 41.3 k; the one-point-per-lane kernel: 43.7 k at 1024) */
         if (packed && block_auto && block == 1024) block = 512;
-        const int static_lds = packed ? (int)fused2_static_lds(block) : (int)(sizeof(double) * (block / 64) * DVO_NACC_PAD + 256 + pose_state_bytes());
+        const int static_lds = packed ? (int)fused2_static_lds(block, with_h) : (int)(sizeof(double) * (block / 64) * DVO_NACC_PAD + 256 + pose_state_bytes());
         /* 256 threads: two workgroups share the CU's LDS -- each gets exactly half, down to the last point that fits (at the
          * request ceiling every point kept out of the per-iteration stream counts: DESIGN.md section 6) */
         const int max_dyn = ((block == 256) ? 80 * 1024 : 160 * 1024) - static_lds - 64;
@@ -676,7 +679,7 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
     }
     /* engine_variant: 0 = auto (packed two-points-per-lane kernel whenever every list is compact), 1 = always the
      * one-point-per-lane kernel of dvo_kernels.hip (A/B measurements, parity tests of both) */
-    if (sc.compact && c->prm.engine_variant != 1 && !(sc.flags & DVO_FLAG_NORMAL_MATRIX)) {
+    if (packed) {
         Outputs o = outputs_of(c);
         /* a launch of more pairs than fit the GPU at once ends when its last workgroup ends: start the pairs with the most
          * point-iterations first (longest-processing-time order), so that the stragglers are the short ones */
@@ -721,7 +724,7 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         HIPCHK(c, launch_align_fused(block, u, ls, sc, c->K, c->dprm, outputs_of(c),
                                      first_pair, n_pairs, c->stream));
     c->last_block = block; c->last_team = sc.team;
-    c->last_packed = (sc.compact && c->prm.engine_variant != 1 && !(sc.flags & DVO_FLAG_NORMAL_MATRIX)) ? 1 : 0;
+    c->last_packed = packed ? 1 : 0;
     stamp_outputs(c, sc, first_pair, n_pairs);
     c->sched = sc;
     c->have_sched = true;

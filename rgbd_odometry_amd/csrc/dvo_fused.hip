@@ -50,18 +50,37 @@ DVO_DEV unsigned long long stamp_real() {
     return t;
 }
 
-/* per-lane sums of one iteration (the sub-gradient policy of :724-920 needs g and the energy only) */
-struct Acc7 {
+/* per-lane sums of one iteration (the sub-gradient policy of :724-920 needs g and the energy only).  WITH_H (round 5,
+ * DVO_FLAG_NORMAL_MATRIX on the packed kernel): also the 21 entries of H = sum w J J^T (upper triangle, row-major; the pattern of
+ * SolvePnP.cpp:168-182) -- exact products of two floats added in double, like g. */
+template <bool WITH_H>
+struct Acc7T {
+    static constexpr bool with_h = WITH_H;
     double g[6];
     double e2;
     int nvis;          /* wave-uniform: ballots */
+    double H[WITH_H ? 21 : 1];
 };
+typedef Acc7T<false> Acc7;
 
-DVO_DEV void acc7_zero(Acc7 &a) {
+template <typename ACC>
+DVO_DEV void acc7_zero(ACC &a) {
 #pragma unroll
     for (int k = 0; k < 6; k++) a.g[k] = 0.0;
     a.e2 = 0.0;
     a.nvis = 0;
+    if constexpr (ACC::with_h) {
+#pragma unroll
+        for (int k = 0; k < 21; k++) a.H[k] = 0.0;
+    }
+}
+/* H += jw (x) J for one point: entry (i, j >= i) at i*6 - i*(i-1)/2 + (j-i) */
+template <typename ACC>
+DVO_DEV void acc_h_add(ACC &a, const double *jwd, const double *Jd) {
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i; j < 6; j++) a.H[i * 6 - (i * (i - 1)) / 2 + (j - i)] = fma(jwd[i], Jd[j], a.H[i * 6 - (i * (i - 1)) / 2 + (j - i)]);
 }
 
 /* Where a level's now-frame texels are read from (chosen per level and pair, wave-uniform):
@@ -271,23 +290,31 @@ DVO_DEV void p4_decode2(const U3 &t0, const U3 &t1, v2f &dt, v2f &gx, v2f &gy, v
 }
 
 /* (double)(float)(J_k w) * (double)eps is exact, so fma(a,b,c) == c + a*b bit for bit (:719-720, :777) */
-DVO_DEV void acc7_add(Acc7 &a, const float *jw, float eps) {
+template <typename ACC>
+DVO_DEV void acc7_add(ACC &a, const float *jw, const float *J, float eps) {
     const double e = (double)eps;
+    double jwd[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) a.g[k] = fma((double)jw[k], e, a.g[k]);
+    for (int k = 0; k < 6; k++) { jwd[k] = (double)jw[k]; a.g[k] = fma(jwd[k], e, a.g[k]); }
     a.e2 = fma(e, e, a.e2);
+    if constexpr (ACC::with_h) {
+        double Jd[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) Jd[k] = (double)J[k];
+        acc_h_add(a, jwd, Jd);
+    }
 }
 
 /* stage 2: weighted Jacobian rows + accumulation */
-template <int TEX, unsigned PAL>
-DVO_DEV void round2_compute(const IterConst &c, const Round2<TEX> &b, Acc7 &a) {
-    v2f jw[6];
+template <int TEX, unsigned PAL, typename ACC>
+DVO_DEV void round2_compute(const IterConst &c, const Round2<TEX> &b, ACC &a) {
+    v2f jw[6], J[6];
     float eps0, eps1;
     if constexpr (TEX == TEX_P4) {
         v2f dt, gx, gy, wt;
         p4_decode2<PAL>(b.t0, b.t1, dt, gx, gy, wt);        /* zeros for a lane without a visible point (sentinel) */
         eps0 = dt.x; eps1 = dt.y;
-        jacobian_weighted2p(c, b.xn, b.yn, b.zn, gx, gy, wt, jw);
+        jacobian_weighted2p(c, b.xn, b.yn, b.zn, gx, gy, wt, jw, ACC::with_h ? J : nullptr);
     } else {
         a.nvis += __popcll(__builtin_amdgcn_ballot_w64(b.vis0)) + __popcll(__builtin_amdgcn_ballot_w64(b.vis1));
         eps0 = b.vis0 ? b.t0.x : 0.0f; eps1 = b.vis1 ? b.t1.x : 0.0f;
@@ -296,23 +323,45 @@ DVO_DEV void round2_compute(const IterConst &c, const Round2<TEX> &b, Acc7 &a) {
          * supplied image may hold Inf / NaN there, and NaN * 0 is NaN; the reference skips such points, :371) */
         const float gx0 = b.vis0 ? b.t0.y : 0.0f, gx1 = b.vis1 ? b.t1.y : 0.0f;
         const float gy0 = b.vis0 ? b.t0.z : 0.0f, gy1 = b.vis1 ? b.t1.z : 0.0f;
-        jacobian_weighted2(c, b.xn, b.yn, b.zn, gx0, gx1, gy0, gy1, w0, w1, jw);
+        jacobian_weighted2(c, b.xn, b.yn, b.zn, gx0, gx1, gy0, gy1, w0, w1, jw, ACC::with_h ? J : nullptr);
     }
     const double e0 = (double)eps0, e1 = (double)eps1;
+    if constexpr (!ACC::with_h) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-        a.g[k] = fma((double)jw[k].x, e0, a.g[k]);
-        a.g[k] = fma((double)jw[k].y, e1, a.g[k]);
+        for (int k = 0; k < 6; k++) {
+            a.g[k] = fma((double)jw[k].x, e0, a.g[k]);
+            a.g[k] = fma((double)jw[k].y, e1, a.g[k]);
+        }
+        a.e2 = fma(e0, e0, a.e2);
+        a.e2 = fma(e1, e1, a.e2);
+    } else {
+        /* the other 21 of the "21 + 6" accumulators (a lane without a visible point has jw = 0 and a finite J: exact zeros).  One
+         * point after the other, with a scheduling fence between them: interleaved, the 24 widened values of both points are live
+         * at once beside the 56 accumulator registers and the loop spills */
+        {
+            double jd[6], Jd[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { jd[k] = (double)jw[k].x; Jd[k] = (double)J[k].x; a.g[k] = fma(jd[k], e0, a.g[k]); }
+            a.e2 = fma(e0, e0, a.e2);
+            acc_h_add(a, jd, Jd);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            double jd[6], Jd[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { jd[k] = (double)jw[k].y; Jd[k] = (double)J[k].y; a.g[k] = fma(jd[k], e1, a.g[k]); }
+            a.e2 = fma(e1, e1, a.e2);
+            acc_h_add(a, jd, Jd);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
-    a.e2 = fma(e0, e0, a.e2);
-    a.e2 = fma(e1, e1, a.e2);
 }
 
 /* the per-point phase of one iteration over points [first, end): rounds of 2*BLOCK points, lane `lane_off` of the
  * round takes points lane_off and BLOCK + lane_off; software-pipelined over rounds with two named buffers */
-template <int BLOCK, bool LDS_SRC, int TEX, int DEPTH = 2, unsigned PAL = 0, bool PT4 = false>
+template <int BLOCK, bool LDS_SRC, int TEX, int DEPTH = 2, unsigned PAL = 0, bool PT4 = false, typename ACC = Acc7>
 DVO_DEV void accumulate_points2(const IterConst &c, const TexSrc &ts, const LdsPoints &lp, const uint2 *__restrict__ gpts,
-                                int first, int end, int lane_off, Acc7 &a, bool &any_odd) {
+                                int first, int end, int lane_off, ACC &a, bool &any_odd) {
     if (first >= end) return;
     constexpr int STEP = 2 * BLOCK;
     /* rounds in which THIS wave still has a point (wave-uniform) */
@@ -320,7 +369,7 @@ DVO_DEV void accumulate_points2(const IterConst &c, const TexSrc &ts, const LdsP
     const int n_rounds = (end - first - wave_off + STEP - 1) / STEP;
     if (n_rounds <= 0) return;
 #define DVO_ISSUE(buf, k) round2_issue<LDS_SRC, TEX, PT4>(c, ts, lp, gpts, base + (k) * STEP, base + (k) * STEP + BLOCK, end, STEP, pf, buf, any_odd, a.nvis)
-#define DVO_COMPUTE(buf) round2_compute<TEX, PAL>(c, buf, a)
+#define DVO_COMPUTE(buf) round2_compute<TEX, PAL, ACC>(c, buf, a)
     int base = first + lane_off;
     PointPf pf;
     if constexpr (PT4) { pf.h0 = pt4_header(lp, base, end); pf.h1 = pt4_header(lp, base + BLOCK, end); }
@@ -388,9 +437,9 @@ DVO_DEV float4 p4_texel(const TexSrc &ts, const float2 *pal_lds, int yy, int xx)
 /* The same sums with the literal-division scalar code (dvo_device_math.h: project_point, jacobian_row) over THIS wave's
  * points of [first, end) -- taken only when one of them has a degenerate z.  Plain loop, not pipelined: never hot.
  * P4: the level is read through its compact form (the 16-byte texels of such a level may not exist). */
-template <int BLOCK, bool LDS_SRC, bool P4, bool PT4 = false>
+template <int BLOCK, bool LDS_SRC, bool P4, bool PT4 = false, typename ACC = Acc7>
 DVO_DEV void accumulate_points_exact(const IterConst &c, const char *__restrict__ tex, const TexSrc &ts, const float2 *pal_lds,
-                                     const LdsPoints &lp, const uint2 *__restrict__ gpts, int first, int end, int lane_off, Acc7 &a) {
+                                     const LdsPoints &lp, const uint2 *__restrict__ gpts, int first, int end, int lane_off, ACC &a) {
     for (int i = first + lane_off; __builtin_amdgcn_ballot_w64(i < end) != 0ull; i += BLOCK) {
         const bool valid = i < end;
         float X, Y, Z, xn, yn, zn, u, v;
@@ -415,7 +464,7 @@ DVO_DEV void accumulate_points_exact(const IterConst &c, const char *__restrict_
             jacobian_row(c, xn, yn, zn, t.y, t.z, J);
 #pragma unroll
             for (int q = 0; q < 6; q++) jw[q] = J[q] * t.w;
-            acc7_add(a, jw, t.x);
+            acc7_add(a, jw, J, t.x);
         }
     }
 }
@@ -565,7 +614,8 @@ DVO_DEV void final_outputs2(const IterConst &c, const TexSrc &ts, const LdsPoint
  * red[wave][0..5] g, [6] sum eps^2, [7] visible points.  After the workgroup barrier lane k < 8 of the waves that go on (wave 0:
  * the update; wave 1: the bookkeeping) adds the waves' rows in wave order into a register (block_sum8) -- round 5: no second
  * pass through LDS, no second barrier. */
-DVO_DEV void wave_sums7(const Acc7 &a, double (*red)[8]) {
+template <typename ACC>
+DVO_DEV void wave_sums7(const ACC &a, double (*red)[8]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double d[8];
 #pragma unroll
@@ -722,9 +772,13 @@ DVO_DEV unsigned long long stamp_now2() {
 #define DVO_STAMP_T2() do {} while (0)
 #endif
 
-template <int BLOCK, bool TEAM>
+/* WITH_H: DVO_FLAG_NORMAL_MATRIX on the packed kernel (round 5): every lane also accumulates the 21 entries of H = sum w J J^T in
+ * double (42 more registers: the 512-thread shape only -- the 256-thread shape has 14 to spare), the waves reduce them in three
+ * passes of the 8-value DPP reduce-scatter, and wave 2 -- idle during the update -- adds the waves' rows and stores the iterate's H */
+template <int BLOCK, bool TEAM, bool WITH_H = false>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK == 256 ? DVO_WPE256 : 1, 8)))
 align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outputs out, int first_pair) {
+    static_assert(!WITH_H || ((BLOCK == 512 || BLOCK == 256) && !TEAM), "H rides on the one-workgroup-per-pair shapes");
     /* team mode: workgroup b -> XCD b % 8; the G members of pair (q*8 + x) are the workgroups x + 8*(q*G + j) */
     /* teams beyond one XCD (one very large frame, G = 8 x g1 members, g1 of them on every XCD): member = workgroup index;
      * the sums are exchanged in two stages -- inside each XCD as above (slot `xcd` of the team buffer), then the 8 XCD sums
@@ -773,8 +827,10 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
      * form -- begins at a compile-time LDS address (kStatic; verified below): palette look-ups then need no address add */
     static_assert(BLOCK >= 128, "wave 0 runs the update, wave 1 the bookkeeping");
     constexpr unsigned kPose = (unsigned)((sizeof(PoseState) + 15) & ~15u);
-    constexpr unsigned kStatic = kPose + (BLOCK / 64) * 64 + 64;
+    constexpr unsigned kRedH = WITH_H ? (BLOCK / 64) * 24 * 8 : 0;             /* the waves' rows of H (24 doubles: 21 + padding) */
+    constexpr unsigned kStatic = kPose + (BLOCK / 64) * 64 + 64 + kRedH;
     __shared__ __attribute__((aligned(16))) char s_static[kStatic];
+    double (*const redH)[24] = reinterpret_cast<double (*)[24]>(s_static + kPose + (BLOCK / 64) * 64 + 64);
     PoseState &st = *reinterpret_cast<PoseState *>(s_static);
     double (*const red)[8] = reinterpret_cast<double (*)[8]>(s_static + kPose);
     double *const tot = reinterpret_cast<double *>(s_static + kPose + (BLOCK / 64) * 64);      /* team mode: [6], [7] = the team's sum eps^2, visible count */
@@ -940,7 +996,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             for (int k = 0; k < 3; k++) c.t[k] = uniform_f(pc.tf[k]);        /* :674 */
 
             DVO_STAMP(t0);
-            Acc7 a;
+            Acc7T<WITH_H> a;
             acc7_zero(a);
             bool any_odd = false;
             /* waves take the lanes of a round in reverse order: the tail of the last, partial round goes to the high
@@ -948,16 +1004,16 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
              * has a round less */
             const int lane_off = BLOCK - 64 - (tid & ~63) + (tid & 63);
             if (mode == TEX_L16) {                 /* staged levels hold every point in LDS */
-                accumulate_points2<BLOCK, true, TEX_L16>(c, ts, lp, gpts, 0, N, lane_off, a, any_odd);             /* :369, :433 */
+                accumulate_points2<BLOCK, true, TEX_L16, 2, 0, false, Acc7T<WITH_H>>(c, ts, lp, gpts, 0, N, lane_off, a, any_odd);             /* :369, :433 */
             } else if (mode == TEX_P4 && pt4) {
-                accumulate_points2<BLOCK, true, TEX_P4, DVO_P4_DEPTH(BLOCK), kStatic, true>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
-                accumulate_points2<BLOCK, false, TEX_P4, DVO_P4_DEPTH(BLOCK), kStatic, true>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);
+                accumulate_points2<BLOCK, true, TEX_P4, (WITH_H ? 2 : DVO_P4_DEPTH(BLOCK)), kStatic, true, Acc7T<WITH_H>>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
+                accumulate_points2<BLOCK, false, TEX_P4, (WITH_H ? 2 : DVO_P4_DEPTH(BLOCK)), kStatic, true, Acc7T<WITH_H>>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);
             } else if (mode == TEX_P4) {
-                accumulate_points2<BLOCK, true, TEX_P4, DVO_P4_DEPTH(BLOCK), kStatic>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
-                accumulate_points2<BLOCK, false, TEX_P4, DVO_P4_DEPTH(BLOCK), kStatic>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);
+                accumulate_points2<BLOCK, true, TEX_P4, (WITH_H ? 2 : DVO_P4_DEPTH(BLOCK)), kStatic, false, Acc7T<WITH_H>>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
+                accumulate_points2<BLOCK, false, TEX_P4, (WITH_H ? 2 : DVO_P4_DEPTH(BLOCK)), kStatic, false, Acc7T<WITH_H>>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);
             } else {
-                accumulate_points2<BLOCK, true, TEX_G16>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
-                accumulate_points2<BLOCK, false, TEX_G16>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);       /* beyond the LDS budget */
+                accumulate_points2<BLOCK, true, TEX_G16, 2, 0, false, Acc7T<WITH_H>>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
+                accumulate_points2<BLOCK, false, TEX_G16, 2, 0, false, Acc7T<WITH_H>>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);       /* beyond the LDS budget */
             }
             {   /* A lane without a visible point keeps its coordinates (round2_issue): its gradient, weight and residual are exact
                  * zeros, so it adds exact zeros -- unless one of its coordinate products overflowed (a point a hair off the camera
@@ -971,14 +1027,14 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
                 acc7_zero(a);
                 const float2 *pal_lds = reinterpret_cast<const float2 *>(lds_dyn);
                 if (mode == TEX_P4 && pt4) {
-                    accumulate_points_exact<BLOCK, true, true, true>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
-                    accumulate_points_exact<BLOCK, false, true, true>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
+                    accumulate_points_exact<BLOCK, true, true, true, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
+                    accumulate_points_exact<BLOCK, false, true, true, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
                 } else if (mode == TEX_P4) {
-                    accumulate_points_exact<BLOCK, true, true>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
-                    accumulate_points_exact<BLOCK, false, true>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
+                    accumulate_points_exact<BLOCK, true, true, false, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
+                    accumulate_points_exact<BLOCK, false, true, false, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
                 } else {
-                    accumulate_points_exact<BLOCK, true, false>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
-                    accumulate_points_exact<BLOCK, false, false>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
+                    accumulate_points_exact<BLOCK, true, false, false, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
+                    accumulate_points_exact<BLOCK, false, false, false, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
                 }
                 if ((tid & 63) == 0) st.exact_ran = 1;          /* inspection: dvo_get_level_texel_mode reports it (tests) */
             }
@@ -991,6 +1047,17 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
              * the update writes `pn`.  (Rounds 1-4: a second pass through LDS and a second barrier for the totals, then one
              * lane doing bookkeeping, update and all LDS traffic in a row.) */
             wave_sums7(a, red);
+            if constexpr (WITH_H) {       /* the wave's 21 sums of H: three passes of the 8-value reduce-scatter */
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    double d[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) d[k] = (8 * q + k < 21) ? a.H[8 * q + k] : 0.0;
+                    wave_reduce_scatter8_dpp(d);
+                    const int idx = reduce_scatter8_dpp_index(tid & 63);
+                    if ((tid & 63) < 8) redH[tid >> 6][8 * q + idx] = d[0];
+                }
+            }
             const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
             double neg_step = 0.0;
             if (wave == 0) neg_step = pose_neg_step(uc, itr);        /* :773: needs the iteration index only -- taken while the other waves arrive */
@@ -1015,6 +1082,13 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
                 double psi[6];
                 pose_direction_lanes(st, uc, neg_step, sl, lane, psi);
                 if (lane == 0) pose_apply(st, pc, pn, uc, psi);
+            } else if (WITH_H && wave == 2) {      /* H of this iterate (dvo_get_level_normal_matrix): waves in order, like the other sums */
+                if (lane < 21) {
+                    double hs = 0.0;
+#pragma unroll
+                    for (int w = 0; w < BLOCK / 64; w++) hs += redH[w][lane];
+                    out.H[((size_t)pair * sc.e_stride + sc.e_off[l] + itr) * 21 + lane] = hs;
+                }
             } else if (wave == 1 && lane == 0) {
                 const double e2 = TEAM ? tot[6] : block_sum8<BLOCK>(red, 6);
                 const double nv = TEAM ? tot[7] : block_sum8<BLOCK>(red, 7);
@@ -1092,6 +1166,25 @@ static hipError_t launch_fused2_b(const LevelSet &lv, const Schedule &sc, const 
                                   const Outputs &out, int first_pair, int n_pairs, hipStream_t s) {
     const size_t dyn = (size_t)sc.lds_bytes;
     hipError_t e;
+    if constexpr (BLOCK == 512) {
+        if (sc.flags & 4) {      /* DVO_FLAG_NORMAL_MATRIX: H per iterate: one 512-thread workgroup per pair, no teams */
+            if (sc.team > 1 || !out.H) return hipErrorInvalidValue;
+            auto kern = align_fused2_kernel<512, false, true>;
+            if ((e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)) != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(n_pairs), dim3(512), dyn, s, lv, sc, K, prm, out, first_pair);
+            return hipGetLastError();
+        }
+    } else if constexpr (BLOCK == 256) {
+        if (sc.flags & 4) {
+            if (sc.team > 1 || !out.H) return hipErrorInvalidValue;
+            auto kern = align_fused2_kernel<256, false, true>;
+            if ((e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)) != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(n_pairs), dim3(256), dyn, s, lv, sc, K, prm, out, first_pair);
+            return hipGetLastError();
+        }
+    } else {
+        if (sc.flags & 4) return hipErrorInvalidValue;      /* DVO_FLAG_NORMAL_MATRIX */
+    }
     if (sc.team > 1) {
         auto kern = align_fused2_kernel<BLOCK, true>;
         if ((e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)) != hipSuccess) return e;
@@ -1140,8 +1233,8 @@ static hipError_t launch_fused2_b(const LevelSet &lv, const Schedule &sc, const 
 }
 
 /* static LDS of align_fused2_kernel<BLOCK> (the host sizes the dynamic part against the CU's 160 KiB) */
-size_t fused2_static_lds(int block_threads) {
-    return ((sizeof(PoseState) + 15) & ~(size_t)15) + (size_t)(block_threads / 64) * 64 + 64 + 16;
+size_t fused2_static_lds(int block_threads, bool with_h) {
+    return ((sizeof(PoseState) + 15) & ~(size_t)15) + (size_t)(block_threads / 64) * 64 + 64 + (with_h ? (size_t)(block_threads / 64) * 24 * 8 : 0) + 16;
 }
 
 hipError_t launch_align_fused2(int block_threads, const LevelSet &lv, const Schedule &sc, const Intrinsics &K,

@@ -114,7 +114,7 @@ hipError_t launch_align_fused(int block_threads, int points_in_flight, const Lev
 /* the same schedule on two points per lane in packed float32 (dvo_fused.hip); needs sc.compact */
 hipError_t launch_align_fused2(int block_threads, const LevelSet &lv, const Schedule &sc, const Intrinsics &K,
                                const DevParams &prm, const Outputs &out, int first_pair, int n_pairs, hipStream_t s);
-size_t fused2_static_lds(int block_threads);
+size_t fused2_static_lds(int block_threads, bool with_h = false);
 /* per-point dump at a float pose (inspection) */
 hipError_t launch_eval_points(const LevelSlab &L, int pair, int level, const Intrinsics &K,
                               const float *Rf, const float *tf,

@@ -79,7 +79,7 @@ DVO_DEV void project_point2(const IterConst &c, v2f X, v2f Y, v2f Z, v2f &xn, v2
  * 16-byte loads, so the products that consume them are written per half (no register shuffles to pair them up).
  * Returns jw[k] = (float)(J_k * w)  (:716): the Jacobian row already scaled by the weight. */
 DVO_DEV void jacobian_weighted2(const IterConst &c, v2f xn, v2f yn, v2f zn, float gx0, float gx1, float gy0, float gy1,
-                                float wt0, float wt1, v2f *jw) {
+                                float wt0, float wt1, v2f *jw, v2f *jout = nullptr /* the unweighted rows (H = sum w J J^T), or NULL */) {
     const v2f n02 = (-c.m00) * xn, n12 = (-c.m11) * yn;
     const v2f dz = pk_splat(1.0f) - zn;                                     /* 0 or 2^-24, exact */
     const v2f cz1 = dz * DVO_K24, cz2 = dz * DVO_K23;                       /* 0 or the constants of (5), (6) */
@@ -109,11 +109,12 @@ DVO_DEV void jacobian_weighted2(const IterConst &c, v2f xn, v2f yn, v2f zn, floa
     jw[3].x = j3.x * wt0; jw[3].y = j3.y * wt1;
     jw[4].x = j4.x * wt0; jw[4].y = j4.y * wt1;
     jw[5].x = j5.x * wt0; jw[5].y = j5.y * wt1;
+    if (jout) { jout[0] = j0; jout[1] = j1; jout[2] = j2; jout[3] = j3; jout[4] = j4; jout[5] = j5; }
 }
 
 /* the same with the gradients and weights of the two points already paired (they come from LDS lookups, dvo_palette.h): every
  * product is packed.  Same operations in the same order per half -> same bits as jacobian_weighted2. */
-DVO_DEV void jacobian_weighted2p(const IterConst &c, v2f xn, v2f yn, v2f zn, v2f gx, v2f gy, v2f wt, v2f *jw) {
+DVO_DEV void jacobian_weighted2p(const IterConst &c, v2f xn, v2f yn, v2f zn, v2f gx, v2f gy, v2f wt, v2f *jw, v2f *jout = nullptr) {
     const v2f n02 = (-c.m00) * xn, n12 = (-c.m11) * yn;
     const v2f dz = pk_splat(1.0f) - zn;
     const v2f cz1 = dz * DVO_K24, cz2 = dz * DVO_K23;
@@ -133,6 +134,7 @@ DVO_DEV void jacobian_weighted2p(const IterConst &c, v2f xn, v2f yn, v2f zn, v2f
     const v2f j4 = ga2 * w0 - ga0 * w2;
     const v2f j5 = ga0 * w1 - ga1 * w0;
     jw[0] = j0 * wt; jw[1] = j1 * wt; jw[2] = j2 * wt; jw[3] = j3 * wt; jw[4] = j4 * wt; jw[5] = j5 * wt;     /* :716 */
+    if (jout) { jout[0] = j0; jout[1] = j1; jout[2] = j2; jout[3] = j3; jout[4] = j4; jout[5] = j5; }
 }
 
 }  // namespace dvo

@@ -133,8 +133,11 @@ def test_normal_matrix_of_every_iterate(scene320, oracle):
     from rgbd_odometry_amd.capi import DVO_FLAG_NORMAL_MATRIX
     sc, lv = scene320
     iters = [6, 0, 5, 4]
-    for compact in (False, True):
-        with DvoContext(1) as ctx:
+    ref = oracle.align_pyramid(iters, lv, sc.intrinsics, np.eye(3), np.zeros(3))
+    # the reference's 3 x N lists (one-point-per-lane kernel); the engine's own lists (round 5: the packed kernel carries H too, on
+    # 16-byte texels here); the same with now levels written natively in the compact form (its throughput look-up path)
+    for compact, want_blk in ((False, 512), (True, 512), ("native", 512), ("native", 256)):     # 256: the throughput shape of large batches
+        with DvoContext(1, block_threads=(256 if want_blk == 256 else 0)) as ctx:
             ctx.set_intrinsics(*sc.intrinsics)
             for l, L in enumerate(lv):
                 if compact:
@@ -142,8 +145,18 @@ def test_normal_matrix_of_every_iterate(scene320, oracle):
                     ctx.set_ref_level_from_images(l, S.ref_edge, S.ref_depth, S.rows, S.cols)
                 else:
                     ctx.set_ref_level(l, L["xyz"])
-                ctx.set_now_level(l, L["dt"], L["gx"], L["gy"], L["rows"], L["cols"])
+                if compact == "native":
+                    ctx.set_now_level_from_edges(l, (np.asarray(sc.levels[l].now_edge) != 0).astype(np.uint8) * 255, L["rows"], L["cols"])
+                else:
+                    ctx.set_now_level(l, L["dt"], L["gx"], L["gy"], L["rows"], L["cols"])
             R, t = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)), flags=DVO_FLAG_NORMAL_MATRIX)
+            blk, g, packed = ctx.last_launch_shape()
+            assert bool(packed) == bool(compact) and blk == want_blk and g == 1, (compact, blk, g, packed)
+            if compact == "native":
+                assert [ctx.level_texel_mode(0, l) for l in (0, 2, 3)] == [2, 2, 2]
+            for l, rep in ref["levels"].items():
+                e, b, ratio = ctx.level_report(0, l, iters[l])
+                assert np.array_equal(e, rep["energy"]) and b == rep["best_idx"] and ratio == rep["visible_ratio"], (compact, l)
             Rp, tp = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
             # same policy, same per-point bits; another kernel may add the double sums in another order (~1e-16)
             assert np.abs(R - Rp).max() <= 1e-12 and np.abs(t - tp).max() <= 1e-12

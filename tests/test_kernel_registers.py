@@ -43,15 +43,23 @@ def _kernel_resources(tmp_path):
 def test_packed_kernel_fits_two_waves_per_simd(tmp_path):
     res = _kernel_resources(tmp_path)
     fused2 = {k: v for k, v in res.items() if "align_fused2_kernel" in k}
-    assert len(fused2) >= 6, sorted(res)[:10]
+    assert len(fused2) >= 7, sorted(res)[:10]
     for block in (256, 512):
-        k = [n for n in fused2 if "ILi%dELb0E" % block in n]
-        assert len(k) == 1, k
-        r = fused2[k[0]]
-        assert r["vgpr"] + r["agpr"] <= 256, (block, r)       # two waves per SIMD (512 registers per lane and SIMD)
-        # loop-invariant values may sit in scratch (stored at kernel start, reloaded once per level or before the final pass);
-        # what must never happen is a scratch access inside a loop over points: test_no_scratch_access_inside_the_point_loops
-        assert r["scratch"] <= 256, (block, r)
+        for team in (0, 1):
+            k = [n for n in fused2 if "ILi%dELb%dELb0E" % (block, team) in n]
+            assert len(k) == 1, k
+            r = fused2[k[0]]
+            assert r["vgpr"] + r["agpr"] <= 256, (block, r)       # two waves per SIMD (512 registers per lane and SIMD)
+            # round 5: the update's constants live in LDS (dvo_device_math.h: UpdConst) instead of being hoisted into registers for
+            # the whole kernel -- that hoisting was what spilled in rounds 2-4 (108 bytes of scratch on the throughput shape): none now
+            assert r["scratch"] == 0 and r["vgpr_spill"] == 0, (block, team, r)
+    # DVO_FLAG_NORMAL_MATRIX on the packed kernel (512 threads): 42 more accumulator registers.  Loop-invariant values may sit in
+    # scratch (stored at kernel start, reloaded once per level or before the final pass); what must never happen is a scratch
+    # access inside a loop over points: test_no_scratch_access_inside_the_point_loops covers this instantiation too
+    k = [n for n in fused2 if "ILi512ELb0ELb1E" in n]
+    assert len(k) == 1, k
+    r = fused2[k[0]]
+    assert r["vgpr"] + r["agpr"] <= 256 and r["scratch"] <= 320, r
 
 
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
