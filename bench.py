@@ -172,6 +172,74 @@ def cpu_baseline(args, scenes, iters, budget_s, max_n=2000):
                        f"1 thread of {os.cpu_count()} host cores, oracle/ built -O2 -ffp-contract=off"), oracle, lvs
 
 
+def host_cpu_info():
+    """what the CPU legs ran on: the cores this process may use (affinity), the container's CPU quota (cgroup cpu.max), model, SMT"""
+    info = {"os_cpu_count": os.cpu_count()}
+    try:
+        info["sched_affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        info["sched_affinity"] = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                info["cgroup_cpu_max"] = " ".join(txt)
+                info["cgroup_cpus"] = None if txt[0] == "max" else float(txt[0]) / float(txt[1])
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+                info["cgroup_cpu_max"] = "%d %d" % (q, per)
+                info["cgroup_cpus"] = None if q < 0 else q / per
+            break
+        except Exception:
+            continue
+    try:
+        model, phys, cores_per, siblings = None, set(), None, None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model is None:
+                model = v
+            elif k == "physical id":
+                phys.add(v)
+            elif k == "cpu cores" and cores_per is None:
+                cores_per = int(v)
+            elif k == "siblings" and siblings is None:
+                siblings = int(v)
+        info.update(model=model, sockets=len(phys) or None, cores_per_socket=cores_per,
+                    threads_per_core=(siblings // cores_per) if cores_per and siblings else None)
+    except Exception:
+        pass
+    try:
+        info["loadavg_1min"] = float(open("/proc/loadavg").read().split()[0])
+    except Exception:
+        pass
+    return info
+
+
+def usable_cpus(info):
+    n = info.get("sched_affinity") or info.get("os_cpu_count") or 1
+    if info.get("cgroup_cpus"):
+        n = max(1, min(n, int(info["cgroup_cpus"] + 0.5)))
+    return n
+
+
+def cpu_baseline_openmp(args, oracle, lvs, scenes, iters, budget_s, single_rate):
+    """BASELINE.md section 4 (ii), the form it asks for: ONE process, OpenMP over the independent pairs of the batch configuration
+    (oracle/dvo_oracle_batch.cpp: every thread runs the single-threaded reference path on its own pair), as many threads as this
+    process has CPUs (affinity, capped by the container's quota); per-thread statistics say how evenly the cores delivered"""
+    info = host_cpu_info()
+    threads = usable_cpus(info)
+    n_pairs = int(max(threads, min(20000, single_rate * threads * budget_s * 0.6)))
+    r = oracle.align_batch_omp(iters, lvs, scenes[0].intrinsics, n_pairs, n_threads=threads)
+    per = r["thread_pairs"] / np.maximum(r["thread_seconds"], 1e-9)
+    return dict(value=n_pairs / r["seconds"], unit="aligns/s", cores=int(r["threads"]), kind="port",
+                sample=f"{n_pairs} alignments ({len(lvs)} distinct scenes) in {r['seconds']:.1f} s, one process, OpenMP over pairs, "
+                       f"{r['threads']} threads",
+                per_thread_aligns_per_s={"min": float(per.min()), "median": float(np.median(per)), "max": float(per.max())},
+                speedup_over_one_thread=(n_pairs / r["seconds"]) / single_rate, host=info)
+
+
 def cpu_baseline_all_cores(args, iters, budget_s):
     """one alignment stream per host core -- one light worker process per core
     (tests/cpu_baseline_worker.py: numpy + the oracle library, no torch, no HIP), each aligning its own scene for
@@ -184,16 +252,22 @@ def cpu_baseline_all_cores(args, iters, budget_s):
     procs = [subprocess.Popen([sys.executable, worker, str(args.width), str(args.height), str(args.levels), str(iters[0]),
                                str(1000 + i % 8), str(budget_s)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
              for i in range(cores)]
-    n_tot, rate, ok = 0, 0.0, 0
+    n_tot, rate, ok, per = 0, 0.0, 0, []
     for p in procs:
         try:
             out, _ = p.communicate(timeout=budget_s * 6 + 120)
             n, el = out.split()[-2:]
             n_tot += int(n); rate += int(n) / float(el); ok += 1
+            per.append(int(n) / float(el))
         except Exception:
             p.kill()
+    info = host_cpu_info()
     return dict(value=rate, unit="aligns/s", cores=ok, kind="port",
-                sample=f"{n_tot} alignments, one oracle process per host core ({ok} of {cores} workers reported) for {budget_s:.0f} s each")
+                sample=f"{n_tot} alignments, one oracle process per CPU of the affinity mask ({ok} of {cores} workers reported) for {budget_s:.0f} s each",
+                per_worker_aligns_per_s=({"min": min(per), "median": float(np.median(per)), "max": max(per)} if per else None),
+                host=info,
+                note="one PROCESS per CPU of the affinity mask, whatever the container's quota (host.cgroup_cpus): where the quota is below "
+                     "the mask the workers share it and each runs at quota / workers of a core -- cpu_baseline_openmp sizes its team by the quota")
 
 
 # ---- extra legs (never `value`) ----------------------------------------------------------------------------------------
@@ -541,6 +615,10 @@ def main_batch(args):
         base, oracle, lvs = cpu_baseline(args, scenes, iters, args.cpu_seconds)
         out["cpu_baseline"] = base
         if not args.no_cpu_all_cores:
+            try:
+                out["cpu_baseline_openmp"] = cpu_baseline_openmp(args, oracle, lvs, scenes, iters, args.cpu_seconds, base["value"])
+            except Exception as e:
+                out["cpu_baseline_openmp"] = {"error": repr(e)}
             try:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args, iters, args.cpu_seconds)
             except Exception as e:

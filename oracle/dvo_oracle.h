@@ -145,6 +145,14 @@ int dvo_oracle_align_pyramid(const dvo_oracle_params *prm, int n_levels, const i
                              float *energy_out, int *best_idx_out, float *ratio_out,
                              float *final_eps, float *final_reproj);
 
+/* n_pairs independent alignments from the identity, OpenMP over pairs (dvo_oracle_batch.cpp); pair i
+ * aligns scene i % n_scenes, per-level inputs of scene s at index s * n_levels + l.  Returns the threads used. */
+int dvo_oracle_align_batch_omp(const dvo_oracle_params *prm, int n_pairs, int n_scenes, int n_levels, const int *iters,
+                               const float *const *xyz, const int *N, const float *const *dt, const float *const *gx,
+                               const float *const *gy, const int *rows, const int *cols, float fx, float fy, float cx, float cy,
+                               int n_threads, double *R_out, double *t_out, double *seconds_out, double *thread_seconds,
+                               int *thread_pairs);
+
 /* Now-frame preprocessing after Canny (computeDistTransfrmOfNow :1768-1795, imageGradient :1063-1098):
  * edge mask (uint8, >0 = edge, column-major) -> exact EDT -> min-max normalise to [0,255] -> central
  * differences with reflect-101 border.  OpenCV 2.4 semantics restated, unpinned (see the .cpp).

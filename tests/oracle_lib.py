@@ -168,6 +168,38 @@ class Oracle:
             last = l
         return dict(R=R, t=t, levels=reports, last_level=last)
 
+    def align_batch_omp(self, iters, scenes_levels, K, n_pairs, n_threads=0, params=None):
+        """n_pairs alignments from the identity, OpenMP over pairs (pair i aligns scene i % len(scenes)).
+        scenes_levels: list (scenes) of lists (levels) of dict(xyz, dt, gx, gy, rows, cols).  Returns dict(R, t, seconds, threads,
+        thread_seconds, thread_pairs)."""
+        ns, nl = len(scenes_levels), len(iters)
+        keep = []
+
+        def arr(key, dtype=np.float32):
+            out = (C.c_void_p * (ns * nl))()
+            for s, lv in enumerate(scenes_levels):
+                for l in range(nl):
+                    a = np.ascontiguousarray(lv[l][key], dtype=dtype)
+                    keep.append(a)
+                    out[s * nl + l] = a.ctypes.data
+            return out
+        xyz, dt, gx, gy = arr("xyz"), arr("dt"), arr("gx"), arr("gy")
+        N = np.array([len(np.asarray(lv[l]["xyz"]).reshape(-1)) // 3 for lv in scenes_levels for l in range(nl)], np.int32)
+        rows = np.array([lv[l]["rows"] for lv in scenes_levels for l in range(nl)], np.int32)
+        cols = np.array([lv[l]["cols"] for lv in scenes_levels for l in range(nl)], np.int32)
+        it = np.array(iters, np.int32)
+        nt = int(n_threads) if n_threads else (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        R, t = np.zeros((n_pairs, 9)), np.zeros((n_pairs, 3))
+        secs = C.c_double(0.0)
+        tsec, tpairs = np.zeros(nt), np.zeros(nt, np.int32)
+        p = params if params is not None else self.default_params()
+        self.lib.dvo_oracle_align_batch_omp.restype = C.c_int
+        used = self.lib.dvo_oracle_align_batch_omp(C.byref(p), int(n_pairs), ns, nl, _p(it), xyz, _p(N), dt, gx, gy, _p(rows), _p(cols),
+                                                   C.c_float(K[0]), C.c_float(K[1]), C.c_float(K[2]), C.c_float(K[3]), nt, _p(R), _p(t),
+                                                   C.byref(secs), _p(tsec), _p(tpairs))
+        return dict(R=R.reshape(n_pairs, 3, 3).transpose(0, 2, 1), t=t, seconds=secs.value, threads=used, thread_seconds=tsec[:used],
+                    thread_pairs=tpairs[:used])
+
     def now_level_from_edges(self, edge, rows, cols):
         edge = np.ascontiguousarray(edge, dtype=np.uint8)
         dt, gx, gy = (np.zeros(rows * cols, np.float32) for _ in range(3))

@@ -226,3 +226,18 @@ def test_now_level_from_edges_brute_force(oracle):
     for L in sc.levels:
         a, b, c = oracle.now_level_from_edges((L.now_edge > 0).astype(np.uint8), L.rows, L.cols)
         assert np.array_equal(a, L.now_dt) and np.array_equal(b, L.now_gx) and np.array_equal(c, L.now_gy)
+
+
+def test_openmp_batch_leg_gives_the_single_thread_results(oracle):
+    """bench.py's `cpu_baseline_openmp` leg (OpenMP over independent pairs, oracle/dvo_oracle_batch.cpp):
+    every pair of the batch comes out with the bits of the single-threaded schedule on the same scene"""
+    from rgbd_odometry_amd import SynthScene
+    import oracle_lib
+    scs = [SynthScene(160, 120, 3, 5 + i) for i in range(2)]
+    lvs = [oracle_lib.scene_levels(sc, oracle) for sc in scs]
+    iters = [4, 0, 4]
+    r = oracle.align_batch_omp(iters, lvs, scs[0].intrinsics, 7, n_threads=3)
+    assert r["threads"] >= 1 and int(r["thread_pairs"].sum()) == 7 and r["seconds"] > 0
+    for i in range(7):
+        ref = oracle.align_pyramid(iters, lvs[i % 2], scs[0].intrinsics, np.eye(3), np.zeros(3))
+        assert np.array_equal(ref["R"], r["R"][i]) and np.array_equal(ref["t"], r["t"][i]), i
