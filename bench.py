@@ -346,6 +346,77 @@ def frames_leg(args, iters):
     return out
 
 
+def sparse_scenes_leg(stream, quick=False):
+    """extra leg, never `value` (round 5): the engine on scenes that do NOT flatter it.  The bench's standard
+    scenes have 5-6 % edge pixels everywhere; these have 0.5 / 1 / 2 % edge pixels, all in the left half of the frame -- the right
+    half is empty (320 px at 640x480, 960 px at 1920x1080, 2048 px at 4096x3072: pixels hundreds of pixels from every edge, many
+    distinct distances).  Per configuration: what form every level of every distinct scene got (the compact form, or the reason it was
+    refused: dvo_get_now_compact_info), what the launch read, aligns/s and the roofline fraction by the same algorithmic-byte
+    definition as the headline (it counts whole images: with few points it exceeds what the launch touches, so `roofline_frac` can
+    pass 1 here -- it is a rate, not an efficiency).  Rounds 3-4 REFUSED the finest levels of such scenes (more than 8191 distinct
+    distances / a pixel 512 px or more from every edge) and read them as 16-byte texels; round 5 writes a PARTIAL compact form
+    (dvo_palette.h): `levels_partial`, and `exact_fallback_ran_pair0` says whether any wave met a pixel the form cannot express."""
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    from rgbd_odometry_amd.capi import DVO_FLAG_FINAL_OUTPUTS, DVO_FLAG_IDENTITY_START
+    flags = DVO_FLAG_IDENTITY_START | DVO_FLAG_FINAL_OUTPUTS
+    reasons = {-1: "not a distance transform", -2: "more than 8191 distinct distances", -3: "rank step beyond +-127", -4: "foreign gradients",
+               -7: "a pixel 512 px or more from every edge"}
+    out = []
+    cfgs = [(640, 480, 4, 1024, 8, 10), (1920, 1080, 5, 256, 4, 4), (4096, 3072, 5, 1, 1, 20)]
+    if quick:
+        cfgs = cfgs[:1]
+    for W, H, nl, B, D, steps in cfgs:
+        iters = [10] * nl
+        for dens in (0.005, 0.01, 0.02):
+            n_seg = max(2, int(round(dens * W * H / (70.0 * W / 320.0))))
+            scenes = [SynthScene(W, H, nl, 2000 + i, n_seg=n_seg, x_frac=0.5) for i in range(D)]
+            ctx = DvoContext(B)
+            try:
+                ctx.set_intrinsics(*scenes[0].intrinsics)
+                for i, sc in enumerate(scenes):
+                    for l, L in enumerate(sc.levels):
+                        ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols, pair=i)
+                        ctx.set_now_level_from_edges(l, u8_edges(L.now_edge), L.rows, L.cols, pair=i)
+                info = [[ctx.now_compact_info(i, l) for l in range(nl)] for i in range(D)]
+                part = [[ctx.now_compact_partial(i, l) for l in range(nl)] for i in range(D)]
+                if B > D:
+                    ctx.replicate_pairs(D)
+                ctx.set_stream(stream.cuda_stream)
+                for _ in range(2):
+                    ctx.enqueue(iters, flags=flags); ctx.get_poses()
+                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for k in range(steps):
+                    ev[k][0].record(stream)
+                    ctx.enqueue(iters, flags=flags)
+                    ev[k][1].record(stream)
+                    ctx.get_poses()
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+                nbytes = sum(ctx.algorithmic_bytes(iters, pair=p % D, flags=DVO_FLAG_FINAL_OUTPUTS) for p in range(B))
+                refused = sum(1 for row in info for v in row if v <= 0)
+                blk, team, packed = ctx.last_launch_shape()
+                out.append({
+                    "workload": "%dx%dx%d, %d pairs (%d distinct), %.1f %% edge pixels in the left half" % (W, H, nl, B, D, 100 * dens),
+                    "edge_density_level0": float(np.mean([(np.asarray(sc.levels[0].now_edge) != 0).mean() for sc in scenes])),
+                    "aligns_per_s": B * steps / el, "kernel_ms": k_ms, "roofline_frac": nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "levels_refused": refused, "levels_partial": sum(1 for row in part for v in row if v), "levels_total": D * nl,
+                    "exact_fallback_ran_pair0": [bool(ctx.level_exact_fallback(0, l)) for l in range(nl)],
+                    "compact_info_per_level_scene0": info[0],          # > 0: palette size; < 0: refusal reason
+                    "refusal_reasons": sorted({reasons.get(v, str(v)) for row in info for v in row if v <= 0}),
+                    "texel_modes_pair0": [ctx.level_texel_mode(0, l) for l in range(nl)],
+                    "launch_shape": {"block_threads": blk, "team": team},
+                    "reference_points_level0": int(ctx.n_points(0)),
+                })
+            except Exception as e:
+                out.append({"workload": "%dx%dx%d %.1f %%" % (W, H, nl, 100 * dens), "error": repr(e)})
+            finally:
+                ctx.close()
+    return out
+
+
 def float_boundary_leg(args, iters, flags, stream, per_scene_bytes):
     """extra leg, never `value`: 256 pairs whose now levels arrive as the reference keeps them -- DT, gradX, gradY float images in
     host memory (SolveDVO.cpp:1788-1795 -> dvo_set_now_level)"""
@@ -689,6 +760,10 @@ def main_batch(args):
             out["float_now_levels"] = float_boundary_leg(args, iters, flags, stream, per_scene_bytes)
         except Exception as e:
             out["float_now_levels"] = {"error": repr(e)}
+        try:
+            out["sparse_scenes"] = sparse_scenes_leg(stream)
+        except Exception as e:
+            out["sparse_scenes"] = {"error": repr(e)}
     if frames_in is not None:
         out["frames_in"] = frames_in
     print(json.dumps(out), flush=True)

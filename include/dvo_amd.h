@@ -335,11 +335,14 @@ int  dvo_now_prepare(dvo_ctx *ctx, int first_pair, int count);
  * three images, or 4 us for the texels alone when they come from device memory: OFF by default, worth it only for a now level
  * that is aligned many times (DVO_DIRECT_COMPACT=on / off in the environment overrides the call). */
 int  dvo_set_direct_compact(dvo_ctx *ctx, int on);
-/* palette_size: > 0 number of distinct distance values of the compact form, 0 not built (yet / stale),
- * < 0 no compact form: -1 negative/inf/nan value, -2 too many distinct values (native 8191, generic 4095), -3 rank step beyond
+/* palette_size: > 0 number of palette entries of the compact form, 0 not built (yet / stale),
+ * < 0 no compact form: -1 negative/inf/nan value, -2 too many distinct values (generic builder: 4095), -3 rank step beyond
  * +-127, -4 gradient is not imageGradient(DT), -5 weight is not getWeightOf(DT), -6 image narrower than 2 pixels, -7 a pixel
- * further than 511 pixels from every edge (native builder) */
+ * further than 511 pixels from every edge.  Round 5: the engine's own distance transform no longer refuses an image for -2 / -3 /
+ * -7 -- it writes a PARTIAL compact form (the lowest 4094 ranks; the other pixels are looked up in the image's 16-byte texels,
+ * which such an image also gets) and dvo_get_now_compact_partial says so; float images handed in directly keep those refusals. */
 int  dvo_get_now_compact_info(dvo_ctx *ctx, int pair, int level, int *palette_size);
+int  dvo_get_now_compact_partial(dvo_ctx *ctx, int pair, int level, int *partial);
 
 /* Diagnostic builds only (make STAMPS=1): per-level phase cycle counters of `pair`,
  * out64[level*8 + {0: per-point loop, 1: reduction, 2: pose update, 3: barrier, 4: iterations}];

@@ -183,12 +183,16 @@ int sparse_map_compact_failures(dvo_ctx *c, int level, int first, int count, hip
     HIPCHK(c, hipMemcpyAsync(pn.data(), L.d_pal_n + first, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost, stream));
     HIPCHK(c, stream_wait(stream));
     if (L.p4_known.empty()) { L.p4_known.assign(c->n_pairs, Level::P4_UNKNOWN); L.p4_fresh.assign(c->n_pairs, 0); }
-    for (int i = 0; i < count; i++) { L.p4_known[first + i] = pn[i] > 0 ? Level::P4_OK : Level::P4_REFUSED; L.p4_fresh[first + i] = 1; }
+    auto needs_tex = [&](int v) { return v <= 0 || pal_partial(v); };      /* refused, or a partial form: 16-byte texels are (also) its form */
+    for (int i = 0; i < count; i++) {
+        L.p4_known[first + i] = pn[i] <= 0 ? Level::P4_REFUSED : (pal_partial(pn[i]) ? Level::P4_PARTIAL : Level::P4_OK);
+        L.p4_fresh[first + i] = 1;
+    }
     int n = 0;
     for (int i = 0; i < count; ) {
-        if (pn[i] > 0) { i++; continue; }
+        if (!needs_tex(pn[i])) { i++; continue; }
         int j = i;
-        while (j < count && pn[j] <= 0) j++;
+        while (j < count && needs_tex(pn[j])) j++;
         const int rc = map_texels(c, level, first + i, j - i, stream);
         if (rc) return rc;
         n += j - i;
@@ -210,8 +214,9 @@ int refresh_p4_known(dvo_ctx *c, int level, int first, int count) {
         HIPCHK(c, hipMemcpyAsync(pn.data(), L.d_pal_n + p, sizeof(int) * (size_t)(q - p), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, stream_wait(c->stream));
         for (int i = p; i < q; i++) {
-            L.p4_known[i] = pn[i - p] > 0 ? Level::P4_OK : Level::P4_REFUSED;
-            if (pn[i - p] <= 0 && !L.tex16_stale.empty()) L.tex16_stale[i] = 0;      /* the refused image's texels were written with it */
+            const int v = pn[i - p];
+            L.p4_known[i] = v <= 0 ? Level::P4_REFUSED : (pal_partial(v) ? Level::P4_PARTIAL : Level::P4_OK);
+            if ((v <= 0 || pal_partial(v)) && !L.tex16_stale.empty()) L.tex16_stale[i] = 0;      /* such an image's texels were written with it */
         }
         p = q;
     }
@@ -301,7 +306,7 @@ int now_written_compact(dvo_ctx *c, int level, int first_pair, int count) {
         L.have_now[p] = 1; L.now_uses[p] = 0; L.pal_built[p] = 1;
         if (L.p4_fresh[p]) L.p4_fresh[p] = 0;               /* pal_n of THIS write was read back (sparse slab): known */
         else L.p4_known[p] = Level::P4_UNKNOWN;
-        L.tex16_stale[p] = (L.p4_known[p] == Level::P4_REFUSED) ? 0 : 1;      /* a refused image got its texels from the same launch */
+        L.tex16_stale[p] = (L.p4_known[p] == Level::P4_REFUSED || L.p4_known[p] == Level::P4_PARTIAL) ? 0 : 1;      /* such an image got its texels from the same launch */
     }
     return DVO_OK;
 }
@@ -1293,6 +1298,22 @@ int dvo_get_now_compact_info(dvo_ctx *c, int pair, int level, int *palette_size)
     if (!L.d_pal_n) return DVO_OK;
     HIPCHK(c, hipMemcpyAsync(palette_size, L.d_pal_n + pair, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, stream_wait(c->stream));
+    if (*palette_size > 0) *palette_size = pal_count(*palette_size);      /* without the partial mark: dvo_get_now_compact_partial */
+    return DVO_OK;
+}
+/* 1 if the compact form of (pair, level) is PARTIAL (round 5, dvo_palette.h): the image has more distinct distances than the palette
+ * holds, a pixel 512 px or more from every edge or a rank step beyond +-127 -- its lowest ranks are in the compact form, the pixels
+ * it cannot express are looked up in the image's 16-byte texels (which such an image also has) */
+int dvo_get_now_compact_partial(dvo_ctx *c, int pair, int level, int *partial) {
+    DVO_ENTER(c);
+    if (!pair_ok(c, pair) || !level_ok(level) || !partial) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    Level &L = c->lv[level];
+    *partial = 0;
+    if (!L.d_pal_n) return DVO_OK;
+    int v = 0;
+    HIPCHK(c, hipMemcpyAsync(&v, L.d_pal_n + pair, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, stream_wait(c->stream));
+    *partial = pal_partial(v) ? 1 : 0;
     return DVO_OK;
 }
 

@@ -65,7 +65,7 @@ struct Level {
      * replication and before a launch-shape decision that depends on it).  A REFUSED pair's 16-byte texels are its real form:
      * they are current (tex16_stale = 0) and travel with it (round 5, ADVICE r4: a replicated refused source left its
      * destinations without texels -- on a sparse slab without memory behind them). */
-    enum : char { P4_UNKNOWN = 0, P4_OK = 1, P4_REFUSED = 2 };
+    enum : char { P4_UNKNOWN = 0, P4_OK = 1, P4_REFUSED = 2, P4_PARTIAL = 3 /* a partial compact form (dvo_palette.h): read as the compact form, 16-byte texels real too */ };
     std::vector<char> p4_known;
     std::vector<char> p4_fresh;     /* set where sparse_map_compact_failures has just read pal_n; consumed by now_written_compact */
 };

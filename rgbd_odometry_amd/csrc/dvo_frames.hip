@@ -773,12 +773,15 @@ hipError_t launch_canny_levels(int n, const int *rows, const int *cols, const un
  *   16-byte texels {DT, gx, gy, w} are not written at all (17 instead of 45 bytes of HBM traffic per pixel); the inspection and
  *   host-driven paths decode them from the compact form on demand (p4_decode_texels_kernel).
  *
- *   Images the compact form cannot hold -- more than DVO_PAL_MAX - 1 distinct distances, a pixel further than 511 pixels
- *   from every edge, a rank step between horizontal neighbours beyond +-127 -- get their 16-byte texels from the same d2
- *   (dt_normalize_gradient_pack_kernel, launched with a per-image predicate) and pal_n = -reason.                           */
+ *   Images the compact form cannot hold completely -- more than DVO_PAL_MAX - 2 distinct distances, a pixel further than 511
+ *   pixels from every edge, a rank step between horizontal neighbours beyond +-127 -- get a PARTIAL compact form (round 5,
+ *   dvo_palette.h: the pixels it cannot express carry the rank of a NaN palette entry) AND their 16-byte texels from the same d2
+ *   (dt_normalize_gradient_pack_kernel, launched with a per-image predicate); pal_n = count | DVO_PAL_PARTIAL.  Float images
+ *   handed in directly keep the all-or-nothing rule (pal_n = -reason).                                                       */
 /* ------------------------------------------------------------------------- */
 #define DVO_EDT_INF(rows, cols) ((rows) + (cols) + 1)
-enum { EDT_FLAG_FAR = 1, EDT_FLAG_STEP = 2, EDT_FLAG_BAD = 4 /* float images only: not an exact distance transform */ };
+enum { EDT_FLAG_FAR = 1, EDT_FLAG_STEP = 2, EDT_FLAG_BAD = 4 /* float images only: not an exact distance transform */,
+       EDT_FLAG_PARTIAL = 8 /* the rank-pack pass wrote the NaN rank somewhere: a partial compact form (dvo_palette.h) */ };
 
 /* 32-bit words of one image's presence bitmap: every possible d2 of a small image, distances below 512 pixels otherwise */
 static inline int edt_bitmap_words(int rows, int cols) {
@@ -1309,15 +1312,21 @@ DVO_DEV void edt_rank_pack_body(const int bx, const int gx, const int by, const 
     const bool small = BM_WORDS == PK_SMALL_WORDS;
     if (rows < 2 || cols < 2) { if (first_wg && tid == 0 && small) pal_n[pair] = -(int)PAL_SHAPE; return; }
     if (flags[by] & EDT_FLAG_BAD) { if (first_wg && tid == 0 && small) pal_n[pair] = -(int)PAL_BAD_VALUE; return; }
-    if (flags[by] & EDT_FLAG_FAR) { if (first_wg && tid == 0 && small) pal_n[pair] = -(int)PAL_FAR; return; }
+    /* round 5: a pixel beyond the bitmap's range (EDT_FLAG_FAR), too many distinct distances, a rank step that does not fit: the
+     * image gets a PARTIAL compact form (dvo_palette.h) instead of none.  Float images handed in directly (unit_bits) keep the
+     * all-or-nothing rule: their planes are verified pixel by pixel against the decode (compact_verify_planes_kernel). */
+    const bool far_img = (flags[by] & EDT_FLAG_FAR) != 0;
+    if (far_img && unit_bits) { if (first_wg && tid == 0 && small) pal_n[pair] = -(int)PAL_FAR; return; }
     int m = 0;
     for (int k = tid; k < n_partial; k += 256) { const int v = partial[k]; m = v > m ? v : m; }
     m = block_reduce_256<true>(m);
     if (tid == 0) s_max = m;
     __syncthreads();
     const unsigned m2 = (unsigned)s_max;
-    const int nw = (int)(m2 >> 5) + 1;                          /* <= bm_words: no FAR flag */
+    int nw = (int)(m2 >> 5) + 1;
+    if (nw > bm_words) nw = bm_words;                           /* EDT_FLAG_FAR: the distances beyond the bitmap take the NaN rank */
     if ((nw <= PK_SMALL_WORDS) != small) return;                /* the other instantiation's image */
+    if (nw > BM_WORDS) nw = BM_WORDS;
     const int per = (nw + 255) / 256;
     const int w0 = tid * per, w1 = (w0 + per < nw) ? w0 + per : nw;
     int cnt = 0;
@@ -1330,7 +1339,11 @@ DVO_DEV void edt_rank_pack_body(const int bx, const int gx, const int by, const 
     int wave_off = 0, n_pal = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) { const int t = s_wave[w]; n_pal += t; if (w < wave) wave_off += t; }
-    if (n_pal > DVO_PAL_MAX - 1) { if (first_wg && tid == 0) pal_n[pair] = -(int)PAL_TOO_MANY; return; }
+    if (n_pal > DVO_PAL_MAX - 2 && unit_bits) { if (first_wg && tid == 0) pal_n[pair] = -(int)PAL_TOO_MANY; return; }
+    /* ranks kept: all of them, or -- too many for the 13-bit field / the LDS -- the lowest DVO_PAL_CAP_PARTIAL.  Palette layout:
+     * [0, cap) real entries, [cap] the zero sentinel (as ever), [cap + 1] the NaN entry (read by partial forms only) */
+    const int cap = (n_pal > DVO_PAL_MAX - 2) ? DVO_PAL_CAP_PARTIAL : n_pal;
+    const bool partial_known = far_img || cap < n_pal;
     {
         int run = wave_off + incl - cnt;
         for (int w = w0; w < w1; w++) { lpre[w] = (unsigned short)run; run += __popc(lbm[w]); }
@@ -1346,14 +1359,26 @@ DVO_DEV void edt_rank_pack_body(const int bx, const int gx, const int by, const 
                 const int b = __ffs((int)v) - 1;
                 v &= v - 1u;
                 const float P = edt_value((unsigned)(w * 32 + b), sc);
-                pal[r++] = make_float2(P, weight_of(P));         /* getWeightOf, SolveDVO.cpp:1047-1053 */
+                if (r < cap) pal[r] = make_float2(P, weight_of(P));         /* getWeightOf, SolveDVO.cpp:1047-1053 */
+                r++;
             }
         }
-        if (tid == 0) pal[n_pal] = make_float2(0.0f, 0.0f);      /* the sentinel entry */
-        if (tid < 32) p4[tid] = (unsigned)n_pal << 3;            /* the sentinel line */
+        if (tid == 0) {
+            const float qnan = __uint_as_float(0x7fc00000u);
+            pal[cap] = make_float2(0.0f, 0.0f);                  /* the sentinel entry */
+            pal[cap + 1] = make_float2(qnan, qnan);              /* the NaN entry (partial forms; never referenced otherwise) */
+            if (partial_known) atomicOr(flags + by, (int)EDT_FLAG_PARTIAL);
+        }
+        if (tid < 32) p4[tid] = (unsigned)cap << 3;              /* the sentinel line */
     }
     const int rshift = 31 - __clz(R);                           /* R is a power of two */
-    auto rank_of = [&](unsigned v) -> int { return (int)lpre[v >> 5] + __popc(lbm[v >> 5] & ((1u << (v & 31u)) - 1u)); };
+    const unsigned v_end = (unsigned)nw << 5;                    /* squared distances the bitmap holds */
+    const int nanr = cap + 1;                                    /* the NaN rank */
+    auto rank_of = [&](unsigned v) -> int {
+        if (v >= v_end) return nanr;                             /* beyond the bitmap */
+        const int r = (int)lpre[v >> 5] + __popc(lbm[v >> 5] & ((1u << (v & 31u)) - 1u));
+        return r < cap ? r : nanr;
+    };
     const int tpc = p4_tiles_per_col(rows);
     const int n_tcols = (cols + 3) >> 2;
     const int n_strips = (tiles_y + strip - 1) / strip;
@@ -1362,7 +1387,7 @@ DVO_DEV void edt_rank_pack_body(const int bx, const int gx, const int by, const 
      * 256 frames just to leave) */
     const int n_work = n_strips * ((n_tcols + PK_LC - 1) / PK_LC);
     int sy = 0, tc0 = 0, x0 = 0;
-    bool bad_step = false;
+    bool bad_step = false, nan_rank = false;
     /* A thread's share of a tile's pixels + one-pixel halo: 12 interior pixels and one of the halo.  d2 lies in row blocks of R
      * rows ([block][column][R]), so the 64 x 48 interior is walked in groups of 8 rows x 32 columns -- eight consecutive lanes
      * read one 32-byte run of a column, a wave 8 adjacent columns -- and the halo (2 rows, 2 columns) takes one more step.
@@ -1415,13 +1440,17 @@ DVO_DEV void edt_rank_pack_body(const int bx, const int gx, const int by, const 
             unsigned word = 0u;
             if (xx < cols && ys <= rows) {
                 const int lx = xx - x0, ly = ys - y0;
-                const int c = rk[lx * PK_H + ly];
-                word = (unsigned)c << 3;
+                int c = rk[lx * PK_H + ly];
                 if (srow >= 1 && srow <= DVO_P4_ROWS && ys < rows) {
-                    const int dr = (int)rk[(lx + 1) * PK_H + ly] - c, dl = (int)rk[(lx - 1) * PK_H + ly] - c;
-                    if (dr < -127 || dr > 127 || dl < -127 || dl > 127) bad_step = true;
-                    word |= (((unsigned)dr & 0xffu) << 16) | (((unsigned)dl & 0xffu) << 24);
+                    int dr = (int)rk[(lx + 1) * PK_H + ly] - c, dl = (int)rk[(lx - 1) * PK_H + ly] - c;
+                    if (dr < -127 || dr > 127 || dl < -127 || dl > 127) {
+                        if (unit_bits) bad_step = true;          /* float images: all or nothing */
+                        else { c = nanr; dr = 0; dl = 0; }       /* this pixel is looked up in the 16-byte texels (NaN rank) */
+                    }
+                    word = (((unsigned)dr & 0xffu) << 16) | (((unsigned)dl & 0xffu) << 24);
                 }
+                if (c == nanr) nan_rank = true;
+                word |= (unsigned)c << 3;
             }
             p4[32u + ((size_t)tc * tpc + ty) * 32u + wd] = word;
         }
@@ -1429,7 +1458,9 @@ DVO_DEV void edt_rank_pack_body(const int bx, const int gx, const int by, const 
     }
     }
     if (__syncthreads_or(bad_step ? 1 : 0) && tid == 0) atomicOr(flags + by, (int)EDT_FLAG_STEP);
-    if (first_wg && tid == 0) pal_n[pair] = n_pal;               /* EDT_FLAG_STEP overrides it in the fallback launch */
+    if (__syncthreads_or(nan_rank ? 1 : 0) && tid == 0) atomicOr(flags + by, (int)EDT_FLAG_PARTIAL);
+    /* EDT_FLAG_STEP / EDT_FLAG_PARTIAL are settled by the texel pass that follows (a launch boundary later: every workgroup's flag is in) */
+    if (first_wg && tid == 0) pal_n[pair] = cap | (partial_known ? DVO_PAL_PARTIAL : 0);
 }
 
 /* squared distances -> 16-byte texels in one pass (images without a compact form; everything when the caller wants no compact
@@ -1451,8 +1482,10 @@ DVO_DEV void dt_normalize_gradient_pack_body(const int bx, const int gx, const i
     if (pal_n) {                                             /* only the images the compact form could not hold */
         const int pair = first_pair + by;
         const bool step = (flags[by] & EDT_FLAG_STEP) != 0;
-        if (pal_n[pair] > 0 && !step) return;
+        const bool part = (flags[by] & EDT_FLAG_PARTIAL) != 0;     /* a partial compact form: the texels are the image's complete form */
+        if (pal_n[pair] > 0 && !step && !part) return;
         if (step && bx == 0 && threadIdx.x == 0) pal_n[pair] = -(int)PAL_STEP;   /* the other workgroups read the flag, not this */
+        else if (part && bx == 0 && threadIdx.x == 0 && pal_n[pair] > 0) pal_n[pair] |= DVO_PAL_PARTIAL;
     }
     /* sparse texel slabs (round 4): the host has not mapped texel memory for these pairs yet -- this pass only settles pal_n;
      * the host reads the palette sizes back, maps the texels of the (rare) images that need them and runs this pass again */
@@ -1569,7 +1602,7 @@ __global__ void __launch_bounds__(256)
 p4_decode_texels_kernel(const unsigned *__restrict__ p4, size_t p4_stride, const float2 *__restrict__ pal, const int *__restrict__ pal_n,
                         float4 *__restrict__ tex, size_t tex_stride, int rows, int cols, int first_pair) {
     const int pair = first_pair + blockIdx.y;
-    if (pal_n[pair] <= 0) return;
+    if (pal_n[pair] <= 0 || pal_partial(pal_n[pair])) return;      /* no compact form / a partial one: the texels were written with it */
     p4 += (size_t)pair * p4_stride;
     pal += (size_t)pair * DVO_PAL_MAX;
     tex += (size_t)pair * tex_stride;

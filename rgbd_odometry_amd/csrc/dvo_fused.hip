@@ -542,11 +542,17 @@ DVO_DEV void final2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints 
     }
 }
 template <int TEX, unsigned PAL>
-DVO_DEV void final2_store(const Final2 &b, int i0, int i1, int end, float *__restrict__ fe, float *__restrict__ fr) {
+DVO_DEV void final2_store(const Final2 &b, int i0, int i1, int end, float *__restrict__ fe, float *__restrict__ fr, const TexSrc &ts, bool partial) {
     float e0, e1;
     if constexpr (TEX == TEX_P4) {
         e0 = *(lds_cfloat *)(size_t)(PAL + (b.w0 & 0xfff8u));
         e1 = *(lds_cfloat *)(size_t)(PAL + (b.w1 & 0xfff8u));
+        /* a partial compact form (dvo_palette.h): a pixel it cannot express decodes to NaN -- its DT comes from the image's 16-byte
+         * texels (wave-uniform test; the rare lane pays one more load) */
+        if (partial && __builtin_amdgcn_ballot_w64((e0 != e0) || (e1 != e1)) != 0ull) {
+            if (e0 != e0) e0 = *reinterpret_cast<const float *>(ts.g16 + texel_byte_offset((int)b.v.x, (int)b.u.x, ts.tile_col_bytes));
+            if (e1 != e1) e1 = *reinterpret_cast<const float *>(ts.g16 + texel_byte_offset((int)b.v.y, (int)b.u.y, ts.tile_col_bytes));
+        }
     } else {
         e0 = b.vis0 ? __uint_as_float(b.w0) : 0.0f;
         e1 = b.vis1 ? __uint_as_float(b.w1) : 0.0f;
@@ -578,7 +584,7 @@ DVO_DEV void final2_store(const Final2 &b, int i0, int i1, int end, float *__res
 /* compact points [first, end) of this workgroup's share; outputs at fe[i], fr[3 i] */
 template <int BLOCK, bool LDS_SRC, int TEX, unsigned PAL, bool PT4 = false>
 DVO_DEV void final_outputs2(const IterConst &c, const TexSrc &ts, const LdsPoints &lp, const uint2 *__restrict__ gpts, int first, int end,
-                            float *__restrict__ fe, float *__restrict__ fr) {
+                            float *__restrict__ fe, float *__restrict__ fr, bool partial = false) {
     constexpr int STEP = 2 * BLOCK;
     const int tid = threadIdx.x;
     const int wave_first = first + __builtin_amdgcn_readfirstlane(tid & ~63);
@@ -596,17 +602,17 @@ DVO_DEV void final_outputs2(const IterConst &c, const TexSrc &ts, const LdsPoint
 #pragma clang loop unroll(disable)
     for (; r + 2 < n_rounds; r += 2) {
         final2_issue<LDS_SRC, TEX, PT4>(c, ts, lp, gpts, base + STEP, base + STEP + BLOCK, end, STEP, pf, B);
-        final2_store<TEX, PAL>(A, base, base + BLOCK, end, fe, fr);
+        final2_store<TEX, PAL>(A, base, base + BLOCK, end, fe, fr, ts, partial);
         final2_issue<LDS_SRC, TEX, PT4>(c, ts, lp, gpts, base + 2 * STEP, base + 2 * STEP + BLOCK, end, STEP, pf, A);
-        final2_store<TEX, PAL>(B, base + STEP, base + STEP + BLOCK, end, fe, fr);
+        final2_store<TEX, PAL>(B, base + STEP, base + STEP + BLOCK, end, fe, fr, ts, partial);
         base += 2 * STEP;
     }
     if (r + 1 < n_rounds) {
         final2_issue<LDS_SRC, TEX, PT4>(c, ts, lp, gpts, base + STEP, base + STEP + BLOCK, end, STEP, pf, B);
-        final2_store<TEX, PAL>(A, base, base + BLOCK, end, fe, fr);
-        final2_store<TEX, PAL>(B, base + STEP, base + STEP + BLOCK, end, fe, fr);
+        final2_store<TEX, PAL>(A, base, base + BLOCK, end, fe, fr, ts, partial);
+        final2_store<TEX, PAL>(B, base + STEP, base + STEP + BLOCK, end, fe, fr, ts, partial);
     } else {
-        final2_store<TEX, PAL>(A, base, base + BLOCK, end, fe, fr);
+        final2_store<TEX, PAL>(A, base, base + BLOCK, end, fe, fr, ts, partial);
     }
 }
 
@@ -887,12 +893,17 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         const int n_pad = (N + 3) & ~3;
         const int tex16_words = (int)(L.tex_stride * 4);
         /* the compact form of this pair's level, if the builder could make one (dvo_palette.h): its palette goes first */
-        const int n_pal = (!sc.no_p4 && L.pal_n) ? max(0, __builtin_amdgcn_readfirstlane(L.pal_n[dpair])) : 0;
+        const int pal_n_raw = (!sc.no_p4 && L.pal_n) ? __builtin_amdgcn_readfirstlane(L.pal_n[dpair]) : 0;
+        const int n_pal = pal_count(pal_n_raw);
+        /* a PARTIAL compact form (dvo_palette.h, round 5): pixels it cannot express decode to NaN; a wave that meets one redoes its
+         * share of the iteration on the image's 16-byte texels (the finiteness test below), the final pass patches them per lane */
+        const bool p4_partial = pal_partial(pal_n_raw);
         /* the compact form first: a now level written by the engine's own distance-transform stage has no other (its 16-byte
          * texels exist only once something asked for them, dvo_capi.cpp: ensure_tex16) */
-        const int mode = (n_pal > 0 && pal_base_ok && 2 * n_pal + 6 <= lds_words) ? TEX_P4
+        const int mode = (n_pal > 0 && pal_base_ok && 2 * n_pal + 8 <= lds_words) ? TEX_P4
                          : ((!TEAM && !sc.no_lds_tex && 2 * n_pad + tex16_words <= lds_words) ? TEX_L16 : TEX_G16);
-        const int pal_words = (mode == TEX_P4) ? ((2 * (n_pal + 1) + 3) & ~3) : 0;           /* + the sentinel entry {0, 0} */
+        const int n_pal_lds = n_pal + (p4_partial ? 2 : 1);                                   /* + the sentinel entry {0, 0} (+ a partial form's NaN entry) */
+        const int pal_words = (mode == TEX_P4) ? ((2 * n_pal_lds + 3) & ~3) : 0;
         /* 4-byte points (dvo_device_math.h: pt4_decode): when the builder validated this list's 4-byte twin, the throughput shape
          * reads that -- twice the points per LDS byte, half the bytes per streamed point.  Not in team mode (a member's share
          * does not start on a 64-point chunk). */
@@ -911,7 +922,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         if (mode == TEX_P4) {
             const float2 *__restrict__ pg = L.pal + (size_t)dpair * DVO_PAL_MAX;
             float2 *pl = reinterpret_cast<float2 *>(lds_dyn);
-            for (int i = tid; i <= n_pal; i += BLOCK) pl[i] = pg[i];
+            for (int i = tid; i < n_pal_lds; i += BLOCK) pl[i] = pg[i];
         }
         const unsigned *__restrict__ g4pts = L.cpt4 + (size_t)dpair * L.pt_cap + pfirst;
         if (pt4) {   /* 16-byte loads of four points, four in flight per lane */
@@ -1026,7 +1037,13 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             if (any_odd || sc.force_exact) {      /* wave-uniform; a point with a degenerate z: this wave's share again, literal divisions */
                 acc7_zero(a);
                 const float2 *pal_lds = reinterpret_cast<const float2 *>(lds_dyn);
-                if (mode == TEX_P4 && pt4) {
+                if (mode == TEX_P4 && p4_partial && pt4) {          /* partial form: the 16-byte texels are the complete image */
+                    accumulate_points_exact<BLOCK, true, false, true, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
+                    accumulate_points_exact<BLOCK, false, false, true, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
+                } else if (mode == TEX_P4 && p4_partial) {
+                    accumulate_points_exact<BLOCK, true, false, false, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
+                    accumulate_points_exact<BLOCK, false, false, false, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
+                } else if (mode == TEX_P4 && pt4) {
                     accumulate_points_exact<BLOCK, true, true, true, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
                     accumulate_points_exact<BLOCK, false, true, true, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
                 } else if (mode == TEX_P4) {
@@ -1122,11 +1139,11 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
                 float *fes = fe + pfirst, *frs = fr + 3 * (size_t)pfirst;
 #ifndef DVO_NO_FINAL
                 if (mode == TEX_P4 && pt4) {
-                    final_outputs2<BLOCK, true, TEX_P4, kStatic, true>(c, ts, lp, gpts, 0, n_lds, fes, frs);
-                    final_outputs2<BLOCK, false, TEX_P4, kStatic, true>(c, ts, lp, gpts, n_lds, N, fes, frs);
+                    final_outputs2<BLOCK, true, TEX_P4, kStatic, true>(c, ts, lp, gpts, 0, n_lds, fes, frs, p4_partial);
+                    final_outputs2<BLOCK, false, TEX_P4, kStatic, true>(c, ts, lp, gpts, n_lds, N, fes, frs, p4_partial);
                 } else if (mode == TEX_P4) {
-                    final_outputs2<BLOCK, true, TEX_P4, kStatic>(c, ts, lp, gpts, 0, n_lds, fes, frs);
-                    final_outputs2<BLOCK, false, TEX_P4, kStatic>(c, ts, lp, gpts, n_lds, N, fes, frs);
+                    final_outputs2<BLOCK, true, TEX_P4, kStatic>(c, ts, lp, gpts, 0, n_lds, fes, frs, p4_partial);
+                    final_outputs2<BLOCK, false, TEX_P4, kStatic>(c, ts, lp, gpts, n_lds, N, fes, frs, p4_partial);
                 } else if (mode == TEX_L16) {
                     final_outputs2<BLOCK, true, TEX_L16, kStatic>(c, ts, lp, gpts, 0, N, fes, frs);
                 } else {

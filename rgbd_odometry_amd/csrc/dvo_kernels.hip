@@ -287,8 +287,9 @@ replicate_compact_kernel(unsigned *p4, size_t p4_stride, float2 *pal, int *pal_n
     const int p = dst_first + blockIdx.y;
     const int src = blockIdx.y % n_src;
     if (p == src) return;
-    const int n = pal_n[src];
-    if (blockIdx.x == 0 && threadIdx.x == 0) pal_n[p] = n;
+    const int pn = pal_n[src];
+    if (blockIdx.x == 0 && threadIdx.x == 0) pal_n[p] = pn;
+    const int n = pal_count(pn);                   /* a partial form (DVO_PAL_PARTIAL) travels as it is */
     if (n <= 0) return;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const uint4 *s4 = reinterpret_cast<const uint4 *>(p4 + (size_t)src * p4_stride);       /* p4_stride % 32 == 0 */
@@ -296,7 +297,8 @@ replicate_compact_kernel(unsigned *p4, size_t p4_stride, float2 *pal, int *pal_n
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < p4_stride / 4; i += stride) d4[i] = s4[i];
     const float2 *sp = pal + (size_t)src * DVO_PAL_MAX;
     float2 *dp = pal + (size_t)p * DVO_PAL_MAX;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i <= (size_t)n; i += stride) dp[i] = sp[i];
+    const size_t n_copy = (size_t)n + (pal_partial(pn) ? 2 : 1);       /* + the zero sentinel (+ the NaN entry) */
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_copy; i += stride) dp[i] = sp[i];
 }
 hipError_t launch_replicate_compact(unsigned *p4, size_t p4_stride, float2 *pal, int *pal_n, int n_src, int dst_first,
                                     int dst_count, hipStream_t s) {

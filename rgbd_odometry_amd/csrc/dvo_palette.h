@@ -45,6 +45,17 @@
 #define DVO_PAL_MAX 8192          /* palette entries per (pair, level) incl. the sentinel: the 13-bit rank field of a word */
 #define DVO_PAL_BUILD_MAX 4096    /* limit of the GENERIC builder (dvo_palette.hip: LDS hash sets); the distance-transform path
                                      (dvo_frames.hip) ranks by a bitmap of squared distances and fills the whole format */
+/* PARTIAL compact forms (round 5; native builder only).  An image with more distinct distances than the palette holds, with a
+ * pixel beyond the range of the presence bitmap (512 px or more from every edge) or with a horizontal rank step beyond +-127 used
+ * to be REFUSED as a whole (pal_n = -reason: 16-byte texels for every look-up).  But the points of an alignment land near the now
+ * frame's edges, i.e. on SMALL distances = low ranks (the palette is sorted by distance).  A partial form keeps the lowest
+ * DVO_PAL_CAP_PARTIAL ranks; every other pixel -- and every pixel whose step does not fit -- carries the rank of a NaN entry
+ * {NaN, NaN} that every native palette now has (index count + 1, right after the zero sentinel at index count).  A look-up that meets it poisons
+ * its lane's sums; the kernel's once-per-iteration finiteness test then sends that wave through the literal scalar path on the
+ * image's 16-byte texels, which such an image also gets (pal_n carries DVO_PAL_PARTIAL: the texels are its complete form, the
+ * compact form its fast path).  bench.py `sparse_scenes`, tests/test_gpu_sparse_scenes.py. */
+#define DVO_PAL_PARTIAL (1 << 20)
+#define DVO_PAL_CAP_PARTIAL 4094
 #define DVO_P4_ROWS 6             /* interior image rows per 128-byte line (8 stored rows) */
 /* squared distances the native builder can rank: bits of the per-image presence bitmap (distances below 512 pixels) */
 #define DVO_EDT_BITMAP_BITS (1 << 18)
@@ -54,6 +65,10 @@ namespace dvo {
 /* reasons for "no compact form" (pal_n = -reason) */
 enum { PAL_BAD_VALUE = 1, PAL_TOO_MANY = 2, PAL_STEP = 3, PAL_GRADIENT = 4, PAL_WEIGHT = 5, PAL_SHAPE = 6, PAL_FAR = 7 };
 
+/* pal_n > 0: entries of the palette (the zero sentinel sits at that index, a partial form's NaN entry one further), with
+ * DVO_PAL_PARTIAL or-ed in for a partial form */
+__host__ __device__ inline int pal_count(int pal_n) { return pal_n > 0 ? (pal_n & (DVO_PAL_PARTIAL - 1)) : 0; }
+__host__ __device__ inline bool pal_partial(int pal_n) { return pal_n > 0 && (pal_n & DVO_PAL_PARTIAL) != 0; }
 __host__ __device__ inline int p4_tiles_per_col(int rows) { return (rows + DVO_P4_ROWS - 1) / DVO_P4_ROWS; }
 /* dwords of one image */
 __host__ __device__ inline size_t p4_count(int rows, int cols) {

@@ -116,8 +116,15 @@ extern "C" {
 int dvo_synth_level_rows(int H, int level) { return cv_round((double)H * std::ldexp(1.0, -level)); }
 int dvo_synth_level_cols(int W, int level) { return cv_round((double)W * std::ldexp(1.0, -level)); }
 
-dvo_synth_scene *dvo_synth_create(int W, int H, int n_levels, uint64_t seed) {
+dvo_synth_scene *dvo_synth_create(int W, int H, int n_levels, uint64_t seed) { return dvo_synth_create_ex(W, H, n_levels, seed, 0, 1.0); }
+
+/* n_seg <= 0 and x_frac >= 1: the scene of SURVEY.md section 8d (60 W/320 segments anywhere: 5-6 % edge pixels).  Otherwise a SPARSE
+ * scene (round 5): n_seg segments drawn only inside the columns [0, x_frac W) -- the rest of the frame has no edge at all, which is
+ * what camera images with sky / walls look like and what the bench's standard scenes never have (pixels hundreds of pixels from
+ * every edge: many distinct distances, far-from-edge tiles). */
+dvo_synth_scene *dvo_synth_create_ex(int W, int H, int n_levels, uint64_t seed, int n_seg_in, double x_frac) {
     if (W < 16 || H < 16 || n_levels < 1 || n_levels > 12) return nullptr;
+    if (!(x_frac > 0.0) || x_frac > 1.0) x_frac = 1.0;
     dvo_synth_scene *sc = new dvo_synth_scene();
     sc->W = W; sc->H = H; sc->n_levels = n_levels; sc->seed = seed;
     /* TUM / ROS-default intrinsics scaled to the level-0 size */
@@ -130,9 +137,10 @@ dvo_synth_scene *dvo_synth_create(int W, int H, int n_levels, uint64_t seed) {
     /* ---- level-0 reference edge mask: random segments, 0.5 px steps ---- */
     std::vector<int32_t> edge0((size_t)W * H, 0);
     const double sW = (double)W / 320.0;
-    const int n_seg = cv_round(60.0 * sW);
+    const int n_seg = n_seg_in > 0 ? n_seg_in : cv_round(60.0 * sW);
+    const int x_end = (x_frac >= 1.0) ? W : std::max(8, (int)(x_frac * W));
     for (int k = 0; k < n_seg; k++) {
-        const double x0 = rng.uniform(0.0, (double)W);
+        const double x0 = rng.uniform(0.0, (double)x_end);
         const double y0 = rng.uniform(0.0, (double)H);
         const double ang = rng.uniform(0.0, M_PI);
         const double len = rng.uniform(20.0, 120.0) * sW;
@@ -140,7 +148,7 @@ dvo_synth_scene *dvo_synth_create(int W, int H, int n_levels, uint64_t seed) {
         for (double s = 0.0; s <= len; s += 0.5) {
             const int x = (int)std::floor(x0 + s * dx);
             const int y = (int)std::floor(y0 + s * dy);
-            if (x >= 0 && x < W && y >= 0 && y < H) edge0[(size_t)x * H + y] = 255;
+            if (x >= 0 && x < x_end && y >= 0 && y < H) edge0[(size_t)x * H + y] = 255;
         }
     }
     /* ---- level-0 reference depth (mm, quantised like a u16 sensor image) ---- */

@@ -16,6 +16,8 @@ int dvo_synth_level_rows(int H, int level);
 int dvo_synth_level_cols(int W, int level);
 
 dvo_synth_scene *dvo_synth_create(int W, int H, int n_levels, uint64_t seed);
+/* sparse scenes: n_seg segments (<= 0: the default 60 W/320) drawn inside the columns [0, x_frac W) only */
+dvo_synth_scene *dvo_synth_create_ex(int W, int H, int n_levels, uint64_t seed, int n_seg, double x_frac);
 void dvo_synth_destroy(dvo_synth_scene *sc);
 
 int dvo_synth_rows(const dvo_synth_scene *sc, int level);

@@ -24,6 +24,8 @@ def _load():
     lib = C.CDLL(path)
     lib.dvo_synth_create.restype = C.c_void_p
     lib.dvo_synth_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64]
+    lib.dvo_synth_create_ex.restype = C.c_void_p
+    lib.dvo_synth_create_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_double]
     lib.dvo_synth_destroy.argtypes = [C.c_void_p]
     for n in ("rows", "cols"):
         getattr(lib, "dvo_synth_" + n).argtypes = [C.c_void_p, C.c_int]
@@ -51,9 +53,10 @@ class SynthScene:
     reference's Eigen::MatrixXf members.
     """
 
-    def __init__(self, W: int, H: int, n_levels: int, seed: int):
+    def __init__(self, W: int, H: int, n_levels: int, seed: int, n_seg: int = 0, x_frac: float = 1.0):
+        """n_seg / x_frac: a SPARSE scene -- n_seg segments drawn inside the columns [0, x_frac W) only (default: SURVEY.md 8d's scene)"""
         lib = _load()
-        h = lib.dvo_synth_create(W, H, n_levels, seed)
+        h = lib.dvo_synth_create_ex(W, H, n_levels, seed, int(n_seg), float(x_frac)) if (n_seg > 0 or x_frac < 1.0) else lib.dvo_synth_create(W, H, n_levels, seed)
         if not h:
             raise ValueError("dvo_synth_create failed (bad size/levels)")
         try:

@@ -192,9 +192,11 @@ def test_native_compact_replicated_batch_and_overwrite(oracle):
             assert ctx.level_texel_mode(p, 0) == (0 if p == 4 else 2), p
 
 
-def test_native_compact_refusals_fall_back_to_16_byte_texels(oracle):
-    """images the native builder cannot hold: a pixel 512 or more pixels from every edge (-7); the same launch writes their
-    16-byte texels instead, results are the oracle's all the same"""
+def test_native_builder_writes_a_partial_form_for_images_it_cannot_hold(oracle):
+    """an image the compact form cannot hold completely -- here: pixels 512 or more pixels from every edge (rounds 3-4 refused it,
+    -7) -- gets a PARTIAL compact form (round 5, dvo_palette.h): the pixels it cannot express carry the rank of a NaN palette entry,
+    the same launch writes the image's 16-byte texels, and a wave whose look-up meets the NaN redoes its share of the iteration on
+    those (this image has two edge pixels: nearly every look-up is far from them).  Results are the oracle's all the same."""
     from rgbd_odometry_amd import DvoContext
     rows, cols = 40, 700
     edge = np.zeros(rows * cols, np.uint8)
@@ -209,12 +211,12 @@ def test_native_compact_refusals_fall_back_to_16_byte_texels(oracle):
         ctx.set_intrinsics(*K)
         xyz, _ = ctx.set_ref_level_from_images(0, ref_edge, depth, rows, cols)
         ctx.set_now_level_from_edges(0, edge, rows, cols)
-        assert ctx.now_compact_info(0, 0) == -7
+        assert ctx.now_compact_info(0, 0) > 0 and ctx.now_compact_partial(0, 0)
         d2, g2, h2 = ctx.get_now_level(0)
         assert _same(d2, dt) and _same(g2, gx) and _same(h2, gy)
         ref = oracle.run_iterations(0, 6, xyz, dt, gx, gy, rows, cols, K, np.eye(3), np.zeros(3))
         got = ctx.run_iterations(0, 6, np.eye(3), np.zeros(3))
-        assert ctx.level_texel_mode(0, 0) in (0, 1)
+        assert ctx.level_texel_mode(0, 0) == 2 and ctx.level_exact_fallback(0, 0)      # the compact form, and waves that met the NaN rank
         assert _same(ref["energy"], got["energy"])
         assert _same(ref["final_eps"], got["final_eps"]) and _same(ref["final_reproj"], got["final_reproj"])
         # an image with no edge pixel at all is refused by the entry point (the distance transform is undefined)
@@ -222,14 +224,14 @@ def test_native_compact_refusals_fall_back_to_16_byte_texels(oracle):
             ctx.set_now_level_from_edges(0, np.zeros(rows * cols, np.uint8), rows, cols)
 
 
-def test_replicating_a_refused_source_carries_its_texels(oracle):
-    """a source whose image the compact form could not hold (pal_n <= 0) has 16-byte texels as its REAL form; replicating
-    it must copy them (and, on a sparse texel slab, map memory behind the destinations') -- beside a second source that has the
-    compact form only.  Both kinds of destination then give their source's oracle results.  (tests/test_gpu_capacity.py runs this
+def test_replicating_a_source_with_real_texels_carries_them(oracle):
+    """a source whose image the compact form cannot hold completely (a partial form since round 5; refused before) has 16-byte
+    texels as its complete form; replicating it must copy them (and, on a sparse texel slab, map memory behind the destinations') --
+    beside a second source that has the compact form only.  Both kinds of destination then give their source's oracle results.  (tests/test_gpu_capacity.py runs this
     file again with DVO_TEX_SLAB=sparse.)"""
     from rgbd_odometry_amd import DvoContext
     rows, cols = 40, 700
-    far = np.zeros(rows * cols, np.uint8)                       # refused: pixels 512 or more from every edge (-7)
+    far = np.zeros(rows * cols, np.uint8)                       # pixels 512 or more from every edge: a partial form + real texels (round 5)
     far[5 + 3 * rows] = 255
     far[7 + 20 * rows] = 255
     rng = np.random.default_rng(11)
@@ -244,7 +246,7 @@ def test_replicating_a_refused_source_carries_its_texels(oracle):
         for p, e in enumerate((far, dense)):
             xyz, _ = ctx.set_ref_level_from_images(0, ref_edge, depth, rows, cols, pair=p)
             ctx.set_now_level_from_edges(0, e, rows, cols, pair=p)
-        assert ctx.now_compact_info(0, 0) == -7 and ctx.now_compact_info(1, 0) > 0
+        assert ctx.now_compact_partial(0, 0) and ctx.now_compact_info(1, 0) > 0 and not ctx.now_compact_partial(1, 0)
         ctx.replicate_pairs(2)
         assert [ctx.now_compact_info(p, 0) for p in range(B)] == [ctx.now_compact_info(p % 2, 0) for p in range(B)]
         refs = []
@@ -261,8 +263,8 @@ def test_replicating_a_refused_source_carries_its_texels(oracle):
             e, b, ratio = ctx.level_report(p, 0, 6)
             ref = refs[p % 2][3]
             assert _same(e, ref["energy"]) and b == ref["best_idx"], p
-            mode = ctx.level_texel_mode(p, 0) & 3
-            assert (mode == 2) if p % 2 else (mode in (0, 1)), (p, mode)      # the compact form / the 16-byte texels
+            assert (ctx.level_texel_mode(p, 0) & 3) == 2, p                 # the compact form: complete (odd pairs) or partial (even pairs)
+            assert ctx.now_compact_partial(p, 0) == (p % 2 == 0), p
 
 
 def test_compact_now_is_built_for_a_level_that_keeps_being_aligned(oracle):
