@@ -301,6 +301,8 @@ int  dvo_get_level_exact_fallback(dvo_ctx *ctx, int pair, int level, int *ran);
  * whole millimetres + chunk headers, validated bit for bit against the 8-byte list when the list is built; taken for lists
  * of at least three times what fits in LDS, where the per-iteration stream of the rest dominates the memory requests).  Tests. */
 int  dvo_get_level_points4(dvo_ctx *ctx, int pair, int level, int *used);
+/* 1 if the last fused launch read that level's ranks from an LDS copy of the whole level (coarse levels of large batches, round 5) */
+int  dvo_get_level_ranks_in_lds(dvo_ctx *ctx, int pair, int level, int *used);
 
 /* Shape the engine chose for the last fused (batch) launch: threads per workgroup (256: two workgroups per compute unit,
  * 512 / 1024: one), workgroups per frame pair (team mode, 1 = none), packed = 1: the two-points-per-lane kernel.  Inspection. */

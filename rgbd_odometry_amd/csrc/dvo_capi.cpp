@@ -645,6 +645,8 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
     {   /* A/B switch: DVO_TEAM_PLAIN_STORES=off keeps every team record on the sc1 (cross-XCD) form */
         static const bool no_plain = [] { const char *e = std::getenv("DVO_TEAM_PLAIN_STORES"); return e && std::strcmp(e, "off") == 0; }();
         sc.team_no_plain = no_plain ? 1 : 0;
+        static const bool no_r16 = [] { const char *e = std::getenv("DVO_RANKS_LDS"); return e && std::strcmp(e, "off") == 0; }();
+        sc.no_r16 = no_r16 ? 1 : 0;
     }
     c->team_used = false;
     if (sc.compact && c->prm.engine_variant != 1 && !(sc.flags & DVO_FLAG_NORMAL_MATRIX) && block == 512 && c->prm.team_size != 1) {
@@ -1804,6 +1806,17 @@ int dvo_get_level_points4(dvo_ctx *c, int pair, int level, int *used) {
     int v = -1;
     HIPCHK(c, hipMemcpy(&v, c->d_tex_mode + (size_t)pair * DVO_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
     *used = (v >= 0 && (v & DVO_TEXMODE_PT4)) ? 1 : 0;
+    return DVO_OK;
+}
+/* 1 if the last fused launch looked that level's ranks up in an LDS copy of the whole level (round 5: coarse levels whose compact form
+ * fits the LDS beside palette and points; dvo_get_level_texel_mode says 2 = compact form for them) */
+int dvo_get_level_ranks_in_lds(dvo_ctx *c, int pair, int level, int *used) {
+    DVO_ENTER(c);
+    if (!pair_ok(c, pair) || !level_ok(level) || !used) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    HIPCHK(c, stream_wait(c->stream));
+    int v = -1;
+    HIPCHK(c, hipMemcpy(&v, c->d_tex_mode + (size_t)pair * DVO_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
+    *used = (v >= 0 && (v & DVO_TEXMODE_RANKS_LDS)) ? 1 : 0;
     return DVO_OK;
 }
 int dvo_get_level_exact_fallback(dvo_ctx *c, int pair, int level, int *ran) {

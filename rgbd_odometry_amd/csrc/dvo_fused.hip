@@ -90,8 +90,13 @@ DVO_DEV void acc_h_add(ACC &a, const double *jwd, const double *Jd) {
  *   TEX_P4   the compact form of dvo_palette.h: ONE 12-byte gather per point fetches the rank words of the pixel above, the
  *            pixel and the pixel below (24 pixels per 128-byte line instead of 8: half the memory requests); DT, w and the
  *            four neighbour values come from the level's palette in LDS, gx = 0.5*(P[r]-P[l]), gy = 0.5*(P[d]-P[u]) -- the
- *            builder verified per pixel that this reproduces the 16-byte texel bit for bit */
-enum { TEX_G16 = DVO_TEXMODE_GLOBAL16, TEX_L16 = DVO_TEXMODE_LDS16, TEX_P4 = DVO_TEXMODE_PAL4 };
+ *            builder verified per pixel that this reproduces the 16-byte texel bit for bit
+ *   TEX_R16  (round 5) a coarse level whose compact form fits the LDS beside its palette and points: the centre ranks of the whole
+ *            level, as 16-bit palette byte offsets with a one-pixel reflected border, staged once per level -- a point's five ranks
+ *            are five ds_read_u16 at fixed offsets around its pixel and the level's iterations never touch its lines in HBM again
+ *            (the reference re-copies the three now images every iteration, SolveDVO.cpp:310,316-317,427).  Reported as TEX_P4 with
+ *            the flag DVO_TEXMODE_RANKS_LDS. */
+enum { TEX_G16 = DVO_TEXMODE_GLOBAL16, TEX_L16 = DVO_TEXMODE_LDS16, TEX_P4 = DVO_TEXMODE_PAL4, TEX_R16 = 3 };
 
 struct TexSrc {
     const char *g16;           /* this pair's level in HBM, tiled 16-byte texels */
@@ -99,6 +104,9 @@ struct TexSrc {
     const char *l16;           /* LDS copy of the same bytes (TEX_L16) */
     const char *p4;            /* this pair's level in HBM, compact form (TEX_P4) */
     unsigned p4_col_bytes;     /* p4_tiles_per_col * 128 */
+    /* TEX_R16: LDS byte addresses of the padded rank image -- element (yy, xx) at r16_org + (xx + 1) * r16_col_bytes + (yy + 1) * 2 --
+     * and of the centre of the sentinel block (all five reads of a lane without a visible point land on the zero entry's offset) */
+    unsigned r16_org, r16_col_bytes, r16_sent;
 };
 
 /* three consecutive dwords at any 4-byte boundary (one global_load_dwordx3) */
@@ -114,6 +122,11 @@ template <> struct Round2<TEX_P4> {
     v2f xn, yn, zn;
     U3 t0, t1;         /* rank words above / at / below the two pixels (the sentinel line for a lane without a visible point) */
 };
+template <> struct Round2<TEX_R16> {
+    v2f xn, yn, zn;
+    unsigned c0, u0, d0, l0, r0, c1, u1, d1, l1, r1;      /* palette byte offsets of the pixel and its four neighbours, per point */
+};
+typedef const __attribute__((address_space(3))) unsigned short lds_cushort;
 
 /* LDS address of the palette = start of the dynamic LDS = size of the kernel's static block (checked at run time) */
 typedef const __attribute__((address_space(3))) float lds_cfloat;
@@ -185,10 +198,12 @@ DVO_DEV unsigned stream_word(const unsigned *__restrict__ p) {
     return *p;
 #endif
 }
-template <bool LDS_SRC, int TEX, bool PT4 = false>
+/* FULL: the caller knows that every lane of the wave has a point in this round (every round but a wave's last): no "past the end"
+ * masks.  (make EXP=nodiet EXPDEFS=-DDVO_NO_VALU_DIET=1 builds the round-4 form of the compact-form issue stage for the A/B.) */
+template <bool LDS_SRC, int TEX, bool PT4 = false, bool FULL = false>
 DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints &lp, const uint2 *__restrict__ gpts,
                           int i0, int i1, int end, int step, PointPf &pf, Round2<TEX> &b, bool &any_odd, int &nvis) {
-    const bool valid0 = i0 < end, valid1 = i1 < end;
+    const bool valid0 = FULL || i0 < end, valid1 = FULL || i1 < end;
     v2f xx, yy, Z;
     if constexpr (PT4) {
         unsigned w0, w1;
@@ -227,6 +242,37 @@ DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints 
     const v2f X = (Z * (xx - c.pcx)) * c.pfx;                               /* :249 */
     const v2f Y = (Z * (yy - c.pcy)) * c.pfy;                               /* :250 */
     v2f xn, yn, zn, u, v;
+#ifndef DVO_NO_VALU_DIET
+    if constexpr (TEX == TEX_P4 || TEX == TEX_R16) {
+        /* every condition of this path is a lane mask in scalar registers (dvo_point_pk.h): the degenerate-z flag, the visible counts
+         * and the selects cost no vector instruction beyond the comparisons themselves.  Round 4 measured this diet as a LOSS (-2 %:
+         * at the HBM ceiling a faster issue stage only deepened the queues); with round 5's shorter serial chain it is +3 % at
+         * 640x480x4 (762 k -> 787 k aligns/s at 8192 pairs), +1-2 % at 1920x1080x5: profiles/r05_experiments/point_loop_ab.txt */
+        lanemask odd;
+        project_point2m(c, X, Y, Z, xn, yn, zn, u, v, odd);
+        any_odd |= (odd != 0ull);
+        int px0, py0, px1, py1;
+        const lanemask in0 = pixel_in_range_mask(u.x, c.cols, px0) & pixel_in_range_mask(v.x, c.rows, py0);
+        const lanemask in1 = pixel_in_range_mask(u.y, c.cols, px1) & pixel_in_range_mask(v.y, c.rows, py1);
+        const lanemask vis0 = FULL ? in0 : (in0 & mask_lt_i32(i0, end)), vis1 = FULL ? in1 : (in1 & mask_lt_i32(i1, end));
+        b.xn = xn; b.yn = yn; b.zn = zn;
+        nvis += __popcll(vis0) + __popcll(vis1);
+        if constexpr (TEX == TEX_R16) {
+            const unsigned a0 = select_or(vis0, ts.r16_org + __umul24((unsigned)px0 + 1u, ts.r16_col_bytes) + ((unsigned)py0 << 1), ts.r16_sent);
+            const unsigned a1 = select_or(vis1, ts.r16_org + __umul24((unsigned)px1 + 1u, ts.r16_col_bytes) + ((unsigned)py1 << 1), ts.r16_sent);
+            b.u0 = *(lds_cushort *)(size_t)(a0);     b.c0 = *(lds_cushort *)(size_t)(a0 + 2u); b.d0 = *(lds_cushort *)(size_t)(a0 + 4u);
+            b.l0 = *(lds_cushort *)(size_t)(a0 + 2u - ts.r16_col_bytes); b.r0 = *(lds_cushort *)(size_t)(a0 + 2u + ts.r16_col_bytes);
+            b.u1 = *(lds_cushort *)(size_t)(a1);     b.c1 = *(lds_cushort *)(size_t)(a1 + 2u); b.d1 = *(lds_cushort *)(size_t)(a1 + 4u);
+            b.l1 = *(lds_cushort *)(size_t)(a1 + 2u - ts.r16_col_bytes); b.r1 = *(lds_cushort *)(size_t)(a1 + 2u + ts.r16_col_bytes);
+        } else {
+            const unsigned o0 = select_or_zero(vis0, p4_byte_offset(py0, px0, ts.p4_col_bytes));     /* else the sentinel line */
+            const unsigned o1 = select_or_zero(vis1, p4_byte_offset(py1, px1, ts.p4_col_bytes));
+            b.t0 = *reinterpret_cast<const U3 *>(ts.p4 + o0);
+            b.t1 = *reinterpret_cast<const U3 *>(ts.p4 + o1);
+        }
+        return;
+    }
+#endif
     bool odd0, odd1;
     project_point2(c, X, Y, Z, xn, yn, zn, u, v, odd0, odd1);
     /* a lane past the end of the list re-reads the last point: if THAT one is degenerate the wave takes the exact path as
@@ -241,7 +287,19 @@ DVO_DEV void round2_issue(const IterConst &c, const TexSrc &ts, const LdsPoints 
     /* a lane without a visible point keeps its (finite: see any_odd) coordinates: its w and eps are exact zeros, so it adds
      * exact zeros to every sum (tests/test_gpu_packed_kernel.py::test_degenerate_depth_takes_the_exact_fallback, team shares) */
     b.xn = xn; b.yn = yn; b.zn = zn;
-    if constexpr (TEX == TEX_P4) {
+    if constexpr (TEX == TEX_R16) {
+        nvis += __popcll(__builtin_amdgcn_ballot_w64(vis0)) + __popcll(__builtin_amdgcn_ballot_w64(vis1));
+        /* address of the element ABOVE the pixel (the three of a column are 2 bytes apart); the sentinel block for a lane without
+         * a visible point */
+        unsigned a0 = ts.r16_org + __umul24((unsigned)px0 + 1u, ts.r16_col_bytes) + ((unsigned)py0 << 1);
+        unsigned a1 = ts.r16_org + __umul24((unsigned)px1 + 1u, ts.r16_col_bytes) + ((unsigned)py1 << 1);
+        a0 = vis0 ? a0 : ts.r16_sent;
+        a1 = vis1 ? a1 : ts.r16_sent;
+        b.u0 = *(lds_cushort *)(size_t)(a0);     b.c0 = *(lds_cushort *)(size_t)(a0 + 2u); b.d0 = *(lds_cushort *)(size_t)(a0 + 4u);
+        b.l0 = *(lds_cushort *)(size_t)(a0 + 2u - ts.r16_col_bytes); b.r0 = *(lds_cushort *)(size_t)(a0 + 2u + ts.r16_col_bytes);
+        b.u1 = *(lds_cushort *)(size_t)(a1);     b.c1 = *(lds_cushort *)(size_t)(a1 + 2u); b.d1 = *(lds_cushort *)(size_t)(a1 + 4u);
+        b.l1 = *(lds_cushort *)(size_t)(a1 + 2u - ts.r16_col_bytes); b.r1 = *(lds_cushort *)(size_t)(a1 + 2u + ts.r16_col_bytes);
+    } else if constexpr (TEX == TEX_P4) {
         nvis += __popcll(__builtin_amdgcn_ballot_w64(vis0)) + __popcll(__builtin_amdgcn_ballot_w64(vis1));
         unsigned o0 = p4_byte_offset(py0, px0, ts.p4_col_bytes);
         unsigned o1 = p4_byte_offset(py1, px1, ts.p4_col_bytes);
@@ -310,7 +368,19 @@ template <int TEX, unsigned PAL, typename ACC>
 DVO_DEV void round2_compute(const IterConst &c, const Round2<TEX> &b, ACC &a) {
     v2f jw[6], J[6];
     float eps0, eps1;
-    if constexpr (TEX == TEX_P4) {
+    if constexpr (TEX == TEX_R16) {
+        /* the ranks arrive as palette byte offsets: five look-ups per point at the compile-time palette address, no decoding */
+        const v2f pw0 = *(lds_cv2f *)(size_t)(PAL + b.c0), pw1 = *(lds_cv2f *)(size_t)(PAL + b.c1);
+        v2f pu, pd, pr, pl, dt, wt;
+        pu.x = *(lds_cfloat *)(size_t)(PAL + b.u0); pu.y = *(lds_cfloat *)(size_t)(PAL + b.u1);
+        pd.x = *(lds_cfloat *)(size_t)(PAL + b.d0); pd.y = *(lds_cfloat *)(size_t)(PAL + b.d1);
+        pr.x = *(lds_cfloat *)(size_t)(PAL + b.r0); pr.y = *(lds_cfloat *)(size_t)(PAL + b.r1);
+        pl.x = *(lds_cfloat *)(size_t)(PAL + b.l0); pl.y = *(lds_cfloat *)(size_t)(PAL + b.l1);
+        dt.x = pw0.x; dt.y = pw1.x; wt.x = pw0.y; wt.y = pw1.y;
+        const v2f gx = (pr - pl) * 0.5f, gy = (pd - pu) * 0.5f;          /* imageGradient, SolveDVO.cpp:1063-1098 */
+        eps0 = dt.x; eps1 = dt.y;
+        jacobian_weighted2p(c, b.xn, b.yn, b.zn, gx, gy, wt, jw, ACC::with_h ? J : nullptr);
+    } else if constexpr (TEX == TEX_P4) {
         v2f dt, gx, gy, wt;
         p4_decode2<PAL>(b.t0, b.t1, dt, gx, gy, wt);        /* zeros for a lane without a visible point (sentinel) */
         eps0 = dt.x; eps1 = dt.y;
@@ -369,6 +439,11 @@ DVO_DEV void accumulate_points2(const IterConst &c, const TexSrc &ts, const LdsP
     const int n_rounds = (end - first - wave_off + STEP - 1) / STEP;
     if (n_rounds <= 0) return;
 #define DVO_ISSUE(buf, k) round2_issue<LDS_SRC, TEX, PT4>(c, ts, lp, gpts, base + (k) * STEP, base + (k) * STEP + BLOCK, end, STEP, pf, buf, any_odd, a.nvis)
+#ifndef DVO_NO_VALU_DIET
+#define DVO_ISSUE_FULL(buf, k) round2_issue<LDS_SRC, TEX, PT4, true>(c, ts, lp, gpts, base + (k) * STEP, base + (k) * STEP + BLOCK, end, STEP, pf, buf, any_odd, a.nvis)
+#else
+#define DVO_ISSUE_FULL(buf, k) DVO_ISSUE(buf, k)
+#endif
 #define DVO_COMPUTE(buf) round2_compute<TEX, PAL, ACC>(c, buf, a)
     int base = first + lane_off;
     PointPf pf;
@@ -385,9 +460,9 @@ DVO_DEV void accumulate_points2(const IterConst &c, const TexSrc &ts, const LdsP
         DVO_ISSUE(A, 0);
         if (n_rounds > 1) DVO_ISSUE(B, 1);
         int r = 0;
-        for (; r + 4 < n_rounds; r += 3) {
-            DVO_ISSUE(C, 2); DVO_COMPUTE(A);
-            DVO_ISSUE(A, 3); DVO_COMPUTE(B);
+        for (; r + 4 < n_rounds; r += 3) {                     /* rounds r + 2 and r + 3 are not the wave's last */
+            DVO_ISSUE_FULL(C, 2); DVO_COMPUTE(A);
+            DVO_ISSUE_FULL(A, 3); DVO_COMPUTE(B);
             DVO_ISSUE(B, 4); DVO_COMPUTE(C);
             base += 3 * STEP;
         }
@@ -408,7 +483,7 @@ DVO_DEV void accumulate_points2(const IterConst &c, const TexSrc &ts, const LdsP
         DVO_ISSUE(A, 0);
         int r = 0;
         for (; r + 2 < n_rounds; r += 2) {
-            DVO_ISSUE(B, 1); DVO_COMPUTE(A);
+            DVO_ISSUE_FULL(B, 1); DVO_COMPUTE(A);
             DVO_ISSUE(A, 2); DVO_COMPUTE(B);
             base += 2 * STEP;
         }
@@ -421,6 +496,7 @@ DVO_DEV void accumulate_points2(const IterConst &c, const TexSrc &ts, const LdsP
         }
     }
 #undef DVO_ISSUE
+#undef DVO_ISSUE_FULL
 #undef DVO_COMPUTE
 }
 
@@ -904,6 +980,24 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
                          : ((!TEAM && !sc.no_lds_tex && 2 * n_pad + tex16_words <= lds_words) ? TEX_L16 : TEX_G16);
         const int n_pal_lds = n_pal + (p4_partial ? 2 : 1);                                   /* + the sentinel entry {0, 0} (+ a partial form's NaN entry) */
         const int pal_words = (mode == TEX_P4) ? ((2 * n_pal_lds + 3) & ~3) : 0;
+        /* TEX_R16 (round 5): the level's ranks as 16-bit palette byte offsets in LDS, with a one-pixel reflected border and a block of
+         * sentinel elements -- when that fits beside the palette and at least four rounds of points.  Not in team mode (every member
+         * would stage the whole level), not on the level whose final outputs are produced (that pass reads the rank words). */
+        const int r16_col = L.rows + 2;                                                       /* elements per padded column */
+        const int r16_elems = r16_col * (L.cols + 2) + 2 * r16_col + 4;                       /* + the sentinel block */
+        const int r16_words = ((r16_elems + 1) / 2 + 3) & ~3;
+#ifdef DVO_ENABLE_R16
+        constexpr bool kR16 = !WITH_H;
+#else
+        /* MEASURED AND NOT TAKEN (profiles/r05_experiments/r16_ab.txt): 640x480x4 at 8192 pairs 744 k aligns/s with the ranks of levels 2
+         * and 3 in LDS against 765 k without (-2.8 %), 1024 pairs -3 %, 1920x1080x5 -1.6 %, 320x240x4x50 +1 % -- the coarse levels' lines
+         * are L2 hits anyway, and staging 25 k elements per pair costs more than their look-ups save.  The code stays for the record:
+         * make EXP=r16 EXPDEFS=-DDVO_ENABLE_R16=1 (then DVO_RANKS_LDS=off switches it off at run time). */
+        constexpr bool kR16 = false;
+#endif
+        const bool r16 = kR16 && !TEAM && mode == TEX_P4 && !sc.no_r16 && !((sc.flags & 1) && l == sc.last_level) &&
+                         pal_words + r16_words + 8 * BLOCK <= lds_words;
+        const int img_words = r16 ? r16_words : 0;
         /* 4-byte points (dvo_device_math.h: pt4_decode): when the builder validated this list's 4-byte twin, the throughput shape
          * reads that -- twice the points per LDS byte, half the bytes per streamed point.  Not in team mode (a member's share
          * does not start on a 64-point chunk). */
@@ -911,11 +1005,11 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
          * the kernel is as close to its instruction-issue ceiling as to the request ceiling.  Measured A/B (DVO_POINTS4=off):
          * 640x480 level 0 (14.8 k points, 8.2 k fit as 8-byte points) 723 k vs 731 k aligns/s -- a wash, so not taken;
          * 1920x1080 (130 k / 67 k points against 19 k that fit) 77.5 k vs 75.0 k.  Taken from three times the LDS capacity. */
-        const bool pt4 = !TEAM && mode == TEX_P4 && !sc.no_pt4 && N >= sc.pt4_factor * (((lds_words - pal_words) >> 1) & ~1) && L.pt4_ok &&
+        const bool pt4 = !TEAM && mode == TEX_P4 && !r16 && !sc.no_pt4 && N >= sc.pt4_factor * (((lds_words - pal_words - img_words) >> 1) & ~1) && L.pt4_ok &&
                          __builtin_amdgcn_readfirstlane(L.pt4_ok[dpair]) != 0;
-        float *const lds_pts = lds_dyn + pal_words;
+        float *const lds_pts = lds_dyn + pal_words + img_words;
         const int cap = (mode == TEX_L16) ? n_pad
-                        : (pt4 ? ((lds_words - pal_words) & ~1) : (((lds_words - pal_words) >> 1) & ~1));      /* points the LDS holds */
+                        : (pt4 ? ((lds_words - pal_words - img_words) & ~1) : (((lds_words - pal_words - img_words) >> 1) & ~1));      /* points the LDS holds */
         const int n_lds = (N <= cap) ? N : (cap / (2 * BLOCK)) * (2 * BLOCK);      /* whole rounds only */
         float *const lds_tex = lds_pts + 2 * cap;
         if (tid == 0) st.exact_ran = 0;
@@ -978,6 +1072,26 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         ts.l16 = reinterpret_cast<const char *>(lds_tex);
         ts.p4 = reinterpret_cast<const char *>(L.p4 + (size_t)dpair * L.p4_stride);
         ts.p4_col_bytes = (unsigned)p4_tiles_per_col(L.rows) * 128u;
+        ts.r16_org = kStatic + 4u * (unsigned)pal_words;
+        ts.r16_col_bytes = 2u * (unsigned)r16_col;
+        ts.r16_sent = ts.r16_org + 2u * (unsigned)(r16_col * (L.cols + 2) + r16_col);        /* the element above the centre of the sentinel block */
+        if (r16) {
+            /* one padded column per wave at a time: element (yy, xx) <- the centre rank word of pixel (reflect101(yy), reflect101(xx)),
+             * its rank field as it is (rank * 8 = the palette byte offset) */
+            unsigned short *img = reinterpret_cast<unsigned short *>(lds_dyn + pal_words);
+            const int wv = tid >> 6, ln = tid & 63;
+            for (int xc = wv; xc < L.cols + 2; xc += BLOCK / 64) {
+                int xx = xc - 1;
+                xx = xx < 0 ? -xx : (xx >= L.cols ? 2 * L.cols - 2 - xx : xx);
+                for (int yc = ln; yc < r16_col; yc += 64) {
+                    int yy = yc - 1;
+                    yy = yy < 0 ? -yy : (yy >= L.rows ? 2 * L.rows - 2 - yy : yy);
+                    const unsigned w = *reinterpret_cast<const unsigned *>(ts.p4 + p4_byte_offset(yy, xx, ts.p4_col_bytes) + 4u);
+                    img[xc * r16_col + yc] = (unsigned short)(w & 0xfff8u);
+                }
+            }
+            for (int i = tid; i < 2 * r16_col + 4; i += BLOCK) img[r16_col * (L.cols + 2) + i] = (unsigned short)(n_pal << 3);      /* the zero entry */
+        }
         __syncthreads();
         DVO_STAMP(ts1);
         DVO_STAMP_ADD(5, ts0, ts1);
@@ -1016,6 +1130,9 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             const int lane_off = BLOCK - 64 - (tid & ~63) + (tid & 63);
             if (mode == TEX_L16) {                 /* staged levels hold every point in LDS */
                 accumulate_points2<BLOCK, true, TEX_L16, 2, 0, false, Acc7T<WITH_H>>(c, ts, lp, gpts, 0, N, lane_off, a, any_odd);             /* :369, :433 */
+            } else if (r16) {                      /* every look-up from LDS: no deep prefetch needed */
+                accumulate_points2<BLOCK, true, TEX_R16, 2, kStatic, false, Acc7T<WITH_H>>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
+                accumulate_points2<BLOCK, false, TEX_R16, 2, kStatic, false, Acc7T<WITH_H>>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);
             } else if (mode == TEX_P4 && pt4) {
                 accumulate_points2<BLOCK, true, TEX_P4, (WITH_H ? 2 : DVO_P4_DEPTH(BLOCK)), kStatic, true, Acc7T<WITH_H>>(c, ts, lp, gpts, 0, n_lds, lane_off, a, any_odd);
                 accumulate_points2<BLOCK, false, TEX_P4, (WITH_H ? 2 : DVO_P4_DEPTH(BLOCK)), kStatic, true, Acc7T<WITH_H>>(c, ts, lp, gpts, n_lds, N, lane_off, a, any_odd);
@@ -1160,7 +1277,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             if (member == 0) {
                 out.best_idx[pair * DVO_LEVELS + l] = st.bestItr;
                 out.ratio[pair * DVO_LEVELS + l] = st.bestRatio;
-                out.tex_mode[pair * DVO_LEVELS + l] = mode | (st.exact_ran ? DVO_TEXMODE_EXACT_RAN : 0) | (pt4 ? DVO_TEXMODE_PT4 : 0);
+                out.tex_mode[pair * DVO_LEVELS + l] = mode | (st.exact_ran ? DVO_TEXMODE_EXACT_RAN : 0) | (pt4 ? DVO_TEXMODE_PT4 : 0) | (r16 ? DVO_TEXMODE_RANKS_LDS : 0);
             }
         }
         __syncthreads();

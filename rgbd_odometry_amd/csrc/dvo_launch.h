@@ -17,7 +17,8 @@
 /* where the fused kernel reads the now level of a (pair, level) from */
 enum { DVO_TEXMODE_GLOBAL16 = 0, DVO_TEXMODE_LDS16 = 1, DVO_TEXMODE_PAL4 = 2,
        DVO_TEXMODE_EXACT_RAN = 0x100 /* flag: a wave of the packed kernel took the literal-division fallback at this level */,
-       DVO_TEXMODE_PT4 = 0x200       /* flag: the level's reference points were read in their 4-byte form */ };
+       DVO_TEXMODE_PT4 = 0x200       /* flag: the level's reference points were read in their 4-byte form */,
+       DVO_TEXMODE_RANKS_LDS = 0x400 /* flag (with DVO_TEXMODE_PAL4): the level's ranks were looked up in an LDS copy of the whole level (round 5) */ };
 
 namespace dvo {
 
@@ -67,6 +68,7 @@ struct Schedule {
     int pt4_factor;          /* 4-byte points for lists of at least this many times what the LDS holds as 8-byte points (default 3) */
     int final_blk;           /* host bookkeeping: the final outputs of this launch are stored in the compact lists' (block) order */
     int team_no_plain;       /* diagnostics (DVO_TEAM_PLAIN_STORES=off): team records always travel as sc1 stores, even inside one XCD */
+    int no_r16;              /* diagnostics (DVO_RANKS_LDS=off): never stage a coarse level's ranks into LDS */
 };
 
 struct Intrinsics { float fx, fy, cx, cy; int interp; /* dvo_params.interpolate_dt, travels with the camera model to every kernel */ };

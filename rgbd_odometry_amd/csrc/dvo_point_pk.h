@@ -55,6 +55,48 @@ DVO_DEV bool pixel_in_range(float u, int C, int &px) {
     return (unsigned)px < (unsigned)C;
 }
 
+/* ---- lane masks as scalar values (round 4 experiment; the product form of the compact-form loops since round 5) --------------------
+ * A comparison that feeds a ballot (a visible count, the wave's "some z is degenerate" flag) or a select is a 64-bit lane mask in a
+ * scalar register pair by nature: v_cmp_* writes one.  Written as `bool`, the compiler turns every __builtin_amdgcn_ballot_w64 of a
+ * combined condition into v_cndmask 0/1 + v_cmp_ne, and keeps an accumulated wave-uniform flag in a vector register: eight vector
+ * instructions per round of two points in the packed loop.  These helpers produce and consume the masks directly; and / or /
+ * popcount of masks are scalar instructions.  All lanes are active wherever they are used (the packed point loops are not
+ * divergent).  Round 4: -2 % alone (not taken); round 5, with the shorter serial chain: +3 % (taken: dvo_fused.hip, round2_issue). */
+typedef unsigned long long lanemask;
+DVO_DEV float uniform_const_f(float k) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, k))); }
+DVO_DEV lanemask mask_lt_u32(unsigned a, unsigned b_uniform) {           /* a < b, b wave-uniform */
+    lanemask m;
+    asm("v_cmp_gt_u32_e64 %0, %2, %1" : "=s"(m) : "v"(a), "s"(b_uniform));
+    return m;
+}
+DVO_DEV lanemask mask_lt_i32(int a, int b_uniform) {
+    lanemask m;
+    asm("v_cmp_gt_i32_e64 %0, %2, %1" : "=s"(m) : "v"(a), "s"(b_uniform));
+    return m;
+}
+/* !(lo <= |x| <= hi), NaN included: the complement of rcp_in_proven_range */
+DVO_DEV lanemask mask_abs_outside(float x, float lo_uniform, float hi_uniform) {
+    lanemask a, b;
+    asm("v_cmp_nge_f32_e64 %0, |%1|, %2" : "=s"(a) : "v"(x), "s"(lo_uniform));
+    asm("v_cmp_nle_f32_e64 %0, |%1|, %2" : "=s"(b) : "v"(x), "s"(hi_uniform));
+    return a | b;
+}
+DVO_DEV unsigned select_or_zero(lanemask m, unsigned v) {                 /* m ? v : 0 */
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
+    return r;
+}
+DVO_DEV unsigned select_or(lanemask m, unsigned v, unsigned other) {      /* m ? v : other */
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, %3, %1, %2" : "=v"(r) : "v"(v), "s"(m), "v"(other));
+    return r;
+}
+/* identity (7) as a mask: pixel column/row of a reprojection, and the lanes where it is inside [0, C) */
+DVO_DEV lanemask pixel_in_range_mask(float u, int C_uniform, int &px) {
+    px = cvt_floor_i32(max_num(u, -1.0f));
+    return mask_lt_u32((unsigned)px, (unsigned)C_uniform);
+}
+
 /* :328-345 for two points.  Returns per-half "degenerate z" flags in odd0/odd1: those lanes must be redone with the
  * scalar project_point (literal IEEE divisions). */
 DVO_DEV void project_point2(const IterConst &c, v2f X, v2f Y, v2f Z, v2f &xn, v2f &yn, v2f &zn, v2f &u, v2f &v,
@@ -69,6 +111,23 @@ DVO_DEV void project_point2(const IterConst &c, v2f X, v2f Y, v2f Z, v2f &xn, v2
     const v2f inv = pk_fma(pk_fma(-p2, r, pk_splat(1.0f)), r, r);           /* == 1.0f/p2, identity (1)   :339 */
     odd0 = !rcp_in_proven_range(p2.x);
     odd1 = !rcp_in_proven_range(p2.y);
+    xn = p0 * inv; yn = p1 * inv; zn = p2 * inv;                            /* :340-341 */
+    u = c.m00 * xn + c.m02 * zn;                                            /* :344 */
+    v = c.m11 * yn + c.m12 * zn;
+}
+
+/* the same with the degenerate-z lanes of both halves as ONE lane mask (DVO_VALU_DIET) */
+DVO_DEV void project_point2m(const IterConst &c, v2f X, v2f Y, v2f Z, v2f &xn, v2f &yn, v2f &zn, v2f &u, v2f &v, lanemask &odd) {
+    const v2f d0 = X - c.t[0], d1 = Y - c.t[1], d2 = Z - c.t[2];            /* _3d - cTRep          :329-330 */
+    const v2f p0 = (c.r[0] * d0 + c.r[1] * d1) + c.r[2] * d2;              /* cR^T * d */
+    const v2f p1 = (c.r[3] * d0 + c.r[4] * d1) + c.r[5] * d2;
+    const v2f p2 = (c.r[6] * d0 + c.r[7] * d1) + c.r[8] * d2;
+    v2f r;
+    r.x = __builtin_amdgcn_rcpf(p2.x);
+    r.y = __builtin_amdgcn_rcpf(p2.y);
+    const v2f inv = pk_fma(pk_fma(-p2, r, pk_splat(1.0f)), r, r);           /* == 1.0f/p2, identity (1)   :339 */
+    const float lo = uniform_const_f(1.17549435e-38f), hi = uniform_const_f(8.50705917e37f);       /* 2^-126 .. 2^126 */
+    odd = mask_abs_outside(p2.x, lo, hi) | mask_abs_outside(p2.y, lo, hi);
     xn = p0 * inv; yn = p1 * inv; zn = p2 * inv;                            /* :340-341 */
     u = c.m00 * xn + c.m02 * zn;                                            /* :344 */
     v = c.m11 * yn + c.m12 * zn;
