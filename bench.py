@@ -551,6 +551,11 @@ def main_batch(args):
     if args.assume_free_gb > 0:
         free_b = args.assume_free_gb * 1e9
     fits = int((free_b / (world if args.ranks_share_gpu else 1) - 12e9) / per_pair)
+    if dist is not None and world > 1:
+        # every rank must size the SAME batch (value = rank 0's batch x world): take the minimum over the ranks
+        t_fits = torch.tensor([fits], dtype=torch.int64, device="cpu" if args.ranks_share_gpu else "cuda")
+        dist.all_reduce(t_fits, op=dist.ReduceOp.MIN)
+        fits = int(t_fits.item())
     if not total_pairs and fits < args.batch:
         args.batch = max(256, fits // 256 * 256)
     ctx = DvoContext(args.batch, block_threads=args.block, debug_alias_mod=args.debug_alias,
@@ -620,7 +625,7 @@ def main_batch(args):
                     "ranks from the integer squared distances; no re-encoding pass exists, 16-byte texels are never written)")
     out = {
         "metric": "frame-pair aligns/sec (%dx%d, %d-lvl pyr)" % (args.width, args.height, args.levels),
-        "value": value, "unit": "aligns/s", "n_gpus": world, "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
+        "value": value, "unit": "aligns/s", "n_gpus": (1 if args.ranks_share_gpu else world), "rccl_ranks": (0 if args.ranks_share_gpu else (dist.get_world_size() if dist is not None else 1)),
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if total_pairs > 0 else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",

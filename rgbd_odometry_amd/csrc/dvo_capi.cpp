@@ -1568,10 +1568,21 @@ int dvo_iter_end(dvo_ctx *c, int pair, int level, double *R, double *t, float *e
 namespace dvo_host {
 
 int ensure_step_buffers(dvo_ctx *c) {
-    if (c->d_step_state) return DVO_OK;
-    HIPCHK(c, hipMalloc((void **)&c->d_step_state, 2 * pose_state_bytes()));
-    HIPCHK(c, hipMalloc((void **)&c->d_step_acc, sizeof(double) * 2 * DVO_NACC_PAD));
-    HIPCHK(c, hipMalloc((void **)&c->d_step_ticket, sizeof(unsigned)));
+    if (c->d_step_state && c->d_step_acc && c->d_step_ticket) return DVO_OK;
+    /* all or nothing: a failed allocation must not leave the first buffer set and the others null */
+    char *st = nullptr; double *acc = nullptr; unsigned *tk = nullptr;
+    if (hipMalloc((void **)&st, 2 * pose_state_bytes()) != hipSuccess || hipMalloc((void **)&acc, sizeof(double) * 2 * DVO_NACC_PAD) != hipSuccess ||
+        hipMalloc((void **)&tk, sizeof(unsigned)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (st) (void)hipFree(st);
+        if (acc) (void)hipFree(acc);
+        if (tk) (void)hipFree(tk);
+        return fail(c, DVO_ERR_NOMEM, "cannot allocate the buffers of the tiled / wide schedule");
+    }
+    if (c->d_step_state) (void)hipFree(c->d_step_state);
+    if (c->d_step_acc) (void)hipFree(c->d_step_acc);
+    if (c->d_step_ticket) (void)hipFree(c->d_step_ticket);
+    c->d_step_state = st; c->d_step_acc = acc; c->d_step_ticket = tk;
     HIPCHK(c, hipMemsetAsync(c->d_step_acc, 0, sizeof(double) * 2 * DVO_NACC_PAD, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_step_ticket, 0, sizeof(unsigned), c->stream));
     HIPCHK(c, stream_wait(c->stream));

@@ -171,8 +171,13 @@ int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters
     };
     auto nccl_fail = [&]() { return fail(c, DVO_ERR_HIP, std::string("ncclAllReduce: ") + (T->errstr ? T->errstr(nccl_rc) : "error " + std::to_string(nccl_rc))); };
     static const bool env_no_graph = std::getenv("DVO_TILED_NO_GRAPH") != nullptr;
+    /* graph replay of a schedule that contains REAL multi-rank collectives has never run (the boxes have one GPU; the
+     * loopback stand-in of the tests refuses capture), and the fallback below only triggers when the capture fails, not when a
+     * replay misbehaves.  So for world > 1 the graph is opt-in (DVO_TILED_GRAPH_MULTIRANK=1) until an 8-GPU node has validated it;
+     * one rank -- where RCCL's in-place all-reduce launches nothing -- keeps the graph. */
+    static const bool env_graph_multirank = std::getenv("DVO_TILED_GRAPH_MULTIRANK") != nullptr;
     const unsigned long long sig = dvo_host::step_schedule_signature(c, sc, pair, n_levels, flags, T->rank, T->world) ^ (unsigned long long)(size_t)T->comm;
-    bool direct = env_no_graph || c->stream == nullptr || T->no_graph;
+    bool direct = env_no_graph || c->stream == nullptr || T->no_graph || (T->world > 1 && !env_graph_multirank);
     if (!direct && (!c->tiled_exec || sig != c->tiled_sig)) {
         if (c->tiled_exec) { (void)hipGraphExecDestroy(c->tiled_exec); c->tiled_exec = nullptr; }
         hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);

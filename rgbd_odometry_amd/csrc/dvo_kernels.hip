@@ -758,6 +758,7 @@ DVO_DEV double load_sc1_f64(const double *p) { return __hip_atomic_load(p, __ATO
 #define DVO_STEP_THREADS 512
 #endif
 static_assert(sizeof(PoseState) % 8 == 0, "the state is copied 8 bytes per lane");
+static_assert(DVO_STEP_THREADS == 512, "the last arriver of tiled_step_kernel adds the rows in 16 chains of 32 lanes");
 template <bool WITH_H>
 __global__ void __launch_bounds__(DVO_STEP_THREADS)
 tiled_step_kernel(LevelSlab L, int pair, int level, Intrinsics K, DevParams prm, const PoseState *st_in, PoseState *st_out,

@@ -190,7 +190,8 @@ def test_batch_bench_with_two_and_three_ranks_sharing_the_gpu():
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1                                     # rank 0 only
         d = json.loads(lines[0])
-        assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["config"]["ranks_share_one_gpu"] is True
+        # one GPU, no RCCL rank (the ranks meet over gloo): the line must say so
+        assert d["n_gpus"] == 1 and d["rccl_ranks"] == 0 and d["config"]["ranks_share_one_gpu"] is True
         assert d["scaling"] == ("weak" if world == 2 else "strong")
         units = 256 * world if world == 2 else 200
         assert abs(d["value"] - units * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) <= 1e-6 * d["value"]

@@ -12,8 +12,8 @@ try() {  # name env... -- program args
   for e in $envs; do unset ${e%%=*}; done
   rm -rf $OUT/$name
 }
-[ -n "$PART2" ] || try teams_coop DVO_DUMP_MAPS=1 -- $REPO/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-extra-legs --batch 32
-[ -n "$PART2" ] || try teams_plain DVO_DUMP_MAPS=1 DVO_TEAM_PLAIN_LAUNCH=1 -- $REPO/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-extra-legs --batch 32
+[ -n "$PART2" ] || try teams_coop DVO_DUMP_MAPS=1 DVO_TEAM_COOP_LAUNCH=1 -- $REPO/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-extra-legs --batch 32
+[ -n "$PART2" ] || try teams_plain DVO_DUMP_MAPS=1 -- $REPO/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-extra-legs --batch 32
 [ -n "$PART2" ] || try noteams DVO_DUMP_MAPS=1 -- $REPO/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-extra-legs --batch 32 --team 1
 [ -n "$PART2" ] || try batch1024 DVO_DUMP_MAPS=1 -- $REPO/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-extra-legs --batch 1024
 [ -n "$PART2" ] || try frames_pinned -- $REPO/tools/bench_frames.py --batch 64 --reps 1 --pinned
