@@ -62,6 +62,8 @@ sys.argv = ["bench.py"] + extra
 a = bench.parse_args()
 key = "%dx%dx%dx%d_b%d" % (a.width, a.height, a.levels, a.iters, a.batch)
 allrec[key] = rec
+# records measured on other kernel sources describe a kernel that no longer exists: drop them (tests/test_bench_record.py)
+allrec = {k: v for k, v in allrec.items() if v.get("kernel_source_sha256") == rec["kernel_source_sha256"]}
 json.dump(allrec, open(path, "w"), indent=2)
 print("wrote", path, "(copy to profiles/pmc_traffic.json)")
 print(json.dumps(rec, indent=2))
