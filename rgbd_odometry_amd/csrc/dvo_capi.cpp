@@ -607,7 +607,11 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         static const bool no_pt4_env = [] { const char *e = std::getenv("DVO_POINTS4"); return e && std::strcmp(e, "off") == 0; }();
         sc.no_pt4 = no_pt4_env ? 1 : 0;
         /* 4-byte points from this many times the LDS capacity (in 8-byte points) on; DVO_POINTS4_FACTOR for A/B measurements */
-        static const int pt4_factor_env = [] { const char *e = std::getenv("DVO_POINTS4_FACTOR"); return e ? std::atoi(e) : 3; }();
+        /* round 5: from 1x on (3x through round 4).  Same-box A/B, 640x480x4 at 8192 pairs: 3x 789-790 k aligns/s, 1x 801-803 k, always
+         * 764 k; 1920x1080x5 unchanged (its lists are far beyond either bound) -- profiles/r05_experiments/pt4_factor_ab.txt.  The
+         * kernel now draws the HBM's whole achievable rate, so the 7 % of its lines that were streamed 8-byte points of level 0 cost
+         * more than the 4-byte decode's instructions (round 4, when the issue stage was the nearer ceiling: a wash) */
+        static const int pt4_factor_env = [] { const char *e = std::getenv("DVO_POINTS4_FACTOR"); return e ? std::atoi(e) : 1; }();
         sc.pt4_factor = pt4_factor_env;
         /* pt4_decode rebuilds a point's pixel from its 16 x 16 block index with the number of block rows of the image the list was
          * ENCODED against; the kernel only knows the now level's rows.  Reference and now levels of different heights (nothing

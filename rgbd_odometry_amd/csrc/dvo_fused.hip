@@ -1001,10 +1001,10 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         /* 4-byte points (dvo_device_math.h: pt4_decode): when the builder validated this list's 4-byte twin, the throughput shape
          * reads that -- twice the points per LDS byte, half the bytes per streamed point.  Not in team mode (a member's share
          * does not start on a 64-point chunk). */
-        /* ... and only where most of the list is streamed: the 4-byte decode costs ~17 % more vector instructions per point, and
-         * the kernel is as close to its instruction-issue ceiling as to the request ceiling.  Measured A/B (DVO_POINTS4=off):
-         * 640x480 level 0 (14.8 k points, 8.2 k fit as 8-byte points) 723 k vs 731 k aligns/s -- a wash, so not taken;
-         * 1920x1080 (130 k / 67 k points against 19 k that fit) 77.5 k vs 75.0 k.  Taken from three times the LDS capacity. */
+        /* ... and only where part of the list would be streamed as 8-byte points: the 4-byte decode costs ~17 % more vector
+         * instructions per point.  Rounds 3-4 (issue stage the nearer ceiling): 640x480 level 0 (14.8 k points, 8.2 k fit as 8-byte
+         * points) a wash, 1920x1080 +3 % -- taken from three times the LDS capacity.  Round 5 (the kernel draws the HBM's whole
+         * achievable rate): from ONE times the capacity, 789 k -> 802 k aligns/s at 640x480x4 (sc.pt4_factor, dvo_capi.cpp). */
         const bool pt4 = !TEAM && mode == TEX_P4 && !r16 && !sc.no_pt4 && N >= sc.pt4_factor * (((lds_words - pal_words - img_words) >> 1) & ~1) && L.pt4_ok &&
                          __builtin_amdgcn_readfirstlane(L.pt4_ok[dpair]) != 0;
         float *const lds_pts = lds_dyn + pal_words + img_words;
