@@ -1,8 +1,8 @@
 """Single camera stream through the C ABI (the reference's actual use: one frame every ~30 ms, SolveDVO.cpp:1945, per frame
 :2092-2109): H2D of a 640x480 BGR8 frame -> pyramid + Canny -> distance transform -> compact now level -> alignment (4 levels x 10
 iterations) -> pose on the host.  Measured (profiles/r03_single_stream): 0.60 ms median / 0.71 ms worst at 30 Hz over 200 frames,
-12.5 ms for the very first alignment of a process (code objects, lazily allocated buffers).  The bound here is loose on
-purpose (a shared test box): steady-state frames must stay below 5 ms."""
+12.5 ms for the very first alignment of a process (code objects, lazily allocated buffers); round 5: 0.39-0.46 ms median.  The bound
+here leaves a shared test box a factor of four: steady-state frames must stay below 2 ms in the median."""
 import time
 
 import numpy as np
@@ -38,7 +38,7 @@ def test_single_stream_frame_latency_is_bounded():
             times.append(dt)
             poses.append((R[0].copy(), t[0].copy()))
         assert [ctx.level_texel_mode(0, l) for l in range(4)] == [2, 2, 2, 2]     # the stream runs on the compact now form
-        assert float(np.median(times)) < 5e-3, times
+        assert float(np.median(times)) < 2e-3, times        # measured 0.4-0.5 ms (round 5); a shared test box gets a factor of four
         assert max(times) < 20e-3, times
         for k in range(4, 40):                    # the same now frame gives the same pose, bit for bit, every time
             assert np.array_equal(poses[k][0], poses[k - 4][0]) and np.array_equal(poses[k][1], poses[k - 4][1])
