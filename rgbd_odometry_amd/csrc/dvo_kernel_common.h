@@ -204,15 +204,15 @@ DVO_DEV void block_reduce(const Acc &a, double (*red)[DVO_NACC_PAD], double *tot
     } else if (lane < 21) {
         red[wave][lane] = 0.0;
     }
-    {
+    {   /* round 5: the DPP / lane-permute reduce-scatter of the packed kernel (twenty ds_bpermute round trips shorter) */
         double d[8];
 #pragma unroll
         for (int k = 0; k < 6; k++) d[k] = a.g[k];
         d[6] = a.e2;
         d[7] = 0.0;
-        wave_reduce_scatter<double, 8>(d);
-        const int idx = lane >> 3;
-        if ((lane & 7) == 0 && idx < 7) red[wave][21 + idx] = d[0];
+        wave_reduce_scatter8_dpp(d);
+        const int idx = reduce_scatter8_dpp_index(lane);
+        if (lane < 8 && idx < 7) red[wave][21 + idx] = d[0];
     }
     if (lane == 0) red[wave][28] = (double)a.nvis;
     __syncthreads();

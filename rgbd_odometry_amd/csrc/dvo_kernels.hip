@@ -663,6 +663,8 @@ iter_begin_kernel(PoseState *st, DevParams prm, const double *Rt12, float *energ
         pose_state_begin(*st);
     }
     for (int i = threadIdx.x; i < max_iters; i += 64) energy[i] = 0.0f;      /* :634 */
+    __syncthreads();
+    if (threadIdx.x == 0) pose_regulariser_precompute(*st, st->p[0], st->u); /* log(pose) for the first update (tiled_step_kernel) */
 }
 
 /* same as accumulate_kernel, but the float pose is read from the device-resident state */
@@ -768,52 +770,89 @@ tiled_step_kernel(LevelSlab L, int pair, int level, Intrinsics K, DevParams prm,
     __shared__ double tot[DVO_NACC_PAD];
     __shared__ double part[16][DVO_NACC_PAD + 1];
     __shared__ PoseState s;
-    __shared__ int s_last;
+    __shared__ PoseCur nxt;                                                 /* the iterate the pending update produces */
+    __shared__ double g_s[8];                                               /* sums 21..28 of the previous launch */
+    __shared__ int s_last, s_stop0;
     const int tid = threadIdx.x;
-    {   /* the state, 8 bytes per lane (sizeof(PoseState) is a multiple of 8) */
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    /* head (round 5): everything the update needs is requested at once -- the state (8 bytes per lane), the eight sums, the stop
+     * flag as the launch found it -- so the head pays ONE memory latency before its barrier (rounds 1-4: state, barrier, sums).
+     * Then the packed kernel's split (dvo_fused.hip, serial part): wave 0 takes direction (one component per lane) and step into
+     * `nxt`, wave 1 the energy and best-iterate bookkeeping of the same iterate; log(pose) for the regulariser was taken by
+     * workgroup 0 of the previous launch (or by iter_begin_kernel) while the others worked. */
+    {
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(st_in);
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(&s);
         for (int i = tid; i < (int)(sizeof(PoseState) / 8); i += DVO_STEP_THREADS) dst[i] = src[i];
+        if (wave == 7) {
+            if (lane < 8) g_s[lane] = apply_prev ? acc_in[21 + lane] : 0.0;
+            if (lane == 8) s_stop0 = st_in->stop;
+        }
     }
     __syncthreads();
-    const int was_stopped = s.stop;                                         /* before lane 0 touches the state */
-    __syncthreads();
-    if (tid == 0 && apply_prev && !was_stopped) {                          /* after :877 nothing runs */
-        double g[6];
-        for (int k = 0; k < 6; k++) g[k] = acc_in[21 + k];
-        const float e = pose_update(s, s.u, itr - 1, n_total, g, acc_in[27], (int)acc_in[28]);
-        if (blockIdx.x == 0) energy[itr - 1] = e;                           /* :690 */
+    const bool upd = apply_prev && !s_stop0;                                /* after :877 nothing runs */
+    if (upd) {
+        if (wave == 0) {
+            double psi[6];
+            pose_direction_lanes(s, s.u, pose_neg_step(s.u, itr - 1), g_s[lane < 6 ? lane : 5], lane, psi);
+            if (lane == 0) pose_apply(s, s.p[0], nxt, s.u, psi);
+        } else if (wave == 1 && lane == 0) {
+            const float e = pose_bookkeep(s, s.p[0], itr - 1, n_total, g_s[6], (int)g_s[7]);
+            if (blockIdx.x == 0) energy[itr - 1] = e;                       /* :690 */
+        } else if (WITH_H && wave == 2) {
+            /* DVO_FLAG_NORMAL_MATRIX: H = sum w J J^T of the previous iterate (reduced over all ranks), kept per iterate like the batch kernels do */
+            if (H_prev && blockIdx.x == 0 && lane < 21) H_prev[lane] = acc_in[lane];
+        }
     }
-    /* DVO_FLAG_NORMAL_MATRIX: H = sum w J J^T of the previous iterate (reduced over all ranks), kept per iterate like the batch kernels do */
-    if (WITH_H && H_prev && apply_prev && blockIdx.x == 0 && tid < 21 && !was_stopped) H_prev[tid] = acc_in[tid];
     __syncthreads();
-    if (blockIdx.x == 0 && apply_prev) {
-        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&s);
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(st_out);
-        for (int i = tid; i < (int)(sizeof(PoseState) / 8); i += DVO_STEP_THREADS) dst[i] = src[i];
-    }
+    const bool moved = upd && !s.stop;                                      /* the points run at nxt, else at the state's iterate */
+    const PoseCur &pc = moved ? nxt : s.p[0];
+    const int nshare = (gridDim.x > 1) ? (int)gridDim.x - 1 : 1;
+    const int share = (gridDim.x > 1) ? (int)blockIdx.x - 1 : 0;
     Acc a;
     acc_zero(a);
-    if (!s.stop) {                                                          /* wave-uniform (LDS) */
+    if (!s.stop && share >= 0) {                                            /* wave-uniform (LDS) */
         const float4 *__restrict__ tex = L.tex + (size_t)pair * L.tex_stride;
         const float *__restrict__ pts = L.pts + (size_t)pair * L.pt_cap * 3;
         IterConst c;
         level_consts(c, K, level, L.rows, L.cols);
 #pragma unroll
-        for (int k = 0; k < 9; k++) c.r[k] = uniform_f(s.p[0].Rf[k]);
+        for (int k = 0; k < 9; k++) c.r[k] = uniform_f(pc.Rf[k]);
 #pragma unroll
-        for (int k = 0; k < 3; k++) c.t[k] = uniform_f(s.p[0].tf[k]);
-        const int per = (n + gridDim.x - 1) / gridDim.x;
-        const int b0 = first + blockIdx.x * per;
+        for (int k = 0; k < 3; k++) c.t[k] = uniform_f(pc.tf[k]);
+        const int per = (n + nshare - 1) / nshare;
+        const int b0 = first + share * per;
         int b1 = b0 + per;
         if (b1 > first + n) b1 = first + n;
         PointSrc psrc;
         psrc.g = pts; psrc.gc = nullptr; psrc.l = nullptr; psrc.n_lds = 0; psrc.cap = 0;
+        /* (round 5, measured: requesting every lane's first six points before the head -- they do not depend on the pose -- and
+         * issuing their gathers together made every launch 3 us SLOWER, 4096 x 3072 included: the head then waits behind eighteen
+         * cold loads, and waves without points work through dummy rounds.  The per-point phase of this kernel is issue-bound.) */
         if (b0 < b1) accumulate_points<DVO_STEP_U, WITH_H, SRC_GLOBAL_XYZ, 2>(c, tex, psrc, b0, b1, tid, DVO_STEP_THREADS, a);
     }
+    /* workgroup 0 keeps the state: the new iterate, log(pose) for the next update's regulariser, st_out (double-buffered: no
+     * workgroup of this launch reads what it writes).  With more than one workgroup it has no share of the points, so none of this
+     * is on the launch's critical path. */
+    if (blockIdx.x == 0) {
+        __syncthreads();                                                    /* gridDim.x == 1: the points above read pc */
+        if (moved && tid < (int)(sizeof(PoseCur) / 8))
+            reinterpret_cast<unsigned long long *>(&s.p[0])[tid] = reinterpret_cast<const unsigned long long *>(&nxt)[tid];
+        __syncthreads();
+        if (tid == 0 && !s.stop) pose_regulariser_precompute(s, s.p[0], s.u);
+        __syncthreads();
+        if (apply_prev) {
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&s);
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(st_out);
+            for (int i = tid; i < (int)(sizeof(PoseState) / 8); i += DVO_STEP_THREADS) dst[i] = src[i];
+        }
+    }
     block_reduce<DVO_STEP_THREADS, WITH_H>(a, red, tot);
-    /* tail: this workgroup's row, then the ticket */
-    if (tid < DVO_NACC_PAD) store_sc1_f64(partials + (size_t)blockIdx.x * DVO_NACC_PAD + tid, (tid < DVO_NACC) ? tot[tid] : 0.0);
+    /* tail: this workgroup's row, then the ticket.  Without H only the eight sums 21..28 exist (round 5: the row is those eight
+     * doubles, a quarter of the bytes the last arriver has to collect) */
+    constexpr int ROW = WITH_H ? DVO_NACC_PAD : 8;
+    if (WITH_H) { if (tid < DVO_NACC_PAD) store_sc1_f64(partials + (size_t)blockIdx.x * ROW + tid, (tid < DVO_NACC) ? tot[tid] : 0.0); }
+    else if (tid < 8) store_sc1_f64(partials + (size_t)blockIdx.x * ROW + tid, tot[21 + tid]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        /* every storing wave: its stores have left */
     __syncthreads();
     if (tid == 0) {
@@ -823,15 +862,16 @@ tiled_step_kernel(LevelSlab L, int pair, int level, Intrinsics K, DevParams prm,
     __syncthreads();
     if (!s_last) return;
     {   /* the last arriver: all rows in the fixed two-level order of reduce_partials_kernel (16 interleaved chains, then in order) */
+        const int nb = (int)gridDim.x;
+        if constexpr (WITH_H) {
         const int k = tid & 31, ch = tid >> 5;                              /* 512 threads: 16 chains x 32 values */
         double sum = 0.0;
-        const int nb = (int)gridDim.x;
         for (int b0 = ch; b0 < nb && ch < 16; b0 += 16 * 16) {                          /* up to 16 rows of this chain at a time, all loads issued first */
             double v[16];
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const int b = b0 + 16 * q;
-                v[q] = (b < nb) ? load_sc1_f64(partials + (size_t)b * DVO_NACC_PAD + k) : 0.0;
+                v[q] = (b < nb) ? load_sc1_f64(partials + (size_t)b * ROW + k) : 0.0;
             }
 #pragma unroll
             for (int q = 0; q < 16; q++) sum += v[q];                       /* fixed order: rows ch, ch + 16, ch + 32, ... */
@@ -843,6 +883,31 @@ tiled_step_kernel(LevelSlab L, int pair, int level, Intrinsics K, DevParams prm,
 #pragma unroll
             for (int j = 0; j < 16; j++) t += part[j][tid];
             acc_out[tid] = t;
+        }
+        } else {
+        /* eight values per row: the same 16 chains (rows ch, ch + 16, ...), eight lanes each; 128 of the 512 threads load */
+        const int k = tid & 7, ch = tid >> 3;
+        double sum = 0.0;
+        for (int b0 = ch; b0 < nb && ch < 16; b0 += 16 * 16) {
+            double v[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int b = b0 + 16 * q;
+                v[q] = (b < nb) ? load_sc1_f64(partials + (size_t)b * ROW + k) : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) sum += v[q];
+        }
+        if (ch < 16) part[ch][k] = sum;
+        __syncthreads();
+        if (tid < DVO_NACC_PAD) {
+            double t = 0.0;
+            if (tid >= 21 && tid < 29) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) t += part[j][tid - 21];
+            }
+            acc_out[tid] = t;
+        }
         }
         if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* for the next launch (visible at the kernel boundary) */
     }
@@ -864,7 +929,7 @@ tiled_finish_kernel(const PoseState *st_in, PoseState *st_out, DevParams prm, co
         if (!s.stop) {
             double g[6];
             for (int k = 0; k < 6; k++) g[k] = acc_in[21 + k];
-            energy[itr_last] = pose_update(s, s.u, itr_last, n_total, g, acc_in[27], (int)acc_in[28]);
+            energy[itr_last] = pose_update_t<true>(s, s.u, itr_last, n_total, g, acc_in[27], (int)acc_in[28]);
         }
         pose_state_finish(s);                                               /* :997-1001 */
         for (int k = 0; k < 9; k++) Rt12[k] = s.R[k];
