@@ -651,6 +651,9 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         sc.team_no_plain = no_plain ? 1 : 0;
         static const bool no_r16 = [] { const char *e = std::getenv("DVO_RANKS_LDS"); return e && std::strcmp(e, "off") == 0; }();
         sc.no_r16 = no_r16 ? 1 : 0;
+        /* solo levels (round 5, measured and not taken: default 0 = off; tools/experiments/r05_team_solo_ab.sh, dvo_fused.hip: solo levels) */
+        static const int solo_max = [] { const char *e = std::getenv("DVO_TEAM_SOLO_MAX"); return e ? std::atoi(e) : DVO_TEAM_SOLO_MAX_DEFAULT; }();
+        sc.team_solo_max = solo_max;
     }
     c->team_used = false;
     if (sc.compact && c->prm.engine_variant != 1 && !(sc.flags & DVO_FLAG_NORMAL_MATRIX) && block == 512 && c->prm.team_size != 1) {

@@ -905,6 +905,15 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         }
         epoch = 1;
     }
+    /* one exchange of wave 0's eight lane values over the whole team (two stages beyond one XCD); `epoch` is advanced by the caller */
+    auto team_total = [&](double sl) -> double {
+        v4u *tb = reinterpret_cast<v4u *>(out.team_buf);
+        if (super_team) {
+            sl = team_exchange(sl, tb + (size_t)xcd * 2 * DVO_TEAM_MAX * 8, local, G >> 3, epoch, out.team_err, true, team_same_xcd);
+            return team_exchange(sl, tb + (size_t)8 * 2 * DVO_TEAM_MAX * 8, xcd, 8, epoch, out.team_err, local == 0);
+        }
+        return team_exchange(sl, tb + (size_t)pair_local * 2 * DVO_TEAM_MAX * 8, member, G, epoch, out.team_err, true, team_same_xcd);
+    };
     /* static LDS as ONE block of known size, so that the dynamic part -- which starts with the palette of the compact now
      * form -- begins at a compile-time LDS address (kStatic; verified below): palette look-ups then need no address add */
     static_assert(BLOCK >= 128, "wave 0 runs the update, wave 1 the bookkeeping");
@@ -944,11 +953,25 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         const int Nall = __builtin_amdgcn_readfirstlane(L.N[dpair]);
         /* this workgroup's share of the list: all of it, or member `member`'s contiguous even-sized chunk of a team */
         int pfirst = 0, N = Nall;
-        if (TEAM) {
+        /* Solo levels (round 5).  An exchange costs every iteration of a team ~2 us; a level of a few thousand points is finished by ONE
+         * workgroup in less than that per iteration.  Such a level is run by member 0 alone (the whole list, no exchange: the serial
+         * part of the one-workgroup shape); the other members skip it and pick its result up afterwards -- the pose is all that
+         * travels from one runIterations call to the next (:2097-2109) -- through one exchange at the level's end.  Nall and the
+         * threshold are the same on every member, so all of them take the same branch.
+         * MEASURED AND NOT TAKEN (profiles/r05_experiments/team_solo_ab.txt; default threshold 0 = off, DVO_TEAM_SOLO_MAX=n switches it
+         * on): one 640x480x4x10 pair 0.258 ms without, 0.251 with level 3 (230 points) solo, 0.265 with levels 3-2, 0.286 with 3-1;
+         * batches of 32 lose 8 %.  The premise was wrong: ONE workgroup's iteration over 230 points takes 3.6 us (1.5 us for the single
+         * round of look-ups to come back from the L2, 0.8 us for the waves to meet, 1.2 us update: profiles/r05_final/stamps_anatomy.txt),
+         * the team's 3.1 us -- the floor of an iteration is latency either way, and the exchange is the smaller part of it. */
+        const bool solo = TEAM && Nall <= sc.team_solo_max;
+        const bool works = !solo || member == 0;
+        if (TEAM && !solo) {
             const int chunk = (((Nall + G - 1) / G) + 1) & ~1;
             pfirst = min(Nall, member * chunk);
             N = min(Nall, pfirst + chunk) - pfirst;
         }
+        if (!works) N = 0;
+        const int iters_run = works ? iters : 0;
         const char *__restrict__ tex = reinterpret_cast<const char *>(L.tex + (size_t)dpair * L.tex_stride);
         const uint2 *__restrict__ gpts = L.cpts + (size_t)dpair * L.pt_cap + pfirst;
         float *energy = out.energy + (size_t)pair * sc.e_stride + sc.e_off[l];
@@ -1013,7 +1036,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         const int n_lds = (N <= cap) ? N : (cap / (2 * BLOCK)) * (2 * BLOCK);      /* whole rounds only */
         float *const lds_tex = lds_pts + 2 * cap;
         if (tid == 0) st.exact_ran = 0;
-        if (mode == TEX_P4) {
+        if (mode == TEX_P4 && works) {
             const float2 *__restrict__ pg = L.pal + (size_t)dpair * DVO_PAL_MAX;
             float2 *pl = reinterpret_cast<float2 *>(lds_dyn);
             for (int i = tid; i < n_pal_lds; i += BLOCK) pl[i] = pg[i];
@@ -1096,7 +1119,8 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
         DVO_STAMP(ts1);
         DVO_STAMP_ADD(5, ts0, ts1);
 
-        for (int itr = 0; itr < iters; ++itr) {                              /* :658 */
+        const bool exch = TEAM && !solo;                                     /* this level's sums are the team's */
+        for (int itr = 0; itr < iters_run; ++itr) {                          /* :658 */
             /* Instruction-issue priority falls with progress.  Two workgroups share a CU; the hardware favours the older
              * one, so of two that start together one ends ~100 us before the other, which then finishes alone on a half-empty
              * CU (launch timeline, tools/exp_timeline.py: the last 15 % of a 1024-pair launch ran with 256 of 512 slots busy).
@@ -1200,18 +1224,12 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             if (wave == 0) {
                 sl = block_sum8<BLOCK>(red, lane & 7);
                 DVO_STAMP_T2();
-                if (TEAM) {    /* the sums of the other members; identical bits on every member */
-                    v4u *tb = reinterpret_cast<v4u *>(out.team_buf);
-                    if (super_team) {
-                        sl = team_exchange(sl, tb + (size_t)xcd * 2 * DVO_TEAM_MAX * 8, local, G >> 3, epoch, out.team_err, true, team_same_xcd);
-                        sl = team_exchange(sl, tb + (size_t)8 * 2 * DVO_TEAM_MAX * 8, xcd, 8, epoch, out.team_err, local == 0);
-                    } else {
-                        sl = team_exchange(sl, tb + (size_t)pair_local * 2 * DVO_TEAM_MAX * 8, member, G, epoch, out.team_err, true, team_same_xcd);
-                    }
+                if (exch) {    /* the sums of the other members; identical bits on every member */
+                    sl = team_total(sl);
                     if (lane == 6 || lane == 7) tot[lane] = sl;            /* for the bookkeeping wave */
                 }
             }
-            if (TEAM) __syncthreads();
+            if (exch) __syncthreads();
             if (wave == 0) {
                 double psi[6];
                 pose_direction_lanes(st, uc, neg_step, sl, lane, psi);
@@ -1224,12 +1242,12 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
                     out.H[((size_t)pair * sc.e_stride + sc.e_off[l] + itr) * 21 + lane] = hs;
                 }
             } else if (wave == 1 && lane == 0) {
-                const double e2 = TEAM ? tot[6] : block_sum8<BLOCK>(red, 6);
-                const double nv = TEAM ? tot[7] : block_sum8<BLOCK>(red, 7);
+                const double e2 = exch ? tot[6] : block_sum8<BLOCK>(red, 6);
+                const double nv = exch ? tot[7] : block_sum8<BLOCK>(red, 7);
                 const float e = pose_bookkeep(st, pc, itr, Nall, e2, (int)nv);
                 if (member == 0) energy[itr] = e;                            /* :690 */
             }
-            epoch++;
+            if (exch) epoch++;
             DVO_STAMP(t3);
             __syncthreads();
             DVO_STAMP(t4);
@@ -1238,7 +1256,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             if (st.stop) break;                                              /* :877 */
             /* log(new pose) for the next iteration's regulariser: lane 0 takes it now, while the other waves are
              * already in their point phase */
-            if (tid == 0 && itr + 1 < iters) pose_regulariser_precompute(st, pn, uc);
+            if (tid == 0 && itr + 1 < iters_run) pose_regulariser_precompute(st, pn, uc);
         }
 
         /* finalEpsilons / finalReprojections = those of the best iterate (:703-704, :1002-1003); recomputed once from
@@ -1281,6 +1299,30 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             }
         }
         __syncthreads();
+        if (TEAM && solo) {
+            /* the level's result: member 0's {q, t} to every member, through the exchange that adds lane values -- the others put
+             * in -0.0, and x + (-0.0) = x for EVERY x (+0.0 would turn a -0.0 component into +0.0), so the bits arrive unchanged
+             * whatever the order of the additions.  R = the matrix of q (pose_state_finish), recomputed alike everywhere. */
+            if (tid < 64) {
+                const int k = tid & 7;
+                double mine = -0.0;
+                if (member == 0 && k < 7) mine = (k < 4) ? st.p[0].q[k] : st.p[0].t[k - 4];
+                const double v = team_total(mine);
+                if (tid < 4) st.p[0].q[tid] = v;
+                else if (tid < 7) st.p[0].t[tid - 4] = v;
+            }
+            epoch++;
+            __syncthreads();
+            if (tid == 0) {
+                double q[4], R[9];
+#pragma unroll
+                for (int k = 0; k < 4; k++) q[k] = st.p[0].q[k];
+                quat_to_matrix(q, R);
+#pragma unroll
+                for (int k = 0; k < 9; k++) st.R[k] = R[k];
+            }
+            __syncthreads();
+        }
     }
 
 #ifdef DVO_STAMPS

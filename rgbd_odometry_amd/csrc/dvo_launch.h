@@ -69,7 +69,11 @@ struct Schedule {
     int final_blk;           /* host bookkeeping: the final outputs of this launch are stored in the compact lists' (block) order */
     int team_no_plain;       /* diagnostics (DVO_TEAM_PLAIN_STORES=off): team records always travel as sc1 stores, even inside one XCD */
     int no_r16;              /* diagnostics (DVO_RANKS_LDS=off): never stage a coarse level's ranks into LDS */
+    int team_solo_max;       /* team mode: a level with at most this many points is run by member 0 alone, the others pick its pose up
+                                at the level's end (dvo_fused.hip: solo levels; DVO_TEAM_SOLO_MAX, 0 = every level by the whole team) */
 };
+
+#define DVO_TEAM_SOLO_MAX_DEFAULT 0          /* measured and not taken, see dvo_fused.hip: solo levels */
 
 struct Intrinsics { float fx, fy, cx, cy; int interp; /* dvo_params.interpolate_dt, travels with the camera model to every kernel */ };
 
