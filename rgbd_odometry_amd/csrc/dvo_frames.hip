@@ -1145,11 +1145,49 @@ DVO_DEV unsigned edt_finish32(const unsigned short *tg, int cols, int xx, int r,
     return best;
 }
 
-template <int R>
+typedef unsigned edt_u2 __attribute__((ext_vector_type(2)));
+/* the 8 + 8 look-ups of one trip of the four-rows-per-lane scan: a[j-1] = 8 bytes at la + (8 - j) * CB, b[j-1] = at ra + j * CB
+ * (CB = bytes per tile column), as sixteen ds_read_b64 with immediate offsets and one wait */
+template <int CB>
+DVO_DEV void edt_rows_read16(unsigned la, unsigned ra, edt_u2 (&a)[8], edt_u2 (&b)[8]) {
+    asm volatile("ds_read_b64 %0, %16 offset:%18\n\tds_read_b64 %8, %17 offset:%26\n\t"
+                 "ds_read_b64 %1, %16 offset:%19\n\tds_read_b64 %9, %17 offset:%27\n\t"
+                 "ds_read_b64 %2, %16 offset:%20\n\tds_read_b64 %10, %17 offset:%28\n\t"
+                 "ds_read_b64 %3, %16 offset:%21\n\tds_read_b64 %11, %17 offset:%29\n\t"
+                 "ds_read_b64 %4, %16 offset:%22\n\tds_read_b64 %12, %17 offset:%30\n\t"
+                 "ds_read_b64 %5, %16 offset:%23\n\tds_read_b64 %13, %17 offset:%31\n\t"
+                 "ds_read_b64 %6, %16 offset:%24\n\tds_read_b64 %14, %17 offset:%32\n\t"
+                 "ds_read_b64 %7, %16 offset:%25\n\tds_read_b64 %15, %17 offset:%33\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7]),
+                   "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7])
+                 : "v"(la), "v"(ra),
+                   "n"(7 * CB), "n"(6 * CB), "n"(5 * CB), "n"(4 * CB), "n"(3 * CB), "n"(2 * CB), "n"(1 * CB), "n"(0 * CB),
+                   "n"(1 * CB), "n"(2 * CB), "n"(3 * CB), "n"(4 * CB), "n"(5 * CB), "n"(6 * CB), "n"(7 * CB), "n"(8 * CB)
+                 : "memory");
+}
+/* Round 5, MEASURED AND NOT TAKEN: FOUR rows per lane (NW = 2 dwords, R >= 4).  The premise: the scan's look-ups are ds_read_b32, which
+ * the LDS delivers at half the bytes per cycle of ds_read_b64 (MI355X_MICROARCH.md, LDS table: 128 against 256 B/clk per CU), so the
+ * same look-ups as 8-byte reads should halve the LDS time.  Result over 256 camera frames (tools/experiments/r05_edt_rows_ab.sh,
+ * profiles/r05_experiments/edt_rows_ab.txt): 157 us per launch against 154 us for two rows per lane (164 us when the compiler is left to
+ * pair the reads into ds_read2_b64: edt_rows_read16 keeps them single).  The counters say why (profiles/r05_frames/pmc_rows.txt): the
+ * kernel issues 0.2 instructions per cycle and SIMD -- 36 k packed vector, 25 k scalar and 7 k LDS instructions per SIMD in 330 k cycles
+ * -- so no unit is near its rate; a wave's trip is a chain (look-ups, wait, 48 dependent packed operations at the single-wave cadence
+ * of 6 cycles, the scalar step counters with their hazard no-ops) and three waves per SIMD do not cover it.
+ * make EXP=rowsb64 EXPDEFS=-DDVO_EDT_ROWS_B64=1 builds this form. */
+#ifdef DVO_EDT_ROWS_B64
+#define DVO_EDT_NW(R) ((R) >= 4 ? 2 : 1)
+#else
+#define DVO_EDT_NW(R) 1
+#endif
+template <int R, int NW = DVO_EDT_NW(R)>
 DVO_DEV void edt_rows_pk_body(const int bx, const int gx, const int by, const unsigned short *__restrict__ g, int rows, int cols, unsigned *__restrict__ d2, int *__restrict__ partial,
                    unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags) {
-    static_assert(R >= 2 && (R & 1) == 0, "two rows per lane");
+    static_assert(R >= 2 && (R & 1) == 0, "two rows per dword");
     constexpr int RP = R / 2;                                  /* row pairs = dwords per tile column */
+    static_assert(NW == 1 || (NW == 2 && RP % 2 == 0), "a lane's dwords are one aligned 8-byte piece of a column");
+    constexpr int LP = RP / NW;                                /* lanes per tile column */
+    constexpr int NR = 2 * NW;                                 /* rows per lane */
     extern __shared__ unsigned char tile_raw[];
     unsigned *tq = reinterpret_cast<unsigned *>(tile_raw);     /* [PAD + cols + PAD][RP]: min(g^2, 65535), two rows per dword */
     unsigned short *tg = reinterpret_cast<unsigned short *>(tq + (size_t)(cols + 2 * EDT_PK_PAD) * RP);     /* [cols][R]: g */
@@ -1159,7 +1197,8 @@ DVO_DEV void edt_rows_pk_body(const int bx, const int gx, const int by, const un
     d2 += (size_t)by * edt_g_count(rows, cols, R) + (size_t)bx * cols * R;      /* d2 too is written in row blocks */
     unsigned *bm = bitmap + (size_t)by * bm_words;
     const int y0 = bx * R;
-    const int totalp = cols * RP;
+    const int totalp = cols * RP;                              /* dwords of the tile */
+    const int totall = cols * LP;                              /* lane items: NW dwords each */
     for (int i = threadIdx.x; i < EDT_LBITS_WORDS; i += 256) lbits[i] = 0u;
     for (int i = threadIdx.x; i < EDT_PK_PAD * RP; i += 256) {
         tq[i] = 0xffffffffu;
@@ -1179,71 +1218,103 @@ DVO_DEV void edt_rows_pk_body(const int bx, const int gx, const int by, const un
     for (int p = 4 * n4 + threadIdx.x; p < totalp; p += 256) stage(p, gblk[p]);
     __syncthreads();
     typedef __attribute__((address_space(3))) const unsigned lds_cu;
+
     const unsigned tq_lds = (unsigned)(size_t)(lds_cu *)tq + (unsigned)(EDT_PK_PAD * RP * 4);         /* LDS byte address of column 0 */
     unsigned mx = 0;
     bool far = false;
     const int lane = threadIdx.x & 63;
     const int wave_base = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
-    for (int base = wave_base; base < totalp; base += 256) {    /* wave-uniform: 64 row pairs = 64/RP columns */
+    for (int base = wave_base; base < totall; base += 256) {    /* wave-uniform: 64 lane items = 64/LP columns */
         const int p = base + lane;
-        const int cp = p < totalp ? p : totalp - 1;
-        const int xx = cp / RP, rp = cp - xx * RP, yy = y0 + 2 * rp;
-        const bool live0 = p < totalp && yy < rows, live1 = p < totalp && yy + 1 < rows;
-        edt_us2 best = edt_as_us2(p < totalp ? tq[EDT_PK_PAD * RP + cp] : 0u);      /* rows past the image hold 0: finished */
+        const int cp = p < totall ? p : totall - 1;
+        const int xx = cp / LP, h = cp - xx * LP;
+        const int dq = xx * RP + h * NW;                        /* the lane's first dword of the tile */
+        const int r0 = 2 * h * NW, yy = y0 + r0;                /* its first row: of the block, of the image */
+        bool live[NR];
+#pragma unroll
+        for (int k = 0; k < NR; k++) live[k] = p < totall && yy + k < rows;
+        edt_us2 best[NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) best[w] = edt_as_us2(p < totall ? tq[EDT_PK_PAD * RP + dq + w] : 0u);      /* rows past the image hold 0: finished */
         /* steps every column of the wave can take inside image + pad (min(xx, cols-1-xx) is concave: the end columns decide),
          * capped where i^2 still fits 16 bits */
-        const int xf = base / RP, xl = ((base + 63 < totalp) ? base + 63 : totalp - 1) / RP;
+        const int xf = base / LP, xl = ((base + 63 < totall) ? base + 63 : totall - 1) / LP;
         const int nf = (xf < cols - 1 - xf) ? xf : cols - 1 - xf, nl = (xl < cols - 1 - xl) ? xl : cols - 1 - xl;
         int lim = __builtin_amdgcn_readfirstlane((nf < nl ? nf : nl) + EDT_PK_PAD);
         lim = lim < 255 ? lim : 255;
         int i = 1;
         /* i^2 and 2i+1 in both halves of a scalar register each: the next step's pair is two scalar additions away */
         unsigned S = 0x00010001u, D = 0x00030003u;
-        unsigned la = tq_lds + (unsigned)((cp - 8 * RP) * 4);   /* far end of a trip's left side: LDS offsets are unsigned */
-        unsigned ra = tq_lds + (unsigned)(cp * 4);
+        unsigned la = tq_lds + (unsigned)((dq - 8 * RP) * 4);   /* far end of a trip's left side: LDS offsets are unsigned */
+        unsigned ra = tq_lds + (unsigned)(dq * 4);
         while (i + 7 <= lim) {                                  /* eight steps per trip, one exit test */
-            const edt_us2 open = __builtin_elementwise_sub_sat(best, edt_as_us2(S));
-            if (__builtin_amdgcn_ballot_w64(edt_as_u32(open) != 0u) == 0ull) break;      /* i^2 >= best everywhere */
+            unsigned open = edt_as_u32(__builtin_elementwise_sub_sat(best[0], edt_as_us2(S)));
+            if (NW == 2) open |= edt_as_u32(__builtin_elementwise_sub_sat(best[NW - 1], edt_as_us2(S)));
+            if (__builtin_amdgcn_ballot_w64(open != 0u) == 0ull) break;      /* i^2 >= best everywhere */
             asm volatile("" : "+v"(la), "+v"(ra));             /* keep the two addresses as they are: offsets go into the instructions */
-            lds_cu *ql = (lds_cu *)(size_t)la, *qr = (lds_cu *)(size_t)ra;
-            edt_us2 acc = best;
+            edt_us2 acc[NW];
 #pragma unroll
-            for (int j = 1; j <= 8; j++) {
-                const edt_us2 a = edt_as_us2(ql[(8 - j) * RP]), b = edt_as_us2(qr[j * RP]);
-                acc = __builtin_elementwise_min(acc, __builtin_elementwise_add_sat(__builtin_elementwise_min(a, b), edt_as_us2(S)));
-                S += D; D += 0x00020002u;
+            for (int w = 0; w < NW; w++) acc[w] = best[w];
+            if constexpr (NW == 1) {
+                lds_cu *ql = (lds_cu *)(size_t)la, *qr = (lds_cu *)(size_t)ra;
+#pragma unroll
+                for (int j = 1; j <= 8; j++) {
+                    const edt_us2 a = edt_as_us2(ql[(8 - j) * RP]), b = edt_as_us2(qr[j * RP]);
+                    acc[0] = __builtin_elementwise_min(acc[0], __builtin_elementwise_add_sat(__builtin_elementwise_min(a, b), edt_as_us2(S)));
+                    S += D; D += 0x00020002u;
+                }
+            } else {
+                /* sixteen ds_read_b64 and their wait as ONE statement: left to itself the compiler pairs them into ds_read2_b64 */
+                edt_u2 av[8], bv2[8];
+                edt_rows_read16<RP * 4>(la, ra, av, bv2);
+#pragma unroll
+                for (int j = 1; j <= 8; j++) {
+                    const edt_u2 a = av[j - 1], b = bv2[j - 1];                        /* four rows of columns x - j, x + j */
+                    acc[0] = __builtin_elementwise_min(acc[0], __builtin_elementwise_add_sat(__builtin_elementwise_min(edt_as_us2(a.x), edt_as_us2(b.x)), edt_as_us2(S)));
+                    acc[NW - 1] = __builtin_elementwise_min(acc[NW - 1], __builtin_elementwise_add_sat(__builtin_elementwise_min(edt_as_us2(a.y), edt_as_us2(b.y)), edt_as_us2(S)));
+                    S += D; D += 0x00020002u;
+                }
             }
-            best = acc;
+#pragma unroll
+            for (int w = 0; w < NW; w++) best[w] = acc[w];
             la -= 8u * RP * 4u; ra += 8u * RP * 4u;
             i += 8;
         }
         const unsigned i2 = S & 0xffffu;
         /* the exact finish of what is still open: rare (a pixel further than the pad from the border AND from every edge found
          * so far, or further than 255 pixels from every edge) */
-        unsigned b0 = best.x, b1 = best.y;
-        if (live0 && i2 < b0) b0 = (b0 == 65535u) ? edt_finish32<R>(tg, cols, xx, 2 * rp, 1, (unsigned)tg[cp * 2] * (unsigned)tg[cp * 2])
-                                                 : edt_finish32<R>(tg, cols, xx, 2 * rp, i, b0);
-        if (live1 && i2 < b1) b1 = (b1 == 65535u) ? edt_finish32<R>(tg, cols, xx, 2 * rp + 1, 1, (unsigned)tg[cp * 2 + 1] * (unsigned)tg[cp * 2 + 1])
-                                                 : edt_finish32<R>(tg, cols, xx, 2 * rp + 1, i, b1);
-        if (p < totalp) {
-            /* both presence words are requested before anything waits on them; one 8-byte store for the lane's two rows
-             * (rows past the image: 0, never read) */
-            const unsigned w0 = b0 >> 5, bit0 = 1u << (b0 & 31u), w1 = b1 >> 5, bit1 = 1u << (b1 & 31u);
-            const bool in0 = w0 < (unsigned)EDT_LBITS_WORDS, in1 = w1 < (unsigned)EDT_LBITS_WORDS;
-            const unsigned have0 = in0 ? __hip_atomic_load(&lbits[w0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
-            const unsigned have1 = in1 ? __hip_atomic_load(&lbits[w1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
-            reinterpret_cast<uint2 *>(d2)[cp] = make_uint2(live0 ? b0 : 0u, live1 ? b1 : 0u);
-            const unsigned m01 = (live0 ? b0 : 0u) > (live1 ? b1 : 0u) ? (live0 ? b0 : 0u) : (live1 ? b1 : 0u);
-            mx = m01 > mx ? m01 : mx;
-            if (live0) {
-                if (in0) { if (!(have0 & bit0)) atomicOr(&lbits[w0], bit0); }
-                else if (w0 < (unsigned)bm_words) { if (!(__hip_atomic_load(bm + w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit0)) atomicOr(bm + w0, bit0); }
-                else far = true;
+        unsigned bv[NR];
+#pragma unroll
+        for (int w = 0; w < NW; w++) { bv[2 * w] = best[w].x; bv[2 * w + 1] = best[w].y; }
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            if (live[k] && i2 < bv[k]) {
+                const unsigned gk = tg[xx * R + r0 + k];
+                bv[k] = (bv[k] == 65535u) ? edt_finish32<R>(tg, cols, xx, r0 + k, 1, gk * gk) : edt_finish32<R>(tg, cols, xx, r0 + k, i, bv[k]);
             }
-            if (live1) {
-                if (in1) { if (!(have1 & bit1)) atomicOr(&lbits[w1], bit1); }
-                else if (w1 < (unsigned)bm_words) { if (!(__hip_atomic_load(bm + w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit1)) atomicOr(bm + w1, bit1); }
-                else far = true;
+        }
+        if (p < totall) {
+            /* all presence words are requested before anything waits on them; one store for the lane's rows (rows past the image:
+             * 0, never read) */
+            unsigned wd[NR], bit[NR], have[NR];
+            bool in[NR];
+#pragma unroll
+            for (int k = 0; k < NR; k++) {
+                wd[k] = bv[k] >> 5; bit[k] = 1u << (bv[k] & 31u); in[k] = wd[k] < (unsigned)EDT_LBITS_WORDS;
+                have[k] = in[k] ? __hip_atomic_load(&lbits[wd[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < NR; k++) if (!live[k]) bv[k] = 0u;
+            if constexpr (NW == 1) reinterpret_cast<uint2 *>(d2)[cp] = make_uint2(bv[0], bv[1]);
+            else reinterpret_cast<uint4 *>(d2)[cp] = make_uint4(bv[0], bv[1], bv[2], bv[3]);
+#pragma unroll
+            for (int k = 0; k < NR; k++) {
+                mx = bv[k] > mx ? bv[k] : mx;
+                if (live[k]) {
+                    if (in[k]) { if (!(have[k] & bit[k])) atomicOr(&lbits[wd[k]], bit[k]); }
+                    else if (wd[k] < (unsigned)bm_words) { if (!(__hip_atomic_load(bm + wd[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit[k])) atomicOr(bm + wd[k], bit[k]); }
+                    else far = true;
+                }
             }
         }
     }

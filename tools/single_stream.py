@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--warm-us", type=int, default=200, help="period of the keep-warm launches")
     ap.add_argument("--out", default="")
     ap.add_argument("--order", default="back_to_back,paced,paced_warm", help="which runs, in which order")
+    ap.add_argument("--upload-flags", type=int, default=0, help="flags of dvo_frames_upload_cameras: 1 = ASYNC (do not wait for the frame stage "
+                    "before enqueueing the alignment), 16 = MAPPED (the pinned frame is pulled by a kernel, no copy into the engine's mirror)")
     ap.add_argument("--warm-busy-us", type=int, default=0, help="> 0: keep-warm as dvo_set_keep_warm2(busy, warm_us) instead of short launches")
     args = ap.parse_args()
     iters = [args.iters] * args.levels
@@ -54,7 +56,8 @@ def main():
 
     def frame(k, ev):
         ev[0].record(stream)
-        ctx.frames_upload_cameras([nows[k % len(nows)]], None, n_levels=args.levels, first_shift=0, first_slot=1, now_first_pair=0)
+        ctx.frames_upload_cameras([nows[k % len(nows)]], None, n_levels=args.levels, first_shift=0, first_slot=1, now_first_pair=0,
+                                  flags=args.upload_flags)
         ctx.enqueue(iters, flags=DVO_FLAG_IDENTITY_START)
         ev[1].record(stream)
         return ctx.get_poses()
@@ -87,7 +90,7 @@ def main():
         ctx.set_keep_warm(0)
         return dict(host_wall=stats(wall), gpu_events=stats(gpu), first_10_wall_ms=[round(w * 1e3, 3) for w in wall[:10]])
     out = {"config": dict(width=args.width, height=args.height, levels=args.levels, iters=args.iters, frames=args.frames, hz=args.hz,
-                          warm_period_us=args.warm_us,
+                          warm_period_us=args.warm_us, upload_flags=args.upload_flags,
                           per_frame="H2D BGR8 -> pyramid + Canny -> distance transform -> compact now level -> alignment -> pose on the host")}
     for name in args.order.split(","):
         out[name] = run(name != "back_to_back", name == "paced_warm")
