@@ -352,8 +352,8 @@ def sparse_scenes_leg(stream, quick=False):
     half is empty (320 px at 640x480, 960 px at 1920x1080, 2048 px at 4096x3072: pixels hundreds of pixels from every edge, many
     distinct distances).  Per configuration: what form every level of every distinct scene got (the compact form, or the reason it was
     refused: dvo_get_now_compact_info), what the launch read, aligns/s and the roofline fraction by the same algorithmic-byte
-    definition as the headline (it counts whole images: with few points it exceeds what the launch touches, so `roofline_frac` can
-    pass 1 here -- it is a rate, not an efficiency).  Rounds 3-4 REFUSED the finest levels of such scenes (more than 8191 distinct
+    definition as the headline (it counts whole images: with few points it exceeds what the launch touches, so the ratio to the HBM
+    peak -- `algorithmic_rate_over_hbm_peak`, deliberately not called a roofline fraction -- can pass 1 here: a rate, not an efficiency).  Rounds 3-4 REFUSED the finest levels of such scenes (more than 8191 distinct
     distances / a pixel 512 px or more from every edge) and read them as 16-byte texels; round 5 writes a PARTIAL compact form
     (dvo_palette.h): `levels_partial`, and `exact_fallback_ran_pair0` says whether any wave met a pixel the form cannot express."""
     from rgbd_odometry_amd import DvoContext, SynthScene
@@ -401,7 +401,10 @@ def sparse_scenes_leg(stream, quick=False):
                 out.append({
                     "workload": "%dx%dx%d, %d pairs (%d distinct), %.1f %% edge pixels in the left half" % (W, H, nl, B, D, 100 * dens),
                     "edge_density_level0": float(np.mean([(np.asarray(sc.levels[0].now_edge) != 0).mean() for sc in scenes])),
-                    "aligns_per_s": B * steps / el, "kernel_ms": k_ms, "roofline_frac": nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "aligns_per_s": B * steps / el, "kernel_ms": k_ms,
+                    # NOT an efficiency: SURVEY 8(d)'s bytes count every level's whole image, a launch over a few thousand points touches a
+                    # fraction of it -- the ratio passes 1 on the sparsest scenes
+                    "algorithmic_rate_over_hbm_peak": nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                     "levels_refused": refused, "levels_partial": sum(1 for row in part for v in row if v), "levels_total": D * nl,
                     "exact_fallback_ran_pair0": [bool(ctx.level_exact_fallback(0, l)) for l in range(nl)],
                     "compact_info_per_level_scene0": info[0],          # > 0: palette size; < 0: refusal reason

@@ -13,6 +13,6 @@ print(json.dumps(res, indent=1))
 for r in res:
     if "error" in r:
         print("#", r["workload"], "ERROR", r["error"], file=sys.stderr); continue
-    print("# %-70s %9.0f aligns/s  frac %.3f  refused %d partial %d of %d %s  info %s  fallback %s" % (r["workload"], r["aligns_per_s"], r["roofline_frac"],
+    print("# %-70s %9.0f aligns/s  alg. rate / HBM peak %.3f  refused %d partial %d of %d %s  info %s  fallback %s" % (r["workload"], r["aligns_per_s"], r["algorithmic_rate_over_hbm_peak"],
           r["levels_refused"], r.get("levels_partial", 0), r["levels_total"], r["refusal_reasons"], r["compact_info_per_level_scene0"],
           r.get("exact_fallback_ran_pair0")), file=sys.stderr)
