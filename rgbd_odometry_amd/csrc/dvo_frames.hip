@@ -1114,7 +1114,13 @@ edt_rows16_kernel(const unsigned short *__restrict__ g, int rows, int cols, unsi
  * the true minimum is below 65535: a clamped candidate is >= 65535 and cannot be it.  What the packed scan cannot finish --
  * a pixel whose best is still 65535, or still open when the wave's common range (the pad, 252 steps) ends -- is finished by
  * the exact 32-bit per-lane scan over the second tile (g itself), from scratch if it saturated. */
-constexpr int EDT_PK_PAD = 32;
+/* Round 5, measured (tools/experiments/r05_edt_rows_ab.sh, 256 camera frames, per launch): pad 32: 153 us, 64: 158, 128: 158, 256: 176 -- the
+ * exact finish that a small pad sends border pixels to is not what the pass spends its time on.  Also measured: the finish reading g from
+ * HBM instead of a second LDS tile (15 instead of 26 KB per workgroup, 10 instead of 6 workgroups per CU): 170 us. */
+#ifndef DVO_EDT_PAD
+#define DVO_EDT_PAD 32
+#endif
+constexpr int EDT_PK_PAD = DVO_EDT_PAD;
 typedef unsigned short edt_us2 __attribute__((ext_vector_type(2)));
 DVO_DEV edt_us2 edt_as_us2(unsigned v) { return __builtin_bit_cast(edt_us2, v); }
 DVO_DEV unsigned edt_as_u32(edt_us2 v) { return __builtin_bit_cast(unsigned, v); }
