@@ -1002,6 +1002,28 @@ DVO_DEV void edt_columns8_body(const int bx, const int gx, const int by, const u
  * the values produced are recorded in the image's presence bitmap (an LDS copy first -- a bit is only set if it is not there
  * yet, so the atomics die out after the first few pixels -- merged into HBM once per workgroup). */
 constexpr int EDT_LBITS_WORDS = 1024;               /* d2 < 32768 go through the LDS copy of the bitmap */
+/* the workgroup's presence bits -> the image's bitmap: only the bits the image does not have yet (most are there already, set by the
+ * workgroups before this one).  The four words of a thread are looked up TOGETHER (round 5: they were four dependent memory round
+ * trips at the end of every workgroup -- 16 % of the row pass's wave time, tools/experiments/r05_edt_stamps.py). */
+DVO_DEV void edt_flush_lbits(const unsigned *lbits, unsigned *bm, int bm_words) {
+    static_assert(EDT_LBITS_WORDS == 4 * 256, "four words per thread of the 256");
+    unsigned v[4], have[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int w = (int)threadIdx.x + 256 * q;
+        v[q] = (w < bm_words) ? lbits[w] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int w = (int)threadIdx.x + 256 * q;
+        have[q] = v[q] ? __hip_atomic_load(bm + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int w = (int)threadIdx.x + 256 * q;
+        if ((have[q] & v[q]) != v[q]) atomicOr(bm + w, v[q]);
+    }
+}
 /* T = unsigned: the tile holds g^2; T = unsigned short (rows too long for that, beyond 16 K columns): g, squared at use */
 template <typename T> DVO_DEV unsigned edt_sq(T v) { return (sizeof(T) == 2) ? (unsigned)v * (unsigned)v : (unsigned)v; }
 template <int R, typename T>
@@ -1097,10 +1119,7 @@ edt_rows16_kernel(const unsigned short *__restrict__ g, int rows, int cols, unsi
     const int m = block_reduce_256<true>((int)(mx > 0x7fffffffu ? 0x7fffffffu : mx));    /* d2 < 2^31 (rows + cols < 46340) */
     if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = m;
     __syncthreads();
-    for (int w = threadIdx.x; w < EDT_LBITS_WORDS && w < bm_words; w += 256) {
-        const unsigned v = lbits[w];
-        if (v && (__hip_atomic_load(bm + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v) atomicOr(bm + w, v);
-    }
+    edt_flush_lbits(lbits, bm, bm_words);
     if (__syncthreads_or(far ? 1 : 0) && threadIdx.x == 0) atomicOr(flags + blockIdx.y, (int)EDT_FLAG_FAR);
 }
 
@@ -1186,6 +1205,25 @@ DVO_DEV void edt_rows_read16(unsigned la, unsigned ra, edt_u2 (&a)[8], edt_u2 (&
 #else
 #define DVO_EDT_NW(R) 1
 #endif
+#ifdef DVO_EDT_STAMPS
+/* diagnostic build (make EXP=edtstamps EXPDEFS=-DDVO_EDT_STAMPS=1; tools/experiments/r05_edt_stamps.py): where the waves of the row pass spend
+ * their cycles -- s_memtime sums over all waves: [0] staging incl. its barrier, [1] scan trips, [2] exact finish, [3] stores + presence
+ * bitmap, [4] tail (block maximum, bitmap flush), [5] waves, [6] trips, [7] whole kernel */
+constexpr int EDT_STAMP_SLOTS = 1 << 18;                 /* one slot per wave: plain stores, no contention added to what is measured */
+__device__ unsigned long long g_edt_stamp[EDT_STAMP_SLOTS][8];
+DVO_DEV unsigned long long edt_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define EDT_T(v) const unsigned long long v = edt_now()
+#define EDT_ACC(k, a, b) acc_t[k] += (b) - (a)
+#else
+#define EDT_T(v) do {} while (0)
+#define EDT_ACC(k, a, b) do {} while (0)
+#endif
 template <int R, int NW = DVO_EDT_NW(R)>
 DVO_DEV void edt_rows_pk_body(const int bx, const int gx, const int by, const unsigned short *__restrict__ g, int rows, int cols, unsigned *__restrict__ d2, int *__restrict__ partial,
                    unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags) {
@@ -1202,6 +1240,10 @@ DVO_DEV void edt_rows_pk_body(const int bx, const int gx, const int by, const un
     const unsigned *gblk = reinterpret_cast<const unsigned *>(g + (size_t)by * edt_g_count(rows, cols, R) + (size_t)bx * cols * R);
     d2 += (size_t)by * edt_g_count(rows, cols, R) + (size_t)bx * cols * R;      /* d2 too is written in row blocks */
     unsigned *bm = bitmap + (size_t)by * bm_words;
+#ifdef DVO_EDT_STAMPS
+    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    EDT_T(t_begin);
     const int y0 = bx * R;
     const int totalp = cols * RP;                              /* dwords of the tile */
     const int totall = cols * LP;                              /* lane items: NW dwords each */
@@ -1223,12 +1265,16 @@ DVO_DEV void edt_rows_pk_body(const int bx, const int gx, const int by, const un
     }
     for (int p = 4 * n4 + threadIdx.x; p < totalp; p += 256) stage(p, gblk[p]);
     __syncthreads();
+    EDT_T(t_staged);
+    EDT_ACC(0, t_begin, t_staged);
     typedef __attribute__((address_space(3))) const unsigned lds_cu;
 
     const unsigned tq_lds = (unsigned)(size_t)(lds_cu *)tq + (unsigned)(EDT_PK_PAD * RP * 4);         /* LDS byte address of column 0 */
     unsigned mx = 0;
     bool far = false;
     const int lane = threadIdx.x & 63;
+    /* (round 5, measured: handing the chunks out dynamically through an LDS counter instead of this static interleave: 161 against 153 us
+     * per launch -- the workgroup's tail is not wave imbalance) */
     const int wave_base = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
     for (int base = wave_base; base < totall; base += 256) {    /* wave-uniform: 64 lane items = 64/LP columns */
         const int p = base + lane;
@@ -1253,6 +1299,7 @@ DVO_DEV void edt_rows_pk_body(const int bx, const int gx, const int by, const un
         unsigned S = 0x00010001u, D = 0x00030003u;
         unsigned la = tq_lds + (unsigned)((dq - 8 * RP) * 4);   /* far end of a trip's left side: LDS offsets are unsigned */
         unsigned ra = tq_lds + (unsigned)(dq * 4);
+        EDT_T(t_s0);
         while (i + 7 <= lim) {                                  /* eight steps per trip, one exit test */
             unsigned open = edt_as_u32(__builtin_elementwise_sub_sat(best[0], edt_as_us2(S)));
             if (NW == 2) open |= edt_as_u32(__builtin_elementwise_sub_sat(best[NW - 1], edt_as_us2(S)));
@@ -1286,6 +1333,11 @@ DVO_DEV void edt_rows_pk_body(const int bx, const int gx, const int by, const un
             la -= 8u * RP * 4u; ra += 8u * RP * 4u;
             i += 8;
         }
+        EDT_T(t_s1);
+        EDT_ACC(1, t_s0, t_s1);
+#ifdef DVO_EDT_STAMPS
+        acc_t[6] += (unsigned long long)(i >> 3);
+#endif
         const unsigned i2 = S & 0xffffu;
         /* the exact finish of what is still open: rare (a pixel further than the pad from the border AND from every edge found
          * so far, or further than 255 pixels from every edge) */
@@ -1299,6 +1351,8 @@ DVO_DEV void edt_rows_pk_body(const int bx, const int gx, const int by, const un
                 bv[k] = (bv[k] == 65535u) ? edt_finish32<R>(tg, cols, xx, r0 + k, 1, gk * gk) : edt_finish32<R>(tg, cols, xx, r0 + k, i, bv[k]);
             }
         }
+        EDT_T(t_s2);
+        EDT_ACC(2, t_s1, t_s2);
         if (p < totall) {
             /* all presence words are requested before anything waits on them; one store for the lane's rows (rows past the image:
              * 0, never read) */
@@ -1323,16 +1377,27 @@ DVO_DEV void edt_rows_pk_body(const int bx, const int gx, const int by, const un
                 }
             }
         }
+        EDT_T(t_s3);
+        EDT_ACC(3, t_s2, t_s3);
     }
+    EDT_T(t_loop);
 
     const int m = block_reduce_256<true>((int)(mx > 0x7fffffffu ? 0x7fffffffu : mx));    /* d2 < 2^31 (rows + cols < 46340) */
     if (threadIdx.x == 0) partial[(size_t)by * gx + bx] = m;
     __syncthreads();
-    for (int w = threadIdx.x; w < EDT_LBITS_WORDS && w < bm_words; w += 256) {
-        const unsigned v = lbits[w];
-        if (v && (__hip_atomic_load(bm + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v) atomicOr(bm + w, v);
-    }
+    edt_flush_lbits(lbits, bm, bm_words);
     if (__syncthreads_or(far ? 1 : 0) && threadIdx.x == 0) atomicOr(flags + by, (int)EDT_FLAG_FAR);
+#ifdef DVO_EDT_STAMPS
+    {
+        EDT_T(t_end);
+        EDT_ACC(4, t_loop, t_end);
+        EDT_ACC(7, t_begin, t_end);
+        acc_t[5] = 1;
+        const unsigned slot = ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6)) & (unsigned)(EDT_STAMP_SLOTS - 1);
+        if ((threadIdx.x & 63) == 0)
+            for (int k = 0; k < 8; k++) g_edt_stamp[slot][k] = acc_t[k];
+    }
+#endif
 }
 
 DVO_DEV int reflect101(int i, int n) { return (n == 1) ? 0 : (i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i)); }
@@ -1973,10 +2038,7 @@ float_level_d2_kernel(const float *__restrict__ dt, int rows, int cols, int R, c
     const int m = block_reduce_256<true>((int)(mx > 0x7fffffffu ? 0x7fffffffu : mx));
     if (threadIdx.x == 0 && m > 0) atomicMax(partial, m);
     __syncthreads();
-    for (int w = threadIdx.x; w < EDT_LBITS_WORDS && w < bm_words; w += 256) {
-        const unsigned v = lbits[w];
-        if (v && (__hip_atomic_load(bitmap + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v) atomicOr(bitmap + w, v);
-    }
+    edt_flush_lbits(lbits, bitmap, bm_words);
     const int f = (bad ? EDT_FLAG_BAD : 0) | (far ? EDT_FLAG_FAR : 0);
     const int any = __syncthreads_or(f & EDT_FLAG_BAD) ? EDT_FLAG_BAD : 0, anyfar = __syncthreads_or(f & EDT_FLAG_FAR) ? EDT_FLAG_FAR : 0;
     if (threadIdx.x == 0 && (any | anyfar)) atomicOr(flags, any | anyfar);
@@ -2196,3 +2258,19 @@ hipError_t launch_enlist_write(const void *edge, int edge_is_u8, size_t edge_str
 }
 
 }  // namespace dvo
+
+#ifdef DVO_EDT_STAMPS
+extern "C" int dvo_debug_edt_stamps(unsigned long long *out, int reset) {
+    static std::vector<unsigned long long> h((size_t)dvo::EDT_STAMP_SLOTS * 8);
+    if (out) {
+        if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(dvo::g_edt_stamp), sizeof(unsigned long long) * h.size()) != hipSuccess) return -1;
+        for (int k = 0; k < 8; k++) out[k] = 0;
+        for (size_t i = 0; i < h.size(); i++) out[i & 7] += h[i];
+    }
+    if (reset) {
+        std::fill(h.begin(), h.end(), 0ull);
+        if (hipMemcpyToSymbol(HIP_SYMBOL(dvo::g_edt_stamp), h.data(), sizeof(unsigned long long) * h.size()) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
