@@ -272,6 +272,11 @@ int  dvo_tiled_shard(dvo_ctx *ctx, int pair, int level, int *first, int *count);
  * per iteration, no host work in between), 0 if the schedule was submitted launch by launch (the runtime refused to capture the
  * collective, DVO_TILED_NO_GRAPH=1, or the legacy null stream) */
 int  dvo_tiled_graph_replayed(dvo_ctx *ctx, int *graph_replayed);
+/* inspection: bit l of *levels_mask = 1 if level l of the last dvo_align_pyramid_wide / _tiled schedule that was ENQUEUED (a replayed
+ * graph keeps the mask of its capture) ran the packed two-points-per-lane step kernel over the compact list (round 5; lists built by
+ * the engine's own reference-point kernels have one), 0 for the one-point-per-lane kernel over the 3 x N list (caller-supplied
+ * lists, DVO_FLAG_NORMAL_MATRIX, dvo_params.interpolate_dt) */
+int  dvo_wide_packed_levels(dvo_ctx *ctx, int *levels_mask);
 
 /* ---- inspection (used by the parity tests) ---------------------------------
  * One evaluation of computeJacobianOfNowFrame + getReprojectedEpsilons at the

@@ -1610,6 +1610,8 @@ hipError_t enqueue_step_schedule(dvo_ctx *c, const Schedule &sc, int pair, int f
     double *acc[2] = {c->d_step_acc, c->d_step_acc + DVO_NACC_PAD};
     double *partials = c->d_scratch;
     int cur = 0, k = 0;                                                 /* state to read next; launches so far (the sums alternate) */
+    bool first_level = true;
+    c->step_pk_mask = 0;
     for (int l = sc.n_levels - 1; l >= 0; --l) {                        /* :2097 */
         if (sc.iters[l] <= 0) continue;                                 /* :2099 */
         const int N = c->lv[l].hN[pair];
@@ -1617,22 +1619,37 @@ hipError_t enqueue_step_schedule(dvo_ctx *c, const Schedule &sc, int pair, int f
         shard_of(N, rank, world, first, count);
         float *energy = c->d_energy + (size_t)pair * sc.e_stride + sc.e_off[l];
         const LevelSlab sl = slab_of(c, l);
-        rec(launch_iter_begin(st[cur], c->dprm, d_pose, energy, sc.iters[l], c->stream));
+        /* the first level's state comes from the pose; every later level's was prepared by the finish launch of the level before it */
+        if (first_level) rec(launch_iter_begin(st[cur], c->dprm, d_pose, energy, sc.iters[l], c->stream));
+        first_level = false;
         const int nb = tiled_step_blocks(count, c->n_cu);
         /* DVO_FLAG_NORMAL_MATRIX: the launches also form H = sum w J J^T (21 more double sums per point: + 40 % on the launch),
          * it rides in the same 32 doubles through the all-reduce and is kept per iterate (dvo_get_level_normal_matrix); without
          * the flag those 21 slots are zeros -- the reference's update never reads them (SolveDVO.cpp:777) */
         double *H = (flags & DVO_FLAG_NORMAL_MATRIX) ? c->d_H + ((size_t)pair * sc.e_stride + sc.e_off[l]) * 21 : nullptr;
+        /* round 5: the packed point loop (dvo_fused.hip: tiled_step_pk_kernel) where the level's list has its compact twin -- lists built
+         * by the engine's own enlist kernels do -- and neither H nor the interpolating look-up is asked for; DVO_TILED_PACKED=off for A/B */
+        static const bool pk_off = [] { const char *e = std::getenv("DVO_TILED_PACKED"); return e && std::strcmp(e, "off") == 0; }();
+        const bool pk = !pk_off && !H && !c->prm.interpolate_dt && c->prm.engine_variant != 1 && sl.cpts &&
+                        !c->lv[l].compact_ok.empty() && c->lv[l].compact_ok[pair];
+        if (pk) c->step_pk_mask |= 1 << l;
         for (int itr = 0; itr < sc.iters[l]; itr++, k++) {
             const int apply = itr > 0;
+            if (pk)
+                rec(launch_tiled_step_pk(sl, pair, l, c->K, st[cur], st[cur ^ 1], acc[(k + 1) & 1], itr, apply, N, first, count, partials,
+                                         c->d_step_ticket, acc[k & 1], energy, nb, c->stream));
+            else
             rec(launch_tiled_step(sl, pair, l, c->K, c->dprm, st[cur], st[cur ^ 1], acc[(k + 1) & 1], itr, apply, N, first, count, partials,
                                   c->d_step_ticket, acc[k & 1], energy, nb, H ? H + (size_t)(itr > 0 ? itr - 1 : 0) * 21 : nullptr, c->stream));
             if (apply) cur ^= 1;
             if (all_reduce) rec(all_reduce(acc[k & 1]));
         }
+        int ln = l - 1;                                                 /* the next level that runs */
+        while (ln >= 0 && sc.iters[ln] <= 0) --ln;
         rec(launch_tiled_finish(st[cur], st[cur ^ 1], c->dprm, acc[(k + 1) & 1], sc.iters[l] - 1, N, energy, d_pose,
                                 c->d_best + pair * DVO_LEVELS + l, c->d_ratio + pair * DVO_LEVELS + l,
-                                H ? H + (size_t)(sc.iters[l] - 1) * 21 : nullptr, c->stream));
+                                H ? H + (size_t)(sc.iters[l] - 1) * 21 : nullptr,
+                                ln >= 0 ? c->d_energy + (size_t)pair * sc.e_stride + sc.e_off[ln] : nullptr, ln >= 0 ? sc.iters[ln] : 0, c->stream));
         cur ^= 1;
         /* finalEpsilons / finalReprojections (:703-704, :1002-1003): this rank's share, at the points' own indices */
         if ((flags & DVO_FLAG_FINAL_OUTPUTS) && l == sc.last_level)
@@ -1653,6 +1670,8 @@ unsigned long long step_schedule_signature(dvo_ctx *c, const Schedule &sc, int p
         const LevelSlab sl = slab_of(c, l);
         mix((unsigned long long)sc.iters[l]); mix((unsigned long long)c->lv[l].hN[pair]);
         mix((unsigned long long)(size_t)sl.tex); mix((unsigned long long)(size_t)sl.pts); mix((unsigned long long)sl.tex_stride);
+        mix((unsigned long long)(size_t)sl.cpts);                       /* which step kernel a level gets (enqueue_step_schedule: pk) */
+        mix((unsigned long long)((!c->lv[l].compact_ok.empty() && c->lv[l].compact_ok[pair]) ? 1 : 0));
         mix((unsigned long long)sl.pt_cap); mix((unsigned long long)sl.rows); mix((unsigned long long)sl.cols);
     }
     { unsigned long long kb[3] = {0, 0, 0}; std::memcpy(kb, &c->K, sizeof(c->K) < sizeof(kb) ? sizeof(c->K) : sizeof(kb)); mix(kb[0]); mix(kb[1]); mix(kb[2]); }

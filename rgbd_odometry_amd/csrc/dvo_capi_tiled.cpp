@@ -134,6 +134,13 @@ int dvo_tiled_graph_replayed(dvo_ctx *c, int *graph_replayed) {
     return DVO_OK;
 }
 
+int dvo_wide_packed_levels(dvo_ctx *c, int *levels_mask) {
+    DVO_ENTER(c);
+    if (!levels_mask) return fail(c, DVO_ERR_INVALID, "levels_mask is NULL");
+    *levels_mask = c->step_pk_mask;
+    return DVO_OK;
+}
+
 int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters, int flags, double *R, double *t) {
     DVO_ENTER(c);
     if (!pair_ok(c, pair) || !R || !t) return fail(c, DVO_ERR_INVALID, "bad arguments");

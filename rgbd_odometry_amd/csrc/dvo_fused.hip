@@ -26,6 +26,7 @@
 #include "dvo_kernel_common.h"
 #include "dvo_point_pk.h"
 #include "dvo_palette.h"
+#include "dvo_tiled_step.h"
 
 #include <cstdlib>
 
@@ -1422,6 +1423,61 @@ hipError_t launch_align_fused2(int block_threads, const LevelSet &lv, const Sche
     case 1024: return launch_fused2_b<1024>(lv, sc, K, prm, out, first_pair, n_pairs, s);
     default: return launch_fused2_b<512>(lv, sc, K, prm, out, first_pair, n_pairs, s);
     }
+}
+
+/* ---- the launch of one iteration of the tiled / wide schedule with THIS file's point loop (round 5) -------------------------------
+ * tiled_step_kernel (dvo_kernels.hip) runs one point per lane over the reference's 3 x N float list: 7.5 us for the 2.4 k points a
+ * workgroup gets of a 4096 x 3072 level 0, issue-bound.  Here the same launch -- head, hand-off and last arriver are shared
+ * (dvo_tiled_step.h) -- streams its share of the COMPACT list (8 bytes per point, a round ahead) through the packed
+ * two-points-per-lane rounds, looking the texels up in the level's 16-byte image (the tiled schedule replicates that image on every
+ * rank; its compact form would need the palette in every workgroup's LDS at every launch).  Lists the engine's own enlist kernels
+ * built have the compact twin; without it, with H, or with interpolate_dt the launch is tiled_step_kernel. */
+__global__ void __launch_bounds__(DVO_STEP_THREADS)
+tiled_step_pk_kernel(LevelSlab L, int pair, int level, Intrinsics K, const PoseState *st_in, PoseState *st_out,
+                     const double *__restrict__ acc_in, int itr, int apply_prev, int n_total, int first, int n,
+                     double *partials, unsigned *ticket, double *acc_out, float *energy) {
+    __shared__ double red[DVO_STEP_THREADS / 64][8];
+    __shared__ TiledStepLds m;
+    tiled_step_body<false>(m, st_in, st_out, acc_in, itr, apply_prev, n_total, first, n, partials, ticket, acc_out, energy, nullptr,
+        [&](const PoseCur &pc, bool run, int b0, int b1, double *tot) {
+            const int tid = threadIdx.x;
+            Acc7 a;
+            acc7_zero(a);
+            if (run) {
+                const char *__restrict__ tex = reinterpret_cast<const char *>(L.tex + (size_t)pair * L.tex_stride);
+                const uint2 *__restrict__ gpts = L.cpts + (size_t)pair * L.pt_cap;
+                IterConst c;
+                level_consts(c, K, level, L.rows, L.cols);
+#pragma unroll
+                for (int k = 0; k < 9; k++) c.r[k] = uniform_f(pc.Rf[k]);
+#pragma unroll
+                for (int k = 0; k < 3; k++) c.t[k] = uniform_f(pc.tf[k]);
+                TexSrc ts = {};
+                ts.g16 = tex; ts.tile_col_bytes = (unsigned)c.tiles_per_col * 128u;
+                LdsPoints lp = {};
+                bool any_odd = false;
+                accumulate_points2<DVO_STEP_THREADS, false, TEX_G16, 2, 0, false, Acc7>(c, ts, lp, gpts, b0, b1, tid, a, any_odd);
+                {   /* a degenerate z somewhere in this wave's share: again with the literal divisions (see align_fused2_kernel) */
+                    const double chk = ((a.g[0] + a.g[1]) + (a.g[2] + a.g[3])) + ((a.g[4] + a.g[5]) + a.e2);
+                    any_odd |= (__builtin_amdgcn_ballot_w64(!__builtin_isfinite(chk)) != 0ull);
+                }
+                if (any_odd) {
+                    acc7_zero(a);
+                    accumulate_points_exact<DVO_STEP_THREADS, false, false, false, Acc7>(c, tex, ts, nullptr, lp, gpts, b0, b1, tid, a);
+                }
+            }
+            wave_sums7(a, red);
+            __syncthreads();
+            if (tid < DVO_NACC_PAD) tot[tid] = (tid >= 21 && tid < 29) ? block_sum8<DVO_STEP_THREADS>(red, tid - 21) : 0.0;
+            __syncthreads();
+        });
+}
+hipError_t launch_tiled_step_pk(const LevelSlab &L, int pair, int level, const Intrinsics &K, const void *st_in, void *st_out,
+                                const double *acc_in, int itr, int apply_prev, int n_total, int first_point, int n_points,
+                                double *partials, unsigned *ticket, double *acc_out, float *energy, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(tiled_step_pk_kernel, dim3(nblocks), dim3(DVO_STEP_THREADS), 0, s, L, pair, level, K, (const PoseState *)st_in,
+                       (PoseState *)st_out, acc_in, itr, apply_prev, n_total, first_point, n_points, partials, ticket, acc_out, energy);
+    return hipGetLastError();
 }
 
 }  // namespace dvo

@@ -25,6 +25,7 @@
  */
 #include "dvo_kernel_common.h"
 #include "dvo_palette.h"
+#include "dvo_tiled_step.h"
 
 namespace dvo {
 
@@ -747,175 +748,45 @@ iter_reduce_update_kernel(PoseState *st, DevParams prm, int itr, int n_total,
  * then the workgroup barrier), the last arriver is told by the value its add returned, its other waves load after a barrier it
  * then joins; hipMalloc memory, one workgroup per CU (the host launches at most that many), all stores and loads of the handed-
  * off rows 8-byte sc1.  */
-DVO_DEV void store_sc1_f64(double *p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
-/* a relaxed agent-scope atomic load IS global_load_dwordx2 sc1 (MI355X_MICROARCH.md, the HIP construct table), with the wait
- * counters left to the compiler: the sixteen loads of a lane below are all in flight before the first is consumed (an inline-asm
- * load would have to wait for itself: 16 dependent memory latencies in the last workgroup of every launch) */
-DVO_DEV double load_sc1_f64(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #ifndef DVO_STEP_U
 #define DVO_STEP_U 1          /* points in flight per lane (measured 4096x3072x5: 1: 12.8 us per iteration, 2: 13.4, 4: 14.7 -- the launch is
                                  dominated by its fixed part, the smallest loop wins) */
 #endif
-#ifndef DVO_STEP_THREADS
-#define DVO_STEP_THREADS 512
-#endif
-static_assert(sizeof(PoseState) % 8 == 0, "the state is copied 8 bytes per lane");
-static_assert(DVO_STEP_THREADS == 512, "the last arriver of tiled_step_kernel adds the rows in 16 chains of 32 lanes");
 template <bool WITH_H>
 __global__ void __launch_bounds__(DVO_STEP_THREADS)
 tiled_step_kernel(LevelSlab L, int pair, int level, Intrinsics K, DevParams prm, const PoseState *st_in, PoseState *st_out,
                   const double *__restrict__ acc_in, int itr, int apply_prev, int n_total, int first, int n,
                   double *partials, unsigned *ticket, double *acc_out, float *energy, double *H_prev) {
     __shared__ double red[DVO_STEP_THREADS / 64][DVO_NACC_PAD];
-    __shared__ double tot[DVO_NACC_PAD];
-    __shared__ double part[16][DVO_NACC_PAD + 1];
-    __shared__ PoseState s;
-    __shared__ PoseCur nxt;                                                 /* the iterate the pending update produces */
-    __shared__ double g_s[8];                                               /* sums 21..28 of the previous launch */
-    __shared__ int s_last, s_stop0;
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    /* head (round 5): everything the update needs is requested at once -- the state (8 bytes per lane), the eight sums, the stop
-     * flag as the launch found it -- so the head pays ONE memory latency before its barrier (rounds 1-4: state, barrier, sums).
-     * Then the packed kernel's split (dvo_fused.hip, serial part): wave 0 takes direction (one component per lane) and step into
-     * `nxt`, wave 1 the energy and best-iterate bookkeeping of the same iterate; log(pose) for the regulariser was taken by
-     * workgroup 0 of the previous launch (or by iter_begin_kernel) while the others worked. */
-    {
-        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(st_in);
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(&s);
-        for (int i = tid; i < (int)(sizeof(PoseState) / 8); i += DVO_STEP_THREADS) dst[i] = src[i];
-        if (wave == 7) {
-            if (lane < 8) g_s[lane] = apply_prev ? acc_in[21 + lane] : 0.0;
-            if (lane == 8) s_stop0 = st_in->stop;
-        }
-    }
-    __syncthreads();
-    const bool upd = apply_prev && !s_stop0;                                /* after :877 nothing runs */
-    if (upd) {
-        if (wave == 0) {
-            double psi[6];
-            pose_direction_lanes(s, s.u, pose_neg_step(s.u, itr - 1), g_s[lane < 6 ? lane : 5], lane, psi);
-            if (lane == 0) pose_apply(s, s.p[0], nxt, s.u, psi);
-        } else if (wave == 1 && lane == 0) {
-            const float e = pose_bookkeep(s, s.p[0], itr - 1, n_total, g_s[6], (int)g_s[7]);
-            if (blockIdx.x == 0) energy[itr - 1] = e;                       /* :690 */
-        } else if (WITH_H && wave == 2) {
-            /* DVO_FLAG_NORMAL_MATRIX: H = sum w J J^T of the previous iterate (reduced over all ranks), kept per iterate like the batch kernels do */
-            if (H_prev && blockIdx.x == 0 && lane < 21) H_prev[lane] = acc_in[lane];
-        }
-    }
-    __syncthreads();
-    const bool moved = upd && !s.stop;                                      /* the points run at nxt, else at the state's iterate */
-    const PoseCur &pc = moved ? nxt : s.p[0];
-    const int nshare = (gridDim.x > 1) ? (int)gridDim.x - 1 : 1;
-    const int share = (gridDim.x > 1) ? (int)blockIdx.x - 1 : 0;
-    Acc a;
-    acc_zero(a);
-    if (!s.stop && share >= 0) {                                            /* wave-uniform (LDS) */
-        const float4 *__restrict__ tex = L.tex + (size_t)pair * L.tex_stride;
-        const float *__restrict__ pts = L.pts + (size_t)pair * L.pt_cap * 3;
-        IterConst c;
-        level_consts(c, K, level, L.rows, L.cols);
+    __shared__ TiledStepLds m;
+    tiled_step_body<WITH_H>(m, st_in, st_out, acc_in, itr, apply_prev, n_total, first, n, partials, ticket, acc_out, energy, H_prev,
+        [&](const PoseCur &pc, bool run, int b0, int b1, double *tot) {
+            Acc a;
+            acc_zero(a);
+            if (run) {
+                const float4 *__restrict__ tex = L.tex + (size_t)pair * L.tex_stride;
+                const float *__restrict__ pts = L.pts + (size_t)pair * L.pt_cap * 3;
+                IterConst c;
+                level_consts(c, K, level, L.rows, L.cols);
 #pragma unroll
-        for (int k = 0; k < 9; k++) c.r[k] = uniform_f(pc.Rf[k]);
+                for (int k = 0; k < 9; k++) c.r[k] = uniform_f(pc.Rf[k]);
 #pragma unroll
-        for (int k = 0; k < 3; k++) c.t[k] = uniform_f(pc.tf[k]);
-        const int per = (n + nshare - 1) / nshare;
-        const int b0 = first + share * per;
-        int b1 = b0 + per;
-        if (b1 > first + n) b1 = first + n;
-        PointSrc psrc;
-        psrc.g = pts; psrc.gc = nullptr; psrc.l = nullptr; psrc.n_lds = 0; psrc.cap = 0;
-        /* (round 5, measured: requesting every lane's first six points before the head -- they do not depend on the pose -- and
-         * issuing their gathers together made every launch 3 us SLOWER, 4096 x 3072 included: the head then waits behind eighteen
-         * cold loads, and waves without points work through dummy rounds.  The per-point phase of this kernel is issue-bound.) */
-        if (b0 < b1) accumulate_points<DVO_STEP_U, WITH_H, SRC_GLOBAL_XYZ, 2>(c, tex, psrc, b0, b1, tid, DVO_STEP_THREADS, a);
-    }
-    /* workgroup 0 keeps the state: the new iterate, log(pose) for the next update's regulariser, st_out (double-buffered: no
-     * workgroup of this launch reads what it writes).  With more than one workgroup it has no share of the points, so none of this
-     * is on the launch's critical path. */
-    if (blockIdx.x == 0) {
-        __syncthreads();                                                    /* gridDim.x == 1: the points above read pc */
-        if (moved && tid < (int)(sizeof(PoseCur) / 8))
-            reinterpret_cast<unsigned long long *>(&s.p[0])[tid] = reinterpret_cast<const unsigned long long *>(&nxt)[tid];
-        __syncthreads();
-        if (tid == 0 && !s.stop) pose_regulariser_precompute(s, s.p[0], s.u);
-        __syncthreads();
-        if (apply_prev) {
-            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&s);
-            unsigned long long *dst = reinterpret_cast<unsigned long long *>(st_out);
-            for (int i = tid; i < (int)(sizeof(PoseState) / 8); i += DVO_STEP_THREADS) dst[i] = src[i];
-        }
-    }
-    block_reduce<DVO_STEP_THREADS, WITH_H>(a, red, tot);
-    /* tail: this workgroup's row, then the ticket.  Without H only the eight sums 21..28 exist (round 5: the row is those eight
-     * doubles, a quarter of the bytes the last arriver has to collect) */
-    constexpr int ROW = WITH_H ? DVO_NACC_PAD : 8;
-    if (WITH_H) { if (tid < DVO_NACC_PAD) store_sc1_f64(partials + (size_t)blockIdx.x * ROW + tid, (tid < DVO_NACC) ? tot[tid] : 0.0); }
-    else if (tid < 8) store_sc1_f64(partials + (size_t)blockIdx.x * ROW + tid, tot[21 + tid]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        /* every storing wave: its stores have left */
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == gridDim.x - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    {   /* the last arriver: all rows in the fixed two-level order of reduce_partials_kernel (16 interleaved chains, then in order) */
-        const int nb = (int)gridDim.x;
-        if constexpr (WITH_H) {
-        const int k = tid & 31, ch = tid >> 5;                              /* 512 threads: 16 chains x 32 values */
-        double sum = 0.0;
-        for (int b0 = ch; b0 < nb && ch < 16; b0 += 16 * 16) {                          /* up to 16 rows of this chain at a time, all loads issued first */
-            double v[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int b = b0 + 16 * q;
-                v[q] = (b < nb) ? load_sc1_f64(partials + (size_t)b * ROW + k) : 0.0;
+                for (int k = 0; k < 3; k++) c.t[k] = uniform_f(pc.tf[k]);
+                PointSrc psrc;
+                psrc.g = pts; psrc.gc = nullptr; psrc.l = nullptr; psrc.n_lds = 0; psrc.cap = 0;
+                /* (round 5, measured: requesting every lane's first six points before the head -- they do not depend on the pose -- and
+                 * issuing their gathers together made every launch 3 us SLOWER, 4096 x 3072 included: the head then waits behind eighteen
+                 * cold loads, and waves without points work through dummy rounds.  The per-point phase of this kernel is issue-bound:
+                 * tiled_step_pk_kernel, dvo_fused.hip, is the answer to that.) */
+                accumulate_points<DVO_STEP_U, WITH_H, SRC_GLOBAL_XYZ, 2>(c, tex, psrc, b0, b1, (int)threadIdx.x, DVO_STEP_THREADS, a);
             }
-#pragma unroll
-            for (int q = 0; q < 16; q++) sum += v[q];                       /* fixed order: rows ch, ch + 16, ch + 32, ... */
-        }
-        if (ch < 16) part[ch][k] = sum;
-        __syncthreads();
-        if (tid < DVO_NACC_PAD) {
-            double t = 0.0;
-#pragma unroll
-            for (int j = 0; j < 16; j++) t += part[j][tid];
-            acc_out[tid] = t;
-        }
-        } else {
-        /* eight values per row: the same 16 chains (rows ch, ch + 16, ...), eight lanes each; 128 of the 512 threads load */
-        const int k = tid & 7, ch = tid >> 3;
-        double sum = 0.0;
-        for (int b0 = ch; b0 < nb && ch < 16; b0 += 16 * 16) {
-            double v[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int b = b0 + 16 * q;
-                v[q] = (b < nb) ? load_sc1_f64(partials + (size_t)b * ROW + k) : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < 16; q++) sum += v[q];
-        }
-        if (ch < 16) part[ch][k] = sum;
-        __syncthreads();
-        if (tid < DVO_NACC_PAD) {
-            double t = 0.0;
-            if (tid >= 21 && tid < 29) {
-#pragma unroll
-                for (int j = 0; j < 16; j++) t += part[j][tid - 21];
-            }
-            acc_out[tid] = t;
-        }
-        }
-        if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* for the next launch (visible at the kernel boundary) */
-    }
+            block_reduce<DVO_STEP_THREADS, WITH_H>(a, red, tot);
+        });
 }
 /* after the last iteration of a level: the pending update, then what iter_end_kernel does */
 __global__ void __launch_bounds__(64)
 tiled_finish_kernel(const PoseState *st_in, PoseState *st_out, DevParams prm, const double *__restrict__ acc_in, int itr_last,
-                    int n_total, float *energy, double *Rt12, int *best_idx, float *ratio, double *H_last) {
+                    int n_total, float *energy, double *Rt12, int *best_idx, float *ratio, double *H_last, float *next_energy, int next_iters) {
     __shared__ PoseState s;
     {
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(st_in);
@@ -936,7 +807,12 @@ tiled_finish_kernel(const PoseState *st_in, PoseState *st_out, DevParams prm, co
         for (int k = 0; k < 3; k++) Rt12[9 + k] = s.p[0].t[k];
         *best_idx = s.bestItr;
         *ratio = s.bestRatio;
+        /* round 5: the next level's iter_begin_kernel rides here (one launch less per level).  The state carries the pose as the
+         * fused kernels do between levels -- the quaternion of the best iterate and its matrix (pose_state_finish) -- instead of
+         * re-deriving the quaternion from the matrix in Rt12 (:642-657 start from cR / cT either way) */
+        if (next_iters > 0) { pose_state_begin(s); pose_regulariser_precompute(s, s.p[0], s.u); }
     }
+    for (int i = threadIdx.x; i < next_iters; i += 64) next_energy[i] = 0.0f;      /* :634 */
     __syncthreads();
     {
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&s);
@@ -947,6 +823,7 @@ tiled_finish_kernel(const PoseState *st_in, PoseState *st_out, DevParams prm, co
 int tiled_step_blocks(int n_points, int n_cu) {
     int b = (n_points + DVO_STEP_THREADS - 1) / DVO_STEP_THREADS;
     if (b < 1) b = 1;
+    if (b > 1) b += 1;                  /* workgroup 0 keeps the state and takes no points once there are several (tiled_step_kernel) */
     if (b > n_cu) b = n_cu;             /* one workgroup per CU: the hand-off form of the tail is measured for that */
     if (b > 1024) b = 1024;             /* rows of the partials buffer */
     return b;
@@ -963,9 +840,10 @@ hipError_t launch_tiled_step(const LevelSlab &L, int pair, int level, const Intr
     return hipGetLastError();
 }
 hipError_t launch_tiled_finish(const void *st_in, void *st_out, const DevParams &prm, const double *acc_in, int itr_last, int n_total,
-                               float *energy, double *Rt12, int *best_idx, float *ratio, double *H_last, hipStream_t s) {
+                               float *energy, double *Rt12, int *best_idx, float *ratio, double *H_last, float *next_energy, int next_iters,
+                               hipStream_t s) {
     hipLaunchKernelGGL(tiled_finish_kernel, dim3(1), dim3(64), 0, s, (const PoseState *)st_in, (PoseState *)st_out, prm, acc_in, itr_last,
-                       n_total, energy, Rt12, best_idx, ratio, H_last);
+                       n_total, energy, Rt12, best_idx, ratio, H_last, next_energy, next_iters);
     return hipGetLastError();
 }
 

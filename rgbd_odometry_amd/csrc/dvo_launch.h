@@ -149,8 +149,13 @@ hipError_t launch_tiled_step(const LevelSlab &L, int pair, int level, const Intr
                              void *st_out, const double *acc_in, int itr, int apply_prev, int n_total, int first_point, int n_points,
                              double *partials, unsigned *ticket, double *acc_out, float *energy, int nblocks,
                              double *H_prev /* NULL: the 21 H sums are not formed; else: where H of iterate itr - 1 goes (21 doubles) */, hipStream_t s);
+/* the same launch with the packed point loop over the compact list (dvo_fused.hip: tiled_step_pk_kernel); no H */
+hipError_t launch_tiled_step_pk(const LevelSlab &L, int pair, int level, const Intrinsics &K, const void *st_in, void *st_out,
+                                const double *acc_in, int itr, int apply_prev, int n_total, int first_point, int n_points,
+                                double *partials, unsigned *ticket, double *acc_out, float *energy, int nblocks, hipStream_t s);
 hipError_t launch_tiled_finish(const void *st_in, void *st_out, const DevParams &prm, const double *acc_in, int itr_last, int n_total,
-                               float *energy, double *Rt12, int *best_idx, float *ratio, double *H_last, hipStream_t s);
+                               float *energy, double *Rt12, int *best_idx, float *ratio, double *H_last, float *next_energy, int next_iters,
+                               hipStream_t s);      /* next_iters > 0: also what iter_begin does for the next level (its energies: next_energy) */
 /* finalEpsilons / finalReprojections of points [first, first+n) at the best iterate kept in `state` (host-driven / tiled paths) */
 hipError_t launch_final_outputs_state(const LevelSlab &L, int pair, int level, const Intrinsics &K, const void *state,
                                       int first_point, int n_points, float *final_eps, float *final_reproj, int *final_N,

@@ -5,6 +5,8 @@ the RCCL all-reduce forced at world size 1 (TiledAligner), and the C-driven tile
 bit-equal, pose within 1e-5 rad / 1e-4 m.  (More than one GPU is not available to the tests; the multi-rank logic is
 covered by the gloo world-size-2 tests in test_distributed_cpu.py and, on the GPU, by host threads as ranks over a loopback
 all-reduce in test_gpu_tiled_ranks.py.)"""
+import os
+
 import numpy as np
 import pytest
 
@@ -52,6 +54,8 @@ def test_config5_wide_path(scene4096, ctx4096):
     sc, lv, iters, ref = scene4096
     assert len(lv[0]["xyz"]) > 500000                      # ~0.63 M reference points at level 0
     Rw, tw = ctx4096.align_pyramid_wide(iters, np.eye(3), np.zeros(3))
+    if not os.environ.get("DVO_TILED_PACKED"):      # lists built by the engine's own kernels: every level on the packed step kernel (round 5)
+        assert ctx4096.wide_packed_levels() == (1 << len(iters)) - 1
     _check_reports(ctx4096, ref, iters)
     assert rot_angle(ref["R"], Rw) <= ROT_TOL and np.linalg.norm(ref["t"] - tw) <= TRANS_TOL
 

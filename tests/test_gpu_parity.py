@@ -481,6 +481,7 @@ def test_align_pyramid_wide_matches_oracle(scene320, oracle):
     try:
         iters = [9, 0, 9, 9]
         R, t = ctx.align_pyramid_wide(iters, np.eye(3), np.zeros(3))
+        assert ctx.wide_packed_levels() == 0            # caller-supplied 3 x N lists have no compact twin: the one-point-per-lane step kernel
         ref = oracle.align_pyramid(iters, lv, sc.intrinsics, np.eye(3), np.zeros(3))
         for l, rep in ref["levels"].items():
             e, b, ratio = ctx.level_report(0, l, iters[l])
