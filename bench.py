@@ -54,7 +54,7 @@ HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_COPY_GBPS = 6290.0      # measured float4 copy (same guide): what a streaming kernel reaches
 
 #: the sources the fused alignment kernels are built from: their hash ties profiles/pmc_traffic.json to a kernel build
-KERNEL_SOURCES = ["dvo_fused.hip", "dvo_point_pk.h", "dvo_palette.h", "dvo_kernels.hip", "dvo_kernel_common.h", "dvo_device_math.h"]
+KERNEL_SOURCES = ["dvo_fused.hip", "dvo_point_pk.h", "dvo_palette.h", "dvo_kernels.hip", "dvo_kernel_common.h", "dvo_device_math.h", "dvo_tiled_step.h"]
 
 
 def kernel_source_hash():
