@@ -824,8 +824,7 @@ int tiled_step_blocks(int n_points, int n_cu) {
     int b = (n_points + DVO_STEP_THREADS - 1) / DVO_STEP_THREADS;
     if (b < 1) b = 1;
     if (b > 1) b += 1;                  /* workgroup 0 keeps the state and takes no points once there are several (tiled_step_kernel) */
-    if (b > n_cu) b = n_cu;             /* one workgroup per CU: the hand-off form of the tail is measured for that (round 5, packed step
-                                           kernel, 4096x3072x5: 0.545 ms with one, 0.627 with two, 0.692 with three workgroups per CU) */
+    if (b > n_cu) b = n_cu;             /* one workgroup per CU: the hand-off form of the tail is measured for that */
     if (b > 1024) b = 1024;             /* rows of the partials buffer */
     return b;
 }
