@@ -1579,7 +1579,7 @@ int ensure_step_buffers(dvo_ctx *c) {
     /* all or nothing: a failed allocation must not leave the first buffer set and the others null */
     char *st = nullptr; double *acc = nullptr; unsigned *tk = nullptr;
     if (hipMalloc((void **)&st, 2 * pose_state_bytes()) != hipSuccess || hipMalloc((void **)&acc, sizeof(double) * 2 * DVO_NACC_PAD) != hipSuccess ||
-        hipMalloc((void **)&tk, sizeof(unsigned)) != hipSuccess) {
+        hipMalloc((void **)&tk, 2 * sizeof(unsigned)) != hipSuccess) {      /* [0] arrival ticket (launches with H), [1] launch sequence number */
         (void)hipGetLastError();
         if (st) (void)hipFree(st);
         if (acc) (void)hipFree(acc);
@@ -1591,7 +1591,7 @@ int ensure_step_buffers(dvo_ctx *c) {
     if (c->d_step_ticket) (void)hipFree(c->d_step_ticket);
     c->d_step_state = st; c->d_step_acc = acc; c->d_step_ticket = tk;
     HIPCHK(c, hipMemsetAsync(c->d_step_acc, 0, sizeof(double) * 2 * DVO_NACC_PAD, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_step_ticket, 0, sizeof(unsigned), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_step_ticket, 0, 2 * sizeof(unsigned), c->stream));
     HIPCHK(c, stream_wait(c->stream));
     return DVO_OK;
 }

@@ -13,6 +13,27 @@ DVO_DEV void store_sc1_f64(double *p, double v) { asm volatile("global_store_dwo
  * counters left to the compiler: the sixteen loads of a lane below are all in flight before the first is consumed (an inline-asm
  * load would have to wait for itself: 16 dependent memory latencies in the last workgroup of every launch) */
 DVO_DEV double load_sc1_f64(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+/* Tagged rows (round 5, the launches without H): a workgroup's eight sums travel as eight 16-byte records {value lo, tag, value hi, tag},
+ * one store each -- a reader that sees the tag in both halves has the value (the team exchange's record, dvo_fused.hip) -- and the
+ * storing workgroup is DONE: no wait for the stores to drain, no barrier, no ticket.  Workgroup 0, which keeps the state and has no
+ * points, polls the rows of all others and adds them in a fixed order.  The tag is the launch's sequence number + 1, kept in device
+ * memory (`ticket[1]`, advanced by workgroup 0 at the end of every launch, read by every workgroup at its head): a replayed graph
+ * passes the same arguments again, so the tag cannot be one.  Rounds 4-5a: sc1 stores, s_waitcnt, barrier, an atomic ticket, a second
+ * barrier, and the LAST workgroup loading all rows -- three dependent memory round trips at the end of every launch. */
+typedef unsigned step_v4u __attribute__((ext_vector_type(4)));
+DVO_DEV void step_store_rec(step_v4u *p, double v, unsigned tag) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    step_v4u rec;
+    rec.x = (unsigned)bits; rec.y = tag; rec.z = (unsigned)(bits >> 32); rec.w = tag;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(rec) : "memory");
+}
+/* one poll round: the loads of a lane's four records and their wait in ONE statement (the compiler never sees a register in flight) */
+DVO_DEV void step_poll4(step_v4u (&r)[4], const step_v4u *p0, const step_v4u *p1, const step_v4u *p2, const step_v4u *p3) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+}
+DVO_DEV double step_rec_value(const step_v4u &r) { return __longlong_as_double((long long)(((unsigned long long)r.z << 32) | r.x)); }
 #ifndef DVO_STEP_THREADS
 #define DVO_STEP_THREADS 512
 #endif
@@ -27,6 +48,7 @@ struct TiledStepLds {
     PoseCur nxt;                                                            /* the iterate the pending update produces */
     double g_s[8];                                                          /* sums 21..28 of the previous launch */
     int s_last, s_stop0;
+    unsigned seq;                                                           /* the launch's sequence number (ticket[1]) */
 };
 
 /* points(pc, run, b0, b1, tot): EVERY thread of the workgroup calls it; it leaves the workgroup's sums of points [b0, b1) at pose pc in
@@ -51,6 +73,7 @@ DVO_DEV void tiled_step_body(TiledStepLds &m, const PoseState *st_in, PoseState 
         if (wave == 7) {
             if (lane < 8) m.g_s[lane] = apply_prev ? acc_in[21 + lane] : 0.0;
             if (lane == 8) m.s_stop0 = st_in->stop;
+            if (lane == 9) m.seq = ticket[1];
         }
     }
     __syncthreads();
@@ -96,6 +119,59 @@ DVO_DEV void tiled_step_body(TiledStepLds &m, const PoseState *st_in, PoseState 
     }
     double *tot = m.tot;
     double (*part)[DVO_NACC_PAD + 1] = m.part;
+    if constexpr (!WITH_H) {
+        /* tail without H: tagged rows to workgroup 0 (see step_store_rec) */
+        const unsigned tag = m.seq + 1u;
+        step_v4u *recs = reinterpret_cast<step_v4u *>(partials);             /* [workgroup][8] records */
+        if (gridDim.x == 1) {                                               /* the only workgroup: its sums are the launch's */
+            if (tid < DVO_NACC_PAD) acc_out[tid] = (tid >= 21 && tid < 29) ? tot[tid] : 0.0;
+            if (tid == 0) ticket[1] = tag;
+            return;
+        }
+        if (blockIdx.x != 0) {
+            if (tid < 8) step_store_rec(recs + (size_t)blockIdx.x * 8 + tid, tot[21 + tid], tag);
+            return;
+        }
+        /* workgroup 0: records 8 .. 8 * gridDim.x - 1; thread t takes t, t + 512, t + 1024, t + 1536 (+ 2048 ...): all of one sum k = t & 7 */
+        const int n_rec = ((int)gridDim.x - 1) * 8;
+        const step_v4u *first_rec = recs + 8;
+        double sum = 0.0;
+        bool lost = false;
+        for (int r0 = tid; r0 < n_rec; r0 += 4 * DVO_STEP_THREADS) {
+            step_v4u r[4];
+            const step_v4u *pq[4];
+            bool valid[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int i = r0 + q * DVO_STEP_THREADS; valid[q] = i < n_rec; pq[q] = first_rec + (valid[q] ? i : r0); }
+            int spins = 0;
+            for (;;) {
+                step_poll4(r, pq[0], pq[1], pq[2], pq[3]);
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < 4; q++) ok = ok && (!valid[q] || (r[q].y == tag && r[q].w == tag));
+                if (ok) break;
+                if (++spins > (1 << 22)) { lost = true; break; }            /* seconds: a workgroup of this launch never delivered -- NaN sums, not a hang */
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) sum += valid[q] ? step_rec_value(r[q]) : 0.0;      /* fixed order: workgroups ascending */
+        }
+        if (lost) sum = __longlong_as_double(0x7ff8000000000000ll);
+        double *flat = &part[0][0];                                         /* 64 chains x 8 sums */
+        static_assert(sizeof(m.part) >= sizeof(double) * DVO_STEP_THREADS, "one partial sum per thread");
+        flat[tid] = sum;
+        __syncthreads();
+        if (tid < DVO_NACC_PAD) {
+            double t = 0.0;
+            if (tid >= 21 && tid < 29) {
+                const int k = tid - 21;
+                for (int ch = 0; ch < DVO_STEP_THREADS / 8; ch++) t += flat[ch * 8 + k];      /* fixed order */
+            }
+            acc_out[tid] = t;
+        }
+        if (tid == 0) ticket[1] = tag;                                      /* the next launch's sequence number (visible at the kernel boundary) */
+        return;
+    }
     /* tail: this workgroup's row, then the ticket.  Without H only the eight sums 21..28 exist (round 5: the row is those eight
      * doubles, a quarter of the bytes the last arriver has to collect) */
     constexpr int ROW = WITH_H ? DVO_NACC_PAD : 8;
