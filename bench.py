@@ -862,6 +862,7 @@ def main_tiled(args):
         dist.all_gather(allp, mine)
         same = all(bool(torch.equal(allp[0], a)) for a in allp)
     graph_replayed = ctx.tiled_graph_replayed()
+    pk_mask, solo_mask = ctx.wide_packed_levels(), ctx.wide_solo_levels()        # of the schedule that was timed (the step measurement below enqueues its own)
     # per-level reports of the LAST timed alignment, read before anything else touches the context's outputs
     reports = {l: ctx.level_report(0, l, iters[l]) for l in range(args.levels) if iters[l] > 0}
     finals = None
@@ -907,6 +908,9 @@ def main_tiled(args):
             "mode": "tiled", "points_per_level": n_pts, "iters_per_level": iters, "final_outputs": not args.no_final_outputs,
             "us_per_iteration": 1e6 * elapsed / args.steps / sum(iters), "timed_region_s": elapsed,
             "all_ranks_bit_identical": same, "graph_replayed": graph_replayed,
+            "levels_on_the_packed_step_kernel": [l for l in range(args.levels) if (pk_mask >> l) & 1],
+            "levels_as_one_launch": [l for l in range(args.levels) if (solo_mask >> l) & 1],
+            "points_per_level": [int(ctx.n_points(l)) for l in range(args.levels)],
             "algorithmic_bytes_per_alignment": bytes_align,
             "alignment_GBps": bytes_align * value / 1e9,
         },

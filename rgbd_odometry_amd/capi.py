@@ -278,7 +278,7 @@ def load_library() -> C.CDLL:
         "dvo_align_pyramid_tiled": [vp, i, i, ip, i, vp, vp],
         "dvo_tiled_shard": [vp, i, i, ip, ip],
         "dvo_tiled_graph_replayed": [vp, ip],
-        "dvo_wide_packed_levels": [vp, ip],
+        "dvo_wide_packed_levels": [vp, ip, ip],
         "dvo_get_ref_level": [vp, i, i, vp, i, ip],
         "dvo_frames_reserve": [vp, i],
         "dvo_frames_upload_pyramids": [vp, i, i, i, C.POINTER(DvoImage), C.POINTER(DvoImage), i, i],
@@ -711,8 +711,14 @@ class DvoContext:
     def wide_packed_levels(self) -> int:
         """bit l set: level l of the last enqueued align_pyramid_wide / _tiled schedule ran the packed step kernel (compact list)"""
         g = C.c_int(0)
-        self._chk(self.lib.dvo_wide_packed_levels(self._h, C.byref(g)))
+        self._chk(self.lib.dvo_wide_packed_levels(self._h, C.byref(g), None))
         return g.value
+
+    def wide_solo_levels(self) -> int:
+        """bit l set: level l of that schedule ran as ONE launch of one workgroup for all its iterations (small levels)"""
+        g, s = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.dvo_wide_packed_levels(self._h, C.byref(g), C.byref(s)))
+        return s.value
 
     def tiled_shard(self, level: int, pair: int = 0):
         """(first, count): the index range of `level`'s reference list this rank works on"""

@@ -1612,6 +1612,7 @@ hipError_t enqueue_step_schedule(dvo_ctx *c, const Schedule &sc, int pair, int f
     int cur = 0, k = 0;                                                 /* state to read next; launches so far (the sums alternate) */
     bool first_level = true;
     c->step_pk_mask = 0;
+    c->step_solo_mask = 0;
     for (int l = sc.n_levels - 1; l >= 0; --l) {                        /* :2097 */
         if (sc.iters[l] <= 0) continue;                                 /* :2099 */
         const int N = c->lv[l].hN[pair];
@@ -1633,6 +1634,23 @@ hipError_t enqueue_step_schedule(dvo_ctx *c, const Schedule &sc, int pair, int f
         const bool pk = !pk_off && !H && !c->prm.interpolate_dt && c->prm.engine_variant != 1 && sl.cpts &&
                         !c->lv[l].compact_ok.empty() && c->lv[l].compact_ok[pair];
         if (pk) c->step_pk_mask |= 1 << l;
+        int ln = l - 1;                                                 /* the next level that runs */
+        while (ln >= 0 && sc.iters[ln] <= 0) --ln;
+        float *next_energy = ln >= 0 ? c->d_energy + (size_t)pair * sc.e_stride + sc.e_off[ln] : nullptr;
+        const int next_iters = ln >= 0 ? sc.iters[ln] : 0;
+        /* round 5: a small level as ONE launch of one workgroup (dvo_fused.hip: tiled_level_solo_kernel) -- every rank runs it over the
+         * whole list, so its iterations need no collective either.  DVO_TILED_SOLO_MAX=n: levels of at most n points (0 = never) */
+        static const int solo_max = [] { const char *e = std::getenv("DVO_TILED_SOLO_MAX"); return e ? std::atoi(e) : DVO_TILED_SOLO_MAX_DEFAULT; }();
+        if (pk && N <= solo_max) {
+            c->step_solo_mask |= 1 << l;
+            rec(launch_tiled_level_solo(sl, pair, l, c->K, st[cur], st[cur ^ 1], sc.iters[l], N, energy, d_pose,
+                                        c->d_best + pair * DVO_LEVELS + l, c->d_ratio + pair * DVO_LEVELS + l, next_energy, next_iters, c->stream));
+            cur ^= 1;
+            if ((flags & DVO_FLAG_FINAL_OUTPUTS) && l == sc.last_level)
+                rec(launch_final_outputs_state(sl, pair, l, c->K, st[cur], first, count, c->d_final_eps + (size_t)pair * c->final_cap,
+                                               c->d_final_reproj + (size_t)pair * c->final_cap * 3, c->d_final_N + pair, c->stream));
+            continue;
+        }
         for (int itr = 0; itr < sc.iters[l]; itr++, k++) {
             const int apply = itr > 0;
             if (pk)
@@ -1644,12 +1662,9 @@ hipError_t enqueue_step_schedule(dvo_ctx *c, const Schedule &sc, int pair, int f
             if (apply) cur ^= 1;
             if (all_reduce) rec(all_reduce(acc[k & 1]));
         }
-        int ln = l - 1;                                                 /* the next level that runs */
-        while (ln >= 0 && sc.iters[ln] <= 0) --ln;
         rec(launch_tiled_finish(st[cur], st[cur ^ 1], c->dprm, acc[(k + 1) & 1], sc.iters[l] - 1, N, energy, d_pose,
                                 c->d_best + pair * DVO_LEVELS + l, c->d_ratio + pair * DVO_LEVELS + l,
-                                H ? H + (size_t)(sc.iters[l] - 1) * 21 : nullptr,
-                                ln >= 0 ? c->d_energy + (size_t)pair * sc.e_stride + sc.e_off[ln] : nullptr, ln >= 0 ? sc.iters[ln] : 0, c->stream));
+                                H ? H + (size_t)(sc.iters[l] - 1) * 21 : nullptr, next_energy, next_iters, c->stream));
         cur ^= 1;
         /* finalEpsilons / finalReprojections (:703-704, :1002-1003): this rank's share, at the points' own indices */
         if ((flags & DVO_FLAG_FINAL_OUTPUTS) && l == sc.last_level)

@@ -134,10 +134,11 @@ int dvo_tiled_graph_replayed(dvo_ctx *c, int *graph_replayed) {
     return DVO_OK;
 }
 
-int dvo_wide_packed_levels(dvo_ctx *c, int *levels_mask) {
+int dvo_wide_packed_levels(dvo_ctx *c, int *levels_mask, int *solo_mask) {
     DVO_ENTER(c);
     if (!levels_mask) return fail(c, DVO_ERR_INVALID, "levels_mask is NULL");
     *levels_mask = c->step_pk_mask;
+    if (solo_mask) *solo_mask = c->step_solo_mask;
     return DVO_OK;
 }
 

@@ -132,6 +132,7 @@ struct dvo_ctx {
     /* dvo_align_pyramid_wide as a replayable hipGraph (the schedule is ~2 dependent launches per iteration) */
     hipGraphExec_t wide_exec = nullptr;
     unsigned long long wide_sig = 0;
+    int step_solo_mask = 0;              /* ... and those that ran as one launch of one workgroup (tiled_level_solo_kernel) */
     int step_pk_mask = 0;                /* levels of the last enqueued step schedule that ran tiled_step_pk_kernel (inspection) */
     double *h_pose = nullptr;       /* pinned: in/out pose of the graph's copy nodes */
     int direct_compact = 0;         /* dvo_set_direct_compact: float now levels go to the compact form at installation */

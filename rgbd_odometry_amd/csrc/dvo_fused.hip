@@ -1482,4 +1482,93 @@ hipError_t launch_tiled_step_pk(const LevelSlab &L, int pair, int level, const I
     return hipGetLastError();
 }
 
+/* ---- a SMALL level of the tiled / wide schedule as one launch (round 5) -------------------------------------------------------------
+ * A step launch costs ~6.8 us whatever the level holds; a level of a few thousand points is finished by ONE workgroup in less than that per
+ * iteration (the packed rounds over the compact list, 16-byte texels; the serial part of align_fused2_kernel: wave 0 direction + step,
+ * wave 1 bookkeeping).  So such a level runs all its iterations here, then does what tiled_finish_kernel does (the pose <- the best
+ * iterate, outputs, the next level's begin).  In a tiled run EVERY rank runs it over the whole list -- same bits everywhere, and no
+ * collective for the level's iterations. */
+__global__ void __launch_bounds__(DVO_STEP_THREADS)
+tiled_level_solo_kernel(LevelSlab L, int pair, int level, Intrinsics K, const PoseState *st_in, PoseState *st_out, int iters, int N,
+                        float *energy, double *Rt12, int *best_idx, float *ratio, float *next_energy, int next_iters) {
+    constexpr int BLOCK = DVO_STEP_THREADS;
+    __shared__ double red[BLOCK / 64][8];
+    __shared__ PoseState st;
+    const int tid = threadIdx.x;
+    {
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(st_in);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(&st);
+        for (int i = tid; i < (int)(sizeof(PoseState) / 8); i += BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+    const UpdConst &uc = st.u;
+    const char *__restrict__ tex = reinterpret_cast<const char *>(L.tex + (size_t)pair * L.tex_stride);
+    const uint2 *__restrict__ gpts = L.cpts + (size_t)pair * L.pt_cap;
+    IterConst c;
+    level_consts(c, K, level, L.rows, L.cols);
+    TexSrc ts = {};
+    ts.g16 = tex; ts.tile_col_bytes = (unsigned)c.tiles_per_col * 128u;
+    LdsPoints lp = {};
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int lane_off = BLOCK - 64 - (tid & ~63) + (tid & 63);      /* the tail of the last round goes to the high waves first (align_fused2_kernel) */
+    for (int itr = 0; itr < iters; ++itr) {                          /* :658 */
+        const PoseCur &pc = st.p[itr & 1];
+        PoseCur &pn = st.p[(itr + 1) & 1];
+#pragma unroll
+        for (int k = 0; k < 9; k++) c.r[k] = uniform_f(pc.Rf[k]);    /* :673 */
+#pragma unroll
+        for (int k = 0; k < 3; k++) c.t[k] = uniform_f(pc.tf[k]);    /* :674 */
+        Acc7 a;
+        acc7_zero(a);
+        bool any_odd = false;
+        accumulate_points2<BLOCK, false, TEX_G16, 2, 0, false, Acc7>(c, ts, lp, gpts, 0, N, lane_off, a, any_odd);
+        {
+            const double chk = ((a.g[0] + a.g[1]) + (a.g[2] + a.g[3])) + ((a.g[4] + a.g[5]) + a.e2);
+            any_odd |= (__builtin_amdgcn_ballot_w64(!__builtin_isfinite(chk)) != 0ull);
+        }
+        if (any_odd) {
+            acc7_zero(a);
+            accumulate_points_exact<BLOCK, false, false, false, Acc7>(c, tex, ts, nullptr, lp, gpts, 0, N, lane_off, a);
+        }
+        wave_sums7(a, red);
+        double neg_step = 0.0;
+        if (wave == 0) neg_step = pose_neg_step(uc, itr);
+        __syncthreads();
+        if (wave == 0) {
+            const double sl = block_sum8<BLOCK>(red, lane & 7);
+            double psi[6];
+            pose_direction_lanes(st, uc, neg_step, sl, lane, psi);
+            if (lane == 0) pose_apply(st, pc, pn, uc, psi);
+        } else if (wave == 1 && lane == 0) {
+            energy[itr] = pose_bookkeep(st, pc, itr, N, block_sum8<BLOCK>(red, 6), (int)block_sum8<BLOCK>(red, 7));      /* :690 */
+        }
+        __syncthreads();
+        if (st.stop) break;                                          /* :877 */
+        if (tid == 0 && itr + 1 < iters) pose_regulariser_precompute(st, pn, uc);
+    }
+    __syncthreads();
+    if (tid == 0) {                                                  /* :997-1005, then the next level's :642-657 */
+        pose_state_finish(st);
+        for (int k = 0; k < 9; k++) Rt12[k] = st.R[k];
+        for (int k = 0; k < 3; k++) Rt12[9 + k] = st.p[0].t[k];
+        *best_idx = st.bestItr;
+        *ratio = st.bestRatio;
+        if (next_iters > 0) { pose_state_begin(st); pose_regulariser_precompute(st, st.p[0], st.u); }
+    }
+    for (int i = tid; i < next_iters; i += BLOCK) next_energy[i] = 0.0f;      /* :634 */
+    __syncthreads();
+    {
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&st);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(st_out);
+        for (int i = tid; i < (int)(sizeof(PoseState) / 8); i += BLOCK) dst[i] = src[i];
+    }
+}
+hipError_t launch_tiled_level_solo(const LevelSlab &L, int pair, int level, const Intrinsics &K, const void *st_in, void *st_out, int iters,
+                                   int n_points, float *energy, double *Rt12, int *best_idx, float *ratio, float *next_energy,
+                                   int next_iters, hipStream_t s) {
+    hipLaunchKernelGGL(tiled_level_solo_kernel, dim3(1), dim3(DVO_STEP_THREADS), 0, s, L, pair, level, K, (const PoseState *)st_in,
+                       (PoseState *)st_out, iters, n_points, energy, Rt12, best_idx, ratio, next_energy, next_iters);
+    return hipGetLastError();
+}
+
 }  // namespace dvo

@@ -73,6 +73,7 @@ struct Schedule {
                                 at the level's end (dvo_fused.hip: solo levels; DVO_TEAM_SOLO_MAX, 0 = every level by the whole team) */
 };
 
+#define DVO_TILED_SOLO_MAX_DEFAULT 6144     /* tiled / wide schedule: levels of at most this many points run as one launch (dvo_fused.hip) */
 #define DVO_TEAM_SOLO_MAX_DEFAULT 0          /* measured and not taken, see dvo_fused.hip: solo levels */
 
 struct Intrinsics { float fx, fy, cx, cy; int interp; /* dvo_params.interpolate_dt, travels with the camera model to every kernel */ };
@@ -153,6 +154,10 @@ hipError_t launch_tiled_step(const LevelSlab &L, int pair, int level, const Intr
 hipError_t launch_tiled_step_pk(const LevelSlab &L, int pair, int level, const Intrinsics &K, const void *st_in, void *st_out,
                                 const double *acc_in, int itr, int apply_prev, int n_total, int first_point, int n_points,
                                 double *partials, unsigned *ticket, double *acc_out, float *energy, int nblocks, hipStream_t s);
+/* a small level of the schedule as ONE launch of one workgroup: all its iterations, then what launch_tiled_finish does (dvo_fused.hip) */
+hipError_t launch_tiled_level_solo(const LevelSlab &L, int pair, int level, const Intrinsics &K, const void *st_in, void *st_out, int iters,
+                                   int n_points, float *energy, double *Rt12, int *best_idx, float *ratio, float *next_energy,
+                                   int next_iters, hipStream_t s);
 hipError_t launch_tiled_finish(const void *st_in, void *st_out, const DevParams &prm, const double *acc_in, int itr_last, int n_total,
                                float *energy, double *Rt12, int *best_idx, float *ratio, double *H_last, float *next_energy, int next_iters,
                                hipStream_t s);      /* next_iters > 0: also what iter_begin does for the next level (its energies: next_energy) */

@@ -150,9 +150,15 @@ def test_c_tiled_path_with_several_ranks_on_one_gpu(world, oracle):
             for r in range(1, world):
                 assert np.array_equal(out[r][0], out[0][0]) and np.array_equal(out[r][1], out[0][1]), r
             assert rot_angle(ref["R"], out[0][0]) <= 1e-5 and np.linalg.norm(ref["t"] - out[0][1]) <= 1e-4
-            n_it = sum(iters)
+            # one all-reduce per iteration of a level that is sharded over the ranks; small levels (round 5: one launch of one workgroup,
+            # every rank runs them whole) need none
+            solo = ctxs[0].wide_solo_levels()
+            assert all(ctxs[r].wide_solo_levels() == solo for r in range(world))
+            n_it = sum(it for l, it in enumerate(iters) if not (solo >> l) & 1)
+            if not os.environ.get("DVO_TILED_SOLO_MAX") and not os.environ.get("DVO_TILED_PACKED"):
+                assert solo != 0 and n_it > 0                                # this scene has levels on both sides of the threshold
             for r in range(world):
-                assert lib.loopback_calls(comms[r]) == (rep + 1) * n_it, (r, lib.loopback_calls(comms[r]))   # one all-reduce per iteration
+                assert lib.loopback_calls(comms[r]) == (rep + 1) * n_it, (r, lib.loopback_calls(comms[r]))
                 assert not ctxs[r].tiled_graph_replayed()                    # the loopback refuses a capturing stream: direct submission
                 for l, rp in ref["levels"].items():
                     e, b, ratio = ctxs[r].level_report(0, l, iters[l])

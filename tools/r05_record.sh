@@ -36,7 +36,7 @@ if has tiled; then
   python3 -c "
 import json
 for l in open('gpurun_out/r05_final/tiled_lines.json'):
-    d=json.loads(l); print(d['config']['workload'][:40], '%.1f aligns/s %.3f ms %.2f us/iter step %.2f us graph=%s parity=%s' % (d['value'], d['ms_per_step'], d['config']['us_per_iteration'], 1e3*d['roofline']['kernel_ms'], d['config']['graph_replayed'], d.get('parity_check',{}).get('pass')))"
+    d=json.loads(l); print(d['config']['workload'][:40], '%.1f aligns/s %.3f ms %.2f us/iter step %.2f us graph=%s parity=%s solo=%s N=%s' % (d['value'], d['ms_per_step'], d['config']['us_per_iteration'], 1e3*d['roofline']['kernel_ms'], d['config']['graph_replayed'], d.get('parity_check',{}).get('pass'), d['config'].get('levels_as_one_launch'), d['config'].get('points_per_level')))"
 fi
 if has frames; then
   python tools/bench_frames.py --batch 256 --pinned --reps 10 > gpurun_out/r05_final/bench_frames_640x480_b256_pinned.json 2>/dev/null
