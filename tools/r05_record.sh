@@ -44,7 +44,10 @@ if has frames; then
 fi
 if has extra; then
   # round 5: stamps anatomy (serial chain), sparse scenes, H on the packed kernel, the team exchange's store flavour
-  for cfg in "2048 0" "256 0" "32 0"; do echo "== stamps B/block = $cfg"; PREP=1 python tools/experiments/exp_stamps2.py $cfg 2>&1 | tail -6; done > gpurun_out/r05_final/stamps_anatomy.txt 2>&1
+  # the stamps build travels with the tree: make -C rgbd_odometry_amd/csrc STAMPS=1 (before gpurun)
+  if [ -f rgbd_odometry_amd/lib/libdvo_amd_stamps.so ]; then
+    for cfg in "2048 0" "256 0" "32 0"; do echo "== stamps B/block = $cfg"; PREP=1 python tools/experiments/exp_stamps2.py $cfg 2>&1 | tail -6; done > gpurun_out/r05_final/stamps_anatomy.txt 2>&1
+  else echo "stamps anatomy skipped: libdvo_amd_stamps.so not built"; fi
   python tools/sparse_scenes.py > gpurun_out/r05_final/sparse_scenes.json 2> gpurun_out/r05_final/sparse_scenes.txt
   for b in 1024 8192; do python bench.py --cpu-seconds 0 --no-extra-legs --batch $b --steps 20 --normal-matrix 2>/dev/null | grep '^{'; done > gpurun_out/r05_final/normal_matrix_lines.json
   tools/experiments/r05_team_ab.sh > gpurun_out/r05_final/team_plain_stores_ab.txt 2>&1
