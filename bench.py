@@ -812,10 +812,12 @@ def main_batch(args):
 def main_tiled(args):
     rank, local_rank, world, dist = dist_setup()
     from rgbd_odometry_amd import DvoContext, SynthScene
-    from rgbd_odometry_amd.capi import RcclComm, DVO_FLAG_FINAL_OUTPUTS
+    from rgbd_odometry_amd.capi import RcclComm, DVO_FLAG_FINAL_OUTPUTS, DVO_FLAG_NORMAL_MATRIX
     from rgbd_odometry_amd.distributed import shard_range
     iters = [args.iters] * args.levels
-    flags = 0 if args.no_final_outputs else DVO_FLAG_FINAL_OUTPUTS
+    # --normal-matrix: the all-reduced sums also carry H = sum w J J^T (BASELINE configs[4] names "6x6 JtJ + 6x1 Jtr"; the reference's
+    # update reads J^T W eps only, SolveDVO.cpp:777, so the default leaves the 21 slots of H zero)
+    flags = (0 if args.no_final_outputs else DVO_FLAG_FINAL_OUTPUTS) | (DVO_FLAG_NORMAL_MATRIX if args.normal_matrix else 0)
     sc = SynthScene(args.width, args.height, args.levels, 7)                   # C5 is seed 7
     ctx = DvoContext(1)
     ctx.set_intrinsics(*sc.intrinsics)

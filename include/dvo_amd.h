@@ -275,7 +275,7 @@ int  dvo_tiled_graph_replayed(dvo_ctx *ctx, int *graph_replayed);
 /* inspection: bit l of *levels_mask = 1 if level l of the last dvo_align_pyramid_wide / _tiled schedule that was ENQUEUED (a replayed
  * graph keeps the mask of its capture) ran the packed two-points-per-lane step kernel over the compact list (round 5; lists built by
  * the engine's own reference-point kernels have one), 0 for the one-point-per-lane kernel over the 3 x N list (caller-supplied
- * lists, DVO_FLAG_NORMAL_MATRIX, dvo_params.interpolate_dt);
+ * lists, dvo_params.interpolate_dt);
  * *solo_mask (may be NULL): the levels among them that ran as ONE launch of one workgroup for all their iterations (levels of at most
  * DVO_TILED_SOLO_MAX = 6144 points; over several ranks every rank runs such a level whole, without a collective) */
 int  dvo_wide_packed_levels(dvo_ctx *ctx, int *levels_mask, int *solo_mask);

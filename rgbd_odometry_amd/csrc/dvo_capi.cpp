@@ -1629,9 +1629,9 @@ hipError_t enqueue_step_schedule(dvo_ctx *c, const Schedule &sc, int pair, int f
          * the flag those 21 slots are zeros -- the reference's update never reads them (SolveDVO.cpp:777) */
         double *H = (flags & DVO_FLAG_NORMAL_MATRIX) ? c->d_H + ((size_t)pair * sc.e_stride + sc.e_off[l]) * 21 : nullptr;
         /* round 5: the packed point loop (dvo_fused.hip: tiled_step_pk_kernel) where the level's list has its compact twin -- lists built
-         * by the engine's own enlist kernels do -- and neither H nor the interpolating look-up is asked for; DVO_TILED_PACKED=off for A/B */
+         * by the engine's own enlist kernels do -- and the interpolating look-up is not asked for (H rides along); DVO_TILED_PACKED=off for A/B */
         static const bool pk_off = [] { const char *e = std::getenv("DVO_TILED_PACKED"); return e && std::strcmp(e, "off") == 0; }();
-        const bool pk = !pk_off && !H && !c->prm.interpolate_dt && c->prm.engine_variant != 1 && sl.cpts &&
+        const bool pk = !pk_off && !c->prm.interpolate_dt && c->prm.engine_variant != 1 && sl.cpts &&
                         !c->lv[l].compact_ok.empty() && c->lv[l].compact_ok[pair];
         if (pk) c->step_pk_mask |= 1 << l;
         int ln = l - 1;                                                 /* the next level that runs */
@@ -1641,7 +1641,7 @@ hipError_t enqueue_step_schedule(dvo_ctx *c, const Schedule &sc, int pair, int f
         /* round 5: a small level as ONE launch of one workgroup (dvo_fused.hip: tiled_level_solo_kernel) -- every rank runs it over the
          * whole list, so its iterations need no collective either.  DVO_TILED_SOLO_MAX=n: levels of at most n points (0 = never) */
         static const int solo_max = [] { const char *e = std::getenv("DVO_TILED_SOLO_MAX"); return e ? std::atoi(e) : DVO_TILED_SOLO_MAX_DEFAULT; }();
-        if (pk && N <= solo_max) {
+        if (pk && !H && N <= solo_max) {
             c->step_solo_mask |= 1 << l;
             rec(launch_tiled_level_solo(sl, pair, l, c->K, st[cur], st[cur ^ 1], sc.iters[l], N, energy, d_pose,
                                         c->d_best + pair * DVO_LEVELS + l, c->d_ratio + pair * DVO_LEVELS + l, next_energy, next_iters, c->stream));
@@ -1655,7 +1655,7 @@ hipError_t enqueue_step_schedule(dvo_ctx *c, const Schedule &sc, int pair, int f
             const int apply = itr > 0;
             if (pk)
                 rec(launch_tiled_step_pk(sl, pair, l, c->K, st[cur], st[cur ^ 1], acc[(k + 1) & 1], itr, apply, N, first, count, partials,
-                                         c->d_step_ticket, acc[k & 1], energy, nb, c->stream));
+                                         c->d_step_ticket, acc[k & 1], energy, nb, H ? H + (size_t)(itr > 0 ? itr - 1 : 0) * 21 : nullptr, c->stream));
             else
             rec(launch_tiled_step(sl, pair, l, c->K, c->dprm, st[cur], st[cur ^ 1], acc[(k + 1) & 1], itr, apply, N, first, count, partials,
                                   c->d_step_ticket, acc[k & 1], energy, nb, H ? H + (size_t)(itr > 0 ? itr - 1 : 0) * 21 : nullptr, c->stream));

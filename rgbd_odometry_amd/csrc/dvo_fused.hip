@@ -1431,19 +1431,22 @@ hipError_t launch_align_fused2(int block_threads, const LevelSet &lv, const Sche
  * (dvo_tiled_step.h) -- streams its share of the COMPACT list (8 bytes per point, a round ahead) through the packed
  * two-points-per-lane rounds, looking the texels up in the level's 16-byte image (the tiled schedule replicates that image on every
  * rank; its compact form would need the palette in every workgroup's LDS at every launch).  Lists the engine's own enlist kernels
- * built have the compact twin; without it, with H, or with interpolate_dt the launch is tiled_step_kernel.
+ * built have the compact twin; without it, or with interpolate_dt, the launch is tiled_step_kernel.  WITH_H: the 21 sums of H = sum w J J^T
+ * ride along (DVO_FLAG_NORMAL_MATRIX; BASELINE configs[4] names "6x6 JtJ + 6x1 Jtr" for the all-reduce).
  * Measured and not kept: round 0's points of every lane requested in the shadow of the head's loads (they do not depend on the pose) --
  * 0.541-0.545 ms per 4096 x 3072 x 5 alignment against 0.538. */
+template <bool WITH_H>
 __global__ void __launch_bounds__(DVO_STEP_THREADS)
 tiled_step_pk_kernel(LevelSlab L, int pair, int level, Intrinsics K, const PoseState *st_in, PoseState *st_out,
                      const double *__restrict__ acc_in, int itr, int apply_prev, int n_total, int first, int n,
-                     double *partials, unsigned *ticket, double *acc_out, float *energy) {
+                     double *partials, unsigned *ticket, double *acc_out, float *energy, double *H_prev) {
     __shared__ double red[DVO_STEP_THREADS / 64][8];
+    __shared__ double redH[WITH_H ? DVO_STEP_THREADS / 64 : 1][24];
     __shared__ TiledStepLds m;
-    tiled_step_body<false>(m, st_in, st_out, acc_in, itr, apply_prev, n_total, first, n, partials, ticket, acc_out, energy, nullptr,
+    tiled_step_body<WITH_H>(m, st_in, st_out, acc_in, itr, apply_prev, n_total, first, n, partials, ticket, acc_out, energy, H_prev,
         [&](const PoseCur &pc, bool run, int b0, int b1, double *tot) {
             const int tid = threadIdx.x;
-            Acc7 a;
+            Acc7T<WITH_H> a;
             acc7_zero(a);
             if (run) {
                 const char *__restrict__ tex = reinterpret_cast<const char *>(L.tex + (size_t)pair * L.tex_stride);
@@ -1458,27 +1461,50 @@ tiled_step_pk_kernel(LevelSlab L, int pair, int level, Intrinsics K, const PoseS
                 ts.g16 = tex; ts.tile_col_bytes = (unsigned)c.tiles_per_col * 128u;
                 LdsPoints lp = {};
                 bool any_odd = false;
-                accumulate_points2<DVO_STEP_THREADS, false, TEX_G16, 2, 0, false, Acc7>(c, ts, lp, gpts, b0, b1, tid, a, any_odd);
+                accumulate_points2<DVO_STEP_THREADS, false, TEX_G16, 2, 0, false, Acc7T<WITH_H>>(c, ts, lp, gpts, b0, b1, tid, a, any_odd);
                 {   /* a degenerate z somewhere in this wave's share: again with the literal divisions (see align_fused2_kernel) */
                     const double chk = ((a.g[0] + a.g[1]) + (a.g[2] + a.g[3])) + ((a.g[4] + a.g[5]) + a.e2);
                     any_odd |= (__builtin_amdgcn_ballot_w64(!__builtin_isfinite(chk)) != 0ull);
                 }
                 if (any_odd) {
                     acc7_zero(a);
-                    accumulate_points_exact<DVO_STEP_THREADS, false, false, false, Acc7>(c, tex, ts, nullptr, lp, gpts, b0, b1, tid, a);
+                    accumulate_points_exact<DVO_STEP_THREADS, false, false, false, Acc7T<WITH_H>>(c, tex, ts, nullptr, lp, gpts, b0, b1, tid, a);
                 }
             }
             wave_sums7(a, red);
+            if constexpr (WITH_H) {       /* the wave's 21 sums of H: three passes of the 8-value reduce-scatter (align_fused2_kernel) */
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    double d[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) d[k] = (8 * q + k < 21) ? a.H[8 * q + k] : 0.0;
+                    wave_reduce_scatter8_dpp(d);
+                    const int idx = reduce_scatter8_dpp_index(tid & 63);
+                    if ((tid & 63) < 8) redH[tid >> 6][8 * q + idx] = d[0];
+                }
+            }
             __syncthreads();
-            if (tid < DVO_NACC_PAD) tot[tid] = (tid >= 21 && tid < 29) ? block_sum8<DVO_STEP_THREADS>(red, tid - 21) : 0.0;
+            if (tid < DVO_NACC_PAD) {
+                double v = 0.0;
+                if (tid >= 21 && tid < 29) v = block_sum8<DVO_STEP_THREADS>(red, tid - 21);
+                else if (WITH_H && tid < 21) {
+#pragma unroll
+                    for (int w = 0; w < DVO_STEP_THREADS / 64; w++) v += redH[w][tid];      /* waves in order, like the other sums */
+                }
+                tot[tid] = v;
+            }
             __syncthreads();
         });
 }
 hipError_t launch_tiled_step_pk(const LevelSlab &L, int pair, int level, const Intrinsics &K, const void *st_in, void *st_out,
                                 const double *acc_in, int itr, int apply_prev, int n_total, int first_point, int n_points,
-                                double *partials, unsigned *ticket, double *acc_out, float *energy, int nblocks, hipStream_t s) {
-    hipLaunchKernelGGL(tiled_step_pk_kernel, dim3(nblocks), dim3(DVO_STEP_THREADS), 0, s, L, pair, level, K, (const PoseState *)st_in,
-                       (PoseState *)st_out, acc_in, itr, apply_prev, n_total, first_point, n_points, partials, ticket, acc_out, energy);
+                                double *partials, unsigned *ticket, double *acc_out, float *energy, int nblocks, double *H_prev, hipStream_t s) {
+    if (H_prev)
+        hipLaunchKernelGGL(tiled_step_pk_kernel<true>, dim3(nblocks), dim3(DVO_STEP_THREADS), 0, s, L, pair, level, K, (const PoseState *)st_in,
+                           (PoseState *)st_out, acc_in, itr, apply_prev, n_total, first_point, n_points, partials, ticket, acc_out, energy, H_prev);
+    else
+        hipLaunchKernelGGL(tiled_step_pk_kernel<false>, dim3(nblocks), dim3(DVO_STEP_THREADS), 0, s, L, pair, level, K, (const PoseState *)st_in,
+                           (PoseState *)st_out, acc_in, itr, apply_prev, n_total, first_point, n_points, partials, ticket, acc_out, energy, H_prev);
     return hipGetLastError();
 }
 

@@ -150,10 +150,10 @@ hipError_t launch_tiled_step(const LevelSlab &L, int pair, int level, const Intr
                              void *st_out, const double *acc_in, int itr, int apply_prev, int n_total, int first_point, int n_points,
                              double *partials, unsigned *ticket, double *acc_out, float *energy, int nblocks,
                              double *H_prev /* NULL: the 21 H sums are not formed; else: where H of iterate itr - 1 goes (21 doubles) */, hipStream_t s);
-/* the same launch with the packed point loop over the compact list (dvo_fused.hip: tiled_step_pk_kernel); no H */
+/* the same launch with the packed point loop over the compact list (dvo_fused.hip: tiled_step_pk_kernel) */
 hipError_t launch_tiled_step_pk(const LevelSlab &L, int pair, int level, const Intrinsics &K, const void *st_in, void *st_out,
                                 const double *acc_in, int itr, int apply_prev, int n_total, int first_point, int n_points,
-                                double *partials, unsigned *ticket, double *acc_out, float *energy, int nblocks, hipStream_t s);
+                                double *partials, unsigned *ticket, double *acc_out, float *energy, int nblocks, double *H_prev, hipStream_t s);
 /* a small level of the schedule as ONE launch of one workgroup: all its iterations, then what launch_tiled_finish does (dvo_fused.hip) */
 hipError_t launch_tiled_level_solo(const LevelSlab &L, int pair, int level, const Intrinsics &K, const void *st_in, void *st_out, int iters,
                                    int n_points, float *energy, double *Rt12, int *best_idx, float *ratio, float *next_energy,

@@ -1,6 +1,6 @@
 /* dvo_tiled_step.h -- the launch of one iteration of the tiled / wide schedule, but for its per-point phase (see the comment above
- * tiled_step_kernel in dvo_kernels.hip: head = pending update, body = this workgroup's share of the points, tail = row + ticket +
- * last arriver).  Two kernels share it: tiled_step_kernel (dvo_kernels.hip: one point per lane, the reference's 3 x N list, H on
+ * tiled_step_kernel in dvo_kernels.hip: head = pending update, body = this workgroup's share of the points, tail = tagged rows to
+ * workgroup 0).  Two kernels share it: tiled_step_kernel (dvo_kernels.hip: one point per lane, the reference's 3 x N list, H on
  * request) and tiled_step_pk_kernel (dvo_fused.hip, round 5: the packed two-points-per-lane loop over the compact list). */
 #ifndef DVO_TILED_STEP_H
 #define DVO_TILED_STEP_H
@@ -8,12 +8,7 @@
 
 namespace dvo {
 
-DVO_DEV void store_sc1_f64(double *p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
-/* a relaxed agent-scope atomic load IS global_load_dwordx2 sc1 (MI355X_MICROARCH.md, the HIP construct table), with the wait
- * counters left to the compiler: the sixteen loads of a lane below are all in flight before the first is consumed (an inline-asm
- * load would have to wait for itself: 16 dependent memory latencies in the last workgroup of every launch) */
-DVO_DEV double load_sc1_f64(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-/* Tagged rows (round 5, the launches without H): a workgroup's eight sums travel as eight 16-byte records {value lo, tag, value hi, tag},
+/* Tagged rows (round 5): a workgroup's sums (eight, or all 32 slots with H) travel as 16-byte records {value lo, tag, value hi, tag},
  * one store each -- a reader that sees the tag in both halves has the value (the team exchange's record, dvo_fused.hip) -- and the
  * storing workgroup is DONE: no wait for the stores to drain, no barrier, no ticket.  Workgroup 0, which keeps the state and has no
  * points, polls the rows of all others and adds them in a fixed order.  The tag is the launch's sequence number + 1, kept in device
@@ -38,7 +33,7 @@ DVO_DEV double step_rec_value(const step_v4u &r) { return __longlong_as_double((
 #define DVO_STEP_THREADS 512
 #endif
 static_assert(sizeof(PoseState) % 8 == 0, "the state is copied 8 bytes per lane");
-static_assert(DVO_STEP_THREADS == 512, "the last arriver of a step launch adds the rows in 16 chains of 32 lanes");
+static_assert(DVO_STEP_THREADS == 512, "wave 7 fetches the sums for the head; workgroup 0 adds the rows as 512 / ROW chains");
 
 /* LDS of a step launch (declared by the kernel, handed to the body) */
 struct TiledStepLds {
@@ -47,7 +42,7 @@ struct TiledStepLds {
     PoseState s;
     PoseCur nxt;                                                            /* the iterate the pending update produces */
     double g_s[8];                                                          /* sums 21..28 of the previous launch */
-    int s_last, s_stop0;
+    int s_stop0;
     unsigned seq;                                                           /* the launch's sequence number (ticket[1]) */
 };
 
@@ -119,22 +114,25 @@ DVO_DEV void tiled_step_body(TiledStepLds &m, const PoseState *st_in, PoseState 
     }
     double *tot = m.tot;
     double (*part)[DVO_NACC_PAD + 1] = m.part;
-    if constexpr (!WITH_H) {
-        /* tail without H: tagged rows to workgroup 0 (see step_store_rec) */
+    {
+        /* tail: tagged rows to workgroup 0 (see step_store_rec).  A row is the eight sums 21..28, or with H all DVO_NACC_PAD slots */
+        constexpr int ROW = WITH_H ? DVO_NACC_PAD : 8;
+        constexpr int OFF = WITH_H ? 0 : 21;                                /* slot of the row's first value */
         const unsigned tag = m.seq + 1u;
-        step_v4u *recs = reinterpret_cast<step_v4u *>(partials);             /* [workgroup][8] records */
+        step_v4u *recs = reinterpret_cast<step_v4u *>(partials);             /* [workgroup][ROW] records */
         if (gridDim.x == 1) {                                               /* the only workgroup: its sums are the launch's */
-            if (tid < DVO_NACC_PAD) acc_out[tid] = (tid >= 21 && tid < 29) ? tot[tid] : 0.0;
+            if (tid < DVO_NACC_PAD) acc_out[tid] = (tid >= OFF && tid < DVO_NACC) ? tot[tid] : 0.0;
             if (tid == 0) ticket[1] = tag;
             return;
         }
         if (blockIdx.x != 0) {
-            if (tid < 8) step_store_rec(recs + (size_t)blockIdx.x * 8 + tid, tot[21 + tid], tag);
+            if (tid < ROW) step_store_rec(recs + (size_t)blockIdx.x * ROW + tid, (OFF + tid < DVO_NACC) ? tot[OFF + tid] : 0.0, tag);
             return;
         }
-        /* workgroup 0: records 8 .. 8 * gridDim.x - 1; thread t takes t, t + 512, t + 1024, t + 1536 (+ 2048 ...): all of one sum k = t & 7 */
-        const int n_rec = ((int)gridDim.x - 1) * 8;
-        const step_v4u *first_rec = recs + 8;
+        /* workgroup 0: records ROW .. ROW * gridDim.x - 1; thread t takes t, t + 512, t + 1024, ...: all of one sum k = t & (ROW - 1) */
+        static_assert(DVO_STEP_THREADS % ROW == 0, "a thread's records all belong to one sum");
+        const int n_rec = ((int)gridDim.x - 1) * ROW;
+        const step_v4u *first_rec = recs + ROW;
         double sum = 0.0;
         bool lost = false;
         for (int r0 = tid; r0 < n_rec; r0 += 4 * DVO_STEP_THREADS) {
@@ -157,83 +155,19 @@ DVO_DEV void tiled_step_body(TiledStepLds &m, const PoseState *st_in, PoseState 
             for (int q = 0; q < 4; q++) sum += valid[q] ? step_rec_value(r[q]) : 0.0;      /* fixed order: workgroups ascending */
         }
         if (lost) sum = __longlong_as_double(0x7ff8000000000000ll);
-        double *flat = &part[0][0];                                         /* 64 chains x 8 sums */
+        double *flat = &part[0][0];                                         /* (512 / ROW) chains x ROW sums */
         static_assert(sizeof(m.part) >= sizeof(double) * DVO_STEP_THREADS, "one partial sum per thread");
         flat[tid] = sum;
         __syncthreads();
         if (tid < DVO_NACC_PAD) {
             double t = 0.0;
-            if (tid >= 21 && tid < 29) {
-                const int k = tid - 21;
-                for (int ch = 0; ch < DVO_STEP_THREADS / 8; ch++) t += flat[ch * 8 + k];      /* fixed order */
+            if (tid >= OFF && tid < DVO_NACC) {
+                const int k = tid - OFF;
+                for (int ch = 0; ch < DVO_STEP_THREADS / ROW; ch++) t += flat[ch * ROW + k];      /* fixed order */
             }
             acc_out[tid] = t;
         }
         if (tid == 0) ticket[1] = tag;                                      /* the next launch's sequence number (visible at the kernel boundary) */
-        return;
-    }
-    /* tail: this workgroup's row, then the ticket.  Without H only the eight sums 21..28 exist (round 5: the row is those eight
-     * doubles, a quarter of the bytes the last arriver has to collect) */
-    constexpr int ROW = WITH_H ? DVO_NACC_PAD : 8;
-    if (WITH_H) { if (tid < DVO_NACC_PAD) store_sc1_f64(partials + (size_t)blockIdx.x * ROW + tid, (tid < DVO_NACC) ? tot[tid] : 0.0); }
-    else if (tid < 8) store_sc1_f64(partials + (size_t)blockIdx.x * ROW + tid, tot[21 + tid]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        /* every storing wave: its stores have left */
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        m.s_last = (t == gridDim.x - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!m.s_last) return;
-    {   /* the last arriver: all rows in the fixed two-level order of reduce_partials_kernel (16 interleaved chains, then in order) */
-        const int nb = (int)gridDim.x;
-        if constexpr (WITH_H) {
-        const int k = tid & 31, ch = tid >> 5;                              /* 512 threads: 16 chains x 32 values */
-        double sum = 0.0;
-        for (int b0 = ch; b0 < nb && ch < 16; b0 += 16 * 16) {                          /* up to 16 rows of this chain at a time, all loads issued first */
-            double v[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int b = b0 + 16 * q;
-                v[q] = (b < nb) ? load_sc1_f64(partials + (size_t)b * ROW + k) : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < 16; q++) sum += v[q];                       /* fixed order: rows ch, ch + 16, ch + 32, ... */
-        }
-        if (ch < 16) part[ch][k] = sum;
-        __syncthreads();
-        if (tid < DVO_NACC_PAD) {
-            double t = 0.0;
-#pragma unroll
-            for (int j = 0; j < 16; j++) t += part[j][tid];
-            acc_out[tid] = t;
-        }
-        } else {
-        /* eight values per row: the same 16 chains (rows ch, ch + 16, ...), eight lanes each; 128 of the 512 threads load */
-        const int k = tid & 7, ch = tid >> 3;
-        double sum = 0.0;
-        for (int b0 = ch; b0 < nb && ch < 16; b0 += 16 * 16) {
-            double v[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int b = b0 + 16 * q;
-                v[q] = (b < nb) ? load_sc1_f64(partials + (size_t)b * ROW + k) : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < 16; q++) sum += v[q];
-        }
-        if (ch < 16) part[ch][k] = sum;
-        __syncthreads();
-        if (tid < DVO_NACC_PAD) {
-            double t = 0.0;
-            if (tid >= 21 && tid < 29) {
-#pragma unroll
-                for (int j = 0; j < 16; j++) t += part[j][tid - 21];
-            }
-            acc_out[tid] = t;
-        }
-        }
-        if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* for the next launch (visible at the kernel boundary) */
     }
 }
 
