@@ -28,4 +28,4 @@ durs = [(int(a['End_Timestamp']) - int(a['Start_Timestamp'])) / 1e3 for a in tai
 print('last 40 step launches: durations', ' '.join('%.1f' % x for x in durs))
 print('gaps to the next launch      ', ' '.join('%.1f' % x for x in gaps))
 PY
-rm -rf $OUT/trace
+python3 tools/experiments/r05_trace_sequence.py $OUT/trace > $OUT/sequence.txt 2>&1; rm -rf $OUT/trace
