@@ -5,6 +5,8 @@ index bit-equal; final pose within 1e-5 rad / 1e-4 m of the oracle (in practice 
 non-bit-identical ingredients are double-precision libm vs ocml sin/cos/atan and the order of
 the double-precision sums, both ~1e-16 relative, far below the float cast at SolveDVO.cpp:673-674).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -88,7 +90,8 @@ def test_accumulators(scene320, ctx320, oracle):
             np.testing.assert_allclose(acc[:21], tr["H"], rtol=1e-12, atol=1e-12 * np.abs(tr["H"]).max())
 
 
-def test_wide_schedule_one_launch_per_iteration_with_and_without_normal_matrix(scene320, oracle):
+@pytest.mark.parametrize("engine_lists", [False, True], ids=["3xN-lists", "engine-lists"])
+def test_wide_schedule_one_launch_per_iteration_with_and_without_normal_matrix(scene320, oracle, engine_lists):
     """dvo_align_pyramid_wide (the single-GPU form of the tiled schedule, same tiled_step_kernel: the update of an iteration at
     the head of the next launch, the sums added by the last workgroup): energies / best index / ratio / final outputs bit-equal to
     the oracle, skipped levels included; with DVO_FLAG_NORMAL_MATRIX the same launches also form H per iterate"""
@@ -99,12 +102,20 @@ def test_wide_schedule_one_launch_per_iteration_with_and_without_normal_matrix(s
     with DvoContext(1) as ctx:
         ctx.set_intrinsics(*sc.intrinsics)
         for l, L in enumerate(lv):
-            ctx.set_ref_level(l, L["xyz"])
+            if engine_lists:        # lists built by the engine's own kernels have the compact twin: the packed step kernel (round 5), with H too
+                ctx.set_ref_level_from_images(l, sc.levels[l].ref_edge, sc.levels[l].ref_depth, L["rows"], L["cols"])
+            else:
+                ctx.set_ref_level(l, L["xyz"])
             ctx.set_now_level(l, L["dt"], L["gx"], L["gy"], L["rows"], L["cols"])
         ref = oracle.align_pyramid(iters, lv, sc.intrinsics, np.eye(3), np.zeros(3))
         for flags in (DVO_FLAG_FINAL_OUTPUTS, DVO_FLAG_FINAL_OUTPUTS | DVO_FLAG_NORMAL_MATRIX):
             for rep in range(2):                        # the second call replays the captured graph
                 R, t = ctx.align_pyramid_wide(iters, np.eye(3), np.zeros(3), flags=flags)
+                if not os.environ.get("DVO_TILED_PACKED") and not os.environ.get("DVO_TILED_SOLO_MAX"):
+                    used = sum(1 << l for l in range(4) if iters[l] > 0)
+                    assert ctx.wide_packed_levels() == (used if engine_lists else 0)
+                    # small levels run as one launch -- unless H is asked for (its per-iterate sums come from the step launches)
+                    assert ctx.wide_solo_levels() == (used if engine_lists and not (flags & DVO_FLAG_NORMAL_MATRIX) else 0)
                 for l, rep_l in ref["levels"].items():
                     e, b, ratio = ctx.level_report(0, l, iters[l])
                     assert np.array_equal(e, rep_l["energy"]) and b == rep_l["best_idx"] and ratio == rep_l["visible_ratio"], (flags, l)
