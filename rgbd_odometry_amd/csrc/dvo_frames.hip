@@ -22,6 +22,7 @@
 #include "dvo_launch.h"
 #include "dvo_palette.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace dvo {
 
@@ -826,7 +827,7 @@ DVO_DEV edt_col_us2 edt_col_pair(unsigned v) { return __builtin_bit_cast(edt_col
 DVO_DEV unsigned edt_col_word(edt_col_us2 v) { return __builtin_bit_cast(unsigned, v); }
 template <int WAVES>
 DVO_DEV void edt_columns8_body(const int bx, const int gx, const int by, const unsigned char *__restrict__ edge, size_t edge_stride, int rows, int cols, int R, unsigned short *__restrict__ g,
-                    unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags) {
+                    unsigned *__restrict__ bitmap, int bm_words, int *__restrict__ flags, const bool keep_flags = false /* round 6: the band stage set them */) {
     /* Round 4: ONE pass per 512-row chunk.  The distance of a lane's row j to the nearest edge of its column is the minimum of
      * three: the nearest edge among the lane's own eight rows (a 256-entry table in LDS: per mask, eight 16-bit distances, 0xffff
      * = none), the nearest edge above the lane's rows (d_up + 1 + j) and the nearest below them (d_dn + 8 - j) -- the last two as
@@ -841,7 +842,7 @@ DVO_DEV void edt_columns8_body(const int bx, const int gx, const int by, const u
     {
         unsigned *bm = bitmap + (size_t)by * bm_words;
         for (int i = bx * (WAVES * 64) + threadIdx.x; i < bm_words; i += gx * (WAVES * 64)) bm[i] = 0u;
-        if (bx == 0 && threadIdx.x == 0) flags[by] = 0;
+        if (bx == 0 && threadIdx.x == 0 && !keep_flags) flags[by] = 0;
     }
     for (int m = threadIdx.x; m < 256; m += WAVES * 64)
         s_lut[m] = make_uint4(EDT_COL_LUT.v[m][0], EDT_COL_LUT.v[m][1], EDT_COL_LUT.v[m][2], EDT_COL_LUT.v[m][3]);
@@ -1738,6 +1739,8 @@ __global__ void __launch_bounds__(256) dt_normalize_gradient_pack_levels_kernel(
                                     t.first_pair, t.ntiles_y[l] * ((t.cols[l] + NP_TX - 1) / NP_TX));
 }
 
+#include "dvo_edt_band.h"
+
 /* compact form -> 16-byte texels {DT, gx, gy, w} of the images that have one (pal_n > 0), decoded exactly as the fused kernel
  * decodes a pixel (dvo_fused.hip, p4_decode2).  For the inspection and host-driven paths, which read the texels. */
 __global__ void __launch_bounds__(256)
@@ -1770,6 +1773,30 @@ hipError_t launch_p4_decode_texels(const unsigned *p4, size_t p4_stride, const f
     return hipGetLastError();
 }
 
+/* ---- round 6: the band stage (dvo_edt_band.h) ---- */
+struct EdtLevelShape { int R, waves; size_t lds_cols, lds_rows; };
+static bool edt_band_enabled() {
+    static const bool on = [] { const char *e = getenv("DVO_EDT_FUSED"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static size_t edt_band_lds(int cols) { return (size_t)(cols + 2 * EB_PAD) * EB_CD * 4 + EB_LDS_LUT_WORDS * 6; }
+static bool edt_band_ok(int rows, int cols) {
+    return edt_band_enabled() && rows >= 2 && cols >= 2 && rows <= EB_MAX_ROWS && cols <= EB_MAX_COLS;
+}
+/* scratch of the band stage for `count` images of one level, in ints: column words | their carries | image maxima | band counters */
+static size_t edt_band_ints(int rows, int cols, int count) {
+    return (((size_t)((rows + 31) / 32) * cols * 2 + 2) * count + 3) & ~(size_t)3;
+}
+static size_t edt_band_list_ints(int count) { return ((size_t)DVO_LEVELS * count + 1 + 3) & ~(size_t)3; }
+static int *edt_band_carve(int *w, int rows, int cols, int count, EdtBandLevels &tb, int l) {
+    const size_t nw = (size_t)((rows + 31) / 32) * cols * count;
+    tb.maskT[l] = reinterpret_cast<unsigned *>(w);
+    tb.carryT[l] = tb.maskT[l] + nw;
+    tb.imax[l] = tb.carryT[l] + nw;
+    tb.done[l] = reinterpret_cast<int *>(tb.imax[l] + count);
+    return w + edt_band_ints(rows, cols, count);
+}
+
 /* LDS rows per workgroup of the row pass.  R >= 2: the packed kernel (two 16-bit tiles, the scanned one padded); R = 1 (rows of
  * more than ~8 K columns): the 32-bit kernel on g^2, beyond 16 K columns on 16-bit g */
 static size_t edt_pk_lds_bytes(int cols, int R) { return (size_t)(cols + 2 * EDT_PK_PAD) * (R / 2) * 4 + (size_t)cols * R * 2; }
@@ -1783,7 +1810,8 @@ static unsigned edt_row_blocks(int rows, int cols) { const int R = edt_rows_per_
 /* scratch of one launch_edges_to_now over `count` images, in ints: g (16 bit) | d2 | per-block maxima | bitmaps | flags */
 size_t edt_work_ints(int rows, int cols, int count) {
     const size_t ng = edt_g_count(rows, cols, edt_rows_per_block(cols));
-    return ((ng + 1) / 2 + 4 + ng + edt_row_blocks(rows, cols) + (size_t)edt_bitmap_words(rows, cols) + 1) * count + 64;
+    return ((ng + 1) / 2 + 4 + ng + edt_row_blocks(rows, cols) + (size_t)edt_bitmap_words(rows, cols) + 1) * count + 64
+           + edt_band_ints(rows, cols, count) + edt_band_list_ints(count) + 8;
 }
 
 template <int R, typename T>
@@ -1812,6 +1840,78 @@ static hipError_t edt_rows_pk_launch(const unsigned short *g, ImgBatch gb, unsig
     return hipGetLastError();
 }
 
+/* the band stage for the levels of `t` (the three-pass stage's table: its scratch serves the images on the list): column words,
+ * bands, the listed images' exact columns + rows, palettes.  tb: scratch pointers carved, everything else filled here. */
+template <int WAVES>
+static void edt_columns8_list_launch(const EdtLevels &t, const EdtListShape &ls, const int *list, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL(edt_columns8_list_kernel<WAVES>, dim3(64), dim3(WAVES * 64), lds, s, t, ls, list);
+}
+template <int R>
+static hipError_t edt_rows_pk_list_launch(const EdtLevels &t, const EdtListShape &ls, const int *list, size_t lds, hipStream_t s) {
+    auto kern = edt_rows_pk_list_kernel<R>;
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(64), dim3(256), lds, s, t, ls, list);
+    return hipGetLastError();
+}
+template <int NI>
+static hipError_t edt_band_kernel_launch(const EdtBandLevels &tb, unsigned g, int count, size_t lds, hipStream_t s) {
+    auto kern = edt_band_levels_kernel<NI>;
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(g, count), dim3(256), lds, s, tb);
+    return hipGetLastError();
+}
+static hipError_t edt_band_run(const EdtLevels &t, const EdtLevelShape &sh, EdtBandLevels &tb, int count, hipStream_t s) {
+    const int n = t.n;
+    int cmax = 0;
+    for (int l = 0; l < n; l++) cmax = t.cols[l] > cmax ? t.cols[l] : cmax;
+    const int T = EB_T;
+    if (cmax > EB_MAX_COLS || (sh.waves != 8 && sh.waves != 4)) return hipErrorInvalidValue;
+    tb.n = n; tb.first_pair = t.first_pair;
+    tb.firstA[0] = 0; tb.firstB[0] = 0;
+    EdtListShape ls;
+    ls.gxmax_cols = 1; ls.gxmax_rows = 1;
+    for (int l = 0; l < n; l++) {
+        tb.rows[l] = t.rows[l]; tb.cols[l] = t.cols[l];
+        tb.nwords[l] = (t.rows[l] + 31) / 32;
+        tb.tpc[l] = p4_tiles_per_col(t.rows[l]);
+        tb.nbands[l] = (tb.tpc[l] + T - 1) / T;
+        tb.n_partial[l] = t.n_partial[l];
+        tb.edge[l] = t.edge[l]; tb.edge_stride[l] = t.edge_stride[l];
+        tb.flags[l] = t.flags[l]; tb.partial[l] = t.partial[l];
+        tb.p4[l] = t.p4[l]; tb.p4_stride[l] = t.p4_stride[l]; tb.pal[l] = t.pal[l]; tb.pal_n[l] = t.pal_n[l];
+        tb.firstA[l + 1] = tb.firstA[l] + (unsigned)((t.cols[l] + 31) / 32);
+        tb.firstB[l + 1] = tb.firstB[l] + (unsigned)tb.nbands[l];
+        const int ngroups = (t.cols[l] + sh.waves - 1) / sh.waves;
+        ls.gx_cols[l] = ngroups < 16 ? ngroups : 16;
+        ls.gxmax_cols = ls.gx_cols[l] > ls.gxmax_cols ? ls.gx_cols[l] : ls.gxmax_cols;
+        ls.gxmax_rows = t.n_partial[l] > ls.gxmax_rows ? t.n_partial[l] : ls.gxmax_rows;
+    }
+    for (int l = n; l < DVO_LEVELS; l++) ls.gx_cols[l] = 0;
+    hipLaunchKernelGGL(edt_colmask_levels_kernel, dim3(tb.firstA[n], count), dim3(512), 0, s, tb);
+    hipError_t e;
+    const size_t lds = edt_band_lds(cmax);
+    e = (2 * cmax <= 256 * 5) ? edt_band_kernel_launch<5>(tb, tb.firstB[n], count, lds, s) : edt_band_kernel_launch<8>(tb, tb.firstB[n], count, lds, s);
+    if (e != hipSuccess) return e;
+    if (sh.waves == 8) edt_columns8_list_launch<8>(t, ls, tb.list, sh.lds_cols, s);
+    else edt_columns8_list_launch<4>(t, ls, tb.list, sh.lds_cols, s);
+    switch (sh.R) {
+    case 16: e = edt_rows_pk_list_launch<16>(t, ls, tb.list, sh.lds_rows, s); break;
+    case 8: e = edt_rows_pk_list_launch<8>(t, ls, tb.list, sh.lds_rows, s); break;
+    case 4: e = edt_rows_pk_list_launch<4>(t, ls, tb.list, sh.lds_rows, s); break;
+    case 2: e = edt_rows_pk_list_launch<2>(t, ls, tb.list, sh.lds_rows, s); break;
+    default: return hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(edt_palette_levels_kernel, dim3(n, count), dim3(256), 0, s, tb);
+    return hipGetLastError();
+}
+
 /* edge masks -> resident now levels of pairs first_pair .. first_pair + count - 1.  With p4 != NULL the compact form is what is
  * written (16-byte texels only for the images it cannot hold); with p4 == NULL the 16-byte texels of every image. */
 hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, ImgBatch gb, int *work,
@@ -1828,7 +1928,32 @@ hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, Im
     unsigned *bitmap = reinterpret_cast<unsigned *>(partial + (size_t)nblk * gb.count);
     int *flags = reinterpret_cast<int *>(bitmap + (size_t)bm_words * gb.count);
     hipError_t e;
-    if (!only_texels) {
+    /* round 6: one pass from the edge mask to the rank words (dvo_edt_band.h); the three-pass stage below for what it does not take */
+    const bool band = p4 && !only_texels && R >= 2 && edt_band_ok(gb.rows, gb.cols);
+    if (band) {
+        EdtLevels t{};
+        t.n = 1; t.R = R; t.first_pair = first_pair;
+        t.rows[0] = gb.rows; t.cols[0] = gb.cols; t.bm_words[0] = bm_words; t.n_partial[0] = (int)nblk;
+        t.edge[0] = edge; t.edge_stride[0] = edge_stride;
+        t.g[0] = g; t.d2[0] = d2; t.partial[0] = partial; t.bitmap[0] = bitmap; t.flags[0] = flags;
+        t.p4[0] = p4; t.p4_stride[0] = p4_stride; t.pal[0] = pal; t.pal_n[0] = pal_n;
+        EdtLevelShape sh;
+        const size_t lds_wave = 16;                           /* rows <= 512: one chunk */
+        sh.R = R; sh.waves = (R <= 8) ? 8 : 4; sh.lds_cols = lds_wave * sh.waves; sh.lds_rows = edt_pk_lds_bytes(gb.cols, R);
+        EdtBandLevels tb{};
+        int *wb = edt_band_carve(flags + gb.count, gb.rows, gb.cols, gb.count, tb, 0);
+        tb.list = wb;
+        if ((e = edt_band_run(t, sh, tb, gb.count, s)) != hipSuccess) return e;
+        if (getenv("DVO_EDT_DEBUG")) {
+            (void)hipStreamSynchronize(s);
+            unsigned im = 0; int fl = 0, pn = 0, dn = 0, li = 0;
+            (void)hipMemcpy(&im, tb.imax[0], 4, hipMemcpyDeviceToHost); (void)hipMemcpy(&fl, tb.flags[0], 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&dn, tb.done[0], 4, hipMemcpyDeviceToHost); (void)hipMemcpy(&li, tb.list, 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&pn, pal_n + first_pair, 4, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[edt band] %dx%d imax %u flags %d done %d list %d pal_n %d nbands %d\n", gb.rows, gb.cols, im, fl, dn, li, pn, tb.nbands[0]);
+        }
+    }
+    if (!only_texels && !band) {
         const size_t lds_wave = (((size_t)((gb.rows + 511) / 512) * 2 * sizeof(int)) + 15) & ~(size_t)15;      /* per wave: two border distances per 512-row chunk */
         if (R <= 8 && lds_wave * 8 <= 48 * 1024) {            /* eight adjacent columns complete a 128-byte line of 8-row blocks */
             const int cg = gb.count >= 64 ? 4 : (gb.count >= 16 ? 2 : 1);      /* column groups per workgroup */
@@ -1844,7 +1969,7 @@ hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, Im
                                bm_words, flags);
         }
     }
-    if (only_texels) e = hipSuccess;
+    if (only_texels || band) e = hipSuccess;
     else switch (R) {
     case 16: e = edt_rows_pk_launch<16>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
     case 8: e = edt_rows_pk_launch<8>(g, gb, nblk, d2, partial, bitmap, bm_words, flags, s); break;
@@ -1856,7 +1981,7 @@ hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, Im
         break;
     }
     if (e != hipSuccess) return e;
-    if (p4 && !only_texels) {
+    if (p4 && !only_texels && !band) {
         const int ptiles_y = (p4_tiles_per_col(gb.rows) + PK_LR - 1) / PK_LR, ptiles_x = (((gb.cols + 3) >> 2) + PK_LC - 1) / PK_LC;
         /* tiles per workgroup: whole tile columns for large batches (the rank table is built once per workgroup), single tiles
          * when the launch would not fill the GPU otherwise (one camera stream) */
@@ -1879,7 +2004,6 @@ hipError_t launch_edges_to_now(const unsigned char *edge, size_t edge_stride, Im
 
 /* launch_edges_to_now for all pyramid levels of the same `count` images at once: five launches (six when squared distances of
  * 65536 and more are possible) instead of that many per level.  work: edt_levels_work_ints() ints; p4 all NULL or all set. */
-struct EdtLevelShape { int R, waves; size_t lds_cols, lds_rows; };
 static bool edt_levels_shape(int n, const int *rows, const int *cols, EdtLevelShape &sh) {
     if (n < 2 || n > DVO_LEVELS) return false;
     int r0 = 0, c0 = 0;
@@ -1902,8 +2026,8 @@ size_t edt_levels_work_ints(int n, const int *rows, const int *cols, int count) 
     EdtLevelShape sh;
     if (!edt_levels_shape(n, rows, cols, sh)) return 0;
     size_t t = 0;
-    for (int l = 0; l < n; l++) t += (edt_level_ints(rows[l], cols[l], sh.R, count) + 3) & ~(size_t)3;
-    return t + 64;
+    for (int l = 0; l < n; l++) t += ((edt_level_ints(rows[l], cols[l], sh.R, count) + 3) & ~(size_t)3) + edt_band_ints(rows[l], cols[l], count);
+    return t + 64 + edt_band_list_ints(count);
 }
 template <int R>
 static hipError_t edt_rows_pk_levels_launch(const EdtLevels &t, unsigned g, int count, size_t lds, hipStream_t s) {
@@ -1948,7 +2072,17 @@ hipError_t launch_edges_to_now_levels(int n, const int *rows, const int *cols, c
     auto prefix = [&](auto blocks_of) { t.first[0] = 0; for (int l = 0; l < n; l++) t.first[l + 1] = t.first[l] + blocks_of(l); return t.first[n]; };
     hipError_t e = hipSuccess;
     unsigned g = 0;
-    if (!only_texels) {
+    /* round 6: one pass from the edge masks to the rank words (dvo_edt_band.h) when every level qualifies */
+    bool band = with_p4 && !only_texels;
+    for (int l = 0; l < n && band; l++) band = edt_band_ok(rows[l], cols[l]);
+    if (band) {
+        EdtBandLevels tb{};
+        int *wb = w;
+        for (int l = 0; l < n; l++) wb = edt_band_carve(wb, rows[l], cols[l], count, tb, l);
+        tb.list = wb;
+        if ((e = edt_band_run(t, sh, tb, count, s)) != hipSuccess) return e;
+    }
+    if (!only_texels && !band) {
         /* column groups per workgroup: several for large batches (the workgroup's table and launch are paid once) */
         const int cg = count >= 64 ? 4 : (count >= 16 ? 2 : 1);
         g = prefix([&](int l) { const int ng = (cols[l] + sh.waves - 1) / sh.waves; return (unsigned)((ng + cg - 1) / cg); });
@@ -1963,7 +2097,7 @@ hipError_t launch_edges_to_now_levels(int n, const int *rows, const int *cols, c
         }
     }
     if (e != hipSuccess) return e;
-    if (with_p4 && !only_texels) {
+    if (with_p4 && !only_texels && !band) {
         g = prefix([&](int l) {
             const int ptx = (((cols[l] + 3) >> 2) + PK_LC - 1) / PK_LC, n_strips = (t.ptiles_y[l] + t.strip[l] - 1) / t.strip[l];
             return (unsigned)(n_strips * ptx);
