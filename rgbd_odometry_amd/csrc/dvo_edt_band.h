@@ -128,23 +128,39 @@ __global__ void __launch_bounds__(512) edt_colmask_levels_kernel(const EdtBandLe
     }
 }
 
-/* (3) above: one band of one image -- two tile rows of the compact image = 12 interior rows + the apron row above and below = 14 rows,
- * every column.  LDS: ONE tile [PAD + cols + PAD][16 row slots as 8 dwords] -- min(g^2, 65535) pairs while the scan runs, the
- * pixels' rank pairs afterwards (a thread keeps the ranks of its <= NI items in registers across the barrier between the two
- * uses) -- and the first 256 words of the rank table (squared distances below 8192; the rest is read from memory): 22.5 KB at 640
- * columns, seven workgroups per CU.  A lane scans EIGHT rows of one column (one ds_read_b128 per neighbour column and side, four
- * packed minima / saturating additions per dword): 2.4 instructions per pixel and step against 4.1 for two rows per lane. */
-constexpr int EB_T = 2, EB_NR = 6 * EB_T + 2, EB_CD = 8;       /* tile rows per band, its rows, dwords per tile column (16 row slots) */
-constexpr int EB_LDS_LUT_WORDS = 256;
+/* (3) above: one band of one image -- T tile rows of the compact image = 6T interior rows + the apron row above and below = NR
+ * rows in NS row slots (a multiple of eight), every column.  Slot s stands for image row ya + s with ya = 6T * band - 1; row -1
+ * is row 1 and row `rows` is row rows - 2 (reflect-101, cv::filter2D's border): those two slots are COPIES made while the tile is
+ * built, so that nothing after it knows about borders in y, and two pad columns get the ranks of columns 1 and cols - 2 for the
+ * same in x.  LDS: ONE tile [PAD + cols + PAD][NS / 2 dwords] -- min(g, 255)^2 pairs while the scan runs, the pixels' rank pairs
+ * afterwards (a thread keeps the ranks of its <= NI items in registers across the barrier between the two uses) -- and the ranks
+ * of the squared distances below EB_DIRECT as a plain table (larger ones go through the bitmap in memory).
+ * A lane scans EIGHT rows of one column: one ds_read_b128 per neighbour column and side, then per dword a packed minimum, a
+ * saturating packed addition of the step's i^2 and a packed minimum -- 1.5 vector instructions per pixel and step.
+ * Two shapes: T = 2, 256 threads (14 of 16 slots used, 29 KB of LDS at 640 columns: small batches, many short workgroups) and
+ * T = 5, 512 threads (32 of 32 slots, 50 KB: 30 of every 32 scanned rows are interior rows, against 12 of 16). */
+constexpr int EB_DIRECT = 4096;
 typedef unsigned eb_v4 __attribute__((ext_vector_type(4)));
-static_assert(EB_NR <= 2 * EB_CD && EB_NR <= 26, "a band's rows fit the column's slots and, with the first at bit 31 at worst, one 64-bit window");
+struct EdtRank16 { unsigned short r[EB_DIRECT]; };
+constexpr EdtRank16 edt_rank16_make() {
+    const EdtSosLut L = edt_sos_lut_make();
+    EdtRank16 t{};
+    int run = 0;
+    for (int v = 0; v < EB_DIRECT; v++) { t.r[v] = (unsigned short)(2 + run); if ((L.bm[v >> 5] >> (v & 31)) & 1u) run++; }
+    return t;
+}
+__device__ const EdtRank16 EDT_RANK16 = edt_rank16_make();
 DVO_DEV eb_v4 eb_mk4(unsigned x, unsigned y, unsigned z, unsigned w) { eb_v4 v; v.x = x; v.y = y; v.z = z; v.w = w; return v; }
 DVO_DEV unsigned eb_rank_global(unsigned v) {
     return 2u + EDT_SOS_LUT.pre[v >> 5] + (unsigned)__popc(EDT_SOS_LUT.bm[v >> 5] & ((1u << (v & 31u)) - 1u));
 }
-template <int NI>                                              /* items (column halves) per thread: 2 * cols <= 256 * NI */
-__global__ void __launch_bounds__(256, (NI <= 5) ? 7 : 5) edt_band_levels_kernel(const EdtBandLevels t) {
-    constexpr int NC = (NI + 1) / 2;                            /* columns per thread while the tile is built */
+DVO_DEV unsigned eb_pk_lo(unsigned hi_src, unsigned lo_src) { return __builtin_amdgcn_perm(hi_src, lo_src, 0x05040100u); }   /* (hi_src.lo16 << 16) | lo_src.lo16 */
+DVO_DEV unsigned eb_pk_hi(unsigned hi_src, unsigned lo_src) { return __builtin_amdgcn_perm(hi_src, lo_src, 0x07060302u); }   /* (hi_src.hi16 << 16) | lo_src.hi16 */
+template <int T, int THREADS, int NI>                          /* NI: items (8 rows of a column) per thread, cols * NS / 8 <= THREADS * NI */
+__global__ void __launch_bounds__(THREADS, (THREADS == 256) ? ((NI <= 5) ? 5 : 4) : 6) edt_band_levels_kernel(const EdtBandLevels t) {
+    constexpr int NR = 6 * T + 2, NS = (NR + 7) & ~7, CD = NS / 2, LPC = NS / 8, CB = CD * 4, C4 = CD / 4;
+    constexpr int NPI = (NI * THREADS / LPC / 2 + THREADS - 1) / THREADS;      /* column pairs per thread while the tile is built */
+    static_assert(NR <= 32 && (LPC & (LPC - 1)) == 0 && EB_PAD >= 4, "a band's rows lie in one 64-bit window of the column; a trip is four steps");
     extern __shared__ eb_v4 eb_lds4[];
     const int l = level_of_block(t.firstB, t.n, blockIdx.x);
     const int band = (int)(blockIdx.x - t.firstB[l]), by = blockIdx.y;
@@ -155,58 +171,81 @@ __global__ void __launch_bounds__(256, (NI <= 5) ? 7 : 5) edt_band_levels_kernel
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};      /* [0] table + g + barrier, [1] scan trips, [2] ranks, [3] rank words, [4] tail, [5] waves, [6] trips, [7] all */
 #endif
     EDT_T(t_begin);
-    unsigned *tq = reinterpret_cast<unsigned *>(eb_lds4);
-    unsigned *lbm = tq + (size_t)(cols + 2 * EB_PAD) * EB_CD;
-    unsigned short *lpre = reinterpret_cast<unsigned short *>(lbm + EB_LDS_LUT_WORDS);
+    unsigned short *lrank = reinterpret_cast<unsigned short *>(eb_lds4 + (size_t)(cols + 2 * EB_PAD) * C4);
 
-    /* ---- the band's rows of g from the column words: every load first, then the arithmetic ---- */
-    const int ya = band == 0 ? 0 : 6 * EB_T * band - 1;
-    const int yb = (rows - 1 < 6 * EB_T * (band + 1)) ? rows - 1 : 6 * EB_T * (band + 1);
-    const int n = yb - ya + 1;                                   /* 2 .. 14 rows */
-    const int w0 = ya >> 5, w1 = yb >> 5, p0 = ya - 32 * w0, nbits = (w1 - w0 + 1) * 32;
+    /* ---- the band's rows of g from the column words, TWO columns per thread in packed 16-bit arithmetic: every load first ---- */
+    const int ya = 6 * T * band - 1, yb = ya + NR - 1;
+    const int ra = ya < 0 ? 0 : ya, rb = yb > rows - 1 ? rows - 1 : yb;         /* the real rows among them */
+    const int off = ra - ya, nreal = rb - ra + 1;                 /* slot of row ra (0, or 1 in band 0); 1 .. NR rows */
+    const int s_bot = (yb >= rows) ? rows - ya : -1;              /* slot of row `rows` (a copy of row rows - 2), if the band has it */
+    const int w0 = ra >> 5, w1 = rb >> 5, p0 = ra - 32 * w0, nbits = (w1 - w0 + 1) * 32, pend = p0 + nreal - 1;
     {
         const int nwords = t.nwords[l];
         const unsigned *mk = t.maskT[l] + (size_t)by * nwords * cols, *cr = t.carryT[l] + (size_t)by * nwords * cols;
-        unsigned ma[NC], mb[NC], ca[NC], cb[NC];
+        unsigned ld[NPI][8];
 #pragma unroll
-        for (int k = 0; k < NC; k++) {
-            const int col = tid + 256 * k, cc = col < cols ? col : cols - 1;
-            ma[k] = mk[(size_t)w0 * cols + cc]; ca[k] = cr[(size_t)w0 * cols + cc];
-            mb[k] = mk[(size_t)w1 * cols + cc]; cb[k] = cr[(size_t)w1 * cols + cc];
+        for (int ip = 0; ip < NPI; ip++) {
+            const int cA = 2 * (tid + THREADS * ip);
+            const int a = cA < cols ? cA : cols - 1, b = cA + 1 < cols ? cA + 1 : cols - 1;
+            ld[ip][0] = mk[(size_t)w0 * cols + a]; ld[ip][1] = mk[(size_t)w1 * cols + a]; ld[ip][2] = cr[(size_t)w0 * cols + a]; ld[ip][3] = cr[(size_t)w1 * cols + a];
+            ld[ip][4] = mk[(size_t)w0 * cols + b]; ld[ip][5] = mk[(size_t)w1 * cols + b]; ld[ip][6] = cr[(size_t)w0 * cols + b]; ld[ip][7] = cr[(size_t)w1 * cols + b];
         }
-        lbm[tid] = EDT_SOS_LUT.bm[tid];
-        if (tid < EB_LDS_LUT_WORDS / 2) reinterpret_cast<unsigned *>(lpre)[tid] = reinterpret_cast<const unsigned *>(EDT_SOS_LUT.pre)[tid];
-        if (tid < EB_PAD * EB_CD / 4) {
+        for (int i = tid; i < EB_DIRECT / 2; i += THREADS) reinterpret_cast<unsigned *>(lrank)[i] = reinterpret_cast<const unsigned *>(EDT_RANK16.r)[i];
+        if (tid < EB_PAD * C4) {
             eb_lds4[tid] = eb_mk4(~0u, ~0u, ~0u, ~0u);
-            eb_lds4[(size_t)(EB_PAD + cols) * (EB_CD / 4) + tid] = eb_mk4(~0u, ~0u, ~0u, ~0u);
+            eb_lds4[(size_t)(EB_PAD + cols) * C4 + tid] = eb_mk4(~0u, ~0u, ~0u, ~0u);
         }
-#pragma unroll
-        for (int k = 0; k < NC; k++) {
-            const int col = tid + 256 * k;
-            if (col >= cols) break;
-            const unsigned long long M = (w1 != w0) ? ((unsigned long long)ma[k] | ((unsigned long long)mb[k] << 32)) : (unsigned long long)ma[k];
-            const int U = (int)(ca[k] & 0xffffu), D = (int)(cb[k] >> 16);
-            const unsigned W = (unsigned)(M >> p0);                /* bit r: an edge at the band's row r (p0 + 13 < 64) */
+        auto prep = [&](unsigned m0, unsigned m1, unsigned c0, unsigned c1, unsigned &W, unsigned &u0, unsigned &d0) {
+            const unsigned long long M = (w1 != w0) ? ((unsigned long long)m0 | ((unsigned long long)m1 << 32)) : (unsigned long long)m0;
+            W = (unsigned)(M >> p0);                               /* bit k: an edge at row ra + k */
             const unsigned long long Mlo = M & ((1ull << p0) - 1ull);
-            int d = Mlo ? (p0 - 1) - (63 - __clzll((long long)Mlo)) : U + p0;      /* row ya - 1 to the nearest edge at or above it */
-            int up[EB_NR];
+            u0 = (unsigned)(Mlo ? (p0 - 1) - (63 - __clzll((long long)Mlo)) : (int)(c0 & 0xffffu) + p0);       /* row ra - 1 to the nearest edge at or above it */
+            const unsigned long long Mhi = M >> (pend + 1);         /* pend <= 62 */
+            d0 = (unsigned)(Mhi ? __ffsll((long long)Mhi) - 1 : (int)(c1 >> 16) + (nbits - 1 - pend));        /* row rb + 1 to the nearest edge at or below it */
+        };
 #pragma unroll
-            for (int r = 0; r < EB_NR; r++) { d = (W & (1u << r)) ? 0 : d + 1; up[r] = d; }
-            const int pend = p0 + n - 1;
-            const unsigned long long Mhi = M >> (pend + 1);
-            d = Mhi ? __ffsll((long long)Mhi) - 1 : D + (nbits - 1 - pend);        /* row yb + 1 to the nearest edge at or below it */
-            unsigned q[2 * EB_CD];
+        for (int ip = 0; ip < NPI; ip++) {
+            const int cA = 2 * (tid + THREADS * ip);
+            if (cA >= cols) break;
+            unsigned WA, WB, uA, uB, dA, dB;
+            prep(ld[ip][0], ld[ip][1], ld[ip][2], ld[ip][3], WA, uA, dA);
+            prep(ld[ip][4], ld[ip][5], ld[ip][6], ld[ip][7], WB, uB, dB);
+            const int NWA = (int)~WA, NWB = (int)~WB;
+            edt_us2 up = edt_as_us2(eb_pk_lo(uB, uA)), dn = edt_as_us2(eb_pk_lo(dB, dA));
+            const edt_us2 one = edt_as_us2(0x00010001u), c255 = edt_as_us2(0x00ff00ffu);
+            unsigned nm[NR];                                       /* per row: 0xffff in the half of a column WITHOUT an edge there */
+            edt_us2 U[NR];
 #pragma unroll
-            for (int r = 2 * EB_CD - 1; r >= 0; r--) {
-                if (r < EB_NR && r < n) {
-                    d = (W & (1u << r)) ? 0 : d + 1;
-                    const unsigned gd = (unsigned)(up[r] < d ? up[r] : d);
-                    q[r] = gd > 255u ? 65535u : gd * gd;
-                } else q[r] = 0u;                                /* row slots past the band: finished before they start */
+            for (int k = 0; k < NR; k++) {
+                nm[k] = eb_pk_lo((unsigned)__builtin_amdgcn_sbfe(NWB, k, 1), (unsigned)__builtin_amdgcn_sbfe(NWA, k, 1));
+                up = edt_as_us2(edt_as_u32(up + one) & nm[k]);
+                U[k] = up;
             }
-            eb_v4 *dst = eb_lds4 + (size_t)(EB_PAD + col) * (EB_CD / 4);
-            dst[0] = eb_mk4(q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), q[6] | (q[7] << 16));
-            dst[1] = eb_mk4(q[8] | (q[9] << 16), q[10] | (q[11] << 16), q[12] | (q[13] << 16), q[14] | (q[15] << 16));
+            unsigned q[NR];
+#pragma unroll
+            for (int k = NR - 1; k >= 0; k--) {
+                if (k < nreal) {
+                    dn = edt_as_us2(edt_as_u32(dn + one) & nm[k]);
+                    const edt_us2 gc = __builtin_elementwise_min(__builtin_elementwise_min(U[k], dn), c255);     /* g > 255: its square is beyond every rank */
+                    q[k] = edt_as_u32(gc * gc);
+                } else q[k] = 0u;
+            }
+            unsigned qs[NS];                                       /* by slot: row ra + k sits in slot k + off */
+#pragma unroll
+            for (int sl = 0; sl < NS; sl++) {
+                const unsigned v0 = sl < NR ? q[sl] : 0u, v1 = (sl >= 1 && sl - 1 < NR) ? q[sl - 1] : 0u;
+                qs[sl] = off ? v1 : v0;
+            }
+            if (off) qs[0] = qs[2];                                /* row -1 is row 1 */
+#pragma unroll
+            for (int sl = 2; sl < NR; sl++) if (sl == s_bot) qs[sl] = qs[sl - 2];      /* row `rows` is row rows - 2; the slots after it stay 0 */
+            eb_v4 *dA4 = eb_lds4 + (size_t)(EB_PAD + cA) * C4;
+#pragma unroll
+            for (int c4 = 0; c4 < C4; c4++) {
+                dA4[c4] = eb_mk4(eb_pk_lo(qs[8 * c4 + 1], qs[8 * c4]), eb_pk_lo(qs[8 * c4 + 3], qs[8 * c4 + 2]), eb_pk_lo(qs[8 * c4 + 5], qs[8 * c4 + 4]), eb_pk_lo(qs[8 * c4 + 7], qs[8 * c4 + 6]));
+                if (cA + 1 < cols)
+                    dA4[C4 + c4] = eb_mk4(eb_pk_hi(qs[8 * c4 + 1], qs[8 * c4]), eb_pk_hi(qs[8 * c4 + 3], qs[8 * c4 + 2]), eb_pk_hi(qs[8 * c4 + 5], qs[8 * c4 + 4]), eb_pk_hi(qs[8 * c4 + 7], qs[8 * c4 + 6]));
+            }
         }
     }
     __syncthreads();
@@ -216,46 +255,43 @@ __global__ void __launch_bounds__(256, (NI <= 5) ? 7 : 5) edt_band_levels_kernel
     /* ---- the row scan, eight rows per lane; the ranks of a thread's items stay in registers ---- */
     typedef __attribute__((address_space(3))) const eb_v4 lds_c4;
     const unsigned tq_lds = (unsigned)(size_t)(lds_c4 *)eb_lds4;
-    const int total = cols * 2;
+    const int total = cols * LPC;
     unsigned mx = 0;
     bool far = false;
     eb_v4 res[NI];
     auto rank_of = [&](unsigned v) -> unsigned {
-        if (v < (unsigned)EB_LDS_LUT_WORDS * 32u) return 2u + lpre[v >> 5] + (unsigned)__popc(lbm[v >> 5] & ((1u << (v & 31u)) - 1u));
+        if (v < (unsigned)EB_DIRECT) return lrank[v];
         if (v < EB_D2_END) return eb_rank_global(v);
         return (unsigned)EB_NANR;
     };
     auto ranks2 = [&](unsigned w) -> unsigned {
         const unsigned v0 = w & 0xffffu, v1 = w >> 16;
-        far = far || v0 >= EB_D2_END || v1 >= EB_D2_END;
-        mx = v0 > mx ? v0 : mx; mx = v1 > mx ? v1 : mx;
         return rank_of(v0) | (rank_of(v1) << 16);
     };
 #pragma unroll
     for (int it = 0; it < NI; it++) {
-        const int p = it * 256 + tid;
-        if (it * 256 + (tid & ~63) >= total) { res[it] = eb_mk4(0u, 0u, 0u, 0u); continue; }      /* wave-uniform */
+        const int p = it * THREADS + tid;
+        if (it * THREADS + (tid & ~63) >= total) { res[it] = eb_mk4(0u, 0u, 0u, 0u); continue; }      /* wave-uniform */
         const int cp = p < total ? p : total - 1;
-        const int h = cp & 1;
-        const int ctr = (EB_PAD * 2 + cp) * 16;                  /* byte offset of the item's four dwords */
-        eb_v4 best = eb_lds4[EB_PAD * 2 + cp];
+        const int h = cp & (LPC - 1), col = cp / LPC;
+        const unsigned ctr = tq_lds + (unsigned)((EB_PAD + col) * CB + h * 16);      /* LDS address of the item's four dwords */
+        eb_v4 best = *(lds_c4 *)(size_t)ctr;
         if (p >= total) best = eb_mk4(0u, 0u, 0u, 0u);
         unsigned S = 0x00010001u, Dd = 0x00030003u;
-        int la = ctr - 4 * 32, ra = ctr;
-        const int la_min = h * 16, ra_max = (EB_PAD + cols + EB_PAD - 5) * 32 + h * 16;
+        unsigned la = ctr - 4u * CB, ra_ = ctr;
+        const unsigned la_min = tq_lds + (unsigned)(h * 16), ra_max = tq_lds + (unsigned)((EB_PAD + cols + EB_PAD - 5) * CB + h * 16);
         EDT_T(t_s0);
         int trip = 0;
         for (; trip < 2 * EB_TRIPS; trip++) {                    /* four steps per trip */
-            const edt_us2 s2 = edt_as_us2(S);
-            const unsigned open = edt_as_u32(__builtin_elementwise_sub_sat(edt_as_us2(best.x), s2)) | edt_as_u32(__builtin_elementwise_sub_sat(edt_as_us2(best.y), s2)) |
-                                  edt_as_u32(__builtin_elementwise_sub_sat(edt_as_us2(best.z), s2)) | edt_as_u32(__builtin_elementwise_sub_sat(edt_as_us2(best.w), s2));
+            const edt_us2 m4 = __builtin_elementwise_max(__builtin_elementwise_max(edt_as_us2(best.x), edt_as_us2(best.y)), __builtin_elementwise_max(edt_as_us2(best.z), edt_as_us2(best.w)));
+            const unsigned open = edt_as_u32(__builtin_elementwise_sub_sat(m4, edt_as_us2(S)));
             if (__builtin_amdgcn_ballot_w64(open != 0u) == 0ull) break;               /* i^2 >= best everywhere */
-            unsigned lac = tq_lds + (unsigned)(la > la_min ? la : la_min), rac = tq_lds + (unsigned)(ra < ra_max ? ra : ra_max);
+            unsigned lac = (int)la > (int)la_min ? la : la_min, rac = ra_ < ra_max ? ra_ : ra_max;
             asm volatile("" : "+v"(lac), "+v"(rac));               /* the four offsets of either side go into the instructions */
             lds_c4 *ql = (lds_c4 *)(size_t)lac, *qr = (lds_c4 *)(size_t)rac;
             eb_v4 a[4], b[4];
 #pragma unroll
-            for (int j = 1; j <= 4; j++) { a[j - 1] = ql[(4 - j) * 2]; b[j - 1] = qr[j * 2]; }
+            for (int j = 1; j <= 4; j++) { a[j - 1] = ql[(4 - j) * C4]; b[j - 1] = qr[j * C4]; }
 #pragma unroll
             for (int j = 1; j <= 4; j++) {
                 const edt_us2 sj = edt_as_us2(S);
@@ -266,13 +302,19 @@ __global__ void __launch_bounds__(256, (NI <= 5) ? 7 : 5) edt_band_levels_kernel
                 best.z = step(best.z, a[j - 1].z, b[j - 1].z); best.w = step(best.w, a[j - 1].w, b[j - 1].w);
                 S += Dd; Dd += 0x00020002u;
             }
-            la -= 4 * 32; ra += 4 * 32;
+            la -= 4u * CB; ra_ += 4u * CB;
         }
         EDT_T(t_s1);
         EDT_ACC(1, t_s0, t_s1);
 #ifdef DVO_EDT_STAMPS
         acc_t[6] += (unsigned long long)trip;
 #endif
+        {
+            const edt_us2 m4 = __builtin_elementwise_max(__builtin_elementwise_max(edt_as_us2(best.x), edt_as_us2(best.y)), __builtin_elementwise_max(edt_as_us2(best.z), edt_as_us2(best.w)));
+            const unsigned m = (unsigned)m4.x > (unsigned)m4.y ? (unsigned)m4.x : (unsigned)m4.y;
+            mx = m > mx ? m : mx;
+            far = far || m >= EB_D2_END;
+        }
         res[it] = eb_mk4(ranks2(best.x), ranks2(best.y), ranks2(best.z), ranks2(best.w));
         EDT_T(t_s2);
         EDT_ACC(2, t_s1, t_s2);
@@ -281,45 +323,52 @@ __global__ void __launch_bounds__(256, (NI <= 5) ? 7 : 5) edt_band_levels_kernel
     EDT_T(t_scanned);
 #pragma unroll
     for (int it = 0; it < NI; it++) {
-        const int p = it * 256 + tid;
+        const int p = it * THREADS + tid;
         if (p < total) {
-            eb_lds4[EB_PAD * 2 + p] = res[it];
-            const int col = p >> 1, h = p & 1;
-            if (col == 1) eb_lds4[(EB_PAD - 1) * 2 + h] = res[it];              /* reflect-101: column -1 is column 1 ... */
-            if (col == cols - 2) eb_lds4[(EB_PAD + cols) * 2 + h] = res[it];     /* ... and column `cols` is column cols - 2 */
+            const int h = p & (LPC - 1), col = p / LPC;
+            eb_lds4[(size_t)(EB_PAD + col) * C4 + h] = res[it];
+            if (col == 1) eb_lds4[(size_t)(EB_PAD - 1) * C4 + h] = res[it];              /* reflect-101: column -1 is column 1 ... */
+            if (col == cols - 2) eb_lds4[(size_t)(EB_PAD + cols) * C4 + h] = res[it];     /* ... and column `cols` is column cols - 2 */
         }
     }
     __syncthreads();
 
-    /* ---- rank words: the band's two lines of every tile column, contiguous in memory.  A thread's place in the 64 words of a
-     *      tile column is fixed; it walks the tile columns tid / 64, + 4, ... ---- */
+    /* ---- rank words, two at a time (stored rows 2 sp, 2 sp + 1 of a tile = slots 6 tyl + 2 sp and the next: one dword of the
+     *      tile): own rank, signed rank steps to the horizontal neighbours; the band's T lines of a tile column are contiguous ---- */
     const int tpc = t.tpc[l], ntc = (cols + 3) >> 2;
-    const int ty0 = band * EB_T, nty = (tpc - ty0 < EB_T) ? tpc - ty0 : EB_T;
+    const int ty0 = band * T, nty = (tpc - ty0 < T) ? tpc - ty0 : T;
     unsigned *p4 = t.p4[l] + (size_t)(t.first_pair + by) * t.p4_stride[l];
     if (band == 0 && tid < 32) p4[tid] = 0u;                       /* the sentinel line: palette entry 0 */
     bool part = false;
     {
-        const int rem = tid & 63, tyl = rem >> 5, wd = rem & 31, xl = wd >> 3, srow = wd & 7;
-        const int ty = ty0 + tyl, ys = ty * DVO_P4_ROWS + srow - 1;
-        const bool row_ok = tyl < nty && ys <= rows;
-        const bool interior = srow >= 1 && srow <= DVO_P4_ROWS && ys < rows;
-        const int r = reflect101(ys <= rows ? ys : rows, rows) - ya;
-        typedef __attribute__((address_space(3))) const unsigned short lds_cs;
-        for (int tc = tid >> 6; tc < ntc; tc += 4) {
-            const int xx = tc * 4 + xl;
-            unsigned word = 0u;
-            if (row_ok && xx < cols) {
-                lds_cs *pc = (lds_cs *)(size_t)(tq_lds + (unsigned)((EB_PAD + xx) * 32 + 2 * r));
-                int c = (int)pc[0];
-                if (interior) {
-                    int dr = (int)pc[16] - c, dl = (int)pc[-16] - c;
-                    if ((unsigned)(dr + 127) > 254u || (unsigned)(dl + 127) > 254u) { c = EB_NANR; dr = 0; dl = 0; }    /* this pixel is looked up in the 16-byte texels */
-                    word = (((unsigned)dr & 0xffu) << 16) | (((unsigned)dl & 0xffu) << 24);
-                }
-                if (c == EB_NANR) part = true;
-                word |= (unsigned)c << 3;
+        typedef __attribute__((address_space(3))) const unsigned lds_cu;
+        const int npairs = ntc * (16 * T);
+        for (int s2 = tid; s2 < npairs; s2 += THREADS) {
+            const int tc = s2 / (16 * T), rem = s2 - tc * (16 * T);
+            const int tyl = rem >> 4, xl = (rem >> 2) & 3, sp = rem & 3;
+            if (tyl >= nty) continue;
+            const int ty = ty0 + tyl, xx = tc * 4 + xl;
+            const int ys0 = ty * DVO_P4_ROWS + 2 * sp - 1;         /* image rows of the two words (-1 / rows: the reflected copies) */
+            unsigned word0 = 0u, word1 = 0u;
+            if (xx < cols && ys0 <= rows) {
+                lds_cu *pc = (lds_cu *)(size_t)(tq_lds + (unsigned)((EB_PAD + xx) * CB + (tyl * 3 + sp) * 4));
+                const unsigned C = pc[0], R = pc[CD], L = pc[-CD];
+                const edt_us2 dR = edt_as_us2(R) - edt_as_us2(C), dL = edt_as_us2(L) - edt_as_us2(C);
+                /* a step fits its signed byte iff step + 128 < 256 */
+                const unsigned bad = (edt_as_u32(dR + edt_as_us2(0x00800080u)) | edt_as_u32(dL + edt_as_us2(0x00800080u))) & 0xff00ff00u;
+                const unsigned steps = __builtin_amdgcn_perm(edt_as_u32(dL), edt_as_u32(dR), 0x06020400u);      /* bytes: dL.hi, dR.hi, dL.lo, dR.lo */
+                const bool in0 = sp >= 1 && ys0 < rows;            /* stored row 2 sp: interior unless it is the apron above (sp = 0) */
+                const bool in1 = sp <= 2 && ys0 + 1 < rows;        /* stored row 2 sp + 1: interior unless it is the apron below (sp = 3) */
+                unsigned c0 = C & 0xffffu, c1 = C >> 16;
+                unsigned st0 = in0 ? (steps & 0xffffu) : 0u, st1 = in1 ? (steps >> 16) : 0u;
+                if (in0 && (bad & 0x0000ff00u)) { c0 = EB_NANR; st0 = 0u; }     /* this pixel is looked up in the 16-byte texels */
+                if (in1 && (bad & 0xff000000u)) { c1 = EB_NANR; st1 = 0u; }
+                word0 = (c0 << 3) | (st0 << 16);
+                if (ys0 + 1 > rows) c1 = 0u;                       /* no such stored row: the word stays 0 */
+                else word1 = (c1 << 3) | (st1 << 16);
+                if (c0 == (unsigned)EB_NANR || c1 == (unsigned)EB_NANR) part = true;
             }
-            if (tyl < nty) p4[32u + ((size_t)tc * tpc + ty) * 32u + wd] = word;
+            *reinterpret_cast<uint2 *>(p4 + 32u + ((size_t)tc * tpc + ty) * 32u + (xl * 8 + 2 * sp)) = make_uint2(word0, word1);
         }
     }
     EDT_T(t_words);
@@ -327,9 +376,13 @@ __global__ void __launch_bounds__(256, (NI <= 5) ? 7 : 5) edt_band_levels_kernel
 
     /* ---- the image's maximum, its flags; the last band of an image puts it on the list if its form is partial.  The atomics are
      *      agent-scope read-modify-writes: one that has RETURNED has been performed, no fence (and none of its cache write-backs) ---- */
-    const int mred = block_reduce_256<true>((int)mx);
+    __shared__ int s_red[THREADS / 64];
+    for (int o = 32; o > 0; o >>= 1) { const unsigned v = (unsigned)__shfl_down((int)mx, o, 64); mx = v > mx ? v : mx; }
+    if ((tid & 63) == 0) s_red[tid >> 6] = (int)mx;
     const int any_far = __syncthreads_or(far ? 1 : 0), any_part = __syncthreads_or(part ? 1 : 0);
     if (tid == 0) {
+        int mred = 0;
+        for (int k = 0; k < THREADS / 64; k++) mred = s_red[k] > mred ? s_red[k] : mred;
         unsigned seen = atomicMax(t.imax[l] + by, (unsigned)mred);
         if (any_far || any_part) seen += (unsigned)atomicOr(t.flags[l] + by, (int)EDT_FLAG_PARTIAL | (any_far ? (int)EDT_FLAG_FAR : 0));
         asm volatile("s_waitcnt vmcnt(0)" :: "v"(seen) : "memory");
@@ -345,7 +398,7 @@ __global__ void __launch_bounds__(256, (NI <= 5) ? 7 : 5) edt_band_levels_kernel
         EDT_ACC(4, t_words, t_end);
         EDT_ACC(7, t_begin, t_end);
         acc_t[5] = 1;
-        const unsigned slot = ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6)) & (unsigned)(EDT_STAMP_SLOTS - 1);
+        const unsigned slot = ((blockIdx.y * gridDim.x + blockIdx.x) * (unsigned)(THREADS / 64) + (threadIdx.x >> 6)) & (unsigned)(EDT_STAMP_SLOTS - 1);
         if ((threadIdx.x & 63) == 0)
             for (int k = 0; k < 8; k++) g_edt_stamp[slot][k] = acc_t[k];
     }

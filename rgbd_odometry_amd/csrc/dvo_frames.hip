@@ -1779,7 +1779,14 @@ static bool edt_band_enabled() {
     static const bool on = [] { const char *e = getenv("DVO_EDT_FUSED"); return !(e && e[0] == '0'); }();
     return on;
 }
-static size_t edt_band_lds(int cols) { return (size_t)(cols + 2 * EB_PAD) * EB_CD * 4 + EB_LDS_LUT_WORDS * 6; }
+/* the two shapes of the band kernel: T tile rows per band */
+static int edt_band_row_slots(int T) { return (6 * T + 2 + 7) & ~7; }
+static size_t edt_band_lds(int cols, int T) { return (size_t)(cols + 2 * EB_PAD) * edt_band_row_slots(T) * 2 + EB_DIRECT * 2; }
+static int edt_band_T_for(int count, int tiles) {                 /* tiles: tile rows of all levels of one image */
+    static const int forced = [] { const char *e = getenv("DVO_EDT_BAND_T"); const int v = e ? atoi(e) : 0; return (v == 2 || v == 5) ? v : 0; }();
+    if (forced) return forced;
+    return ((long long)count * tiles >= 5 * 768) ? 5 : 2;         /* T = 5 once its 512-thread workgroups fill the chip (three per CU) */
+}
 static bool edt_band_ok(int rows, int cols) {
     return edt_band_enabled() && rows >= 2 && cols >= 2 && rows <= EB_MAX_ROWS && cols <= EB_MAX_COLS;
 }
@@ -1856,21 +1863,23 @@ static hipError_t edt_rows_pk_list_launch(const EdtLevels &t, const EdtListShape
     hipLaunchKernelGGL(kern, dim3(64), dim3(256), lds, s, t, ls, list);
     return hipGetLastError();
 }
-template <int NI>
+template <int T, int THREADS, int NI>
 static hipError_t edt_band_kernel_launch(const EdtBandLevels &tb, unsigned g, int count, size_t lds, hipStream_t s) {
-    auto kern = edt_band_levels_kernel<NI>;
+    auto kern = edt_band_levels_kernel<T, THREADS, NI>;
     if (lds > 48 * 1024) {
         const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(g, count), dim3(256), lds, s, tb);
+    hipLaunchKernelGGL(kern, dim3(g, count), dim3(THREADS), lds, s, tb);
     return hipGetLastError();
 }
 static hipError_t edt_band_run(const EdtLevels &t, const EdtLevelShape &sh, EdtBandLevels &tb, int count, hipStream_t s) {
     const int n = t.n;
     int cmax = 0;
     for (int l = 0; l < n; l++) cmax = t.cols[l] > cmax ? t.cols[l] : cmax;
-    const int T = EB_T;
+    int tiles = 0;
+    for (int l = 0; l < n; l++) tiles += p4_tiles_per_col(t.rows[l]);
+    const int T = edt_band_T_for(count, tiles);
     if (cmax > EB_MAX_COLS || (sh.waves != 8 && sh.waves != 4)) return hipErrorInvalidValue;
     tb.n = n; tb.first_pair = t.first_pair;
     tb.firstA[0] = 0; tb.firstB[0] = 0;
@@ -1895,8 +1904,9 @@ static hipError_t edt_band_run(const EdtLevels &t, const EdtLevelShape &sh, EdtB
     for (int l = n; l < DVO_LEVELS; l++) ls.gx_cols[l] = 0;
     hipLaunchKernelGGL(edt_colmask_levels_kernel, dim3(tb.firstA[n], count), dim3(512), 0, s, tb);
     hipError_t e;
-    const size_t lds = edt_band_lds(cmax);
-    e = (2 * cmax <= 256 * 5) ? edt_band_kernel_launch<5>(tb, tb.firstB[n], count, lds, s) : edt_band_kernel_launch<8>(tb, tb.firstB[n], count, lds, s);
+    const size_t lds = edt_band_lds(cmax, T);
+    if (T == 5) e = (cmax <= 640) ? edt_band_kernel_launch<5, 512, 5>(tb, tb.firstB[n], count, lds, s) : edt_band_kernel_launch<5, 512, 8>(tb, tb.firstB[n], count, lds, s);
+    else e = (cmax <= 640) ? edt_band_kernel_launch<2, 256, 5>(tb, tb.firstB[n], count, lds, s) : edt_band_kernel_launch<2, 256, 8>(tb, tb.firstB[n], count, lds, s);
     if (e != hipSuccess) return e;
     if (sh.waves == 8) edt_columns8_list_launch<8>(t, ls, tb.list, sh.lds_cols, s);
     else edt_columns8_list_launch<4>(t, ls, tb.list, sh.lds_cols, s);

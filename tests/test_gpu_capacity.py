@@ -69,3 +69,16 @@ def test_suite_subset_on_sparse_texel_slabs():
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_compact_now.py", "tests/test_gpu_frames.py",
                         "tests/test_gpu_parity.py", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize("env_kv", [("DVO_EDT_BAND_T", "5"), ("DVO_EDT_BAND_T", "2"), ("DVO_EDT_FUSED", "0")],
+                         ids=["band-T5-512-threads", "band-T2-256-threads", "three-pass-stage"])
+def test_frame_suites_on_every_shape_of_the_distance_transform_stage(env_kv):
+    """round 6: the stage that turns edge masks into compact now levels has three forms -- the band kernel with five tile rows per
+    512-thread workgroup (large batches), with two per 256 threads (small batches, the default of these tests) and the three-pass stage
+    of rounds 3-5 (columns, rows, rank pack: wide or tall images, and the images on the band stage's list).  The compact-now and frame
+    suites with each of them forced -- in a child process, because the choice is read once per process."""
+    env = dict(os.environ, **{env_kv[0]: env_kv[1]})
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_compact_now.py", "tests/test_gpu_frames.py",
+                        "tests/test_gpu_sparse_scenes.py", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
