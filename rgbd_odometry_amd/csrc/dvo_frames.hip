@@ -625,6 +625,72 @@ DVO_DEV void canny_final4_body(const int bx, const int gx, const int by, const u
     }
 }
 
+/* round 6: the same two passes, SIXTEEN pixels per thread (one 16-byte load; images whose pixel count is a multiple of sixteen).
+ * The four-pixel forms issued one dword load per thread and took 84 + 144 us per 256 four-level 640x480 frames -- 1.4 TB/s for
+ * passes that move 1 and 2 bytes per pixel. */
+DVO_DEV void canny_flag16_body(const int bx, const int gx, const int by, const unsigned char *__restrict__ cand, size_t n, int *__restrict__ label, unsigned char *__restrict__ flag) {
+    cand += (size_t)by * n; label += (size_t)by * n; flag += (size_t)by * n;
+    const uint4 *cand16 = reinterpret_cast<const uint4 *>(cand);
+    for (size_t q = (size_t)bx * blockDim.x + threadIdx.x; q < n / 16; q += (size_t)gx * blockDim.x) {
+        const uint4 v = cand16[q];
+        const unsigned ws[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            unsigned w = ws[j];
+            if (!(w & (0x01010101u * CAND_ROOT))) continue;
+            for (int k = 0; w; k++, w >>= 8) {
+                const unsigned c = w & 0xffu;
+                if (!(c & CAND_ROOT)) continue; /* tile-local roots speak for their components */
+                const int p = (int)(16 * q) + 4 * j + k;
+                const int r = uf_find(label, p);
+                label[p] = r;                   /* racing writers only ever store ancestors: find() stays correct */
+                if ((c & CAND_KIND) == CAND_SURE) flag[r] = 1;
+            }
+        }
+    }
+}
+DVO_DEV void canny_final16_body(const int bx, const int gx, const int by, const unsigned char *__restrict__ cand, const int *__restrict__ label,
+                                const unsigned char *__restrict__ flag, size_t n, unsigned char *__restrict__ edge, size_t edge_stride) {
+    cand += (size_t)by * n; label += (size_t)by * n; flag += (size_t)by * n;
+    edge += (size_t)by * edge_stride;
+    const uint4 *cand16 = reinterpret_cast<const uint4 *>(cand);
+    uint4 *edge16 = reinterpret_cast<uint4 *>(edge);
+    for (size_t q = (size_t)bx * blockDim.x + threadIdx.x; q < n / 16; q += (size_t)gx * blockDim.x) {
+        const uint4 v = cand16[q];
+        const unsigned ws[4] = {v.x, v.y, v.z, v.w};
+        unsigned o[4], weak = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned w = ws[j];
+            o[j] = ((w >> 1) & ~w & 0x01010101u) * 0xffu;          /* kind 2: surely an edge */
+            const unsigned t = w & ~(w >> 1) & 0x01010101u;         /* kind 1: ask the component */
+            weak |= ((t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xfu) << (4 * j);
+        }
+        if (weak) {
+            /* After the flag pass a candidate's label is its tile-local root and THAT pixel's label the root of the whole component:
+             * the answer is flag[label[label[p]]], three loads deep for every weak candidate of the thread AT ONCE (the loop of the
+             * four-pixel form walked the positions one after the other: a wave paid a dependent chain per position that held a weak
+             * candidate in any of its lanes). */
+            const int p0 = (int)(16 * q);
+            int a[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) a[i] = label[((weak >> i) & 1u) ? p0 + i : p0];
+#pragma unroll
+            for (int i = 0; i < 16; i++) a[i] = label[((weak >> i) & 1u) ? a[i] : p0];
+            unsigned e = 0u;
+#pragma unroll
+            for (int i = 0; i < 16; i++) e |= (unsigned)(flag[((weak >> i) & 1u) ? a[i] : p0] != 0) << i;
+            e &= weak;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned b4 = (e >> (4 * j)) & 0xfu;
+                o[j] |= ((b4 & 1u) | ((b4 & 2u) << 7) | ((b4 & 4u) << 14) | ((b4 & 8u) << 21)) * 0xffu;
+            }
+        }
+        edge16[q] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 canny_tile_kernel(const unsigned char *__restrict__ grey, size_t stride, int rows, int cols, int tiles_y, int low, int high,
                   unsigned char *__restrict__ cand, unsigned char *__restrict__ flag, int *__restrict__ label) {
@@ -678,6 +744,16 @@ __global__ void __launch_bounds__(256) canny_final4_levels_kernel(const CannyLev
     const int l = level_of_block(t.first, t.n, blockIdx.x);
     canny_final4_body((int)(blockIdx.x - t.first[l]), (int)(t.first[l + 1] - t.first[l]), blockIdx.y, t.cand[l], t.label[l], t.flag[l],
                       (size_t)t.rows[l] * t.cols[l], t.edge[l], t.edge_stride[l]);
+}
+
+__global__ void __launch_bounds__(256) canny_flag16_levels_kernel(const CannyLevels t) {
+    const int l = level_of_block(t.first, t.n, blockIdx.x);
+    canny_flag16_body((int)(blockIdx.x - t.first[l]), (int)(t.first[l + 1] - t.first[l]), blockIdx.y, t.cand[l], (size_t)t.rows[l] * t.cols[l], t.label[l], t.flag[l]);
+}
+__global__ void __launch_bounds__(256) canny_final16_levels_kernel(const CannyLevels t) {
+    const int l = level_of_block(t.first, t.n, blockIdx.x);
+    canny_final16_body((int)(blockIdx.x - t.first[l]), (int)(t.first[l + 1] - t.first[l]), blockIdx.y, t.cand[l], t.label[l], t.flag[l],
+                       (size_t)t.rows[l] * t.cols[l], t.edge[l], t.edge_stride[l]);
 }
 
 /* number of edge pixels of one image (inspection only: kept out of the per-frame pipeline, thousands of
@@ -753,6 +829,17 @@ hipError_t launch_canny_levels(int n, const int *rows, const int *cols, const un
     hipLaunchKernelGGL(canny_tile_levels_kernel, dim3(g, count), blk, 0, s, t);
     g = prefix([&](int l) { const int nb = ((rows[l] - 1) / CT_Y) * cols[l] + ((cols[l] - 1) / CT_X) * rows[l]; return nb > 0 ? grid_x((size_t)nb) : 0u; });
     if (g) hipLaunchKernelGGL(canny_border_levels_kernel, dim3(g, count), blk, 0, s, t);
+    bool wide = true;                                          /* sixteen pixels per thread where every level allows it */
+    for (int l = 0; l < n; l++) {
+        const size_t px = (size_t)rows[l] * cols[l];
+        wide = wide && (px & 15) == 0 && (edge_stride[l] & 15) == 0 && (reinterpret_cast<size_t>(edge[l]) & 15) == 0 && (reinterpret_cast<size_t>(t.cand[l]) & 15) == 0;
+    }
+    if (wide) {
+        g = prefix([&](int l) { return grid_x((size_t)rows[l] * cols[l] / 16); });
+        hipLaunchKernelGGL(canny_flag16_levels_kernel, dim3(g, count), blk, 0, s, t);
+        hipLaunchKernelGGL(canny_final16_levels_kernel, dim3(g, count), blk, 0, s, t);
+        return hipGetLastError();
+    }
     g = prefix([&](int l) { return grid_x((size_t)rows[l] * cols[l] / 4); });
     hipLaunchKernelGGL(canny_flag4_levels_kernel, dim3(g, count), blk, 0, s, t);
     hipLaunchKernelGGL(canny_final4_levels_kernel, dim3(g, count), blk, 0, s, t);
