@@ -264,6 +264,11 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256) ? ((NI <= 5) ? 5 : 4
         if (v < EB_D2_END) return eb_rank_global(v);
         return (unsigned)EB_NANR;
     };
+    /* the ranks of a dword's two squared distances; fast: both below EB_DIRECT (one table look-up each, no branch) */
+    auto ranks2_fast = [&](unsigned w) -> unsigned {
+        const edt_us2 c = __builtin_elementwise_min(edt_as_us2(w), edt_as_us2((unsigned)(EB_DIRECT - 1) * 0x00010001u));
+        return (unsigned)lrank[c.x] | ((unsigned)lrank[c.y] << 16);
+    };
     auto ranks2 = [&](unsigned w) -> unsigned {
         const unsigned v0 = w & 0xffffu, v1 = w >> 16;
         return rank_of(v0) | (rank_of(v1) << 16);
@@ -309,13 +314,15 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256) ? ((NI <= 5) ? 5 : 4
 #ifdef DVO_EDT_STAMPS
         acc_t[6] += (unsigned long long)trip;
 #endif
+        unsigned mi;                                                /* the largest of the item's eight squared distances */
         {
             const edt_us2 m4 = __builtin_elementwise_max(__builtin_elementwise_max(edt_as_us2(best.x), edt_as_us2(best.y)), __builtin_elementwise_max(edt_as_us2(best.z), edt_as_us2(best.w)));
-            const unsigned m = (unsigned)m4.x > (unsigned)m4.y ? (unsigned)m4.x : (unsigned)m4.y;
-            mx = m > mx ? m : mx;
-            far = far || m >= EB_D2_END;
+            mi = (unsigned)m4.x > (unsigned)m4.y ? (unsigned)m4.x : (unsigned)m4.y;
+            mx = mi > mx ? mi : mx;
+            far = far || mi >= EB_D2_END;
         }
-        res[it] = eb_mk4(ranks2(best.x), ranks2(best.y), ranks2(best.z), ranks2(best.w));
+        res[it] = eb_mk4(ranks2_fast(best.x), ranks2_fast(best.y), ranks2_fast(best.z), ranks2_fast(best.w));
+        if (mi >= (unsigned)EB_DIRECT) res[it] = eb_mk4(ranks2(best.x), ranks2(best.y), ranks2(best.z), ranks2(best.w));      /* rare: far from every edge */
         EDT_T(t_s2);
         EDT_ACC(2, t_s1, t_s2);
     }
@@ -342,33 +349,39 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256) ? ((NI <= 5) ? 5 : 4
     bool part = false;
     {
         typedef __attribute__((address_space(3))) const unsigned lds_cu;
-        const int npairs = ntc * (16 * T);
-        for (int s2 = tid; s2 < npairs; s2 += THREADS) {
-            const int tc = s2 / (16 * T), rem = s2 - tc * (16 * T);
-            const int tyl = rem >> 4, xl = (rem >> 2) & 3, sp = rem & 3;
-            if (tyl >= nty) continue;
-            const int ty = ty0 + tyl, xx = tc * 4 + xl;
-            const int ys0 = ty * DVO_P4_ROWS + 2 * sp - 1;         /* image rows of the two words (-1 / rows: the reflected copies) */
-            unsigned word0 = 0u, word1 = 0u;
-            if (xx < cols && ys0 <= rows) {
-                lds_cu *pc = (lds_cu *)(size_t)(tq_lds + (unsigned)((EB_PAD + xx) * CB + (tyl * 3 + sp) * 4));
-                const unsigned C = pc[0], R = pc[CD], L = pc[-CD];
-                const edt_us2 dR = edt_as_us2(R) - edt_as_us2(C), dL = edt_as_us2(L) - edt_as_us2(C);
-                /* a step fits its signed byte iff step + 128 < 256 */
-                const unsigned bad = (edt_as_u32(dR + edt_as_us2(0x00800080u)) | edt_as_u32(dL + edt_as_us2(0x00800080u))) & 0xff00ff00u;
-                const unsigned steps = __builtin_amdgcn_perm(edt_as_u32(dL), edt_as_u32(dR), 0x06020400u);      /* bytes: dL.hi, dR.hi, dL.lo, dR.lo */
-                const bool in0 = sp >= 1 && ys0 < rows;            /* stored row 2 sp: interior unless it is the apron above (sp = 0) */
-                const bool in1 = sp <= 2 && ys0 + 1 < rows;        /* stored row 2 sp + 1: interior unless it is the apron below (sp = 3) */
-                unsigned c0 = C & 0xffffu, c1 = C >> 16;
-                unsigned st0 = in0 ? (steps & 0xffffu) : 0u, st1 = in1 ? (steps >> 16) : 0u;
-                if (in0 && (bad & 0x0000ff00u)) { c0 = EB_NANR; st0 = 0u; }     /* this pixel is looked up in the 16-byte texels */
-                if (in1 && (bad & 0xff000000u)) { c1 = EB_NANR; st1 = 0u; }
-                word0 = (c0 << 3) | (st0 << 16);
-                if (ys0 + 1 > rows) c1 = 0u;                       /* no such stored row: the word stays 0 */
-                else word1 = (c1 << 3) | (st1 << 16);
-                if (c0 == (unsigned)EB_NANR || c1 == (unsigned)EB_NANR) part = true;
+        /* a thread's place among the 16 T word pairs of a tile column is fixed; the THREADS / (16 T) groups walk the tile columns */
+        constexpr int PL = 16 * T, G = THREADS / PL;
+        const int grp = tid / PL, rem = tid - grp * PL;
+        const int tyl = rem >> 4, xl = (rem >> 2) & 3, sp = rem & 3;
+        const int ty = ty0 + tyl;
+        const int ys0 = ty * DVO_P4_ROWS + 2 * sp - 1;             /* image rows of the two words (-1 / rows: the reflected copies) */
+        const bool in0 = sp >= 1 && ys0 < rows;                    /* stored row 2 sp: interior unless it is the apron above (sp = 0) */
+        const bool in1 = sp <= 2 && ys0 + 1 < rows;                /* stored row 2 sp + 1: interior unless it is the apron below (sp = 3) */
+        const unsigned keep = (in0 ? 0x0000ffffu : 0u) | (in1 ? 0xffff0000u : 0u);      /* the steps of interior words */
+        const unsigned cmask = (ys0 + 1 <= rows) ? 0xffffffffu : 0x0000ffffu;         /* no stored row beyond `rows`: that word stays 0 */
+        if (grp < G && tyl < nty) {
+            unsigned lds_a = tq_lds + (unsigned)((EB_PAD + xl) * CB + (tyl * 3 + sp) * 4) + (unsigned)(grp * 4 * CB);
+            unsigned *dst = p4 + 32u + ((size_t)grp * tpc + ty) * 32u + (xl * 8 + 2 * sp);
+            for (int tc = grp; tc < ntc; tc += G, lds_a += (unsigned)(G * 4 * CB), dst += (size_t)G * tpc * 32u) {
+                unsigned word0 = 0u, word1 = 0u;
+                if (ys0 <= rows && tc * 4 + xl < cols) {       /* else: no such stored rows / columns, the words stay 0 */
+                    lds_cu *pc = (lds_cu *)(size_t)lds_a;
+                    const unsigned C = pc[0] & cmask, R = pc[CD], L = pc[-CD];
+                    const edt_us2 dR = edt_as_us2(R) - edt_as_us2(C), dL = edt_as_us2(L) - edt_as_us2(C);
+                    /* a step fits its signed byte iff step + 128 < 256 */
+                    const unsigned bad = (edt_as_u32(dR + edt_as_us2(0x00800080u)) | edt_as_u32(dL + edt_as_us2(0x00800080u))) & 0xff00ff00u & keep;
+                    unsigned steps = __builtin_amdgcn_perm(edt_as_u32(dL), edt_as_u32(dR), 0x06020400u) & keep;      /* bytes: dL.hi, dR.hi, dL.lo, dR.lo */
+                    unsigned c0 = C & 0xffffu, c1 = C >> 16;
+                    if (bad) {                                   /* rare: this pixel is looked up in the 16-byte texels */
+                        if (bad & 0x0000ff00u) { c0 = EB_NANR; steps &= 0xffff0000u; }
+                        if (bad & 0xff000000u) { c1 = EB_NANR; steps &= 0x0000ffffu; }
+                        part = true;
+                    }
+                    word0 = (c0 << 3) | (steps << 16);
+                    word1 = (c1 << 3) | (steps & 0xffff0000u);
+                }
+                *reinterpret_cast<uint2 *>(dst) = make_uint2(word0, word1);
             }
-            *reinterpret_cast<uint2 *>(p4 + 32u + ((size_t)tc * tpc + ty) * 32u + (xl * 8 + 2 * sp)) = make_uint2(word0, word1);
         }
     }
     EDT_T(t_words);
