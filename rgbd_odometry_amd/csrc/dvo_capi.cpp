@@ -202,14 +202,16 @@ int sparse_map_compact_failures(dvo_ctx *c, int level, int first, int count, hip
     return DVO_OK;
 }
 /* pal_n of the pairs whose compact form the host has not looked at yet (one copy + one wait per run of such pairs) */
-int refresh_p4_known(dvo_ctx *c, int level, int first, int count) {
+int refresh_p4_known(dvo_ctx *c, int level, int first, int count, bool skip_native) {
     Level &L = c->lv[level];
     if (!L.d_pal_n || L.pal_built.empty()) return DVO_OK;
     if (L.p4_known.empty()) { L.p4_known.assign(c->n_pairs, Level::P4_UNKNOWN); L.p4_fresh.assign(c->n_pairs, 0); }
+    if (L.p4_native.empty()) L.p4_native.assign(c->n_pairs, 0);
+    auto unknown = [&](int p) { return L.pal_built[p] && L.p4_known[p] == Level::P4_UNKNOWN && !(skip_native && L.p4_native[p]); };
     for (int p = first; p < first + count; ) {
-        if (!L.pal_built[p] || L.p4_known[p] != Level::P4_UNKNOWN) { p++; continue; }
+        if (!unknown(p)) { p++; continue; }
         int q = p;
-        while (q < first + count && L.pal_built[q] && L.p4_known[q] == Level::P4_UNKNOWN) q++;
+        while (q < first + count && unknown(q)) q++;
         std::vector<int> pn((size_t)(q - p));
         HIPCHK(c, hipMemcpyAsync(pn.data(), L.d_pal_n + p, sizeof(int) * (size_t)(q - p), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, stream_wait(c->stream));
@@ -232,7 +234,7 @@ int ensure_texels(dvo_ctx *c, int level, int rows, int cols) {
         free_texels(c, L);
         std::fill(L.have_now.begin(), L.have_now.end(), 0);
         if (L.p4) { (void)hipFree(L.p4); (void)hipFree(L.pal); (void)hipFree(L.d_pal_n); L.p4 = nullptr; L.pal = nullptr; L.d_pal_n = nullptr; }
-        L.pal_built.clear(); L.now_uses.clear(); L.tex16_stale.clear(); L.p4_known.clear(); L.p4_fresh.clear();
+        L.pal_built.clear(); L.now_uses.clear(); L.tex16_stale.clear(); L.p4_known.clear(); L.p4_fresh.clear(); L.p4_native.clear();
     }
 
     L.rows = rows; L.cols = cols;
@@ -269,6 +271,7 @@ static void level_flags(dvo_ctx *c, Level &L) {
     if (L.tex16_stale.empty()) L.tex16_stale.assign(c->n_pairs, 0);
     if (L.have_now.empty()) L.have_now.assign(c->n_pairs, 0);
     if (L.p4_known.empty()) { L.p4_known.assign(c->n_pairs, Level::P4_UNKNOWN); L.p4_fresh.assign(c->n_pairs, 0); }
+    if (L.p4_native.empty()) L.p4_native.assign(c->n_pairs, 0);
 }
 
 bool native_compact_wanted(const dvo_ctx *c) { return c->prm.engine_variant != 4 && compact_now_policy() != 2; }
@@ -304,6 +307,7 @@ int now_written_compact(dvo_ctx *c, int level, int first_pair, int count) {
     level_flags(c, L);
     for (int p = first_pair; p < first_pair + count; p++) {
         L.have_now[p] = 1; L.now_uses[p] = 0; L.pal_built[p] = 1;
+        L.p4_native[p] = 1;
         if (L.p4_fresh[p]) L.p4_fresh[p] = 0;               /* pal_n of THIS write was read back (sparse slab): known */
         else L.p4_known[p] = Level::P4_UNKNOWN;
         L.tex16_stale[p] = (L.p4_known[p] == Level::P4_REFUSED || L.p4_known[p] == Level::P4_PARTIAL) ? 0 : 1;      /* such an image got its texels from the same launch */
@@ -329,7 +333,7 @@ int ensure_tex16(dvo_ctx *c, int level, int first_pair, int count) {
 int now_written(dvo_ctx *c, int level, int first_pair, int count) {
     Level &L = c->lv[level];
     level_flags(c, L);
-    for (int p = first_pair; p < first_pair + count; p++) { L.tex16_stale[p] = 0; L.p4_known[p] = Level::P4_UNKNOWN; L.p4_fresh[p] = 0; }
+    for (int p = first_pair; p < first_pair + count; p++) { L.tex16_stale[p] = 0; L.p4_known[p] = Level::P4_UNKNOWN; L.p4_fresh[p] = 0; L.p4_native[p] = 0; }
     for (int p = first_pair; p < first_pair + count; ) {
         L.have_now[p] = 1; L.now_uses[p] = 0;
         if (!L.pal_built[p]) { p++; continue; }
@@ -365,7 +369,7 @@ int build_compact_now(dvo_ctx *c, int level, int first_pair, int count, bool onl
             }
             HIPCHK(c, launch_palette_build(L.tex, L.tex_stride, L.rows, L.cols, L.p4, L.p4_stride, L.pal, L.d_pal_n, b, nb, c->pal_work, c->stream));
         }
-        for (int i = p; i < q; i++) { L.pal_built[i] = 1; L.p4_known[i] = Level::P4_UNKNOWN; }      /* the builder may have refused (pal_n < 0) */
+        for (int i = p; i < q; i++) { L.pal_built[i] = 1; L.p4_known[i] = Level::P4_UNKNOWN; if (!L.p4_native.empty()) L.p4_native[i] = 0; }      /* the builder may have refused (pal_n < 0) */
         p = q;
     }
     return DVO_OK;
@@ -541,7 +545,7 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
                                    (2 * n_pairs >= 3 * c->n_cu || n_pairs > c->n_cu);
         for (int l = 0; l < n_levels && shape_depends && all_p4; l++) {
             if (sc.iters[l] <= 0) continue;
-            if ((rc = refresh_p4_known(c, l, first_pair, n_pairs))) return rc;
+            if ((rc = refresh_p4_known(c, l, first_pair, n_pairs, true))) return rc;      /* natively written forms are never refused: no read-back, no wait */
             const Level &L = c->lv[l];
             int refused = 0;
             for (int p = first_pair; p < first_pair + n_pairs; p++) refused += (L.p4_known[p] == Level::P4_REFUSED);
@@ -1268,6 +1272,7 @@ int dvo_replicate_pairs(dvo_ctx *c, int n_src, int dst_first, int dst_count) {
                     L.pal_built[p] = L.pal_built[src];
                     L.tex16_stale[p] = L.tex16_stale[src];
                     L.p4_known[p] = L.p4_known[src];
+                    if (!L.p4_native.empty()) L.p4_native[p] = L.p4_native[src];
                 }
             }
         }
@@ -1579,7 +1584,7 @@ int ensure_step_buffers(dvo_ctx *c) {
     /* all or nothing: a failed allocation must not leave the first buffer set and the others null */
     char *st = nullptr; double *acc = nullptr; unsigned *tk = nullptr;
     if (hipMalloc((void **)&st, 2 * pose_state_bytes()) != hipSuccess || hipMalloc((void **)&acc, sizeof(double) * 2 * DVO_NACC_PAD) != hipSuccess ||
-        hipMalloc((void **)&tk, 2 * sizeof(unsigned)) != hipSuccess) {      /* [0] arrival ticket (launches with H), [1] launch sequence number */
+        hipMalloc((void **)&tk, 4 * sizeof(unsigned)) != hipSuccess) {      /* [0] arrival ticket (launches with H), [1] launch sequence number, [2] a launch lost a workgroup's rows */
         (void)hipGetLastError();
         if (st) (void)hipFree(st);
         if (acc) (void)hipFree(acc);
@@ -1591,9 +1596,18 @@ int ensure_step_buffers(dvo_ctx *c) {
     if (c->d_step_ticket) (void)hipFree(c->d_step_ticket);
     c->d_step_state = st; c->d_step_acc = acc; c->d_step_ticket = tk;
     HIPCHK(c, hipMemsetAsync(c->d_step_acc, 0, sizeof(double) * 2 * DVO_NACC_PAD, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_step_ticket, 0, 2 * sizeof(unsigned), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_step_ticket, 0, 4 * sizeof(unsigned), c->stream));
     HIPCHK(c, stream_wait(c->stream));
     return DVO_OK;
+}
+
+/* a step launch whose workgroup 0 never saw the tagged rows of another workgroup leaves NaN sums and this word (dvo_tiled_step.h) */
+int check_step_lost(dvo_ctx *c) {
+    unsigned lost = 0;
+    std::memcpy(&lost, c->h_pose + 12, sizeof(lost));
+    if (!lost) return DVO_OK;
+    (void)hipMemsetAsync(c->d_step_ticket + 2, 0, sizeof(unsigned), c->stream);
+    return fail(c, DVO_ERR_HIP, "wide / tiled schedule: a step launch never received the sums of one of its workgroups; the results of that alignment are void");
 }
 
 static void shard_of(int n, int rank, int world, int &first, int &count) {      /* distributed.py::shard_range, dvo_tiled_shard */
@@ -1709,7 +1723,7 @@ int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters,
         if (sc.iters[l] > 0 && ((rc = check_ready(c, pair, l)) || (rc = ensure_tex16(c, l, pair, 1)))) return rc;
     if ((rc = ensure_outputs(c, sc))) return rc;
     if ((rc = ensure_step_buffers(c))) return rc;
-    if (!c->h_pose) HIPCHK(c, hipHostMalloc((void **)&c->h_pose, sizeof(double) * 12, hipHostMallocDefault));
+    if (!c->h_pose) HIPCHK(c, hipHostMalloc((void **)&c->h_pose, sizeof(double) * 13, hipHostMallocDefault));      /* [12]: the step launches' error word */
     double *h = c->h_pose;
     std::memcpy(h, R, sizeof(double) * 9);
     std::memcpy(h + 9, t, sizeof(double) * 3);
@@ -1728,6 +1742,7 @@ int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters,
         rec(hipMemcpyAsync(d_pose, h, sizeof(double) * 12, hipMemcpyHostToDevice, c->stream));
         rec(enqueue_step_schedule(c, sc, pair, flags, d_pose, 0, 1, nullptr));
         rec(hipMemcpyAsync(h, d_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, c->stream));
+        rec(hipMemcpyAsync(h + 12, c->d_step_ticket + 2, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         if (!no_graph) {
             hipGraph_t graph = nullptr;
             rec(hipStreamEndCapture(c->stream, &graph));
@@ -1739,6 +1754,7 @@ int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters,
     }
     if (!no_graph) HIPCHK(c, hipGraphLaunch(c->wide_exec, c->stream));
     HIPCHK(c, stream_wait(c->stream));
+    { const int lrc = dvo_host::check_step_lost(c); if (lrc) return lrc; }
     std::memcpy(R, h, sizeof(double) * 9);
     std::memcpy(t, h + 9, sizeof(double) * 3);
     stamp_outputs(c, sc, pair, 1);

@@ -155,7 +155,7 @@ int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters
         if (sc.iters[l] > 0 && ((rc = dvo_host::check_ready(c, pair, l)) || (rc = dvo_host::ensure_tex16(c, l, pair, 1)))) return rc;
     if ((rc = dvo_host::ensure_outputs(c, sc))) return rc;
     if ((rc = dvo_host::ensure_step_buffers(c))) return rc;
-    if (!c->h_pose) HIPCHK(c, hipHostMalloc((void **)&c->h_pose, sizeof(double) * 12, hipHostMallocDefault));
+    if (!c->h_pose) HIPCHK(c, hipHostMalloc((void **)&c->h_pose, sizeof(double) * 13, hipHostMallocDefault));      /* [12]: the step launches' error word */
     double *h = c->h_pose;
     std::memcpy(h, R, sizeof(double) * 9);
     std::memcpy(h + 9, t, sizeof(double) * 3);
@@ -175,6 +175,7 @@ int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters
         hipError_t e = hipMemcpyAsync(d_pose, h, sizeof(double) * 12, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = dvo_host::enqueue_step_schedule(c, sc, pair, flags, d_pose, T->rank, T->world, all_reduce);
         if (e == hipSuccess) e = hipMemcpyAsync(h, d_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h + 12, c->d_step_ticket + 2, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
         return e;
     };
     auto nccl_fail = [&]() { return fail(c, DVO_ERR_HIP, std::string("ncclAllReduce: ") + (T->errstr ? T->errstr(nccl_rc) : "error " + std::to_string(nccl_rc))); };
@@ -215,6 +216,7 @@ int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters
         HIPCHK(c, hipGraphLaunch(c->tiled_exec, c->stream));
     }
     HIPCHK(c, stream_wait(c->stream));
+    { const int lrc = dvo_host::check_step_lost(c); if (lrc) return lrc; }
     std::memcpy(R, h, sizeof(double) * 9);
     std::memcpy(t, h + 9, sizeof(double) * 3);
     dvo_host::stamp_outputs(c, sc, pair, 1);

@@ -67,6 +67,10 @@ struct Level {
      * destinations without texels -- on a sparse slab without memory behind them). */
     enum : char { P4_UNKNOWN = 0, P4_OK = 1, P4_REFUSED = 2, P4_PARTIAL = 3 /* a partial compact form (dvo_palette.h): read as the compact form, 16-byte texels real too */ };
     std::vector<char> p4_known;
+    /* set where the engine's own distance-transform stage wrote the pair's compact form (now_written_compact): such a form is complete or
+     * PARTIAL, never refused (dvo_frames.hip) -- what dvo_enqueue's choice of launch shape asks about -- so that choice needs no read-back
+     * and no wait on the stream for these pairs (one host sync per level per step of a frames -> align pipeline otherwise) */
+    std::vector<char> p4_native;
     std::vector<char> p4_fresh;     /* set where sparse_map_compact_failures has just read pal_n; consumed by now_written_compact */
 };
 
@@ -259,13 +263,14 @@ void free_texels(dvo_ctx *c, Level &L);
 /* sparse slabs, after a distance-transform launch over pairs [first, first + count) that ran WITHOUT texel output: waits for it,
  * reads the palette sizes back and maps the texels of the images the compact form could not hold; *n_failed = how many */
 int sparse_map_compact_failures(dvo_ctx *c, int level, int first, int count, hipStream_t stream, int *n_failed);
-int refresh_p4_known(dvo_ctx *c, int level, int first, int count);      /* reads pal_n back where the host does not know it yet */
+int refresh_p4_known(dvo_ctx *c, int level, int first, int count, bool skip_native = false);      /* reads pal_n back where the host does not know it yet (skip_native: only where a refusal is possible) */
 /* enqueues the level schedule of one pair as ONE launch per iteration on c->stream (dvo_kernels.hip: tiled_step_kernel): this
  * rank's contiguous share of every level's points (rank / world: dvo_tiled_shard's decomposition), `all_reduce` (may be empty:
  * one GPU) called on the 32 sums between two launches.  Pose in / out through d_pose (12 doubles on the device). */
 hipError_t enqueue_step_schedule(dvo_ctx *c, const dvo::Schedule &sc, int pair, int flags, double *d_pose, int rank, int world,
                                  const std::function<hipError_t(double *)> &all_reduce);
 int ensure_step_buffers(dvo_ctx *c);
+int check_step_lost(dvo_ctx *c);      /* after the wait of a wide / tiled alignment: DVO_ERR_HIP if a step launch lost a workgroup's rows */
 unsigned long long step_schedule_signature(dvo_ctx *c, const dvo::Schedule &sc, int pair, int n_levels, int flags, int rank, int world);
 /* the reference lists of pairs [first, first + n) of a level were (re)written: bumps points_gen and the pairs' list stamps;
  * rows > 0: the rows of the image their 4-byte twins were encoded against (0: no valid 4-byte twin) */

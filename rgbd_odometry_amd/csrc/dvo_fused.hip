@@ -856,7 +856,8 @@ DVO_DEV unsigned long long stamp_now2() {
 #endif
 
 /* WITH_H: DVO_FLAG_NORMAL_MATRIX on the packed kernel (round 5): every lane also accumulates the 21 entries of H = sum w J J^T in
- * double (42 more registers: the 512-thread shape only -- the 256-thread shape has 14 to spare), the waves reduce them in three
+ * double (42 more registers: both one-workgroup-per-pair shapes carry them since round 5, with loop-invariant values in scratch --
+ * tests/test_kernel_registers.py), the waves reduce them in three
  * passes of the 8-value DPP reduce-scatter, and wave 2 -- idle during the update -- adds the waves' rows and stores the iterate's H */
 template <int BLOCK, bool TEAM, bool WITH_H = false>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK == 256 ? DVO_WPE256 : 1, 8)))

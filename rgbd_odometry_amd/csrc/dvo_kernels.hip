@@ -825,7 +825,11 @@ int tiled_step_blocks(int n_points, int n_cu) {
     if (b < 1) b = 1;
     if (b > 1) b += 1;                  /* workgroup 0 keeps the state and takes no points once there are several (tiled_step_kernel) */
     if (b > n_cu) b = n_cu;             /* one workgroup per CU: the hand-off form of the tail is measured for that */
-    if (b > 1024) b = 1024;             /* rows of the partials buffer */
+    /* the partials buffer (dvo_ctx.h: d_scratch) holds 1024 x DVO_NACC_PAD doubles before the sums: a workgroup's tagged rows are
+     * 16-byte records, 32 of them with DVO_FLAG_NORMAL_MATRIX -- 512 workgroups' worth (the old bound of 1024 was that of
+     * the 8-byte rows of round 4) */
+    static_assert(1024 * DVO_NACC_PAD * sizeof(double) >= 512 * 32 * 16, "tagged rows of 512 workgroups fit the partials buffer");
+    if (b > 512) b = 512;
     return b;
 }
 hipError_t launch_tiled_step(const LevelSlab &L, int pair, int level, const Intrinsics &K, const DevParams &prm, const void *st_in,

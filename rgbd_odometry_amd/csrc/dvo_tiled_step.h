@@ -154,7 +154,10 @@ DVO_DEV void tiled_step_body(TiledStepLds &m, const PoseState *st_in, PoseState 
 #pragma unroll
             for (int q = 0; q < 4; q++) sum += valid[q] ? step_rec_value(r[q]) : 0.0;      /* fixed order: workgroups ascending */
         }
-        if (lost) sum = __longlong_as_double(0x7ff8000000000000ll);
+        if (lost) {                                                         /* NaN sums AND an error word the host checks: DVO_ERR_HIP, not DVO_OK with NaN poses */
+            sum = __longlong_as_double(0x7ff8000000000000ll);
+            ticket[2] = 1u;
+        }
         double *flat = &part[0][0];                                         /* (512 / ROW) chains x ROW sums */
         static_assert(sizeof(m.part) >= sizeof(double) * DVO_STEP_THREADS, "one partial sum per thread");
         flat[tid] = sum;
