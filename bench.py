@@ -363,8 +363,9 @@ def energy_ulps(e_gpu, e_ref):
     return int(a.size), int(neq.sum()), int(d[neq].max())
 
 
-PARITY_TOLERANCE = ("poses 1e-5 rad / 1e-4 m; best index and visible ratio equal; energies bit-equal up to the float rounding of the double sum "
-                    "whose order of additions differs from the oracle's (at most 1 ulp: energies_differing / max_energy_ulp count them)")
+PARITY_TOLERANCE = ("poses 1e-5 rad / 1e-4 m; best index and visible ratio equal; energies bit-equal -- strictly when fewer than 10 000 are compared; "
+                    "beyond that at most 1e-4 of them may differ by one float ulp (the double sum's order of additions differs from the oracle's: "
+                    "energies_differing / max_energy_ulp count them)")
 
 
 def sparse_scenes_leg(stream, quick=False):
@@ -749,7 +750,12 @@ def main_batch(args):
             "energies_bit_equal": bool(bit_equal), "energies_compared": n_e, "energies_differing": n_diff, "max_energy_ulp": max_ulp,
             "best_index_and_ratio_equal": bool(decisions_equal), "replicas_bit_identical": bool(replicas_equal),
             "tolerance": PARITY_TOLERANCE,
-            "pass": bool(decisions_equal and replicas_equal and max_ulp <= 1 and worst_r <= 1e-5 and worst_t <= 1e-4),
+            # the gate is STRICT again wherever the energies compared are few enough that a one-ulp straddle of the double
+            # sum (2 distinct energies in 102 400: DESIGN.md section 2) is not expected: a differing energy among fewer than 10 000
+            # fails the run.  Larger comparisons (--batch sweeps with thousands of distinct scenes) get the explicit, counted
+            # allowance energies_differing / energies_compared <= 1e-4, each of at most one ulp.
+            "pass": bool(decisions_equal and replicas_equal and worst_r <= 1e-5 and worst_t <= 1e-4 and
+                         (bit_equal or (n_e >= 10000 and max_ulp <= 1 and n_diff <= 1e-4 * n_e))),
         }
     # transparency legs, never `value`; default launch only
     default_launch = default_knobs and not total_pairs
@@ -949,7 +955,7 @@ def main_tiled(args):
         out["parity_check"] = {"max_rot_err_rad": wr, "max_trans_err_m": wt, "energies_bit_equal": bool(bit_equal), "energies_compared": n_e,
                                "energies_differing": n_diff, "max_energy_ulp": max_ulp, "best_index_and_ratio_equal": bool(decisions_equal),
                                "final_outputs_bit_equal": fin, "tolerance": PARITY_TOLERANCE + "; final outputs bit-equal",
-                               "pass": bool(decisions_equal and max_ulp <= 1 and fin and wr <= 1e-5 and wt <= 1e-4)}
+                               "pass": bool(decisions_equal and bit_equal and fin and wr <= 1e-5 and wt <= 1e-4)}      # one pair, 50 energies: strict
     print(json.dumps(out), flush=True)
     ctx.tiled_detach(); ctx.close(); comm.close()
     if dist is not None:
