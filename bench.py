@@ -98,6 +98,9 @@ def parse_args():
                     help="install the now levels as caller-supplied float images (dvo_set_now_level: 16-byte texels; the generic "
                          "compact form only after 16 alignments or with --prepare) instead of through the engine's distance transform")
     ap.add_argument("--prepare", action="store_true", help="with --float-now-levels: dvo_now_prepare at set-up (round 2's headline)")
+    ap.add_argument("--float-ref-lists", action="store_true",
+                    help="install the reference points as caller-supplied 3xN float lists (dvo_set_ref_level, the literal drop-in of INTEGRATION.md) "
+                         "instead of edge + depth images; round 6: a list that verifies as an enlistRefEdgePts list gets its compact twin")
     ap.add_argument("--no-extra-legs", "--no-frames-leg", dest="no_extra_legs", action="store_true",
                     help="skip the extra (never `value`) measurements: 16-byte texels, camera frames in host memory -> poses out, ...")
     ap.add_argument("--ranks-share-gpu", action="store_true",
@@ -133,7 +136,9 @@ def build_batch(ctx, args, rank):
     t0 = time.perf_counter()
     for i, sc in enumerate(scenes):
         for l, L in enumerate(sc.levels):
-            ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols, pair=i)   # GPU enlistRefEdgePts
+            xyz, _ = ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols, pair=i)   # GPU enlistRefEdgePts
+            if args.float_ref_lists:      # the literal drop-in: the reference's 3xN float list (dvo_set_ref_level), after the now level's size is known
+                ctx.set_ref_level(l, xyz, pair=i)
             if args.float_now_levels:
                 ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols, pair=i)
             else:
@@ -451,9 +456,11 @@ def float_boundary_leg(args, iters, flags, stream, per_scene_bytes):
     ctx = DvoContext(B)
     try:
         ctx.set_intrinsics(*scenes[0].intrinsics)
+        ctx.set_direct_compact(False)                  # the first two measurements: the boundary as rounds 2-5 had it (16-byte texels first)
+        xyz_lists = {}
         for p in range(D):
             for l, L in enumerate(scenes[p].levels):
-                ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols, pair=p)
+                xyz_lists[(p, l)] = ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols, pair=p)[0]
                 ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols, pair=p)
         ctx.replicate_pairs(D)
         ctx.synchronize()
@@ -491,8 +498,22 @@ def float_boundary_leg(args, iters, flags, stream, per_scene_bytes):
         ctx.synchronize()
         build_us = 1e6 * (time.perf_counter() - t0) / B
         r4 = rate(8)
+        # round 6: the LITERAL drop-in of INTEGRATION.md -- the reference's 3xN float lists through dvo_set_ref_level
+        # and its three float images through dvo_set_now_level, nothing else -- as a batch context gets it by default: lists that verify
+        # as enlistRefEdgePts lists get their compact twin, exact distance transforms their compact form at installation
+        ctx.set_direct_compact(True)
+        for p in range(B):
+            for l, L in enumerate(scenes[p % D].levels):
+                ctx.set_ref_level(l, xyz_lists[(p % D, l)], pair=p)
+        install()
+        t0 = time.perf_counter()
+        install()
+        install_direct_us = 1e6 * (time.perf_counter() - t0) / B
+        lit = rate(8)
+        lit["install_us_per_pair_pcie_inclusive"] = install_direct_us
+        lit["launch_shape"] = ctx.last_launch_shape() if hasattr(ctx, "last_launch_shape") else None
         return {"pairs": B, "install_us_per_pair_pcie_inclusive": install_us, "on_16_byte_texels": r16,
-                "compact_build_us_per_pair": build_us, "on_compact_form": r4,
+                "compact_build_us_per_pair": build_us, "on_compact_form": r4, "literal_drop_in_float_lists_and_float_images": lit,
                 "break_even_alignments_per_now_level": (build_us * 1e-6) / max(1e-12, (1.0 / r16["aligns_per_s"] - 1.0 / r4["aligns_per_s"])),
                 "note": "never `value`.  Three float images per level from pageable host memory (12 B/pixel over PCIe) dominate this boundary: "
                         "installing a pair costs a hundred alignments.  The alignment starts on the 16-byte texels the installation "

@@ -279,7 +279,10 @@ bool native_compact_wanted(const dvo_ctx *c) { return c->prm.engine_variant != 4
  * environment (which wins) */
 static bool direct_compact_wanted(const dvo_ctx *c) {
     const char *e = getenv("DVO_DIRECT_COMPACT");
-    const bool on = e ? !strcmp(e, "on") : c->direct_compact != 0;
+    /* default (round 6): on for batch contexts (64 pairs and more: throughput is what they are for, and the packed kernel on the compact
+     * form is 1.7 x the 16-byte route), off for a single stream, whose alignment is latency-bound either way and whose frame would pay
+     * 0.16 ms more per installed pair; dvo_set_direct_compact(0 / 1) overrides */
+    const bool on = e ? !strcmp(e, "on") : (c->direct_compact < 0 ? c->n_pairs >= 64 : c->direct_compact != 0);
     return native_compact_wanted(c) && on;
 }
 /* the kernel addresses a pair's rank words with 32-bit byte offsets built from 24-bit multiplies (dvo_fused.hip, p4_byte_offset) */
@@ -988,9 +991,33 @@ static int set_ref_common(dvo_ctx *c, int pair, int level, const float *xyz, int
                              device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     L.hN[pair] = N;
     ref_list_written(c, level, pair, 1, 0);
-    L.compact_ok[pair] = 0;                                         /* arbitrary X, Y: no 8-byte form */
+    L.compact_ok[pair] = 0;                                         /* arbitrary X, Y: no 8-byte form ... */
     HIPCHK(c, hipMemsetAsync(L.d_pt4_ok + pair, 0, sizeof(int), c->stream));
     HIPCHK(c, hipMemcpyAsync(L.dN + pair, &L.hN[pair], sizeof(int), hipMemcpyHostToDevice, c->stream));
+    /* ... unless the list IS what enlistRefEdgePts (:224-264) makes of some edge map for these intrinsics -- the literal drop-in hands over
+     * exactly that (_ref_edge_3d[level]).  Round 6: every point's pixel is recovered and put through
+     * the enlist expression again; all points equal bit for bit -> the list gets its compact twin (the packed kernel then reads the caller's
+     * bits), any mismatch -> the one-point-per-lane kernel as before.  Costs one launch and one 4-byte read-back per call. */
+    static const bool recover_off = std::getenv("DVO_REF_RECOVER") && !strcmp(std::getenv("DVO_REF_RECOVER"), "off");
+    if (c->have_K && !recover_off && fused_uses_compact(c->prm.points_in_flight, c->prm.interpolate_dt)) {
+        if (!c->h_poses) HIPCHK(c, hipHostMalloc((void **)&c->h_poses, sizeof(double) * (12 * (size_t)c->n_pairs + 2), hipHostMallocDefault));
+        int *h_fail = reinterpret_cast<int *>(c->h_poses + 12 * (size_t)c->n_pairs) + 1;      /* pinned: the slot beside the team error word */
+        int *d_fail = L.d_pt4_ok + pair;                            /* a scratch word: zero now, rewritten by points4_build below or left zero */
+        HIPCHK(c, launch_points_recover_compact(dst, N, level, c->K, L.cpts + (size_t)pair * L.pt_cap, L.cidx + (size_t)pair * L.pt_cap, d_fail, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h_fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, stream_wait(c->stream));
+        const bool ok = *h_fail == 0;
+        if (!ok) HIPCHK(c, hipMemsetAsync(d_fail, 0, sizeof(int), c->stream));
+        if (ok) {
+            L.compact_ok[pair] = 1;
+            /* 4-byte points need the level's row count (their row field): known once the now level of this size has been installed */
+            if (L.rows > 0) {
+                HIPCHK(c, launch_points4_build(L.cpts, L.dN, L.pt_cap, L.rows, L.cpt4, L.chdr, L.d_pt4_ok, pair, 1, c->stream));
+                L.pt4_rows[pair] = L.rows;
+            }
+        }
+        return DVO_OK;
+    }
     if (!device_src) HIPCHK(c, stream_wait(c->stream));   /* host buffer is only borrowed */
     return DVO_OK;
 }

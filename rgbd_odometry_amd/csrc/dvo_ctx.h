@@ -139,7 +139,7 @@ struct dvo_ctx {
     int step_solo_mask = 0;              /* ... and those that ran as one launch of one workgroup (tiled_level_solo_kernel) */
     int step_pk_mask = 0;                /* levels of the last enqueued step schedule that ran tiled_step_pk_kernel (inspection) */
     double *h_pose = nullptr;       /* pinned: in/out pose of the graph's copy nodes */
-    int direct_compact = 0;         /* dvo_set_direct_compact: float now levels go to the compact form at installation */
+    int direct_compact = -1;        /* dvo_set_direct_compact: float now levels go to the compact form at installation (-1: auto, by batch size) */
     double *h_poses = nullptr;      /* pinned: dvo_get_poses / dvo_set_poses staging, 12 doubles per pair */
     unsigned long long *d_dbg = nullptr;
     char *d_states = nullptr;       /* n_pairs x pose_state_bytes(): host-driven iteration state */

@@ -2452,6 +2452,44 @@ enlist_write_kernel(const E *__restrict__ edge, size_t edge_stride, const float 
     }
 }
 
+/* round 6: a caller's 3xN float list -> its compact twin, if it IS an enlistRefEdgePts list for these intrinsics.
+ * X = (Z * ((float)xx - tmpcx)) * tmpfx (:249) is inverted to a candidate column, the three nearest integers are put through the very
+ * expression enlist_write_kernel uses and compared bit for bit (Y and the row alike); a point whose X or Y no integer pixel
+ * reproduces -- or whose pixel does not fit the 16-bit fields -- raises `fail`, and the list keeps the one-point-per-lane kernel.
+ * Lossless by verification, like the compact form of caller-supplied now images: the packed kernel recomputes X, Y from {xx, yy, Z}
+ * with the same expression, so it sees the caller's bits.  The twin is in the caller's order (cidx = identity). */
+__global__ void __launch_bounds__(256)
+points_recover_compact_kernel(const float *__restrict__ xyz, int N, int level, Intrinsics K, uint2 *__restrict__ compact,
+                              unsigned *__restrict__ cidx, int *__restrict__ fail) {
+    const float scaleFac = pow2_neg_f(level);
+    const float tmpfx = (float)(1. / (double)(scaleFac * K.fx)), tmpfy = (float)(1. / (double)(scaleFac * K.fy));
+    const float tmpcx = scaleFac * K.cx, tmpcy = scaleFac * K.cy;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const float X = xyz[3 * i], Y = xyz[3 * i + 1], Z = xyz[3 * i + 2];
+        auto recover = [&](float V, float tc, float tf) -> int {
+            const double guess = (double)V / ((double)Z * (double)tf) + (double)tc;
+            if (!(guess > -2.0 && guess < 65537.0)) return -1;
+            const int g0 = (int)__double2int_rn(guess);
+            for (int d = 0; d < 3; d++) {
+                const int q = g0 + (d == 0 ? 0 : (d == 1 ? -1 : 1));
+                if (q < 0 || q > 65535) continue;
+                const float v = Z * ((float)q - tc) * tf;                 /* :249 / :250, the order of enlist_write_kernel */
+                if (__float_as_uint(v) == __float_as_uint(V)) return q;
+            }
+            return -1;
+        };
+        const int xx = recover(X, tmpcx, tmpfx), yy = recover(Y, tmpcy, tmpfy);
+        if (xx < 0 || yy < 0) { *fail = 1; continue; }
+        compact[i] = make_uint2((unsigned)xx | ((unsigned)yy << 16), __float_as_uint(Z));
+        cidx[i] = (unsigned)i;
+    }
+}
+hipError_t launch_points_recover_compact(const float *xyz, int N, int level, const Intrinsics &K, uint2 *compact, unsigned *cidx, int *fail, hipStream_t s) {
+    if (N < 1) return hipSuccess;
+    hipLaunchKernelGGL(points_recover_compact_kernel, dim3(grid_x((size_t)N, 1024)), dim3(256), 0, s, xyz, N, level, K, compact, cidx, fail);
+    return hipGetLastError();
+}
+
 size_t enlist_block_ints(int rows, int cols) { return (size_t)((cols + 15) >> 4) * ((rows + 15) >> 4) * 16 + 2; }
 
 template <typename E>

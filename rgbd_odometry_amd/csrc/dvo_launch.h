@@ -108,6 +108,8 @@ hipError_t launch_replicate_level(float4 *tex, const unsigned char *src_has_tex 
                                   int dst_count, hipStream_t s);
 /* 4-byte twins of the compact lists of pairs [first_pair, first_pair + count): encode, decode with pt4_decode, compare with the
  * 8-byte form; pt4_ok[pair] = 1 only if every point survives */
+/* a caller's 3xN list -> {xx | yy << 16, Z} where every point verifies bit for bit (dvo_frames.hip); *fail is set otherwise */
+hipError_t launch_points_recover_compact(const float *xyz, int N, int level, const Intrinsics &K, uint2 *compact, unsigned *cidx, int *fail, hipStream_t s);
 hipError_t launch_points4_build(const uint2 *cpts, const int *N, int pt_cap, int rows, unsigned *cpt4, unsigned *chdr, int *pt4_ok,
                                 int first_pair, int count, hipStream_t s);
 /* final outputs stored in block order -> the reference's order: out[cidx[i]] = in[i] */

@@ -90,8 +90,8 @@ def test_accumulators(scene320, ctx320, oracle):
             np.testing.assert_allclose(acc[:21], tr["H"], rtol=1e-12, atol=1e-12 * np.abs(tr["H"]).max())
 
 
-@pytest.mark.parametrize("engine_lists", [False, True], ids=["3xN-lists", "engine-lists"])
-def test_wide_schedule_one_launch_per_iteration_with_and_without_normal_matrix(scene320, oracle, engine_lists):
+@pytest.mark.parametrize("lists", ["3xN-lists", "3xN-lists-foreign", "engine-lists"])
+def test_wide_schedule_one_launch_per_iteration_with_and_without_normal_matrix(scene320, oracle, lists):
     """dvo_align_pyramid_wide (the single-GPU form of the tiled schedule, same tiled_step_kernel: the update of an iteration at
     the head of the next launch, the sums added by the last workgroup): energies / best index / ratio / final outputs bit-equal to
     the oracle, skipped levels included; with DVO_FLAG_NORMAL_MATRIX the same launches also form H per iterate"""
@@ -99,10 +99,19 @@ def test_wide_schedule_one_launch_per_iteration_with_and_without_normal_matrix(s
     from rgbd_odometry_amd.capi import DVO_FLAG_NORMAL_MATRIX, DVO_FLAG_FINAL_OUTPUTS
     sc, lv = scene320
     iters = [6, 0, 5, 4]
+    # round 6: a caller's 3xN list that IS an enlistRefEdgePts list for the context's intrinsics (every point verifies bit for bit) gets the
+    # compact twin like the engine's own lists; a foreign list -- one point moved by an ulp is enough -- keeps the one-point-per-lane route
+    engine_lists = lists != "3xN-lists-foreign"
+    if lists == "3xN-lists-foreign":
+        lv = [dict(L) for L in lv]
+        for L in lv:
+            xyz = np.array(L["xyz"], np.float32).copy()
+            xyz.reshape(-1)[3 * (len(xyz) // 2)] = np.nextafter(xyz.reshape(-1)[3 * (len(xyz) // 2)], np.float32(10), dtype=np.float32)
+            L["xyz"] = xyz
     with DvoContext(1) as ctx:
         ctx.set_intrinsics(*sc.intrinsics)
         for l, L in enumerate(lv):
-            if engine_lists:        # lists built by the engine's own kernels have the compact twin: the packed step kernel (round 5), with H too
+            if lists == "engine-lists":   # lists built by the engine's own kernels have the compact twin: the packed step kernel (round 5), with H too
                 ctx.set_ref_level_from_images(l, sc.levels[l].ref_edge, sc.levels[l].ref_depth, L["rows"], L["cols"])
             else:
                 ctx.set_ref_level(l, L["xyz"])
@@ -147,8 +156,13 @@ def test_normal_matrix_of_every_iterate(scene320, oracle):
     ref = oracle.align_pyramid(iters, lv, sc.intrinsics, np.eye(3), np.zeros(3))
     # the reference's 3 x N lists (one-point-per-lane kernel); the engine's own lists (round 5: the packed kernel carries H too, on
     # 16-byte texels here); the same with now levels written natively in the compact form (its throughput look-up path)
-    for compact, want_blk in ((False, 512), (True, 512), ("native", 512), ("native", 256)):     # 256: the throughput shape of large batches
-        with DvoContext(1, block_threads=(256 if want_blk == 256 else 0)) as ctx:
+    # round 6: the reference's 3 x N lists verify as enlistRefEdgePts lists and get the compact twin too ("lists"); the one-point-per-lane
+    # kernel is asked for by engine_variant = 1 ("lists-one-point")
+    for compact, want_blk in ((False, 512), ("lists-one-point", 512), (True, 512), ("native", 512), ("native", 256)):     # 256: the throughput shape of large batches
+        one_point = compact == "lists-one-point"
+        if one_point:
+            compact = False
+        with DvoContext(1, block_threads=(256 if want_blk == 256 else 0), **({"engine_variant": 1} if one_point else {})) as ctx:
             ctx.set_intrinsics(*sc.intrinsics)
             for l, L in enumerate(lv):
                 if compact:
@@ -162,7 +176,7 @@ def test_normal_matrix_of_every_iterate(scene320, oracle):
                     ctx.set_now_level(l, L["dt"], L["gx"], L["gy"], L["rows"], L["cols"])
             R, t = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)), flags=DVO_FLAG_NORMAL_MATRIX)
             blk, g, packed = ctx.last_launch_shape()
-            assert bool(packed) == bool(compact) and blk == want_blk and g == 1, (compact, blk, g, packed)
+            assert bool(packed) == (not one_point) and blk == want_blk and g == 1, (compact, one_point, blk, g, packed)
             if compact == "native":
                 assert [ctx.level_texel_mode(0, l) for l in (0, 2, 3)] == [2, 2, 2]
             for l, rep in ref["levels"].items():
@@ -492,7 +506,7 @@ def test_align_pyramid_wide_matches_oracle(scene320, oracle):
     try:
         iters = [9, 0, 9, 9]
         R, t = ctx.align_pyramid_wide(iters, np.eye(3), np.zeros(3))
-        assert ctx.wide_packed_levels() == 0            # caller-supplied 3 x N lists have no compact twin: the one-point-per-lane step kernel
+        assert ctx.wide_packed_levels() == 0b1101       # round 6: these 3 x N lists verify as enlistRefEdgePts lists: compact twin, packed step kernel
         ref = oracle.align_pyramid(iters, lv, sc.intrinsics, np.eye(3), np.zeros(3))
         for l, rep in ref["levels"].items():
             e, b, ratio = ctx.level_report(0, l, iters[l])
