@@ -128,3 +128,100 @@ def test_undistort_restatement(oracle):
     # where the map leaves the source the constant border 0 comes out (strong pincushion: the corners sample far outside)
     far = oracle.undistort_bgr8(np.full_like(img, 200), K, (5.0, 0, 0, 0, 0))
     assert far[0, 0].max() == 0 and far[-1, -1].max() == 0 and far[rows // 2, cols // 2].min() == 200
+
+
+# ---- pinning row f1 against the real reference (tools/ref_dump/frames_dump.cpp; round 6) ----------------------------------------
+REFERENCE_FRAMES = os.path.join(os.path.dirname(GOLDEN), "reference_frames_golden.npz")
+
+
+def _frames_tools():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mods = []
+    for name in ("to_npz", "export_frames"):
+        spec = importlib.util.spec_from_file_location("ref_dump_" + name, os.path.join(root, "tools", "ref_dump", name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        mods.append(m)
+    return mods
+
+
+def oracle_frame_levels(oracle, export, name):
+    """what frames_dump.cpp computes for an exported frame, by the oracle: {key: array} in the converter's layout"""
+    out = {}
+    _, seed, rows, cols, levels, fs = [f for f in export.FRAMES if f[0] == name][0]
+    gl = export.grey_levels(oracle, seed, rows, cols, levels, fs)
+    out[f"{name}_levels"] = np.array(len(gl), np.int32)
+    for l, g in enumerate(gl):
+        dt, gx, gy, edge = oracle.now_level_from_grey(g)
+        out[f"{name}_L{l}_shape"] = np.array(g.shape, np.int32)
+        out[f"{name}_L{l}_edge"] = np.asarray(edge, np.int32).ravel()
+        for k, a in (("dt", dt), ("gx", gx), ("gy", gy)):
+            out[f"{name}_L{l}_{k}"] = np.asarray(a, np.float32).ravel()
+    return out
+
+
+def compare_with_reference_frames(ref, got, name):
+    """edge maps equal; distance transform and gradients within one float ulp (bit-equal is reported, not required: OpenCV's
+    MASK_PRECISE transform and cv::normalize are float code whose last bit this repository could only restate)"""
+    n = int(ref[f"{name}_levels"])
+    assert n == int(got[f"{name}_levels"])
+    for l in range(n):
+        assert np.array_equal(ref[f"{name}_L{l}_shape"], got[f"{name}_L{l}_shape"]), (name, l)
+        assert np.array_equal(ref[f"{name}_L{l}_edge"] != 0, got[f"{name}_L{l}_edge"] != 0), (name, l, "edge map")
+        for k in ("dt", "gx", "gy"):
+            a, b = np.asarray(ref[f"{name}_L{l}_{k}"], np.float32), np.asarray(got[f"{name}_L{l}_{k}"], np.float32)
+            ulp = np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+            same_sign_or_zero = (np.signbit(a) == np.signbit(b)) | ((a == 0) & (b == 0))
+            assert np.all(same_sign_or_zero) and int(ulp[(a != 0) | (b != 0)].max(initial=0)) <= 1, (name, l, k, int(ulp.max()))
+
+
+def test_frames_dump_text_format_round_trips(oracle, tmp_path):
+    """the text format tools/ref_dump/frames_dump.cpp writes (run-length edge map, C99 hex floats) -> to_npz.parse_frames -> the arrays
+    the reference tests read: written here from the ORACLE's outputs exactly as the driver's fprintf calls would"""
+    to_npz, export = _frames_tools()
+    name = export.FRAMES[0][0]
+    want = oracle_frame_levels(oracle, export, name)
+    lines = ["frame %s %d" % (name, int(want[f"{name}_levels"]))]
+    for l in range(int(want[f"{name}_levels"])):
+        rows, cols = (int(v) for v in want[f"{name}_L{l}_shape"])
+        lines.append("level %d %d %d" % (l, rows, cols))
+        e = want[f"{name}_L{l}_edge"]
+        runs, i = [], 0
+        while i < e.size:
+            j = i
+            while j < e.size and e[j] == e[i]:
+                j += 1
+            runs.append("%d %d" % (int(e[i]), j - i))
+            i = j
+        lines.append("edge " + " ".join(runs))
+        for k in ("dt", "gx", "gy"):
+            lines.append(k + " " + " ".join(float(x).hex() for x in want[f"{name}_L{l}_{k}"]))
+    f = tmp_path / "frames.txt"
+    f.write_text("\n".join(lines) + "\n")
+    got = to_npz.parse_frames(str(f))
+    assert set(got) == set(want)
+    for k in want:
+        assert np.array_equal(np.asarray(want[k]), got[k]), k
+    compare_with_reference_frames(got, want, name)
+    # and the exporter writes what the driver reads: column-major uint8 levels + their shapes
+    export_dir = tmp_path / "inputs"
+    import sys
+    argv = sys.argv
+    sys.argv = ["export_frames.py", str(export_dir)]
+    try:
+        export.main()
+    finally:
+        sys.argv = argv
+    meta = (export_dir / name / "meta.txt").read_text().split()
+    assert int(meta[0]) == int(want[f"{name}_levels"])
+    g0 = np.fromfile(export_dir / name / "grey_0.u8", np.uint8)
+    assert g0.size == int(meta[1]) * int(meta[2])
+
+
+@pytest.mark.skipif(not os.path.exists(REFERENCE_FRAMES), reason="tests/golden/reference_frames_golden.npz absent: nobody has run tools/ref_dump/frames_dump.cpp against the real reference yet (row f1 UNPINNED)")
+def test_matches_reference_vectors(oracle):
+    _, export = _frames_tools()
+    ref = np.load(REFERENCE_FRAMES)
+    for name, *_ in export.FRAMES:
+        compare_with_reference_frames(ref, oracle_frame_levels(oracle, export, name), name)

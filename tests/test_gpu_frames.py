@@ -502,3 +502,29 @@ def test_full_hd_frame_five_levels_through_the_level_tables(oracle):
             dt, gx, gy, _ = oracle.now_level_from_grey(g)
             for got, want, what in zip(ctx.get_now_level(l), (dt, gx, gy), ("DT", "gx", "gy")):
                 assert np.array_equal(got, want), f"{what} level {l}"
+
+
+def test_gpu_frame_stage_matches_reference_vectors(oracle):
+    """round 6: the HIP frame stage against the REAL reference's now-frame preprocessing (OpenCV 2.4 through SolveDVO::
+    computeDistTransfrmOfNow, src/SolveDVO.cpp:1740-1799), from the vectors tools/ref_dump/frames_dump.cpp produces -- skipped until
+    somebody has run that driver (row f1 UNPINNED); the CPU twin and the format test live in tests/test_frames_oracle.py"""
+    import os
+    import test_frames_oracle as tfo
+    if not os.path.exists(tfo.REFERENCE_FRAMES):
+        pytest.skip("tests/golden/reference_frames_golden.npz absent: tools/ref_dump/frames_dump.cpp has not been run against the reference")
+    _, export = tfo._frames_tools()
+    ref = np.load(tfo.REFERENCE_FRAMES)
+    for name, seed, rows, cols, levels, fs in export.FRAMES:
+        bgr, depth = frame_gen.camera_frame(seed, rows, cols)
+        pyr = oracle.build_pyramid(bgr, depth, levels, fs)
+        got = {f"{name}_levels": np.array(levels, np.int32)}
+        with _ctx() as ctx:
+            ctx.frames_upload_pyramids([pyr])
+            ctx.frames_as_now(0, 0, 1)
+            for l, (g, _) in enumerate(pyr):
+                ddt, dgx, dgy = ctx.get_now_level(l)
+                edge = ctx.frame_level(0, l)[2]
+                got[f"{name}_L{l}_shape"] = np.array(g.shape, np.int32)
+                got[f"{name}_L{l}_edge"] = _cm(edge).astype(np.int32)
+                got[f"{name}_L{l}_dt"], got[f"{name}_L{l}_gx"], got[f"{name}_L{l}_gy"] = ddt, dgx, dgy
+        tfo.compare_with_reference_frames(ref, got, name)
