@@ -279,6 +279,10 @@ int  dvo_tiled_graph_replayed(dvo_ctx *ctx, int *graph_replayed);
  * *solo_mask (may be NULL): the levels among them that ran as ONE launch of one workgroup for all their iterations (levels of at most
  * DVO_TILED_SOLO_MAX = 6144 points; over several ranks every rank runs such a level whole, without a collective) */
 int  dvo_wide_packed_levels(dvo_ctx *ctx, int *levels_mask, int *solo_mask);
+/* round 6: *levels_mask = the levels of the last dvo_align_pyramid_wide that ran inside ONE launch of the fused kernel in team mode (the
+ * coarse levels of a large frame: levels of at most DVO_WIDE_TEAM_MAX = 200 000 points from the coarsest down, when finer ones remain for
+ * the step launches); 0 when the schedule ran as step launches only */
+int  dvo_wide_team_levels(dvo_ctx *ctx, int *levels_mask);
 
 /* ---- inspection (used by the parity tests) ---------------------------------
  * One evaluation of computeJacobianOfNowFrame + getReprojectedEpsilons at the

@@ -31,7 +31,7 @@ C_ABI_SYMBOLS = [
     "dvo_get_final_outputs", "dvo_get_level_normal_matrix", "dvo_eval_points", "dvo_accumulate", "dvo_device_se3_exp",
     "dvo_device_se3_log", "dvo_device_rotationize", "dvo_algorithmic_bytes", "dvo_point_iterations",
     "dvo_debug_stamps", "dvo_get_level_texel_mode", "dvo_get_level_exact_fallback", "dvo_get_level_points4", "dvo_get_level_ranks_in_lds", "dvo_now_prepare", "dvo_set_direct_compact", "dvo_host_alloc_mapped", "dvo_host_free_mapped", "dvo_get_now_compact_info", "dvo_get_now_compact_partial", "dvo_get_last_launch_shape", "dvo_replicate_pairs", "dvo_set_now_level_from_edges", "dvo_get_now_level", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
-    "dvo_align_pyramid_wide", "dvo_tiled_attach", "dvo_tiled_detach", "dvo_align_pyramid_tiled", "dvo_tiled_shard", "dvo_tiled_graph_replayed", "dvo_wide_packed_levels",
+    "dvo_align_pyramid_wide", "dvo_tiled_attach", "dvo_tiled_detach", "dvo_align_pyramid_tiled", "dvo_tiled_shard", "dvo_tiled_graph_replayed", "dvo_wide_packed_levels", "dvo_wide_team_levels",
     "dvo_get_ref_level", "dvo_frames_reserve", "dvo_frames_upload_pyramids", "dvo_frames_upload_cameras", "dvo_frames_set_undistort",
     "dvo_photo_params_default", "dvo_photo_configure", "dvo_photo_set_ref", "dvo_photo_align", "dvo_photo_get_jacobian", "dvo_frames_as_now",
     "dvo_frames_as_ref", "dvo_frame_get_level", "dvo_frames_num_levels",
@@ -279,6 +279,7 @@ def load_library() -> C.CDLL:
         "dvo_tiled_shard": [vp, i, i, ip, ip],
         "dvo_tiled_graph_replayed": [vp, ip],
         "dvo_wide_packed_levels": [vp, ip, ip],
+        "dvo_wide_team_levels": [vp, ip],
         "dvo_get_ref_level": [vp, i, i, vp, i, ip],
         "dvo_frames_reserve": [vp, i],
         "dvo_frames_upload_pyramids": [vp, i, i, i, C.POINTER(DvoImage), C.POINTER(DvoImage), i, i],
@@ -712,6 +713,12 @@ class DvoContext:
         """bit l set: level l of the last enqueued align_pyramid_wide / _tiled schedule ran the packed step kernel (compact list)"""
         g = C.c_int(0)
         self._chk(self.lib.dvo_wide_packed_levels(self._h, C.byref(g), None))
+        return g.value
+
+    def wide_team_levels(self) -> int:
+        """bit l set: level l of the last align_pyramid_wide ran inside the fused kernel's team launch (coarse levels of a large frame)"""
+        g = C.c_int(0)
+        self._chk(self.lib.dvo_wide_team_levels(self._h, C.byref(g)))
         return g.value
 
     def wide_solo_levels(self) -> int:

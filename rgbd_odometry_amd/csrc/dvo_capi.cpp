@@ -505,12 +505,20 @@ void cast_pose(const double *R, const double *t, float *Rf, float *tf) {
     for (int k = 0; k < 3; k++) tf[k] = (float)t[k];       /* :674 */
 }
 
-int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *iters, int flags) {
+/* level_mask: the levels THIS launch runs (the energy layout stays that of the whole schedule `iters`): the wide schedule hands its
+ * coarse levels to the fused team kernel and keeps the fine ones for its step launches (round 6, dvo_align_pyramid_wide) */
+int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *iters, int flags, unsigned level_mask = ~0u) {
     if (!pair_ok(c, first_pair) || n_pairs < 1 || first_pair + n_pairs > c->n_pairs)
         return fail(c, DVO_ERR_INVALID, "pair range out of bounds");
     Schedule sc;
     int rc = build_schedule(c, n_levels, iters, flags, sc);
     if (rc) return rc;
+    if (level_mask != ~0u) {
+        sc.last_level = -1;
+        for (int l = 0; l < n_levels; l++) if (!((level_mask >> l) & 1u)) sc.iters[l] = 0;
+        for (int l = n_levels - 1; l >= 0; l--) if (sc.iters[l] > 0) sc.last_level = l;
+        if (sc.last_level < 0) return fail(c, DVO_ERR_INVALID, "schedule has no iterations");
+    }
     for (int l = 0; l < n_levels; l++) {
         if (sc.iters[l] <= 0) continue;
         for (int p = first_pair; p < first_pair + n_pairs; p++)
@@ -1643,6 +1651,63 @@ static void shard_of(int n, int rank, int world, int &first, int &count) {      
     first = rank * base + (rank < rem ? rank : rem);
 }
 
+int team_err_check(dvo_ctx *c) { return check_team_err(c); }
+
+/* Round 6: the coarse levels of a large frame do not need 256 CUs -- a step launch costs ~7 us whatever it
+ * holds (boundary + 255 -> 1 fan-in + the update at its head), an iteration of the fused kernel's team inside one XCD ~3-5 us.
+ * The levels from the coarsest down to the first one beyond DVO_WIDE_TEAM_MAX points go to ONE launch of align_fused2_kernel in
+ * team mode (dvo_enqueue's own machinery: same energies, best index, ratio bit for bit; the pose travels through d_poses), the
+ * finer ones keep the step launches: on return `sc` holds those (same energy layout), coarse_mask the levels handed over (0: none --
+ * then nothing was enqueued and the caller's sequence copies the pose in itself).  Over several ranks every rank runs the coarse levels
+ * whole, like the one-launch small levels: no collective, identical bits.  Not with H (its per-iterate sums come from the step
+ * launches), not without compact lists. */
+int wide_coarse_levels_as_team(dvo_ctx *c, int pair, int n_levels, const int *iters, int flags, Schedule &sc, const double *h_pose_in,
+                               double *d_pose, unsigned &coarse_mask, bool &coarse_team) {
+    /* Two tiers, measured on one 4096x3072x5 and one 1920x1080x5 pair (profiles/r06_final/wide_team_sweep.txt): levels of up to 80 k points
+     * as a team of 32 inside ONE XCD (records as plain stores), levels of up to 350 k points as a team of 128 over all XCDs (two-stage
+     * exchange); larger levels -- and always the finest one, whose final outputs the step path writes -- keep the step launches.
+     * DVO_WIDE_TEAM_MAX=a,b overrides the two limits (0 switches the whole thing off), DVO_WIDE_TEAM_SIZE=a,b the two team sizes. */
+    static int lim[2] = {80000, 350000}, size[2] = {32, 128};
+    static const bool parsed = [] {
+        if (const char *e = std::getenv("DVO_WIDE_TEAM_MAX")) { int a = 0, b = -1; const int n = std::sscanf(e, "%d,%d", &a, &b); lim[0] = a; lim[1] = n > 1 ? b : a; }
+        if (const char *e = std::getenv("DVO_WIDE_TEAM_SIZE")) { int a = 0, b = -1; const int n = std::sscanf(e, "%d,%d", &a, &b); size[0] = a; size[1] = n > 1 ? b : a; }
+        return true;
+    }();
+    (void)parsed;
+    coarse_mask = 0;
+    coarse_team = false;
+    if (lim[1] <= 0 || (flags & DVO_FLAG_NORMAL_MATRIX) || c->prm.interpolate_dt || c->prm.engine_variant == 1 || c->prm.team_size != 0 ||
+        c->n_cu < 64 || c->stream == nullptr) return DVO_OK;
+    int finest = -1;
+    for (int l = 0; l < n_levels; l++) if (sc.iters[l] > 0) { finest = l; break; }
+    unsigned tier[2] = {0u, 0u};
+    bool big_enough = false;
+    for (int l = n_levels - 1; l > finest; l--) {               /* from the coarsest down; never the finest level */
+        if (sc.iters[l] <= 0) continue;
+        const int N = c->lv[l].hN[pair];
+        if (N > lim[1] || c->lv[l].compact_ok.empty() || !c->lv[l].compact_ok[pair]) break;
+        const int k = (N <= lim[0] && !tier[1]) ? 0 : 1;          /* once a level went to the second tier the finer ones follow */
+        if (k == 1 && (c->n_cu < size[1] || size[1] < 2)) break;
+        tier[k] |= 1u << l;
+        big_enough = big_enough || N > DVO_TILED_SOLO_MAX_DEFAULT;
+    }
+    if (!big_enough || !(tier[0] | tier[1])) return DVO_OK;       /* small levels are one launch each already */
+    HIPCHK(c, hipMemcpyAsync(d_pose, h_pose_in, sizeof(double) * 12, hipMemcpyHostToDevice, c->stream));
+    for (int k = 0; k < 2; k++) {
+        if (!tier[k]) continue;
+        c->prm.team_size = size[k];
+        const int rc = enqueue(c, pair, 1, n_levels, iters, 0, tier[k]);
+        c->prm.team_size = 0;
+        if (rc) return rc;
+        coarse_team = coarse_team || c->team_used;
+    }
+    coarse_mask = tier[0] | tier[1];
+    for (int l = 0; l < n_levels; l++) if ((coarse_mask >> l) & 1u) sc.iters[l] = 0;      /* what is left for the step launches */
+    sc.last_level = -1;
+    for (int l = n_levels - 1; l >= 0; l--) if (sc.iters[l] > 0) sc.last_level = l;
+    return DVO_OK;
+}
+
 hipError_t enqueue_step_schedule(dvo_ctx *c, const Schedule &sc, int pair, int flags, double *d_pose, int rank, int world,
                                  const std::function<hipError_t(double *)> &all_reduce) {
     hipError_t first_err = hipSuccess;
@@ -1755,10 +1820,13 @@ int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters,
     std::memcpy(h, R, sizeof(double) * 9);
     std::memcpy(h + 9, t, sizeof(double) * 3);
     double *d_pose = c->d_poses + (size_t)12 * pair;
+    unsigned coarse_mask = 0;
+    bool coarse_team = false;
+    if ((rc = dvo_host::wide_coarse_levels_as_team(c, pair, n_levels, iters, flags, sc, h, d_pose, coarse_mask, coarse_team))) return rc;
     /* everything the enqueued sequence depends on; an unchanged signature replays the instantiated graph.  One launch per iteration
      * (round 4: the update of an iteration rides at the head of the next one's accumulate launch, the partial sums are added by the
      * workgroup that arrives last -- dvo_kernels.hip: tiled_step_kernel); rounds 1-3 used two. */
-    const unsigned long long sig = step_schedule_signature(c, sc, pair, n_levels, flags, 0, 1);
+    const unsigned long long sig = step_schedule_signature(c, sc, pair, n_levels, flags, 0, 1) ^ ((unsigned long long)coarse_mask << 48);
     static const bool env_no_graph = std::getenv("DVO_WIDE_NO_GRAPH") != nullptr;  /* A/B switch for measurements */
     const bool no_graph = env_no_graph || c->stream == nullptr;                    /* the legacy null stream cannot be captured */
     if (no_graph || !c->wide_exec || sig != c->wide_sig) {
@@ -1766,7 +1834,7 @@ int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters,
         if (!no_graph) HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         hipError_t first_err = hipSuccess;
         auto rec = [&first_err](hipError_t e) { if (first_err == hipSuccess && e != hipSuccess) first_err = e; };
-        rec(hipMemcpyAsync(d_pose, h, sizeof(double) * 12, hipMemcpyHostToDevice, c->stream));
+        if (!coarse_mask) rec(hipMemcpyAsync(d_pose, h, sizeof(double) * 12, hipMemcpyHostToDevice, c->stream));      /* else: went in front of the team launch */
         rec(enqueue_step_schedule(c, sc, pair, flags, d_pose, 0, 1, nullptr));
         rec(hipMemcpyAsync(h, d_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, c->stream));
         rec(hipMemcpyAsync(h + 12, c->d_step_ticket + 2, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
@@ -1784,10 +1852,17 @@ int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters,
     { const int lrc = dvo_host::check_step_lost(c); if (lrc) return lrc; }
     std::memcpy(R, h, sizeof(double) * 9);
     std::memcpy(t, h + 9, sizeof(double) * 3);
+    if (coarse_mask) {                                    /* the outputs follow the WHOLE schedule again */
+        Schedule full;
+        if ((rc = build_schedule(c, n_levels, iters, flags, full))) return rc;
+        sc = full;
+    }
+    c->wide_team_mask = (int)coarse_mask;
     stamp_outputs(c, sc, pair, 1);
     c->sched = sc;
     c->have_sched = true;
-    c->team_used = false;
+    c->team_used = coarse_team;
+    if (coarse_team) { const int trc = check_team_err(c); if (trc) return trc; }
     return DVO_OK;
 }
 

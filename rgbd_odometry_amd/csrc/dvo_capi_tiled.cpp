@@ -142,6 +142,13 @@ int dvo_wide_packed_levels(dvo_ctx *c, int *levels_mask, int *solo_mask) {
     return DVO_OK;
 }
 
+int dvo_wide_team_levels(dvo_ctx *c, int *levels_mask) {
+    DVO_ENTER(c);
+    if (!levels_mask) return fail(c, DVO_ERR_INVALID, "levels_mask is NULL");
+    *levels_mask = c->wide_team_mask;
+    return DVO_OK;
+}
+
 int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters, int flags, double *R, double *t) {
     DVO_ENTER(c);
     if (!pair_ok(c, pair) || !R || !t) return fail(c, DVO_ERR_INVALID, "bad arguments");
@@ -160,6 +167,11 @@ int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters
     std::memcpy(h, R, sizeof(double) * 9);
     std::memcpy(h + 9, t, sizeof(double) * 3);
     double *d_pose = c->d_poses + (size_t)12 * pair;
+    /* round 6: the coarse levels of a large frame as ONE team launch of the fused kernel, run whole by every rank (no collective: identical
+     * inputs, a fixed order of additions, identical bits); `sc` keeps the fine levels for the step launches below */
+    unsigned coarse_mask = 0;
+    bool coarse_team = false;
+    if ((rc = dvo_host::wide_coarse_levels_as_team(c, pair, n_levels, iters, flags, sc, h, d_pose, coarse_mask, coarse_team))) return rc;
     /* Per iteration ONE kernel and ONE collective (round 4; rounds 1-3: accumulate, reduce, all-reduce, update): the update of an
      * iteration is applied at the head of the next iteration's launch by every workgroup of every rank from the same all-reduced
      * bits (dvo_kernels.hip: tiled_step_kernel), the 32 sums of a launch are written by its last workgroup.  The whole schedule,
@@ -172,7 +184,7 @@ int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters
         return nrc == 0 ? hipSuccess : hipErrorUnknown;
     };
     auto submit = [&]() -> hipError_t {
-        hipError_t e = hipMemcpyAsync(d_pose, h, sizeof(double) * 12, hipMemcpyHostToDevice, c->stream);
+        hipError_t e = coarse_mask ? hipSuccess : hipMemcpyAsync(d_pose, h, sizeof(double) * 12, hipMemcpyHostToDevice, c->stream);      /* else: went in front of the team launch */
         if (e == hipSuccess) e = dvo_host::enqueue_step_schedule(c, sc, pair, flags, d_pose, T->rank, T->world, all_reduce);
         if (e == hipSuccess) e = hipMemcpyAsync(h, d_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(h + 12, c->d_step_ticket + 2, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
@@ -185,7 +197,7 @@ int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters
      * replay misbehaves.  So for world > 1 the graph is opt-in (DVO_TILED_GRAPH_MULTIRANK=1) until an 8-GPU node has validated it;
      * one rank -- where RCCL's in-place all-reduce launches nothing -- keeps the graph. */
     static const bool env_graph_multirank = std::getenv("DVO_TILED_GRAPH_MULTIRANK") != nullptr;
-    const unsigned long long sig = dvo_host::step_schedule_signature(c, sc, pair, n_levels, flags, T->rank, T->world) ^ (unsigned long long)(size_t)T->comm;
+    const unsigned long long sig = dvo_host::step_schedule_signature(c, sc, pair, n_levels, flags, T->rank, T->world) ^ (unsigned long long)(size_t)T->comm ^ ((unsigned long long)coarse_mask << 48);
     bool direct = env_no_graph || c->stream == nullptr || T->no_graph || (T->world > 1 && !env_graph_multirank);
     if (!direct && (!c->tiled_exec || sig != c->tiled_sig)) {
         if (c->tiled_exec) { (void)hipGraphExecDestroy(c->tiled_exec); c->tiled_exec = nullptr; }
@@ -219,11 +231,14 @@ int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters
     { const int lrc = dvo_host::check_step_lost(c); if (lrc) return lrc; }
     std::memcpy(R, h, sizeof(double) * 9);
     std::memcpy(t, h + 9, sizeof(double) * 3);
+    if (coarse_mask && (rc = dvo_host::build_schedule(c, n_levels, iters, flags, sc))) return rc;      /* the outputs follow the WHOLE schedule */
     dvo_host::stamp_outputs(c, sc, pair, 1);
     c->sched = sc;
     c->have_sched = true;
-    c->team_used = false;
+    c->team_used = coarse_team;
     c->tiled_graph_used = !direct;
+    c->wide_team_mask = (int)coarse_mask;
+    if (coarse_team && (rc = dvo_host::team_err_check(c))) return rc;
     return DVO_OK;
 }
 

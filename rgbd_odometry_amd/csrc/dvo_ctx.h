@@ -139,6 +139,7 @@ struct dvo_ctx {
     int step_solo_mask = 0;              /* ... and those that ran as one launch of one workgroup (tiled_level_solo_kernel) */
     int step_pk_mask = 0;                /* levels of the last enqueued step schedule that ran tiled_step_pk_kernel (inspection) */
     double *h_pose = nullptr;       /* pinned: in/out pose of the graph's copy nodes */
+    int wide_team_mask = 0;         /* levels the last dvo_align_pyramid_wide handed to the fused team kernel (round 6) */
     int direct_compact = -1;        /* dvo_set_direct_compact: float now levels go to the compact form at installation (-1: auto, by batch size) */
     double *h_poses = nullptr;      /* pinned: dvo_get_poses / dvo_set_poses staging, 12 doubles per pair */
     unsigned long long *d_dbg = nullptr;
@@ -270,6 +271,10 @@ int refresh_p4_known(dvo_ctx *c, int level, int first, int count, bool skip_nati
 hipError_t enqueue_step_schedule(dvo_ctx *c, const dvo::Schedule &sc, int pair, int flags, double *d_pose, int rank, int world,
                                  const std::function<hipError_t(double *)> &all_reduce);
 int ensure_step_buffers(dvo_ctx *c);
+int team_err_check(dvo_ctx *c);       /* after a wait: DVO_ERR_HIP if a member of the last team launch gave up waiting for its team */
+/* the wide / tiled schedule's coarse levels as one team launch of the fused kernel (dvo_capi.cpp) */
+int wide_coarse_levels_as_team(dvo_ctx *c, int pair, int n_levels, const int *iters, int flags, dvo::Schedule &sc, const double *h_pose_in,
+                               double *d_pose, unsigned &coarse_mask, bool &coarse_team);
 int check_step_lost(dvo_ctx *c);      /* after the wait of a wide / tiled alignment: DVO_ERR_HIP if a step launch lost a workgroup's rows */
 unsigned long long step_schedule_signature(dvo_ctx *c, const dvo::Schedule &sc, int pair, int n_levels, int flags, int rank, int world);
 /* the reference lists of pairs [first, first + n) of a level were (re)written: bumps points_gen and the pairs' list stamps;
