@@ -53,6 +53,16 @@ Tiled *find(dvo_ctx *c) {
     return nullptr;
 }
 
+/* communicators attached to contexts on this context's device: more than one = several ranks of one process share a GPU (the thread-rank
+ * arrangement of tests/test_gpu_tiled_ranks.py; a real node has one rank per GPU).  Their team launches would compete for co-residency --
+ * three half-resident teams of 128 can hold each other's compute units -- so the coarse levels then keep the step launches. */
+int ranks_on_device_of(dvo_ctx *c) {
+    std::lock_guard<std::mutex> lock(registry_mutex());
+    int n = 0;
+    for (Entry *e : registry()) n += (e->ctx->device == c->device) ? 1 : 0;
+    return n;
+}
+
 void shard(int n, int rank, int world, int &first, int &count) {      /* same decomposition as distributed.py::shard_range */
     const int base = n / world, rem = n % world;
     count = base + (rank < rem ? 1 : 0);
@@ -171,7 +181,9 @@ int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters
      * inputs, a fixed order of additions, identical bits); `sc` keeps the fine levels for the step launches below */
     unsigned coarse_mask = 0;
     bool coarse_team = false;
-    if ((rc = dvo_host::wide_coarse_levels_as_team(c, pair, n_levels, iters, flags, sc, h, d_pose, coarse_mask, coarse_team))) return rc;
+    /* DVO_TILED_TEAM_SHARED=1 (tests): hand the coarse levels over although several ranks share the device */
+    if ((ranks_on_device_of(c) <= 1 || std::getenv("DVO_TILED_TEAM_SHARED") != nullptr) &&
+        (rc = dvo_host::wide_coarse_levels_as_team(c, pair, n_levels, iters, flags, sc, h, d_pose, coarse_mask, coarse_team))) return rc;
     /* Per iteration ONE kernel and ONE collective (round 4; rounds 1-3: accumulate, reduce, all-reduce, update): the update of an
      * iteration is applied at the head of the next iteration's launch by every workgroup of every rank from the same all-reduced
      * bits (dvo_kernels.hip: tiled_step_kernel), the 32 sums of a launch are written by its last workgroup.  The whole schedule,

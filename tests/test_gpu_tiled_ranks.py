@@ -186,6 +186,65 @@ def test_c_tiled_path_with_several_ranks_on_one_gpu(world, oracle):
         lib.loopback_destroy(comms, world)
 
 
+def test_coarse_levels_as_team_launches_on_every_rank(oracle, monkeypatch):
+    """round 6: the coarse levels of a large frame run as team launches of the fused kernel -- over several ranks every rank runs them
+    WHOLE (identical inputs, a fixed order of additions: identical bits, no collective), only the finest level is sharded and
+    all-reduced.  Two host threads as ranks 0 / 1 of 2 on one GPU (the library hands the coarse levels over in this arrangement only when
+    asked to: two teams of 32 fit the chip side by side), 1920x1080x5."""
+    import ctypes as C
+    import threading
+    import numpy as np
+    import oracle_lib
+    from oracle_lib import rot_angle
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    monkeypatch.setenv("DVO_TILED_TEAM_SHARED", "1")
+    if os.environ.get("DVO_WIDE_TEAM_MAX") or os.environ.get("DVO_TILED_PACKED"):
+        pytest.skip("the default limits of the hand-over are what this test is about")
+    world = 2
+    lib = _loopback_library()
+    sc = SynthScene(1920, 1080, 5, 4)
+    lv = oracle_lib.scene_levels(sc, oracle)
+    iters = [3, 3, 2, 3, 4]
+    ref = oracle.align_pyramid(iters, lv, sc.intrinsics, np.eye(3), np.zeros(3))
+    comms = (C.c_void_p * world)()
+    assert lib.loopback_create(world, comms) == 0
+    ctxs = []
+    try:
+        for r in range(world):
+            ctx = DvoContext(1)
+            ctx.set_intrinsics(*sc.intrinsics)
+            for l, L in enumerate(sc.levels):
+                ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols)
+                ctx.set_now_level_from_edges(l, (np.asarray(L.now_edge) != 0).astype(np.uint8) * 255, L.rows, L.cols)
+            ctx.tiled_attach(comms[r], r, world, LOOPBACK_SO)
+            ctxs.append(ctx)
+        out, err = [None] * world, [None] * world
+
+        def run(r):
+            try:
+                out[r] = ctxs[r].align_pyramid_tiled(iters, np.eye(3), np.zeros(3))
+            except Exception as e:
+                err[r] = e
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join(180)
+        assert not any(x.is_alive() for x in th) and err == [None] * world, err
+        assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][1], out[0][1])
+        assert rot_angle(ref["R"], out[0][0]) <= 1e-5 and np.linalg.norm(ref["t"] - out[0][1]) <= 1e-4
+        for r in range(world):
+            assert ctxs[r].wide_team_levels() == 0b11110, bin(ctxs[r].wide_team_levels())      # 67 k / 32 k / 14 k / 5.5 k points: one team launch
+            assert lib.loopback_calls(comms[r]) == iters[0]                                      # only the finest level met the collective
+            for l, rp in ref["levels"].items():
+                e, b, ratio = ctxs[r].level_report(0, l, iters[l])
+                assert np.array_equal(e, rp["energy"]) and b == rp["best_idx"] and ratio == rp["visible_ratio"], (r, l)
+    finally:
+        for ctx in ctxs:
+            ctx.close()
+        lib.loopback_destroy(comms, world)
+
+
 def test_batch_bench_with_two_and_three_ranks_sharing_the_gpu():
     """The N > 1 path of the batch bench -- bench.py starting its own ranks under torch.distributed.run, per-rank scene seeds,
     barriers, MAX over ranks, the rank-0 line -- has never run on hardware (one-GPU boxes).  --ranks-share-gpu puts all ranks on
