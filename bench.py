@@ -939,6 +939,7 @@ def main_tiled(args):
             "all_ranks_bit_identical": same, "graph_replayed": graph_replayed,
             "levels_on_the_packed_step_kernel": [l for l in range(args.levels) if (pk_mask >> l) & 1],
             "levels_as_one_launch": [l for l in range(args.levels) if (solo_mask >> l) & 1],
+            "levels_as_team_launches": [l for l in range(args.levels) if (ctx.wide_team_levels() >> l) & 1],   # round 6: run whole by every rank, no collective
             "points_per_level": [int(ctx.n_points(l)) for l in range(args.levels)],
             "algorithmic_bytes_per_alignment": bytes_align,
             "alignment_GBps": bytes_align * value / 1e9,
@@ -947,6 +948,10 @@ def main_tiled(args):
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
             "kernel": "tiled_step_kernel (dvo_kernels.hip: update of the previous iteration + this rank's shard of level 0, %d of %d points, + the sums of the launch) and its ncclAllReduce" % (count, n_pts[0]),
             "kernel_ms": acc_ms, "algorithmic_bytes_per_launch": bytes_launch,
+            # the per-launch fraction above is one level-0 step with the images amortised over its iterations; the whole
+            # alignment -- SURVEY 8(d)'s bytes over the time of ALL its launches -- is latency-bound and sits far lower
+            "per_alignment": {"achieved": bytes_align * value / 1e9, "frac": bytes_align * value / 1e9 / HBM_PEAK_GBPS, "unit": "GB/s",
+                              "algorithmic_bytes": bytes_align},
             "definition": "12 B x points of the shard + the level's 12 B/pixel images amortised over its iterations, per accumulate "
                           "launch; kernel_ms = one iteration at level 0 measured through the product path (slope of the alignment time over "
                           "the number of level-0 iterations): the launch, its boundary and the 256-byte all-reduce",

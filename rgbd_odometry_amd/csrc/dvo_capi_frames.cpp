@@ -814,7 +814,9 @@ int dvo_frame_get_level(dvo_ctx *c, int slot, int level, int *rows, int *cols, u
         HIPCHK(c, launch_count_edges(F.edge + off, F.npx, c->work, c->stream));
         HIPCHK(c, hipMemcpyAsync(n_edges, c->work, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     }
-    HIPCHK(c, stream_wait(c->stream));
+    /* round 6: a question about the level's size alone touches no device memory and must not wait for the stream (the Python binding asks
+     * after every upload: four host syncs per step of a frames -> poses pipeline, 45 us of idle GPU in front of every alignment) */
+    if (grey || edge || depth_mm || n_edges) HIPCHK(c, stream_wait(c->stream));
     return DVO_OK;
 }
 
