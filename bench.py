@@ -892,6 +892,7 @@ def main_tiled(args):
         same = all(bool(torch.equal(allp[0], a)) for a in allp)
     graph_replayed = ctx.tiled_graph_replayed()
     pk_mask, solo_mask = ctx.wide_packed_levels(), ctx.wide_solo_levels()        # of the schedule that was timed (the step measurement below enqueues its own)
+    team_mask = ctx.wide_team_levels()
     # per-level reports of the LAST timed alignment, read before anything else touches the context's outputs
     reports = {l: ctx.level_report(0, l, iters[l]) for l in range(args.levels) if iters[l] > 0}
     finals = None
@@ -939,14 +940,14 @@ def main_tiled(args):
             "all_ranks_bit_identical": same, "graph_replayed": graph_replayed,
             "levels_on_the_packed_step_kernel": [l for l in range(args.levels) if (pk_mask >> l) & 1],
             "levels_as_one_launch": [l for l in range(args.levels) if (solo_mask >> l) & 1],
-            "levels_as_team_launches": [l for l in range(args.levels) if (ctx.wide_team_levels() >> l) & 1],   # round 6: run whole by every rank, no collective
+            "levels_as_team_launches": [l for l in range(args.levels) if (team_mask >> l) & 1],   # round 6: team launches of the fused kernel, run whole by every rank (no collective)
             "points_per_level": [int(ctx.n_points(l)) for l in range(args.levels)],
             "algorithmic_bytes_per_alignment": bytes_align,
             "alignment_GBps": bytes_align * value / 1e9,
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-            "kernel": "tiled_step_kernel (dvo_kernels.hip: update of the previous iteration + this rank's shard of level 0, %d of %d points, + the sums of the launch) and its ncclAllReduce" % (count, n_pts[0]),
+            "kernel": ("align_fused2_kernel<512,true> as a team of 256 over the whole chip (one rank: the finest level is not sharded; one iteration of %d points)" % n_pts[0]) if (team_mask & 1) else ("tiled_step_kernel (dvo_kernels.hip: update of the previous iteration + this rank's shard of level 0, %d of %d points, + the sums of the launch) and its ncclAllReduce" % (count, n_pts[0])),
             "kernel_ms": acc_ms, "algorithmic_bytes_per_launch": bytes_launch,
             # the per-launch fraction above is one level-0 step with the images amortised over its iterations; the whole
             # alignment -- SURVEY 8(d)'s bytes over the time of ALL its launches -- is latency-bound and sits far lower

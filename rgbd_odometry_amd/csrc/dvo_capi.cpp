@@ -1662,15 +1662,17 @@ int team_err_check(dvo_ctx *c) { return check_team_err(c); }
  * whole, like the one-launch small levels: no collective, identical bits.  Not with H (its per-iterate sums come from the step
  * launches), not without compact lists. */
 int wide_coarse_levels_as_team(dvo_ctx *c, int pair, int n_levels, const int *iters, int flags, Schedule &sc, const double *h_pose_in,
-                               double *d_pose, unsigned &coarse_mask, bool &coarse_team) {
+                               double *d_pose, unsigned &coarse_mask, bool &coarse_team, bool allow_finest) {
     /* Two tiers, measured on one 4096x3072x5 and one 1920x1080x5 pair (profiles/r06_final/wide_team_sweep.txt): levels of up to 80 k points
      * as a team of 32 inside ONE XCD (records as plain stores), levels of up to 350 k points as a team of 128 over all XCDs (two-stage
      * exchange); larger levels -- and always the finest one, whose final outputs the step path writes -- keep the step launches.
      * DVO_WIDE_TEAM_MAX=a,b overrides the two limits (0 switches the whole thing off), DVO_WIDE_TEAM_SIZE=a,b the two team sizes. */
-    static int lim[2] = {80000, 350000}, size[2] = {32, 128};
+    /* allow_finest (one rank: nothing is sharded): a finest level of more than 350 k points joins as a third tier, a team of 256 over
+     * the whole chip, with the final outputs written by that launch -- then no step launch is left at all (sc comes back empty). */
+    static int lim[2] = {80000, 350000}, size[3] = {32, 128, 256};
     static const bool parsed = [] {
         if (const char *e = std::getenv("DVO_WIDE_TEAM_MAX")) { int a = 0, b = -1; const int n = std::sscanf(e, "%d,%d", &a, &b); lim[0] = a; lim[1] = n > 1 ? b : a; }
-        if (const char *e = std::getenv("DVO_WIDE_TEAM_SIZE")) { int a = 0, b = -1; const int n = std::sscanf(e, "%d,%d", &a, &b); size[0] = a; size[1] = n > 1 ? b : a; }
+        if (const char *e = std::getenv("DVO_WIDE_TEAM_SIZE")) { int a = 0, b = -1, d = -1; const int n = std::sscanf(e, "%d,%d,%d", &a, &b, &d); size[0] = a; size[1] = n > 1 ? b : a; if (n > 2) size[2] = d; }
         return true;
     }();
     (void)parsed;
@@ -1680,28 +1682,34 @@ int wide_coarse_levels_as_team(dvo_ctx *c, int pair, int n_levels, const int *it
         c->n_cu < 64 || c->stream == nullptr) return DVO_OK;
     int finest = -1;
     for (int l = 0; l < n_levels; l++) if (sc.iters[l] > 0) { finest = l; break; }
-    unsigned tier[2] = {0u, 0u};
+    /* the finest level joins only where it is what the third tier is for: a list no team of 128 should carry */
+    static const bool finest_off = std::getenv("DVO_WIDE_TEAM_FINEST") && !std::strcmp(std::getenv("DVO_WIDE_TEAM_FINEST"), "off");
+    const bool take_finest = allow_finest && !finest_off && finest >= 0 && c->lv[finest].hN[pair] > lim[1] && c->n_cu >= size[2] && size[2] >= 2 &&
+                             !c->lv[finest].compact_ok.empty() && c->lv[finest].compact_ok[pair];
+    unsigned tier[3] = {0u, 0u, 0u};
     bool big_enough = false;
-    for (int l = n_levels - 1; l > finest; l--) {               /* from the coarsest down; never the finest level */
+    for (int l = n_levels - 1; l >= (take_finest ? finest : finest + 1); l--) {               /* from the coarsest down */
         if (sc.iters[l] <= 0) continue;
         const int N = c->lv[l].hN[pair];
-        if (N > lim[1] || c->lv[l].compact_ok.empty() || !c->lv[l].compact_ok[pair]) break;
-        const int k = (N <= lim[0] && !tier[1]) ? 0 : 1;          /* once a level went to the second tier the finer ones follow */
+        if (c->lv[l].compact_ok.empty() || !c->lv[l].compact_ok[pair]) break;
+        if (N > lim[1] && !(take_finest && l == finest)) break;
+        const int k = (N > lim[1]) ? 2 : ((N <= lim[0] && !tier[1]) ? 0 : 1);          /* once a level went to a later tier the finer ones follow */
         if (k == 1 && (c->n_cu < size[1] || size[1] < 2)) break;
         tier[k] |= 1u << l;
         big_enough = big_enough || N > DVO_TILED_SOLO_MAX_DEFAULT;
     }
-    if (!big_enough || !(tier[0] | tier[1])) return DVO_OK;       /* small levels are one launch each already */
+    if (take_finest && !((tier[2] >> finest) & 1u)) tier[2] = 0;      /* the walk stopped above it: the finest level keeps its step launches */
+    if (!big_enough || !(tier[0] | tier[1] | tier[2])) return DVO_OK;       /* small levels are one launch each already */
     HIPCHK(c, hipMemcpyAsync(d_pose, h_pose_in, sizeof(double) * 12, hipMemcpyHostToDevice, c->stream));
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < 3; k++) {
         if (!tier[k]) continue;
         c->prm.team_size = size[k];
-        const int rc = enqueue(c, pair, 1, n_levels, iters, 0, tier[k]);
+        const int rc = enqueue(c, pair, 1, n_levels, iters, (k == 2) ? (flags & DVO_FLAG_FINAL_OUTPUTS) : 0, tier[k]);
         c->prm.team_size = 0;
         if (rc) return rc;
         coarse_team = coarse_team || c->team_used;
     }
-    coarse_mask = tier[0] | tier[1];
+    coarse_mask = tier[0] | tier[1] | tier[2];
     for (int l = 0; l < n_levels; l++) if ((coarse_mask >> l) & 1u) sc.iters[l] = 0;      /* what is left for the step launches */
     sc.last_level = -1;
     for (int l = n_levels - 1; l >= 0; l--) if (sc.iters[l] > 0) sc.last_level = l;
@@ -1822,14 +1830,18 @@ int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters,
     double *d_pose = c->d_poses + (size_t)12 * pair;
     unsigned coarse_mask = 0;
     bool coarse_team = false;
-    if ((rc = dvo_host::wide_coarse_levels_as_team(c, pair, n_levels, iters, flags, sc, h, d_pose, coarse_mask, coarse_team))) return rc;
+    if ((rc = dvo_host::wide_coarse_levels_as_team(c, pair, n_levels, iters, flags, sc, h, d_pose, coarse_mask, coarse_team, true))) return rc;
+    const bool all_team = coarse_mask != 0 && sc.last_level < 0;      /* every level ran inside team launches: no step launch, no graph */
     /* everything the enqueued sequence depends on; an unchanged signature replays the instantiated graph.  One launch per iteration
      * (round 4: the update of an iteration rides at the head of the next one's accumulate launch, the partial sums are added by the
      * workgroup that arrives last -- dvo_kernels.hip: tiled_step_kernel); rounds 1-3 used two. */
     const unsigned long long sig = step_schedule_signature(c, sc, pair, n_levels, flags, 0, 1) ^ ((unsigned long long)coarse_mask << 48);
     static const bool env_no_graph = std::getenv("DVO_WIDE_NO_GRAPH") != nullptr;  /* A/B switch for measurements */
     const bool no_graph = env_no_graph || c->stream == nullptr;                    /* the legacy null stream cannot be captured */
-    if (no_graph || !c->wide_exec || sig != c->wide_sig) {
+    if (all_team) {
+        HIPCHK(c, hipMemcpyAsync(h, d_pose, sizeof(double) * 12, hipMemcpyDeviceToHost, c->stream));
+        std::memset(h + 12, 0, sizeof(double));
+    } else if (no_graph || !c->wide_exec || sig != c->wide_sig) {
         if (c->wide_exec) { (void)hipGraphExecDestroy(c->wide_exec); c->wide_exec = nullptr; }
         if (!no_graph) HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         hipError_t first_err = hipSuccess;
@@ -1847,7 +1859,7 @@ int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters,
         }
         HIPCHK(c, first_err);
     }
-    if (!no_graph) HIPCHK(c, hipGraphLaunch(c->wide_exec, c->stream));
+    if (!no_graph && !all_team) HIPCHK(c, hipGraphLaunch(c->wide_exec, c->stream));
     HIPCHK(c, stream_wait(c->stream));
     { const int lrc = dvo_host::check_step_lost(c); if (lrc) return lrc; }
     std::memcpy(R, h, sizeof(double) * 9);
@@ -1855,6 +1867,7 @@ int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters,
     if (coarse_mask) {                                    /* the outputs follow the WHOLE schedule again */
         Schedule full;
         if ((rc = build_schedule(c, n_levels, iters, flags, full))) return rc;
+        full.final_blk = all_team ? 1 : 0;                /* final outputs written by the fused kernel sit in the compact list's order */
         sc = full;
     }
     c->wide_team_mask = (int)coarse_mask;

@@ -183,7 +183,8 @@ int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters
     bool coarse_team = false;
     /* DVO_TILED_TEAM_SHARED=1 (tests): hand the coarse levels over although several ranks share the device */
     if ((ranks_on_device_of(c) <= 1 || std::getenv("DVO_TILED_TEAM_SHARED") != nullptr) &&
-        (rc = dvo_host::wide_coarse_levels_as_team(c, pair, n_levels, iters, flags, sc, h, d_pose, coarse_mask, coarse_team))) return rc;
+        (rc = dvo_host::wide_coarse_levels_as_team(c, pair, n_levels, iters, flags, sc, h, d_pose, coarse_mask, coarse_team, T->world == 1))) return rc;
+    const bool all_team = coarse_mask != 0 && sc.last_level < 0;      /* one rank, every level inside team launches: the sequence below is two copies */
     /* Per iteration ONE kernel and ONE collective (round 4; rounds 1-3: accumulate, reduce, all-reduce, update): the update of an
      * iteration is applied at the head of the next iteration's launch by every workgroup of every rank from the same all-reduced
      * bits (dvo_kernels.hip: tiled_step_kernel), the 32 sums of a launch are written by its last workgroup.  The whole schedule,
@@ -244,6 +245,7 @@ int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters
     std::memcpy(R, h, sizeof(double) * 9);
     std::memcpy(t, h + 9, sizeof(double) * 3);
     if (coarse_mask && (rc = dvo_host::build_schedule(c, n_levels, iters, flags, sc))) return rc;      /* the outputs follow the WHOLE schedule */
+    if (all_team) sc.final_blk = 1;                        /* final outputs written by the fused kernel sit in the compact list's order */
     dvo_host::stamp_outputs(c, sc, pair, 1);
     c->sched = sc;
     c->have_sched = true;

@@ -274,7 +274,7 @@ int ensure_step_buffers(dvo_ctx *c);
 int team_err_check(dvo_ctx *c);       /* after a wait: DVO_ERR_HIP if a member of the last team launch gave up waiting for its team */
 /* the wide / tiled schedule's coarse levels as one team launch of the fused kernel (dvo_capi.cpp) */
 int wide_coarse_levels_as_team(dvo_ctx *c, int pair, int n_levels, const int *iters, int flags, dvo::Schedule &sc, const double *h_pose_in,
-                               double *d_pose, unsigned &coarse_mask, bool &coarse_team);
+                               double *d_pose, unsigned &coarse_mask, bool &coarse_team, bool allow_finest);
 int check_step_lost(dvo_ctx *c);      /* after the wait of a wide / tiled alignment: DVO_ERR_HIP if a step launch lost a workgroup's rows */
 unsigned long long step_schedule_signature(dvo_ctx *c, const dvo::Schedule &sc, int pair, int n_levels, int flags, int rank, int world);
 /* the reference lists of pairs [first, first + n) of a level were (re)written: bumps points_gen and the pairs' list stamps;

@@ -58,7 +58,7 @@ def test_config5_wide_path(scene4096, ctx4096):
         team = ctx4096.wide_team_levels()           # ... or, round 6, inside the fused kernel's team launches (the coarse levels of a large frame)
         assert ctx4096.wide_packed_levels() | team == (1 << len(iters)) - 1 and not (ctx4096.wide_packed_levels() & team)
         if not os.environ.get("DVO_WIDE_TEAM_MAX"):
-            assert team == 0b11110, bin(team)       # 29 k / 72 k points: a team of 32 in one XCD; 159 k / 327 k: a team of 128; 629 k: step launches
+            assert team == 0b11111, bin(team)       # 29 k / 72 k points: a team of 32 in one XCD; 159 k / 327 k: a team of 128; 629 k (one rank): a team of 256
     _check_reports(ctx4096, ref, iters)
     assert rot_angle(ref["R"], Rw) <= ROT_TOL and np.linalg.norm(ref["t"] - tw) <= TRANS_TOL
 
