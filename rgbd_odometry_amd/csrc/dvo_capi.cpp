@@ -505,6 +505,25 @@ void cast_pose(const double *R, const double *t, float *Rf, float *tf) {
     for (int k = 0; k < 3; k++) tf[k] = (float)t[k];       /* :674 */
 }
 
+/* Tiers of team launches for the COARSE levels of the wide / tiled schedule when the finest levels are sharded over ranks (round 6;
+ * measured: profiles/r06_final/wide_team_sweep.txt): levels of up to 80 k points as a team of 32 inside ONE XCD (records as plain
+ * stores), up to 350 k as a team of 128 over all XCDs (two-stage exchange).  DVO_WIDE_TEAM_MAX=a,b overrides the two limits (0 switches
+ * the team launches off), DVO_WIDE_TEAM_SIZE=a,b,c the team sizes.  (One rank: ONE launch of the whole pyramid, see below.) */
+struct TeamTiers { int lim[2] = {80000, 350000}; int size[3] = {32, 128, 256}; };
+static const TeamTiers &team_tiers() {
+    static const TeamTiers t = [] {
+        TeamTiers v;
+        if (const char *e = std::getenv("DVO_WIDE_TEAM_MAX")) { int a = 0, b = -1; const int n = std::sscanf(e, "%d,%d", &a, &b); v.lim[0] = a; v.lim[1] = n > 1 ? b : a; }
+        if (const char *e = std::getenv("DVO_WIDE_TEAM_SIZE")) { int a = 0, b = -1, d = -1; const int n = std::sscanf(e, "%d,%d,%d", &a, &b, &d); v.size[0] = a; v.size[1] = n > 1 ? b : a; if (n > 2) v.size[2] = d; }
+        return v;
+    }();
+    return t;
+}
+static bool team_tiers_possible(const dvo_ctx *c, int flags) {
+    return team_tiers().lim[1] > 0 && !(flags & DVO_FLAG_NORMAL_MATRIX) && !c->prm.interpolate_dt && c->prm.engine_variant != 1 && c->prm.team_size == 0 &&
+           c->n_cu >= 64 && c->stream != nullptr;
+}
+
 /* level_mask: the levels THIS launch runs (the energy layout stays that of the whole schedule `iters`): the wide schedule hands its
  * coarse levels to the fused team kernel and keeps the fine ones for its step launches (round 6, dvo_align_pyramid_wide) */
 int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *iters, int flags, unsigned level_mask = ~0u) {
@@ -688,7 +707,9 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
          * alignment by team size: 4096x3072x5 (629 k points at level 0) 32: 0.94, 64: 0.65-0.73, 128: 0.61-0.62, 256: 0.66
          * (all-CU wide path 0.78-0.80); 1920x1080x5 (130 k) 16: 0.52-0.54, 32: 0.54, 64: 0.48-0.49, 128: 0.50, 256: 0.57 (wide 0.58) */
         bool super_team = (n_pairs == 1 && n_fine >= 100000 && c->n_cu >= 256);
-        if (super_team) g = (n_fine >= 400000) ? 128 : 64;
+        /* round 6, compact now levels, one host round trip per alignment: 4096x3072x5 128: 0.353, 256: 0.332; 1920x1080x5 64: 0.275, 128: 0.289;
+         * a launch per tier of level sizes (32 / 128 / 256 members) 0.350 / 0.324: every launch stages its levels again and drains */
+        if (super_team) g = (n_fine >= 400000) ? 256 : 64;
         if (c->prm.team_size > 1) {
             g = c->prm.team_size;
             super_team = (g == 64 || g == 128 || g == 256) && n_pairs == 1;
@@ -696,12 +717,32 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
                 return fail(c, DVO_ERR_INVALID, "team_size: the launch would need more workgroups than compute units (members must be co-resident; 64 / 128 / 256 only for a single pair)");
         }
         if (g > 1) {
+            const size_t buf_bytes = 16 * 2 * 32 * 8 * (size_t)std::max(c->n_pairs, 9);     /* 16-byte records, [2][32][8] per pair (a team over all XCDs: 8 + 1 slots) */
+            bool zero = false;
             if (!c->d_team_buf) {
-                HIPCHK(c, hipMalloc((void **)&c->d_team_buf, 16 * 2 * 32 * 8 * (size_t)std::max(c->n_pairs, 9)));     /* 16-byte records, [2][32][8] per pair (a team over all XCDs: 8 + 1 slots) */
+                HIPCHK(c, hipMalloc((void **)&c->d_team_buf, buf_bytes));
                 HIPCHK(c, hipMalloc((void **)&c->d_team_cnt, sizeof(unsigned) * ((size_t)c->n_pairs + 1)));
+                zero = c->team_err_dirty = true;
             }
-            HIPCHK(c, hipMemsetAsync(c->d_team_cnt, 0, sizeof(unsigned) * ((size_t)c->n_pairs + 1), c->stream));
-            HIPCHK(c, hipMemsetAsync(c->d_team_buf, 0, 16 * 2 * 32 * 8 * (size_t)(g > 32 ? 9 : n_pairs), c->stream));       /* tags of an earlier launch */
+            /* A record is {value, tag}, tag = exchange count + 1.  Rounds 2-5 zeroed the records before every launch (two fills, ~10 us of
+             * a 240 us single-pair alignment); since round 6 the count runs on from launch to launch, so whatever an earlier launch left
+             * carries a tag below every tag this one waits for.  Zeroed only when the 32-bit count would wrap -- and always once a launch
+             * was captured into a caller's graph (its replays would repeat their tags). */
+            unsigned need = 2;
+            for (int l = 0; l < n_levels; l++) if (sc.iters[l] > 0) need += (unsigned)sc.iters[l] + 1u;
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (c->stream && hipStreamIsCapturing(c->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) c->team_legacy = true;
+            if (c->team_legacy || c->team_epoch > 0xfffffff0u - need) zero = true;
+            if (zero) {
+                HIPCHK(c, hipMemsetAsync(c->d_team_buf, 0, buf_bytes, c->stream));
+                c->team_epoch = 0;
+            }
+            if (c->team_err_dirty || c->team_legacy) {
+                HIPCHK(c, hipMemsetAsync(c->d_team_cnt, 0, sizeof(unsigned) * ((size_t)c->n_pairs + 1), c->stream));
+                c->team_err_dirty = false;
+            }
+            sc.team_epoch0 = c->team_epoch;
+            if (!c->team_legacy) c->team_epoch += need;
             sc.team = g;
             c->team_used = true;
         }
@@ -1367,8 +1408,9 @@ int dvo_get_now_compact_partial(dvo_ctx *c, int pair, int level, int *partial) {
 }
 
 /* ---- hot path ---------------------------------------------------------------- */
-int dvo_set_poses(dvo_ctx *c, int first_pair, int n_pairs, const double *R, const double *t) {
-    DVO_ENTER(c);
+/* wait = false (dvo_align_batch): the launch that reads the poses follows on the same stream, and every host-side writer of the staging
+ * buffer waits for the stream first -- no host round trip for the upload */
+static int set_poses_impl(dvo_ctx *c, int first_pair, int n_pairs, const double *R, const double *t, bool wait) {
     if (!pair_ok(c, first_pair) || n_pairs < 1 || first_pair + n_pairs > c->n_pairs || !R || !t)
         return fail(c, DVO_ERR_INVALID, "bad pose arguments");
     if (!c->h_poses) HIPCHK(c, hipHostMalloc((void **)&c->h_poses, sizeof(double) * (12 * (size_t)c->n_pairs + 2), hipHostMallocDefault));
@@ -1380,8 +1422,12 @@ int dvo_set_poses(dvo_ctx *c, int first_pair, int n_pairs, const double *R, cons
     }
     HIPCHK(c, hipMemcpyAsync(c->d_poses + (size_t)12 * first_pair, h, sizeof(double) * 12 * (size_t)n_pairs,
                              hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, stream_wait(c->stream));
+    if (wait) HIPCHK(c, stream_wait(c->stream));
     return DVO_OK;
+}
+int dvo_set_poses(dvo_ctx *c, int first_pair, int n_pairs, const double *R, const double *t) {
+    DVO_ENTER(c);
+    return set_poses_impl(c, first_pair, n_pairs, R, t, true);
 }
 
 /* team mode: a member that gave up waiting for its team leaves a flag; every result of that launch is void */
@@ -1393,6 +1439,7 @@ static int check_team_err(dvo_ctx *c) {
     HIPCHK(c, hipMemcpyAsync(flag, c->d_team_cnt + c->n_pairs, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, stream_wait(c->stream));
     const int team_err = *flag;
+    if (team_err) c->team_err_dirty = true;
     if (team_err)
         return fail(c, DVO_ERR_HIP, "team mode: a workgroup gave up waiting for its team (members were not resident together); "
                                     "the results of that launch are void -- set dvo_params.team_size = 1");
@@ -1405,10 +1452,16 @@ int dvo_get_poses(dvo_ctx *c, int first_pair, int n_pairs, double *R, double *t)
         return fail(c, DVO_ERR_INVALID, "bad pose arguments");
     if (!c->h_poses) HIPCHK(c, hipHostMalloc((void **)&c->h_poses, sizeof(double) * (12 * (size_t)c->n_pairs + 2), hipHostMallocDefault));
     double *h = c->h_poses;
+    int *flag = reinterpret_cast<int *>(c->h_poses + 12 * (size_t)c->n_pairs);      /* team mode: the error word rides on the same wait */
+    *flag = 0;
+    if (c->team_used) HIPCHK(c, hipMemcpyAsync(flag, c->d_team_cnt + c->n_pairs, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h, c->d_poses + (size_t)12 * first_pair, sizeof(double) * 12 * (size_t)n_pairs,
                              hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, stream_wait(c->stream));
-    { const int trc = check_team_err(c); if (trc) return trc; }
+    if (c->team_used && *flag) c->team_err_dirty = true;
+    if (c->team_used && *flag)
+        return fail(c, DVO_ERR_HIP, "team mode: a workgroup gave up waiting for its team (members were not resident together); "
+                                    "the results of that launch are void -- set dvo_params.team_size = 1");
     for (int p = 0; p < n_pairs; p++) {
         std::memcpy(R + 9 * p, &h[12 * p], sizeof(double) * 9);
         std::memcpy(t + 3 * p, &h[12 * p + 9], sizeof(double) * 3);
@@ -1424,7 +1477,9 @@ int dvo_align_batch_enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_level
 int dvo_align_batch(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *iters,
                     int flags, double *R, double *t) {
     DVO_ENTER(c);
-    int rc = dvo_set_poses(c, first_pair, n_pairs, R, t);
+    if (!pair_ok(c, first_pair) || n_pairs < 1 || first_pair + n_pairs > c->n_pairs || !R || !t)
+        return fail(c, DVO_ERR_INVALID, "bad pose arguments");
+    int rc = set_poses_impl(c, first_pair, n_pairs, R, t, false);
     if (rc) return rc;
     if ((rc = enqueue(c, first_pair, n_pairs, n_levels, iters, flags & ~DVO_FLAG_IDENTITY_START))) return rc;
     return dvo_get_poses(c, first_pair, n_pairs, R, t);
@@ -1652,6 +1707,18 @@ static void shard_of(int n, int rank, int world, int &first, int &count) {      
 }
 
 int team_err_check(dvo_ctx *c) { return check_team_err(c); }
+/* the same without a host round trip of its own: the error word travels into a pinned slot in front of a wait the caller makes anyway */
+hipError_t team_err_fetch(dvo_ctx *c, int *pinned_slot) {
+    *pinned_slot = 0;
+    if (!c->team_used || !c->d_team_cnt) return hipSuccess;
+    return hipMemcpyAsync(pinned_slot, c->d_team_cnt + c->n_pairs, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+}
+int team_err_result(dvo_ctx *c, const int *pinned_slot) {
+    if (!*pinned_slot) return DVO_OK;
+    c->team_err_dirty = true;
+    return fail(c, DVO_ERR_HIP, "team mode: a workgroup gave up waiting for its team (members were not resident together); "
+                                "the results of that launch are void -- set dvo_params.team_size = 1");
+}
 
 /* Round 6: the coarse levels of a large frame do not need 256 CUs -- a step launch costs ~7 us whatever it
  * holds (boundary + 255 -> 1 fan-in + the update at its head), an iteration of the fused kernel's team inside one XCD ~3-5 us.
@@ -1669,23 +1736,35 @@ int wide_coarse_levels_as_team(dvo_ctx *c, int pair, int n_levels, const int *it
      * DVO_WIDE_TEAM_MAX=a,b overrides the two limits (0 switches the whole thing off), DVO_WIDE_TEAM_SIZE=a,b the two team sizes. */
     /* allow_finest (one rank: nothing is sharded): a finest level of more than 350 k points joins as a third tier, a team of 256 over
      * the whole chip, with the final outputs written by that launch -- then no step launch is left at all (sc comes back empty). */
-    static int lim[2] = {80000, 350000}, size[3] = {32, 128, 256};
-    static const bool parsed = [] {
-        if (const char *e = std::getenv("DVO_WIDE_TEAM_MAX")) { int a = 0, b = -1; const int n = std::sscanf(e, "%d,%d", &a, &b); lim[0] = a; lim[1] = n > 1 ? b : a; }
-        if (const char *e = std::getenv("DVO_WIDE_TEAM_SIZE")) { int a = 0, b = -1, d = -1; const int n = std::sscanf(e, "%d,%d,%d", &a, &b, &d); size[0] = a; size[1] = n > 1 ? b : a; if (n > 2) size[2] = d; }
-        return true;
-    }();
-    (void)parsed;
+    const int *lim = team_tiers().lim, *size = team_tiers().size;
     coarse_mask = 0;
     coarse_team = false;
-    if (lim[1] <= 0 || (flags & DVO_FLAG_NORMAL_MATRIX) || c->prm.interpolate_dt || c->prm.engine_variant == 1 || c->prm.team_size != 0 ||
-        c->n_cu < 64 || c->stream == nullptr) return DVO_OK;
+    if (!team_tiers_possible(c, flags)) return DVO_OK;
     int finest = -1;
     for (int l = 0; l < n_levels; l++) if (sc.iters[l] > 0) { finest = l; break; }
     /* the finest level joins only where it is what the third tier is for: a list no team of 128 should carry */
     static const bool finest_off = std::getenv("DVO_WIDE_TEAM_FINEST") && !std::strcmp(std::getenv("DVO_WIDE_TEAM_FINEST"), "off");
     const bool take_finest = allow_finest && !finest_off && finest >= 0 && c->lv[finest].hN[pair] > lim[1] && c->n_cu >= size[2] && size[2] >= 2 &&
                              !c->lv[finest].compact_ok.empty() && c->lv[finest].compact_ok[pair];
+    /* One rank (nothing is sharded): the whole pyramid as ONE team launch of the fused kernel, team size by the finest level exactly as
+     * dvo_align_batch picks it.  Measured on the compact now form, ms per alignment (tools/experiments/exp_team_single.py, PREP=1):
+     * 4096x3072x5 0.332 (a launch per tier 0.350-0.363), 1920x1080x5 0.275 (0.312-0.324), 640x480x4 0.188 (one launch per level by one
+     * workgroup, rounds 4-5: 0.246) -- every further launch stages its levels again and drains. */
+    static const bool one_off = std::getenv("DVO_WIDE_ONE_LAUNCH") && !std::strcmp(std::getenv("DVO_WIDE_ONE_LAUNCH"), "off");
+    if (allow_finest && !finest_off && !one_off && finest >= 0 && c->lv[finest].hN[pair] >= 5000) {
+        bool all_compact = true;
+        for (int l = 0; l < n_levels; l++)
+            if (sc.iters[l] > 0 && (c->lv[l].compact_ok.empty() || !c->lv[l].compact_ok[pair])) all_compact = false;
+        if (all_compact) {
+            HIPCHK(c, hipMemcpyAsync(d_pose, h_pose_in, sizeof(double) * 12, hipMemcpyHostToDevice, c->stream));
+            const int rc = enqueue(c, pair, 1, n_levels, iters, flags & DVO_FLAG_FINAL_OUTPUTS);
+            if (rc) return rc;
+            coarse_team = c->team_used;
+            for (int l = 0; l < n_levels; l++) if (sc.iters[l] > 0) { coarse_mask |= 1u << l; sc.iters[l] = 0; }
+            sc.last_level = -1;
+            return DVO_OK;
+        }
+    }
     unsigned tier[3] = {0u, 0u, 0u};
     bool big_enough = false;
     for (int l = n_levels - 1; l >= (take_finest ? finest : finest + 1); l--) {               /* from the coarsest down */
@@ -1823,7 +1902,7 @@ int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters,
         if (sc.iters[l] > 0 && ((rc = check_ready(c, pair, l)) || (rc = ensure_tex16(c, l, pair, 1)))) return rc;
     if ((rc = ensure_outputs(c, sc))) return rc;
     if ((rc = ensure_step_buffers(c))) return rc;
-    if (!c->h_pose) HIPCHK(c, hipHostMalloc((void **)&c->h_pose, sizeof(double) * 13, hipHostMallocDefault));      /* [12]: the step launches' error word */
+    if (!c->h_pose) HIPCHK(c, hipHostMalloc((void **)&c->h_pose, sizeof(double) * 14, hipHostMallocDefault));      /* [12]: the step launches' error word, [13]: the team launches' */
     double *h = c->h_pose;
     std::memcpy(h, R, sizeof(double) * 9);
     std::memcpy(h + 9, t, sizeof(double) * 3);
@@ -1860,8 +1939,11 @@ int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters,
         HIPCHK(c, first_err);
     }
     if (!no_graph && !all_team) HIPCHK(c, hipGraphLaunch(c->wide_exec, c->stream));
+    c->team_used = coarse_team;
+    HIPCHK(c, dvo_host::team_err_fetch(c, reinterpret_cast<int *>(h + 13)));
     HIPCHK(c, stream_wait(c->stream));
     { const int lrc = dvo_host::check_step_lost(c); if (lrc) return lrc; }
+    { const int trc = dvo_host::team_err_result(c, reinterpret_cast<const int *>(h + 13)); if (trc) return trc; }
     std::memcpy(R, h, sizeof(double) * 9);
     std::memcpy(t, h + 9, sizeof(double) * 3);
     if (coarse_mask) {                                    /* the outputs follow the WHOLE schedule again */
@@ -1875,7 +1957,6 @@ int dvo_align_pyramid_wide(dvo_ctx *c, int pair, int n_levels, const int *iters,
     c->sched = sc;
     c->have_sched = true;
     c->team_used = coarse_team;
-    if (coarse_team) { const int trc = check_team_err(c); if (trc) return trc; }
     return DVO_OK;
 }
 

@@ -172,7 +172,7 @@ int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters
         if (sc.iters[l] > 0 && ((rc = dvo_host::check_ready(c, pair, l)) || (rc = dvo_host::ensure_tex16(c, l, pair, 1)))) return rc;
     if ((rc = dvo_host::ensure_outputs(c, sc))) return rc;
     if ((rc = dvo_host::ensure_step_buffers(c))) return rc;
-    if (!c->h_pose) HIPCHK(c, hipHostMalloc((void **)&c->h_pose, sizeof(double) * 13, hipHostMallocDefault));      /* [12]: the step launches' error word */
+    if (!c->h_pose) HIPCHK(c, hipHostMalloc((void **)&c->h_pose, sizeof(double) * 14, hipHostMallocDefault));      /* [12]: the step launches' error word, [13]: the team launches' */
     double *h = c->h_pose;
     std::memcpy(h, R, sizeof(double) * 9);
     std::memcpy(h + 9, t, sizeof(double) * 3);
@@ -240,8 +240,11 @@ int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters
     } else {
         HIPCHK(c, hipGraphLaunch(c->tiled_exec, c->stream));
     }
+    c->team_used = coarse_team;
+    HIPCHK(c, dvo_host::team_err_fetch(c, reinterpret_cast<int *>(h + 13)));
     HIPCHK(c, stream_wait(c->stream));
     { const int lrc = dvo_host::check_step_lost(c); if (lrc) return lrc; }
+    if ((rc = dvo_host::team_err_result(c, reinterpret_cast<const int *>(h + 13)))) return rc;
     std::memcpy(R, h, sizeof(double) * 9);
     std::memcpy(t, h + 9, sizeof(double) * 3);
     if (coarse_mask && (rc = dvo_host::build_schedule(c, n_levels, iters, flags, sc))) return rc;      /* the outputs follow the WHOLE schedule */
@@ -252,7 +255,6 @@ int dvo_align_pyramid_tiled(dvo_ctx *c, int pair, int n_levels, const int *iters
     c->team_used = coarse_team;
     c->tiled_graph_used = !direct;
     c->wide_team_mask = (int)coarse_mask;
-    if (coarse_team && (rc = dvo_host::team_err_check(c))) return rc;
     return DVO_OK;
 }
 

@@ -130,6 +130,9 @@ struct dvo_ctx {
     double *d_team_buf = nullptr;
     unsigned *d_team_cnt = nullptr;      /* n_pairs counters followed by one int error flag */
     int last_block = 0, last_team = 0, last_packed = 0;   /* shape of the last fused launch (dvo_get_last_launch_shape) */
+    unsigned team_epoch = 0;             /* team mode: exchanges every launch so far may have run (Schedule.team_epoch0 of the next launch) */
+    bool team_legacy = false;            /* a team launch was captured into a caller's graph once: zero the records before every launch again */
+    bool team_err_dirty = false;         /* the device's error word is set (reported by the getters): the next team launch clears it */
     bool team_used = false;              /* the last enqueue ran in team mode: dvo_get_poses checks the error flag */      /* n_pairs x DVO_LEVELS, written by the packed fused kernel */
     int final_cap = 0;
     double *d_scratch = nullptr;    /* partials (1024 x 32) + acc (32) + misc doubles */
@@ -271,6 +274,8 @@ int refresh_p4_known(dvo_ctx *c, int level, int first, int count, bool skip_nati
 hipError_t enqueue_step_schedule(dvo_ctx *c, const dvo::Schedule &sc, int pair, int flags, double *d_pose, int rank, int world,
                                  const std::function<hipError_t(double *)> &all_reduce);
 int ensure_step_buffers(dvo_ctx *c);
+hipError_t team_err_fetch(dvo_ctx *c, int *pinned_slot);      /* the error word of the last team launch -> a pinned slot, on the stream (no wait) */
+int team_err_result(dvo_ctx *c, const int *pinned_slot);       /* after the caller's wait: DVO_ERR_HIP if it was set */
 int team_err_check(dvo_ctx *c);       /* after a wait: DVO_ERR_HIP if a member of the last team launch gave up waiting for its team */
 /* the wide / tiled schedule's coarse levels as one team launch of the fused kernel (dvo_capi.cpp) */
 int wide_coarse_levels_as_team(dvo_ctx *c, int pair, int n_levels, const int *iters, int flags, dvo::Schedule &sc, const double *h_pose_in,

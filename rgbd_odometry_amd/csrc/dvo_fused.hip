@@ -886,7 +886,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
      * the whole kernel (the 256-thread shape has exactly the 256 registers two waves per SIMD allow) */
     const int pair = __builtin_amdgcn_readfirstlane(first_pair + pair_local);
     const int tid = threadIdx.x;
-    unsigned epoch = 0;                          /* exchanges done so far (team mode) */
+    unsigned epoch = TEAM ? sc.team_epoch0 : 0u;  /* team mode: exchanges done so far, counted on from the launches before (record tag = epoch + 1) */
     /* Team mode, once per launch: do the members that exchange records directly (a team of up to 32, or the members of one XCD
      * of a team over all XCDs) really share an XCD?  The placement (workgroup b on XCD b % 8) is an observation, not a contract:
      * every member publishes its HW_REG_XCC_ID and its square through the sc1 exchange; sum x = G x and sum x^2 = G x^2 hold for
@@ -905,7 +905,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             const double sx = readlane_f64(tot, 0), sxx = readlane_f64(tot, 1);
             team_same_xcd = !sc.team_no_plain && sx == (double)Gs * x && sxx == (double)Gs * (x * x);
         }
-        epoch = 1;
+        epoch = sc.team_epoch0 + 1u;
     }
     /* one exchange of wave 0's eight lane values over the whole team (two stages beyond one XCD); `epoch` is advanced by the caller */
     auto team_total = [&](double sl) -> double {

@@ -69,6 +69,7 @@ struct Schedule {
     int final_blk;           /* host bookkeeping: the final outputs of this launch are stored in the compact lists' (block) order */
     int team_no_plain;       /* diagnostics (DVO_TEAM_PLAIN_STORES=off): team records always travel as sc1 stores, even inside one XCD */
     int no_r16;              /* diagnostics (DVO_RANKS_LDS=off): never stage a coarse level's ranks into LDS */
+    unsigned team_epoch0;    /* team mode: tags of this launch's records start above every tag an earlier launch left in the buffer (no memset between launches) */
     int team_solo_max;       /* team mode: a level with at most this many points is run by member 0 alone, the others pick its pose up
                                 at the level's end (dvo_fused.hip: solo levels; DVO_TEAM_SOLO_MAX, 0 = every level by the whole team) */
 };
@@ -89,7 +90,7 @@ struct Outputs {
     int final_cap;
     unsigned long long *dbg; /* diagnostics (DVO_STAMPS builds): n_pairs x 64 counters, else NULL */
     double *H;               /* DVO_FLAG_NORMAL_MATRIX: n_pairs x e_stride x 21 (upper triangle of sum w J J^T per iterate), else NULL */
-    double *team_buf;        /* team mode: n_pairs x 2 x 16 x 8 records of 16 bytes {value, tag} (partial sums of the members, double-buffered; zero before the launch) */
+    double *team_buf;        /* team mode: n_pairs x 2 x 16 x 8 records of 16 bytes {value, tag} (partial sums of the members, double-buffered; tags of earlier launches are all below Schedule.team_epoch0 + 1) */
     unsigned *team_cnt;      /* (unused by the kernel; the int after n_pairs entries is the error flag) */
     int *team_err;           /* set to 1 by a member that gave up waiting (members not co-resident) */
     int *tex_mode;           /* n_pairs x DVO_LEVELS: where the fused kernel read the now level from (DVO_TEXMODE_*), inspection */

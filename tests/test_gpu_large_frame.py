@@ -66,7 +66,7 @@ def test_config5_wide_path(scene4096, ctx4096):
 @pytest.mark.parametrize("team", [0, 64, 128, 256, 32])
 def test_config5_team_over_all_xcds(scene4096, team):
     """the fused kernel with ONE pair spread over the whole GPU: a team of 8 x g1 workgroups, sums exchanged inside every XCD
-    and then between the 8 XCDs (auto = 128 for this frame); same bits as the oracle, run-to-run deterministic, final outputs
+    and then between the 8 XCDs (auto = a launch per tier of level sizes, 32 / 128 / 256 members); same bits as the oracle, run-to-run deterministic, final outputs
     of the best iterate included"""
     from rgbd_odometry_amd import DvoContext
     from rgbd_odometry_amd.capi import DVO_FLAG_FINAL_OUTPUTS
@@ -78,7 +78,7 @@ def test_config5_team_over_all_xcds(scene4096, team):
             ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols)
         R, t = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)), flags=DVO_FLAG_FINAL_OUTPUTS)
         blk, g, packed = ctx.last_launch_shape()
-        assert packed and blk == 512 and g == (team if team else 128), (blk, g, packed)
+        assert packed and blk == 512 and g == (team if team else 256), (blk, g, packed)      # auto: tiers of 32 / 128 / 256, the finest level last
         _check_reports(ctx, ref, iters)
         assert rot_angle(ref["R"], R[0]) <= ROT_TOL and np.linalg.norm(ref["t"] - t[0]) <= TRANS_TOL
         last = ref["levels"][ref["last_level"]]

@@ -15,6 +15,7 @@ for team in [int(x) for x in os.environ.get("TEAMS", "1,2,4,8,16,32,64,128,256,0
         for l, L in enumerate(sc.levels):
             ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols)
             ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols)
+        if os.environ.get("PREP"): ctx.now_prepare()        # the compact now form at once (otherwise it appears after 16 alignments: the loops below would mix the two)
         R, t = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
         t0 = time.perf_counter()
         for _ in range(20): R, t = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
