@@ -544,9 +544,61 @@ void dvo_oracle_rotationize(double *R) {
 static void accumulate_from(const float *J, const float *eps, const float *w, const int *vis, int n,
                             double *acc29);
 
+/* ---- sum of eps^2 without an order (round 6) -------------------------------------------------------------------------------
+ * aggregateEpsilons (:1310-1312) is epsilon.norm(): a float sum whose order is Eigen's business.  The oracle's definition since round 1
+ * is E = (float)sqrt(S), S = sum of (double)eps_i^2; rounds 1-5 added the terms one by one, so S -- and, once in ~50 000 energies, the
+ * float E -- depended on the order, which no parallel sum can reproduce.  Since round 6 S is the CORRECTLY ROUNDED double of the exact
+ * sum: every eps^2 is a 48-bit integer times a power of four; on the grid of 2^-68 the terms of |eps| in [2^-11, 2^12) (every
+ * normalised distance, :1063-1098) are integers below 2^92, summed exactly in three 32-bit limbs (kept as doubles: < 2^53 for up to 2^21
+ * points, so partial sums of shards add exactly in ANY order -- tiled mode all-reduces them) and rounded once.  A value outside that
+ * range (never produced by the pipeline) marks limb 2 with 2^50 and the sequential sum is used as before. */
+static const int kE2Exp0 = 116, kE2MaxBinades = 22;
+static const double kE2Bad = 1125899906842624.0;      /* 2^50 */
+void dvo_oracle_e2_limbs(const float *eps, int n, double *limbs3) {
+    unsigned long long L[3] = {0ull, 0ull, 0ull};
+    double bad = 0.0;
+    for (int i = 0; i < n; i++) {
+        unsigned bits;
+        std::memcpy(&bits, &eps[i], 4);
+        bits &= 0x7fffffffu;
+        if (bits == 0u) continue;
+        const int e = (int)(bits >> 23);
+        if (e < kE2Exp0 || e > kE2Exp0 + kE2MaxBinades) { bad += 1.0; continue; }
+        const unsigned long long m = (bits & 0x7fffffu) | 0x800000u;
+        const unsigned __int128 v = (unsigned __int128)(m * m) << (2 * (e - kE2Exp0));
+        L[0] += (unsigned long long)(v & 0xffffffffu);
+        L[1] += (unsigned long long)((v >> 32) & 0xffffffffu);
+        L[2] += (unsigned long long)(v >> 64);
+    }
+    limbs3[0] = (double)L[0];
+    limbs3[1] = (double)L[1];
+    limbs3[2] = (double)L[2] + bad * kE2Bad;
+}
+/* limbs (possibly sums of several shards' limbs) -> the correctly rounded double of the exact sum; `fallback` when a term was out of range */
+double dvo_oracle_e2_from_limbs(const double *limbs3, double fallback) {
+    if (!(limbs3[2] < kE2Bad)) return fallback;
+    unsigned __int128 S = (unsigned __int128)(unsigned long long)limbs3[0] + ((unsigned __int128)(unsigned long long)limbs3[1] << 32) +
+                          ((unsigned __int128)(unsigned long long)limbs3[2] << 64);
+    if (S == 0) return 0.0;
+    int p = 127;
+    while (!((S >> p) & 1)) p--;
+    if (p <= 52) return std::ldexp((double)(unsigned long long)S, -68);
+    const int r = p - 52;
+    unsigned long long q = (unsigned long long)(S >> r);
+    const unsigned __int128 rem = S & ((((unsigned __int128)1) << r) - 1), half = ((unsigned __int128)1) << (r - 1);
+    if (rem > half || (rem == half && (q & 1ull))) q++;
+    return std::ldexp((double)q, r - 68);
+}
+static double sum_eps2_exact(const float *eps, int n) {
+    double seq = 0.0, limbs[3];
+    for (int i = 0; i < n; i++) seq += (double)eps[i] * (double)eps[i];
+    dvo_oracle_e2_limbs(eps, n, limbs);
+    return dvo_oracle_e2_from_limbs(limbs, seq);
+}
+
 /* The 29 sums of one evaluation over points [first, first+n) at a float pose:
  * acc[0..20] upper triangle of sum w J J^T, acc[21..26] g = (J^T W) eps (:714-720, :777),
- * acc[27] sum eps^2 (:1312), acc[28] number of visible points.  Sequential order. */
+ * acc[27] sum eps^2 (:1312; correctly rounded exact sum), acc[28] number of visible points.  The others: sequential order. */
 void dvo_oracle_accumulate(const dvo_oracle_params *prm, int level, const float *xyz, int first, int n,
                            const float *dt, const float *gx, const float *gy, int rows, int cols,
                            float fx, float fy, float cx, float cy,
@@ -556,6 +608,19 @@ void dvo_oracle_accumulate(const dvo_oracle_params *prm, int level, const float 
     dvo_oracle_eval_points(prm, level, xyz + 3 * (size_t)first, n, dt, gx, gy, rows, cols, fx, fy, cx, cy,
                            cR_32, cT_32, nullptr, J.data(), eps.data(), w.data(), vis.data());
     accumulate_from(J.data(), eps.data(), w.data(), vis.data(), n, acc29);
+}
+/* the same with the three limbs of the range's exact sum of eps^2 in acc32[29..31] (tiled mode: the ranks' limbs add exactly, the
+ * reduced acc32[27] is then replaced by dvo_oracle_e2_from_limbs(acc32 + 29, acc32[27])) */
+void dvo_oracle_accumulate32(const dvo_oracle_params *prm, int level, const float *xyz, int first, int n,
+                             const float *dt, const float *gx, const float *gy, int rows, int cols,
+                             float fx, float fy, float cx, float cy,
+                             const float *cR_32, const float *cT_32, double *acc32) {
+    std::vector<float> J(6 * (size_t)n), eps(n), w(n);
+    std::vector<int> vis(n);
+    dvo_oracle_eval_points(prm, level, xyz + 3 * (size_t)first, n, dt, gx, gy, rows, cols, fx, fy, cx, cy,
+                           cR_32, cT_32, nullptr, J.data(), eps.data(), w.data(), vis.data());
+    accumulate_from(J.data(), eps.data(), w.data(), vis.data(), n, acc32);
+    dvo_oracle_e2_limbs(eps.data(), n, acc32 + 29);
 }
 
 static void accumulate_from(const float *J, const float *eps, const float *w, const int *vis, int n,
@@ -568,9 +633,9 @@ static void accumulate_from(const float *J, const float *eps, const float *w, co
         int h = 0;
         for (int a_ = 0; a_ < 6; a_++)
             for (int b_ = a_; b_ < 6; b_++) acc29[h++] += (double)jw[a_] * (double)J[6 * i + b_];
-        acc29[27] += (double)eps[i] * (double)eps[i];
         if (vis[i]) acc29[28] += 1.0;
     }
+    acc29[27] = sum_eps2_exact(eps, n);                 /* the correctly rounded exact sum, see above */
 }
 
 /* ---- runIterations as an explicit state machine (same arithmetic as :642-1005) ---- */
@@ -592,7 +657,7 @@ int dvo_oracle_state_update(const dvo_oracle_params *prm, dvo_oracle_state *s, i
                             double *psi_out) {
     double *cR = s->R, *cT = s->t;
     /* aggregateEpsilons (:1310-1312) = epsilon.norm().  Oracle definition:
-     * (float)sqrt(sum of (double)eps^2), order-insensitive before narrowing. */
+     * (float)sqrt(S), S = the correctly rounded exact sum of (double)eps^2 (sum_eps2_exact above): no order. */
     const float currentTotalEpsilon = (float)std::sqrt(sum_eps2);
     *energy_out = currentTotalEpsilon;                              /* :690 */
     const float ratio_of_visible_pts = (float)n_vis / (float)N;     /* :457 */

@@ -116,6 +116,16 @@ void dvo_oracle_accumulate(const dvo_oracle_params *prm, int level, const float 
                            float fx, float fy, float cx, float cy,
                            const float *Rf, const float *tf, double *acc29);
 
+/* acc32[0..28] as above; acc32[29..31] = the three limbs of the range's EXACT sum of eps^2 (integers below 2^53 held in doubles, unit
+ * 2^-68: limbs of several ranges add exactly in any order).  dvo_oracle_e2_from_limbs turns (summed) limbs into the correctly rounded
+ * double of the exact sum -- what acc[27] holds for one range; `fallback` is returned when a term was outside [2^-11, 2^12). */
+void dvo_oracle_accumulate32(const dvo_oracle_params *prm, int level, const float *xyz, int first, int n,
+                             const float *dt, const float *gx, const float *gy, int rows, int cols,
+                             float fx, float fy, float cx, float cy,
+                             const float *Rf, const float *tf, double *acc32);
+void dvo_oracle_e2_limbs(const float *eps, int n, double *limbs3);
+double dvo_oracle_e2_from_limbs(const double *limbs3, double fallback);
+
 /* runIterations as an explicit state machine (what run_iterations itself uses), so that a
  * host-driven loop -- e.g. the multi-GPU tiled mode with an all-reduce between the per-point
  * phase and the update -- can be checked step by step. */

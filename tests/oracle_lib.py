@@ -125,6 +125,27 @@ class Oracle:
                                        *[C.c_float(k) for k in K], _p(Rf), _p(tf), _p(acc))
         return acc
 
+    def accumulate32(self, level, xyz, first, n, dt, gx, gy, rows, cols, K, R, t, params=None):
+        """the 29 accumulators + the three limbs of the exact sum of eps^2 in [29..31] (they add exactly over shards)"""
+        xyz = _f32(xyz).reshape(-1)
+        Rf = np.asfortranarray(np.asarray(R, dtype=np.float64)).astype(np.float32, order="F")
+        tf = np.asarray(t, dtype=np.float64).astype(np.float32)
+        acc = np.zeros(32)
+        self.lib.dvo_oracle_accumulate32(C.byref(params) if params is not None else C.byref(self.default_params()),
+                                         level, _p(xyz), first, n, _p(_f32(dt)), _p(_f32(gx)), _p(_f32(gy)), rows, cols,
+                                         *[C.c_float(k) for k in K], _p(Rf), _p(tf), _p(acc))
+        return acc
+
+    def e2_limbs(self, eps):
+        eps = _f32(eps).reshape(-1)
+        limbs = np.zeros(3)
+        self.lib.dvo_oracle_e2_limbs(_p(eps), eps.size, _p(limbs))
+        return limbs
+
+    def e2_from_limbs(self, limbs, fallback=float("nan")):
+        limbs = np.ascontiguousarray(limbs, dtype=np.float64)
+        return float(self.lib.dvo_oracle_e2_from_limbs(_p(limbs), C.c_double(fallback)))
+
     def state_begin(self, R, t) -> OracleState:
         st = OracleState()
         R = np.array(R, dtype=np.float64, order="F")
@@ -406,6 +427,12 @@ def load() -> Oracle:
         lib.dvo_oracle_accumulate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_void_p] * 3
         lib.dvo_oracle_accumulate.restype = None
+        lib.dvo_oracle_accumulate32.argtypes = lib.dvo_oracle_accumulate.argtypes
+        lib.dvo_oracle_accumulate32.restype = None
+        lib.dvo_oracle_e2_limbs.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.dvo_oracle_e2_limbs.restype = None
+        lib.dvo_oracle_e2_from_limbs.argtypes = [C.c_void_p, C.c_double]
+        lib.dvo_oracle_e2_from_limbs.restype = C.c_double
         lib.dvo_oracle_state_begin.argtypes = [C.c_void_p] * 3
         lib.dvo_oracle_state_begin.restype = None
         lib.dvo_oracle_state_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double,

@@ -9,6 +9,8 @@ piece of third-party arithmetic the oracle restates from a published algorithm:
 and the oracle's own scalar restatement of the per-point path against the reference's MATRIX form written out in numpy:
   computeJacobianOfNowFrame + getReprojectedEpsilons (SolveDVO.cpp:306-462) as 3xN / 2x3 / 3x6 matrix products in float64
 """
+import math
+
 import numpy as np
 import pytest
 from scipy.linalg import polar
@@ -370,7 +372,7 @@ def test_energy_definition_sensitivity(oracle):
             for itr, (Rk, tk) in enumerate(poses):
                 ev = oracle.eval_points(level, L["xyz"], L["dt"], L["gx"], L["gy"], L["rows"], L["cols"], sc.intrinsics,
                                         np.asarray(Rk, np.float32).astype(float), np.asarray(tk, np.float32).astype(float))
-                assert np.float32(np.sqrt(np.sum(ev["eps"].astype(np.float64) ** 2))) == out["energy"][itr]      # the oracle's definition
+                assert np.float32(np.sqrt(math.fsum(ev["eps"].astype(np.float64) ** 2))) == out["energy"][itr]      # the oracle's definition: the correctly rounded exact sum
                 for k, v in _float_norms(ev["eps"]).items():
                     alt[k].append(v)
                     worst[k] = max(worst.get(k, 0.0), abs(float(v) - float(out["energy"][itr])) / float(out["energy"][itr]))
@@ -384,3 +386,37 @@ def test_energy_definition_sensitivity(oracle):
         runs, flips, ", ".join("%s %.1e" % kv for kv in sorted(worst.items()))))
     assert worst["sequential"] <= 3e-5 and max(worst[k] for k in ("avx8", "avx16", "pairwise")) <= 2e-6     # float32 sums of ~10^3..10^4 terms
     assert flips <= runs // 4       # the choice is rarely affected; when it is, two iterates have energies within those differences
+
+
+def test_energy_sum_is_the_correctly_rounded_exact_sum(oracle):
+    """S = sum of (double)eps^2 has no order (round 6): the oracle adds the terms exactly (three 32-bit limbs on a grid of 2^-68)
+    and rounds once.  Pinned against math.fsum (Shewchuk's exact summation, correctly rounded) on distance-like values, on ties of
+    the final rounding, under permutation and under sharding (limbs of shards add exactly: what tiled mode all-reduces); a value
+    outside [2^-11, 2^12) falls back to the caller's sequential sum."""
+    rng = np.random.default_rng(11)
+    for n in (1, 7, 1000, 14800, 300000):
+        d2 = rng.integers(0, 32000, n)
+        eps = (np.sqrt(d2.astype(np.float64)) * (255.0 / 178.9)).astype(np.float32)          # normalised distances, zeros included
+        want = math.fsum(eps.astype(np.float64) ** 2)
+        limbs = oracle.e2_limbs(eps)
+        assert all(float(v).is_integer() and 0 <= v < 2.0 ** 53 for v in limbs)
+        assert oracle.e2_from_limbs(limbs) == want
+        assert oracle.e2_from_limbs(oracle.e2_limbs(rng.permutation(eps))) == want
+        parts = np.array_split(eps, 5)
+        assert oracle.e2_from_limbs(sum(oracle.e2_limbs(p) for p in parts)) == want
+        seq = 0.0
+        for v in eps[:2000].astype(np.float64):
+            seq += v * v
+        assert abs(seq - math.fsum(eps[:2000].astype(np.float64) ** 2)) <= 2000 * 2.0 ** -53 * seq      # the bound the kernels' certificate uses
+    # the whole range of binades, both signs
+    eps = np.array([2.0 ** -11, -(2.0 ** 12) * (1 - 2.0 ** -24), 1.0, -0.0, 0.0, 3.14159, 2047.99], np.float32)
+    assert oracle.e2_from_limbs(oracle.e2_limbs(eps)) == math.fsum(eps.astype(np.float64) ** 2)
+    # ties of the one rounding: 2^33 + 2^-20 is half-way (even below: down), 2^33 + 2^-19 + 2^-20 is half-way above an odd (up)
+    big = np.full(2048, 2048.0, np.float32)
+    for tail in ([2.0 ** -10], [2.0 ** -10] * 3, [2.0 ** -10, 2.0 ** -11], [2.0 ** -10, 2.0 ** -10, 2.0 ** -10, 2.0 ** -11]):
+        eps = np.concatenate([big, np.array(tail, np.float32)])
+        assert oracle.e2_from_limbs(oracle.e2_limbs(eps)) == math.fsum(eps.astype(np.float64) ** 2), tail
+    # out of range: marked, the fallback is returned
+    for bad in (2.0 ** -12, 4096.0, np.inf, np.nan, 1e-40):
+        limbs = oracle.e2_limbs(np.array([1.0, bad, 2.0], np.float32))
+        assert limbs[2] >= 2.0 ** 50 and oracle.e2_from_limbs(limbs, 123.0) == 123.0
