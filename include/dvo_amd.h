@@ -85,7 +85,8 @@ typedef struct dvo_params {
     int    engine_variant;     /* engine tuning / diagnostics: 0 = auto; 1 = always the one-point-per-lane fused kernel;
                                   2 = packed kernel, but never stage a now level into LDS; 3 = packed kernel with every wave
                                   forced through its literal-division fallback (tests); 4 = packed kernel, but never the
-                                  compact form of a now level (dvo_now_prepare) */
+                                  compact form of a now level (dvo_now_prepare); 5 = packed kernel with every iteration's energy
+                                  taken from the exact sweep (dvo_get_level_energy_sweeps; tests) */
     int    lds_point_bytes;    /* engine tuning: LDS bytes per workgroup for the level's resident point list
                                   (0 = auto from block_threads, < 0 = none) */
     int    debug_alias_mod;    /* diagnostics only: if > 0, pair p reads the inputs of pair p % debug_alias_mod
@@ -308,6 +309,13 @@ int  dvo_get_level_texel_mode(dvo_ctx *ctx, int pair, int level, int *mode);
 /* *ran = 1 if, at that level of that launch, a wave of the packed kernel took its literal-division fallback (a reference point
  * whose reprojected z left the range the fast reciprocal is proven exact on, or dvo_params.engine_variant = 3).  Tests. */
 int  dvo_get_level_exact_fallback(dvo_ctx *ctx, int pair, int level, int *ran);
+/* *n = the iterations of that level of that launch whose energy came from the exact sweep (round 6).  The energy is defined without an
+ * order of summation: E = (float)sqrt(S), S = the correctly rounded double of the exact sum of eps^2 (SolveDVO.cpp:689, :1310-1312 is a
+ * float norm whose order is Eigen's).  The packed kernel adds eps^2 in its own order and certifies that no order could have rounded to
+ * another float; where it cannot (about N 2^-28 of the iterations of an N-point level) every wave sweeps the residuals once more into
+ * exact 32-bit limbs.  dvo_params.engine_variant = 5 sends every iteration that way (tests).  The kernels whose sums travel between
+ * launches or ranks (tiled mode) carry the limbs always: they report 0. */
+int  dvo_get_level_energy_sweeps(dvo_ctx *ctx, int pair, int level, int *n);
 /* *used = 1 if that level's reference points were read in their 4-byte form (engine detail: block-relative pixel + depth in
  * whole millimetres + chunk headers, validated bit for bit against the 8-byte list when the list is built; taken for lists
  * of at least three times what fits in LDS, where the per-iteration stream of the rest dominates the memory requests).  Tests. */

@@ -30,7 +30,7 @@ C_ABI_SYMBOLS = [
     "dvo_set_poses", "dvo_align_batch_enqueue", "dvo_get_poses", "dvo_get_level_report",
     "dvo_get_final_outputs", "dvo_get_level_normal_matrix", "dvo_eval_points", "dvo_accumulate", "dvo_device_se3_exp",
     "dvo_device_se3_log", "dvo_device_rotationize", "dvo_algorithmic_bytes", "dvo_point_iterations",
-    "dvo_debug_stamps", "dvo_get_level_texel_mode", "dvo_get_level_exact_fallback", "dvo_get_level_points4", "dvo_get_level_ranks_in_lds", "dvo_now_prepare", "dvo_set_direct_compact", "dvo_host_alloc_mapped", "dvo_host_free_mapped", "dvo_get_now_compact_info", "dvo_get_now_compact_partial", "dvo_get_last_launch_shape", "dvo_replicate_pairs", "dvo_set_now_level_from_edges", "dvo_get_now_level", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
+    "dvo_debug_stamps", "dvo_get_level_texel_mode", "dvo_get_level_exact_fallback", "dvo_get_level_energy_sweeps", "dvo_get_level_points4", "dvo_get_level_ranks_in_lds", "dvo_now_prepare", "dvo_set_direct_compact", "dvo_host_alloc_mapped", "dvo_host_free_mapped", "dvo_get_now_compact_info", "dvo_get_now_compact_partial", "dvo_get_last_launch_shape", "dvo_replicate_pairs", "dvo_set_now_level_from_edges", "dvo_get_now_level", "dvo_iter_begin", "dvo_iter_accumulate", "dvo_iter_update", "dvo_iter_end",
     "dvo_align_pyramid_wide", "dvo_tiled_attach", "dvo_tiled_detach", "dvo_align_pyramid_tiled", "dvo_tiled_shard", "dvo_tiled_graph_replayed", "dvo_wide_packed_levels", "dvo_wide_team_levels",
     "dvo_get_ref_level", "dvo_frames_reserve", "dvo_frames_upload_pyramids", "dvo_frames_upload_cameras", "dvo_frames_set_undistort",
     "dvo_photo_params_default", "dvo_photo_configure", "dvo_photo_set_ref", "dvo_photo_align", "dvo_photo_get_jacobian", "dvo_frames_as_now",
@@ -250,6 +250,7 @@ def load_library() -> C.CDLL:
         "dvo_debug_stamps": [vp, i, vp],
         "dvo_get_level_texel_mode": [vp, i, i, ip],
         "dvo_get_level_exact_fallback": [vp, i, i, ip],
+        "dvo_get_level_energy_sweeps": [vp, i, i, ip],
         "dvo_get_level_points4": [vp, i, i, ip],
         "dvo_get_level_ranks_in_lds": [vp, i, i, ip],
         "dvo_now_prepare": [vp, i, i],
@@ -785,6 +786,13 @@ class DvoContext:
         """0 = 16-byte texels gathered from HBM/L2, 1 = the level's texels staged in LDS, 2 = the compact form, -1 = not run"""
         m = C.c_int(-2)
         self._chk(self.lib.dvo_get_level_texel_mode(self._h, pair, level, C.byref(m)))
+        return m.value
+
+    def level_energy_sweeps(self, pair: int, level: int) -> int:
+        """iterations of that level whose energy came from the exact sweep of the residuals (the certificate of the fast sum failed,
+        or engine_variant = 5)"""
+        m = C.c_int(0)
+        self._chk(self.lib.dvo_get_level_energy_sweeps(self._h, pair, level, C.byref(m)))
         return m.value
 
     def level_exact_fallback(self, pair: int, level: int) -> bool:

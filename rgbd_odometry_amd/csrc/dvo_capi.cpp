@@ -638,6 +638,7 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
         sc.lds_bytes = bytes;
         sc.no_lds_tex = (c->prm.engine_variant == 2) ? 1 : 0;
         sc.force_exact = (c->prm.engine_variant == 3) ? 1 : 0;
+        sc.force_e2 = (c->prm.engine_variant == 5) ? 1 : 0;
         static const bool no_pt4_env = [] { const char *e = std::getenv("DVO_POINTS4"); return e && std::strcmp(e, "off") == 0; }();
         sc.no_pt4 = no_pt4_env ? 1 : 0;
         /* 4-byte points from this many times the LDS capacity (in 8-byte points) on; DVO_POINTS4_FACTOR for A/B measurements */
@@ -2090,6 +2091,16 @@ int dvo_get_level_exact_fallback(dvo_ctx *c, int pair, int level, int *ran) {
     int v = -1;
     HIPCHK(c, hipMemcpy(&v, c->d_tex_mode + (size_t)pair * DVO_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
     *ran = (v >= 0 && (v & DVO_TEXMODE_EXACT_RAN)) ? 1 : 0;
+    return DVO_OK;
+}
+
+int dvo_get_level_energy_sweeps(dvo_ctx *c, int pair, int level, int *n) {
+    DVO_ENTER(c);
+    if (!pair_ok(c, pair) || !level_ok(level) || !n) return fail(c, DVO_ERR_INVALID, "bad arguments");
+    HIPCHK(c, stream_wait(c->stream));
+    int v = -1;
+    HIPCHK(c, hipMemcpy(&v, c->d_tex_mode + (size_t)pair * DVO_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
+    *n = (v < 0) ? 0 : ((v >> DVO_TEXMODE_E2_SHIFT) & DVO_TEXMODE_E2_MAX);
     return DVO_OK;
 }
 

@@ -160,19 +160,22 @@ DVO_DEV void jacobian_row(const IterConst &c, float xn, float yn, float zn,
     /* Z is z*(1/z): exactly 1 or 1-2^-24 for every point whose 1/z took the fast path; the four
      * divisions by Z and Z*Z then have closed forms (identities 3 and 4).  Anything else (a point
      * with a degenerate z) takes the literal divisions. */
-    const float n02 = (-c.m00) * xn, n12 = (-c.m11) * yn;
+    /* all four read before they are chosen from: `cond ? c.m00 : c.m00_z1` is a choice between two ADDRESSES to the compiler, which can
+     * pin a slice of IterConst to scratch memory (it did when the exact energy sweep added a second user, round 6) */
+    const float m00 = c.m00, m11 = c.m11, m00_z1 = c.m00_z1, m11_z1 = c.m11_z1;
+    const float n02 = (-m00) * xn, n12 = (-m11) * yn;
     const unsigned zb = __float_as_uint(zn);
     const bool z_is_1 = (zb == 0x3f800000u);           /* Z == 1 */
     const bool z_is_z1 = (zb == DVO_Z1);               /* Z == 1-2^-24, Z*Z == 1-2^-23 */
-    float a00 = z_is_1 ? c.m00 : c.m00_z1;             /* scaleFac*fx/Z            :388 */
-    float a11 = z_is_1 ? c.m11 : c.m11_z1;             /* :392 */
+    float a00 = z_is_1 ? m00 : m00_z1;                 /* scaleFac*fx/Z            :388 */
+    float a11 = z_is_1 ? m11 : m11_z1;                 /* :392 */
     float a02 = z_is_1 ? n02 : exact_div_zz1(n02);     /* -scaleFac*fx*X/(Z*Z)     :390 */
     float a12 = z_is_1 ? n12 : exact_div_zz1(n12);     /* :393 */
     const bool odd = !(z_is_1 || z_is_z1);
     if (__builtin_amdgcn_ballot_w64(odd) != 0ull) {    /* wave-uniform; literal divisions for degenerate z */
         if (odd) {
             const float zz = zn * zn;
-            a00 = c.m00 / zn; a02 = n02 / zz; a11 = c.m11 / zn; a12 = n12 / zz;
+            a00 = m00 / zn; a02 = n02 / zz; a11 = m11 / zn; a12 = n12 / zz;
         }
     }
     const float ga0 = gxv * a00;                       /* G*A1, structural zeros dropped */
@@ -726,7 +729,7 @@ struct PoseCur {
 };
 struct __attribute__((aligned(16))) PoseState {
     PoseCur p[2];
-    double R[9], pad0_;          /* matrix of the current q */
+    double R[9], e2_fast;        /* matrix of the current q; packed kernel: the iteration's sum of eps^2 as added (its energy is open) */
     double d[6];                 /* descentDirection (:654) */
     double creg[6], creg_scale, pad1_;  /* regulariser of the CURRENT pose, precomputed (fused kernels): log(pose) and lambda/|log| */
     double bq[4], bt[3], pad2_;  /* best iterate (:646-647) */
@@ -734,7 +737,9 @@ struct __attribute__((aligned(16))) PoseState {
     float bestE, bestRatio;      /* :644-645 */
     int bestItr;                 /* :648 */
     int stop;
-    int exact_ran, pad3_[3];     /* packed kernel, inspection: a wave took the literal-division fallback during this level */
+    int exact_ran;               /* packed kernel, inspection: a wave took the literal-division fallback during this level */
+    int e2_open, e2_nvis;        /* packed kernel: the certificate of this iteration's energy failed -> every wave sweeps the residuals again, exactly */
+    int e2_ran;                  /* inspection: iterations of this level that took that sweep */
     UpdConst u;                  /* the update's constants: built once per kernel (or once per level by iter_begin_kernel for the state
                                     that travels through HBM between the launches of the tiled schedule) */
 };
@@ -819,7 +824,79 @@ DVO_DEV void pose_regulariser_precompute(PoseState &s, const PoseCur &cur, const
  *   pose_apply      trust region, termination, exponential map, compose (:832-919, :673-674): cur -> nxt
  * The pieces are independent but for `cur`, which the first only reads and the last only reads before it writes `nxt`. */
 
-/* energy narrows to float, so it needs the correctly rounded double sqrt to match the oracle's (float)sqrt(double) bit for bit */
+/* ---- the energy without an order of summation (round 6) ---------------------------------------------------------------------
+ * E = (float)sqrt(S) (:689, :1310-1312) with S the CORRECTLY ROUNDED double of the exact sum of eps^2 -- a definition no order of
+ * additions enters (rounds 1-5: S was whatever the kernel's tree of double additions gave; once in ~50 000 energies that flipped the
+ * float).  Two tools:
+ *  (a) the certificate.  A sum S' of N non-negative doubles added in ANY order is within N 2^-53 S' of the exact sum, the exact
+ *      sum's rounding within 2^-53 more; sqrt and the narrowing are monotone, so if every x in S' (1 -+ (N + 16) 2^-53) gives the same
+ *      (float)sqrt(x), that float IS the energy.  It fails for about N 2^-28 of the iterations.
+ *  (b) the exact sum.  eps^2 of a float is a 48-bit integer times a power of four: on the grid of 2^-68 every |eps| in
+ *      [2^-11, 2^12) (every normalised distance) gives an integer below 2^92, added into three 32-bit limbs.  Limb sums stay below
+ *      2^53 for up to 2^21 points, so held in doubles they pass through every reduction the other sums use (DPP, LDS, team
+ *      exchange, ncclAllReduce) EXACTLY, in any order; one rounding at the end.  A value outside the range marks limb 2 with 2^50
+ *      and the caller keeps S'.
+ * The packed fused kernel runs (a) every iteration and (b) -- one more sweep over the points, residual only -- where (a) fails; the
+ * kernels whose sums travel between launches or ranks carry the limbs always. */
+#define DVO_E2_EXP0 116              /* biased exponent of 2^-11 */
+#define DVO_E2_BINADES 22
+#define DVO_E2_BAD 1125899906842624.0 /* 2^50 */
+struct E2Limbs { unsigned long long l0, l1, l2; };
+DVO_DEV void e2_limbs_zero(E2Limbs &a) { a.l0 = a.l1 = a.l2 = 0ull; }
+DVO_DEV void e2_limbs_add(E2Limbs &a, float eps) {
+    const unsigned bits = __float_as_uint(eps) & 0x7fffffffu;
+    const unsigned de = (bits >> 23) - (unsigned)DVO_E2_EXP0;
+    const bool ok = de <= (unsigned)DVO_E2_BINADES;
+    const unsigned m = (bits & 0x7fffffu) | 0x800000u;
+    const unsigned long long sq = (unsigned long long)m * m;             /* 48 bits */
+    const unsigned sh = ok ? 2u * de : 0u;                               /* <= 44 */
+    const unsigned long long lo = sq << sh, hi = sh ? (sq >> (64u - sh)) : 0ull;
+    if (ok) { a.l0 += lo & 0xffffffffull; a.l1 += lo >> 32; a.l2 += hi; }
+    else if (bits != 0u) a.l2 += 1ull << 50;
+}
+/* (sums of) limbs -> the correctly rounded double of the exact sum; `fallback` if a term was out of range */
+DVO_DEV double e2_from_limbs(double d0, double d1, double d2, double fallback) {
+    if (!(d2 < DVO_E2_BAD)) return fallback;
+    const unsigned long long a0 = (unsigned long long)d0, a1 = (unsigned long long)d1, a2 = (unsigned long long)d2;
+    const unsigned long long t = a1 << 32;
+    unsigned long long lo = a0 + t, hi = a2 + (a1 >> 32) + ((lo < t) ? 1ull : 0ull);      /* a0 + a1 2^32 + a2 2^64 */
+    if (hi == 0ull) return (double)lo * 0x1p-68;                         /* u64 -> f64 rounds to nearest even */
+    const int n = __builtin_clzll(hi);
+    const unsigned long long H = n ? ((hi << n) | (lo >> (64 - n))) : hi, L = lo << n;      /* bit 63 of H set */
+    unsigned long long q = H >> 11;
+    const unsigned rem = (unsigned)(H & 0x7ffull);
+    if (rem > 0x400u || (rem == 0x400u && (L != 0ull || (q & 1ull)))) q++;
+    return (double)q * __longlong_as_double((long long)(1023 + 7 - n) << 52);      /* q 2^(11 + 64 - n - 68) */
+}
+DVO_DEV bool energy_certified(double sum_eps2, int N, float &energy) {
+    const float e = (float)sqrt(sum_eps2);
+    energy = e;
+    if (sum_eps2 == 0.0) return true;
+    const unsigned b = __float_as_uint(e);
+    if (b - 0x00800000u >= 0x7effffffu) return false;                   /* not a positive normal float below FLT_MAX (NaN, inf, ...) */
+    /* (float)sqrt(x) == e for every x strictly between the squares of the midpoints to e's two neighbours; the squares are rounded
+     * (2^-53 each, like sqrt itself): the slack of 16 covers that */
+    const double m_lo = 0.5 * ((double)e + (double)__uint_as_float(b - 1u)), m_hi = 0.5 * ((double)e + (double)__uint_as_float(b + 1u));
+    const double d = sum_eps2 * ((double)(N + 16) * 0x1p-53);
+    return (sum_eps2 - d) > m_lo * m_lo && (sum_eps2 + d) < m_hi * m_hi;
+}
+
+/* :696-705 with the energy in hand */
+DVO_DEV void pose_bookkeep_e(PoseState &s, const PoseCur &cur, int itr, int N, float energy, int n_vis) {
+    if (energy <= s.bestE) {                                              /* :696 */
+        s.bestE = energy;
+        s.bestRatio = (float)n_vis / (float)N;                            /* :457 */
+#pragma unroll
+        for (int k = 0; k < 4; k++) s.bq[k] = cur.q[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { s.bt[k] = cur.t[k]; s.btf[k] = cur.tf[k]; }
+#pragma unroll
+        for (int k = 0; k < 9; k++) s.bRf[k] = cur.Rf[k];
+        s.bestItr = itr;
+    }
+}
+/* energy narrows to float, so it needs the correctly rounded double sqrt to match the oracle's (float)sqrt(double) bit for bit;
+ * sum_eps2 = the correctly rounded exact sum (e2_from_limbs), or a sum the caller has certified */
 DVO_DEV float pose_bookkeep(PoseState &s, const PoseCur &cur, int itr, int N, double sum_eps2, int n_vis) {
     const float energy = (float)sqrt(sum_eps2);                           /* :689, :1312 */
     if (energy <= s.bestE) {                                              /* :696 */

@@ -29,6 +29,7 @@
 #include "dvo_tiled_step.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 /* rounds of gathers in flight in the compact-form loop.  Measured (640x480x4x10, 1024 pairs): two 256-thread workgroups per
  * CU 555 k aligns/s at depth 2, 593 k at depth 3; one 512-thread workgroup 517 k / 510 k (its serial phases are exposed, not
@@ -364,6 +365,25 @@ DVO_DEV void acc7_add(ACC &a, const float *jw, const float *J, float eps) {
     }
 }
 
+/* the iteration's float pose into the constants, with literal indices: IterConst then splits into registers in the compiler's FIRST
+ * pass over the kernel (a loop over k does so only once it is unrolled, and round 6's exact-energy block after the barrier then left a
+ * 24-byte slice of it in scratch memory) */
+DVO_DEV void iter_const_pose(IterConst &c, const float *Rf, const float *tf) {
+    c.r[0] = uniform_f(Rf[0]); c.r[1] = uniform_f(Rf[1]); c.r[2] = uniform_f(Rf[2]);
+    c.r[3] = uniform_f(Rf[3]); c.r[4] = uniform_f(Rf[4]); c.r[5] = uniform_f(Rf[5]);
+    c.r[6] = uniform_f(Rf[6]); c.r[7] = uniform_f(Rf[7]); c.r[8] = uniform_f(Rf[8]);
+    c.t[0] = uniform_f(tf[0]); c.t[1] = uniform_f(tf[1]); c.t[2] = uniform_f(tf[2]);
+}
+
+/* the exact sweep of an iteration whose energy the certificate left open (dvo_device_math.h: the energy without an order): the
+ * residual alone, into the three limbs */
+struct AccE2 {
+    static constexpr bool with_h = false;
+    E2Limbs l;
+    int nvis;
+};
+DVO_DEV void acc7_add(AccE2 &a, const float *, const float *, float eps) { e2_limbs_add(a.l, eps); }
+
 /* stage 2: weighted Jacobian rows + accumulation */
 template <int TEX, unsigned PAL, typename ACC>
 DVO_DEV void round2_compute(const IterConst &c, const Round2<TEX> &b, ACC &a) {
@@ -543,6 +563,28 @@ DVO_DEV void accumulate_points_exact(const IterConst &c, const char *__restrict_
             for (int q = 0; q < 6; q++) jw[q] = J[q] * t.w;
             acc7_add(a, jw, J, t.x);
         }
+    }
+}
+
+/* a wave's share of a level through that code, whichever forms the level's points and texels are read in */
+template <int BLOCK, typename ACC>
+DVO_DEV void sweep_literal(int mode, bool p4_partial, bool pt4, const IterConst &c, const char *__restrict__ tex, const TexSrc &ts, const float2 *pal_lds,
+                           const LdsPoints &lp, const uint2 *__restrict__ gpts, int n_lds, int N, int lane_off, ACC &a) {
+    if (mode == DVO_TEXMODE_PAL4 && p4_partial && pt4) {          /* partial form: the 16-byte texels are the complete image */
+        accumulate_points_exact<BLOCK, true, false, true, ACC>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
+        accumulate_points_exact<BLOCK, false, false, true, ACC>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
+    } else if (mode == DVO_TEXMODE_PAL4 && p4_partial) {
+        accumulate_points_exact<BLOCK, true, false, false, ACC>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
+        accumulate_points_exact<BLOCK, false, false, false, ACC>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
+    } else if (mode == DVO_TEXMODE_PAL4 && pt4) {
+        accumulate_points_exact<BLOCK, true, true, true, ACC>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
+        accumulate_points_exact<BLOCK, false, true, true, ACC>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
+    } else if (mode == DVO_TEXMODE_PAL4) {
+        accumulate_points_exact<BLOCK, true, true, false, ACC>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
+        accumulate_points_exact<BLOCK, false, true, false, ACC>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
+    } else {
+        accumulate_points_exact<BLOCK, true, false, false, ACC>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
+        accumulate_points_exact<BLOCK, false, false, false, ACC>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
     }
 }
 
@@ -726,6 +768,18 @@ DVO_DEV double block_sum8(const double (*red)[8], int k /* 0..7 */) {
 #pragma unroll
     for (int w = 0; w < BLOCK / 64; w++) s += v[w];
     return s;
+}
+
+/* the three limbs of a wave -> red[wave][0..2] (integers below 2^53: every addition on the way is exact) */
+DVO_DEV void wave_sums_e2(const AccE2 &a, double (*red)[8]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double d[8];
+    d[0] = (double)a.l.l0; d[1] = (double)a.l.l1; d[2] = (double)a.l.l2;
+#pragma unroll
+    for (int k = 3; k < 8; k++) d[k] = 0.0;
+    wave_reduce_scatter8_dpp(d);
+    const int idx = reduce_scatter8_dpp_index(lane);
+    if (lane < 8) red[wave][idx] = d[0];
 }
 
 /* ---- teams: G workgroups share ONE frame pair (small batches) ------------------------------------------------------
@@ -1037,7 +1091,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
                         : (pt4 ? ((lds_words - pal_words - img_words) & ~1) : (((lds_words - pal_words - img_words) >> 1) & ~1));      /* points the LDS holds */
         const int n_lds = (N <= cap) ? N : (cap / (2 * BLOCK)) * (2 * BLOCK);      /* whole rounds only */
         float *const lds_tex = lds_pts + 2 * cap;
-        if (tid == 0) st.exact_ran = 0;
+        if (tid == 0) { st.exact_ran = 0; st.e2_open = 0; st.e2_ran = 0; }
         if (mode == TEX_P4 && works) {
             const float2 *__restrict__ pg = L.pal + (size_t)dpair * DVO_PAL_MAX;
             float2 *pl = reinterpret_cast<float2 *>(lds_dyn);
@@ -1141,10 +1195,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
              * runs beside the update) */
             const PoseCur &pc = st.p[itr & 1];
             PoseCur &pn = st.p[(itr + 1) & 1];
-#pragma unroll
-            for (int k = 0; k < 9; k++) c.r[k] = uniform_f(pc.Rf[k]);        /* :673 */
-#pragma unroll
-            for (int k = 0; k < 3; k++) c.t[k] = uniform_f(pc.tf[k]);        /* :674 */
+            iter_const_pose(c, pc.Rf, pc.tf);                                 /* :673-674 */
 
             DVO_STAMP(t0);
             Acc7T<WITH_H> a;
@@ -1179,23 +1230,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             }
             if (any_odd || sc.force_exact) {      /* wave-uniform; a point with a degenerate z: this wave's share again, literal divisions */
                 acc7_zero(a);
-                const float2 *pal_lds = reinterpret_cast<const float2 *>(lds_dyn);
-                if (mode == TEX_P4 && p4_partial && pt4) {          /* partial form: the 16-byte texels are the complete image */
-                    accumulate_points_exact<BLOCK, true, false, true, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
-                    accumulate_points_exact<BLOCK, false, false, true, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
-                } else if (mode == TEX_P4 && p4_partial) {
-                    accumulate_points_exact<BLOCK, true, false, false, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
-                    accumulate_points_exact<BLOCK, false, false, false, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
-                } else if (mode == TEX_P4 && pt4) {
-                    accumulate_points_exact<BLOCK, true, true, true, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
-                    accumulate_points_exact<BLOCK, false, true, true, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
-                } else if (mode == TEX_P4) {
-                    accumulate_points_exact<BLOCK, true, true, false, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
-                    accumulate_points_exact<BLOCK, false, true, false, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
-                } else {
-                    accumulate_points_exact<BLOCK, true, false, false, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, 0, n_lds, lane_off, a);
-                    accumulate_points_exact<BLOCK, false, false, false, Acc7T<WITH_H>>(c, tex, ts, pal_lds, lp, gpts, n_lds, N, lane_off, a);
-                }
+                sweep_literal<BLOCK>(mode, p4_partial, pt4, c, tex, ts, reinterpret_cast<const float2 *>(lds_dyn), lp, gpts, n_lds, N, lane_off, a);
                 if ((tid & 63) == 0) st.exact_ran = 1;          /* inspection: dvo_get_level_texel_mode reports it (tests) */
             }
             DVO_STAMP(t1);
@@ -1246,13 +1281,45 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             } else if (wave == 1 && lane == 0) {
                 const double e2 = exch ? tot[6] : block_sum8<BLOCK>(red, 6);
                 const double nv = exch ? tot[7] : block_sum8<BLOCK>(red, 7);
-                const float e = pose_bookkeep(st, pc, itr, Nall, e2, (int)nv);
-                if (member == 0) energy[itr] = e;                            /* :690 */
+                float e;
+                if (energy_certified(e2, Nall, e) && !sc.force_e2) {          /* no order of additions could have given another float */
+                    pose_bookkeep_e(st, pc, itr, Nall, e, (int)nv);
+                    if (member == 0) energy[itr] = e;                        /* :690 */
+                } else {                                                     /* about Nall 2^-28 of the iterations: settled below */
+                    st.e2_fast = e2;
+                    st.e2_nvis = (int)nv;
+                    st.e2_open = 1;
+                }
             }
             if (exch) epoch++;
             DVO_STAMP(t3);
             __syncthreads();
             DVO_STAMP(t4);
+            if (st.e2_open) {       /* workgroup- (and team-) uniform: the same sum bits everywhere */
+                /* the residuals of this iterate once more (c still holds its pose), added exactly: three limbs per lane -> wave ->
+                 * workgroup (-> team), all of them integers below 2^53 in doubles, so the sums are exact whatever their order */
+                AccE2 ae;
+                e2_limbs_zero(ae.l);
+                ae.nvis = 0;
+                sweep_literal<BLOCK>(mode, p4_partial, pt4, c, tex, ts, reinterpret_cast<const float2 *>(lds_dyn), lp, gpts, n_lds, N, lane_off, ae);
+                wave_sums_e2(ae, red);
+                __syncthreads();
+                if (wave == 0) {
+                    double sl2 = block_sum8<BLOCK>(red, lane & 7);
+                    if (exch) sl2 = team_total(sl2);
+                    if (lane < 3) tot[lane] = sl2;
+                }
+                if (exch) epoch++;
+                __syncthreads();
+                if (wave == 1 && lane == 0) {
+                    const float e = (float)sqrt(e2_from_limbs(tot[0], tot[1], tot[2], st.e2_fast));
+                    pose_bookkeep_e(st, pc, itr, Nall, e, st.e2_nvis);
+                    if (member == 0) energy[itr] = e;                        /* :690 */
+                    st.e2_open = 0;
+                    st.e2_ran++;
+                }
+                __syncthreads();
+            }
             DVO_STAMP_ADD(0, t0, t1); DVO_STAMP_ADD(1, t1, t2); DVO_STAMP_ADD(2, t2, t3); DVO_STAMP_ADD(3, t3, t4);
             DVO_STAMP_ADD(4, t0, t0 + 1);
             if (st.stop) break;                                              /* :877 */
@@ -1265,10 +1332,7 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
          * the same float pose -> same bits */
         if ((sc.flags & 1) && l == sc.last_level) {
             if (st.bestItr >= 0) {
-#pragma unroll
-                for (int k = 0; k < 9; k++) c.r[k] = uniform_f(st.bRf[k]);
-#pragma unroll
-                for (int k = 0; k < 3; k++) c.t[k] = uniform_f(st.btf[k]);
+                iter_const_pose(c, st.bRf, st.btf);
                 float *fe = out.final_eps + (size_t)pair * out.final_cap;
                 float *fr = out.final_reproj + (size_t)pair * out.final_cap * 3;
                 /* written in the order of the compact list (this workgroup's share starts at pfirst); the host hands them out in
@@ -1297,7 +1361,8 @@ align_fused2_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Outpu
             if (member == 0) {
                 out.best_idx[pair * DVO_LEVELS + l] = st.bestItr;
                 out.ratio[pair * DVO_LEVELS + l] = st.bestRatio;
-                out.tex_mode[pair * DVO_LEVELS + l] = mode | (st.exact_ran ? DVO_TEXMODE_EXACT_RAN : 0) | (pt4 ? DVO_TEXMODE_PT4 : 0) | (r16 ? DVO_TEXMODE_RANKS_LDS : 0);
+                out.tex_mode[pair * DVO_LEVELS + l] = mode | (st.exact_ran ? DVO_TEXMODE_EXACT_RAN : 0) | (pt4 ? DVO_TEXMODE_PT4 : 0) | (r16 ? DVO_TEXMODE_RANKS_LDS : 0) |
+                                                       (min(st.e2_ran, DVO_TEXMODE_E2_MAX) << DVO_TEXMODE_E2_SHIFT);
             }
         }
         __syncthreads();

@@ -18,6 +18,7 @@
 enum { DVO_TEXMODE_GLOBAL16 = 0, DVO_TEXMODE_LDS16 = 1, DVO_TEXMODE_PAL4 = 2,
        DVO_TEXMODE_EXACT_RAN = 0x100 /* flag: a wave of the packed kernel took the literal-division fallback at this level */,
        DVO_TEXMODE_PT4 = 0x200       /* flag: the level's reference points were read in their 4-byte form */,
+       DVO_TEXMODE_E2_SHIFT = 12, DVO_TEXMODE_E2_MAX = 0xffff /* bits 12..27: iterations of the level whose energy came from the exact sweep (round 6) */,
        DVO_TEXMODE_RANKS_LDS = 0x400 /* flag (with DVO_TEXMODE_PAL4): the level's ranks were looked up in an LDS copy of the whole level (round 5) */ };
 
 namespace dvo {
@@ -62,6 +63,7 @@ struct Schedule {
     int no_p4;               /* diagnostics: never read the compact form of a now level (dvo_palette.h) */
     int team;                /* workgroups per pair of the packed kernel (1 = none; > 1: team mode, see dvo_fused.hip) */
     int n_pairs_launch;      /* pairs of this launch (team mode maps workgroups to pairs itself) */
+    int force_e2;            /* tests (engine_variant 5): the energy certificate always fails -> every iteration takes the exact sweep of the residuals */
     int force_exact;         /* tests: every wave takes the literal-division fallback of the packed kernel (accumulate_points_exact) */
     int compact;             /* every pair/level of this launch has a compact point list: read 8 B / point instead of 12 */
     int no_pt4;              /* diagnostics: never read the 4-byte form of a reference list (DVO_POINTS4=off) */

@@ -51,6 +51,9 @@ def _check(ctx, ref, iters, pair=0, R0=None, t0=None):
     dict(lds_point_bytes=16 * 1024, team_size=1),    # palette + 1 k points resident, the rest streamed (both passes)
     dict(engine_variant=3, team_size=1),             # every wave redone by the literal-division fallback, reading the compact form
     dict(engine_variant=3),                          # the same in a team
+    dict(engine_variant=5, team_size=1),             # every energy from the exact sweep of the residuals (round 6: the energy without an order)
+    dict(engine_variant=5),                          # the same in a team: the limbs go through the team's exchange
+    dict(engine_variant=5, block_threads=256), dict(engine_variant=5, lds_point_bytes=16 * 1024, team_size=1),
 ])
 def test_compact_now_640x480(oracle, kw):
     """C2 (640x480, 4 levels, 10 iterations): prepared now levels through every launch shape of the packed kernel"""
@@ -71,6 +74,10 @@ def test_compact_now_640x480(oracle, kw):
         assert modes == [2, 2, 2, 2], modes                       # a level that has a compact form is read through it
         # engine_variant = 3 really runs the literal-division code (it used to be a silent no-op), nothing else does
         assert [ctx.level_exact_fallback(0, l) for l in range(4)] == [kw.get("engine_variant", 0) == 3] * 4
+        # engine_variant = 5: every iteration's energy came from the exact limbs; otherwise the certificate of the fast sum holds
+        # (it fails once in ~20 000 iterations of such levels: not on this scene)
+        sweeps = [ctx.level_energy_sweeps(0, l) for l in range(4)]
+        assert sweeps == ([10] * 4 if kw.get("engine_variant", 0) == 5 else [0] * 4), sweeps
     if kw.get("engine_variant", 0) == 0:
         # the same alignment with the compact form switched off: same kernel otherwise -> the very same bits
         with DvoContext(1, **{**kw, "engine_variant": 4}) as ctx2:

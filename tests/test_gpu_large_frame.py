@@ -93,6 +93,24 @@ def test_config5_team_over_all_xcds(scene4096, team):
             assert np.abs(R3 - R).max() <= 1e-12 and np.abs(t3 - t).max() <= 1e-12
 
 
+def test_config5_exact_energy_sweep_over_the_whole_chip(scene4096):
+    """every energy of the 4096x3072 pyramid from the exact sweep (engine_variant 5): 256 workgroups add their three limbs through the
+    two-stage exchange -- integers below 2^53, exact in any order -- and round once; same bits as the oracle's exact sum"""
+    from rgbd_odometry_amd import DvoContext
+    sc, lv, iters, ref = scene4096
+    with DvoContext(1, engine_variant=5) as ctx:
+        ctx.set_intrinsics(*sc.intrinsics)
+        for l, L in enumerate(sc.levels):
+            ctx.set_ref_level_from_images(l, L.ref_edge, L.ref_depth, L.rows, L.cols)
+            ctx.set_now_level(l, L.now_dt, L.now_gx, L.now_gy, L.rows, L.cols)
+        ctx.now_prepare()
+        R, t = ctx.align_batch(iters, np.eye(3)[None], np.zeros((1, 3)))
+        assert ctx.last_launch_shape()[1] == 256
+        _check_reports(ctx, ref, iters)
+        assert [ctx.level_energy_sweeps(0, l) for l in range(5)] == iters
+        assert rot_angle(ref["R"], R[0]) <= ROT_TOL and np.linalg.norm(ref["t"] - t[0]) <= TRANS_TOL
+
+
 def test_config5_tiled_loop_with_forced_collective(scene4096, ctx4096):
     """the multi-GPU loop (accumulate -> all_reduce of 32 doubles -> update) with the RCCL collective really issued"""
     import torch

@@ -63,6 +63,7 @@ def _check(ctx, oracle, sc, lv, iters, pair=0, R0=None, t0=None):
     dict(engine_variant=1),                          # the one-point-per-lane kernel on the same compact lists
     dict(engine_variant=3),                          # every wave through the literal-division fallback of the packed kernel
     dict(engine_variant=3, team_size=1), dict(engine_variant=2, team_size=1),
+    dict(engine_variant=5), dict(engine_variant=5, team_size=1),      # every energy from the exact sweep (16-byte texels here)
     dict(block_threads=256), dict(block_threads=1024),
     dict(lds_point_bytes=-1),                        # every point streamed from HBM
     dict(lds_point_bytes=16 * 1024),                 # 2048 points resident, the rest streamed (both passes run)
@@ -82,6 +83,7 @@ def test_packed_kernel_variants_640x480(oracle, kw):
         team_on = variant != 1 and kw.get("team_size", 0) != 1 and kw.get("block_threads", 0) in (0, 512)
         if variant != 1:            # engine_variant = 3 really runs the literal-division code, nothing else does here
             assert [ctx.level_exact_fallback(0, l) for l in range(4)] == [variant == 3] * 4
+            assert [ctx.level_energy_sweeps(0, l) for l in range(4)] == [10 if variant == 5 else 0] * 4
         if variant == 1 or modes is None:
             pass                                      # the other kernel: modes untouched
         elif team_on or variant == 2 or kw.get("lds_point_bytes", 0) != 0:
