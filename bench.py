@@ -368,9 +368,9 @@ def energy_ulps(e_gpu, e_ref):
     return int(a.size), int(neq.sum()), int(d[neq].max())
 
 
-PARITY_TOLERANCE = ("poses 1e-5 rad / 1e-4 m; best index and visible ratio equal; energies bit-equal -- strictly when fewer than 10 000 are compared; "
-                    "beyond that at most 1e-4 of them may differ by one float ulp (the double sum's order of additions differs from the oracle's: "
-                    "energies_differing / max_energy_ulp count them)")
+PARITY_TOLERANCE = ("poses 1e-5 rad / 1e-4 m; best index and visible ratio equal; EVERY energy bit-equal (round 6: the energy is "
+                    "(float)sqrt of the correctly rounded exact sum of eps^2 on both sides -- no order of additions enters; "
+                    "energies_from_exact_sweep counts the iterations whose fast sum the kernel could not certify and settled with exact limbs)")
 
 
 def sparse_scenes_leg(stream, quick=False):
@@ -751,7 +751,7 @@ def main_batch(args):
         import oracle_lib
         worst_r = worst_t = 0.0
         bit_equal = decisions_equal = replicas_equal = True
-        n_e = n_diff = max_ulp = 0
+        n_e = n_diff = max_ulp = n_sweeps = 0
         for i, sc_i in enumerate(scenes):
             lv_i = lvs[i] if i < len(lvs) else oracle_lib.scene_levels(sc_i, oracle)
             ref = oracle.align_pyramid(iters, lv_i, sc_i.intrinsics, np.eye(3), np.zeros(3))
@@ -763,20 +763,19 @@ def main_batch(args):
                 decisions_equal = decisions_equal and bi == rep["best_idx"] and ratio == rep["visible_ratio"]
                 n, k, u = energy_ulps(e, rep["energy"])
                 n_e += n; n_diff += k; max_ulp = max(max_ulp, u)
+                n_sweeps += ctx.level_energy_sweeps(i, l)
             # a replica far down the batch must carry the same bits as its source
             j = i + D * ((args.batch - 1 - i) // D)
             replicas_equal = replicas_equal and bool(np.array_equal(R[i], R[j])) and bool(np.array_equal(t[i], t[j]))
         out["parity_check"] = {
             "pairs_checked": D, "max_rot_err_rad": worst_r, "max_trans_err_m": worst_t,
             "energies_bit_equal": bool(bit_equal), "energies_compared": n_e, "energies_differing": n_diff, "max_energy_ulp": max_ulp,
+            "energies_from_exact_sweep": n_sweeps,
             "best_index_and_ratio_equal": bool(decisions_equal), "replicas_bit_identical": bool(replicas_equal),
             "tolerance": PARITY_TOLERANCE,
-            # the gate is STRICT again wherever the energies compared are few enough that a one-ulp straddle of the double
-            # sum (2 distinct energies in 102 400: DESIGN.md section 2) is not expected: a differing energy among fewer than 10 000
-            # fails the run.  Larger comparisons (--batch sweeps with thousands of distinct scenes) get the explicit, counted
-            # allowance energies_differing / energies_compared <= 1e-4, each of at most one ulp.
-            "pass": bool(decisions_equal and replicas_equal and worst_r <= 1e-5 and worst_t <= 1e-4 and
-                         (bit_equal or (n_e >= 10000 and max_ulp <= 1 and n_diff <= 1e-4 * n_e))),
+            # round 6: strict at every size.  (Round 5 allowed 1e-4 of the energies of a large comparison to differ by one ulp: the
+            # kernel's order of additions was not the oracle's.  The energy no longer has an order: DESIGN.md section 2.)
+            "pass": bool(decisions_equal and replicas_equal and bit_equal and worst_r <= 1e-5 and worst_t <= 1e-4),
         }
     # transparency legs, never `value`; default launch only
     default_launch = default_knobs and not total_pairs

@@ -226,8 +226,11 @@ int  dvo_get_final_outputs(dvo_ctx *ctx, int pair, float *final_eps, float *fina
  * The grid of the accumulate kernel spans all CUs, so this is also the path for frames whose
  * point lists are too long for one workgroup (1920x1080, 4096x3072).  All calls except
  * dvo_iter_begin/_end are asynchronous on the context stream.
- *   d_acc32: DEVICE pointer to 32 doubles: [0..20] H upper triangle, [21..26] g, [27] sum eps^2,
- *            [28] visible points, [29..31] zero.
+ *   d_acc32: DEVICE pointer to 32 doubles: [0..20] H upper triangle, [21..26] g, [27] sum eps^2 as this GPU added it,
+ *            [28] visible points, [29..31] the three 32-bit limbs of the EXACT sum of eps^2 (integers below 2^53 on a grid of
+ *            2^-68: sums of them over shards are exact in any order; dvo_iter_update rounds the exact total once and takes the
+ *            energy from that -- the same float on every rank and for every sharding; [27] is used only if a residual was
+ *            outside [2^-11, 2^12), which no normalised distance is).
  *   n_total: number of reference points of the level over ALL shards (visible ratio, :457).
  * After an early termination (:877) later dvo_iter_update calls are no-ops, like the reference's break. */
 int  dvo_iter_begin(dvo_ctx *ctx, int pair, int level, int max_iters, const double *R, const double *t);
@@ -293,7 +296,8 @@ int  dvo_eval_points(dvo_ctx *ctx, int pair, int level, const double *R, const d
                      float *reproj, float *J, float *eps, float *w, int *visible);
 /* The 29 accumulators of one iteration at the given pose:
  * acc[0..20] = upper triangle of sum_i w_i J_i J_i^T, acc[21..26] = g = J^T W eps
- * (SolveDVO.cpp:777), acc[27] = sum eps_i^2, acc[28] = number of visible points. */
+ * (SolveDVO.cpp:777), acc[27] = sum eps_i^2 (the correctly rounded exact sum: no order of additions enters), acc[28] = number of
+ * visible points. */
 int  dvo_accumulate(dvo_ctx *ctx, int pair, int level, const double *R, const double *t,
                     double *acc29);
 /* Device SE(3) helpers exposed for property tests (same code the kernels use). */

@@ -2002,6 +2002,26 @@ int dvo_accumulate(dvo_ctx *c, int pair, int level, const double *R, const doubl
     HIPCHK(c, hipMemcpyAsync(h, acc, sizeof(double) * DVO_NACC_PAD, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, stream_wait(c->stream));
     std::memcpy(acc29, h, sizeof(double) * DVO_NUM_ACC);
+    /* sum eps^2 = the correctly rounded exact sum (the three limbs in slots 29..31; dvo_device_math.h: the energy without an order);
+     * the sum as the kernel added it only if a residual was outside the limbs' range (2^50 in limb 2) */
+    if (h[31] < 1125899906842624.0) {
+        unsigned __int128 S = (unsigned __int128)(unsigned long long)h[29] + ((unsigned __int128)(unsigned long long)h[30] << 32) +
+                              ((unsigned __int128)(unsigned long long)h[31] << 64);
+        double v = 0.0;
+        if (S != 0) {
+            int p = 127;
+            while (!((S >> p) & 1)) p--;
+            if (p <= 52) v = std::ldexp((double)(unsigned long long)S, -68);
+            else {
+                const int r = p - 52;
+                unsigned long long q = (unsigned long long)(S >> r);
+                const unsigned __int128 rem = S & ((((unsigned __int128)1) << r) - 1), half = ((unsigned __int128)1) << (r - 1);
+                if (rem > half || (rem == half && (q & 1ull))) q++;
+                v = std::ldexp((double)q, r - 68);
+            }
+        }
+        acc29[27] = v;
+    }
     return DVO_OK;
 }
 

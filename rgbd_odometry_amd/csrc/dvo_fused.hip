@@ -55,13 +55,15 @@ DVO_DEV unsigned long long stamp_real() {
 /* per-lane sums of one iteration (the sub-gradient policy of :724-920 needs g and the energy only).  WITH_H (round 5,
  * DVO_FLAG_NORMAL_MATRIX on the packed kernel): also the 21 entries of H = sum w J J^T (upper triangle, row-major; the pattern of
  * SolvePnP.cpp:168-182) -- exact products of two floats added in double, like g. */
-template <bool WITH_H>
+template <bool WITH_H, bool WITH_E2 = false>
 struct Acc7T {
-    static constexpr bool with_h = WITH_H;
+    static constexpr bool with_h = WITH_H, with_e2 = WITH_E2;
     double g[6];
     double e2;
     int nvis;          /* wave-uniform: ballots */
     double H[WITH_H ? 21 : 1];
+    E2Limbs l;         /* WITH_E2 (the step launches of the tiled / wide schedule, whose sums travel between launches and ranks): the exact
+                          sum of eps^2 rides along (dvo_device_math.h: the energy without an order); untouched otherwise */
 };
 typedef Acc7T<false> Acc7;
 
@@ -75,6 +77,7 @@ DVO_DEV void acc7_zero(ACC &a) {
 #pragma unroll
         for (int k = 0; k < 21; k++) a.H[k] = 0.0;
     }
+    if constexpr (ACC::with_e2) e2_limbs_zero(a.l);
 }
 /* H += jw (x) J for one point: entry (i, j >= i) at i*6 - i*(i-1)/2 + (j-i) */
 template <typename ACC>
@@ -357,6 +360,7 @@ DVO_DEV void acc7_add(ACC &a, const float *jw, const float *J, float eps) {
 #pragma unroll
     for (int k = 0; k < 6; k++) { jwd[k] = (double)jw[k]; a.g[k] = fma(jwd[k], e, a.g[k]); }
     a.e2 = fma(e, e, a.e2);
+    if constexpr (ACC::with_e2) e2_limbs_add(a.l, eps);
     if constexpr (ACC::with_h) {
         double Jd[6];
 #pragma unroll
@@ -417,6 +421,7 @@ DVO_DEV void round2_compute(const IterConst &c, const Round2<TEX> &b, ACC &a) {
         jacobian_weighted2(c, b.xn, b.yn, b.zn, gx0, gx1, gy0, gy1, w0, w1, jw, ACC::with_h ? J : nullptr);
     }
     const double e0 = (double)eps0, e1 = (double)eps1;
+    if constexpr (ACC::with_e2) { e2_limbs_add(a.l, eps0); e2_limbs_add(a.l, eps1); }
     if constexpr (!ACC::with_h) {
 #pragma unroll
         for (int k = 0; k < 6; k++) {
@@ -771,7 +776,8 @@ DVO_DEV double block_sum8(const double (*red)[8], int k /* 0..7 */) {
 }
 
 /* the three limbs of a wave -> red[wave][0..2] (integers below 2^53: every addition on the way is exact) */
-DVO_DEV void wave_sums_e2(const AccE2 &a, double (*red)[8]) {
+template <typename ACC>
+DVO_DEV void wave_sums_e2(const ACC &a, double (*red)[8]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double d[8];
     d[0] = (double)a.l.l0; d[1] = (double)a.l.l1; d[2] = (double)a.l.l2;
@@ -1507,12 +1513,14 @@ tiled_step_pk_kernel(LevelSlab L, int pair, int level, Intrinsics K, const PoseS
                      const double *__restrict__ acc_in, int itr, int apply_prev, int n_total, int first, int n,
                      double *partials, unsigned *ticket, double *acc_out, float *energy, double *H_prev) {
     __shared__ double red[DVO_STEP_THREADS / 64][8];
+    __shared__ double red2[DVO_STEP_THREADS / 64][8];                        /* the limbs of the exact sum of eps^2 */
     __shared__ double redH[WITH_H ? DVO_STEP_THREADS / 64 : 1][24];
     __shared__ TiledStepLds m;
     tiled_step_body<WITH_H>(m, st_in, st_out, acc_in, itr, apply_prev, n_total, first, n, partials, ticket, acc_out, energy, H_prev,
         [&](const PoseCur &pc, bool run, int b0, int b1, double *tot) {
             const int tid = threadIdx.x;
-            Acc7T<WITH_H> a;
+            typedef Acc7T<WITH_H, true> AccS;
+            AccS a;
             acc7_zero(a);
             if (run) {
                 const char *__restrict__ tex = reinterpret_cast<const char *>(L.tex + (size_t)pair * L.tex_stride);
@@ -1527,17 +1535,18 @@ tiled_step_pk_kernel(LevelSlab L, int pair, int level, Intrinsics K, const PoseS
                 ts.g16 = tex; ts.tile_col_bytes = (unsigned)c.tiles_per_col * 128u;
                 LdsPoints lp = {};
                 bool any_odd = false;
-                accumulate_points2<DVO_STEP_THREADS, false, TEX_G16, 2, 0, false, Acc7T<WITH_H>>(c, ts, lp, gpts, b0, b1, tid, a, any_odd);
+                accumulate_points2<DVO_STEP_THREADS, false, TEX_G16, 2, 0, false, AccS>(c, ts, lp, gpts, b0, b1, tid, a, any_odd);
                 {   /* a degenerate z somewhere in this wave's share: again with the literal divisions (see align_fused2_kernel) */
                     const double chk = ((a.g[0] + a.g[1]) + (a.g[2] + a.g[3])) + ((a.g[4] + a.g[5]) + a.e2);
                     any_odd |= (__builtin_amdgcn_ballot_w64(!__builtin_isfinite(chk)) != 0ull);
                 }
                 if (any_odd) {
                     acc7_zero(a);
-                    accumulate_points_exact<DVO_STEP_THREADS, false, false, false, Acc7T<WITH_H>>(c, tex, ts, nullptr, lp, gpts, b0, b1, tid, a);
+                    accumulate_points_exact<DVO_STEP_THREADS, false, false, false, AccS>(c, tex, ts, nullptr, lp, gpts, b0, b1, tid, a);
                 }
             }
             wave_sums7(a, red);
+            wave_sums_e2(a, red2);
             if constexpr (WITH_H) {       /* the wave's 21 sums of H: three passes of the 8-value reduce-scatter (align_fused2_kernel) */
 #pragma unroll
                 for (int q = 0; q < 3; q++) {
@@ -1553,6 +1562,7 @@ tiled_step_pk_kernel(LevelSlab L, int pair, int level, Intrinsics K, const PoseS
             if (tid < DVO_NACC_PAD) {
                 double v = 0.0;
                 if (tid >= 21 && tid < 29) v = block_sum8<DVO_STEP_THREADS>(red, tid - 21);
+                else if (tid >= 29) v = block_sum8<DVO_STEP_THREADS>(red2, tid - 29);
                 else if (WITH_H && tid < 21) {
 #pragma unroll
                     for (int w = 0; w < DVO_STEP_THREADS / 64; w++) v += redH[w][tid];      /* waves in order, like the other sums */
@@ -1585,6 +1595,7 @@ tiled_level_solo_kernel(LevelSlab L, int pair, int level, Intrinsics K, const Po
                         float *energy, double *Rt12, int *best_idx, float *ratio, float *next_energy, int next_iters) {
     constexpr int BLOCK = DVO_STEP_THREADS;
     __shared__ double red[BLOCK / 64][8];
+    __shared__ double red2[BLOCK / 64][8];                                   /* the limbs of the exact sum of eps^2 */
     __shared__ PoseState st;
     const int tid = threadIdx.x;
     {
@@ -1610,19 +1621,21 @@ tiled_level_solo_kernel(LevelSlab L, int pair, int level, Intrinsics K, const Po
         for (int k = 0; k < 9; k++) c.r[k] = uniform_f(pc.Rf[k]);    /* :673 */
 #pragma unroll
         for (int k = 0; k < 3; k++) c.t[k] = uniform_f(pc.tf[k]);    /* :674 */
-        Acc7 a;
+        typedef Acc7T<false, true> AccS;      /* one workgroup, all iterations: nothing to gain from the certificate, the limbs ride along */
+        AccS a;
         acc7_zero(a);
         bool any_odd = false;
-        accumulate_points2<BLOCK, false, TEX_G16, 2, 0, false, Acc7>(c, ts, lp, gpts, 0, N, lane_off, a, any_odd);
+        accumulate_points2<BLOCK, false, TEX_G16, 2, 0, false, AccS>(c, ts, lp, gpts, 0, N, lane_off, a, any_odd);
         {
             const double chk = ((a.g[0] + a.g[1]) + (a.g[2] + a.g[3])) + ((a.g[4] + a.g[5]) + a.e2);
             any_odd |= (__builtin_amdgcn_ballot_w64(!__builtin_isfinite(chk)) != 0ull);
         }
         if (any_odd) {
             acc7_zero(a);
-            accumulate_points_exact<BLOCK, false, false, false, Acc7>(c, tex, ts, nullptr, lp, gpts, 0, N, lane_off, a);
+            accumulate_points_exact<BLOCK, false, false, false, AccS>(c, tex, ts, nullptr, lp, gpts, 0, N, lane_off, a);
         }
         wave_sums7(a, red);
+        wave_sums_e2(a, red2);
         double neg_step = 0.0;
         if (wave == 0) neg_step = pose_neg_step(uc, itr);
         __syncthreads();
@@ -1632,7 +1645,8 @@ tiled_level_solo_kernel(LevelSlab L, int pair, int level, Intrinsics K, const Po
             pose_direction_lanes(st, uc, neg_step, sl, lane, psi);
             if (lane == 0) pose_apply(st, pc, pn, uc, psi);
         } else if (wave == 1 && lane == 0) {
-            energy[itr] = pose_bookkeep(st, pc, itr, N, block_sum8<BLOCK>(red, 6), (int)block_sum8<BLOCK>(red, 7));      /* :690 */
+            const double e2 = e2_from_limbs(block_sum8<BLOCK>(red2, 0), block_sum8<BLOCK>(red2, 1), block_sum8<BLOCK>(red2, 2), block_sum8<BLOCK>(red, 6));
+            energy[itr] = pose_bookkeep(st, pc, itr, N, e2, (int)block_sum8<BLOCK>(red, 7));      /* :690 */
         }
         __syncthreads();
         if (st.stop) break;                                          /* :877 */

@@ -46,7 +46,12 @@ struct Acc {
                            Exact float x float products summed in double, like g.  Only the kernels instantiated WITH_H carry
                            them: the reference's sub-gradient policy never forms H (SolveDVO.cpp:777) */
     int nvis;           /* visible points, counted per WAVE with ballots (uniform) */
+    E2Limbs l;          /* the exact sum of eps^2 (round 6, dvo_device_math.h: the energy without an order): these kernels' sums travel
+                           between launches, workgroups and ranks, so the limbs ride along always -- slots 29..31 of the 32 */
 };
+/* the 32 slots of a reduced accumulator row -> sum eps^2: the correctly rounded exact sum (slot 27 -- the sum as added -- only if a
+ * residual was outside the limbs' range) */
+DVO_DEV double acc_sum_eps2(const double *acc) { return e2_from_limbs(acc[29], acc[30], acc[31], acc[27]); }
 DVO_DEV void acc_zero(Acc &a) {
 #pragma unroll
     for (int k = 0; k < 6; k++) a.g[k] = 0.0;
@@ -54,6 +59,7 @@ DVO_DEV void acc_zero(Acc &a) {
 #pragma unroll
     for (int k = 0; k < 21; k++) a.H[k] = 0.0;
     a.nvis = 0;
+    e2_limbs_zero(a.l);
 }
 /* visible point -> accumulators.  jw = (float)(J_k*w) (:716) widened, times eps
  * widened (:719-720): both factors are floats, so the double product is exact and
@@ -68,6 +74,7 @@ DVO_DEV void acc_add(Acc &a, const float *J, float eps, float w) {
         a.g[k] = fma((double)jw[k], e, a.g[k]);
     }
     a.e2 = fma(e, e, a.e2);
+    e2_limbs_add(a.l, eps);
     if (WITH_H) {
         /* upper triangle, row-major: index(i,j) = i*6 - i*(i-1)/2 + (j-i); written with
          * compile-time indices so H stays in registers */
@@ -189,8 +196,8 @@ DVO_DEV void wave_reduce_scatter8_dpp(double (&v)[8]) {
 /* value index held by lane L after wave_reduce_scatter8_dpp */
 DVO_DEV int reduce_scatter8_dpp_index(int lane) { return 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1); }
 
-/* Fixed-shape reduction of the 29 accumulators over a workgroup.
- * Result in tot[0..28] (valid after the trailing barrier). */
+/* Fixed-shape reduction of the 29 accumulators and the three limbs of the exact sum of eps^2 over a workgroup.
+ * Result in tot[0..31] (valid after the trailing barrier). */
 template <int BLOCK, bool WITH_H>
 DVO_DEV void block_reduce(const Acc &a, double (*red)[DVO_NACC_PAD], double *tot) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -214,9 +221,18 @@ DVO_DEV void block_reduce(const Acc &a, double (*red)[DVO_NACC_PAD], double *tot
         const int idx = reduce_scatter8_dpp_index(lane);
         if (lane < 8 && idx < 7) red[wave][21 + idx] = d[0];
     }
+    {   /* the three limbs: integers below 2^53, every addition from here on is exact */
+        double d[8];
+        d[0] = (double)a.l.l0; d[1] = (double)a.l.l1; d[2] = (double)a.l.l2;
+#pragma unroll
+        for (int k = 3; k < 8; k++) d[k] = 0.0;
+        wave_reduce_scatter8_dpp(d);
+        const int idx = reduce_scatter8_dpp_index(lane);
+        if (lane < 8 && idx < 3) red[wave][29 + idx] = d[0];
+    }
     if (lane == 0) red[wave][28] = (double)a.nvis;
     __syncthreads();
-    if (threadIdx.x < DVO_NACC) {
+    if (threadIdx.x < DVO_NACC_PAD) {
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < BLOCK / 64; w++) s += red[w][threadIdx.x];

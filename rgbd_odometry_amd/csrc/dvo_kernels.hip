@@ -431,7 +431,7 @@ align_fused_kernel(LevelSet lv, Schedule sc, Intrinsics K, DevParams prm, Output
                 out.H[((size_t)pair * sc.e_stride + sc.e_off[l] + itr) * 21 + tid] = tot[tid];
             DVO_STAMP(t2);
             if (tid == 0) {
-                const float e = pose_update_t<true>(st, st.u, itr, N, &tot[21], tot[27], (int)tot[28]);
+                const float e = pose_update_t<true>(st, st.u, itr, N, &tot[21], acc_sum_eps2(tot), (int)tot[28]);
                 energy[itr] = e;                                             /* :690 */
             }
             DVO_STAMP(t3);
@@ -609,7 +609,7 @@ accumulate_kernel(LevelSlab L, int pair, int level, Intrinsics K, FloatPose P,
     if (b0 < b1) accumulate_points<4, true, SRC_GLOBAL_XYZ, 2>(c, tex, psrc, b0, b1, threadIdx.x, 256, a);
     block_reduce<256, true>(a, red, tot);
     if (threadIdx.x < DVO_NACC_PAD)
-        partials[(size_t)blockIdx.x * DVO_NACC_PAD + threadIdx.x] = (threadIdx.x < DVO_NACC) ? tot[threadIdx.x] : 0.0;
+        partials[(size_t)blockIdx.x * DVO_NACC_PAD + threadIdx.x] = tot[threadIdx.x];
 }
 
 /* acc[k] = sum over blocks of partials[b][k], in a fixed two-level order (32 interleaved chains per value,
@@ -693,7 +693,7 @@ accumulate_state_kernel(LevelSlab L, int pair, int level, Intrinsics K, const Po
     if (b0 < b1) accumulate_points<2, true, SRC_GLOBAL_XYZ, 2>(c, tex, psrc, b0, b1, threadIdx.x, 256, a);
     block_reduce<256, true>(a, red, tot);
     if (threadIdx.x < DVO_NACC_PAD)
-        partials[(size_t)blockIdx.x * DVO_NACC_PAD + threadIdx.x] = (threadIdx.x < DVO_NACC) ? tot[threadIdx.x] : 0.0;
+        partials[(size_t)blockIdx.x * DVO_NACC_PAD + threadIdx.x] = tot[threadIdx.x];
 }
 
 __global__ void __launch_bounds__(64)
@@ -702,7 +702,7 @@ iter_update_kernel(PoseState *st, DevParams prm, int itr, int n_total, const dou
     if (threadIdx.x == 0 && !st->stop) {                                    /* after :877 nothing runs */
         double g[6];
         for (int k = 0; k < 6; k++) g[k] = acc[21 + k];
-        energy[itr] = pose_update(*st, st->u, itr, n_total, g, acc[27], (int)acc[28]);
+        energy[itr] = pose_update(*st, st->u, itr, n_total, g, acc_sum_eps2(acc), (int)acc[28]);
     }
 }
 
@@ -727,7 +727,7 @@ iter_reduce_update_kernel(PoseState *st, DevParams prm, int itr, int n_total,
     if (threadIdx.x == 0 && !st->stop) {
         double g[6];
         for (int q = 0; q < 6; q++) g[q] = acc[21 + q];
-        energy[itr] = pose_update(*st, st->u, itr, n_total, g, acc[27], (int)acc[28]);
+        energy[itr] = pose_update(*st, st->u, itr, n_total, g, acc_sum_eps2(acc), (int)acc[28]);
     }
 }
 
@@ -800,7 +800,7 @@ tiled_finish_kernel(const PoseState *st_in, PoseState *st_out, DevParams prm, co
         if (!s.stop) {
             double g[6];
             for (int k = 0; k < 6; k++) g[k] = acc_in[21 + k];
-            energy[itr_last] = pose_update_t<true>(s, s.u, itr_last, n_total, g, acc_in[27], (int)acc_in[28]);
+            energy[itr_last] = pose_update_t<true>(s, s.u, itr_last, n_total, g, acc_sum_eps2(acc_in), (int)acc_in[28]);
         }
         pose_state_finish(s);                                               /* :997-1001 */
         for (int k = 0; k < 9; k++) Rt12[k] = s.R[k];

@@ -41,13 +41,13 @@ struct TiledStepLds {
     double part[16][DVO_NACC_PAD + 1];
     PoseState s;
     PoseCur nxt;                                                            /* the iterate the pending update produces */
-    double g_s[8];                                                          /* sums 21..28 of the previous launch */
+    double g_s[12];                                                         /* sums 21..31 of the previous launch (29..31: the limbs of the exact sum of eps^2) */
     int s_stop0;
     unsigned seq;                                                           /* the launch's sequence number (ticket[1]) */
 };
 
 /* points(pc, run, b0, b1, tot): EVERY thread of the workgroup calls it; it leaves the workgroup's sums of points [b0, b1) at pose pc in
- * tot[0 .. DVO_NACC) (zeros when !run), behind a workgroup barrier */
+ * tot[0 .. DVO_NACC_PAD) (zeros when !run), behind a workgroup barrier */
 template <bool WITH_H, typename Points>
 DVO_DEV void tiled_step_body(TiledStepLds &m, const PoseState *st_in, PoseState *st_out, const double *__restrict__ acc_in, int itr, int apply_prev,
                              int n_total, int first, int n, double *partials, unsigned *ticket, double *acc_out, float *energy, double *H_prev,
@@ -66,9 +66,9 @@ DVO_DEV void tiled_step_body(TiledStepLds &m, const PoseState *st_in, PoseState 
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(&s);
         for (int i = tid; i < (int)(sizeof(PoseState) / 8); i += DVO_STEP_THREADS) dst[i] = src[i];
         if (wave == 7) {
-            if (lane < 8) m.g_s[lane] = apply_prev ? acc_in[21 + lane] : 0.0;
-            if (lane == 8) m.s_stop0 = st_in->stop;
-            if (lane == 9) m.seq = ticket[1];
+            if (lane < 11) m.g_s[lane] = apply_prev ? acc_in[21 + lane] : 0.0;
+            if (lane == 11) m.s_stop0 = st_in->stop;
+            if (lane == 12) m.seq = ticket[1];
         }
     }
     __syncthreads();
@@ -79,7 +79,8 @@ DVO_DEV void tiled_step_body(TiledStepLds &m, const PoseState *st_in, PoseState 
             pose_direction_lanes(s, s.u, pose_neg_step(s.u, itr - 1), m.g_s[lane < 6 ? lane : 5], lane, psi);
             if (lane == 0) pose_apply(s, s.p[0], nxt, s.u, psi);
         } else if (wave == 1 && lane == 0) {
-            const float e = pose_bookkeep(s, s.p[0], itr - 1, n_total, m.g_s[6], (int)m.g_s[7]);
+            /* the energy without an order (dvo_device_math.h): the limbs were added exactly over workgroups and ranks */
+            const float e = pose_bookkeep(s, s.p[0], itr - 1, n_total, e2_from_limbs(m.g_s[8], m.g_s[9], m.g_s[10], m.g_s[6]), (int)m.g_s[7]);
             if (blockIdx.x == 0) energy[itr - 1] = e;                       /* :690 */
         } else if (WITH_H && wave == 2) {
             /* DVO_FLAG_NORMAL_MATRIX: H = sum w J J^T of the previous iterate (reduced over all ranks), kept per iterate like the batch kernels do */
@@ -115,18 +116,19 @@ DVO_DEV void tiled_step_body(TiledStepLds &m, const PoseState *st_in, PoseState 
     double *tot = m.tot;
     double (*part)[DVO_NACC_PAD + 1] = m.part;
     {
-        /* tail: tagged rows to workgroup 0 (see step_store_rec).  A row is the eight sums 21..28, or with H all DVO_NACC_PAD slots */
-        constexpr int ROW = WITH_H ? DVO_NACC_PAD : 8;
+        /* tail: tagged rows to workgroup 0 (see step_store_rec).  A row is the sums 21..31 (sixteen records: g, sum eps^2, the visible
+         * count, the three limbs of the exact sum of eps^2 -- round 6; eight until then), or with H all DVO_NACC_PAD slots */
+        constexpr int ROW = WITH_H ? DVO_NACC_PAD : 16;
         constexpr int OFF = WITH_H ? 0 : 21;                                /* slot of the row's first value */
         const unsigned tag = m.seq + 1u;
         step_v4u *recs = reinterpret_cast<step_v4u *>(partials);             /* [workgroup][ROW] records */
         if (gridDim.x == 1) {                                               /* the only workgroup: its sums are the launch's */
-            if (tid < DVO_NACC_PAD) acc_out[tid] = (tid >= OFF && tid < DVO_NACC) ? tot[tid] : 0.0;
+            if (tid < DVO_NACC_PAD) acc_out[tid] = (tid >= OFF) ? tot[tid] : 0.0;
             if (tid == 0) ticket[1] = tag;
             return;
         }
         if (blockIdx.x != 0) {
-            if (tid < ROW) step_store_rec(recs + (size_t)blockIdx.x * ROW + tid, (OFF + tid < DVO_NACC) ? tot[OFF + tid] : 0.0, tag);
+            if (tid < ROW) step_store_rec(recs + (size_t)blockIdx.x * ROW + tid, (OFF + tid < DVO_NACC_PAD) ? tot[OFF + tid] : 0.0, tag);
             return;
         }
         /* workgroup 0: records ROW .. ROW * gridDim.x - 1; thread t takes t, t + 512, t + 1024, ...: all of one sum k = t & (ROW - 1) */
@@ -164,7 +166,7 @@ DVO_DEV void tiled_step_body(TiledStepLds &m, const PoseState *st_in, PoseState 
         __syncthreads();
         if (tid < DVO_NACC_PAD) {
             double t = 0.0;
-            if (tid >= OFF && tid < DVO_NACC) {
+            if (tid >= OFF) {
                 const int k = tid - OFF;
                 for (int ch = 0; ch < DVO_STEP_THREADS / ROW; ch++) t += flat[ch * ROW + k];      /* fixed order */
             }

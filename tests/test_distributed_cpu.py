@@ -56,15 +56,16 @@ class OracleTiledEngine:
     def iter_accumulate(self, level, first, count, acc):
         L = self.lv[level]
         R, t = self.o.state_pose(self.st)
-        a = self.o.accumulate(level, L["xyz"], first, count, L["dt"], L["gx"], L["gy"], L["rows"], L["cols"], self.K, R, t)
-        acc.zero_()
-        acc[:29] = torch.from_numpy(a)
+        # slots 29..31: the three limbs of the shard's exact sum of eps^2 -- they add exactly in the all-reduce (round 6)
+        a = self.o.accumulate32(level, L["xyz"], first, count, L["dt"], L["gx"], L["gy"], L["rows"], L["cols"], self.K, R, t)
+        acc.copy_(torch.from_numpy(a))
 
     def iter_update(self, level, itr, n_total, acc):
         if self.broke:
             return
         a = acc.numpy()
-        e, broke, _ = self.o.state_update(self.st, itr, n_total, a[21:27], float(a[27]), int(a[28]))
+        sum_eps2 = self.o.e2_from_limbs(a[29:32], float(a[27]))      # the correctly rounded exact sum over ALL shards: no order, no sharding enters
+        e, broke, _ = self.o.state_update(self.st, itr, n_total, a[21:27], sum_eps2, int(a[28]))
         self.energy[itr] = e
         self.broke = broke
 
