@@ -324,7 +324,7 @@ def frames_leg(args, iters):
     # the same now frames as DEVICE buffers (a decoder / camera driver that lands frames in HBM): everything the GPU does per
     # now frame -- landing copy, pyramid, Canny, distance transform -> compact now level, alignment -- and no PCIe
     dev_now = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in now]
-    dev_ptrs = [dev_now[i % D].data_ptr() for i in range(B)]
+    dev_ptrs = ctx.pointer_table([dev_now[i % D].data_ptr() for i in range(B)])      # the decoder's ring: the table is built once
 
     def device_step():
         ctx.frames_upload_cameras_device(dev_ptrs, None, args.height, args.width, n_levels=args.levels, first_shift=0,

@@ -577,14 +577,20 @@ class DvoContext:
         pinned host memory the GPU addresses (pulled over PCIe by a kernel).  Lists of addresses (ints) of (rows, cols, 3) uint8
         BGR images and, or None, (rows, cols) float32 depth images"""
         count = len(bgr_ptrs)
-        B = (C.c_void_p * count)(*[int(p) for p in bgr_ptrs])
-        Dp = (C.c_void_p * count)(*[int(p) for p in depth_ptrs]) if depth_ptrs is not None else None
+        # a caller that feeds the same buffers every step (a decoder's ring) passes prepared tables: pointer_table(addresses)
+        B = bgr_ptrs if isinstance(bgr_ptrs, C.Array) else (C.c_void_p * count)(*[int(p) for p in bgr_ptrs])
+        Dp = None if depth_ptrs is None else (depth_ptrs if isinstance(depth_ptrs, C.Array) else (C.c_void_p * count)(*[int(p) for p in depth_ptrs]))
         if not flags & DVO_UPLOAD_MAPPED:
             flags |= DVO_UPLOAD_DEVICE
         self._chk(self.lib.dvo_frames_upload_cameras(self._h, first_slot, count, B, Dp, rows, cols, n_levels, first_shift,
                                                      now_first_pair, flags))
         if now_first_pair >= 0:
             self._note_dims(first_slot)
+
+    @staticmethod
+    def pointer_table(addresses):
+        """a list of addresses as the C array frames_upload_cameras_device takes (built once, passed every step)"""
+        return (C.c_void_p * len(addresses))(*[int(p) for p in addresses])
 
     def frames_as_now(self, first_slot: int = 0, first_pair: int = 0, count: int = 1):
         self._chk(self.lib.dvo_frames_as_now(self._h, first_slot, first_pair, count))

@@ -982,6 +982,7 @@ int dvo_destroy(dvo_ctx *c) {
     if (c->copy_stream2) { (void)hipStreamSynchronize(c->copy_stream2); (void)hipStreamDestroy(c->copy_stream2); }
     for (int b = 0; b < 2; b++) {
         if (c->up_buf[b]) (void)hipFree(c->up_buf[b]);
+        if (b == 0) { if (c->src_tab_dev) (void)hipFree(c->src_tab_dev); if (c->src_tab_host) (void)hipHostFree(c->src_tab_host); if (c->ev_src_tab) (void)hipEventDestroy(c->ev_src_tab); }
         if (c->up_host[b]) (void)hipHostFree(c->up_host[b]);
         if (c->ev_copied[b]) (void)hipEventDestroy(c->ev_copied[b]);
         if (c->ev_copied2[b]) (void)hipEventDestroy(c->ev_copied2[b]);

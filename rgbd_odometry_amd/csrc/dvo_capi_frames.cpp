@@ -495,10 +495,40 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
     const size_t b_img = (npx * 3 + 15) / 16 * 16, d_img = depth_m ? npx * 4 : 0;
     const bool dev_src = (flags & DVO_UPLOAD_DEVICE) != 0;     /* no PCIe to overlap with: whole batches per stage */
     const bool pulled = dev_src || (flags & DVO_UPLOAD_MAPPED);  /* device-addressable sources: gathered by a kernel, no pinned mirror */
+    /* Frames already in HBM are read where they are (round 6): their addresses go up as a table and the level kernels index it -- no
+     * landing copy (per 256 VGA frames 236 MB each way, 71 us, and a stream hand-over: 1.60 -> 1.5 ms per `frames in HBM -> poses` step).
+     * Needs the alignment of the landing buffer (4 bytes BGR, 16 depth); DVO_DEVICE_DIRECT=off keeps the copy (A/B). */
+    static const bool direct_off = [] { const char *e = getenv("DVO_DEVICE_DIRECT"); return e && !std::strcmp(e, "off"); }();
+    bool direct = dev_src && !direct_off;
+    for (int f = 0; f < count && direct; f++)
+        direct = (reinterpret_cast<size_t>(bgr8[f]) & 3) == 0 && (!depth_m || (reinterpret_cast<size_t>(depth_m[f]) & 15) == 0);
     const size_t half = dev_src ? kDeviceHalf : ((flags & DVO_UPLOAD_MAPPED) ? kMappedHalf : kUploadHalf);
-    int chunk = (int)std::min<size_t>(std::max<size_t>(half / (b_img + d_img), 1), (size_t)count);
-    if (pulled && chunk > 32) chunk -= chunk % 32;              /* whole gather launches of 32 images: a short tail launch runs far below the link rate */
-    if ((rc = ensure_upload(c, (b_img + d_img) * chunk, !pulled))) return rc;
+    int chunk = direct ? count : (int)std::min<size_t>(std::max<size_t>(half / (b_img + d_img), 1), (size_t)count);
+    if (!direct && pulled && chunk > 32) chunk -= chunk % 32;   /* whole gather launches of 32 images: a short tail launch runs far below the link rate */
+    if (!direct && (rc = ensure_upload(c, (b_img + d_img) * chunk, !pulled))) return rc;
+    SrcTab tab0 = {nullptr, nullptr};
+    if (direct) {
+        const int need = 2 * count;
+        if (need > c->src_tab_cap) {
+            HIPCHK(c, stream_wait(c->stream));
+            if (c->src_tab_dev) HIPCHK(c, hipFree(c->src_tab_dev));
+            if (c->src_tab_host) HIPCHK(c, hipHostFree(c->src_tab_host));
+            c->src_tab_dev = nullptr; c->src_tab_host = nullptr; c->src_tab_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->src_tab_dev, sizeof(void *) * (size_t)need));
+            HIPCHK(c, hipHostMalloc((void **)&c->src_tab_host, sizeof(void *) * (size_t)need, hipHostMallocDefault));
+            c->src_tab_cap = need;
+        }
+        if (!c->ev_src_tab) HIPCHK(c, hipEventCreateWithFlags(&c->ev_src_tab, hipEventDisableTiming));
+        else HIPCHK(c, hipEventSynchronize(c->ev_src_tab));      /* the staging table's previous copy has gone up; the DEVICE table's readers are ahead of this call's copy on the stream */
+        for (int f = 0; f < count; f++) {
+            c->src_tab_host[f] = const_cast<unsigned char *>(bgr8[f]);
+            c->src_tab_host[count + f] = depth_m ? const_cast<float *>(depth_m[f]) : nullptr;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->src_tab_dev, c->src_tab_host, sizeof(void *) * (size_t)need, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_src_tab, c->stream));
+        tab0.bgr = c->src_tab_dev;
+        tab0.depth = depth_m ? c->src_tab_dev + count : nullptr;
+    }
     /* chunk k+1 is copied (copy streams) while chunk k is preprocessed (context stream), over two landing buffers.  The copies
      * of chunk k+1 are SUBMITTED before the kernels of chunk k: measured on this pool (tools/experiments/exp_pull_overlap.sh),
      * work of two streams that becomes ready at the same moment starts in submission order, and a pull submitted after ~45
@@ -506,6 +536,7 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
     struct Chunk { int b, nc, ub; unsigned char *sb; float *sd; };
     int next_ub = c->up_next;
     auto issue_copy = [&](int b, Chunk &k) -> int {
+        if (direct) { k.b = b; k.nc = std::min(chunk, count - b); k.ub = -1; k.sb = nullptr; k.sd = nullptr; return DVO_OK; }
         k.b = b; k.nc = std::min(chunk, count - b); k.ub = next_ub; next_ub ^= 1;
         k.sb = c->up_buf[k.ub]; k.sd = (float *)(k.sb + b_img * chunk);
         if (c->up_used[k.ub]) {                             /* the buffer's previous consumer (two chunks back) has read it */
@@ -548,17 +579,21 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
         int rc2;
         LevelLanes ln;
         if ((rc2 = lanes_begin(c, n_levels, k.nc, now_first_pair >= 0, ln))) return rc2;
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copied[k.ub], 0));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copied2[k.ub], 0));
+        const SrcTab tab = direct ? SrcTab{tab0.bgr + k.b, tab0.depth ? tab0.depth + k.b : nullptr} : SrcTab{nullptr, nullptr};
+        const float *const dsrc = depth_m ? (direct ? reinterpret_cast<const float *>(16) /* "has depth"; the table holds the addresses */ : k.sd) : nullptr;
+        if (k.ub >= 0) {
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copied[k.ub], 0));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copied2[k.ub], 0));
+        }
         if ((rc2 = lanes_fork(c, n_levels, ln))) return rc2;
         for (int pass = 0; pass < 2; pass++) {
             for (int l = 0; l < n_levels; l++) {
                 FrameLevel &F = c->fs.lv[l];
                 const size_t off = (size_t)(first_slot + k.b) * F.npx;
                 if (ln.parallel || (pass == 0 && (l == 0 || n_levels == 2)))
-                    HIPCHK(c, launch_camera_level(k.sb, b_img, depth_m ? k.sd : nullptr, npx, rows, cols, first_shift + l,
+                    HIPCHK(c, launch_camera_level(k.sb, b_img, dsrc, npx, rows, cols, first_shift + l,
                                                   c->d_umap_xy, c->d_umap_frac, (flags & DVO_UPLOAD_DEPTH_RAW) ? 1 : 0,
-                                                  F.grey + off, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, k.nc}, ln.s[l]));
+                                                  F.grey + off, F.depth + off, F.npx, ImgBatch{F.rows, F.cols, k.nc}, ln.s[l], tab));
                 else if (pass == 0 && l == 1) {                  /* levels 1 .. n-1 in one launch */
                     int sh[DVO_LEVELS], lr2[DVO_LEVELS], lc2[DVO_LEVELS]; unsigned char *gl[DVO_LEVELS]; float *dl[DVO_LEVELS]; size_t st[DVO_LEVELS];
                     for (int m = 1; m < n_levels; m++) {
@@ -566,8 +601,8 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
                         sh[m - 1] = first_shift + m; lr2[m - 1] = G.rows; lc2[m - 1] = G.cols; st[m - 1] = G.npx;
                         gl[m - 1] = G.grey + (size_t)(first_slot + k.b) * G.npx; dl[m - 1] = G.depth + (size_t)(first_slot + k.b) * G.npx;
                     }
-                    HIPCHK(c, launch_camera_levels(k.sb, b_img, depth_m ? k.sd : nullptr, npx, rows, cols, n_levels - 1, sh, lr2, lc2, c->d_umap_xy,
-                                                   c->d_umap_frac, (flags & DVO_UPLOAD_DEPTH_RAW) ? 1 : 0, gl, dl, st, k.nc, c->stream));
+                    HIPCHK(c, launch_camera_levels(k.sb, b_img, dsrc, npx, rows, cols, n_levels - 1, sh, lr2, lc2, c->d_umap_xy,
+                                                   c->d_umap_frac, (flags & DVO_UPLOAD_DEPTH_RAW) ? 1 : 0, gl, dl, st, k.nc, c->stream, tab));
                 }
                 if (pass == 1 && !ln.parallel && l == 0) {         /* one launch per stage for all levels */
                     if ((rc2 = run_canny_all(c, n_levels, first_slot + k.b, k.nc, c->stream))) return rc2;
@@ -580,11 +615,11 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
                 }
             }
             if (ln.parallel) break;
-            if (pass == 0) HIPCHK(c, hipEventRecord(c->ev_done[k.ub], c->stream));     /* the landing buffer is free again */
+            if (pass == 0 && k.ub >= 0) HIPCHK(c, hipEventRecord(c->ev_done[k.ub], c->stream));     /* the landing buffer is free again */
         }
         if (ln.parallel) {
             if ((rc2 = lanes_join(c, n_levels, ln))) return rc2;
-            HIPCHK(c, hipEventRecord(c->ev_done[k.ub], c->stream));
+            if (k.ub >= 0) HIPCHK(c, hipEventRecord(c->ev_done[k.ub], c->stream));
         }
         return DVO_OK;
     };
@@ -603,7 +638,7 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
             if (more && !ahead && (rc = issue_copy(b + chunk, nxt))) return rc;
             cur = nxt;
         }
-        c->up_next = next_ub;
+        if (!direct) c->up_next = next_ub;
     }
     for (int f = 0; f < count; f++) { c->fs.valid[first_slot + f] = 1; c->fs.has_depth[first_slot + f] = depth_m ? 1 : 0; }
     if (!(flags & DVO_UPLOAD_ASYNC)) HIPCHK(c, stream_wait(c->stream));

@@ -175,6 +175,10 @@ struct dvo_ctx {
     int *work = nullptr;            /* preprocessing scratch (Canny / distance transform / point counts) */
     size_t work_bytes = 0;
     /* frame uploads: two landing buffers filled by a copy stream while the context stream preprocesses the other */
+    /* camera frames that already sit in HBM are read where they are (round 6): their addresses go up as a table (pinned staging -> device) */
+    void **src_tab_dev = nullptr, **src_tab_host = nullptr;
+    int src_tab_cap = 0;
+    hipEvent_t ev_src_tab = nullptr;
     unsigned char *up_buf[2] = {nullptr, nullptr};
     unsigned char *up_host[2] = {nullptr, nullptr};      /* pinned mirrors: small images are gathered here and go up in one copy */
     size_t up_bytes = 0, up_host_bytes = 0;              /* landing buffers / their pinned mirrors (no mirror for device sources) */

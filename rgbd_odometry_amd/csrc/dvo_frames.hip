@@ -147,15 +147,22 @@ DVO_DEV void undistort_taps(int sx, int sy, int src_rows, int src_cols, size_t (
         }
 }
 constexpr int CAM_TY = 64, CAM_TX = 16;
+/* image `by` of a launch: at base + by * stride (the landing buffer), or -- camera frames that already sit in HBM, round 6 -- wherever the
+ * caller's pointer table says: the frames are read where they are, no landing copy (236 MB each way per 256 VGA frames) */
+DVO_DEV void camera_sources(const SrcTab &tab, int by, const unsigned char *__restrict__ &bgr, size_t bgr_stride,
+                            const float *__restrict__ &depth_m, size_t depth_stride) {
+    if (tab.bgr) bgr = static_cast<const unsigned char *>(tab.bgr[by]); else bgr += (size_t)by * bgr_stride;
+    if (tab.depth) depth_m = static_cast<const float *>(tab.depth[by]); else if (depth_m) depth_m += (size_t)by * depth_stride;
+}
 DVO_DEV void camera_level_body(const int bx, const int by, const unsigned char *__restrict__ bgr, size_t bgr_stride,
                     const float *__restrict__ depth_m, size_t depth_stride,
                     int src_rows, int src_cols, int shift, int tiles_y, UndistortMaps um,
-                    unsigned char *__restrict__ grey, float *__restrict__ depth, size_t stride, int rows, int cols) {
+                    unsigned char *__restrict__ grey, float *__restrict__ depth, size_t stride, int rows, int cols, const SrcTab tab) {
     __shared__ unsigned char sg[CAM_TX][CAM_TY + 4];
     __shared__ float sd[CAM_TX][CAM_TY + 1];
-    bgr += (size_t)by * bgr_stride;
+    camera_sources(tab, by, bgr, bgr_stride, depth_m, depth_stride);
     grey += (size_t)by * stride;
-    if (depth_m) { depth_m += (size_t)by * depth_stride; depth += (size_t)by * stride; }
+    if (depth_m) depth += (size_t)by * stride;
     const int y0 = (bx % tiles_y) * CAM_TY, x0 = (bx / tiles_y) * CAM_TX;
 #pragma unroll
     for (int k = 0; k < CAM_TY * CAM_TX / 256; k++) {
@@ -218,8 +225,8 @@ DVO_DEV void camera_level_body(const int bx, const int by, const unsigned char *
 __global__ void __launch_bounds__(256)
 camera_level_kernel(const unsigned char *__restrict__ bgr, size_t bgr_stride, const float *__restrict__ depth_m, size_t depth_stride,
                     int src_rows, int src_cols, int shift, int tiles_y, UndistortMaps um,
-                    unsigned char *__restrict__ grey, float *__restrict__ depth, size_t stride, int rows, int cols) {
-    camera_level_body(blockIdx.x, blockIdx.y, bgr, bgr_stride, depth_m, depth_stride, src_rows, src_cols, shift, tiles_y, um, grey, depth, stride, rows, cols);
+                    unsigned char *__restrict__ grey, float *__restrict__ depth, size_t stride, int rows, int cols, const SrcTab tab) {
+    camera_level_body(blockIdx.x, blockIdx.y, bgr, bgr_stride, depth_m, depth_stride, src_rows, src_cols, shift, tiles_y, um, grey, depth, stride, rows, cols, tab);
 }
 /* several pyramid levels of the same camera frames in one launch (see CannyLevels in the Canny section) */
 struct CameraLevels {
@@ -230,11 +237,11 @@ struct CameraLevels {
 };
 __global__ void __launch_bounds__(256)
 camera_levels_kernel(const unsigned char *__restrict__ bgr, size_t bgr_stride, const float *__restrict__ depth_m, size_t depth_stride,
-                     UndistortMaps um, const CameraLevels t) {
+                     UndistortMaps um, const CameraLevels t, const SrcTab tab) {
     int l = 0;
     while (l + 1 < t.n && blockIdx.x >= t.first[l + 1]) l++;
     camera_level_body((int)(blockIdx.x - t.first[l]), blockIdx.y, bgr, bgr_stride, depth_m, depth_stride, t.src_rows, t.src_cols, t.shift[l],
-                      (t.rows[l] + CAM_TY - 1) / CAM_TY, um, t.grey[l], t.depth[l], t.stride[l], t.rows[l], t.cols[l]);
+                      (t.rows[l] + CAM_TY - 1) / CAM_TY, um, t.grey[l], t.depth[l], t.stride[l], t.rows[l], t.cols[l], tab);
 }
 
 /* The full-resolution level of an undistortion-free camera frame (shift 0, no map: every pixel is read once): four pixels per
@@ -245,13 +252,13 @@ constexpr int CF_T = 64;
 __global__ void __launch_bounds__(256)
 camera_level0_kernel(const unsigned char *__restrict__ bgr, size_t bgr_stride, const float *__restrict__ depth_m, size_t depth_stride,
                      int rows, int cols, int tiles_y, int depth_raw,
-                     unsigned char *__restrict__ grey, float *__restrict__ depth, size_t stride) {
+                     unsigned char *__restrict__ grey, float *__restrict__ depth, size_t stride, const SrcTab tab) {
     __shared__ unsigned sg4[CF_T][CF_T / 4 + 1];                /* [x][y / 4]: grey bytes */
     __shared__ float sd[CF_T][CF_T + 1];
     unsigned char (*sg)[CF_T + 4] = reinterpret_cast<unsigned char (*)[CF_T + 4]>(sg4);
-    bgr += (size_t)blockIdx.y * bgr_stride;
+    camera_sources(tab, blockIdx.y, bgr, bgr_stride, depth_m, depth_stride);
     grey += (size_t)blockIdx.y * stride;
-    if (depth_m) { depth_m += (size_t)blockIdx.y * depth_stride; depth += (size_t)blockIdx.y * stride; }
+    if (depth_m) depth += (size_t)blockIdx.y * stride;
     const int y0 = (blockIdx.x % tiles_y) * CF_T, x0 = (blockIdx.x / tiles_y) * CF_T;
     auto to_grey = [](unsigned b, unsigned g, unsigned r) { return (unsigned char)((1868u * b + 9617u * g + 4899u * r + (1u << 13)) >> 14); };   /* BGR2GRAY 8u */
 #pragma unroll
@@ -325,25 +332,28 @@ hipError_t launch_gather_images(const void *const *src, int count, void *dst, si
 
 hipError_t launch_camera_level(const unsigned char *bgr, size_t bgr_stride, const float *depth_m, size_t depth_stride,
                                int src_rows, int src_cols, int shift, const short2 *umap_xy, const unsigned short *umap_frac,
-                               int depth_raw, unsigned char *grey, float *depth_mm, size_t stride, ImgBatch g, hipStream_t s) {
-    if (shift == 0 && !umap_xy && g.rows == src_rows && g.cols == src_cols && (g.rows & 3) == 0 && (g.cols & 3) == 0 &&
-        ((reinterpret_cast<size_t>(bgr) | bgr_stride | reinterpret_cast<size_t>(grey) | stride) & 3) == 0 &&
-        (!depth_m || ((reinterpret_cast<size_t>(depth_m) | (depth_stride * 4)) & 15) == 0)) {
+                               int depth_raw, unsigned char *grey, float *depth_mm, size_t stride, ImgBatch g, hipStream_t s, SrcTab tab) {
+    /* a pointer table: the caller has checked every image's alignment (4 bytes for BGR, 16 for depth) and passes depth_m != NULL iff
+     * the table has depth images */
+    const bool src_ok = tab.bgr ? true : (((reinterpret_cast<size_t>(bgr) | bgr_stride) & 3) == 0 &&
+                                          (!depth_m || ((reinterpret_cast<size_t>(depth_m) | (depth_stride * 4)) & 15) == 0));
+    if (shift == 0 && !umap_xy && g.rows == src_rows && g.cols == src_cols && (g.rows & 3) == 0 && (g.cols & 3) == 0 && src_ok &&
+        ((reinterpret_cast<size_t>(grey) | stride) & 3) == 0) {
         const int ty = (g.rows + CF_T - 1) / CF_T, tx = (g.cols + CF_T - 1) / CF_T;
         hipLaunchKernelGGL(camera_level0_kernel, dim3(ty * tx, g.count), dim3(256), 0, s, bgr, bgr_stride, depth_m, depth_stride,
-                           g.rows, g.cols, ty, depth_raw, grey, depth_mm, stride);
+                           g.rows, g.cols, ty, depth_raw, grey, depth_mm, stride, tab);
         return hipGetLastError();
     }
     const int tiles_y = (g.rows + CAM_TY - 1) / CAM_TY, tiles_x = (g.cols + CAM_TX - 1) / CAM_TX;
     UndistortMaps um{umap_xy, umap_frac, depth_raw};
     hipLaunchKernelGGL(camera_level_kernel, dim3(tiles_y * tiles_x, g.count), dim3(256), 0, s, bgr, bgr_stride, depth_m,
-                       depth_stride, src_rows, src_cols, shift, tiles_y, um, grey, depth_mm, stride, g.rows, g.cols);
+                       depth_stride, src_rows, src_cols, shift, tiles_y, um, grey, depth_mm, stride, g.rows, g.cols, tab);
     return hipGetLastError();
 }
 /* levels first_level .. n-1 of the same camera frames in one launch (the full-resolution level keeps its own kernel) */
 hipError_t launch_camera_levels(const unsigned char *bgr, size_t bgr_stride, const float *depth_m, size_t depth_stride, int src_rows, int src_cols,
                                 int n, const int *shift, const int *rows, const int *cols, const short2 *umap_xy, const unsigned short *umap_frac,
-                                int depth_raw, unsigned char *const *grey, float *const *depth_mm, const size_t *stride, int count, hipStream_t s) {
+                                int depth_raw, unsigned char *const *grey, float *const *depth_mm, const size_t *stride, int count, hipStream_t s, SrcTab tab) {
     if (n < 1 || n > DVO_LEVELS) return hipErrorInvalidValue;
     CameraLevels t;
     t.n = n; t.src_rows = src_rows; t.src_cols = src_cols;
@@ -353,7 +363,7 @@ hipError_t launch_camera_levels(const unsigned char *bgr, size_t bgr_stride, con
         t.first[l + 1] = t.first[l] + (unsigned)(((rows[l] + CAM_TY - 1) / CAM_TY) * ((cols[l] + CAM_TX - 1) / CAM_TX));
     }
     UndistortMaps um{umap_xy, umap_frac, depth_raw};
-    hipLaunchKernelGGL(camera_levels_kernel, dim3(t.first[n], count), dim3(256), 0, s, bgr, bgr_stride, depth_m, depth_stride, um, t);
+    hipLaunchKernelGGL(camera_levels_kernel, dim3(t.first[n], count), dim3(256), 0, s, bgr, bgr_stride, depth_m, depth_stride, um, t, tab);
     return hipGetLastError();
 }
 

@@ -187,14 +187,18 @@ hipError_t launch_import_grey(const void *src, int dtype, int row_major, size_t 
                               unsigned char *grey, size_t stride, ImgBatch g, hipStream_t s);
 hipError_t launch_import_depth(const void *src, int dtype, int row_major, size_t src_stride,
                                float *depth_mm, size_t stride, ImgBatch g, hipStream_t s);
-/* row f2: full-resolution BGR8 (+ depth in metres, may be NULL) row-major -> pyramid level decimated by 2^shift */
+/* row f2: full-resolution BGR8 (+ depth in metres, may be NULL) row-major -> pyramid level decimated by 2^shift.
+ * SrcTab (round 6): DEVICE arrays of image pointers, one per image of the launch; non-NULL = the images are read where they are (camera
+ * frames already in HBM) instead of at base + i * stride */
+struct SrcTab { const void *const *bgr; const void *const *depth; };
 hipError_t launch_gather_images(const void *const *src, int count, void *dst, size_t bytes, size_t stride, hipStream_t s, int max_wgs_per_image = 64);
 hipError_t launch_camera_level(const unsigned char *bgr, size_t bgr_stride, const float *depth_m, size_t depth_stride,
                                int src_rows, int src_cols, int shift, const short2 *umap_xy, const unsigned short *umap_frac,
-                               int depth_raw, unsigned char *grey, float *depth_mm, size_t stride, ImgBatch g, hipStream_t s);
+                               int depth_raw, unsigned char *grey, float *depth_mm, size_t stride, ImgBatch g, hipStream_t s, SrcTab tab = {nullptr, nullptr});
 hipError_t launch_camera_levels(const unsigned char *bgr, size_t bgr_stride, const float *depth_m, size_t depth_stride, int src_rows, int src_cols,
                                 int n, const int *shift, const int *rows, const int *cols, const short2 *umap_xy, const unsigned short *umap_frac,
-                                int depth_raw, unsigned char *const *grey, float *const *depth_mm, const size_t *stride, int count, hipStream_t s);
+                                int depth_raw, unsigned char *const *grey, float *const *depth_mm, const size_t *stride, int count, hipStream_t s,
+                                SrcTab tab = {nullptr, nullptr});
 /* row f1: cv::Canny(grey, low/high as squared integer thresholds, 3, L2).  work: canny_work_ints() ints;
  * edge out: 0/255 u8 */
 size_t canny_work_ints(int rows, int cols, int count);

@@ -357,19 +357,32 @@ def test_distance_transform_refuses_a_mask_without_edges():
             ctx.set_now_level_from_edges(0, np.zeros(240 * 320, np.uint8), 240, 320)
 
 
-def test_camera_frames_in_device_memory_equal_host_uploads(oracle):
+@pytest.mark.parametrize("first_shift,misalign", [(0, 0), (1, 0), (0, 1), (0, 2)])
+def test_camera_frames_in_device_memory_equal_host_uploads(oracle, first_shift, misalign):
     """DVO_UPLOAD_DEVICE: BGR8 + depth images that already sit in HBM (torch tensors here) go through the same pyramid / Canny /
-    distance transform as host uploads; as_now fused into the upload (now_first_pair) as well"""
+    distance transform as host uploads; as_now fused into the upload (now_first_pair) as well.  Round 6: aligned frames are READ WHERE
+    THEY ARE through a pointer table (the full-resolution kernel at shift 0, the general one at shift 1; tables prepared once or built
+    per call; a second batch through the same staging table); a frame at an odd address (misalign 1: BGR, 2: depth) takes the landing
+    copy as before"""
     import torch
     frames = [frame_gen.camera_frame(300 + i, 240, 320) for i in range(3)]
     with _ctx(3) as a, _ctx(3) as b:
         for c in (a, b):
             c.set_intrinsics(262.5, 262.5, 159.75, 119.75)
             c.frames_reserve(3)
-        a.frames_upload_cameras([f[0] for f in frames], [f[1] for f in frames], n_levels=3, first_shift=0, now_first_pair=0)
-        tb = [torch.from_numpy(np.ascontiguousarray(f[0])).cuda() for f in frames]
-        td = [torch.from_numpy(np.ascontiguousarray(f[1], dtype=np.float32)).cuda() for f in frames]
-        b.frames_upload_cameras_device([t.data_ptr() for t in tb], [t.data_ptr() for t in td], 240, 320, n_levels=3, first_shift=0,
+        a.frames_upload_cameras([f[0] for f in frames], [f[1] for f in frames], n_levels=3, first_shift=first_shift, now_first_pair=0)
+
+        def dev(arr, off):
+            raw = torch.zeros(arr.nbytes + 64, dtype=torch.uint8, device="cuda")
+            raw[off:off + arr.nbytes] = torch.from_numpy(np.frombuffer(np.ascontiguousarray(arr).tobytes(), np.uint8).copy()).cuda()
+            return raw
+        tb = [dev(f[0], 1 if misalign == 1 else 0) for f in frames]
+        td = [dev(np.asarray(f[1], np.float32), 4 if misalign == 2 else 0) for f in frames]
+        pb = [t.data_ptr() + (1 if misalign == 1 else 0) for t in tb]
+        pd = [t.data_ptr() + (4 if misalign == 2 else 0) for t in td]
+        # first other frames through the same staging table (its reuse), then the ones compared -- as prepared tables
+        b.frames_upload_cameras_device(list(reversed(pb)), list(reversed(pd)), 240, 320, n_levels=3, first_shift=first_shift, now_first_pair=0)
+        b.frames_upload_cameras_device(b.pointer_table(pb), b.pointer_table(pd), 240, 320, n_levels=3, first_shift=first_shift,
                                        now_first_pair=0)
         for slot in range(3):
             for l in range(3):
