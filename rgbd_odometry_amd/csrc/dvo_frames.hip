@@ -438,10 +438,15 @@ DVO_DEV void canny_tile_body(const int bx, const int by, const unsigned char *__
     const int y0 = ty * CT_Y, x0 = tx * CT_X;
     const int tid = threadIdx.x, ry = tid & 63, cx = tid >> 6;
 
+    /* tiles whose halo lies inside the image (all but the rim: 84 % of a VGA frame's) skip the clamps and the bounds tests: this
+     * kernel is bound by its vector instructions (round 6: 1128 per wave, the vector unit ~90 % busy) */
+    const bool halo_inside = x0 >= 2 && x0 + CT_X + 2 <= cols && y0 >= 2 && y0 + CT_Y + 2 <= rows;      /* workgroup-uniform */
     auto load_grey = [&](int lx, int ly) {
         int gy = y0 + ly - 2, gx = x0 + lx - 2;
-        gy = gy < 0 ? 0 : (gy > rows - 1 ? rows - 1 : gy);                      /* BORDER_REPLICATE */
-        gx = gx < 0 ? 0 : (gx > cols - 1 ? cols - 1 : gx);
+        if (!halo_inside) {
+            gy = gy < 0 ? 0 : (gy > rows - 1 ? rows - 1 : gy);                  /* BORDER_REPLICATE */
+            gx = gx < 0 ? 0 : (gx > cols - 1 ? cols - 1 : gx);
+        }
         sg[lx * GH + ly] = grey[(unsigned)(gx * rows + gy)];
     };
 #pragma unroll
@@ -456,15 +461,29 @@ DVO_DEV void canny_tile_body(const int bx, const int by, const unsigned char *__
         dx = (cc - a) + 2 * (f - d) + (i - g);
         dy = (g - a) + 2 * (h - b) + (i - cc);
     };
-    auto magnitude = [&](int lx, int ly) {
+    /* the tile's own 64 x 32 pixels: gradient kept in registers for the suppression below (round 6; it used to be recomputed there --
+     * eight LDS byte reads and fourteen operations per pixel of every wave that holds a candidate, i.e. of every wave) */
+    int gdx[CT_X / 4], gdy[CT_X / 4];
+#pragma unroll
+    for (int k = 0; k < CT_X / 4; k++) {
+        const int lx = cx + 4 * k, ly = ry;
+        sobel(lx + 1, ly + 1, gdx[k], gdy[k]);
+        int m = gdx[k] * gdx[k] + gdy[k] * gdy[k];
+        if (!halo_inside && !(y0 + ly < rows && x0 + lx < cols)) m = 0;         /* outside the image (y0 + ly, x0 + lx are never negative) */
+        smag[(lx + 1) * MH + (ly + 1)] = m;
+    }
+    /* the ring around them (magnitudes only): columns -1 and 32 (66 rows each), rows -1 and 64 (32 columns each) */
+    if (tid < 2 * MH + 2 * CT_X) {
+        int lx, ly;
+        if (tid < MH) { lx = 0; ly = tid; }
+        else if (tid < 2 * MH) { lx = MW - 1; ly = tid - MH; }
+        else if (tid < 2 * MH + CT_X) { lx = tid - 2 * MH + 1; ly = 0; }
+        else { lx = tid - 2 * MH - CT_X + 1; ly = MH - 1; }
         const int py = y0 + ly - 1, px = x0 + lx - 1;
         int m = 0;
-        if (py >= 0 && py < rows && px >= 0 && px < cols) { int dx, dy; sobel(lx, ly, dx, dy); m = dx * dx + dy * dy; }
+        if (halo_inside || (py >= 0 && py < rows && px >= 0 && px < cols)) { int dx, dy; sobel(lx, ly, dx, dy); m = dx * dx + dy * dy; }
         smag[lx * MH + ly] = m;
-    };
-#pragma unroll
-    for (int k = 0; k < (MW + 3) / 4; k++) if (cx + 4 * k < MW) magnitude(cx + 4 * k, ry);
-    if (tid < 2 * MW) magnitude(tid >> 1, 64 + (tid & 1));                      /* rows 64, 65 */
+    }
     __syncthreads();
     constexpr int SHIFT = 15;
     constexpr int TG22 = 13573;                                   /* round(tan(22.5 deg) * 2^15) */
@@ -474,9 +493,8 @@ DVO_DEV void canny_tile_body(const int bx, const int by, const unsigned char *__
         const int mi = (lx + 1) * MH + (ly + 1);
         const int m = smag[mi];
         bool keep = false;
-        if (m > low && y0 + ly < rows && x0 + lx < cols) {
-            int xs, ys;
-            sobel(lx + 1, ly + 1, xs, ys);
+        if (m > low) {                                            /* pixels outside the image carry m = 0 <= low */
+            const int xs = gdx[k], ys = gdy[k];
             const int ax = xs < 0 ? -xs : xs, ay = (ys < 0 ? -ys : ys) << SHIFT;
             const int tg22x = ax * TG22;
             int o1, o2;                                           /* the two neighbours of the sector (offsets in smag) */
