@@ -892,6 +892,7 @@ def main_tiled(args):
     graph_replayed = ctx.tiled_graph_replayed()
     pk_mask, solo_mask = ctx.wide_packed_levels(), ctx.wide_solo_levels()        # of the schedule that was timed (the step measurement below enqueues its own)
     team_mask = ctx.wide_team_levels()
+    team_g = ctx.last_launch_shape()[1] if team_mask else 0                       # members of the team launch that ran the finest level
     # per-level reports of the LAST timed alignment, read before anything else touches the context's outputs
     reports = {l: ctx.level_report(0, l, iters[l]) for l in range(args.levels) if iters[l] > 0}
     finals = None
@@ -946,7 +947,8 @@ def main_tiled(args):
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-            "kernel": ("align_fused2_kernel<512,true> as a team of 256 over the whole chip (one rank: the finest level is not sharded; one iteration of %d points)" % n_pts[0]) if (team_mask & 1) else ("tiled_step_kernel (dvo_kernels.hip: update of the previous iteration + this rank's shard of level 0, %d of %d points, + the sums of the launch) and its ncclAllReduce" % (count, n_pts[0])),
+            "kernel": ("align_fused2_kernel<512,true>: ONE launch of the whole pyramid as a team of %d workgroups (one rank: nothing is sharded); "
+                       "kernel_ms = one iteration of level 0 (%d points) inside that launch" % (team_g, n_pts[0])) if (team_mask & 1) else ("tiled_step_kernel (dvo_kernels.hip: update of the previous iteration + this rank's shard of level 0, %d of %d points, + the sums of the launch) and its ncclAllReduce" % (count, n_pts[0])),
             "kernel_ms": acc_ms, "algorithmic_bytes_per_launch": bytes_launch,
             # the per-launch fraction above is one level-0 step with the images amortised over its iterations; the whole
             # alignment -- SURVEY 8(d)'s bytes over the time of ALL its launches -- is latency-bound and sits far lower

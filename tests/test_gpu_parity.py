@@ -84,7 +84,7 @@ def test_accumulators(scene320, ctx320, oracle):
             tr = r["trace"][0]
             acc = ctx320.accumulate(l, R, t)
             assert int(acc[28]) == tr["n_visible"]
-            np.testing.assert_allclose(acc[27], tr["sum_eps2"], rtol=1e-13)
+            assert acc[27] == tr["sum_eps2"]      # round 6: both sides hold the correctly rounded EXACT sum of eps^2 -- no order, no tolerance
             np.testing.assert_allclose(acc[21:27], tr["g"], rtol=1e-11, atol=1e-9 * np.abs(tr["g"]).max())
             # H: exact float x float products summed in double on both sides; only the summation order differs
             np.testing.assert_allclose(acc[:21], tr["H"], rtol=1e-12, atol=1e-12 * np.abs(tr["H"]).max())
@@ -446,31 +446,37 @@ def test_host_driven_iteration_matches_oracle(scene320, oracle):
 
 
 def test_point_shards_sum_to_the_full_frame(scene320, oracle):
-    """tiled mode on one GPU: the sums of 3 point shards, added like an all-reduce would, drive the
-    same alignment (this is what every rank computes after ncclAllReduce of the 29 doubles)"""
+    """tiled mode on one GPU: the sums of point shards, added like an all-reduce would -- in ANY order -- drive the same alignment
+    (this is what every rank computes after ncclAllReduce of the 32 doubles).  Round 6: the energy comes from the three limbs of the
+    exact sum of eps^2 (slots 29..31), so 1, 3 and 7 shards, added forwards or backwards, give the same energies bit for bit"""
     import torch
     from rgbd_odometry_amd.distributed import HipTiledEngine, shard_range
     sc, lv = scene320
     ctx = _ctx_for(sc, lv)
     try:
         eng = HipTiledEngine(ctx)
-        level, iters, world = 1, 10, 3
+        level, iters = 1, 10
         n_total = eng.n_points(level)
-        parts = [eng.new_acc() for _ in range(world)]
-        eng.iter_begin(level, iters, np.eye(3), np.zeros(3))
-        for itr in range(iters):
-            for r in range(world):
-                f, c = shard_range(n_total, r, world)
-                eng.iter_accumulate(level, f, c, parts[r].data_ptr())
-            total = parts[0] + parts[1] + parts[2]
-            eng.iter_update(level, itr, n_total, total.data_ptr())
-            torch.cuda.synchronize()          # `total` must outlive the update kernel
-        got = eng.iter_end(level)
         L = lv[level]
         ref = oracle.run_iterations(level, iters, L["xyz"], L["dt"], L["gx"], L["gy"], L["rows"], L["cols"],
                                     sc.intrinsics, np.eye(3), np.zeros(3))
-        assert np.array_equal(got["energy"], ref["energy"]) and got["best_idx"] == ref["best_idx"]
-        assert rot_angle(ref["R"], got["R"]) <= ROT_TOL and np.linalg.norm(ref["t"] - got["t"]) <= TRANS_TOL
+        for world, backwards in ((3, False), (1, False), (7, True)):
+            parts = [eng.new_acc() for _ in range(world)]
+            eng.iter_begin(level, iters, np.eye(3), np.zeros(3))
+            for itr in range(iters):
+                for r in range(world):
+                    f, c = shard_range(n_total, r, world)
+                    eng.iter_accumulate(level, f, c, parts[r].data_ptr())
+                total = torch.zeros_like(parts[0])
+                for r in (range(world - 1, -1, -1) if backwards else range(world)):
+                    total = total + parts[r]
+                limbs = total[29:32].cpu().numpy()
+                assert all(float(v).is_integer() and 0 <= v < 2.0 ** 53 for v in limbs), limbs
+                eng.iter_update(level, itr, n_total, total.data_ptr())
+                torch.cuda.synchronize()          # `total` must outlive the update kernel
+            got = eng.iter_end(level)
+            assert np.array_equal(got["energy"], ref["energy"]) and got["best_idx"] == ref["best_idx"], world
+            assert rot_angle(ref["R"], got["R"]) <= ROT_TOL and np.linalg.norm(ref["t"] - got["t"]) <= TRANS_TOL
     finally:
         ctx.close()
 

@@ -50,7 +50,6 @@ if has extra; then
   else echo "stamps anatomy skipped: libdvo_amd_stamps.so not built"; fi
   python tools/sparse_scenes.py > gpurun_out/r06_final/sparse_scenes.json 2> gpurun_out/r06_final/sparse_scenes.txt
   for b in 1024 8192; do python bench.py --cpu-seconds 0 --no-extra-legs --batch $b --steps 20 --normal-matrix 2>/dev/null | grep '^{'; done > gpurun_out/r06_final/normal_matrix_lines.json
-  tools/experiments/r06_team_ab.sh > gpurun_out/r06_final/team_plain_stores_ab.txt 2>&1
   TEAMS=64,128,256,0 python tools/experiments/exp_team_single.py 4096 3072 5 2>&1 | tail -1 > gpurun_out/r06_final/team_single_4096.txt
   tail -3 gpurun_out/r06_final/stamps_anatomy.txt; grep "^#" gpurun_out/r06_final/sparse_scenes.txt | head -3; cat gpurun_out/r06_final/team_single_4096.txt
 fi
