@@ -601,8 +601,14 @@ int dvo_frames_upload_cameras(dvo_ctx *c, int first_slot, int count, const unsig
                         sh[m - 1] = first_shift + m; lr2[m - 1] = G.rows; lc2[m - 1] = G.cols; st[m - 1] = G.npx;
                         gl[m - 1] = G.grey + (size_t)(first_slot + k.b) * G.npx; dl[m - 1] = G.depth + (size_t)(first_slot + k.b) * G.npx;
                     }
-                    HIPCHK(c, launch_camera_levels(k.sb, b_img, dsrc, npx, rows, cols, n_levels - 1, sh, lr2, lc2, c->d_umap_xy,
-                                                   c->d_umap_frac, (flags & DVO_UPLOAD_DEPTH_RAW) ? 1 : 0, gl, dl, st, k.nc, c->stream, tab));
+                    static const bool decimate_off = [] { const char *e = getenv("DVO_PYRAMID_DECIMATE"); return e && !std::strcmp(e, "off"); }();
+                    FrameLevel &F0 = c->fs.lv[0];
+                    if (!decimate_off && camera_levels_decimate_ok(n_levels, lr, lc))      /* from level 0, written just before on this stream */
+                        HIPCHK(c, launch_camera_decimate_levels(F0.grey + (size_t)(first_slot + k.b) * F0.npx, depth_m ? F0.depth + (size_t)(first_slot + k.b) * F0.npx : nullptr,
+                                                                F0.npx, F0.rows, F0.cols, n_levels - 1, lr2, lc2, gl, dl, st, k.nc, c->stream));
+                    else
+                        HIPCHK(c, launch_camera_levels(k.sb, b_img, dsrc, npx, rows, cols, n_levels - 1, sh, lr2, lc2, c->d_umap_xy,
+                                                       c->d_umap_frac, (flags & DVO_UPLOAD_DEPTH_RAW) ? 1 : 0, gl, dl, st, k.nc, c->stream, tab));
                 }
                 if (pass == 1 && !ln.parallel && l == 0) {         /* one launch per stage for all levels */
                     if ((rc2 = run_canny_all(c, n_levels, first_slot + k.b, k.nc, c->stream))) return rc2;

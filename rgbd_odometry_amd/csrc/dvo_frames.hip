@@ -244,6 +244,51 @@ camera_levels_kernel(const unsigned char *__restrict__ bgr, size_t bgr_stride, c
                       (t.rows[l] + CAM_TY - 1) / CAM_TY, um, t.grey[l], t.depth[l], t.stride[l], t.rows[l], t.cols[l], tab);
 }
 
+/* levels 1 .. n-1 FROM LEVEL 0 (round 6): nearest-neighbour decimation commutes with every per-pixel step of the level kernel
+ * (BGR2GRAY, metres -> millimetres, the undistortion remap), so pixel (yy, xx) of level l IS pixel (yy << l, xx << l) of level 0
+ * whenever that index needs no clamping -- the host checks ((rows_l - 1) << l <= rows_0 - 1, columns alike; every camera format).
+ * One byte (+ one float) per pixel read from the column-major level 0 instead of three BGR bytes of the row-major source at a
+ * stride: 61 -> ~20 us per 256 four-level VGA frames. */
+struct DecimateLevels {
+    int n, rows0, cols0;
+    int rows[DVO_LEVELS], cols[DVO_LEVELS];                     /* levels 1 .. n (index 0 = level 1) */
+    unsigned first[DVO_LEVELS + 1];                             /* first workgroup of every level */
+    const unsigned char *grey0; const float *depth0; size_t stride0;
+    unsigned char *grey[DVO_LEVELS]; float *depth[DVO_LEVELS]; size_t stride[DVO_LEVELS];
+};
+__global__ void __launch_bounds__(256) camera_decimate_levels_kernel(const DecimateLevels t) {
+    int l = 0;
+    while (l + 1 < t.n && blockIdx.x >= t.first[l + 1]) l++;
+    const int rows = t.rows[l], cols = t.cols[l], sh = l + 1;
+    const unsigned p = (blockIdx.x - t.first[l]) * 256u + threadIdx.x;
+    if (p >= (unsigned)(rows * cols)) return;
+    const unsigned xx = p / (unsigned)rows, yy = p - xx * (unsigned)rows;
+    const size_t src = (size_t)(xx << sh) * t.rows0 + (yy << sh);
+    const size_t img0 = (size_t)blockIdx.y * t.stride0, img = (size_t)blockIdx.y * t.stride[l];
+    t.grey[l][img + p] = t.grey0[img0 + src];
+    if (t.depth0) t.depth[l][img + p] = t.depth0[img0 + src];
+}
+/* false: some level would need the clamp of resizeNN -- the caller keeps launch_camera_levels */
+bool camera_levels_decimate_ok(int n_levels, const int *rows, const int *cols) {
+    for (int l = 1; l < n_levels; l++)
+        if (((long long)(rows[l] - 1) << l) > rows[0] - 1 || ((long long)(cols[l] - 1) << l) > cols[0] - 1) return false;
+    return n_levels > 1;
+}
+hipError_t launch_camera_decimate_levels(const unsigned char *grey0, const float *depth0, size_t stride0, int rows0, int cols0, int n,
+                                         const int *rows, const int *cols, unsigned char *const *grey, float *const *depth, const size_t *stride,
+                                         int count, hipStream_t s) {
+    if (n < 1 || n > DVO_LEVELS) return hipErrorInvalidValue;
+    DecimateLevels t;
+    t.n = n; t.rows0 = rows0; t.cols0 = cols0; t.grey0 = grey0; t.depth0 = depth0; t.stride0 = stride0;
+    t.first[0] = 0;
+    for (int l = 0; l < n; l++) {
+        t.rows[l] = rows[l]; t.cols[l] = cols[l]; t.grey[l] = grey[l]; t.depth[l] = depth[l]; t.stride[l] = stride[l];
+        t.first[l + 1] = t.first[l] + (unsigned)(((size_t)rows[l] * cols[l] + 255) / 256);
+    }
+    hipLaunchKernelGGL(camera_decimate_levels_kernel, dim3(t.first[n], count), dim3(256), 0, s, t);
+    return hipGetLastError();
+}
+
 /* The full-resolution level of an undistortion-free camera frame (shift 0, no map: every pixel is read once): four pixels per
  * lane -- twelve contiguous BGR bytes as three dwords, four depth floats as one 16-byte load -- 64 x 64 tiles, the transpose to
  * the column-major result through LDS with 4-byte stores along yy.  Needs cols and rows in multiples of four (every camera

@@ -199,6 +199,11 @@ hipError_t launch_camera_levels(const unsigned char *bgr, size_t bgr_stride, con
                                 int n, const int *shift, const int *rows, const int *cols, const short2 *umap_xy, const unsigned short *umap_frac,
                                 int depth_raw, unsigned char *const *grey, float *const *depth_mm, const size_t *stride, int count, hipStream_t s,
                                 SrcTab tab = {nullptr, nullptr});
+/* levels 1 .. n of a pyramid as nearest-neighbour decimations of its level 0 (valid when camera_levels_decimate_ok: no clamped index) */
+bool camera_levels_decimate_ok(int n_levels, const int *rows, const int *cols);
+hipError_t launch_camera_decimate_levels(const unsigned char *grey0, const float *depth0, size_t stride0, int rows0, int cols0, int n,
+                                         const int *rows, const int *cols, unsigned char *const *grey, float *const *depth, const size_t *stride,
+                                         int count, hipStream_t s);
 /* row f1: cv::Canny(grey, low/high as squared integer thresholds, 3, L2).  work: canny_work_ints() ints;
  * edge out: 0/255 u8 */
 size_t canny_work_ints(int rows, int cols, int count);
