@@ -323,8 +323,10 @@ def frames_leg(args, iters):
 
     # the same now frames as DEVICE buffers (a decoder / camera driver that lands frames in HBM): everything the GPU does per
     # now frame -- landing copy, pyramid, Canny, distance transform -> compact now level, alignment -- and no PCIe
-    dev_now = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in now]
-    dev_ptrs = ctx.pointer_table([dev_now[i % D].data_ptr() for i in range(B)])      # the decoder's ring: the table is built once
+    # every one of the B frames in its OWN device buffer (D distinct scenes): the engine reads such frames where they are (round 6), and
+    # B pointers to D buffers would let the caches serve what a real ring of frames has to stream from HBM
+    dev_now = [torch.from_numpy(np.ascontiguousarray(now[i % D])).cuda() for i in range(B)]
+    dev_ptrs = ctx.pointer_table([t_.data_ptr() for t_ in dev_now])                 # the decoder's ring: the table is built once
 
     def device_step():
         ctx.frames_upload_cameras_device(dev_ptrs, None, args.height, args.width, n_levels=args.levels, first_shift=0,

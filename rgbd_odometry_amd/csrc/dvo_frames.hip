@@ -256,17 +256,38 @@ struct DecimateLevels {
     const unsigned char *grey0; const float *depth0; size_t stride0;
     unsigned char *grey[DVO_LEVELS]; float *depth[DVO_LEVELS]; size_t stride[DVO_LEVELS];
 };
+/* QUAD: four consecutive rows per thread (rows of every level a multiple of four, images 16-byte aligned: every camera format) -- the
+ * 4 << l source bytes of a column as dword loads, one dword store; else one pixel per thread */
+template <bool QUAD>
 __global__ void __launch_bounds__(256) camera_decimate_levels_kernel(const DecimateLevels t) {
     int l = 0;
     while (l + 1 < t.n && blockIdx.x >= t.first[l + 1]) l++;
     const int rows = t.rows[l], cols = t.cols[l], sh = l + 1;
-    const unsigned p = (blockIdx.x - t.first[l]) * 256u + threadIdx.x;
+    const unsigned p = ((blockIdx.x - t.first[l]) * 256u + threadIdx.x) * (QUAD ? 4u : 1u);
     if (p >= (unsigned)(rows * cols)) return;
     const unsigned xx = p / (unsigned)rows, yy = p - xx * (unsigned)rows;
     const size_t src = (size_t)(xx << sh) * t.rows0 + (yy << sh);
     const size_t img0 = (size_t)blockIdx.y * t.stride0, img = (size_t)blockIdx.y * t.stride[l];
-    t.grey[l][img + p] = t.grey0[img0 + src];
-    if (t.depth0) t.depth[l][img + p] = t.depth0[img0 + src];
+    if constexpr (QUAD) {
+        const unsigned *g = reinterpret_cast<const unsigned *>(t.grey0 + img0 + src);      /* 4 << sh bytes: 2, 4 or 8 ... dwords */
+        const unsigned nd = 1u << sh;                                                      /* dwords per output quad */
+        unsigned out = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned byte = (unsigned)k << sh;                                       /* source byte of output k */
+            out |= ((g[(byte >> 2) < nd ? (byte >> 2) : 0] >> (8u * (byte & 3u))) & 0xffu) << (8 * k);
+        }
+        *reinterpret_cast<unsigned *>(t.grey[l] + img + p) = out;
+        if (t.depth0) {
+            const float *d = t.depth0 + img0 + src;
+            float4 o;
+            o.x = d[0]; o.y = d[1u << sh]; o.z = d[2u << sh]; o.w = d[3u << sh];
+            *reinterpret_cast<float4 *>(t.depth[l] + img + p) = o;
+        }
+    } else {
+        t.grey[l][img + p] = t.grey0[img0 + src];
+        if (t.depth0) t.depth[l][img + p] = t.depth0[img0 + src];
+    }
 }
 /* false: some level would need the clamp of resizeNN -- the caller keeps launch_camera_levels */
 bool camera_levels_decimate_ok(int n_levels, const int *rows, const int *cols) {
@@ -281,11 +302,17 @@ hipError_t launch_camera_decimate_levels(const unsigned char *grey0, const float
     DecimateLevels t;
     t.n = n; t.rows0 = rows0; t.cols0 = cols0; t.grey0 = grey0; t.depth0 = depth0; t.stride0 = stride0;
     t.first[0] = 0;
+    bool quad = (rows0 & 3) == 0 && (stride0 & 3) == 0 && (reinterpret_cast<size_t>(grey0) & 3) == 0 &&
+                (!depth0 || (reinterpret_cast<size_t>(depth0) & 15) == 0);
+    for (int l = 0; l < n; l++)
+        quad = quad && (rows[l] & 3) == 0 && (stride[l] & 3) == 0 && (reinterpret_cast<size_t>(grey[l]) & 3) == 0 &&
+               (!depth0 || (reinterpret_cast<size_t>(depth[l]) & 15) == 0);
     for (int l = 0; l < n; l++) {
         t.rows[l] = rows[l]; t.cols[l] = cols[l]; t.grey[l] = grey[l]; t.depth[l] = depth[l]; t.stride[l] = stride[l];
-        t.first[l + 1] = t.first[l] + (unsigned)(((size_t)rows[l] * cols[l] + 255) / 256);
+        t.first[l + 1] = t.first[l] + (unsigned)(((size_t)rows[l] * cols[l] / (quad ? 4 : 1) + 255) / 256);
     }
-    hipLaunchKernelGGL(camera_decimate_levels_kernel, dim3(t.first[n], count), dim3(256), 0, s, t);
+    if (quad) hipLaunchKernelGGL(camera_decimate_levels_kernel<true>, dim3(t.first[n], count), dim3(256), 0, s, t);
+    else hipLaunchKernelGGL(camera_decimate_levels_kernel<false>, dim3(t.first[n], count), dim3(256), 0, s, t);
     return hipGetLastError();
 }
 

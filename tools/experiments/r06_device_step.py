@@ -15,8 +15,8 @@ ctx.frames_reserve(2 * B)
 kw = dict(n_levels=NL, first_shift=0, flags=DVO_UPLOAD_ASYNC)
 ctx.frames_upload_cameras([ref[i % D][0] for i in range(B)], [ref[i % D][1] for i in range(B)], first_slot=0, **kw)
 ctx.frames_as_ref(0, 0, B)
-dev_now = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in now]
-dev_ptrs = ctx.pointer_table([dev_now[i % D].data_ptr() for i in range(B)])
+dev_now = [torch.from_numpy(np.ascontiguousarray(now[i % D])).cuda() for i in range(B)]      # every frame in its own buffer
+dev_ptrs = ctx.pointer_table([t_.data_ptr() for t_ in dev_now])
 iters = [10] * NL
 def step():
     ctx.frames_upload_cameras_device(dev_ptrs, None, H, W, n_levels=NL, first_shift=0, first_slot=B, flags=DVO_UPLOAD_ASYNC, now_first_pair=0)
