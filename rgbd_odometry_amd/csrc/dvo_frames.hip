@@ -23,6 +23,7 @@
 #include "dvo_palette.h"
 #include <stdlib.h>
 #include <stdio.h>
+#include <string.h>
 
 namespace dvo {
 
@@ -494,8 +495,27 @@ DVO_DEV void uf_union(int *L, int a, int b) {
  * the grey tile for the few pixels above `low` instead of being parked in LDS for all of them (22 KB of LDS per workgroup). */
 constexpr int CT_Y = 64, CT_X = 32;
 enum { CAND_WEAK = 1, CAND_SURE = 2, CAND_KIND = 3, CAND_ROOT = 16 };
+/* LISTS (round 6, the all-levels launch): the tile writes the EDGE MAP itself -- 0 none, 255 a sure edge, EDGE_WEAK a weak candidate still
+ * to be decided -- and keeps a RECORD of 256 ints per tile: its weak candidates and the roots of its strong components (global pixel
+ * indices, up to CT_WEAK / CT_STRONG of them; places from wave ballots + one LDS atomic per wave, column and list; the counts by
+ * fire-and-forget global atomics -- nothing the tile has to wait for).  The passes that follow walk the records (a few per cent of the
+ * pixels) instead of reading every pixel's candidate byte and writing every pixel's edge byte: 52 + 69 us of the 256-frame step ->
+ * 22 + 25, at +41 us in the tile kernel (ballots and places per column: the kernel is bound by its vector instructions) -- net -35.  A tile with more entries than its record holds is looked at pixel by pixel by both passes (correct for any image; never
+ * seen on camera frames).  `cand` then IS the edge map (`cand_stride` bytes per image): the border pass only asks whether a pixel is a
+ * candidate at all.  (A first form with one list per image -- staging in LDS, a global atomic WITH return per tile -- made the tile
+ * kernel 18 % slower: every tile waited a memory round trip at its end.) */
+constexpr unsigned char EDGE_WEAK = 1;
+constexpr int CT_REC = 256, CT_WEAK = 192, CT_STRONG = CT_REC - CT_WEAK;
+struct CannyLists {
+    int *cnt;          /* [image][tile][2]: {weak, strong} entries (zeroed before the launch) */
+    int *ent;          /* [image][tile][CT_REC]: weak[CT_WEAK], strong[CT_STRONG] */
+    int tiles;         /* per image */
+    int weak_cap, strong_cap;
+};
+template <bool LISTS = false>
 DVO_DEV void canny_tile_body(const int bx, const int by, const unsigned char *__restrict__ grey, size_t stride, int rows, int cols, int tiles_y,
-                             int low, int high, unsigned char *__restrict__ cand, unsigned char *__restrict__ flag, int *__restrict__ label) {
+                             int low, int high, unsigned char *__restrict__ cand, unsigned char *__restrict__ flag, int *__restrict__ label,
+                             size_t cand_stride = 0, CannyLists lists = CannyLists{}) {
     constexpr int GH = CT_Y + 4, GW = CT_X + 4, MH = CT_Y + 2, MW = CT_X + 2, NT = CT_Y * CT_X;
     static_assert(CT_Y == 64 && 4 * GW <= 256 && 2 * MW <= 256, "thread mapping: 64 rows per step, the extra halo rows in one more");
     __shared__ unsigned char sg[GW * GH];         /* grey, halo 2, [x][y] */
@@ -505,10 +525,12 @@ DVO_DEV void canny_tile_body(const int bx, const int by, const unsigned char *__
     unsigned char *scand = reinterpret_cast<unsigned char *>(scand32);
     const size_t n = (size_t)rows * cols;
     grey += (size_t)by * stride;
-    cand += (size_t)by * n; flag += (size_t)by * n; label += (size_t)by * n;
+    cand += (size_t)by * (LISTS ? cand_stride : n); flag += (size_t)by * n; label += (size_t)by * n;
     const int ty = bx % tiles_y, tx = bx / tiles_y;
     const int y0 = ty * CT_Y, x0 = tx * CT_X;
     const int tid = threadIdx.x, ry = tid & 63, cx = tid >> 6;
+    __shared__ int s_cnt[2];                        /* LISTS: {weak, strong} entries of this tile so far */
+    if (LISTS && tid < 2) s_cnt[tid] = 0;
 
     /* tiles whose halo lies inside the image (all but the rim: 84 % of a VGA frame's) skip the clamps and the bounds tests: this
      * kernel is bound by its vector instructions (round 6: 1128 per wave, the vector unit ~90 % busy) */
@@ -633,18 +655,87 @@ DVO_DEV void canny_tile_body(const int bx, const int by, const unsigned char *__
         if (scand[idx] & 3) {
             const int r = uf_find_halving(slab, idx);
             const int rx = r >> 6, rr = r & 63;
-            c = (unsigned char)(((scand[r] & 4) ? CAND_SURE : CAND_WEAK) | (r == idx ? CAND_ROOT : 0));
+            const bool sure = (scand[r] & 4) != 0;
+            c = (unsigned char)((sure ? CAND_SURE : CAND_WEAK) | (r == idx ? CAND_ROOT : 0));
             label[p] = (x0 + rx) * rows + (y0 + rr);
             if (r == idx) flag[p] = 0;
+            if constexpr (LISTS) c = sure ? 255 : EDGE_WEAK;
         }
         cand[p] = c;
+        if constexpr (LISTS) {
+            const bool is_weak = c == EDGE_WEAK, is_root = c == 255 && slab[idx] == idx;
+            const unsigned long long mw = __builtin_amdgcn_ballot_w64(is_weak), ms = __builtin_amdgcn_ballot_w64(is_root);
+            if (mw | ms) {                                        /* wave-uniform; most columns of most tiles hold neither */
+                int *rec = lists.ent + ((size_t)by * lists.tiles + bx) * CT_REC, *rcnt = lists.cnt + ((size_t)by * lists.tiles + bx) * 2;
+                const unsigned long long below = (1ull << (tid & 63)) - 1ull;
+                if (mw) {
+                    const int first = (int)__builtin_ctzll(mw), k_w = __popcll(mw);
+                    int base = 0;
+                    if ((tid & 63) == first) { base = atomicAdd(&s_cnt[0], k_w); __hip_atomic_fetch_add(rcnt + 0, k_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    base = __builtin_amdgcn_readlane(base, first) + __popcll(mw & below);
+                    if (is_weak && base < lists.weak_cap) rec[base] = (int)p;
+                }
+                if (ms) {
+                    const int first = (int)__builtin_ctzll(ms), k_s = __popcll(ms);
+                    int base = 0;
+                    if ((tid & 63) == first) { base = atomicAdd(&s_cnt[1], k_s); __hip_atomic_fetch_add(rcnt + 1, k_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    base = __builtin_amdgcn_readlane(base, first) + __popcll(ms & below);
+                    if (is_root && base < lists.strong_cap) rec[CT_WEAK + base] = (int)p;
+                }
+            }
+        }
+    }
+}
+
+/* LISTS: the two passes after the border unions, one wave per tile record. */
+DVO_DEV void canny_flag_list_body(const int bx, const int by, const unsigned char *__restrict__ edge, size_t edge_stride, int rows, int cols,
+                                  const int *__restrict__ label, unsigned char *__restrict__ flag, CannyLists lists) {
+    const size_t n = (size_t)rows * cols;
+    label += (size_t)by * n; flag += (size_t)by * n;
+    const int tile = bx * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile >= lists.tiles) return;
+    const int *rec = lists.ent + ((size_t)by * lists.tiles + tile) * CT_REC;
+    const int cnt = lists.cnt[((size_t)by * lists.tiles + tile) * 2 + 1];
+    if (cnt <= lists.strong_cap) {
+        for (int i = lane; i < cnt; i += 64) flag[uf_find(label, rec[CT_WEAK + i])] = 1;
+    } else {                                                       /* every sure edge of the tile speaks for its component */
+        edge += (size_t)by * edge_stride;
+        const int tiles_y = (rows + CT_Y - 1) / CT_Y, y0 = (tile % tiles_y) * CT_Y, x0 = (tile / tiles_y) * CT_X;
+        for (int lx = 0; lx < CT_X; lx++) {
+            const int py = y0 + lane, px = x0 + lx;
+            if (py < rows && px < cols && edge[(size_t)px * rows + py] == 255) flag[uf_find(label, px * rows + py)] = 1;
+        }
+    }
+}
+DVO_DEV void canny_weak_list_body(const int bx, const int by, unsigned char *__restrict__ edge, size_t edge_stride, int rows, int cols,
+                                  const int *__restrict__ label, const unsigned char *__restrict__ flag, CannyLists lists) {
+    const size_t n = (size_t)rows * cols;
+    label += (size_t)by * n; flag += (size_t)by * n; edge += (size_t)by * edge_stride;
+    const int tile = bx * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile >= lists.tiles) return;
+    const int *rec = lists.ent + ((size_t)by * lists.tiles + tile) * CT_REC;
+    const int cnt = lists.cnt[((size_t)by * lists.tiles + tile) * 2 + 0];
+    if (cnt <= lists.weak_cap) {
+        for (int i = lane; i < cnt; i += 64) {
+            const int p = rec[i];
+            edge[p] = flag[uf_find(label, p)] ? 255 : 0;
+        }
+    } else {
+        const int tiles_y = (rows + CT_Y - 1) / CT_Y, y0 = (tile % tiles_y) * CT_Y, x0 = (tile / tiles_y) * CT_X;
+        for (int lx = 0; lx < CT_X; lx++) {
+            const int py = y0 + lane, px = x0 + lx;
+            if (py >= rows || px >= cols) continue;
+            const size_t p = (size_t)px * rows + py;
+            if (edge[p] == EDGE_WEAK) edge[p] = flag[uf_find(label, (int)p)] ? 255 : 0;
+        }
     }
 }
 
 /* candidate pairs that straddle a tile boundary: rows r = 64, 128, ... looking up, columns c = 32, 64, ... looking left */
-DVO_DEV void canny_border_body(const int bx, const int gx, const int by, const unsigned char *__restrict__ cand, int rows, int cols, int *__restrict__ label) {
+DVO_DEV void canny_border_body(const int bx, const int gx, const int by, const unsigned char *__restrict__ cand, int rows, int cols, int *__restrict__ label,
+                               size_t cand_stride = 0 /* bytes per image when the candidates are read off the edge map (LISTS) */) {
     const size_t n = (size_t)rows * cols;
-    cand += (size_t)by * n; label += (size_t)by * n;
+    cand += (size_t)by * (cand_stride ? cand_stride : n); label += (size_t)by * n;
     const int nA = ((rows - 1) / CT_Y) * cols, nB = ((cols - 1) / CT_X) * rows;
     for (int i = bx * blockDim.x + threadIdx.x; i < nA + nB; i += gx * blockDim.x) {
         if (i < nB) {                                             /* lanes along yy: coalesced */
@@ -821,6 +912,7 @@ struct CannyLevels {
     const unsigned char *grey[DVO_LEVELS]; size_t grey_stride[DVO_LEVELS];
     unsigned char *cand[DVO_LEVELS], *flag[DVO_LEVELS]; int *label[DVO_LEVELS];
     unsigned char *edge[DVO_LEVELS]; size_t edge_stride[DVO_LEVELS];
+    CannyLists lists[DVO_LEVELS];
 };
 DVO_DEV int level_of_block(const unsigned *first, int n, unsigned bx) {
     int l = 0;
@@ -844,6 +936,24 @@ __global__ void __launch_bounds__(256) canny_final4_levels_kernel(const CannyLev
     const int l = level_of_block(t.first, t.n, blockIdx.x);
     canny_final4_body((int)(blockIdx.x - t.first[l]), (int)(t.first[l + 1] - t.first[l]), blockIdx.y, t.cand[l], t.label[l], t.flag[l],
                       (size_t)t.rows[l] * t.cols[l], t.edge[l], t.edge_stride[l]);
+}
+
+__global__ void __launch_bounds__(256) canny_tile_lists_levels_kernel(const CannyLevels t) {
+    const int l = level_of_block(t.first, t.n, blockIdx.x);
+    canny_tile_body<true>((int)(blockIdx.x - t.first[l]), blockIdx.y, t.grey[l], t.grey_stride[l], t.rows[l], t.cols[l], (t.rows[l] + CT_Y - 1) / CT_Y,
+                          t.low, t.high, t.edge[l], t.flag[l], t.label[l], t.edge_stride[l], t.lists[l]);
+}
+__global__ void __launch_bounds__(256) canny_border_lists_levels_kernel(const CannyLevels t) {
+    const int l = level_of_block(t.first, t.n, blockIdx.x);
+    canny_border_body((int)(blockIdx.x - t.first[l]), (int)(t.first[l + 1] - t.first[l]), blockIdx.y, t.edge[l], t.rows[l], t.cols[l], t.label[l], t.edge_stride[l]);
+}
+__global__ void __launch_bounds__(256) canny_flag_list_levels_kernel(const CannyLevels t) {
+    const int l = level_of_block(t.first, t.n, blockIdx.x);
+    canny_flag_list_body((int)(blockIdx.x - t.first[l]), blockIdx.y, t.edge[l], t.edge_stride[l], t.rows[l], t.cols[l], t.label[l], t.flag[l], t.lists[l]);
+}
+__global__ void __launch_bounds__(256) canny_weak_list_levels_kernel(const CannyLevels t) {
+    const int l = level_of_block(t.first, t.n, blockIdx.x);
+    canny_weak_list_body((int)(blockIdx.x - t.first[l]), blockIdx.y, t.edge[l], t.edge_stride[l], t.rows[l], t.cols[l], t.label[l], t.flag[l], t.lists[l]);
 }
 
 __global__ void __launch_bounds__(256) canny_flag16_levels_kernel(const CannyLevels t) {
@@ -896,9 +1006,11 @@ hipError_t launch_canny(const unsigned char *grey, size_t stride, ImgBatch g, in
 
 /* Canny of `n` levels of the same `count` images in four launches.  work: the levels' scratch back to back (canny_work_ints each,
  * rounded to 4 ints).  False if a level does not meet the four-pixels-per-thread conditions: the caller then launches per level. */
+/* + per level and image: a record of CT_REC entries and two counters per tile (the all-levels launch's lists) */
+static inline size_t canny_tiles(int rows, int cols) { return (size_t)((rows + CT_Y - 1) / CT_Y) * ((cols + CT_X - 1) / CT_X); }
 size_t canny_levels_work_ints(int n, const int *rows, const int *cols, int count) {
     size_t t = 0;
-    for (int l = 0; l < n; l++) t += (canny_work_ints(rows[l], cols[l], count) + 3) / 4 * 4;
+    for (int l = 0; l < n; l++) t += (canny_work_ints(rows[l], cols[l], count) + 3) / 4 * 4 + canny_tiles(rows[l], cols[l]) * (CT_REC + 2) * (size_t)count;
     return t;
 }
 bool canny_levels_ok(int n, const int *rows, const int *cols, unsigned char *const *edge, const size_t *edge_stride) {
@@ -922,9 +1034,32 @@ hipError_t launch_canny_levels(int n, const int *rows, const int *cols, const un
         t.cand[l] = reinterpret_cast<unsigned char *>(w + nb);
         t.flag[l] = t.cand[l] + ((nb + 3) / 4) * 4;
         w += (canny_work_ints(rows[l], cols[l], count) + 3) / 4 * 4;
+        /* LISTS: the tiles' records behind the level's scratch; the counters of ALL levels together at the very end (one fill) */
+        const char *shrink_env = getenv("DVO_CANNY_LIST_SHRINK");      /* tests; read at every call: capacities divided by k, so that
+                                                                          ordinary tiles overflow their records and take the dense form */
+        const int shrink = shrink_env && atoi(shrink_env) > 1 ? atoi(shrink_env) : 1;
+        t.lists[l].tiles = (int)canny_tiles(rows[l], cols[l]);
+        t.lists[l].ent = w;
+        t.lists[l].weak_cap = CT_WEAK / shrink;
+        t.lists[l].strong_cap = CT_STRONG / shrink;
+        w += canny_tiles(rows[l], cols[l]) * CT_REC * (size_t)count;
     }
+    size_t cnt_ints = 0;
+    for (int l = 0; l < n; l++) { t.lists[l].cnt = w + cnt_ints; cnt_ints += canny_tiles(rows[l], cols[l]) * 2 * (size_t)count; }
     auto prefix = [&](auto blocks_of) { t.first[0] = 0; for (int l = 0; l < n; l++) t.first[l + 1] = t.first[l] + blocks_of(l); return t.first[n]; };
     const dim3 blk(256);
+    static const bool lists_off = [] { const char *e = getenv("DVO_CANNY_LISTS"); return e && !strcmp(e, "off"); }();
+    if (!lists_off) {
+        (void)hipMemsetAsync(t.lists[0].cnt, 0, sizeof(int) * cnt_ints, s);
+        unsigned g = prefix([&](int l) { return (unsigned)(((rows[l] + CT_Y - 1) / CT_Y) * ((cols[l] + CT_X - 1) / CT_X)); });
+        hipLaunchKernelGGL(canny_tile_lists_levels_kernel, dim3(g, count), blk, 0, s, t);
+        g = prefix([&](int l) { const int nb = ((rows[l] - 1) / CT_Y) * cols[l] + ((cols[l] - 1) / CT_X) * rows[l]; return nb > 0 ? grid_x((size_t)nb) : 0u; });
+        if (g) hipLaunchKernelGGL(canny_border_lists_levels_kernel, dim3(g, count), blk, 0, s, t);
+        g = prefix([&](int l) { return (unsigned)((canny_tiles(rows[l], cols[l]) + 3) / 4); });      /* one wave per tile record */
+        hipLaunchKernelGGL(canny_flag_list_levels_kernel, dim3(g, count), blk, 0, s, t);
+        hipLaunchKernelGGL(canny_weak_list_levels_kernel, dim3(g, count), blk, 0, s, t);
+        return hipGetLastError();
+    }
     unsigned g = prefix([&](int l) { return (unsigned)(((rows[l] + CT_Y - 1) / CT_Y) * ((cols[l] + CT_X - 1) / CT_X)); });
     hipLaunchKernelGGL(canny_tile_levels_kernel, dim3(g, count), blk, 0, s, t);
     g = prefix([&](int l) { const int nb = ((rows[l] - 1) / CT_Y) * cols[l] + ((cols[l] - 1) / CT_X) * rows[l]; return nb > 0 ? grid_x((size_t)nb) : 0u; });

@@ -148,6 +148,42 @@ def test_canny_random_stress(oracle):
                 assert np.array_equal(edge, oracle.canny(im)), (trial, k, rows, cols)
 
 
+@pytest.mark.parametrize("shrink", [1, 1000000])
+def test_canny_all_levels_launch_stress(oracle, shrink, monkeypatch):
+    """the all-levels launch (round 6: the tile kernel writes the edge map and two lists -- weak candidates, roots of strong
+    components -- and the two passes after the border unions walk the lists): every level of a pyramid its own random texture, batched;
+    with the lists' capacities shrunk to nothing every image overflows them and takes the dense form of both passes"""
+    if shrink > 1:
+        monkeypatch.setenv("DVO_CANNY_LIST_SHRINK", str(shrink))
+    rng = np.random.default_rng(77 + shrink)
+
+    def texture(kind, rows, cols):
+        if kind == 0:
+            img = rng.integers(0, 256, (rows, cols))
+        elif kind == 1:                                            # blocky: long chains across tiles
+            b = int(rng.integers(2, 9))
+            img = np.kron(rng.integers(0, 2, ((rows + b - 1) // b, (cols + b - 1) // b)) * 200 + 20, np.ones((b, b), np.int64))[:rows, :cols]
+        elif kind == 2:                                            # smooth + noise near the thresholds: many weak candidates
+            yy, xx = np.mgrid[0:rows, 0:cols]
+            img = 128 + 60 * np.sin(xx / 3.0) * np.cos(yy / 2.5) + rng.integers(-12, 13, (rows, cols))
+        elif kind == 3:                                            # sparse spikes: many small strong components
+            img = np.full((rows, cols), 40); img[rng.random((rows, cols)) < 0.05] = 255
+        else:                                                      # low-amplitude noise: gradients between the thresholds
+            img = 120 + rng.integers(0, 40, (rows, cols))
+        return np.clip(img, 0, 255).astype(np.uint8)
+    for trial, (rows, cols) in enumerate([(128, 96), (200, 260), (64, 32), (332, 132)]):
+        sizes = [(rows, cols), (rows // 2, cols // 2), (rows // 4, cols // 4)]
+        frames = [[(texture((trial + k + l) % 5, *sizes[l]), None) for l in range(3)] for k in range(5)]
+        with _ctx(5) as ctx:
+            ctx.frames_reserve(5)
+            ctx.frames_upload_pyramids(frames)
+            for k, fr in enumerate(frames):
+                for l, (im, _) in enumerate(fr):
+                    edge = ctx.frame_level(k, l, want_depth=False)[2]
+                    ref = oracle.canny(im)
+                    assert np.array_equal(edge, ref), (shrink, trial, k, l, int((edge != ref).sum()))
+
+
 def test_canny_thresholds_from_params(oracle):
     img = oracle.bgr2gray(frame_gen.camera_frame(5, 120, 160)[0])
     with _ctx(canny_threshold1=40, canny_threshold2=90) as ctx:
