@@ -497,17 +497,16 @@ constexpr int CT_Y = 64, CT_X = 32;
 enum { CAND_WEAK = 1, CAND_SURE = 2, CAND_KIND = 3, CAND_ROOT = 16 };
 /* LISTS (round 6, the all-levels launch): the tile writes the EDGE MAP itself -- 0 none, 255 a sure edge, EDGE_WEAK a weak candidate still
  * to be decided -- and keeps a RECORD of 256 ints per tile: its weak candidates and the roots of its strong components (global pixel
- * indices, up to CT_WEAK / CT_STRONG of them; places from wave ballots + one LDS atomic per wave, column and list; the counts by
- * fire-and-forget global atomics -- nothing the tile has to wait for).  The passes that follow walk the records (a few per cent of the
- * pixels) instead of reading every pixel's candidate byte and writing every pixel's edge byte: 52 + 69 us of the 256-frame step ->
- * 22 + 25, at +41 us in the tile kernel (ballots and places per column: the kernel is bound by its vector instructions) -- net -35.  A tile with more entries than its record holds is looked at pixel by pixel by both passes (correct for any image; never
- * seen on camera frames).  `cand` then IS the edge map (`cand_stride` bytes per image): the border pass only asks whether a pixel is a
- * candidate at all.  (A first form with one list per image -- staging in LDS, a global atomic WITH return per tile -- made the tile
- * kernel 18 % slower: every tile waited a memory round trip at its end.) */
+ * indices, up to CT_WEAK / CT_STRONG of them) plus their two counts.  The passes that follow walk the records (a few per cent of the
+ * pixels) instead of reading every pixel's candidate byte and writing every pixel's edge byte.  A tile with more entries than its
+ * record holds is looked at pixel by pixel by both passes (correct for any image; never seen on camera frames).  `cand` then IS the
+ * edge map (`cand_stride` bytes per image): the border pass only asks whether a pixel is a candidate at all.  (A first form with one
+ * list per image -- staging in LDS, a global atomic WITH return per tile -- made the tile kernel 18 % slower: every tile waited a
+ * memory round trip at its end.) */
 constexpr unsigned char EDGE_WEAK = 1;
 constexpr int CT_REC = 256, CT_WEAK = 192, CT_STRONG = CT_REC - CT_WEAK;
 struct CannyLists {
-    int *cnt;          /* [image][tile][2]: {weak, strong} entries (zeroed before the launch) */
+    int *cnt;          /* [image][tile][2]: {weak, strong} entries (written by every tile) */
     int *ent;          /* [image][tile][CT_REC]: weak[CT_WEAK], strong[CT_STRONG] */
     int tiles;         /* per image */
     int weak_cap, strong_cap;
@@ -645,6 +644,7 @@ DVO_DEV void canny_tile_body(const int bx, const int by, const unsigned char *__
         atomicOr(&scand32[r >> 2], 4u << (8 * (r & 3)));
     }
     __syncthreads();
+    unsigned wbits = 0u, rbits = 0u;                                  /* LISTS: which of the lane's eight pixels are weak candidates / strong roots */
 #pragma unroll
     for (int k = 0; k < CT_X / 4; k++) {
         const int lx = cx + 4 * k, ly = ry, idx = lx * CT_Y + ly;
@@ -659,31 +659,35 @@ DVO_DEV void canny_tile_body(const int bx, const int by, const unsigned char *__
             c = (unsigned char)((sure ? CAND_SURE : CAND_WEAK) | (r == idx ? CAND_ROOT : 0));
             label[p] = (x0 + rx) * rows + (y0 + rr);
             if (r == idx) flag[p] = 0;
-            if constexpr (LISTS) c = sure ? 255 : EDGE_WEAK;
-        }
-        cand[p] = c;
-        if constexpr (LISTS) {
-            const bool is_weak = c == EDGE_WEAK, is_root = c == 255 && slab[idx] == idx;
-            const unsigned long long mw = __builtin_amdgcn_ballot_w64(is_weak), ms = __builtin_amdgcn_ballot_w64(is_root);
-            if (mw | ms) {                                        /* wave-uniform; most columns of most tiles hold neither */
-                int *rec = lists.ent + ((size_t)by * lists.tiles + bx) * CT_REC, *rcnt = lists.cnt + ((size_t)by * lists.tiles + bx) * 2;
-                const unsigned long long below = (1ull << (tid & 63)) - 1ull;
-                if (mw) {
-                    const int first = (int)__builtin_ctzll(mw), k_w = __popcll(mw);
-                    int base = 0;
-                    if ((tid & 63) == first) { base = atomicAdd(&s_cnt[0], k_w); __hip_atomic_fetch_add(rcnt + 0, k_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                    base = __builtin_amdgcn_readlane(base, first) + __popcll(mw & below);
-                    if (is_weak && base < lists.weak_cap) rec[base] = (int)p;
-                }
-                if (ms) {
-                    const int first = (int)__builtin_ctzll(ms), k_s = __popcll(ms);
-                    int base = 0;
-                    if ((tid & 63) == first) { base = atomicAdd(&s_cnt[1], k_s); __hip_atomic_fetch_add(rcnt + 1, k_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                    base = __builtin_amdgcn_readlane(base, first) + __popcll(ms & below);
-                    if (is_root && base < lists.strong_cap) rec[CT_WEAK + base] = (int)p;
-                }
+            if constexpr (LISTS) {
+                c = sure ? 255 : EDGE_WEAK;
+                wbits |= (sure ? 0u : 1u) << k;
+                rbits |= ((sure && r == idx) ? 1u : 0u) << k;
             }
         }
+        cand[p] = c;
+    }
+    if constexpr (LISTS) {
+        /* a lane's entries go to the tile's record at places it draws from two LDS counters -- one atomic per lane THAT HAS entries and list
+         * (a first form drew places per column from wave ballots: +41 us on the 256-frame step; this kernel is bound by its vector
+         * instructions) -- and the counts are written by one lane behind a barrier: the record needs no zeroing and no global atomic */
+        int *rec = lists.ent + ((size_t)by * lists.tiles + bx) * CT_REC;
+        if (wbits) {
+            int at = atomicAdd(&s_cnt[0], __popc(wbits));
+            for (unsigned m = wbits; m; m &= m - 1u, at++) {
+                const int k = __ffs((int)m) - 1;
+                if (at < lists.weak_cap) rec[at] = (x0 + cx + 4 * k) * rows + (y0 + ry);
+            }
+        }
+        if (rbits) {
+            int at = atomicAdd(&s_cnt[1], __popc(rbits));
+            for (unsigned m = rbits; m; m &= m - 1u, at++) {
+                const int k = __ffs((int)m) - 1;
+                if (at < lists.strong_cap) rec[CT_WEAK + at] = (x0 + cx + 4 * k) * rows + (y0 + ry);
+            }
+        }
+        __syncthreads();
+        if (tid < 2) lists.cnt[((size_t)by * lists.tiles + bx) * 2 + tid] = s_cnt[tid];
     }
 }
 
@@ -1050,7 +1054,6 @@ hipError_t launch_canny_levels(int n, const int *rows, const int *cols, const un
     const dim3 blk(256);
     static const bool lists_off = [] { const char *e = getenv("DVO_CANNY_LISTS"); return e && !strcmp(e, "off"); }();
     if (!lists_off) {
-        (void)hipMemsetAsync(t.lists[0].cnt, 0, sizeof(int) * cnt_ints, s);
         unsigned g = prefix([&](int l) { return (unsigned)(((rows[l] + CT_Y - 1) / CT_Y) * ((cols[l] + CT_X - 1) / CT_X)); });
         hipLaunchKernelGGL(canny_tile_lists_levels_kernel, dim3(g, count), blk, 0, s, t);
         g = prefix([&](int l) { const int nb = ((rows[l] - 1) / CT_Y) * cols[l] + ((cols[l] - 1) / CT_X) * rows[l]; return nb > 0 ? grid_x((size_t)nb) : 0u; });
