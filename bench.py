@@ -914,7 +914,8 @@ def main_tiled(args):
             ctx.align_pyramid_tiled(it, I, z, flags=0)
         torch.cuda.synchronize(); barrier()
         return 1e3 * (time.perf_counter() - t0) / reps
-    acc_ms = max(1e-6, (level0_ms(60) - level0_ms(10)) / 50.0)
+    # --no-extra-legs (the PMC passes of tools/update_pmc_traffic.py): whole alignments only in the kernel trace, no slope measurement
+    acc_ms = max(1e-6, (level0_ms(60) - level0_ms(10)) / 50.0) if not args.no_extra_legs else 1e-6
     if dist is not None:
         tt = torch.tensor([acc_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -928,6 +929,10 @@ def main_tiled(args):
             dist.destroy_process_group()
         return
     achieved = bytes_launch / (acc_ms * 1e-3) / 1e9
+    # traffic of the whole alignment from the PMC passes: only the one-launch form (one rank, every level inside the fused team launch)
+    # has a single kernel per alignment to attribute it to
+    all_team = world == 1 and team_mask == (1 << args.levels) - 1
+    rec, traffic_reason = traffic_record(args, "tiled_%dx%dx%dx%d" % (args.width, args.height, args.levels, args.iters), all_team and not args.normal_matrix)
     out = {
         "metric": "frame-pair aligns/sec (%dx%d, %d-lvl pyr)" % (args.width, args.height, args.levels),
         "value": value, "unit": "aligns/s", "n_gpus": world, "rccl_ranks": comm.count(), "steps": args.steps, "warmup": args.warmup,
@@ -959,7 +964,10 @@ def main_tiled(args):
             "definition": "12 B x points of the shard + the level's 12 B/pixel images amortised over its iterations, per accumulate "
                           "launch; kernel_ms = one iteration at level 0 measured through the product path (slope of the alignment time over "
                           "the number of level-0 iterations): the launch, its boundary and the 256-byte all-reduce",
-            "traffic_reason": "no PMC record for the tiled mode",
+            **({"traffic_reason": traffic_reason} if rec is None else
+               {"traffic_per_alignment": rec["hbm_bytes_per_launch"], "traffic_over_algorithmic": rec["hbm_bytes_per_launch"] / bytes_align,
+                "traffic_note": "HBM bytes of ONE alignment = one team launch (PMC passes: TCC_EA0_RDREQ x 128 + WRITE_SIZE; "
+                                "roofline.traffic stays null: it is defined per `kernel_ms`, which here is one level-0 iteration)"}),
         },
     }
     if world == 1 and args.cpu_seconds > 0:

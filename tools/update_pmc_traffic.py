@@ -60,7 +60,7 @@ for src in (os.path.join(ROOT, "profiles", "pmc_traffic.json"), path):      # se
         pass
 sys.argv = ["bench.py"] + extra
 a = bench.parse_args()
-key = "%dx%dx%dx%d_b%d" % (a.width, a.height, a.levels, a.iters, a.batch)
+key = ("tiled_%dx%dx%dx%d" % (a.width, a.height, a.levels, a.iters)) if a.mode == "tiled" else "%dx%dx%dx%d_b%d" % (a.width, a.height, a.levels, a.iters, a.batch)
 allrec[key] = rec
 # records measured on other kernel sources describe a kernel that no longer exists: drop them (tests/test_bench_record.py)
 allrec = {k: v for k, v in allrec.items() if v.get("kernel_source_sha256") == rec["kernel_source_sha256"]}
