@@ -724,19 +724,23 @@ int enqueue(dvo_ctx *c, int first_pair, int n_pairs, int n_levels, const int *it
                 HIPCHK(c, hipMalloc((void **)&c->d_team_buf, buf_bytes));
                 HIPCHK(c, hipMalloc((void **)&c->d_team_cnt, sizeof(unsigned) * ((size_t)c->n_pairs + 1)));
                 zero = c->team_err_dirty = true;
+                /* tests: start the count close to its 32-bit end, so that a few alignments cross the wrap (read when the buffer is made) */
+                if (const char *e = std::getenv("DVO_TEAM_EPOCH0")) c->team_epoch = (unsigned)std::strtoul(e, nullptr, 0);
             }
             /* A record is {value, tag}, tag = exchange count + 1.  Rounds 2-5 zeroed the records before every launch (two fills, ~10 us of
              * a 240 us single-pair alignment); since round 6 the count runs on from launch to launch, so whatever an earlier launch left
              * carries a tag below every tag this one waits for.  Zeroed only when the 32-bit count would wrap -- and always once a launch
              * was captured into a caller's graph (its replays would repeat their tags). */
+            /* exchanges a launch can make: the XCD check, per level one per iteration, one more per iteration whose energy takes the exact
+             * sweep (dvo_fused.hip: the limbs travel through an exchange of their own), one for a solo level's hand-over */
             unsigned need = 2;
-            for (int l = 0; l < n_levels; l++) if (sc.iters[l] > 0) need += (unsigned)sc.iters[l] + 1u;
+            for (int l = 0; l < n_levels; l++) if (sc.iters[l] > 0) need += 2u * (unsigned)sc.iters[l] + 2u;
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             if (c->stream && hipStreamIsCapturing(c->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) c->team_legacy = true;
             if (c->team_legacy || c->team_epoch > 0xfffffff0u - need) zero = true;
             if (zero) {
                 HIPCHK(c, hipMemsetAsync(c->d_team_buf, 0, buf_bytes, c->stream));
-                c->team_epoch = 0;
+                if (c->team_legacy || c->team_epoch > 0xfffffff0u - need) c->team_epoch = 0;
             }
             if (c->team_err_dirty || c->team_legacy) {
                 HIPCHK(c, hipMemsetAsync(c->d_team_cnt, 0, sizeof(unsigned) * ((size_t)c->n_pairs + 1), c->stream));

@@ -89,6 +89,33 @@ def test_compact_now_640x480(oracle, kw):
             assert np.array_equal(R1, R2) and np.array_equal(t1, t2)
 
 
+@pytest.mark.parametrize("epoch0", [None, "4294967000"])
+@pytest.mark.parametrize("variant", [0, 5])
+def test_team_launches_in_a_row_keep_their_exchange_tags_apart(oracle, epoch0, variant, monkeypatch):
+    """round 6: the team records are no longer zeroed between launches -- a record is recognised by its tag, the count of exchanges,
+    which runs on from launch to launch.  A launch must therefore reserve as many tags as it can use (with engine_variant 5 every
+    iteration makes a second exchange for the limbs of its exact energy), and the 32-bit count must survive its wrap
+    (DVO_TEAM_EPOCH0 starts it just below): six alignments in a row, teams of different sizes, every one equal to the oracle's"""
+    from rgbd_odometry_amd import DvoContext, SynthScene
+    if epoch0:
+        monkeypatch.setenv("DVO_TEAM_EPOCH0", epoch0)
+    sc = SynthScene(640, 480, 4, 3)
+    lv = oracle_lib.scene_levels(sc, oracle)
+    iters = [10, 10, 10, 10]
+    ref = oracle.align_pyramid(iters, lv, sc.intrinsics, np.eye(3), np.zeros(3))
+    ref2 = oracle.align_pyramid([3, 0, 4, 2], lv, sc.intrinsics, np.eye(3), np.zeros(3))
+    with DvoContext(1, engine_variant=variant) as ctx:
+        ctx.set_intrinsics(*sc.intrinsics)
+        _load(ctx, sc)
+        ctx.now_prepare()
+        for rep in range(6):
+            if rep % 3 == 2:
+                _check(ctx, ref2, [3, 0, 4, 2])
+            else:
+                _check(ctx, ref, iters)
+            assert ctx.last_launch_shape()[1] > 1                  # a team launch
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(team_size=1), dict(block_threads=256), dict(engine_variant=3, team_size=1),
                                 dict(lds_point_bytes=16 * 1024, team_size=1), dict(engine_variant=1)])
 def test_native_compact_now_levels_from_edges_640x480(oracle, kw):
